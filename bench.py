@@ -1,0 +1,273 @@
+#!/usr/bin/env python
+"""Headline benchmark: BASELINE.json configs[1] -- 65 536 chains x 1 024-D
+diagonal Gaussian, L = 10 leapfrog steps per HMC transition, on N MI355X
+(weak scaling: 65 536 chains per GPU, configs[3] at N = 8).
+
+A "step" is one full HMC transition over all chains (momentum resample, L+1
+gradient kicks, L drifts, MH accept, step-size update).  State is resident in
+HBM before the timed region.  Prints ONE JSON line (see the task contract):
+
+  value     = chain-leapfrog-steps/s = n_chains_total * L * steps / t
+  roofline  = algorithmic bytes (8 B per chain-latent per transition:
+              read q + write q) / fused-kernel duration, vs 8 TB/s HBM
+  cpu_baseline = the NumPy oracle (port of zhusuan/hmc.py) on a bounded
+              sample of the same workload on the host cores (rank 0, N = 1)
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+N_CHAINS_PER_GPU = 65536
+N_DATA = 1024
+N_LEAPFROGS = 10
+BURN_IN_ADAPT = 50
+HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md
+ALGO_BYTES_PER_ELEM = 8.0   # read q + write q per transition
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--chains-per-gpu', type=int, default=N_CHAINS_PER_GPU)
+    ap.add_argument('--n-data', type=int, default=N_DATA)
+    ap.add_argument('--leapfrogs', type=int, default=N_LEAPFROGS)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-ess', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(n_data, n_leapfrogs, budget_s):
+    """Time the NumPy restatement of zhusuan/hmc.py (oracle/hmc_ref.py) on
+    C = 4096 chains of the same target; throughput is size-independent once
+    DRAM-bound."""
+    from oracle.hmc_ref import HMC as RefHMC, DiagNormalModel
+    C = 4096
+    logstd = np.linspace(-1.0, 1.0, n_data).astype(np.float32)
+    model = DiagNormalModel(np.zeros(n_data, np.float32), logstd=logstd)
+    x = np.zeros((C, n_data), np.float32)
+    ref = RefHMC(step_size=0.05, n_leapfrogs=n_leapfrogs, seed=1)
+    ref.sample(model.log_joint, model.grad, [x])
+    ref.step()                       # warm-up (allocations, page faults)
+    iters = 0
+    t0 = time.perf_counter()
+    while True:
+        ref.step()
+        iters += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or iters >= 400:
+            break
+    return {
+        'value': C * n_leapfrogs * iters / el,
+        'unit': 'chain-leapfrog-steps/s',
+        'cores': 1,
+        'host_cores_available': os.cpu_count(),
+        'kind': 'port',
+        'sample': '%d chains x %d latents, L=%d, %d transitions in %.1f s '
+                  '(NumPy float32 restatement of zhusuan/hmc.py, same pass '
+                  'structure as the TF graph; TF itself is not installable '
+                  'in this image)' % (C, n_data, n_leapfrogs, iters, el),
+        'elem_leapfrog_steps_per_sec': C * n_data * n_leapfrogs * iters / el,
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import zhusuan_amd as zs
+    from zhusuan_amd.distributed import ChainSharding
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(
+                'bench.py --gpus %d must be launched with torch.distributed.run '
+                '--nproc-per-node %d' % (args.gpus, args.gpus))
+    assert torch.cuda.is_available(), 'bench.py needs an MI355X'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    sharding = None
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl', rank=rank, world_size=world,
+                                device_id=dev)
+        sharding = ChainSharding(chain_offset=rank * args.chains_per_gpu,
+                                 n_chains_global=world * args.chains_per_gpu)
+
+    C, D, L = args.chains_per_gpu, args.n_data, args.leapfrogs
+    logstd = torch.linspace(-1.0, 1.0, D, device=dev)     # std = e^[-1, 1]
+    mean = torch.zeros(D, device=dev)
+
+    @zs.meta_bayesian_net()
+    def gaussian():
+        bn = zs.BayesianNet()
+        bn.normal('x', mean, logstd=logstd, n_samples=C, group_ndims=1)
+        return bn
+
+    x = torch.zeros(C, D, device=dev)                     # q0 = 0 (config 2)
+    adapt = zs.placeholder(bool)
+    hmc = zs.HMC(step_size=0.05, n_leapfrogs=L, adapt_step_size=adapt,
+                 target_acceptance_rate=0.8, seed=1, sharding=sharding)
+    sample_op, info = hmc.sample(gaussian(), {}, {'x': x})
+    assert hmc.plan_kind == 'fused_diag_normal', hmc.plan_kind
+
+    # adaptive burn-in, untimed (config 2: 50 adaptive iterations)
+    for _ in range(BURN_IN_ADAPT):
+        sample_op.run(feed_dict={adapt: True}, sync=False)
+    hmc.check_numerics()
+    # timed region: adaptation off on one GPU (config 2); on for N > 1 so
+    # that the RCCL all-reduce of the acceptance statistic is in the loop
+    # (config 4)
+    adapt_timed = world > 1
+    feed = {adapt: adapt_timed}
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        sample_op.run(feed_dict=feed, sync=False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sample_op.run(feed_dict=feed, sync=False)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    hmc.check_numerics()
+    acc_mean = float(info.acceptance_rate.mean().item())
+    eps = float(info.updated_step_size.item())
+
+    # dominant kernel alone, HIP events on the launch stream
+    plan = hmc._plan
+    stream = torch.cuda.current_stream().cuda_stream
+    reps = max(20, min(args.steps, 200))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(
+        enable_timing=True)
+    t_iter = hmc.t
+    for i in range(5):
+        plan._launch(t_iter + 1 + i, None, 1, L, stream)
+    torch.cuda.synchronize()
+    e0.record()
+    for i in range(reps):
+        plan._launch(t_iter + 6 + i, None, 1, L, stream)
+    e1.record()
+    torch.cuda.synchronize()
+    plan.acc_sum.zero_()
+    kern_ms = e0.elapsed_time(e1) / reps
+    hmc.t = t_iter + 6 + reps
+    algo_bytes = ALGO_BYTES_PER_ELEM * C * D
+    achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
+    traffic = None
+    pmc_path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    if os.path.exists(pmc_path):
+        try:
+            with open(pmc_path) as f:
+                traffic = json.load(f).get('hbm_bytes_per_launch')
+        except Exception:
+            traffic = None
+
+    ms_per_step = elapsed / args.steps * 1e3
+    total_chains = C * world
+    value = total_chains * L * args.steps / elapsed
+
+    # ESS/s on a fixed subset (reference estimator, zhusuan/diagnostics.py)
+    ess = None
+    if not args.no_ess and rank == 0:
+        n_draws, n_sub, dims = 400, 64, np.linspace(0, D - 1, 16).astype(int)
+        buf = np.empty((n_draws, n_sub, len(dims)), np.float32)
+        dims_t = torch.tensor(dims, device=dev)
+        for i in range(n_draws):
+            sample_op.run(feed_dict={adapt: False}, sync=False)
+            buf[i] = x[:n_sub][:, dims_t].cpu().numpy()
+        per = zs.diagnostics.effective_sample_size_batch(buf, burn_in=100)
+        ess_chain = per.min(axis=1)          # min over dims, as the reference
+        ess_per_iter = float(ess_chain.mean()) / (n_draws - 100)
+        ess = {
+            'ess_per_sec': ess_per_iter * total_chains * 1e3 / ms_per_step,
+            'ess_per_chain_per_transition': ess_per_iter,
+            'method': 'zhusuan.diagnostics estimator (min over dims), %d '
+                      'chains x %d dims subset, %d draws, burn_in=100, '
+                      'scaled to all chains' % (n_sub, len(dims), n_draws),
+        }
+    elif world > 1 and not args.no_ess:
+        # keep ranks in lock-step while rank 0 collects ESS draws
+        for i in range(400):
+            sample_op.run(feed_dict={adapt: False}, sync=False)
+    if world > 1:
+        barrier()
+
+    if rank == 0:
+        out = {
+            'metric': 'leapfrog-steps/sec',
+            'value': value,
+            'unit': 'chain-leapfrog-steps/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': ms_per_step,
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {
+                'workload': 'configs[1]: %d chains/GPU x %d-D diagonal '
+                            'Gaussian (std=exp(linspace(-1,1))), L=%d, q0=0, '
+                            '50 adaptive burn-in transitions, timed with '
+                            'adaptation %s' % (C, D, L,
+                                               'on' if adapt_timed else 'off'),
+                'n_chains_total': total_chains,
+                'n_latents': D,
+                'n_leapfrogs': L,
+                'parallelism': 'chains sharded over %d GPU(s); %s' % (
+                    world, 'one RCCL all-reduce (1 double) per transition'
+                    if world > 1 else 'no collective'),
+            },
+            'elem_leapfrog_steps_per_sec': value * D,
+            'mean_acceptance': acc_mean,
+            'step_size': eps,
+            'roofline': {
+                'bound': 'hbm',
+                'kernel': 'hmc_diag_normal_kernel<64,%d>' % ((D + 255) // 256),
+                'achieved': achieved,
+                'peak': HBM_PEAK_GBPS,
+                'unit': 'GB/s',
+                'frac': achieved / HBM_PEAK_GBPS,
+                'traffic': traffic,
+                'kernel_ms': kern_ms,
+                'algorithmic_bytes_per_launch': algo_bytes,
+            },
+        }
+        if ess is not None:
+            out['ess'] = ess
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(D, L, args.cpu_seconds)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,250 @@
+/*
+ * zshmc.h -- C-ABI of libzshmc.so: the MI355X (gfx950) native HMC hot path
+ * behind the zhusuan.HMC API.
+ *
+ * The reference (thu-ml/zhusuan) has NO FFI/plugin boundary: the path is a
+ * Python API over a TensorFlow graph (zhusuan/hmc.py).  This header is the
+ * boundary a maintainer would bind with ctypes; every
+ * entry point cites the reference code it replaces (paths relative to the
+ * reference root).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host;
+ *   - all tensors are dense, row-major ("chain-major"), float32
+ *     (hmc.py:22,72-87,258-264 hard-code float32);
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *     every call only ENQUEUES work, nothing synchronises;
+ *   - return value: ZSHMC_OK or an error code; zshmc_last_error() gives the
+ *     thread-local message of the last failing call;
+ *   - the caller owns every buffer.  Nothing is allocated by the library.
+ *
+ * Random numbers: Philox4x32-10, key = seed, counter =
+ *   (d/4, global chain index, iteration, stream id | latent_id<<8); see
+ *   DESIGN.md "RNG".  Results are invariant to how chains are sharded.
+ */
+#ifndef ZSHMC_H_
+#define ZSHMC_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZSHMC_VERSION 100 /* 0.1.0 */
+
+/* status codes */
+#define ZSHMC_OK 0
+#define ZSHMC_ERR_BAD_ARG 1
+#define ZSHMC_ERR_HIP 2
+#define ZSHMC_ERR_UNSUPPORTED 3
+
+/* bits of the device-side `flags` word */
+#define ZSHMC_FLAG_OLD_LOGPROB_NONFINITE 1u /* hmc.py:51-53 check_numerics */
+
+/* layout of the float32 sampler state block (device, ZSHMC_STATE_WORDS) */
+#define ZSHMC_STATE_WORDS 8
+#define ZSHMC_ST_STEP_SIZE 0       /* HMC.step_size            hmc.py:258 */
+#define ZSHMC_ST_TUNER_STEP 1      /* StepsizeTuner.step       hmc.py:82  */
+#define ZSHMC_ST_LOG_EPS_BAR 2     /* .log_epsilon_bar         hmc.py:84  */
+#define ZSHMC_ST_H_BAR 3           /* .h_bar                   hmc.py:86  */
+#define ZSHMC_ST_EWMV_T 4          /* EWMV.t                   hmc.py:118 */
+#define ZSHMC_ST_USED_STEP_SIZE 5  /* epsilon used by the last transition */
+#define ZSHMC_ST_MEAN_ACCEPT 6     /* mean acceptance fed to the tuner    */
+#define ZSHMC_ST_RESERVED 7
+
+/* broadcast modes of a distribution parameter against x[rows, cols] */
+#define ZSHMC_BCAST_FULL 0   /* [rows, cols]            */
+#define ZSHMC_BCAST_ROW 1    /* [cols], same for each row */
+#define ZSHMC_BCAST_SCALAR 2 /* [1]                      */
+
+const char* zshmc_last_error(void);
+int zshmc_version(void);
+
+/* Largest n_data the fused diag-Normal kernel accepts. */
+int64_t zshmc_fused_max_n_data(void);
+
+/* ------------------------------------------------------------------------
+ * Fused HMC transition for a diagonal-Normal log-joint
+ *      log p(q_c) = sum_d  -0.5*log(2*pi) - logstd_d
+ *                          - 0.5*exp(-2*logstd_d)*(q_cd - mean_d)^2
+ * ONE launch = momentum resample + (L+1) kicks / L drifts + both
+ * Hamiltonians + MH accept + in-place update of q.
+ *
+ * Replaces, for this model family, one execution of `sample_op`:
+ *   hmc.py:21-23   random_momentum           (Philox N(0,1) * sqrt(mass))
+ *   hmc.py:348-372 HMC._leapfrog + :38-43 leapfrog_integrator
+ *   hmc.py:30-35   hamiltonian, :46-61 get_acceptance_rate
+ *   hmc.py:479-498 MH test, where(accept, q', q), Variable.assign
+ *   distributions/univariate.py:174-181 Normal._log_prob and its gradient,
+ *   distributions/base.py:302-304 group_ndims reduce_sum,
+ *   framework/bn.py:454-465 log_joint of the single stochastic node.
+ *
+ *   q               [n_chains, n_data]  in/out (written only where accepted)
+ *   mean, logstd    [n_data]
+ *   mass            [n_data] or NULL (= ones; hmc.py:456)
+ *   step_size_dev   device scalar, or NULL to use step_size_host
+ *   chain_offset    global index of local chain 0 (RNG counter)
+ *   commit          1: full transition.  0: dry run for _init_step_size
+ *                   (hmc.py:308-345): nothing but acc_sum/flags is written
+ *   acceptance_rate, orig_hamiltonian, hamiltonian, orig_log_prob, log_prob
+ *                   [n_chains] each, any may be NULL  (HMCInfo, hmc.py:162-201)
+ *   acc_sum         device double; the call ADDS sum_c acceptance_rate_c
+ *                   (caller zeroes it; feeds hmc.py:377 reduce_mean)
+ *   flags           device word, OR-ed with ZSHMC_FLAG_* ; may be NULL
+ */
+int zshmc_hmc_diag_normal_step(
+    float* q, const float* mean, const float* logstd, const float* mass,
+    const float* step_size_dev, float step_size_host,
+    int64_t n_chains, int64_t n_data, int64_t chain_offset,
+    int n_leapfrogs, uint64_t seed, uint32_t iteration, int commit,
+    float* acceptance_rate, float* orig_hamiltonian, float* hamiltonian,
+    float* orig_log_prob, float* log_prob,
+    double* acc_sum, uint32_t* flags, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Dual-averaging step-size update, one tiny launch, state stays on device.
+ * Replaces StepsizeTuner.tune (hmc.py:89-112) + HMC._adapt_step_size
+ * (hmc.py:375-380).  mean acceptance = *acc_sum / n_chains_global.
+ *   adapt        this run's value of the adapt_step_size flag
+ *   fresh_start  1 when if_initialize_step_size (hmc.py:466-467)
+ *   mu           10 * initial step size (hmc.py:79, sic)
+ * Before updating, state[ZSHMC_ST_USED_STEP_SIZE] = state[ZSHMC_ST_STEP_SIZE]
+ * (the epsilon the transition just used when no search ran).  *acc_sum is
+ * consumed and reset to 0 so the next transition can accumulate into it.
+ */
+int zshmc_stepsize_update(
+    float* state, double* acc_sum, int64_t n_chains_global,
+    int adapt, int fresh_start, float delta, float gamma, float t0,
+    float kappa, float mu, void* stream);
+
+/* Store `value` into state[index] (used by the host-driven step-size
+ * search hmc.py:308-345 and by checkpoint restore). */
+int zshmc_state_set(float* state, int index, float value, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Diagonal mass adaptation (hmc.py:115-159 EWMV, :284-305 _adapt_mass).
+ * Two launches so that a cross-GPU sum of `colsum` can sit between them:
+ *   colstats : colsum[0:D]   += sum_c (q_cd - ewmv_mean_d)
+ *              colsum[D:2D]  += sum_c (q_cd - ewmv_mean_d)^2   (double)
+ *   update   : tau += 1; w = (1-decay)/(1-decay^tau);
+ *              delta = w*S1/C; mean += delta;
+ *              var = (1-w)*var + w*S2/C - delta^2   (== hmc.py:135-145)
+ *              mass_out = ones if use_ones else 1/var (hmc.py:151-152,299-302)
+ * With update == 0 only mass_out is produced (hmc.py:158-159).  An update
+ * consumes colsum and resets it to 0 for the next colstats call.
+ * update == 1 also advances tau (state[ZSHMC_ST_EWMV_T]) afterwards;
+ * update == 2 leaves tau alone, for all but the last latent of a
+ * multi-latent model (EWMV.t is shared by the latents, hmc.py:118,131).
+ */
+int zshmc_mass_colstats(const float* q, const float* ewmv_mean,
+                        int64_t n_chains, int64_t n_data, double* colsum,
+                        void* stream);
+int zshmc_mass_update(float* state, float* ewmv_mean, float* ewmv_var,
+                      double* colsum, int64_t n_chains_global,
+                      int64_t n_data, float decay, int update, int use_ones,
+                      float* mass_out, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Building blocks of the generic transition (arbitrary log-joint whose
+ * gradient is supplied by the caller, e.g. autograd over the log_prob ops
+ * below).  Same counter mapping as the fused kernel, so both paths draw the
+ * same momentum / uniforms.
+ */
+/* p = N(0,1)*sqrt(mass)  (hmc.py:21-23).  kinetic[c] += 0.5*sum_d p^2/mass
+ * (hmc.py:32-34) when kinetic != NULL. */
+int zshmc_momentum(float* p, const float* mass, int64_t n_chains,
+                   int64_t n_data, int64_t chain_offset, uint64_t seed,
+                   uint32_t iteration, uint32_t latent_id, float* kinetic,
+                   void* stream);
+/* p += kick_scale*eps*grad ; then q += drift_scale*eps*p/mass
+ * (hmc.py:38-43 with the schedule of :352-364; drift_scale==0 skips q).
+ * kinetic[c] += 0.5*sum_d p_new^2/mass when kinetic != NULL. */
+int zshmc_kick_drift(float* q, float* p, const float* grad, const float* mass,
+                     const float* step_size_dev, float step_size_host,
+                     float kick_scale, float drift_scale, int64_t n_chains,
+                     int64_t n_data, float* kinetic, void* stream);
+/* MH test (hmc.py:46-61, 479-498) from per-chain log-probs and kinetic
+ * energies.  accept[c] (uint8) = u < acceptance_rate; log_prob_out =
+ * accept ? log_prob_new : log_prob_old. Any output may be NULL. */
+int zshmc_mh_accept(const float* log_prob_old, const float* log_prob_new,
+                    const float* kinetic_old, const float* kinetic_new,
+                    int64_t n_chains, int64_t chain_offset, uint64_t seed,
+                    uint32_t iteration, float* acceptance_rate,
+                    float* orig_hamiltonian, float* hamiltonian,
+                    float* log_prob_out, uint8_t* accept, double* acc_sum,
+                    uint32_t* flags, void* stream);
+/* q[c,:] = accept[c] ? q_new[c,:] : q[c,:]   (hmc.py:488-497) */
+int zshmc_select_rows(float* q, const float* q_new, const uint8_t* accept,
+                      int64_t n_chains, int64_t n_data, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Stand-alone distribution ops (forward, analytic backward, sampling).
+ * x is viewed as [rows, cols]; reduce_cols != 0 sums each row (the
+ * group_ndims reduction, distributions/base.py:302-304) and out is [rows],
+ * otherwise out is [rows, cols].
+ */
+/* Normal._log_prob, distributions/univariate.py:174-181 */
+int zshmc_normal_log_prob(const float* x, const float* mean,
+                          const float* logstd, float* out, int64_t rows,
+                          int64_t cols, int mean_bcast, int logstd_bcast,
+                          int reduce_cols, void* stream);
+/* Backward of the above given upstream gout ([rows] if reduce_cols else
+ * [rows, cols]).  gx/gmean/glogstd are full [rows, cols] element-wise
+ * gradients (any may be NULL); the caller sums over broadcast axes. */
+int zshmc_normal_log_prob_grad(const float* x, const float* mean,
+                               const float* logstd, const float* gout,
+                               float* gx, float* gmean, float* glogstd,
+                               int64_t rows, int64_t cols, int mean_bcast,
+                               int logstd_bcast, int reduce_cols,
+                               void* stream);
+/* Bernoulli._log_prob, univariate.py:398-403
+ * (= -sigmoid_cross_entropy_with_logits(labels=given, logits)). */
+int zshmc_bernoulli_log_prob(const float* logits, const float* given,
+                             float* out, int64_t rows, int64_t cols,
+                             int logits_bcast, int given_bcast,
+                             int reduce_cols, void* stream);
+/* d/dlogits = gout * (given - sigmoid(logits)), full [rows, cols]. */
+int zshmc_bernoulli_log_prob_grad(const float* logits, const float* given,
+                                  const float* gout, float* glogits,
+                                  int64_t rows, int64_t cols,
+                                  int logits_bcast, int given_bcast,
+                                  int reduce_cols, void* stream);
+/* Categorical._log_prob, univariate.py:496-548
+ * (= logits[k] - logsumexp(logits)); logits [rows, n_cat], labels [rows]. */
+int zshmc_categorical_log_prob(const float* logits, const int64_t* labels,
+                               float* out, int64_t rows, int64_t n_cat,
+                               void* stream);
+/* d/dlogits = gout * (onehot(k) - softmax(logits)), [rows, n_cat]. */
+int zshmc_categorical_log_prob_grad(const float* logits,
+                                    const int64_t* labels, const float* gout,
+                                    float* glogits, int64_t rows,
+                                    int64_t n_cat, void* stream);
+/* UnnormalizedMultinomial._log_prob, distributions/multivariate.py:435-443:
+ * sum_v given_v * (logits_v - [normalize] logsumexp(logits)). */
+int zshmc_unnormalized_multinomial_log_prob(const float* logits,
+                                            const float* given, float* out,
+                                            int64_t rows, int64_t n_cat,
+                                            int normalize, void* stream);
+int zshmc_unnormalized_multinomial_log_prob_grad(
+    const float* logits, const float* given, const float* gout,
+    float* glogits, int64_t rows, int64_t n_cat, int normalize, void* stream);
+
+/* Sampling (Normal._sample univariate.py:161-172, Bernoulli._sample
+ * :386-396, Categorical._sample :478-494) on Philox stream STREAM_DIST with
+ * counter (i/4, offset).  n = total number of output elements. */
+int zshmc_normal_sample(float* out, const float* mean, const float* std,
+                        int64_t n, int64_t inner, int mean_bcast,
+                        int std_bcast, uint64_t seed, uint32_t offset,
+                        void* stream);
+int zshmc_bernoulli_sample(int32_t* out, const float* logits, int64_t n,
+                           int64_t inner, uint64_t seed, uint32_t offset,
+                           void* stream);
+int zshmc_categorical_sample(int32_t* out, const float* logits,
+                             int64_t n_samples, int64_t rows, int64_t n_cat,
+                             uint64_t seed, uint32_t offset, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZSHMC_H_ */

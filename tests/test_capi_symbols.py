@@ -1,0 +1,91 @@
+"""The C-ABI library loads (no GPU needed) and exports exactly what
+include/zshmc.h declares; the ctypes table in zhusuan_amd/_capi.py mirrors the
+header argument for argument."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, 'include', 'zshmc.h')
+
+
+def _header_functions():
+    src = open(HEADER).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    src = re.sub(r'^\s*#.*$', '', src, flags=re.M)
+    out = {}
+    for m in re.finditer(
+            r'([A-Za-z_][\w\s\*]*?)\b(zshmc_\w+)\s*\(([^;{]*?)\)\s*;', src):
+        args = m.group(3).strip()
+        n = 0 if args in ('', 'void') else len(args.split(','))
+        out[m.group(2)] = (m.group(1).strip(), n, args)
+    return out
+
+
+@pytest.fixture(scope='module')
+def lib():
+    import __graft_entry__ as g
+    g.build()
+    from zhusuan_amd import _capi
+    return _capi.load()
+
+
+def test_header_declares_functions():
+    fns = _header_functions()
+    assert 'zshmc_hmc_diag_normal_step' in fns
+    assert len(fns) >= 20
+
+
+def test_every_declared_symbol_is_exported(lib):
+    for name in _header_functions():
+        assert hasattr(lib, name), name
+        assert isinstance(getattr(lib, name), ctypes._CFuncPtr)
+
+
+def test_ctypes_table_matches_header(lib):
+    from zhusuan_amd import _capi
+    fns = _header_functions()
+    assert set(fns) == set(_capi.PROTOTYPES), (
+        set(fns) ^ set(_capi.PROTOTYPES))
+    for name, (ret, nargs, args) in fns.items():
+        restype, argtypes = _capi.PROTOTYPES[name]
+        assert len(argtypes) == nargs, (name, len(argtypes), nargs)
+        # pointer / scalar kinds agree position by position
+        for decl, ct in zip([a.strip() for a in args.split(',')] if nargs
+                            else [], argtypes):
+            is_ptr = '*' in decl
+            assert is_ptr == (ct is ctypes.c_void_p), (name, decl, ct)
+            if not is_ptr:
+                kinds = {'float': ctypes.c_float, 'int64_t': ctypes.c_int64,
+                         'uint64_t': ctypes.c_uint64,
+                         'uint32_t': ctypes.c_uint32, 'int': ctypes.c_int}
+                base = decl.split()[0]
+                assert kinds[base] is ct, (name, decl, ct)
+
+
+def test_version_and_limits_callable_without_gpu(lib):
+    assert lib.zshmc_version() == 100
+    assert lib.zshmc_fused_max_n_data() == 2048
+    assert lib.zshmc_last_error() is not None
+
+
+def test_bad_arguments_are_rejected_before_any_launch(lib):
+    """Argument validation happens on the host, so it works without a GPU."""
+    from zhusuan_amd import _capi
+    rc = lib.zshmc_hmc_diag_normal_step(
+        None, None, None, None, None, 0.1, 4, 4, 0, 1, 0, 0, 1, None, None,
+        None, None, None, None, None, None)
+    assert rc == 1
+    assert 'null' in _capi.last_error()
+    rc = lib.zshmc_state_set(ctypes.c_void_p(8), 99, 0.0, None)
+    assert rc == 1 and 'out of range' in _capi.last_error()
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from zhusuan_amd import _capi
+    monkeypatch.setattr(_capi, '_lib', None)
+    monkeypatch.setattr(_capi, 'LIB_PATH', str(tmp_path / 'nope.so'))
+    with pytest.raises(_capi.LibraryMissing, match='no CPU fallback'):
+        _capi.load()

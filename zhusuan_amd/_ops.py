@@ -1,0 +1,215 @@
+"""torch.autograd wrappers around the libzshmc.so log_prob kernels.
+
+Forward and backward both run the hand-written HIP kernels
+(csrc/distributions.hip); torch only provides device memory, the stream and
+the tape that chains these ops with whatever deterministic torch ops the user
+model contains (tf.gradients, reference hmc.py:430-432).
+"""
+import torch
+
+from . import _capi
+
+_F32 = torch.float32
+
+
+def require_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "zhusuan_amd: log_prob / sampling kernels run on an MI355X "
+                "only; got a %s tensor. There is no CPU fallback." % t.device)
+
+
+def bcast_plan(full_shape, n_col_dims, *params):
+    """For x viewed as [rows, cols] (cols = prod(full_shape[-n_col_dims:])),
+    return [(tensor, mode)] for each param: SCALAR / ROW / FULL, materialising
+    an expanded copy only when the param fits none of them."""
+    nd = len(full_shape)
+    col_shape = tuple(full_shape[nd - n_col_dims:])
+    out = []
+    for p in params:
+        ps = (1,) * (nd - p.dim()) + tuple(p.shape)
+        if p.numel() == 1:
+            out.append((p.reshape(1).contiguous(), _capi.BCAST_SCALAR))
+        elif (all(s == 1 for s in ps[:nd - n_col_dims]) and
+              tuple(ps[nd - n_col_dims:]) == col_shape):
+            out.append((p.reshape(-1).contiguous(), _capi.BCAST_ROW))
+        elif tuple(ps) == tuple(full_shape):
+            out.append((p.contiguous(), _capi.BCAST_FULL))
+        else:
+            out.append((p.expand(full_shape).contiguous(), _capi.BCAST_FULL))
+    return out
+
+
+def choose_col_dims(full_shape, group_ndims, *params):
+    """Number of trailing dims folded into `cols`.  With group_ndims > 0 it
+    is group_ndims (the kernel sums each row).  Otherwise pick the widest
+    suffix for which no param needs materialising."""
+    nd = len(full_shape)
+    if group_ndims > 0:
+        return group_ndims
+    if nd == 0:
+        return 0
+    for n in range(nd, 0, -1):
+        ok = True
+        for p in params:
+            ps = (1,) * (nd - p.dim()) + tuple(p.shape)
+            if p.numel() == 1 or tuple(ps) == tuple(full_shape):
+                continue
+            if (all(s == 1 for s in ps[:nd - n]) and
+                    tuple(ps[nd - n:]) == tuple(full_shape[nd - n:])):
+                continue
+            ok = False
+            break
+        if ok:
+            return n
+    return 1
+
+
+def _rows_cols(full_shape, n_col_dims):
+    nd = len(full_shape)
+    cols = 1
+    for s in full_shape[nd - n_col_dims:]:
+        cols *= int(s)
+    rows = 1
+    for s in full_shape[:nd - n_col_dims]:
+        rows *= int(s)
+    return rows, max(cols, 1)
+
+
+def _sum_to(g_full, target_shape):
+    """Reduce a full-shape gradient back to a broadcast parameter's shape."""
+    return g_full.sum_to_size(target_shape) if tuple(g_full.shape) != tuple(
+        target_shape) else g_full
+
+
+class NormalLogProb(torch.autograd.Function):
+    """Normal._log_prob + group_ndims sum (reference
+    distributions/univariate.py:174-181, base.py:302-304)."""
+
+    @staticmethod
+    def forward(ctx, x, mean, logstd, group_ndims):
+        require_device(x, mean, logstd)
+        full = torch.broadcast_shapes(x.shape, mean.shape, logstd.shape)
+        n_col = choose_col_dims(full, group_ndims, mean, logstd)
+        rows, cols = _rows_cols(full, n_col)
+        xf = x.expand(full).contiguous()
+        (m, mm), (s, sm) = bcast_plan(full, n_col, mean, logstd)
+        reduce_cols = 1 if group_ndims > 0 else 0
+        out_shape = full[:len(full) - group_ndims] if reduce_cols else full
+        out = torch.empty(out_shape, dtype=_F32, device=x.device)
+        _capi.call('zshmc_normal_log_prob', xf.data_ptr(), m.data_ptr(),
+                   s.data_ptr(), out.data_ptr(), rows, cols, mm, sm,
+                   reduce_cols, _capi.current_stream())
+        ctx.save_for_backward(xf, m, s)
+        ctx.meta = (full, rows, cols, mm, sm, reduce_cols, x.shape,
+                    mean.shape, logstd.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        xf, m, s = ctx.saved_tensors
+        full, rows, cols, mm, sm, reduce_cols, xs, ms, ss = ctx.meta
+        need_x, need_m, need_s = ctx.needs_input_grad[:3]
+        gout = gout.contiguous()
+        gx = torch.empty(full, dtype=_F32, device=xf.device) if need_x else None
+        gm = torch.empty(full, dtype=_F32, device=xf.device) if need_m else None
+        gs = torch.empty(full, dtype=_F32, device=xf.device) if need_s else None
+        _capi.call('zshmc_normal_log_prob_grad', xf.data_ptr(), m.data_ptr(),
+                   s.data_ptr(), gout.data_ptr(), _capi.ptr(gx),
+                   _capi.ptr(gm), _capi.ptr(gs), rows, cols, mm, sm,
+                   reduce_cols, _capi.current_stream())
+        return (_sum_to(gx, xs) if need_x else None,
+                _sum_to(gm, ms) if need_m else None,
+                _sum_to(gs, ss) if need_s else None, None)
+
+
+class BernoulliLogProb(torch.autograd.Function):
+    """Bernoulli._log_prob (reference univariate.py:398-403)."""
+
+    @staticmethod
+    def forward(ctx, logits, given, group_ndims):
+        require_device(logits, given)
+        full = torch.broadcast_shapes(logits.shape, given.shape)
+        n_col = choose_col_dims(full, group_ndims, logits, given)
+        rows, cols = _rows_cols(full, n_col)
+        (l, lm), (z, zm) = bcast_plan(full, n_col, logits, given)
+        reduce_cols = 1 if group_ndims > 0 else 0
+        out_shape = full[:len(full) - group_ndims] if reduce_cols else full
+        out = torch.empty(out_shape, dtype=_F32, device=logits.device)
+        _capi.call('zshmc_bernoulli_log_prob', l.data_ptr(), z.data_ptr(),
+                   out.data_ptr(), rows, cols, lm, zm, reduce_cols,
+                   _capi.current_stream())
+        ctx.save_for_backward(l, z)
+        ctx.meta = (full, rows, cols, lm, zm, reduce_cols, logits.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        l, z = ctx.saved_tensors
+        full, rows, cols, lm, zm, reduce_cols, ls = ctx.meta
+        if not ctx.needs_input_grad[0]:
+            return None, None, None
+        gl = torch.empty(full, dtype=_F32, device=l.device)
+        _capi.call('zshmc_bernoulli_log_prob_grad', l.data_ptr(),
+                   z.data_ptr(), gout.contiguous().data_ptr(), gl.data_ptr(),
+                   rows, cols, lm, zm, reduce_cols, _capi.current_stream())
+        return _sum_to(gl, ls), None, None
+
+
+class CategoricalLogProb(torch.autograd.Function):
+    """Categorical._log_prob (reference univariate.py:496-548); logits
+    [rows, n_cat] and int64 labels [rows], already broadcast."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        require_device(logits, labels)
+        rows, n_cat = logits.shape
+        out = torch.empty((rows,), dtype=_F32, device=logits.device)
+        _capi.call('zshmc_categorical_log_prob', logits.data_ptr(),
+                   labels.data_ptr(), out.data_ptr(), rows, n_cat,
+                   _capi.current_stream())
+        ctx.save_for_backward(logits, labels)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        logits, labels = ctx.saved_tensors
+        if not ctx.needs_input_grad[0]:
+            return None, None
+        rows, n_cat = logits.shape
+        gl = torch.empty_like(logits)
+        _capi.call('zshmc_categorical_log_prob_grad', logits.data_ptr(),
+                   labels.data_ptr(), gout.contiguous().data_ptr(),
+                   gl.data_ptr(), rows, n_cat, _capi.current_stream())
+        return gl, None
+
+
+class UnnormalizedMultinomialLogProb(torch.autograd.Function):
+    """UnnormalizedMultinomial._log_prob (reference
+    distributions/multivariate.py:435-443)."""
+
+    @staticmethod
+    def forward(ctx, logits, given, normalize):
+        require_device(logits, given)
+        rows, n_cat = logits.shape
+        out = torch.empty((rows,), dtype=_F32, device=logits.device)
+        _capi.call('zshmc_unnormalized_multinomial_log_prob',
+                   logits.data_ptr(), given.data_ptr(), out.data_ptr(), rows,
+                   n_cat, int(bool(normalize)), _capi.current_stream())
+        ctx.save_for_backward(logits, given)
+        ctx.normalize = int(bool(normalize))
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        logits, given = ctx.saved_tensors
+        if not ctx.needs_input_grad[0]:
+            return None, None, None
+        rows, n_cat = logits.shape
+        gl = torch.empty_like(logits)
+        _capi.call('zshmc_unnormalized_multinomial_log_prob_grad',
+                   logits.data_ptr(), given.data_ptr(),
+                   gout.contiguous().data_ptr(), gl.data_ptr(), rows, n_cat,
+                   ctx.normalize, _capi.current_stream())
+        return gl, None, None

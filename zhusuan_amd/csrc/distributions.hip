@@ -1,0 +1,446 @@
+// Stand-alone log_prob / analytic-gradient / sampling kernels for the
+// distributions on the HMC hot path (gfx950).  Reference formulas:
+//   Normal       zhusuan/distributions/univariate.py:161-181
+//   Bernoulli    zhusuan/distributions/univariate.py:386-403
+//   Categorical  zhusuan/distributions/univariate.py:478-548
+//   UnnormalizedMultinomial  zhusuan/distributions/multivariate.py:435-443
+//   group_ndims reduction    zhusuan/distributions/base.py:302-304
+// The TensorFlow closed forms they delegate to are restated:
+//   sigmoid_cross_entropy_with_logits(z, l) = max(l,0) - l z + log1p(exp(-|l|))
+//   sparse_softmax_cross_entropy_with_logits(k, l) = logsumexp(l) - l[k]
+//
+// All kernels are HBM-bound element-wise / row-reduction passes: flat
+// grid-stride loops with coalesced accesses; row sums use one wave per row
+// and shuffle reductions.
+#include "common.h"
+#include "philox.h"
+
+namespace zshmc {
+
+constexpr float kNegHalfLog2Pi = -0.91893853320467274178f;
+
+__device__ __forceinline__ float fetch(const float* __restrict__ p, int mode,
+                                       int64_t i, int64_t col) {
+  return mode == ZSHMC_BCAST_FULL ? p[i] : (mode == ZSHMC_BCAST_ROW ? p[col] : p[0]);
+}
+
+__device__ __forceinline__ float normal_lp(float x, float mean, float logstd) {
+  const float prec = expf(-2.0f * logstd);
+  const float d = x - mean;
+  return kNegHalfLog2Pi - logstd - 0.5f * prec * d * d;
+}
+
+__device__ __forceinline__ float bernoulli_lp(float l, float z) {
+  return -(fmaxf(l, 0.f) - l * z + log1pf(expf(-fabsf(l))));
+}
+
+__device__ __forceinline__ float sigmoidf(float l) {
+  return 1.0f / (1.0f + expf(-l));
+}
+
+// ---- element-wise forward (reduce_cols == 0) -----------------------------
+template <int KIND>  // 0 normal, 1 bernoulli
+__global__ __launch_bounds__(256) void lp_elementwise_kernel(
+    const float* __restrict__ a, const float* __restrict__ b,
+    const float* __restrict__ c, float* __restrict__ out, int64_t n,
+    int64_t cols, int mode_b, int mode_c) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t col = i % cols;
+    if (KIND == 0) {
+      out[i] = normal_lp(a[i], fetch(b, mode_b, i, col), fetch(c, mode_c, i, col));
+    } else {
+      out[i] = bernoulli_lp(fetch(a, mode_b, i, col), fetch(b, mode_c, i, col));
+    }
+  }
+}
+
+// ---- row-reduced forward (reduce_cols != 0): one wave per row -------------
+template <int KIND>
+__global__ __launch_bounds__(256) void lp_rowsum_kernel(
+    const float* __restrict__ a, const float* __restrict__ b,
+    const float* __restrict__ c, float* __restrict__ out, int64_t rows,
+    int64_t cols, int mode_b, int mode_c) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+  const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x / 64);
+  for (int64_t r = wave; r < rows; r += n_waves) {
+    float s = 0.f;
+    for (int64_t col = lane; col < cols; col += 64) {
+      const int64_t i = r * cols + col;
+      if (KIND == 0)
+        s += normal_lp(a[i], fetch(b, mode_b, i, col), fetch(c, mode_c, i, col));
+      else
+        s += bernoulli_lp(fetch(a, mode_b, i, col), fetch(b, mode_c, i, col));
+    }
+    s = group_sum<64>(s);
+    if (lane == 0) out[r] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void normal_grad_kernel(
+    const float* __restrict__ x, const float* __restrict__ mean,
+    const float* __restrict__ logstd, const float* __restrict__ gout,
+    float* __restrict__ gx, float* __restrict__ gmean,
+    float* __restrict__ glogstd, int64_t n, int64_t cols, int mode_m,
+    int mode_s, int reduce_cols) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t col = i % cols;
+    const float g = reduce_cols ? gout[i / cols] : gout[i];
+    const float ls = fetch(logstd, mode_s, i, col);
+    const float prec = expf(-2.0f * ls);
+    const float d = x[i] - fetch(mean, mode_m, i, col);
+    const float pd = prec * d;
+    if (gx) gx[i] = -g * pd;
+    if (gmean) gmean[i] = g * pd;
+    if (glogstd) glogstd[i] = g * (pd * d - 1.0f);
+  }
+}
+
+__global__ __launch_bounds__(256) void bernoulli_grad_kernel(
+    const float* __restrict__ logits, const float* __restrict__ given,
+    const float* __restrict__ gout, float* __restrict__ glogits, int64_t n,
+    int64_t cols, int mode_l, int mode_z, int reduce_cols) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t col = i % cols;
+    const float g = reduce_cols ? gout[i / cols] : gout[i];
+    glogits[i] = g * (fetch(given, mode_z, i, col) -
+                      sigmoidf(fetch(logits, mode_l, i, col)));
+  }
+}
+
+// ---- Categorical / UnnormalizedMultinomial: one wave per row ----------------
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+__device__ __forceinline__ float row_logsumexp(const float* __restrict__ row,
+                                               int64_t n_cat, int lane) {
+  float m = -INFINITY;
+  for (int64_t j = lane; j < n_cat; j += 64) m = fmaxf(m, row[j]);
+  m = wave_max(m);
+  float s = 0.f;
+  for (int64_t j = lane; j < n_cat; j += 64) s += expf(row[j] - m);
+  s = group_sum<64>(s);
+  return m + logf(s);
+}
+
+// MODE 0: categorical forward; 1: categorical grad; 2: multinomial forward;
+// 3: multinomial grad
+template <int MODE>
+__global__ __launch_bounds__(256) void softmax_family_kernel(
+    const float* __restrict__ logits, const int64_t* __restrict__ labels,
+    const float* __restrict__ given, const float* __restrict__ gout,
+    float* __restrict__ out, int64_t rows, int64_t n_cat, int normalize) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+  const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x / 64);
+  for (int64_t r = wave; r < rows; r += n_waves) {
+    const float* __restrict__ row = logits + r * n_cat;
+    const float lse = (MODE < 2 || normalize) ? row_logsumexp(row, n_cat, lane) : 0.f;
+    if (MODE == 0) {
+      if (lane == 0) {
+        const int64_t k = labels[r];
+        out[r] = (k >= 0 && k < n_cat) ? row[k] - lse : NAN;
+      }
+    } else if (MODE == 1) {
+      const int64_t k = labels[r];
+      const float g = gout[r];
+      for (int64_t j = lane; j < n_cat; j += 64)
+        out[r * n_cat + j] = g * ((j == k ? 1.0f : 0.0f) - expf(row[j] - lse));
+    } else if (MODE == 2) {
+      float s = 0.f;
+      for (int64_t j = lane; j < n_cat; j += 64)
+        s += given[r * n_cat + j] * (row[j] - lse);
+      s = group_sum<64>(s);
+      if (lane == 0) out[r] = s;
+    } else {
+      const float g = gout[r];
+      float tot = 0.f;
+      if (normalize) {
+        for (int64_t j = lane; j < n_cat; j += 64) tot += given[r * n_cat + j];
+        tot = group_sum<64>(tot);
+      }
+      for (int64_t j = lane; j < n_cat; j += 64) {
+        float v = given[r * n_cat + j];
+        if (normalize) v -= tot * expf(row[j] - lse);
+        out[r * n_cat + j] = g * v;
+      }
+    }
+  }
+}
+
+// ---- sampling ---------------------------------------------------------------
+__global__ __launch_bounds__(256) void normal_sample_kernel(
+    float* __restrict__ out, const float* __restrict__ mean,
+    const float* __restrict__ std, int64_t n, int64_t inner, int mode_m,
+    int mode_s, uint32_t k0, uint32_t k1, uint32_t offset) {
+  const int64_t n_groups = (n + 3) / 4;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_groups;
+       g += (int64_t)gridDim.x * blockDim.x) {
+    float z[4];
+    normal4((uint32_t)g, (uint32_t)((uint64_t)g >> 32), offset, kStreamDist, k0,
+            k1, z[0], z[1], z[2], z[3]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t i = g * 4 + j;
+      if (i < n) {
+        const int64_t b = i % inner;
+        const float m = mode_m == ZSHMC_BCAST_SCALAR ? mean[0] : mean[b];
+        const float s = mode_s == ZSHMC_BCAST_SCALAR ? std[0] : std[b];
+        out[i] = z[j] * s + m;  // univariate.py:167
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bernoulli_sample_kernel(
+    int32_t* __restrict__ out, const float* __restrict__ logits, int64_t n,
+    int64_t inner, uint32_t k0, uint32_t k1, uint32_t offset) {
+  const int64_t n_groups = (n + 3) / 4;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_groups;
+       g += (int64_t)gridDim.x * blockDim.x) {
+    const U4 r = philox4x32_10((uint32_t)g, (uint32_t)((uint64_t)g >> 32),
+                               offset, kStreamDist, k0, k1);
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t i = g * 4 + j;
+      if (i < n) out[i] = u01(w[j]) < sigmoidf(logits[i % inner]) ? 1 : 0;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void categorical_sample_kernel(
+    int32_t* __restrict__ out, const float* __restrict__ logits,
+    int64_t n_samples, int64_t rows, int64_t n_cat, uint32_t k0, uint32_t k1,
+    uint32_t offset) {
+  const int64_t n = n_samples * rows;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t g = i >> 2;
+    const U4 r = philox4x32_10((uint32_t)g, (uint32_t)((uint64_t)g >> 32),
+                               offset, kStreamDist, k0, k1);
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+    const float u = u01(w[i & 3]);
+    const float* __restrict__ row = logits + (i % rows) * n_cat;
+    float m = -INFINITY;
+    for (int64_t j = 0; j < n_cat; ++j) m = fmaxf(m, row[j]);
+    float s = 0.f;
+    for (int64_t j = 0; j < n_cat; ++j) s += expf(row[j] - m);
+    const float lse = m + logf(s);
+    float cdf = 0.f;
+    int32_t k = 0;
+    for (int64_t j = 0; j < n_cat; ++j) {
+      cdf += expf(row[j] - lse);
+      if (cdf <= u) ++k;
+    }
+    out[i] = k < (int32_t)n_cat ? k : (int32_t)n_cat - 1;
+  }
+}
+
+static inline int flat_grid(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  const int64_t cap = (int64_t)device_cu_count() * 16;
+  if (b > cap) b = cap;
+  return (int)(b > 0 ? b : 1);
+}
+static inline int wave_row_grid(int64_t rows) {
+  int64_t b = (rows + 3) / 4;
+  const int64_t cap = (int64_t)device_cu_count() * 8;
+  if (b > cap) b = cap;
+  return (int)(b > 0 ? b : 1);
+}
+static inline bool mode_ok(int m) {
+  return m == ZSHMC_BCAST_FULL || m == ZSHMC_BCAST_ROW || m == ZSHMC_BCAST_SCALAR;
+}
+
+}  // namespace zshmc
+
+using namespace zshmc;
+#define ZS_STREAM reinterpret_cast<hipStream_t>(stream)
+
+extern "C" int zshmc_normal_log_prob(const float* x, const float* mean,
+                                     const float* logstd, float* out,
+                                     int64_t rows, int64_t cols,
+                                     int mean_bcast, int logstd_bcast,
+                                     int reduce_cols, void* stream) {
+  ZS_REQUIRE(x && mean && logstd && out, "zshmc_normal_log_prob: null pointer");
+  ZS_REQUIRE(rows >= 0 && cols >= 1, "zshmc_normal_log_prob: bad shape");
+  ZS_REQUIRE(mode_ok(mean_bcast) && mode_ok(logstd_bcast),
+             "zshmc_normal_log_prob: bad broadcast mode");
+  if (rows == 0) return ZSHMC_OK;
+  if (reduce_cols)
+    hipLaunchKernelGGL(lp_rowsum_kernel<0>, dim3(wave_row_grid(rows)), dim3(256),
+                       0, ZS_STREAM, x, mean, logstd, out, rows, cols,
+                       mean_bcast, logstd_bcast);
+  else
+    hipLaunchKernelGGL(lp_elementwise_kernel<0>, dim3(flat_grid(rows * cols)),
+                       dim3(256), 0, ZS_STREAM, x, mean, logstd, out,
+                       rows * cols, cols, mean_bcast, logstd_bcast);
+  ZS_LAUNCH_CHECK("normal_log_prob launch");
+  return ZSHMC_OK;
+}
+
+extern "C" int zshmc_normal_log_prob_grad(
+    const float* x, const float* mean, const float* logstd, const float* gout,
+    float* gx, float* gmean, float* glogstd, int64_t rows, int64_t cols,
+    int mean_bcast, int logstd_bcast, int reduce_cols, void* stream) {
+  ZS_REQUIRE(x && mean && logstd && gout, "zshmc_normal_log_prob_grad: null pointer");
+  ZS_REQUIRE(rows >= 0 && cols >= 1, "zshmc_normal_log_prob_grad: bad shape");
+  ZS_REQUIRE(mode_ok(mean_bcast) && mode_ok(logstd_bcast),
+             "zshmc_normal_log_prob_grad: bad broadcast mode");
+  if (rows == 0) return ZSHMC_OK;
+  hipLaunchKernelGGL(normal_grad_kernel, dim3(flat_grid(rows * cols)), dim3(256),
+                     0, ZS_STREAM, x, mean, logstd, gout, gx, gmean, glogstd,
+                     rows * cols, cols, mean_bcast, logstd_bcast, reduce_cols);
+  ZS_LAUNCH_CHECK("normal_grad_kernel launch");
+  return ZSHMC_OK;
+}
+
+extern "C" int zshmc_bernoulli_log_prob(const float* logits, const float* given,
+                                        float* out, int64_t rows, int64_t cols,
+                                        int logits_bcast, int given_bcast,
+                                        int reduce_cols, void* stream) {
+  ZS_REQUIRE(logits && given && out, "zshmc_bernoulli_log_prob: null pointer");
+  ZS_REQUIRE(rows >= 0 && cols >= 1, "zshmc_bernoulli_log_prob: bad shape");
+  ZS_REQUIRE(mode_ok(logits_bcast) && mode_ok(given_bcast),
+             "zshmc_bernoulli_log_prob: bad broadcast mode");
+  if (rows == 0) return ZSHMC_OK;
+  if (reduce_cols)
+    hipLaunchKernelGGL(lp_rowsum_kernel<1>, dim3(wave_row_grid(rows)), dim3(256),
+                       0, ZS_STREAM, logits, given, nullptr, out, rows, cols,
+                       logits_bcast, given_bcast);
+  else
+    hipLaunchKernelGGL(lp_elementwise_kernel<1>, dim3(flat_grid(rows * cols)),
+                       dim3(256), 0, ZS_STREAM, logits, given, nullptr, out,
+                       rows * cols, cols, logits_bcast, given_bcast);
+  ZS_LAUNCH_CHECK("bernoulli_log_prob launch");
+  return ZSHMC_OK;
+}
+
+extern "C" int zshmc_bernoulli_log_prob_grad(
+    const float* logits, const float* given, const float* gout, float* glogits,
+    int64_t rows, int64_t cols, int logits_bcast, int given_bcast,
+    int reduce_cols, void* stream) {
+  ZS_REQUIRE(logits && given && gout && glogits,
+             "zshmc_bernoulli_log_prob_grad: null pointer");
+  ZS_REQUIRE(rows >= 0 && cols >= 1, "zshmc_bernoulli_log_prob_grad: bad shape");
+  ZS_REQUIRE(mode_ok(logits_bcast) && mode_ok(given_bcast),
+             "zshmc_bernoulli_log_prob_grad: bad broadcast mode");
+  if (rows == 0) return ZSHMC_OK;
+  hipLaunchKernelGGL(bernoulli_grad_kernel, dim3(flat_grid(rows * cols)),
+                     dim3(256), 0, ZS_STREAM, logits, given, gout, glogits,
+                     rows * cols, cols, logits_bcast, given_bcast, reduce_cols);
+  ZS_LAUNCH_CHECK("bernoulli_grad_kernel launch");
+  return ZSHMC_OK;
+}
+
+extern "C" int zshmc_categorical_log_prob(const float* logits,
+                                          const int64_t* labels, float* out,
+                                          int64_t rows, int64_t n_cat,
+                                          void* stream) {
+  ZS_REQUIRE(logits && labels && out, "zshmc_categorical_log_prob: null pointer");
+  ZS_REQUIRE(rows >= 0 && n_cat >= 1, "zshmc_categorical_log_prob: bad shape");
+  if (rows == 0) return ZSHMC_OK;
+  hipLaunchKernelGGL(softmax_family_kernel<0>, dim3(wave_row_grid(rows)),
+                     dim3(256), 0, ZS_STREAM, logits, labels, nullptr, nullptr,
+                     out, rows, n_cat, 1);
+  ZS_LAUNCH_CHECK("categorical_log_prob launch");
+  return ZSHMC_OK;
+}
+
+extern "C" int zshmc_categorical_log_prob_grad(const float* logits,
+                                               const int64_t* labels,
+                                               const float* gout,
+                                               float* glogits, int64_t rows,
+                                               int64_t n_cat, void* stream) {
+  ZS_REQUIRE(logits && labels && gout && glogits,
+             "zshmc_categorical_log_prob_grad: null pointer");
+  ZS_REQUIRE(rows >= 0 && n_cat >= 1, "zshmc_categorical_log_prob_grad: bad shape");
+  if (rows == 0) return ZSHMC_OK;
+  hipLaunchKernelGGL(softmax_family_kernel<1>, dim3(wave_row_grid(rows)),
+                     dim3(256), 0, ZS_STREAM, logits, labels, nullptr, gout,
+                     glogits, rows, n_cat, 1);
+  ZS_LAUNCH_CHECK("categorical_log_prob_grad launch");
+  return ZSHMC_OK;
+}
+
+extern "C" int zshmc_unnormalized_multinomial_log_prob(
+    const float* logits, const float* given, float* out, int64_t rows,
+    int64_t n_cat, int normalize, void* stream) {
+  ZS_REQUIRE(logits && given && out,
+             "zshmc_unnormalized_multinomial_log_prob: null pointer");
+  ZS_REQUIRE(rows >= 0 && n_cat >= 1,
+             "zshmc_unnormalized_multinomial_log_prob: bad shape");
+  if (rows == 0) return ZSHMC_OK;
+  hipLaunchKernelGGL(softmax_family_kernel<2>, dim3(wave_row_grid(rows)),
+                     dim3(256), 0, ZS_STREAM, logits, nullptr, given, nullptr,
+                     out, rows, n_cat, normalize);
+  ZS_LAUNCH_CHECK("unnormalized_multinomial_log_prob launch");
+  return ZSHMC_OK;
+}
+
+extern "C" int zshmc_unnormalized_multinomial_log_prob_grad(
+    const float* logits, const float* given, const float* gout, float* glogits,
+    int64_t rows, int64_t n_cat, int normalize, void* stream) {
+  ZS_REQUIRE(logits && given && gout && glogits,
+             "zshmc_unnormalized_multinomial_log_prob_grad: null pointer");
+  ZS_REQUIRE(rows >= 0 && n_cat >= 1,
+             "zshmc_unnormalized_multinomial_log_prob_grad: bad shape");
+  if (rows == 0) return ZSHMC_OK;
+  hipLaunchKernelGGL(softmax_family_kernel<3>, dim3(wave_row_grid(rows)),
+                     dim3(256), 0, ZS_STREAM, logits, nullptr, given, gout,
+                     glogits, rows, n_cat, normalize);
+  ZS_LAUNCH_CHECK("unnormalized_multinomial_log_prob_grad launch");
+  return ZSHMC_OK;
+}
+
+extern "C" int zshmc_normal_sample(float* out, const float* mean,
+                                   const float* std, int64_t n, int64_t inner,
+                                   int mean_bcast, int std_bcast, uint64_t seed,
+                                   uint32_t offset, void* stream) {
+  ZS_REQUIRE(out && mean && std, "zshmc_normal_sample: null pointer");
+  ZS_REQUIRE(n >= 0 && inner >= 1, "zshmc_normal_sample: bad shape");
+  if (n == 0) return ZSHMC_OK;
+  hipLaunchKernelGGL(normal_sample_kernel, dim3(flat_grid((n + 3) / 4)),
+                     dim3(256), 0, ZS_STREAM, out, mean, std, n, inner,
+                     mean_bcast, std_bcast, (uint32_t)(seed & 0xFFFFFFFFull),
+                     (uint32_t)(seed >> 32), offset);
+  ZS_LAUNCH_CHECK("normal_sample_kernel launch");
+  return ZSHMC_OK;
+}
+
+extern "C" int zshmc_bernoulli_sample(int32_t* out, const float* logits,
+                                      int64_t n, int64_t inner, uint64_t seed,
+                                      uint32_t offset, void* stream) {
+  ZS_REQUIRE(out && logits, "zshmc_bernoulli_sample: null pointer");
+  ZS_REQUIRE(n >= 0 && inner >= 1, "zshmc_bernoulli_sample: bad shape");
+  if (n == 0) return ZSHMC_OK;
+  hipLaunchKernelGGL(bernoulli_sample_kernel, dim3(flat_grid((n + 3) / 4)),
+                     dim3(256), 0, ZS_STREAM, out, logits, n, inner,
+                     (uint32_t)(seed & 0xFFFFFFFFull), (uint32_t)(seed >> 32),
+                     offset);
+  ZS_LAUNCH_CHECK("bernoulli_sample_kernel launch");
+  return ZSHMC_OK;
+}
+
+extern "C" int zshmc_categorical_sample(int32_t* out, const float* logits,
+                                        int64_t n_samples, int64_t rows,
+                                        int64_t n_cat, uint64_t seed,
+                                        uint32_t offset, void* stream) {
+  ZS_REQUIRE(out && logits, "zshmc_categorical_sample: null pointer");
+  ZS_REQUIRE(n_samples >= 0 && rows >= 0 && n_cat >= 1,
+             "zshmc_categorical_sample: bad shape");
+  if (n_samples * rows == 0) return ZSHMC_OK;
+  hipLaunchKernelGGL(categorical_sample_kernel, dim3(flat_grid(n_samples * rows)),
+                     dim3(256), 0, ZS_STREAM, out, logits, n_samples, rows,
+                     n_cat, (uint32_t)(seed & 0xFFFFFFFFull),
+                     (uint32_t)(seed >> 32), offset);
+  ZS_LAUNCH_CHECK("categorical_sample_kernel launch");
+  return ZSHMC_OK;
+}

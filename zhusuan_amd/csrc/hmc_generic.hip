@@ -1,0 +1,224 @@
+// Building blocks of the generic HMC transition on gfx950: the log-joint and
+// its gradient come from the caller (autograd over the log_prob ops of
+// distributions.hip, or any user callable), these kernels do everything else
+// of reference zhususan/hmc.py's sample_op with q, p resident in HBM:
+//
+//   momentum_kernel     random_momentum            hmc.py:21-23
+//   kick_drift_kernel   leapfrog_integrator        hmc.py:38-43 (schedule :352-364)
+//                       + kinetic part of hamiltonian :32-34
+//   mh_accept_kernel    get_acceptance_rate        hmc.py:46-61, MH test :479-487
+//   select_rows_kernel  where(accept, q', q)       hmc.py:488-497
+//
+// Row layout [n_chains, n_data]; one wave per row, lanes stride over the row
+// in 4-element chunks (coalesced), per-row sums by wave shuffles.  The Philox
+// counter mapping is the fused kernel's, so both paths draw identical
+// momenta and uniforms.
+#include "common.h"
+#include "philox.h"
+
+namespace zshmc {
+
+__device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
+
+__global__ __launch_bounds__(256) void momentum_kernel(
+    float* __restrict__ p, const float* __restrict__ mass, int64_t n_chains,
+    int64_t n_data, int64_t chain_offset, uint32_t k0, uint32_t k1,
+    uint32_t iteration, uint32_t stream_word, float* __restrict__ kinetic) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+  const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x / 64);
+  const int64_t n_groups = (n_data + 3) / 4;
+  for (int64_t c = wave; c < n_chains; c += n_waves) {
+    const uint32_t gchain = (uint32_t)(c + chain_offset);
+    float* __restrict__ row = p + c * n_data;
+    float kin = 0.f;
+    for (int64_t g = lane; g < n_groups; g += 64) {
+      float z[4];
+      normal4((uint32_t)g, gchain, iteration, stream_word, k0, k1, z[0], z[1],
+              z[2], z[3]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t d = g * 4 + j;
+        if (d < n_data) {
+          const float m = mass ? mass[d] : 1.0f;
+          const float v = z[j] * sqrtf(m);
+          row[d] = v;
+          kin += v * v / m;
+        }
+      }
+    }
+    if (kinetic) {
+      kin = wave_sum(kin);
+      if (lane == 0) kinetic[c] += 0.5f * kin;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void kick_drift_kernel(
+    float* __restrict__ q, float* __restrict__ p,
+    const float* __restrict__ grad, const float* __restrict__ mass,
+    const float* __restrict__ step_size_dev, float step_size_host,
+    float kick_scale, float drift_scale, int64_t n_chains, int64_t n_data,
+    float* __restrict__ kinetic) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+  const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x / 64);
+  const float eps = step_size_dev ? *step_size_dev : step_size_host;
+  const float s2 = kick_scale * eps;
+  const float s1 = drift_scale * eps;
+  for (int64_t c = wave; c < n_chains; c += n_waves) {
+    const int64_t off = c * n_data;
+    float kin = 0.f;
+    for (int64_t d = lane; d < n_data; d += 64) {
+      const float m = mass ? mass[d] : 1.0f;
+      // p = p + step_size2 * grad           (hmc.py:42)
+      const float pv = p[off + d] + s2 * grad[off + d];
+      p[off + d] = pv;
+      // q = q + step_size1 * (p / mass)     (hmc.py:39, :26-27)
+      if (drift_scale != 0.f) q[off + d] = q[off + d] + s1 * (pv / m);
+      kin += pv * pv / m;
+    }
+    if (kinetic) {
+      kin = wave_sum(kin);
+      if (lane == 0) kinetic[c] += 0.5f * kin;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void mh_accept_kernel(
+    const float* __restrict__ lp_old, const float* __restrict__ lp_new,
+    const float* __restrict__ kin_old, const float* __restrict__ kin_new,
+    int64_t n_chains, int64_t chain_offset, uint32_t k0, uint32_t k1,
+    uint32_t iteration, float* __restrict__ acceptance_rate,
+    float* __restrict__ orig_hamiltonian, float* __restrict__ hamiltonian,
+    float* __restrict__ log_prob_out, uint8_t* __restrict__ accept,
+    double* __restrict__ acc_sum, uint32_t* __restrict__ flags) {
+  double acc_local = 0.0;
+  bool bad = false;
+  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+       c < n_chains; c += (int64_t)gridDim.x * blockDim.x) {
+    const float lo = lp_old[c], ln = lp_new[c];
+    const float h_old = -lo + kin_old[c];  // hmc.py:31-35
+    const float h_new = -ln + kin_new[c];
+    const float diff = h_old - h_new;
+    float acc = expf(fminf(diff, 0.0f));
+    if (!(diff == diff) || !isfinite(acc) || !isfinite(ln)) acc = 0.f;
+    if (!isfinite(lo)) bad = true;  // hmc.py:51-53
+    const float u = uniform_chain((uint32_t)(c + chain_offset), iteration, k0, k1);
+    const bool ok = u < acc;  // hmc.py:486
+    if (acceptance_rate) acceptance_rate[c] = acc;
+    if (orig_hamiltonian) orig_hamiltonian[c] = h_old;
+    if (hamiltonian) hamiltonian[c] = h_new;
+    if (log_prob_out) log_prob_out[c] = ok ? ln : lo;
+    if (accept) accept[c] = ok ? 1 : 0;
+    acc_local += (double)acc;
+  }
+  const double w = wave_sum_f64(acc_local);
+  const unsigned long long any_bad = __ballot(bad);
+  if ((threadIdx.x & 63) == 0) {
+    if (acc_sum && w != 0.0) atomicAdd(acc_sum, w);
+    if (any_bad && flags) atomicOr(flags, ZSHMC_FLAG_OLD_LOGPROB_NONFINITE);
+  }
+}
+
+__global__ __launch_bounds__(256) void select_rows_kernel(
+    float* __restrict__ q, const float* __restrict__ q_new,
+    const uint8_t* __restrict__ accept, int64_t n_chains, int64_t n_data) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+  const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x / 64);
+  for (int64_t c = wave; c < n_chains; c += n_waves) {
+    if (!accept[c]) continue;  // wave-uniform
+    const int64_t off = c * n_data;
+    for (int64_t d = lane; d < n_data; d += 64) q[off + d] = q_new[off + d];
+  }
+}
+
+static inline int row_grid(int64_t n_rows) {
+  const int64_t need = (n_rows + 3) / 4;  // 4 waves per block
+  const int64_t cap = (int64_t)device_cu_count() * 8;
+  int64_t g = need < cap ? need : cap;
+  return (int)(g > 0 ? g : 1);
+}
+
+}  // namespace zshmc
+
+using namespace zshmc;
+
+extern "C" int zshmc_momentum(float* p, const float* mass, int64_t n_chains,
+                              int64_t n_data, int64_t chain_offset,
+                              uint64_t seed, uint32_t iteration,
+                              uint32_t latent_id, float* kinetic,
+                              void* stream) {
+  ZS_REQUIRE(p, "zshmc_momentum: null p");
+  ZS_REQUIRE(n_chains >= 0 && n_data >= 1, "zshmc_momentum: bad shape");
+  ZS_REQUIRE(latent_id < (1u << 24), "zshmc_momentum: latent_id too large");
+  ZS_REQUIRE(n_chains + chain_offset <= 0xFFFFFFFFll,
+             "zshmc_momentum: global chain index exceeds 2^32");
+  if (n_chains == 0) return ZSHMC_OK;
+  hipLaunchKernelGGL(momentum_kernel, dim3(row_grid(n_chains)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), p, mass, n_chains,
+                     n_data, chain_offset, (uint32_t)(seed & 0xFFFFFFFFull),
+                     (uint32_t)(seed >> 32), iteration,
+                     kStreamMomentum | (latent_id << 8), kinetic);
+  ZS_LAUNCH_CHECK("momentum_kernel launch");
+  return ZSHMC_OK;
+}
+
+extern "C" int zshmc_kick_drift(float* q, float* p, const float* grad,
+                                const float* mass, const float* step_size_dev,
+                                float step_size_host, float kick_scale,
+                                float drift_scale, int64_t n_chains,
+                                int64_t n_data, float* kinetic, void* stream) {
+  ZS_REQUIRE(q && p && grad, "zshmc_kick_drift: null q/p/grad");
+  ZS_REQUIRE(n_chains >= 0 && n_data >= 1, "zshmc_kick_drift: bad shape");
+  if (n_chains == 0) return ZSHMC_OK;
+  hipLaunchKernelGGL(kick_drift_kernel, dim3(row_grid(n_chains)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), q, p, grad, mass,
+                     step_size_dev, step_size_host, kick_scale, drift_scale,
+                     n_chains, n_data, kinetic);
+  ZS_LAUNCH_CHECK("kick_drift_kernel launch");
+  return ZSHMC_OK;
+}
+
+extern "C" int zshmc_mh_accept(const float* log_prob_old,
+                               const float* log_prob_new,
+                               const float* kinetic_old,
+                               const float* kinetic_new, int64_t n_chains,
+                               int64_t chain_offset, uint64_t seed,
+                               uint32_t iteration, float* acceptance_rate,
+                               float* orig_hamiltonian, float* hamiltonian,
+                               float* log_prob_out, uint8_t* accept,
+                               double* acc_sum, uint32_t* flags, void* stream) {
+  ZS_REQUIRE(log_prob_old && log_prob_new && kinetic_old && kinetic_new,
+             "zshmc_mh_accept: null input");
+  ZS_REQUIRE(n_chains >= 0, "zshmc_mh_accept: bad n_chains");
+  ZS_REQUIRE(n_chains + chain_offset <= 0xFFFFFFFFll,
+             "zshmc_mh_accept: global chain index exceeds 2^32");
+  if (n_chains == 0) return ZSHMC_OK;
+  int64_t blocks = (n_chains + 255) / 256;
+  const int64_t cap = (int64_t)device_cu_count() * 8;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(mh_accept_kernel, dim3((int)blocks), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), log_prob_old,
+                     log_prob_new, kinetic_old, kinetic_new, n_chains,
+                     chain_offset, (uint32_t)(seed & 0xFFFFFFFFull),
+                     (uint32_t)(seed >> 32), iteration, acceptance_rate,
+                     orig_hamiltonian, hamiltonian, log_prob_out, accept,
+                     acc_sum, flags);
+  ZS_LAUNCH_CHECK("mh_accept_kernel launch");
+  return ZSHMC_OK;
+}
+
+extern "C" int zshmc_select_rows(float* q, const float* q_new,
+                                 const uint8_t* accept, int64_t n_chains,
+                                 int64_t n_data, void* stream) {
+  ZS_REQUIRE(q && q_new && accept, "zshmc_select_rows: null pointer");
+  ZS_REQUIRE(n_chains >= 0 && n_data >= 1, "zshmc_select_rows: bad shape");
+  if (n_chains == 0) return ZSHMC_OK;
+  hipLaunchKernelGGL(select_rows_kernel, dim3(row_grid(n_chains)), dim3(256),
+                     0, reinterpret_cast<hipStream_t>(stream), q, q_new,
+                     accept, n_chains, n_data);
+  ZS_LAUNCH_CHECK("select_rows_kernel launch");
+  return ZSHMC_OK;
+}

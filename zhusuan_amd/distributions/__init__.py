@@ -1,0 +1,6 @@
+from .base import Distribution
+from .univariate import Normal, Bernoulli, Categorical, Discrete
+from .multivariate import UnnormalizedMultinomial, BagofCategoricals
+
+__all__ = ['Distribution', 'Normal', 'Bernoulli', 'Categorical', 'Discrete',
+           'UnnormalizedMultinomial', 'BagofCategoricals']

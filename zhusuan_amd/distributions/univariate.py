@@ -1,0 +1,304 @@
+"""Normal / Bernoulli / Categorical on the HMC hot path.  Mirrors the
+constructor contracts, error messages and shape rules of reference
+zhusuan/distributions/univariate.py:43-184 (Normal), :334-406 (Bernoulli),
+:409-551 (Categorical); all arithmetic runs in the HIP kernels of
+csrc/distributions.hip through zhusuan_amd._ops."""
+import torch
+
+from .. import _capi, _ops
+from ..utils import next_op_offset
+from .base import Distribution, as_tensor, common_device, default_device
+
+__all__ = ['Normal', 'Bernoulli', 'Categorical', 'Discrete']
+
+_FLOATS = (torch.float16, torch.float32, torch.float64)
+_INTS = (torch.int16, torch.int32, torch.int64)
+
+
+def _assert_same_float_dtype(tensors_with_name):
+    """distributions/utils.py:146-190 (message kept)."""
+    dtype = None
+    for t, name in tensors_with_name:
+        if t.dtype not in _FLOATS:
+            raise TypeError("{}({}) must have a float dtype.".format(
+                name, t.dtype))
+        if dtype is None:
+            dtype = t.dtype
+        elif t.dtype != dtype:
+            raise TypeError(
+                "{} must have the same dtype as {}.".format(
+                    name, tensors_with_name[0][1]))
+    return dtype
+
+
+def _require_f32(dtype, what):
+    if dtype != torch.float32:
+        raise TypeError(
+            "{}: the MI355X kernels compute in float32 only (HMC is float32 "
+            "in the reference, hmc.py:22,72-87); got {}.".format(what, dtype))
+
+
+class Normal(Distribution):
+    """Univariate Normal (univariate.py:43-184)."""
+
+    def __init__(self, mean=0., _sentinel=None, std=None, logstd=None,
+                 group_ndims=0, is_reparameterized=True,
+                 use_path_derivative=False, check_numerics=False, **kwargs):
+        if _sentinel is not None:
+            raise ValueError(
+                "The order of logstd/std has changed to std/logstd since "
+                "0.3.1. Please use named arguments: Normal(mean, std=..., "
+                "...) or Normal(mean, logstd=..., ...).")
+        if (logstd is None) == (std is None):
+            raise ValueError(
+                "Either `std` or `logstd` should be passed. It is not allowed "
+                "that both are specified or both are not.")
+        dev = common_device(mean, std, logstd) or default_device()
+        f32 = torch.float32
+        self._mean = as_tensor(mean, dtype=None if isinstance(
+            mean, torch.Tensor) else f32, device=dev)
+        if logstd is None:
+            self._std = as_tensor(std, dtype=None if isinstance(
+                std, torch.Tensor) else f32, device=dev)
+            dtype = _assert_same_float_dtype([(self._mean, 'Normal.mean'),
+                                              (self._std, 'Normal.std')])
+            self._logstd = torch.log(self._std)          # :99
+            if check_numerics and not bool(
+                    torch.isfinite(self._logstd).all()):
+                raise FloatingPointError("log(std) : Tensor had Inf or NaN")
+        else:
+            self._logstd = as_tensor(logstd, dtype=None if isinstance(
+                logstd, torch.Tensor) else f32, device=dev)
+            dtype = _assert_same_float_dtype(
+                [(self._mean, 'Normal.mean'),
+                 (self._logstd, 'Normal.logstd')])
+            self._std = torch.exp(self._logstd)          # :108
+            if check_numerics and not bool(torch.isfinite(self._std).all()):
+                raise FloatingPointError("exp(logstd) : Tensor had Inf or NaN")
+        _require_f32(dtype, 'Normal')
+        try:
+            torch.broadcast_shapes(self._mean.shape, self._std.shape)
+        except RuntimeError:
+            raise ValueError(
+                "mean and std/logstd should be broadcastable to match each "
+                "other. ({} vs. {})".format(tuple(self._mean.shape),
+                                            tuple(self._std.shape)))
+        self._check_numerics = check_numerics
+        super(Normal, self).__init__(
+            dtype=dtype, param_dtype=dtype, is_continuous=True,
+            is_reparameterized=is_reparameterized,
+            use_path_derivative=use_path_derivative,
+            group_ndims=group_ndims, **kwargs)
+
+    @property
+    def mean(self):
+        return self._mean
+
+    @property
+    def logstd(self):
+        return self._logstd
+
+    @property
+    def std(self):
+        return self._std
+
+    def _device(self):
+        return self._mean.device
+
+    def _get_value_shape(self):
+        return torch.Size([])
+
+    def _get_batch_shape(self):
+        return torch.broadcast_shapes(self._mean.shape, self._std.shape)
+
+    def _sample(self, n_samples):
+        """univariate.py:161-172 on the Philox STREAM_DIST stream."""
+        mean, std = self._mean, self._std
+        if not self.is_reparameterized:
+            mean, std = mean.detach(), std.detach()
+        batch = self._get_batch_shape()
+        m = mean.expand(batch).contiguous() if mean.numel() != 1 else mean
+        s = std.expand(batch).contiguous() if std.numel() != 1 else std
+        _ops.require_device(m, s)
+        inner = 1
+        for d in batch:
+            inner *= int(d)
+        n = int(n_samples) * inner
+        eps_shape = (int(n_samples),) + tuple(batch)
+        seed, offset = next_op_offset()
+        if self.is_reparameterized and (mean.requires_grad or
+                                        std.requires_grad):
+            # reparameterisation trick: draw N(0,1) with the kernel, then
+            # let autograd see  eps * std + mean
+            one = torch.ones(1, device=m.device)
+            zero = torch.zeros(1, device=m.device)
+            eps = torch.empty(eps_shape, dtype=torch.float32, device=m.device)
+            _capi.call('zshmc_normal_sample', eps.data_ptr(), zero.data_ptr(),
+                       one.data_ptr(), n, max(inner, 1), _capi.BCAST_SCALAR,
+                       _capi.BCAST_SCALAR, seed, offset,
+                       _capi.current_stream())
+            return eps * std + mean
+        out = torch.empty(eps_shape, dtype=torch.float32, device=m.device)
+        _capi.call(
+            'zshmc_normal_sample', out.data_ptr(), m.data_ptr(), s.data_ptr(),
+            n, max(inner, 1),
+            _capi.BCAST_SCALAR if m.numel() == 1 else _capi.BCAST_FULL,
+            _capi.BCAST_SCALAR if s.numel() == 1 else _capi.BCAST_FULL,
+            seed, offset, _capi.current_stream())
+        return out
+
+    def _log_prob_grouped(self, given):
+        mean = self.path_param(self._mean)
+        logstd = self.path_param(self._logstd)
+        full = torch.broadcast_shapes(given.shape, mean.shape, logstd.shape)
+        if self._group_ndims > len(full):
+            raise ValueError("group_ndims {} exceeds log_prob rank {}"
+                             .format(self._group_ndims, len(full)))
+        out = _ops.NormalLogProb.apply(given, mean, logstd, self._group_ndims)
+        if self._check_numerics and not bool(torch.isfinite(
+                torch.exp(-2 * logstd)).all()):
+            raise FloatingPointError("precision : Tensor had Inf or NaN")
+        return out
+
+    def _log_prob(self, given):
+        return _ops.NormalLogProb.apply(
+            given, self.path_param(self._mean),
+            self.path_param(self._logstd), 0)
+
+
+class Bernoulli(Distribution):
+    """Univariate Bernoulli (univariate.py:334-406)."""
+
+    def __init__(self, logits, dtype=torch.int32, group_ndims=0, **kwargs):
+        dev = common_device(logits) or default_device()
+        self._logits = as_tensor(logits, dtype=None if isinstance(
+            logits, torch.Tensor) else torch.float32, device=dev)
+        param_dtype = _assert_same_float_dtype(
+            [(self._logits, 'Bernoulli.logits')])
+        _require_f32(param_dtype, 'Bernoulli')
+        if dtype not in _FLOATS + _INTS:
+            raise TypeError("`dtype`({}) must be int or float.".format(dtype))
+        super(Bernoulli, self).__init__(
+            dtype=dtype, param_dtype=param_dtype, is_continuous=False,
+            is_reparameterized=False, group_ndims=group_ndims, **kwargs)
+
+    @property
+    def logits(self):
+        return self._logits
+
+    def _device(self):
+        return self._logits.device
+
+    def _get_value_shape(self):
+        return torch.Size([])
+
+    def _get_batch_shape(self):
+        return self._logits.shape
+
+    def _sample(self, n_samples):
+        """univariate.py:386-396: U[0,1) < sigmoid(logits)."""
+        logits = self._logits.detach().contiguous()
+        _ops.require_device(logits)
+        inner = max(logits.numel(), 1)
+        n = int(n_samples) * inner
+        out = torch.empty((int(n_samples),) + tuple(logits.shape),
+                          dtype=torch.int32, device=logits.device)
+        seed, offset = next_op_offset()
+        _capi.call('zshmc_bernoulli_sample', out.data_ptr(),
+                   logits.data_ptr(), n, inner, seed, offset,
+                   _capi.current_stream())
+        return out if self.dtype == torch.int32 else out.to(self.dtype)
+
+    def _log_prob_grouped(self, given):
+        given = given.to(self.param_dtype)          # :399
+        try:
+            full = torch.broadcast_shapes(given.shape, self._logits.shape)
+        except RuntimeError:
+            raise ValueError(
+                "given and logits cannot broadcast to match. ({} vs. {})"
+                .format(tuple(given.shape), tuple(self._logits.shape)))
+        if self._group_ndims > len(full):
+            raise ValueError("group_ndims {} exceeds log_prob rank {}"
+                             .format(self._group_ndims, len(full)))
+        return _ops.BernoulliLogProb.apply(self._logits, given,
+                                           self._group_ndims)
+
+    def _log_prob(self, given):
+        return _ops.BernoulliLogProb.apply(
+            self._logits, given.to(self.param_dtype), 0)
+
+
+class Categorical(Distribution):
+    """Univariate Categorical (univariate.py:409-551)."""
+
+    def __init__(self, logits, dtype=torch.int32, group_ndims=0, **kwargs):
+        dev = common_device(logits) or default_device()
+        self._logits = as_tensor(logits, dtype=None if isinstance(
+            logits, torch.Tensor) else torch.float32, device=dev)
+        if self._logits.dtype not in (torch.float32, torch.float64):
+            raise TypeError(
+                "Categorical.logits({}) must be float32 or float64.".format(
+                    self._logits.dtype))
+        _require_f32(self._logits.dtype, 'Categorical')
+        if dtype not in (torch.float32, torch.float64, torch.int32,
+                         torch.int64):
+            raise TypeError(
+                "`dtype`({}) not in allowed dtypes.".format(dtype))
+        if self._logits.dim() < 1:
+            raise ValueError(
+                "Categorical.logits should have rank >= 1, got a scalar.")
+        self._n_categories = int(self._logits.shape[-1])
+        super(Categorical, self).__init__(
+            dtype=dtype, param_dtype=self._logits.dtype, is_continuous=False,
+            is_reparameterized=False, group_ndims=group_ndims, **kwargs)
+
+    @property
+    def logits(self):
+        return self._logits
+
+    @property
+    def n_categories(self):
+        return self._n_categories
+
+    def _device(self):
+        return self._logits.device
+
+    def _get_value_shape(self):
+        return torch.Size([])
+
+    def _get_batch_shape(self):
+        return self._logits.shape[:-1]
+
+    def _sample(self, n_samples):
+        """univariate.py:478-494; inverse-CDF on the Philox stream."""
+        logits = self._logits.detach().contiguous()
+        _ops.require_device(logits)
+        batch = tuple(logits.shape[:-1])
+        rows = 1
+        for d in batch:
+            rows *= int(d)
+        out = torch.empty((int(n_samples),) + batch, dtype=torch.int32,
+                          device=logits.device)
+        seed, offset = next_op_offset()
+        _capi.call('zshmc_categorical_sample', out.data_ptr(),
+                   logits.data_ptr(), int(n_samples), rows,
+                   self._n_categories, seed, offset, _capi.current_stream())
+        return out if self.dtype == torch.int32 else out.to(self.dtype)
+
+    def _log_prob(self, given):
+        # :499-505 explicit broadcast of given vs logits[..., :-1]
+        try:
+            batch = torch.broadcast_shapes(given.shape,
+                                           self._logits.shape[:-1])
+        except RuntimeError:
+            raise ValueError(
+                "given and logits cannot broadcast to match. ({} vs. {})"
+                .format(tuple(given.shape), tuple(self._logits.shape)))
+        labels = given.expand(batch).to(torch.int64).contiguous().reshape(-1)
+        logits = self._logits.expand(tuple(batch) + (self._n_categories,)) \
+            .contiguous().reshape(-1, self._n_categories)
+        out = _ops.CategoricalLogProb.apply(logits, labels)
+        return out.reshape(batch)
+
+
+Discrete = Categorical

@@ -1,0 +1,281 @@
+"""BayesianNet / StochasticTensor: named stochastic + deterministic nodes and
+the joint log-probability contract HMC differentiates.  Mirrors reference
+zhusuan/framework/bn.py:26-316 (StochasticTensor), :319-478 (_BayesianNet),
+:556-590/:628-682/:938-965 (factory methods on the HMC path).  Values are
+torch device tensors; log-probs come from the HIP kernels via
+zhusuan_amd.distributions."""
+import torch
+
+from .. import distributions
+from ..distributions.base import as_tensor
+from .meta_bn import Local
+from .utils import Context
+
+__all__ = ['StochasticTensor', 'BayesianNet']
+
+
+class StochasticTensor(object):
+    """bn.py:26-316.  Behaves like its `tensor` in torch expressions."""
+
+    def __init__(self, bn, name, dist, observation=None, **kwargs):
+        self._bn = bn
+        self._name = name
+        self._dist = dist
+        self._dtype = dist.dtype
+        self._n_samples = kwargs.get("n_samples", None)
+        if observation is not None:
+            self._observation = self._check_observation(observation)
+        else:
+            self._observation = None
+
+    def _check_observation(self, observation):
+        """bn.py:94-115 (messages kept)."""
+        type_msg = "Incompatible types of {}('{}') and its observation: {}"
+        try:
+            observation = as_tensor(observation, dtype=self._dtype,
+                                    device=self._dist._device())
+        except (ValueError, TypeError, RuntimeError) as e:
+            raise ValueError(type_msg.format(self.__class__.__name__,
+                                             self._name, e))
+        shape_msg = "Incompatible shapes of {}('{}') and its observation: " \
+                    "{} vs {}."
+        dist_shape = tuple(self._dist.get_batch_shape()) + tuple(
+            self._dist.get_value_shape())
+        try:
+            torch.broadcast_shapes(dist_shape, tuple(observation.shape))
+        except RuntimeError:
+            raise ValueError(shape_msg.format(
+                self.__class__.__name__, self._name, dist_shape,
+                tuple(observation.shape)))
+        return observation
+
+    @property
+    def bn(self):
+        return self._bn
+
+    @property
+    def name(self):
+        return self._name
+
+    @property
+    def dtype(self):
+        return self._dtype
+
+    @property
+    def dist(self):
+        return self._dist
+
+    def is_observed(self):
+        return self._observation is not None
+
+    @property
+    def tensor(self):
+        """Observation if observed, else (cached) samples (bn.py:164-175)."""
+        if self._observation is not None:
+            return self._observation
+        elif not hasattr(self, "_samples"):
+            self._samples = self._dist.sample(n_samples=self._n_samples)
+        return self._samples
+
+    @property
+    def shape(self):
+        return self.tensor.shape
+
+    def get_shape(self):
+        return self.shape
+
+    @property
+    def cond_log_p(self):
+        """log p(value | parents), cached (bn.py:195-204)."""
+        if not hasattr(self, "_cond_log_p"):
+            self._cond_log_p = self._dist.log_prob(self.tensor)
+        return self._cond_log_p
+
+    # -- tensor-like behaviour (TensorArithmeticMixin, utils.py:18-174) -----
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        def unwrap(a):
+            if isinstance(a, StochasticTensor):
+                return a.tensor
+            if isinstance(a, (list, tuple)):
+                return type(a)(unwrap(x) for x in a)
+            return a
+        kwargs = kwargs or {}
+        return func(*unwrap(args), **{k: unwrap(v) for k, v in kwargs.items()})
+
+    def __add__(self, o): return self.tensor + _val(o)
+    def __radd__(self, o): return _val(o) + self.tensor
+    def __sub__(self, o): return self.tensor - _val(o)
+    def __rsub__(self, o): return _val(o) - self.tensor
+    def __mul__(self, o): return self.tensor * _val(o)
+    def __rmul__(self, o): return _val(o) * self.tensor
+    def __truediv__(self, o): return self.tensor / _val(o)
+    def __rtruediv__(self, o): return _val(o) / self.tensor
+    def __pow__(self, o): return self.tensor ** _val(o)
+    def __rpow__(self, o): return _val(o) ** self.tensor
+    def __matmul__(self, o): return self.tensor @ _val(o)
+    def __rmatmul__(self, o): return _val(o) @ self.tensor
+    def __neg__(self): return -self.tensor
+    def __abs__(self): return abs(self.tensor)
+    def __getitem__(self, item): return self.tensor[item]
+
+
+def _val(o):
+    return o.tensor if isinstance(o, StochasticTensor) else o
+
+
+class _BayesianNet(object):
+    """bn.py:319-552."""
+
+    def __init__(self):
+        self._nodes = {}
+        try:
+            self._local_cxt = Local.get_context()
+        except RuntimeError:
+            self._local_cxt = None
+        if self._local_cxt:
+            self._meta_bn = self._local_cxt.meta_bn
+        else:
+            self._meta_bn = None
+
+    @property
+    def nodes(self):
+        return self._nodes
+
+    def _get_observation(self, name):
+        if self._local_cxt:
+            return self._local_cxt.observations.get(name, None)
+        return None
+
+    def stochastic(self, name, dist, **kwargs):
+        """Add a stochastic node (bn.py:348-371)."""
+        if name in self._nodes:
+            raise ValueError(
+                "There exists a node with name '{}' in the {}. Names should "
+                "be unique.".format(name, BayesianNet.__name__))
+        if hasattr(self, "_log_joint_cache"):
+            del self._log_joint_cache
+        node = StochasticTensor(
+            self, name, dist, observation=self._get_observation(name),
+            **kwargs)
+        self._nodes[name] = node
+        return node
+
+    def deterministic(self, name, input_tensor):
+        """Add a named deterministic node (bn.py:373-385)."""
+        input_tensor = as_tensor(input_tensor)
+        self._nodes[name] = input_tensor
+        return input_tensor
+
+    def _check_name_exist(self, name, only_stochastic=False):
+        if not isinstance(name, str):
+            raise TypeError(
+                "Expected string in `name_or_names`, got {} of type {}."
+                .format(repr(name), type(name)))
+        if name not in self._nodes:
+            raise ValueError("There isn't a node named '{}' in the {}."
+                             .format(name, BayesianNet.__name__))
+        elif only_stochastic and not isinstance(
+                self._nodes[name], StochasticTensor):
+            raise ValueError("Node '{}' is deterministic (input or output)."
+                             .format(name))
+        return name
+
+    def _check_names_exist(self, name_or_names, only_stochastic=False):
+        if isinstance(name_or_names, str):
+            names = (name_or_names,)
+        else:
+            name_or_names = tuple(name_or_names)
+            names = name_or_names
+        for name in names:
+            self._check_name_exist(name, only_stochastic=only_stochastic)
+        return name_or_names
+
+    def get(self, name_or_names):
+        """bn.py:420-435."""
+        name_or_names = self._check_names_exist(name_or_names)
+        if isinstance(name_or_names, tuple):
+            return [self._nodes[name] for name in name_or_names]
+        return self._nodes[name_or_names]
+
+    def cond_log_prob(self, name_or_names):
+        """bn.py:437-452."""
+        name_or_names = self._check_names_exist(name_or_names,
+                                                only_stochastic=True)
+        if isinstance(name_or_names, tuple):
+            return [self._nodes[name].cond_log_p for name in name_or_names]
+        return self._nodes[name_or_names].cond_log_p
+
+    def _log_joint(self):
+        """bn.py:454-465."""
+        if (self._meta_bn is None) or (self._meta_bn.log_joint is None):
+            ret = sum(node.cond_log_p for node in self._nodes.values()
+                      if isinstance(node, StochasticTensor))
+        elif callable(self._meta_bn.log_joint):
+            ret = self._meta_bn.log_joint(self)
+        else:
+            raise TypeError(
+                "{}.log_joint is set to a non-callable instance: {}"
+                .format(self._meta_bn.__class__.__name__,
+                        repr(self._meta_bn.log_joint)))
+        return ret
+
+    def log_joint(self):
+        """Sum of all stochastic nodes' cond_log_p, or the user's
+        meta_bn.log_joint(bn); cached (bn.py:467-478)."""
+        if not hasattr(self, "_log_joint_cache"):
+            self._log_joint_cache = self._log_joint()
+        return self._log_joint_cache
+
+    def __getitem__(self, name):
+        name = self._check_name_exist(name)
+        return self._nodes[name]
+
+    # -- factory methods on the HMC path ------------------------------------
+    def normal(self, name, mean=0., _sentinel=None, std=None, logstd=None,
+               group_ndims=0, n_samples=None, is_reparameterized=True,
+               check_numerics=False, **kwargs):
+        """bn.py:556-590."""
+        dist = distributions.Normal(
+            mean, _sentinel=_sentinel, std=std, logstd=logstd,
+            group_ndims=group_ndims, is_reparameterized=is_reparameterized,
+            check_numerics=check_numerics, **kwargs)
+        return self.stochastic(name, dist, n_samples=n_samples, **kwargs)
+
+    def bernoulli(self, name, logits, n_samples=None, group_ndims=0,
+                  dtype=torch.int32, **kwargs):
+        """bn.py:628-654."""
+        dist = distributions.Bernoulli(
+            logits, group_ndims=group_ndims, dtype=dtype, **kwargs)
+        return self.stochastic(name, dist, n_samples=n_samples, **kwargs)
+
+    def categorical(self, name, logits, n_samples=None, group_ndims=0,
+                    dtype=torch.int32, **kwargs):
+        """bn.py:656-682."""
+        dist = distributions.Categorical(
+            logits, group_ndims=group_ndims, dtype=dtype, **kwargs)
+        return self.stochastic(name, dist, n_samples=n_samples, **kwargs)
+
+    discrete = categorical
+
+    def unnormalized_multinomial(self, name, logits, normalize_logits=True,
+                                 group_ndims=0, dtype=torch.int32, **kwargs):
+        """bn.py:938-965."""
+        dist = distributions.UnnormalizedMultinomial(
+            logits, normalize_logits=normalize_logits,
+            group_ndims=group_ndims, dtype=dtype, **kwargs)
+        return self.stochastic(name, dist, **kwargs)
+
+    bag_of_categoricals = unnormalized_multinomial
+
+
+class BayesianNet(_BayesianNet, Context):
+    """bn.py:481-520 (the deprecated context-manager / `observed=` /
+    `query()` API of :1191-1249 is out of scope)."""
+
+    def __init__(self, observed=None):
+        if observed is not None:
+            raise NotImplementedError(
+                "BayesianNet(observed=...) is the deprecated 0.3 API; use "
+                "@meta_bayesian_net and .observe(**observed).")
+        super(BayesianNet, self).__init__()

@@ -1,0 +1,643 @@
+"""HMC front-end: the `zhusuan.HMC(...).sample(meta_bn, observed, latent)`
+surface (reference zhusuan/hmc.py:204-522) over the HIP kernels of
+libzshmc.so.
+
+What differs from the reference, and why (no TensorFlow):
+  * latents are float32 torch tensors living on an MI355X instead of
+    tf.Variables; they are updated in place by `sample_op`;
+  * `sample_op` is a host object: `sample_op.run(feed_dict)` (or calling it)
+    performs one transition; `HMCInfo` fields are device tensors valid until
+    the next run (the reference: "must be fetched together with the sampling
+    operation", hmc.py:168-172);
+  * `adapt_step_size` / `adapt_mass` accept None, a Python bool, or a
+    `placeholder()` whose value comes from `feed_dict` per run (the
+    tf.placeholder idiom of examples/toy_examples/gaussian.py:40-41,57-58);
+  * random numbers come from the documented Philox4x32-10 counter mapping
+    (csrc/philox.h), not TensorFlow's graph-seeded stream.
+
+Two execution plans, chosen in `sample()`:
+  fused   -- the model is one Normal node with chain-independent parameters
+             (gaussian.py:15-20, BASELINE config 2): ONE kernel per
+             transition (csrc/hmc_fused_normal.hip).
+  generic -- any other log-joint: torch autograd over the HIP log_prob ops
+             supplies grad log p; momentum / kick / drift / MH run in the
+             kernels of csrc/hmc_generic.hip.
+Both use the same RNG counters and the same on-device adaptation state.
+"""
+import math
+
+import torch
+
+from . import _capi
+from .distributions import Normal
+from .framework.bn import StochasticTensor
+from .framework.meta_bn import MetaBayesianNet
+from .utils import merge_dicts, next_sampler_seed
+
+__all__ = ['HMCInfo', 'HMC', 'placeholder', 'InvalidArgumentError']
+
+OLD_LOG_PROB_MSG = ('HMC: old_log_prob has numeric errors! Try better '
+                    'initialization.')
+
+
+class InvalidArgumentError(ArithmeticError):
+    """Raised where the reference's tf.check_numerics raises
+    tf.errors.InvalidArgumentError (hmc.py:51-53)."""
+
+
+class placeholder(object):
+    """Per-run feedable flag: `flag = placeholder(bool)`;
+    `sample_op.run(feed_dict={flag: i < burnin})`."""
+
+    def __init__(self, dtype=bool, shape=None, name=None, default=None):
+        self.dtype = dtype
+        self.name = name
+        self.default = default
+
+    def __repr__(self):
+        return 'placeholder(%s)' % (self.name or hex(id(self)))
+
+
+def _flag_value(flag, feed_dict, what):
+    if isinstance(flag, placeholder):
+        if feed_dict is not None and flag in feed_dict:
+            return bool(feed_dict[flag])
+        if flag.default is None:
+            raise ValueError(
+                "You must feed a value for placeholder %r (%s)" % (flag, what))
+        return bool(flag.default)
+    if isinstance(flag, torch.Tensor):
+        return bool(flag.item())
+    return bool(flag)
+
+
+class HMCInfo(object):
+    """Statistics of one HMC iteration (hmc.py:162-201).  All fields are
+    device tensors refreshed in place by every run of the sampling op."""
+
+    def __init__(self, samples, acceptance_rate, updated_step_size,
+                 init_momentum, orig_hamiltonian, hamiltonian, orig_log_prob,
+                 log_prob):
+        self.samples = samples
+        self.acceptance_rate = acceptance_rate
+        self.updated_step_size = updated_step_size
+        self.init_momentum = init_momentum
+        self.orig_hamiltonian = orig_hamiltonian
+        self.hamiltonian = hamiltonian
+        self.orig_log_prob = orig_log_prob
+        self.log_prob = log_prob
+
+
+class _LazyMomentum(dict):
+    """HMCInfo.init_momentum: p0 is a pure function of (seed, iteration,
+    chain, latent, mass), so it is regenerated on demand from the Philox
+    counters instead of being written to HBM every transition (4 B/element
+    saved unless somebody asks)."""
+
+    def __init__(self, plan):
+        super(_LazyMomentum, self).__init__()
+        self._plan = plan
+
+    def __getitem__(self, name):
+        return self._plan.regenerate_momentum(name)
+
+    def keys(self):
+        return list(self._plan.names)
+
+    def __iter__(self):
+        return iter(self._plan.names)
+
+    def __len__(self):
+        return len(self._plan.names)
+
+    def __contains__(self, name):
+        return name in self._plan.names
+
+    def items(self):
+        return [(k, self[k]) for k in self._plan.names]
+
+    def values(self):
+        return [self[k] for k in self._plan.names]
+
+
+class _SampleOp(object):
+    """What `HMC.sample` returns in place of a tf.Operation."""
+
+    def __init__(self, hmc):
+        self._hmc = hmc
+
+    def run(self, feed_dict=None, sync=True):
+        """Execute one HMC transition.  sync=True mirrors sess.run (returns
+        after the device finished; raises InvalidArgumentError if the current
+        log-prob was non-finite).  sync=False only enqueues; call
+        `hmc.check_numerics()` later."""
+        self._hmc._run(feed_dict, sync)
+
+    __call__ = run
+
+
+class HMC(object):
+    """Hamiltonian Monte Carlo with dual-averaging step-size adaptation and
+    diagonal mass adaptation (hmc.py:204-281; same arguments and defaults).
+
+    Extra keyword-only arguments: `seed` (Philox key; default derives from
+    zhusuan_amd.set_random_seed) and `sharding`
+    (zhusuan_amd.distributed.ChainSharding) for chains sharded over GPUs.
+    """
+
+    def __init__(self, step_size=1., n_leapfrogs=10, adapt_step_size=None,
+                 target_acceptance_rate=0.8, gamma=0.05, t0=100, kappa=0.75,
+                 adapt_mass=None, mass_collect_iters=10, mass_decay=0.99,
+                 *, seed=None, sharding=None):
+        self._init_step_size_value = float(step_size)
+        self.n_leapfrogs = int(n_leapfrogs)
+        self.target_acceptance_rate = float(target_acceptance_rate)
+        self.t = 0                                     # hmc.py:264
+        self.adapt_step_size = adapt_step_size
+        self.gamma, self.t0, self.kappa = float(gamma), float(t0), float(kappa)
+        if adapt_mass is not None:
+            if adapt_step_size is None:                # hmc.py:270-272
+                raise ValueError(
+                    'If adapt mass is set, we should also adapt step size')
+            self.adapt_mass = adapt_mass
+        else:
+            mass_collect_iters = 0                     # hmc.py:276
+            self.adapt_mass = None
+        self.mass_collect_iters = int(mass_collect_iters)
+        self.mass_decay = float(mass_decay)
+        self.seed = next_sampler_seed() if seed is None else \
+            int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.sharding = sharding
+        self._plan = None
+        self._pending_check = False
+
+    # -- sample(): builds the execution plan (hmc.py:382-522) -------------
+    def sample(self, meta_bn, observed, latent):
+        """Return `(sample_op, hmc_info)`; see hmc.py:382-411 for the
+        argument contract (log-joint callable or MetaBayesianNet; `observed`
+        name->tensor; `latent` name->device tensor of shape
+        chain axes + data axes, updated in place)."""
+        if self._plan is not None:
+            raise RuntimeError(
+                "HMC.sample may be invoked once per HMC instance "
+                "(reference hmc.py:218-222); declare one HMC per call.")
+        if callable(meta_bn) and not isinstance(meta_bn, MetaBayesianNet):
+            log_joint = meta_bn
+        else:
+            log_joint = lambda obs: meta_bn.observe(**obs).log_joint()
+        latent_k, latent_v = [list(i) for i in zip(*latent.items())]
+        for k, v in zip(latent_k, latent_v):
+            if not isinstance(v, torch.Tensor):
+                raise TypeError(
+                    "latent['{}'] is not a torch Tensor (the device buffer "
+                    "that replaces a tensorflow Variable).".format(k))
+            if v.dtype != torch.float32:
+                raise TypeError("latent['{}'] must be float32 (HMC is "
+                                "float32-only, hmc.py:22), got {}."
+                                .format(k, v.dtype))
+            if not v.is_cuda:
+                raise RuntimeError(
+                    "latent['{}'] lives on {}; the sampler runs on an MI355X "
+                    "only (no CPU fallback).".format(k, v.device))
+            if not v.is_contiguous():
+                raise ValueError("latent['{}'] must be contiguous."
+                                 .format(k))
+            if v.requires_grad:
+                raise ValueError("latent['{}'] must not require grad."
+                                 .format(k))
+        self._log_joint = log_joint
+        self._observed = dict(observed)
+        # chain shape = shape of the log-joint (hmc.py:434-442)
+        lp = self._eval_log_joint(latent_k, latent_v)
+        if not isinstance(lp, torch.Tensor) or lp.dim() == 0:
+            raise ValueError(
+                "HMC requires that the static shape of the value returned "
+                "by log joint function should be at least partially defined. "
+                "(shape: {})".format(tuple(getattr(lp, 'shape', ()))))
+        chain_shape = tuple(lp.shape)
+        n_chain_dims = len(chain_shape)
+        for k, v in zip(latent_k, latent_v):
+            if tuple(v.shape[:n_chain_dims]) != chain_shape:
+                raise ValueError(
+                    "latent['{}'] has shape {} whose leading axes do not "
+                    "match the chain shape {} of the log joint."
+                    .format(k, tuple(v.shape), chain_shape))
+        device = latent_v[0].device
+        plan = _try_fused_plan(self, meta_bn, latent_k, latent_v, chain_shape,
+                               device)
+        if plan is None:
+            plan = _GenericPlan(self, latent_k, latent_v, chain_shape, device)
+        self._plan = plan
+        st = plan.state
+        st[_capi.ST_STEP_SIZE] = self._init_step_size_value
+        info = HMCInfo(
+            samples=dict(zip(latent_k, latent_v)),
+            acceptance_rate=plan.acceptance_rate.view(chain_shape),
+            updated_step_size=st[_capi.ST_STEP_SIZE],
+            init_momentum=_LazyMomentum(plan),
+            orig_hamiltonian=plan.orig_hamiltonian.view(chain_shape),
+            hamiltonian=plan.hamiltonian.view(chain_shape),
+            orig_log_prob=plan.orig_log_prob.view(chain_shape),
+            log_prob=plan.log_prob.view(chain_shape))
+        self.hmc_info = info
+        return _SampleOp(self), info
+
+    def _eval_log_joint(self, names, values):
+        joint_obs = merge_dicts(dict(zip(names, values)), self._observed)
+        return self._log_joint(joint_obs)                # hmc.py:426-428
+
+    @property
+    def plan_kind(self):
+        return None if self._plan is None else self._plan.kind
+
+    # -- one execution of sample_op ----------------------------------------
+    def _run(self, feed_dict, sync):
+        plan = self._plan
+        self.t += 1                                       # hmc.py:418
+        t = self.t
+        adapt_ss = None if self.adapt_step_size is None else _flag_value(
+            self.adapt_step_size, feed_dict, 'adapt_step_size')
+        adapt_m = None if self.adapt_mass is None else _flag_value(
+            self.adapt_mass, feed_dict, 'adapt_mass')
+        stream = _capi.current_stream()
+        sh = self.sharding
+
+        # mass (hmc.py:452-456, :284-305)
+        use_mass = False
+        if self.adapt_mass is not None:
+            use_ones = t < self.mass_collect_iters        # hmc.py:299-302
+            plan.update_mass(adapt_m, use_ones, stream, sh)
+            use_mass = not use_ones
+        plan.use_mass = use_mass
+
+        # step size for this iteration (hmc.py:463-472)
+        init = False
+        eps_host = None
+        if self.adapt_step_size is not None:
+            init = (t == 1) or (t == self.mass_collect_iters)
+            if init:
+                eps_host = self._search_step_size(plan, stream, sh)
+        self.last_init = init
+
+        plan.transition(t, eps_host, stream)              # leapfrog + MH
+
+        if self.adapt_step_size is not None:              # hmc.py:501-505
+            if sh is not None:
+                sh.all_reduce_sum(plan.acc_sum)
+            _capi.call('zshmc_stepsize_update', plan.state.data_ptr(),
+                       plan.acc_sum.data_ptr(), plan.n_chains_global,
+                       int(adapt_ss), int(init),
+                       self.target_acceptance_rate, self.gamma, self.t0,
+                       self.kappa, 10.0 * self._init_step_size_value, stream)
+            if eps_host is not None:
+                _capi.call('zshmc_state_set', plan.state.data_ptr(),
+                           _capi.ST_USED_STEP_SIZE, float(eps_host), stream)
+        self._pending_check = True
+        if sync:
+            self.check_numerics()
+
+    def _search_step_size(self, plan, stream, sh):
+        """HMC._init_step_size (hmc.py:308-345): host-driven loop of dry-run
+        single-leapfrog launches from the same (q, p0); runs only at t == 1
+        and t == mass_collect_iters, so the host sync is off the hot loop."""
+        factor = 1.5
+        f32 = lambda x: float(torch.tensor(x, dtype=torch.float32))
+        step_size = float(plan.state[_capi.ST_STEP_SIZE].item())
+        delta = f32(self.target_acceptance_rate)
+        last = 1.0
+        cond = True
+        trips = 0
+        plan.begin_search(self.t, stream)
+        while cond:
+            plan.acc_sum.zero_()
+            plan.search_trip(self.t, step_size, stream)
+            if sh is not None:
+                sh.all_reduce_sum(plan.acc_sum)
+            acc = f32(plan.acc_sum.item() / plan.n_chains_global)
+            self.check_numerics(sync=False)
+            if acc < delta:
+                new_step = f32(step_size * f32(1.0 / factor))
+            else:
+                new_step = f32(step_size * factor)
+            cond = not ((last < delta) ^ (acc < delta))
+            step_size, last = new_step, acc
+            trips += 1
+            if trips > 200:
+                raise RuntimeError("step-size search did not terminate")
+        plan.acc_sum.zero_()
+        self.n_init_trips = trips
+        return step_size
+
+    def check_numerics(self, sync=True):
+        """Raise InvalidArgumentError if any transition since the last check
+        started from a non-finite log-prob (tf.check_numerics, hmc.py:51-53)."""
+        if self._plan is None:
+            return
+        if sync:
+            torch.cuda.current_stream().synchronize()
+        flags = int(self._plan.flags.item())
+        self._pending_check = False
+        if flags & _capi.FLAG_OLD_LOGPROB_NONFINITE:
+            self._plan.flags.zero_()
+            raise InvalidArgumentError(OLD_LOG_PROB_MSG)
+
+    # -- checkpoint / resume of the sampler state -----
+    def get_state(self):
+        """Sampler state as host values: t, step_size, tuner triple, EWMV
+        t/mean/var (the tf.Variables of hmc.py:82-87,118-123,258-264)."""
+        plan = self._plan
+        st = plan.state.cpu()
+        out = {'t': self.t, 'state': st.clone(), 'seed': self.seed}
+        if self.adapt_mass is not None:
+            out['ewmv_mean'] = [m.cpu().clone() for m in plan.ewmv_mean]
+            out['ewmv_var'] = [v.cpu().clone() for v in plan.ewmv_var]
+            out['mass'] = [m.cpu().clone() for m in plan.mass]
+        return out
+
+    def set_state(self, state):
+        plan = self._plan
+        self.t = int(state['t'])
+        self.seed = int(state['seed'])
+        plan.state.copy_(state['state'])
+        if self.adapt_mass is not None:
+            for dst, src in zip(plan.ewmv_mean, state['ewmv_mean']):
+                dst.copy_(src)
+            for dst, src in zip(plan.ewmv_var, state['ewmv_var']):
+                dst.copy_(src)
+            for dst, src in zip(plan.mass, state['mass']):
+                dst.copy_(src)
+
+
+# ----------------------------------------------------------------------------
+# execution plans
+# ----------------------------------------------------------------------------
+def _prod(shape):
+    n = 1
+    for s in shape:
+        n *= int(s)
+    return n
+
+
+class _PlanBase(object):
+    def __init__(self, hmc, names, values, chain_shape, device):
+        self.hmc = hmc
+        self.names = list(names)
+        self.q = list(values)
+        self.chain_shape = chain_shape
+        self.n_chains = _prod(chain_shape)
+        self.n_data = [_prod(v.shape[len(chain_shape):]) for v in values]
+        self.device = device
+        sh = hmc.sharding
+        if sh is not None:
+            self.chain_offset, self.n_chains_global = sh.layout(self.n_chains,
+                                                                device)
+        else:
+            self.chain_offset, self.n_chains_global = 0, self.n_chains
+        f32 = dict(dtype=torch.float32, device=device)
+        C = self.n_chains
+        self.state = torch.zeros(_capi.STATE_WORDS, **f32)
+        self.acc_sum = torch.zeros(1, dtype=torch.float64, device=device)
+        self.flags = torch.zeros(1, dtype=torch.int32, device=device)
+        self.acceptance_rate = torch.zeros(C, **f32)
+        self.orig_hamiltonian = torch.zeros(C, **f32)
+        self.hamiltonian = torch.zeros(C, **f32)
+        self.orig_log_prob = torch.zeros(C, **f32)
+        self.log_prob = torch.zeros(C, **f32)
+        self.use_mass = False
+        if hmc.adapt_mass is not None:
+            self.mass = [torch.ones(d, **f32) for d in self.n_data]
+            self.ewmv_mean = [torch.zeros(d, **f32) for d in self.n_data]
+            self.ewmv_var = [torch.zeros(d, **f32) for d in self.n_data]
+            self.colsum = [torch.zeros(2 * d, dtype=torch.float64,
+                                       device=device) for d in self.n_data]
+        self.last_t = 0
+
+    def update_mass(self, update, use_ones, stream, sharding):
+        """HMC._adapt_mass (hmc.py:284-305) for every latent."""
+        hmc = self.hmc
+        for k, q in enumerate(self.q):
+            if update:
+                _capi.call('zshmc_mass_colstats', q.data_ptr(),
+                           self.ewmv_mean[k].data_ptr(), self.n_chains,
+                           self.n_data[k], self.colsum[k].data_ptr(), stream)
+                if sharding is not None:
+                    sharding.all_reduce_sum(self.colsum[k])
+            # EWMV.t is shared by all latents (hmc.py:118,131): bump once,
+            # after the last latent
+            last = k == len(self.q) - 1
+            _capi.call('zshmc_mass_update', self.state.data_ptr(),
+                       self.ewmv_mean[k].data_ptr(),
+                       self.ewmv_var[k].data_ptr(),
+                       self.colsum[k].data_ptr(), self.n_chains_global,
+                       self.n_data[k], hmc.mass_decay,
+                       (1 if last else 2) if update else 0,
+                       int(use_ones), self.mass[k].data_ptr(), stream)
+
+    def mass_ptr(self, k):
+        return self.mass[k].data_ptr() if self.use_mass else None
+
+    def regenerate_momentum(self, name):
+        k = self.names.index(name)
+        p = torch.empty_like(self.q[k])
+        _capi.call('zshmc_momentum', p.data_ptr(), self.mass_ptr(k),
+                   self.n_chains, self.n_data[k], self.chain_offset,
+                   self.hmc.seed, self.last_t & 0xFFFFFFFF, k, None,
+                   _capi.current_stream())
+        return p
+
+
+class _FusedDiagNormalPlan(_PlanBase):
+    """One kernel per transition (csrc/hmc_fused_normal.hip)."""
+    kind = 'fused_diag_normal'
+
+    def __init__(self, hmc, names, values, chain_shape, device, mean, logstd):
+        super(_FusedDiagNormalPlan, self).__init__(hmc, names, values,
+                                                   chain_shape, device)
+        self.mean = mean
+        self.logstd = logstd
+
+    def _launch(self, t, eps_host, commit, n_leapfrogs, stream):
+        info = commit
+        _capi.call(
+            'zshmc_hmc_diag_normal_step', self.q[0].data_ptr(),
+            self.mean.data_ptr(), self.logstd.data_ptr(), self.mass_ptr(0),
+            None if eps_host is not None else self.state.data_ptr(),
+            0.0 if eps_host is None else float(eps_host),
+            self.n_chains, self.n_data[0], self.chain_offset, n_leapfrogs,
+            self.hmc.seed, t & 0xFFFFFFFF, int(commit),
+            self.acceptance_rate.data_ptr() if info else None,
+            self.orig_hamiltonian.data_ptr() if info else None,
+            self.hamiltonian.data_ptr() if info else None,
+            self.orig_log_prob.data_ptr() if info else None,
+            self.log_prob.data_ptr() if info else None,
+            self.acc_sum.data_ptr(), self.flags.data_ptr(), stream)
+
+    def begin_search(self, t, stream):
+        pass
+
+    def search_trip(self, t, step_size, stream):
+        # one full leapfrog step (hmc.py:316-321) == the kernel with L = 1
+        self._launch(t, step_size, 0, 1, stream)
+
+    def transition(self, t, eps_host, stream):
+        self.last_t = t
+        self._launch(t, eps_host, 1, self.hmc.n_leapfrogs, stream)
+
+
+class _GenericPlan(_PlanBase):
+    """Arbitrary log-joint: autograd supplies the gradient (tf.gradients,
+    hmc.py:430-432); everything else runs in csrc/hmc_generic.hip."""
+    kind = 'generic'
+
+    def __init__(self, hmc, names, values, chain_shape, device):
+        super(_GenericPlan, self).__init__(hmc, names, values, chain_shape,
+                                           device)
+        f32 = dict(dtype=torch.float32, device=device)
+        C = self.n_chains
+        self.p = [torch.empty_like(q) for q in self.q]
+        self.q_new = [torch.empty_like(q) for q in self.q]
+        self.kin_old = torch.zeros(C, **f32)
+        self.kin_new = torch.zeros(C, **f32)
+        self.accept = torch.zeros(C, dtype=torch.uint8, device=device)
+        self._search_cache = None
+
+    def value_and_grad(self, qs):
+        """log p(q) per chain and d/dq (hmc.py:426-432)."""
+        leaves = [q.detach().requires_grad_(True) for q in qs]
+        lp = self.hmc._eval_log_joint(self.names, leaves)
+        if tuple(lp.shape) != tuple(self.chain_shape):
+            raise ValueError(
+                "log joint returned shape {} but the chain shape is {}"
+                .format(tuple(lp.shape), tuple(self.chain_shape)))
+        grads = torch.autograd.grad(lp.sum(), leaves, allow_unused=True)
+        grads = [torch.zeros_like(q) if g is None else g.contiguous()
+                 for g, q in zip(grads, leaves)]
+        return lp.detach().reshape(-1).to(torch.float32).contiguous(), grads
+
+    def _momentum(self, t, stream):
+        self.kin_old.zero_()
+        for k, p in enumerate(self.p):
+            _capi.call('zshmc_momentum', p.data_ptr(), self.mass_ptr(k),
+                       self.n_chains, self.n_data[k], self.chain_offset,
+                       self.hmc.seed, t & 0xFFFFFFFF, k,
+                       self.kin_old.data_ptr(), stream)
+
+    def _kick_drift(self, qs, ps, grads, eps_host, kick, drift, kinetic,
+                    stream):
+        for k in range(len(qs)):
+            _capi.call('zshmc_kick_drift', qs[k].data_ptr(), ps[k].data_ptr(),
+                       grads[k].data_ptr(), self.mass_ptr(k),
+                       None if eps_host is not None else self.state.data_ptr(),
+                       0.0 if eps_host is None else float(eps_host),
+                       float(kick), float(drift), self.n_chains,
+                       self.n_data[k],
+                       None if kinetic is None else kinetic.data_ptr(), stream)
+
+    def begin_search(self, t, stream):
+        self._momentum(t, stream)
+        lp0, g0 = self.value_and_grad(self.q)
+        self._search_cache = (lp0, g0)
+
+    def search_trip(self, t, step_size, stream):
+        lp0, g0 = self._search_cache
+        q1 = [q.clone() for q in self.q]
+        p1 = [p.clone() for p in self.p]
+        self._kick_drift(q1, p1, g0, step_size, 0.5, 1.0, None, stream)
+        lp1, g1 = self.value_and_grad(q1)
+        self.kin_new.zero_()
+        self._kick_drift(q1, p1, g1, step_size, 0.5, 0.0, self.kin_new, stream)
+        _capi.call('zshmc_mh_accept', lp0.data_ptr(), lp1.data_ptr(),
+                   self.kin_old.data_ptr(), self.kin_new.data_ptr(),
+                   self.n_chains, self.chain_offset, self.hmc.seed,
+                   t & 0xFFFFFFFF, None, None, None, None, None,
+                   self.acc_sum.data_ptr(), self.flags.data_ptr(), stream)
+
+    def transition(self, t, eps_host, stream):
+        self.last_t = t
+        L = self.hmc.n_leapfrogs
+        if self._search_cache is not None:
+            lp_old, g = self._search_cache     # same q, same p0 (Appendix B 11)
+            self._search_cache = None
+        else:
+            self._momentum(t, stream)
+            lp_old, g = self.value_and_grad(self.q)
+        for qn, q in zip(self.q_new, self.q):
+            qn.copy_(q)
+        p = self.p
+        lp_new = lp_old
+        self.kin_new.zero_()
+        # i = 0: zero-length drift, half kick (hmc.py:352-364); the drift of
+        # trip i+1 is fused behind the kick of trip i
+        self._kick_drift(self.q_new, p, g, eps_host, 0.5,
+                         1.0 if L >= 1 else 0.0,
+                         self.kin_new if L == 0 else None, stream)
+        for i in range(1, L + 1):
+            lp_new, g = self.value_and_grad(self.q_new)
+            last = i == L
+            self._kick_drift(self.q_new, p, g, eps_host,
+                             0.5 if last else 1.0, 0.0 if last else 1.0,
+                             self.kin_new if last else None, stream)
+        _capi.call('zshmc_mh_accept', lp_old.data_ptr(), lp_new.data_ptr(),
+                   self.kin_old.data_ptr(), self.kin_new.data_ptr(),
+                   self.n_chains, self.chain_offset, self.hmc.seed,
+                   t & 0xFFFFFFFF, self.acceptance_rate.data_ptr(),
+                   self.orig_hamiltonian.data_ptr(),
+                   self.hamiltonian.data_ptr(), self.log_prob.data_ptr(),
+                   self.accept.data_ptr(), self.acc_sum.data_ptr(),
+                   self.flags.data_ptr(), stream)
+        self.orig_log_prob.copy_(lp_old)
+        for k in range(len(self.q)):
+            _capi.call('zshmc_select_rows', self.q[k].data_ptr(),
+                       self.q_new[k].data_ptr(), self.accept.data_ptr(),
+                       self.n_chains, self.n_data[k], stream)
+
+
+def _to_data_shape(param, data_shape):
+    """Flatten a parameter that is constant along the chain axes to a
+    contiguous float32 [prod(data_shape)] vector, or None if it is not."""
+    t = param.detach().to(torch.float32)
+    extra = t.dim() - len(data_shape)
+    if extra > 0:
+        if any(int(s) != 1 for s in t.shape[:extra]):
+            return None
+        t = t.reshape(t.shape[extra:])
+    try:
+        t = t.expand(data_shape)
+    except RuntimeError:
+        return None
+    return t.contiguous().reshape(-1)
+
+
+def _try_fused_plan(hmc, meta_bn, names, values, chain_shape, device):
+    """Recognise the diagonal-Normal family: a MetaBayesianNet with the
+    default log-joint whose only stochastic node is the (single) latent, a
+    Normal with group_ndims == #data axes and chain-independent parameters."""
+    if not isinstance(meta_bn, MetaBayesianNet) or meta_bn.log_joint is not None:
+        return None
+    if len(names) != 1:
+        return None
+    name, q = names[0], values[0]
+    n_chain_dims = len(chain_shape)
+    data_shape = tuple(q.shape[n_chain_dims:])
+    n_data = _prod(data_shape)
+    if n_data > int(_capi.load().zshmc_fused_max_n_data()):
+        return None
+    probe = q.detach().requires_grad_(True)
+    bn = meta_bn.observe(**merge_dicts({name: probe}, hmc._observed))
+    stoch = [n for n in bn.nodes.values() if isinstance(n, StochasticTensor)]
+    if len(stoch) != 1 or stoch[0].name != name:
+        return None
+    dist = stoch[0].dist
+    if type(dist) is not Normal or dist.group_ndims != len(data_shape):
+        return None
+    if dist.use_path_derivative:
+        return None
+    mean, logstd = dist.mean, dist.logstd
+    if mean.requires_grad or logstd.requires_grad:
+        return None                      # parameters depend on the latent
+    mean_d = _to_data_shape(mean, data_shape)
+    logstd_d = _to_data_shape(logstd, data_shape)
+    if mean_d is None or logstd_d is None or n_data == 0:
+        return None                      # parameters vary along chain axes
+    return _FusedDiagNormalPlan(hmc, names, values, chain_shape, device,
+                                mean_d, logstd_d)
