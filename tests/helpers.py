@@ -21,7 +21,8 @@ def ref_sampler(mean, logstd, q0, **hmc_kwargs):
     return ref, x
 
 
-def gpu_sampler(zs, torch, mean, logstd, q0, generic=False, **hmc_kwargs):
+def gpu_sampler(zs, torch, mean, logstd, q0, generic=False, group_ndims=None,
+                **hmc_kwargs):
     dev = torch.device('cuda', 0)
     C = q0.shape[0]
     mean_t = torch.tensor(mean, device=dev)
@@ -31,7 +32,8 @@ def gpu_sampler(zs, torch, mean, logstd, q0, generic=False, **hmc_kwargs):
     def model():
         bn = zs.BayesianNet()
         bn.normal('x', mean_t, logstd=logstd_t, n_samples=C,
-                  group_ndims=q0.ndim - 1)
+                  group_ndims=q0.ndim - 1 if group_ndims is None
+                  else group_ndims)
         return bn
 
     x = torch.tensor(q0, device=dev)
@@ -71,11 +73,14 @@ def compare_transition(info, x_gpu, rinfo, x_ref, ref, lp_tol=None):
     borderline = np.abs(u - acc_r) < 12 * h_tol
     xg = x_gpu.cpu().numpy().reshape(acc_r.shape[0], -1)
     xr = np.asarray(x_ref).reshape(acc_r.shape[0], -1)
-    ok = ~borderline
     q_scale = max(1.0, float(np.abs(xr).max()))
-    np.testing.assert_allclose(xg[ok], xr[ok], rtol=0, atol=2e-5 * q_scale)
+    row_bad = ~np.isclose(xg, xr, rtol=0, atol=2e-5 * q_scale).all(axis=1)
     lp_g = info.log_prob.cpu().numpy().reshape(-1)
-    np.testing.assert_allclose(lp_g[ok], np.asarray(
-        rinfo.log_prob).reshape(-1)[ok], rtol=0, atol=2 * h_tol)
-    assert borderline.mean() <= 0.02, borderline.mean()
-    return int(borderline.sum())
+    lp_bad = ~np.isclose(lp_g, np.asarray(rinfo.log_prob).reshape(-1),
+                         rtol=0, atol=2 * h_tol)
+    flipped = row_bad | lp_bad
+    # every disagreement must be a borderline accept decision ...
+    assert not np.any(flipped & ~borderline), np.nonzero(flipped & ~borderline)
+    # ... and those must be rare
+    assert flipped.sum() <= max(2, 0.01 * flipped.size), flipped.sum()
+    return int(flipped.sum())

@@ -57,7 +57,8 @@ def test_multi_axis_chains(env):
     q0 = rng.normal(size=(A, B, K)).astype(np.float32)
     kw = dict(step_size=0.2, n_leapfrogs=4, seed=5)
     ref, xr = ref_sampler(mean, logstd, q0.reshape(A * B, K), **kw)
-    hmc, op, info, xg = gpu_sampler(zs, torch, mean, logstd, q0, **kw)
+    hmc, op, info, xg = gpu_sampler(zs, torch, mean, logstd, q0,
+                                    group_ndims=1, **kw)
     assert tuple(info.acceptance_rate.shape) == (A, B)
     rinfo = ref.step()
     op.run()
@@ -153,7 +154,7 @@ def test_adaptation_trace_config1(env):
     # later, rare accept flips decorrelate chains slightly: 1 % (north_star)
     np.testing.assert_allclose(eps_g, eps_r, rtol=1e-2)
     np.testing.assert_allclose(acc_g, acc_r, atol=1e-2)
-    assert abs(eps_g[1] - 1.0) < 0.05            # Appendix B #1
+    assert abs(eps_g[0] - 1.0) < 0.05            # Appendix B #1
     assert hmc.n_init_trips >= 2
     s = np.vstack(samples)
     assert np.abs(s.mean(0)).max() < 0.02

@@ -1,0 +1,51 @@
+#!/usr/bin/env python
+"""Condense rocprofv3 CSV output (tools/profile.sh) into one text summary:
+per-kernel stats and, for the fused HMC kernel, mean PMC values per launch."""
+import csv
+import glob
+import os
+import sys
+
+out, tag = sys.argv[1], sys.argv[2]
+lines = []
+
+
+def find(pattern):
+    return sorted(glob.glob(os.path.join(out, pattern), recursive=True))
+
+
+for f in find('%s_trace/**/*kernel_stats.csv' % tag):
+    lines.append('== kernel stats (%s)' % os.path.relpath(f, out))
+    with open(f) as fh:
+        for i, row in enumerate(csv.reader(fh)):
+            if i < 12:
+                lines.append('  ' + ', '.join(row))
+
+for sub in ('pmc_fetch', 'pmc_write', 'pmc_sq', 'pmc_sq2'):
+    for f in find('%s_%s/**/*counter_collection.csv' % (tag, sub)):
+        agg = {}
+        with open(f) as fh:
+            rd = csv.DictReader(fh)
+            for row in rd:
+                k = row.get('Kernel_Name', '')
+                if 'hmc_diag_normal_kernel' not in k:
+                    continue
+                c = row.get('Counter_Name')
+                v = float(row.get('Counter_Value', 0))
+                key = (c, row.get('Dispatch_Id'))
+                agg.setdefault(c, {}).setdefault(row.get('Dispatch_Id'), 0.0)
+                agg[c][row.get('Dispatch_Id')] += v
+        if agg:
+            lines.append('== %s: fused kernel, mean per launch (%s)' % (
+                sub, os.path.relpath(f, out)))
+            for c, d in sorted(agg.items()):
+                vals = list(d.values())
+                # skip the first launches (search / burn-in have other L)
+                tail = vals[len(vals) // 2:]
+                lines.append('  %-24s mean %.6g  (n=%d, all-launch mean %.6g)' % (
+                    c, sum(tail) / len(tail), len(tail), sum(vals) / len(vals)))
+
+txt = '\n'.join(lines)
+print(txt)
+with open(os.path.join(out, '%s_summary.txt' % tag), 'w') as fh:
+    fh.write(txt + '\n')

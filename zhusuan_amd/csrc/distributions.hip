@@ -269,11 +269,11 @@ extern "C" int zshmc_normal_log_prob(const float* x, const float* mean,
                                      int64_t rows, int64_t cols,
                                      int mean_bcast, int logstd_bcast,
                                      int reduce_cols, void* stream) {
+  if (rows == 0) return ZSHMC_OK;
   ZS_REQUIRE(x && mean && logstd && out, "zshmc_normal_log_prob: null pointer");
   ZS_REQUIRE(rows >= 0 && cols >= 1, "zshmc_normal_log_prob: bad shape");
   ZS_REQUIRE(mode_ok(mean_bcast) && mode_ok(logstd_bcast),
              "zshmc_normal_log_prob: bad broadcast mode");
-  if (rows == 0) return ZSHMC_OK;
   if (reduce_cols)
     hipLaunchKernelGGL(lp_rowsum_kernel<0>, dim3(wave_row_grid(rows)), dim3(256),
                        0, ZS_STREAM, x, mean, logstd, out, rows, cols,
@@ -290,11 +290,11 @@ extern "C" int zshmc_normal_log_prob_grad(
     const float* x, const float* mean, const float* logstd, const float* gout,
     float* gx, float* gmean, float* glogstd, int64_t rows, int64_t cols,
     int mean_bcast, int logstd_bcast, int reduce_cols, void* stream) {
+  if (rows == 0) return ZSHMC_OK;
   ZS_REQUIRE(x && mean && logstd && gout, "zshmc_normal_log_prob_grad: null pointer");
   ZS_REQUIRE(rows >= 0 && cols >= 1, "zshmc_normal_log_prob_grad: bad shape");
   ZS_REQUIRE(mode_ok(mean_bcast) && mode_ok(logstd_bcast),
              "zshmc_normal_log_prob_grad: bad broadcast mode");
-  if (rows == 0) return ZSHMC_OK;
   hipLaunchKernelGGL(normal_grad_kernel, dim3(flat_grid(rows * cols)), dim3(256),
                      0, ZS_STREAM, x, mean, logstd, gout, gx, gmean, glogstd,
                      rows * cols, cols, mean_bcast, logstd_bcast, reduce_cols);
@@ -306,11 +306,11 @@ extern "C" int zshmc_bernoulli_log_prob(const float* logits, const float* given,
                                         float* out, int64_t rows, int64_t cols,
                                         int logits_bcast, int given_bcast,
                                         int reduce_cols, void* stream) {
+  if (rows == 0) return ZSHMC_OK;
   ZS_REQUIRE(logits && given && out, "zshmc_bernoulli_log_prob: null pointer");
   ZS_REQUIRE(rows >= 0 && cols >= 1, "zshmc_bernoulli_log_prob: bad shape");
   ZS_REQUIRE(mode_ok(logits_bcast) && mode_ok(given_bcast),
              "zshmc_bernoulli_log_prob: bad broadcast mode");
-  if (rows == 0) return ZSHMC_OK;
   if (reduce_cols)
     hipLaunchKernelGGL(lp_rowsum_kernel<1>, dim3(wave_row_grid(rows)), dim3(256),
                        0, ZS_STREAM, logits, given, nullptr, out, rows, cols,
@@ -327,12 +327,12 @@ extern "C" int zshmc_bernoulli_log_prob_grad(
     const float* logits, const float* given, const float* gout, float* glogits,
     int64_t rows, int64_t cols, int logits_bcast, int given_bcast,
     int reduce_cols, void* stream) {
+  if (rows == 0) return ZSHMC_OK;
   ZS_REQUIRE(logits && given && gout && glogits,
              "zshmc_bernoulli_log_prob_grad: null pointer");
   ZS_REQUIRE(rows >= 0 && cols >= 1, "zshmc_bernoulli_log_prob_grad: bad shape");
   ZS_REQUIRE(mode_ok(logits_bcast) && mode_ok(given_bcast),
              "zshmc_bernoulli_log_prob_grad: bad broadcast mode");
-  if (rows == 0) return ZSHMC_OK;
   hipLaunchKernelGGL(bernoulli_grad_kernel, dim3(flat_grid(rows * cols)),
                      dim3(256), 0, ZS_STREAM, logits, given, gout, glogits,
                      rows * cols, cols, logits_bcast, given_bcast, reduce_cols);
@@ -344,9 +344,9 @@ extern "C" int zshmc_categorical_log_prob(const float* logits,
                                           const int64_t* labels, float* out,
                                           int64_t rows, int64_t n_cat,
                                           void* stream) {
+  if (rows == 0) return ZSHMC_OK;
   ZS_REQUIRE(logits && labels && out, "zshmc_categorical_log_prob: null pointer");
   ZS_REQUIRE(rows >= 0 && n_cat >= 1, "zshmc_categorical_log_prob: bad shape");
-  if (rows == 0) return ZSHMC_OK;
   hipLaunchKernelGGL(softmax_family_kernel<0>, dim3(wave_row_grid(rows)),
                      dim3(256), 0, ZS_STREAM, logits, labels, nullptr, nullptr,
                      out, rows, n_cat, 1);
@@ -359,10 +359,10 @@ extern "C" int zshmc_categorical_log_prob_grad(const float* logits,
                                                const float* gout,
                                                float* glogits, int64_t rows,
                                                int64_t n_cat, void* stream) {
+  if (rows == 0) return ZSHMC_OK;
   ZS_REQUIRE(logits && labels && gout && glogits,
              "zshmc_categorical_log_prob_grad: null pointer");
   ZS_REQUIRE(rows >= 0 && n_cat >= 1, "zshmc_categorical_log_prob_grad: bad shape");
-  if (rows == 0) return ZSHMC_OK;
   hipLaunchKernelGGL(softmax_family_kernel<1>, dim3(wave_row_grid(rows)),
                      dim3(256), 0, ZS_STREAM, logits, labels, nullptr, gout,
                      glogits, rows, n_cat, 1);
@@ -373,11 +373,11 @@ extern "C" int zshmc_categorical_log_prob_grad(const float* logits,
 extern "C" int zshmc_unnormalized_multinomial_log_prob(
     const float* logits, const float* given, float* out, int64_t rows,
     int64_t n_cat, int normalize, void* stream) {
+  if (rows == 0) return ZSHMC_OK;
   ZS_REQUIRE(logits && given && out,
              "zshmc_unnormalized_multinomial_log_prob: null pointer");
   ZS_REQUIRE(rows >= 0 && n_cat >= 1,
              "zshmc_unnormalized_multinomial_log_prob: bad shape");
-  if (rows == 0) return ZSHMC_OK;
   hipLaunchKernelGGL(softmax_family_kernel<2>, dim3(wave_row_grid(rows)),
                      dim3(256), 0, ZS_STREAM, logits, nullptr, given, nullptr,
                      out, rows, n_cat, normalize);
@@ -388,11 +388,11 @@ extern "C" int zshmc_unnormalized_multinomial_log_prob(
 extern "C" int zshmc_unnormalized_multinomial_log_prob_grad(
     const float* logits, const float* given, const float* gout, float* glogits,
     int64_t rows, int64_t n_cat, int normalize, void* stream) {
+  if (rows == 0) return ZSHMC_OK;
   ZS_REQUIRE(logits && given && gout && glogits,
              "zshmc_unnormalized_multinomial_log_prob_grad: null pointer");
   ZS_REQUIRE(rows >= 0 && n_cat >= 1,
              "zshmc_unnormalized_multinomial_log_prob_grad: bad shape");
-  if (rows == 0) return ZSHMC_OK;
   hipLaunchKernelGGL(softmax_family_kernel<3>, dim3(wave_row_grid(rows)),
                      dim3(256), 0, ZS_STREAM, logits, nullptr, given, gout,
                      glogits, rows, n_cat, normalize);
@@ -404,9 +404,9 @@ extern "C" int zshmc_normal_sample(float* out, const float* mean,
                                    const float* std, int64_t n, int64_t inner,
                                    int mean_bcast, int std_bcast, uint64_t seed,
                                    uint32_t offset, void* stream) {
+  if (n == 0) return ZSHMC_OK;
   ZS_REQUIRE(out && mean && std, "zshmc_normal_sample: null pointer");
   ZS_REQUIRE(n >= 0 && inner >= 1, "zshmc_normal_sample: bad shape");
-  if (n == 0) return ZSHMC_OK;
   hipLaunchKernelGGL(normal_sample_kernel, dim3(flat_grid((n + 3) / 4)),
                      dim3(256), 0, ZS_STREAM, out, mean, std, n, inner,
                      mean_bcast, std_bcast, (uint32_t)(seed & 0xFFFFFFFFull),
@@ -418,9 +418,9 @@ extern "C" int zshmc_normal_sample(float* out, const float* mean,
 extern "C" int zshmc_bernoulli_sample(int32_t* out, const float* logits,
                                       int64_t n, int64_t inner, uint64_t seed,
                                       uint32_t offset, void* stream) {
+  if (n == 0) return ZSHMC_OK;
   ZS_REQUIRE(out && logits, "zshmc_bernoulli_sample: null pointer");
   ZS_REQUIRE(n >= 0 && inner >= 1, "zshmc_bernoulli_sample: bad shape");
-  if (n == 0) return ZSHMC_OK;
   hipLaunchKernelGGL(bernoulli_sample_kernel, dim3(flat_grid((n + 3) / 4)),
                      dim3(256), 0, ZS_STREAM, out, logits, n, inner,
                      (uint32_t)(seed & 0xFFFFFFFFull), (uint32_t)(seed >> 32),
@@ -433,10 +433,10 @@ extern "C" int zshmc_categorical_sample(int32_t* out, const float* logits,
                                         int64_t n_samples, int64_t rows,
                                         int64_t n_cat, uint64_t seed,
                                         uint32_t offset, void* stream) {
+  if (n_samples * rows == 0) return ZSHMC_OK;
   ZS_REQUIRE(out && logits, "zshmc_categorical_sample: null pointer");
   ZS_REQUIRE(n_samples >= 0 && rows >= 0 && n_cat >= 1,
              "zshmc_categorical_sample: bad shape");
-  if (n_samples * rows == 0) return ZSHMC_OK;
   hipLaunchKernelGGL(categorical_sample_kernel, dim3(flat_grid(n_samples * rows)),
                      dim3(256), 0, ZS_STREAM, out, logits, n_samples, rows,
                      n_cat, (uint32_t)(seed & 0xFFFFFFFFull),

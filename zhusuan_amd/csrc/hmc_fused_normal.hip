@@ -79,9 +79,29 @@ __device__ __forceinline__ void store4(float* __restrict__ base, int64_t d0,
 }
 
 // G lanes per chain, NCH 4-element chunks per lane.
+//
+// Register budget (the kernel is latency-bound below ~4 waves/SIMD): per lane
+// r, p, the prefetched next row and ONE parameter array (nep = -eps*prec; with
+// mass also eim = eps/mass) = 4..5 x 4*NCH floats.  mean and sqrt(mass) are
+// touched only when a row is loaded / stored / its momentum scaled, so they
+// are staged in LDS once per workgroup ("LDS-staged parameter tile") and read
+// back with conflict-free ds_read_b128.  prec itself is never kept:
+//   sum prec*r^2 = (-1/eps) * sum nep*r^2   (one scalar multiply per chain).
+#ifndef ZS_WAVES_PER_EU
+#define ZS_WAVES_PER_EU 1  // A/B knob: minimum waves per SIMD asked of hipcc
+#endif
 template <int G, int NCH, bool VEC, bool HAS_MASS>
-__global__ __launch_bounds__(256) void hmc_diag_normal_kernel(FusedArgs a) {
+__global__ __launch_bounds__(256, ZS_WAVES_PER_EU) void hmc_diag_normal_kernel(
+    FusedArgs a) {
   constexpr int kChainsPerWave = kWave / G;
+  constexpr int kPad = G * NCH * 4;  // padded row length held by one group
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* __restrict__ s_mean = reinterpret_cast<float*>(smem);
+  float* __restrict__ s_sqrtm = s_mean + kPad;  // only if HAS_MASS
+  double* __restrict__ s_acc =
+      reinterpret_cast<double*>(s_mean + (HAS_MASS ? 2 : 1) * kPad);
+  int* __restrict__ s_bad = reinterpret_cast<int*>(s_acc + 4);
+
   const int lane = threadIdx.x & (kWave - 1);
   const int l = lane % G;    // lane within the chain group
   const int sub = lane / G;  // which chain of this wave
@@ -90,125 +110,187 @@ __global__ __launch_bounds__(256) void hmc_diag_normal_kernel(FusedArgs a) {
   const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x / kWave);
   const int64_t D = a.n_data;
 
-  // ---- per-latent parameters: registers, loaded once per wave -----------
-  f4 mean[NCH], prec[NCH], inv_m[NCH], sqrt_m[NCH];
+  // ---- stage mean / sqrt(mass) in LDS (zero padding beyond n_data) --------
+  for (int d = threadIdx.x; d < kPad; d += blockDim.x) {
+    s_mean[d] = d < D ? a.mean[d] : 0.f;
+    if (HAS_MASS) s_sqrtm[d] = d < D ? sqrtf(a.mass[d]) : 0.f;
+  }
+  if (threadIdx.x == 0) *s_bad = 0;
+
+  // wave-uniform step size; se is the scale folded into nep / eim
+  const float eps =
+      a.step_size_dev ? *a.step_size_dev : a.step_size_host;
+  const bool moving = eps != 0.f;
+  const float se = moving ? eps : 1.f;
+  const float inv_se = 1.0f / se;
+
+  // ---- per-latent parameters kept in registers ---------------------------
+  f4 nep[NCH];   // -se * exp(-2*logstd)   (precision: univariate.py:178)
+  f4 eim[NCH];   //  se / mass             (only if HAS_MASS)
   float logz_part = 0.f;
 #pragma unroll
   for (int k = 0; k < NCH; ++k) {
     const int64_t d0 = (int64_t)(k * G + l) * 4;
-    mean[k] = load4<VEC>(a.mean, d0, D, 0.f);
     const f4 ls = load4<VEC>(a.logstd, d0, D, 0.f);
+    f4 m = f4{1.f, 1.f, 1.f, 1.f};
+    if (HAS_MASS) m = load4<VEC>(a.mass, d0, D, 1.f);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const bool valid = d0 + j < D;
-      // precision = exp(-2*logstd) (univariate.py:178); 0 for padding so
-      // padded elements contribute nothing to any sum.
-      prec[k][j] = valid ? __expf(-2.0f * ls[j]) : 0.f;
+      // padding gets precision 0 and inverse mass 0: no contribution anywhere
+      nep[k][j] = valid ? -se * expf(-2.0f * ls[j]) : 0.f;
       logz_part += valid ? (kHalfLog2PiNeg - ls[j]) : 0.f;
-    }
-    if (HAS_MASS) {
-      const f4 m = load4<VEC>(a.mass, d0, D, 1.f);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const bool valid = d0 + j < D;
-        inv_m[k][j] = valid ? 1.0f / m[j] : 0.f;
-        sqrt_m[k][j] = valid ? sqrtf(m[j]) : 0.f;
-      }
+      if (HAS_MASS) eim[k][j] = valid ? se / m[j] : 0.f;
     }
   }
   const float logz = group_sum<G>(logz_part);
-  const float eps =
-      a.step_size_dev ? *a.step_size_dev : a.step_size_host;  // wave-uniform
-  const int L = a.n_leapfrogs;
+  // eps == 0 (degenerate but legal): nothing moves, acceptance is 1
+  const int Lr = moving ? a.n_leapfrogs : 0;
+  const float hk = moving ? 0.5f : 0.f;          // first half kick
+  const float hk2 = Lr >= 1 ? 0.5f : 0.f;        // taken back from the last
+  __syncthreads();  // LDS tile ready
 
   double acc_local = 0.0;
   bool bad_old = false;
+
+  // ---- software pipeline: the next row is in flight while this one runs ---
+  // Row indices are clamped instead of branched on, so the prefetch is
+  // unconditional (no phi copies of the 4*NCH row registers); the one
+  // redundant load per wave at the end of its range re-reads a row this wave
+  // has just touched (an L2 hit, not HBM traffic).
+  const int64_t last_row = a.n_chains - 1;
+  auto row_of = [&](int64_t b) -> int64_t {
+    int64_t c = b + sub;
+    c = c < last_row ? c : last_row;
+    if (G == kWave) {  // one chain per wave: keep the row index scalar
+      const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)c);
+      const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(c >> 32));
+      c = (int64_t)(((uint64_t)hi << 32) | lo);
+    }
+    return c;
+  };
+  const int loff = l * 4;  // this lane's element offset inside a G*4 chunk
+  f4 qn[NCH];
+  {
+    const float* __restrict__ row0 =
+        a.q + row_of(wave_id * kChainsPerWave) * D + loff;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k)
+      qn[k] = load4<VEC>(row0, k * G * 4, D - loff, 0.f);
+  }
 
   for (int64_t base = wave_id * kChainsPerWave; base < a.n_chains;
        base += n_waves * kChainsPerWave) {
     const int64_t chain = base + sub;
     const bool active = chain < a.n_chains;
-    const int64_t chain_c = active ? chain : a.n_chains - 1;  // clamp: loads
-    float* __restrict__ qrow = a.q + chain_c * D;
+    const int64_t chain_c = row_of(base);
+    float* __restrict__ qrow = a.q + chain_c * D + loff;
     const uint32_t gchain = (uint32_t)(chain_c + a.chain_offset);
 
-    // ---- load q, resample momentum (hmc.py:21-23, :458) ----------------
-    f4 r[NCH], p[NCH];  // r = q - mean
-    float k_old = 0.f, u_old = 0.f;
+    // ---- r = q - mean; issue the prefetch of the next row ----------------
+    f4 r[NCH], p[NCH];
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
-      const int64_t d0 = (int64_t)(k * G + l) * 4;
-      const f4 qv = load4<VEC>(qrow, d0, D, 0.f);
-      r[k] = qv - mean[k];
+      const f4 mu = *reinterpret_cast<const f4*>(s_mean + (k * G + l) * 4);
+      r[k] = qn[k] - mu;
     }
+    {
+      const float* __restrict__ nrow =
+          a.q + row_of(base + n_waves * kChainsPerWave) * D + loff;
+#pragma unroll
+      for (int k = 0; k < NCH; ++k)
+        qn[k] = load4<VEC>(nrow, k * G * 4, D - loff, 0.f);
+    }
+    // keep the LDS reads of `mean` here and at the store from being merged
+    // (which would pin 4*NCH more registers across the whole trajectory)
+    asm volatile("" ::: "memory");
+
+    // ---- momentum resample (hmc.py:21-23, :458), initial energies and the
+    // first half kick (trip i = 0 of hmc.py:352-364: zero drift, eps/2 kick),
+    // fused chunk by chunk.  grad log p = -prec * r (d/dx of
+    // univariate.py:181); with nep = -eps*prec a kick of s2 is
+    // p += (s2/eps) * (nep * r), a drift is r += eps * p / m.
+    // The Philox key is made opaque per chain so that the 20 round keys are
+    // recomputed on the scalar unit instead of being pinned in (spilled)
+    // SGPRs for the whole kernel.
+    uint32_t key0 = a.k0, key1 = a.k1;
+    asm volatile("" : "+s"(key0), "+s"(key1));
+    f4 ko = f4{0.f, 0.f, 0.f, 0.f}, uo = ko;
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
       const uint32_t group = (uint32_t)(k * G + l);
       float z0, z1, z2, z3;
-      normal4(group, gchain, a.iteration, kStreamMomentum, a.k0, a.k1, z0, z1,
+      normal4(group, gchain, a.iteration, kStreamMomentum, key0, key1, z0, z1,
               z2, z3);
       p[k] = f4{z0, z1, z2, z3};
       if (HAS_MASS) {
-        p[k] = p[k] * sqrt_m[k];
-        const f4 pp = p[k] * p[k] * inv_m[k];
-        k_old += (pp[0] + pp[1]) + (pp[2] + pp[3]);
+        p[k] = p[k] * *reinterpret_cast<const f4*>(s_sqrtm + (k * G + l) * 4);
+        ko += (p[k] * p[k]) * eim[k];
       } else {
-        // padded elements must not contribute: prec==0 marks padding only
-        // when VEC is false or D is not a multiple of 4*G*NCH
-        const int64_t d0 = (int64_t)group * 4;
+        if (!VEC || kPad != D) {  // zero the padding lanes' momentum
+          const int64_t d0 = (int64_t)group * 4;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (d0 + j >= D) p[k][j] = 0.f;
-        const f4 pp = p[k] * p[k];
-        k_old += (pp[0] + pp[1]) + (pp[2] + pp[3]);
+          for (int j = 0; j < 4; ++j)
+            if (d0 + j >= D) p[k][j] = 0.f;
+        }
+        ko += p[k] * p[k];
       }
-      const f4 uu = prec[k] * r[k] * r[k];
-      u_old += (uu[0] + uu[1]) + (uu[2] + uu[3]);
+      const f4 t = nep[k] * r[k];
+      uo += t * r[k];
+      p[k] += hk * t;
     }
 
-    // ---- leapfrog (hmc.py:348-372): L+1 kicks, L drifts ------------------
-    // grad log p = -prec * r  (d/dx of univariate.py:181).
-    // kick:  p += s2 * (-prec * r) ;  drift: r += eps * p / m
-    const float half = 0.5f * eps;
-#pragma unroll
-    for (int k = 0; k < NCH; ++k) p[k] -= (half * prec[k]) * r[k];
-    for (int i = 1; i <= L; ++i) {
-      const float s2 = (i < L) ? eps : half;
+    // ---- leapfrog (hmc.py:348-372) ----------------------------------------
+    // Trips 1..L each do a full drift and a FULL kick; the last trip's kick
+    // must be eps/2, so half of it is taken back below (hk2), sharing the
+    // product nep*r with the potential energy of the proposal.
+    for (int i = 0; i < Lr; ++i) {
 #pragma unroll
       for (int k = 0; k < NCH; ++k) {
         if (HAS_MASS)
-          r[k] += (eps * inv_m[k]) * p[k];
+          r[k] += eim[k] * p[k];
         else
           r[k] += eps * p[k];
-        p[k] -= (s2 * prec[k]) * r[k];
+        p[k] += nep[k] * r[k];
       }
     }
 
     // ---- Hamiltonians (hmc.py:30-35) and acceptance (hmc.py:46-61) -------
-    float k_new = 0.f, u_new = 0.f;
+    f4 kn = f4{0.f, 0.f, 0.f, 0.f}, un = kn;
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
-      f4 pp = p[k] * p[k];
-      if (HAS_MASS) pp = pp * inv_m[k];
-      k_new += (pp[0] + pp[1]) + (pp[2] + pp[3]);
-      const f4 uu = prec[k] * r[k] * r[k];
-      u_new += (uu[0] + uu[1]) + (uu[2] + uu[3]);
+      const f4 t = nep[k] * r[k];
+      un += t * r[k];
+      p[k] -= hk2 * t;
+      if (HAS_MASS)
+        kn += (p[k] * p[k]) * eim[k];
+      else
+        kn += p[k] * p[k];
     }
+    float k_old = (ko[0] + ko[1]) + (ko[2] + ko[3]);
+    float u_old = (uo[0] + uo[1]) + (uo[2] + uo[3]);
+    float k_new = (kn[0] + kn[1]) + (kn[2] + kn[3]);
+    float u_new = (un[0] + un[1]) + (un[2] + un[3]);
     k_old = group_sum<G>(k_old);
     u_old = group_sum<G>(u_old);
     k_new = group_sum<G>(k_new);
     u_new = group_sum<G>(u_new);
-    const float lp_old = logz - 0.5f * u_old;
-    const float lp_new = logz - 0.5f * u_new;
+    if (HAS_MASS) {  // sum p^2/m = (1/se) sum p^2 * (se/m)
+      k_old *= inv_se;
+      k_new *= inv_se;
+    }
+    // sum prec r^2 = -(1/se) sum nep r^2 ;  log p = logz - 0.5 * that
+    const float lp_old = logz + 0.5f * inv_se * u_old;
+    const float lp_new = logz + 0.5f * inv_se * u_new;
     const float h_old = -lp_old + 0.5f * k_old;
     const float h_new = -lp_new + 0.5f * k_new;
-    float acc = __expf(fminf(h_old - h_new, 0.0f));
-    // fminf drops a NaN operand; test the operands explicitly (hmc.py:56-59)
-    const bool finite = isfinite(h_old - h_new) || (h_old - h_new) == INFINITY;
-    if (!(finite && isfinite(acc) && isfinite(lp_new))) acc = 0.f;
+    const float dh = h_old - h_new;
+    float acc = expf(fminf(dh, 0.0f));
+    // fminf drops a NaN operand: test explicitly (hmc.py:56-59)
+    if (!(dh == dh) || !isfinite(acc) || !isfinite(lp_new)) acc = 0.f;
     if (active && !isfinite(lp_old)) bad_old = true;
 
-    const float u = uniform_chain(gchain, a.iteration, a.k0, a.k1);
+    const float u = uniform_chain(gchain, a.iteration, key0, key1);
     const bool accept = u < acc;  // strict, hmc.py:486
 
     if (active && l == 0) acc_local += (double)acc;
@@ -216,8 +298,8 @@ __global__ __launch_bounds__(256) void hmc_diag_normal_kernel(FusedArgs a) {
       if (accept) {
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
-          const int64_t d0 = (int64_t)(k * G + l) * 4;
-          store4<VEC>(qrow, d0, D, r[k] + mean[k]);
+          const f4 mu = *reinterpret_cast<const f4*>(s_mean + (k * G + l) * 4);
+          store4<VEC>(qrow, k * G * 4, D - loff, r[k] + mu);
         }
       }
       if (l == 0) {
@@ -231,19 +313,15 @@ __global__ __launch_bounds__(256) void hmc_diag_normal_kernel(FusedArgs a) {
   }
 
   // ---- sum of acceptance rates: wave shuffle -> LDS -> one atomic/block --
-  __shared__ double s_acc[4];
-  __shared__ int s_bad;
-  if (threadIdx.x == 0) s_bad = 0;
   const double w = wave_sum_f64(acc_local);
-  __syncthreads();
   if (lane == 0) s_acc[threadIdx.x / kWave] = w;
-  if (bad_old) s_bad = 1;
+  if (bad_old) *s_bad = 1;
   __syncthreads();
   if (threadIdx.x == 0) {
     double tot = 0.0;
     for (int i = 0; i < (int)(blockDim.x / kWave); ++i) tot += s_acc[i];
     if (a.acc_sum) atomicAdd(a.acc_sum, tot);
-    if (s_bad && a.flags) atomicOr(a.flags, ZSHMC_FLAG_OLD_LOGPROB_NONFINITE);
+    if (*s_bad && a.flags) atomicOr(a.flags, ZSHMC_FLAG_OLD_LOGPROB_NONFINITE);
   }
 }
 
@@ -259,22 +337,49 @@ static int launch_cfg(const FusedArgs& a, hipStream_t stream) {
   constexpr int kWavesPerBlock = 4;
   const int64_t chains_per_block = (int64_t)kChainsPerWave * kWavesPerBlock;
   const int64_t need = (a.n_chains + chains_per_block - 1) / chains_per_block;
-  // persistent grid: 8 blocks of 4 waves per CU fill the 32 wave slots
-  const int64_t cap = (int64_t)device_cu_count() * 8;
+  // dynamic LDS: mean tile (+ sqrt(mass) tile) + 4 doubles + 1 int, all
+  // carved from the 16-B aligned dynamic region (no static __shared__)
+  const size_t lds = (size_t)(has_mass ? 2 : 1) * G * NCH * 4 * sizeof(float) +
+                     4 * sizeof(double) + 16;
+  // persistent grid = exactly the resident blocks (register-limited
+  // occupancy x CUs), so every wave amortises its parameter prologue over
+  // as many chains as possible
+  static int blocks_per_cu[4] = {0, 0, 0, 0};
+  const int variant = (vec ? 2 : 0) + (has_mass ? 1 : 0);
+  if (blocks_per_cu[variant] == 0) {
+    int nb = 0;
+    hipError_t e = hipSuccess;
+    if (vec && has_mass)
+      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(
+          &nb, hmc_diag_normal_kernel<G, NCH, true, true>, 256, lds);
+    else if (vec)
+      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(
+          &nb, hmc_diag_normal_kernel<G, NCH, true, false>, 256, lds);
+    else if (has_mass)
+      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(
+          &nb, hmc_diag_normal_kernel<G, NCH, false, true>, 256, lds);
+    else
+      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(
+          &nb, hmc_diag_normal_kernel<G, NCH, false, false>, 256, lds);
+    if (e != hipSuccess || nb < 1) nb = 2;
+    if (nb > 8) nb = 8;
+    blocks_per_cu[variant] = nb;
+  }
+  const int64_t cap = (int64_t)device_cu_count() * blocks_per_cu[variant];
   const int grid = (int)(need < cap ? need : cap);
   dim3 g(grid > 0 ? grid : 1), b(kWave * kWavesPerBlock);
   if (vec && has_mass)
-    hipLaunchKernelGGL((hmc_diag_normal_kernel<G, NCH, true, true>), g, b, 0,
+    hipLaunchKernelGGL((hmc_diag_normal_kernel<G, NCH, true, true>), g, b, lds,
                        stream, a);
   else if (vec)
-    hipLaunchKernelGGL((hmc_diag_normal_kernel<G, NCH, true, false>), g, b, 0,
-                       stream, a);
+    hipLaunchKernelGGL((hmc_diag_normal_kernel<G, NCH, true, false>), g, b,
+                       lds, stream, a);
   else if (has_mass)
-    hipLaunchKernelGGL((hmc_diag_normal_kernel<G, NCH, false, true>), g, b, 0,
-                       stream, a);
+    hipLaunchKernelGGL((hmc_diag_normal_kernel<G, NCH, false, true>), g, b,
+                       lds, stream, a);
   else
-    hipLaunchKernelGGL((hmc_diag_normal_kernel<G, NCH, false, false>), g, b, 0,
-                       stream, a);
+    hipLaunchKernelGGL((hmc_diag_normal_kernel<G, NCH, false, false>), g, b,
+                       lds, stream, a);
   ZS_LAUNCH_CHECK("hmc_diag_normal_kernel launch");
   return ZSHMC_OK;
 }
