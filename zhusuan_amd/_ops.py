@@ -74,6 +74,8 @@ def _rows_cols(full_shape, n_col_dims):
     rows = 1
     for s in full_shape[:nd - n_col_dims]:
         rows *= int(s)
+    if cols == 0:          # empty input: nothing to launch
+        rows = 0
     return rows, max(cols, 1)
 
 
