@@ -230,6 +230,24 @@ int zshmc_unnormalized_multinomial_log_prob_grad(
     const float* logits, const float* given, const float* gout,
     float* glogits, int64_t rows, int64_t n_cat, int normalize, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Fused dense-logit Bernoulli likelihood on the fp32 matrix cores
+ * (BASELINE config 3, Bayesian logistic regression):
+ *     logits[c, n] = sum_d W[c, d] * X[n, d]
+ *     log_lik[c]   = sum_n Bernoulli(logits[c, n]).log_prob(y[n])
+ *     grad_w[c, :] = d log_lik[c] / d W[c, :] = sum_n (y_n - sigmoid(l)) X[n, :]
+ * Replaces, for this model family, Bernoulli._log_prob (univariate.py:398-403)
+ * with group_ndims = 1 (base.py:302-304) on logits = matmul(w, X^T), and what
+ * tf.gradients (hmc.py:430-432) computes through them; the [C, N] logits are
+ * never materialised.  W [n_chains, n_features], X [n_rows, n_features]
+ * row-major, 16-byte aligned; y [n_rows] float (0/1); n_features in
+ * {64, 128, 256} (zero-pad otherwise); grad_w may be NULL.
+ */
+int zshmc_linear_bernoulli_log_lik(const float* W, const float* X,
+                                   const float* y, int64_t n_chains,
+                                   int64_t n_rows, int64_t n_features,
+                                   float* log_lik, float* grad_w, void* stream);
+
 /* Sampling (Normal._sample univariate.py:161-172, Bernoulli._sample
  * :386-396, Categorical._sample :478-494) on Philox stream STREAM_DIST with
  * counter (i/4, offset).  n = total number of output elements. */

@@ -1,0 +1,139 @@
+"""GPU parity of the fused dense-logit Bernoulli kernel
+(csrc/linear_bernoulli.hip, fp32 MFMA) vs the oracle's materialised
+Bernoulli(logits = w @ X^T) log_prob / gradient, and end-to-end HMC on a
+Bayesian logistic regression (BASELINE config 3 at reduced size) through
+`Bernoulli(linear_logits(w, X))`."""
+import numpy as np
+import pytest
+
+from oracle import hmc_ref
+from oracle.distributions_ref import Bernoulli as RB, Normal as RN
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def env():
+    import torch
+    import zhusuan_amd as zs
+    assert torch.cuda.is_available()
+    return zs, torch, torch.device('cuda', 0)
+
+
+def _data(C, N, D, seed):
+    rng = np.random.RandomState(seed)
+    X = rng.normal(size=(N, D)).astype(np.float32)
+    w_true = rng.normal(size=D).astype(np.float32)
+    y = (rng.uniform(size=N) < 1 / (1 + np.exp(-X @ w_true / np.sqrt(D)))
+         ).astype(np.int32)
+    W = (rng.normal(size=(C, D)) * 0.3).astype(np.float32)
+    return X, y, W
+
+
+def _ref(W, X, y):
+    l = W.astype(np.float64) @ X.astype(np.float64).T
+    yf = y.astype(np.float64)
+    ll = (yf * l - np.maximum(l, 0) - np.log1p(np.exp(-np.abs(l)))).sum(1)
+    g = (yf - 1 / (1 + np.exp(-l))) @ X.astype(np.float64)
+    return ll, g
+
+
+# ragged C (not a multiple of 64), ragged N (not a multiple of 32), every
+# kernel width (64/128/256) and zero-padded feature counts
+@pytest.mark.parametrize('C,N,D', [(64, 32, 64), (100, 1000, 256), (7, 45, 128),
+                                   (130, 333, 20), (64, 4096, 200), (1, 1, 3),
+                                   (256, 10000, 256)])
+def test_loglik_and_grad_match_float64_reference(env, C, N, D):
+    zs, torch, dev = env
+    X, y, W = _data(C, N, D, seed=C + N + D)
+    wt = torch.tensor(W, device=dev, requires_grad=True)
+    d = zs.distributions.Bernoulli(
+        zs.linear_logits(wt, torch.tensor(X, device=dev)), group_ndims=1)
+    ll = d.log_prob(torch.tensor(y, device=dev))
+    assert tuple(ll.shape) == (C,)
+    ll_ref, g_ref = _ref(W, X, y)
+    # fp32 MFMA = k-ordered fmaf chain: error ~1e-7 * sum|terms|
+    np.testing.assert_allclose(ll.detach().cpu().numpy(), ll_ref,
+                               rtol=2e-5, atol=2e-5 * N)
+    coef = torch.linspace(0.5, 1.5, C, device=dev)
+    (ll * coef).sum().backward()
+    scale = np.abs(g_ref).max() + 1.0
+    np.testing.assert_allclose(wt.grad.cpu().numpy(),
+                               g_ref * coef.cpu().numpy()[:, None],
+                               rtol=1e-4, atol=2e-5 * scale)
+    # and agrees with the element-wise HIP Bernoulli kernel on dense logits
+    dense = zs.distributions.Bernoulli(wt.detach() @ torch.tensor(
+        X, device=dev).t(), group_ndims=1).log_prob(torch.tensor(y, device=dev))
+    np.testing.assert_allclose(ll.detach().cpu().numpy(), dense.cpu().numpy(),
+                               rtol=2e-5, atol=2e-5 * N)
+
+
+def test_multi_axis_chains_and_fallback(env):
+    zs, torch, dev = env
+    X, y, W = _data(24, 50, 10, seed=1)
+    w3 = torch.tensor(W.reshape(4, 6, 10), device=dev)
+    Xt, yt = torch.tensor(X, device=dev), torch.tensor(y, device=dev)
+    ll = zs.distributions.Bernoulli(zs.linear_logits(w3, Xt),
+                                    group_ndims=1).log_prob(yt)
+    assert tuple(ll.shape) == (4, 6)
+    ll_ref, _ = _ref(W, X, y)
+    np.testing.assert_allclose(ll.cpu().numpy().reshape(-1), ll_ref, rtol=2e-5,
+                               atol=1e-3)
+    # group_ndims = 0 cannot use the fused kernel: dense fallback, [4, 6, 50]
+    e = zs.distributions.Bernoulli(zs.linear_logits(w3, Xt)).log_prob(yt)
+    assert tuple(e.shape) == (4, 6, 50)
+    np.testing.assert_allclose(e.sum(-1).cpu().numpy().reshape(-1), ll_ref,
+                               rtol=2e-5, atol=1e-3)
+
+
+def test_bayesian_logistic_regression_hmc(env):
+    """w ~ N(0, 1), y ~ Bernoulli(w X^T): generic plan driving the fused MFMA
+    kernel vs the oracle with materialised logits."""
+    zs, torch, dev = env
+    C, N, D = 96, 600, 16
+    X, y, W0 = _data(C, N, D, seed=5)
+    W0 *= 0.3
+    Xt, yt = torch.tensor(X, device=dev), torch.tensor(y, device=dev)
+
+    @zs.meta_bayesian_net()
+    def blr():
+        bn = zs.BayesianNet()
+        w = bn.normal('w', torch.zeros(D, device=dev),
+                      std=torch.ones(D, device=dev), n_samples=C,
+                      group_ndims=1)
+        bn.bernoulli('y', zs.linear_logits(w.tensor, Xt), group_ndims=1)
+        return bn
+
+    wt = torch.tensor(W0, device=dev)
+    hmc = zs.HMC(step_size=0.01, n_leapfrogs=6, adapt_step_size=True, seed=9)
+    op, info = hmc.sample(blr(), {'y': yt}, {'w': wt})
+    assert hmc.plan_kind == 'generic'
+
+    def lj(q):
+        w = q[0]
+        return (RN(np.zeros(D, np.float32), std=np.ones(D, np.float32),
+                   group_ndims=1).log_prob(w) +
+                RB((w @ X.T).astype(np.float32), group_ndims=1).log_prob(y))
+
+    def grad(q):
+        w = q[0]
+        l = (w @ X.T).astype(np.float32)
+        res = y.astype(np.float32) - 1 / (1 + np.exp(-l))
+        return [(-w + res @ X).astype(np.float32)]
+
+    wr = W0.copy()
+    ref = hmc_ref.HMC(step_size=0.01, n_leapfrogs=6, adapt_step_size=True,
+                      seed=9)
+    ref.sample(lj, grad, [wr])
+    for it in range(4):
+        rinfo = ref.step()
+        op.run()
+        np.testing.assert_allclose(info.orig_log_prob.cpu().numpy(),
+                                   rinfo.orig_log_prob, rtol=3e-5, atol=5e-3)
+        np.testing.assert_allclose(info.acceptance_rate.cpu().numpy(),
+                                   rinfo.acceptance_rate, atol=1e-2)
+        np.testing.assert_allclose(float(info.updated_step_size.item()),
+                                   float(rinfo.updated_step_size), rtol=1e-2)
+        ok = np.abs(ref.last_u01 - rinfo.acceptance_rate) > 2e-2
+        np.testing.assert_allclose(wt.cpu().numpy()[ok], wr[ok], atol=5e-4)
+        wt.copy_(torch.tensor(wr, device=dev))

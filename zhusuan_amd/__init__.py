@@ -7,6 +7,7 @@ zs.diagnostics.effective_sample_size."""
 from . import diagnostics, distributions, framework
 from .framework import (BayesianNet, MetaBayesianNet, StochasticTensor,
                         meta_bayesian_net)
+from .distributions import linear_logits
 from .hmc import HMC, HMCInfo, InvalidArgumentError, placeholder
 from .session import Session
 from .utils import merge_dicts, set_random_seed
@@ -16,4 +17,4 @@ __version__ = '0.1.0'
 __all__ = ['HMC', 'HMCInfo', 'InvalidArgumentError', 'placeholder', 'Session',
            'BayesianNet', 'MetaBayesianNet', 'StochasticTensor',
            'meta_bayesian_net', 'distributions', 'diagnostics', 'framework',
-           'merge_dicts', 'set_random_seed']
+           'merge_dicts', 'set_random_seed', 'linear_logits']

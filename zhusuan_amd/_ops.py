@@ -215,3 +215,67 @@ class UnnormalizedMultinomialLogProb(torch.autograd.Function):
                    gout.contiguous().data_ptr(), gl.data_ptr(), rows, n_cat,
                    ctx.normalize, _capi.current_stream())
         return gl, None, None
+
+
+# ----------------------------------------------------------------------------
+# dense-logit Bernoulli likelihood (fp32 MFMA, csrc/linear_bernoulli.hip)
+# ----------------------------------------------------------------------------
+LINEAR_BERNOULLI_WIDTHS = (64, 128, 256)
+
+
+def _pad_features(t, width):
+    d = t.shape[-1]
+    if d == width and t.is_contiguous():
+        return t
+    out = torch.zeros(t.shape[:-1] + (width,), dtype=_F32, device=t.device)
+    out[..., :d] = t
+    return out
+
+
+_x_cache = {}
+
+
+def _padded_x(X, width):
+    """Zero-padded contiguous copy of the design matrix, cached per tensor
+    version (the model builder re-runs on every joint evaluation)."""
+    if X.shape[-1] == width and X.is_contiguous() and X.dtype == _F32:
+        return X
+    key = (X.data_ptr(), tuple(X.shape), X._version, width)
+    hit = _x_cache.get('x')
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    Xp = _pad_features(X.detach().to(_F32), width)
+    _x_cache['x'] = (key, Xp)
+    return Xp
+
+
+class LinearBernoulliLogLik(torch.autograd.Function):
+    """ll[c] = sum_n Bernoulli(w_c . x_n).log_prob(y_n) and its gradient in one
+    pass over X (logits are never materialised)."""
+
+    @staticmethod
+    def forward(ctx, w, X, y):
+        require_device(w, X, y)
+        d = w.shape[-1]
+        width = next(v for v in LINEAR_BERNOULLI_WIDTHS if v >= d)
+        w2 = _pad_features(w.detach().reshape(-1, d).to(_F32), width)
+        Xp = _padded_x(X, width)
+        yf = y.detach().to(_F32).contiguous()
+        C, N = w2.shape[0], Xp.shape[0]
+        ll = torch.empty(C, dtype=_F32, device=w.device)
+        need_grad = ctx.needs_input_grad[0]
+        gw = torch.empty_like(w2) if need_grad else None
+        _capi.call('zshmc_linear_bernoulli_log_lik', w2.data_ptr(),
+                   Xp.data_ptr(), yf.data_ptr(), C, N, width, ll.data_ptr(),
+                   _capi.ptr(gw), _capi.current_stream())
+        ctx.w_shape = tuple(w.shape)
+        if need_grad:
+            ctx.save_for_backward(gw)
+        return ll.reshape(w.shape[:-1])
+
+    @staticmethod
+    def backward(ctx, gout):
+        (gw,) = ctx.saved_tensors
+        d = ctx.w_shape[-1]
+        g = gw[:, :d] * gout.reshape(-1, 1)
+        return g.reshape(ctx.w_shape), None, None

@@ -9,7 +9,8 @@ from .. import _capi, _ops
 from ..utils import next_op_offset
 from .base import Distribution, as_tensor, common_device, default_device
 
-__all__ = ['Normal', 'Bernoulli', 'Categorical', 'Discrete']
+__all__ = ['Normal', 'Bernoulli', 'Categorical', 'Discrete', 'LinearLogits',
+           'linear_logits']
 
 _FLOATS = (torch.float16, torch.float32, torch.float64)
 _INTS = (torch.int16, torch.int32, torch.int64)
@@ -166,10 +167,59 @@ class Normal(Distribution):
             self.path_param(self._logstd), 0)
 
 
+class LinearLogits(object):
+    """Lazy `w @ X^T`: logits of shape w.shape[:-1] + [n_rows] that are never
+    materialised.  `Bernoulli(linear_logits(w, X), group_ndims=1)` evaluates
+    log_prob and its gradient with the fused fp32-MFMA kernel
+    (csrc/linear_bernoulli.hip); anything else falls back to `.dense()`."""
+
+    def __init__(self, w, X):
+        w = as_tensor(w)
+        X = as_tensor(X)
+        if X.dim() != 2 or w.dim() < 1 or w.shape[-1] != X.shape[-1]:
+            raise ValueError(
+                "linear_logits: w[..., D] and X[N, D] expected, got {} and {}"
+                .format(tuple(w.shape), tuple(X.shape)))
+        self.w = w
+        self.X = X
+
+    @property
+    def shape(self):
+        return torch.Size(tuple(self.w.shape[:-1]) + (self.X.shape[0],))
+
+    @property
+    def dtype(self):
+        return self.w.dtype
+
+    @property
+    def device(self):
+        return self.w.device
+
+    def dense(self):
+        return self.w @ self.X.t()
+
+
+def linear_logits(w, X):
+    return LinearLogits(w, X)
+
+
 class Bernoulli(Distribution):
     """Univariate Bernoulli (univariate.py:334-406)."""
 
     def __init__(self, logits, dtype=torch.int32, group_ndims=0, **kwargs):
+        self._lazy = None
+        if isinstance(logits, LinearLogits):
+            if logits.dtype != torch.float32:
+                raise TypeError("Bernoulli: linear_logits must be float32")
+            self._lazy = logits
+            if dtype not in _FLOATS + _INTS:
+                raise TypeError(
+                    "`dtype`({}) must be int or float.".format(dtype))
+            self._logits = None
+            super(Bernoulli, self).__init__(
+                dtype=dtype, param_dtype=torch.float32, is_continuous=False,
+                is_reparameterized=False, group_ndims=group_ndims, **kwargs)
+            return
         dev = common_device(logits) or default_device()
         self._logits = as_tensor(logits, dtype=None if isinstance(
             logits, torch.Tensor) else torch.float32, device=dev)
@@ -184,20 +234,24 @@ class Bernoulli(Distribution):
 
     @property
     def logits(self):
+        if self._logits is None:
+            self._logits = self._lazy.dense()
         return self._logits
 
     def _device(self):
-        return self._logits.device
+        return self._lazy.device if self._lazy is not None \
+            else self._logits.device
 
     def _get_value_shape(self):
         return torch.Size([])
 
     def _get_batch_shape(self):
-        return self._logits.shape
+        return self._lazy.shape if self._lazy is not None \
+            else self._logits.shape
 
     def _sample(self, n_samples):
         """univariate.py:386-396: U[0,1) < sigmoid(logits)."""
-        logits = self._logits.detach().contiguous()
+        logits = self.logits.detach().contiguous()
         _ops.require_device(logits)
         inner = max(logits.numel(), 1)
         n = int(n_samples) * inner
@@ -211,6 +265,17 @@ class Bernoulli(Distribution):
 
     def _log_prob_grouped(self, given):
         given = given.to(self.param_dtype)          # :399
+        lazy = self._lazy
+        if (lazy is not None and self._group_ndims >= 1 and
+                given.dim() == 1 and given.shape[0] == lazy.X.shape[0] and
+                lazy.w.shape[-1] <= _ops.LINEAR_BERNOULLI_WIDTHS[-1] and
+                lazy.w.dim() - 1 >= self._group_ndims - 1):
+            ll = _ops.LinearBernoulliLogLik.apply(lazy.w, lazy.X, given)
+            extra = self._group_ndims - 1
+            return ll if extra == 0 else ll.sum(
+                dim=tuple(range(-extra, 0)))
+        if self._logits is None:
+            self._logits = lazy.dense()
         try:
             full = torch.broadcast_shapes(given.shape, self._logits.shape)
         except RuntimeError:
@@ -225,7 +290,7 @@ class Bernoulli(Distribution):
 
     def _log_prob(self, given):
         return _ops.BernoulliLogProb.apply(
-            self._logits, given.to(self.param_dtype), 0)
+            self.logits, given.to(self.param_dtype), 0)
 
 
 class Categorical(Distribution):
