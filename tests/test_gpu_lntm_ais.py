@@ -1,0 +1,145 @@
+"""GPU tests of the callers / data formats either side of the hot path:
+  * the logistic-normal topic model E-step shape (BASELINE config 5,
+    examples/topic_models/lntm_mcem.py:33-48,97-102): chain axes
+    [n_chains, n_docs], data axis [K], softmax + theta.phi GEMM +
+    UnnormalizedMultinomial, step-size and mass adaptation on -- generic plan
+    vs the oracle with the analytic gradient;
+  * AIS (zhusuan/evaluation.py:57-172) on a conjugate Gaussian whose marginal
+    likelihood is known in closed form."""
+import numpy as np
+import pytest
+
+from oracle import hmc_ref
+from oracle.distributions_ref import Normal as RN, UnnormalizedMultinomial as RM
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def env():
+    import torch
+    import zhusuan_amd as zs
+    assert torch.cuda.is_available()
+    return zs, torch, torch.device('cuda', 0)
+
+
+def _softmax(a):
+    e = np.exp(a - a.max(-1, keepdims=True))
+    return e / e.sum(-1, keepdims=True)
+
+
+def test_lntm_estep_matches_oracle(env):
+    zs, torch, dev = env
+    n_chains, n_docs, K, V = 3, 7, 5, 40
+    rng = np.random.RandomState(0)
+    beta = rng.normal(size=(K, V)).astype(np.float32)
+    phi = _softmax(beta)
+    x = np.stack([rng.multinomial(60, phi[rng.randint(K)])
+                  for _ in range(n_docs)]).astype(np.float32)
+    eta_mean = np.zeros((n_docs, K), np.float32)
+    eta_logstd = np.zeros(K, np.float32)
+    eta0 = (0.1 * rng.normal(size=(n_chains, n_docs, K))).astype(np.float32)
+    T = lambda a: torch.tensor(a, device=dev)
+    beta_t, x_t = T(beta), T(x)
+
+    @zs.meta_bayesian_net()
+    def lntm():
+        bn = zs.BayesianNet()
+        eta = bn.normal('eta', T(eta_mean), logstd=T(eta_logstd),
+                        n_samples=n_chains, group_ndims=1)
+        theta = torch.softmax(eta.tensor, dim=-1)
+        phi_t = torch.softmax(beta_t, dim=-1)
+        doc_word = theta.reshape(-1, K) @ phi_t
+        doc_word = doc_word.reshape(eta.tensor.shape[0], n_docs, V)
+        bn.unnormalized_multinomial('x', torch.log(doc_word),
+                                    normalize_logits=False,
+                                    dtype=torch.float32)
+        return bn
+
+    model = lntm()
+    # lntm_mcem.py:97-102: E-step objective = cond_log_prob(eta) + (x)
+    model.log_joint = lambda bn: (bn.cond_log_prob('eta') +
+                                  bn.cond_log_prob('x'))
+    eta_t = T(eta0)
+    kw = dict(step_size=1e-3, n_leapfrogs=8, adapt_step_size=True,
+              adapt_mass=True, target_acceptance_rate=0.6, seed=21)
+    hmc = zs.HMC(**kw)
+    op, info = hmc.sample(model, {'x': x_t}, {'eta': eta_t})
+    assert hmc.plan_kind == 'generic'
+    assert tuple(info.acceptance_rate.shape) == (n_chains, n_docs)
+
+    def lj(q):
+        eta = q[0]
+        theta = _softmax(eta)
+        dw = theta @ phi
+        return (RN(eta_mean, logstd=eta_logstd, group_ndims=1).log_prob(eta) +
+                RM(np.log(dw).astype(np.float32),
+                   normalize_logits=False).log_prob(x))
+
+    def grad(q):
+        eta = q[0]
+        theta = _softmax(eta)
+        dw = theta @ phi                                   # [c, docs, V]
+        g_theta = (x / dw) @ phi.T                         # [c, docs, K]
+        g_lik = theta * (g_theta - (theta * g_theta).sum(-1, keepdims=True))
+        g_prior = -(eta - eta_mean) * np.exp(-2 * eta_logstd)
+        return [(g_prior + g_lik).astype(np.float32)]
+
+    eta_r = eta0.copy()
+    ref = hmc_ref.HMC(**kw)
+    ref.sample(lj, grad, [eta_r])
+    assert ref.n_chain_dims == 2
+    for it in range(14):
+        rinfo = ref.step()
+        op.run()
+        np.testing.assert_allclose(info.orig_log_prob.cpu().numpy(),
+                                   rinfo.orig_log_prob, rtol=1e-4, atol=2e-2)
+        np.testing.assert_allclose(info.acceptance_rate.cpu().numpy(),
+                                   rinfo.acceptance_rate, atol=2e-2)
+        np.testing.assert_allclose(float(info.updated_step_size.item()),
+                                   float(rinfo.updated_step_size), rtol=2e-2)
+        if it >= 10:    # mass is live after mass_collect_iters = 10
+            np.testing.assert_allclose(
+                hmc._plan.mass[0].cpu().numpy(),
+                np.asarray(ref.last_mass[0]).reshape(-1), rtol=5e-3)
+        eta_t.copy_(T(eta_r))       # keep the two samplers on the same state
+
+
+def test_ais_conjugate_gaussian(env):
+    zs, torch, dev = env
+    D, n_chains, sigma = 4, 200, 0.7
+    rng = np.random.RandomState(1)
+    x_obs = rng.normal(size=D).astype(np.float32) * 1.2
+    x_t = torch.tensor(x_obs, device=dev)
+
+    @zs.meta_bayesian_net()
+    def model():
+        bn = zs.BayesianNet()
+        z = bn.normal('z', torch.zeros(D, device=dev),
+                      std=torch.ones(D, device=dev), n_samples=n_chains,
+                      group_ndims=1)
+        bn.normal('x', z, std=sigma * torch.ones(D, device=dev), group_ndims=1)
+        return bn
+
+    @zs.meta_bayesian_net()
+    def proposal():
+        bn = zs.BayesianNet()
+        bn.normal('z', torch.zeros(D, device=dev),
+                  std=torch.ones(D, device=dev), n_samples=n_chains,
+                  group_ndims=1)
+        return bn
+
+    zs.set_random_seed(7)
+    z = torch.zeros(n_chains, D, device=dev)
+    hmc = zs.HMC(step_size=0.1, n_leapfrogs=5, adapt_step_size=True,
+                 target_acceptance_rate=0.8)
+    ais = zs.AIS(model(), proposal(), hmc, {'x': x_t}, {'z': z},
+                 n_temperatures=120, n_adapt=10)
+    est = ais.run()
+    var = 1 + sigma ** 2
+    truth = float((-0.5 * np.log(2 * np.pi * var) -
+                   0.5 * x_obs.astype(np.float64) ** 2 / var).sum())
+    assert abs(est - truth) < 0.15, (est, truth)
+    # schedule end points (evaluation.py:112-117)
+    assert ais._get_schedule_t(0) == 0.0
+    assert abs(ais._get_schedule_t(120) - 1.0) < 1e-12

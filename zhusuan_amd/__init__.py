@@ -4,17 +4,18 @@ hand-written HIP kernels.  Same surface as `import zhusuan as zs` for the
 path: zs.HMC, zs.HMCInfo, zs.BayesianNet, zs.meta_bayesian_net,
 zs.distributions.{Normal, Bernoulli, Categorical, UnnormalizedMultinomial},
 zs.diagnostics.effective_sample_size."""
-from . import diagnostics, distributions, framework
+from . import diagnostics, distributions, evaluation, framework
 from .framework import (BayesianNet, MetaBayesianNet, StochasticTensor,
                         meta_bayesian_net)
 from .distributions import linear_logits
+from .evaluation import AIS
 from .hmc import HMC, HMCInfo, InvalidArgumentError, placeholder
 from .session import Session
 from .utils import merge_dicts, set_random_seed
 
 __version__ = '0.1.0'
 
-__all__ = ['HMC', 'HMCInfo', 'InvalidArgumentError', 'placeholder', 'Session',
+__all__ = ['AIS', 'evaluation', 'HMC', 'HMCInfo', 'InvalidArgumentError', 'placeholder', 'Session',
            'BayesianNet', 'MetaBayesianNet', 'StochasticTensor',
            'meta_bayesian_net', 'distributions', 'diagnostics', 'framework',
            'merge_dicts', 'set_random_seed', 'linear_logits']
