@@ -100,13 +100,21 @@ def main():
                 'bench.py --gpus %d must be launched with torch.distributed.run '
                 '--nproc-per-node %d' % (args.gpus, args.gpus))
     assert torch.cuda.is_available(), 'bench.py needs an MI355X'
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    # ZSHMC_DIST_BACKEND=gloo lets two ranks share one GPU (functional test of
+    # the N > 1 path on a 1-GPU box); the real runs use RCCL ("nccl")
+    backend = os.environ.get('ZSHMC_DIST_BACKEND', 'nccl')
+    local_dev = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(local_dev)
+    dev = torch.device('cuda', local_dev)
     sharding = None
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='nccl', rank=rank, world_size=world,
-                                device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group(backend='nccl', rank=rank,
+                                    world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend=backend, rank=rank,
+                                    world_size=world)
         sharding = ChainSharding(chain_offset=rank * args.chains_per_gpu,
                                  n_chains_global=world * args.chains_per_gpu)
 
@@ -152,7 +160,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64,
+                          device=dev if backend == 'nccl' else 'cpu')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     hmc.check_numerics()

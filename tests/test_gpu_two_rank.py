@@ -1,0 +1,141 @@
+"""N > 1 path on real kernels: two processes (gloo rendezvous, both on
+cuda:0 because the test box has one GPU) shard the chains of one problem.
+With adaptation off the sharded run must equal the single-process run bit
+for bit (global-chain-index RNG); with adaptation on, the replicated state
+must agree across ranks and with the single-process trace.  Also launches
+bench.py --gpus 2 the way the driver does (torch.distributed.run)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %(root)r)
+import zhusuan_amd as zs
+from zhusuan_amd.distributed import ChainSharding, shard_bounds
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+dist.init_process_group('gloo', rank=rank, world_size=world)
+dev = torch.device('cuda', 0)
+C, D, L = 640, 96, 5
+rng = np.random.RandomState(0)
+mean = torch.tensor(rng.normal(size=D).astype(np.float32), device=dev)
+logstd = torch.tensor(rng.uniform(-.5, .5, size=D).astype(np.float32), device=dev)
+q0 = torch.tensor(rng.normal(size=(C, D)).astype(np.float32), device=dev)
+lo, hi = shard_bounds(C, rank, world)
+out = {}
+for adapt in (None, True):
+    x = q0[lo:hi].clone()
+    n = hi - lo
+    @zs.meta_bayesian_net()
+    def model():
+        bn = zs.BayesianNet()
+        bn.normal('x', mean, logstd=logstd, n_samples=n, group_ndims=1)
+        return bn
+    hmc = zs.HMC(step_size=0.08, n_leapfrogs=L, adapt_step_size=adapt,
+                 adapt_mass=adapt, mass_collect_iters=3, seed=5,
+                 sharding=ChainSharding())
+    op, info = hmc.sample(model(), {}, {'x': x})
+    eps = []
+    for i in range(8):
+        op.run()
+        eps.append(float(info.updated_step_size.item()))
+    out['x_%%s' %% adapt] = x.cpu().numpy()
+    out['eps_%%s' %% adapt] = np.array(eps)
+    if adapt:
+        out['mass'] = hmc._plan.mass[0].cpu().numpy()
+np.savez(os.path.join(%(out)r, 'rank%%d.npz' %% rank), lo=lo, hi=hi, **out)
+dist.destroy_process_group()
+'''
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _launch(script_args, nproc, env_extra=None, timeout=600):
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           '--nproc-per-node', str(nproc), '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port())] + script_args
+    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+def test_two_rank_sharded_gpu_run_matches_single_process(tmp_path):
+    import torch
+    import zhusuan_amd as zs
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER % dict(root=ROOT, out=str(tmp_path)))
+    r = _launch([str(script)], 2)
+    assert r.returncode == 0, r.stderr[-3000:]
+    ranks = [np.load(str(tmp_path / ('rank%d.npz' % i))) for i in range(2)]
+
+    dev = torch.device('cuda', 0)
+    C, D, L = 640, 96, 5
+    rng = np.random.RandomState(0)
+    mean = torch.tensor(rng.normal(size=D).astype(np.float32), device=dev)
+    logstd = torch.tensor(rng.uniform(-.5, .5, size=D).astype(np.float32),
+                          device=dev)
+    q0 = torch.tensor(rng.normal(size=(C, D)).astype(np.float32), device=dev)
+    single = {}
+    for adapt in (None, True):
+        x = q0.clone()
+
+        @zs.meta_bayesian_net()
+        def model():
+            bn = zs.BayesianNet()
+            bn.normal('x', mean, logstd=logstd, n_samples=C, group_ndims=1)
+            return bn
+        hmc = zs.HMC(step_size=0.08, n_leapfrogs=L, adapt_step_size=adapt,
+                     adapt_mass=adapt, mass_collect_iters=3, seed=5)
+        op, info = hmc.sample(model(), {}, {'x': x})
+        eps = []
+        for i in range(8):
+            op.run()
+            eps.append(float(info.updated_step_size.item()))
+        single['x_%s' % adapt] = x.cpu().numpy()
+        single['eps_%s' % adapt] = np.array(eps)
+        if adapt:
+            single['mass'] = hmc._plan.mass[0].cpu().numpy()
+    # no adaptation: bit-exact regardless of the sharding
+    x_sh = np.concatenate([ranks[0]['x_None'], ranks[1]['x_None']])
+    np.testing.assert_array_equal(x_sh, single['x_None'])
+    # adaptation on: replicated state identical on both ranks ...
+    np.testing.assert_array_equal(ranks[0]['eps_True'], ranks[1]['eps_True'])
+    np.testing.assert_array_equal(ranks[0]['mass'], ranks[1]['mass'])
+    # ... and equal to the single-process trace up to summation order
+    np.testing.assert_allclose(ranks[0]['eps_True'], single['eps_True'],
+                               rtol=1e-5)
+    np.testing.assert_allclose(ranks[0]['mass'], single['mass'], rtol=1e-5)
+    x_sh = np.concatenate([ranks[0]['x_True'], ranks[1]['x_True']])
+    close = np.isclose(x_sh, single['x_True'], atol=1e-4).all(axis=1)
+    assert close.mean() > 0.98
+
+
+def test_bench_two_ranks_prints_contract_json():
+    r = _launch(['bench.py', '--gpus', '2', '--steps', '10', '--warmup', '2',
+                 '--chains-per-gpu', '4096', '--no-ess'], 2,
+                {'ZSHMC_DIST_BACKEND': 'gloo'})
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
+    out = json.loads(line)
+    assert out['n_gpus'] == 2 and out['steps'] == 10 and out['warmup'] == 2
+    assert out['scaling'] == 'weak' and out['higher_is_better'] is True
+    assert out['config']['n_chains_total'] == 8192
+    assert out['value'] > 0 and 0.3 < out['mean_acceptance'] <= 1.0
+    assert out['roofline']['bound'] == 'hbm'
+    assert 'cpu_baseline' not in out       # rank 0 at N = 1 only

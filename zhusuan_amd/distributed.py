@@ -46,6 +46,8 @@ class ChainSharding(object):
         counts at plan-build time (not on the hot loop)."""
         if self._chain_offset is not None and self._n_chains_global is not None:
             return int(self._chain_offset), int(self._n_chains_global)
+        if dist.get_backend(self.group) == 'gloo':
+            device = torch.device('cpu')
         mine = torch.tensor([int(n_local)], dtype=torch.int64, device=device)
         counts = [torch.zeros_like(mine) for _ in range(self.world_size)]
         dist.all_gather(counts, mine, group=self.group)
@@ -53,7 +55,16 @@ class ChainSharding(object):
         return sum(counts[:self.rank]), sum(counts)
 
     def all_reduce_sum(self, tensor):
-        """In-place sum over ranks, enqueued on the current stream."""
+        """In-place sum over ranks.  With the RCCL ("nccl") backend the
+        collective is enqueued on the device, ordered with the current
+        stream; with gloo (CPU tests, or two ranks sharing one GPU in the
+        functional test) device tensors are staged through the host."""
         if self.world_size > 1:
-            dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group)
+            if tensor.is_cuda and dist.get_backend(self.group) == 'gloo':
+                host = tensor.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                tensor.copy_(host)
+            else:
+                dist.all_reduce(tensor, op=dist.ReduceOp.SUM,
+                                group=self.group)
         return tensor
