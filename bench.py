@@ -187,6 +187,8 @@ def main():
     kern_ms = e0.elapsed_time(e1) / reps
     hmc.t = t_iter + 6 + reps
     algo_bytes = ALGO_BYTES_PER_ELEM * C * D
+    from zhusuan_amd import _capi
+    kernel_name = _capi.load().zshmc_fused_kernel_name(D, 0).decode()
     achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
     traffic = None
     pmc_path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
@@ -259,7 +261,7 @@ def main():
             'step_size': eps,
             'roofline': {
                 'bound': 'hbm',
-                'kernel': 'hmc_diag_normal_kernel<64,%d>' % ((D + 255) // 256),
+                'kernel': kernel_name,
                 'achieved': achieved,
                 'peak': HBM_PEAK_GBPS,
                 'unit': 'GB/s',

@@ -64,6 +64,12 @@ int zshmc_version(void);
 /* Largest n_data the fused diag-Normal kernel accepts. */
 int64_t zshmc_fused_max_n_data(void);
 
+/* Name of the kernel zshmc_hmc_diag_normal_step dispatches for 16-B aligned
+ * buffers of this shape ("hmc_diag_normal_ring_kernel<NCH,K,mass>" or
+ * "hmc_diag_normal_kernel<G,NCH,vec,mass>"), so that benchmarks and profiler
+ * summaries can name the kernel they measured.  Static storage, thread-local. */
+const char* zshmc_fused_kernel_name(int64_t n_data, int has_mass);
+
 /* ------------------------------------------------------------------------
  * Fused HMC transition for a diagonal-Normal log-joint
  *      log p(q_c) = sum_d  -0.5*log(2*pi) - logstd_d

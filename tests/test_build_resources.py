@@ -1,0 +1,98 @@
+"""The LDS-DMA ring kernel (zhusuan_amd/csrc/hmc_fused_ring.hip) guards its
+ring slots with hand-counted `s_waitcnt vmcnt(N)`.  That ledger is only valid
+if the compiler adds no VMEM of its own inside the kernel: no scratch spills
+(spill code is scratch_load/scratch_store = VMEM) for ANY instantiation.
+hipcc cross-compiles for gfx950 without a GPU, so this runs on CPU."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, 'zhusuan_amd', 'csrc', 'hmc_fused_ring.hip')
+
+
+def _hipcc():
+    for c in ('/opt/rocm/bin/hipcc', shutil.which('hipcc')):
+        if c and os.path.exists(c):
+            return c
+    pytest.skip('hipcc not available')
+
+
+@pytest.fixture(scope='module')
+def ring_build(tmp_path_factory):
+    out = tmp_path_factory.mktemp('ringasm')
+    import __graft_entry__ as ge
+    cmd = [_hipcc()] + ge.HIPCC_FLAGS + [
+        '-c', SRC, '-save-temps', '-Rpass-analysis=kernel-resource-usage',
+        '-o', str(out / 'ring.o')]
+    p = subprocess.run(cmd, cwd=str(out), stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, universal_newlines=True)
+    assert p.returncode == 0, p.stdout[-4000:]
+    asm = [f for f in os.listdir(str(out)) if f.endswith('gfx950.s')]
+    assert asm, os.listdir(str(out))
+    return p.stdout, open(os.path.join(str(out), asm[0])).read()
+
+
+def _kernels(remarks):
+    cur, table = None, {}
+    for line in remarks.splitlines():
+        m = re.search(r'Function Name: (\S+)', line)
+        if m:
+            cur = m.group(1)
+            table[cur] = {}
+            continue
+        m = re.search(r'    ([A-Za-z \[\]/]+): (\d+)', line)
+        if m and cur:
+            table[cur][m.group(1).strip()] = int(m.group(2))
+    return table
+
+
+def test_ring_kernels_have_no_spills(ring_build):
+    remarks, _ = ring_build
+    table = {k: v for k, v in _kernels(remarks).items()
+             if 'hmc_diag_normal_ring_kernel' in k}
+    # NCH = 1..8 with / without mass, minus <8, mass> (register-prefetch path)
+    assert len(table) == 15, sorted(table)
+    for name, row in table.items():
+        assert row['VGPRs Spill'] == 0, (name, row)
+        assert row['SGPRs Spill'] == 0, (name, row)
+        assert row['ScratchSize [bytes/lane]'] == 0, (name, row)
+
+
+def test_ring_trip_loop_has_only_hand_counted_vmem(ring_build):
+    """Inside each ring kernel every global_load_lds / row store / HMCInfo
+    store must come from an inline-asm statement (between ASMSTART/ASMEND);
+    compiler-issued VMEM is allowed only in the prologue (parameter loads)
+    and the epilogue (atomics)."""
+    _, asm = ring_build
+    n_kernels = 0
+    for m in re.finditer(r'^(_ZN5zshmc27hmc_diag_normal_ring_kernel\w+):[^\n]*\n(.*?)s_endpgm',
+                         asm, re.S | re.M):
+        n_kernels += 1
+        body = m.group(2)
+        assert 'scratch_' not in body and 'buffer_' not in body, m.group(1)
+        in_asm = False
+        first_dma = last_store = None
+        stray = []
+        for i, line in enumerate(body.splitlines()):
+            if '#ASMSTART' in line:
+                in_asm = True
+            elif '#ASMEND' in line:
+                in_asm = False
+            op = line.strip().split(' ')[0].split('\t')[0]
+            if op.startswith('global_load_lds'):
+                assert in_asm, (m.group(1), line)
+                first_dma = i if first_dma is None else first_dma
+            if op.startswith('global_store') and in_asm:
+                last_store = i
+            if op.startswith(('global_', 'flat_')) and not in_asm:
+                stray.append((i, op))
+        assert first_dma is not None and last_store is not None
+        # compiler VMEM may only sit before the first DMA or after the last
+        # hand-written store (epilogue atomics)
+        for i, op in stray:
+            assert i < first_dma or i > last_store, (m.group(1), i, op)
+    assert n_kernels == 15

@@ -71,10 +71,12 @@ void run(const char* name, K kern, int waves_per_simd) {
 }
 
 int main() {
-  for (int w = 1; w <= 2; ++w) {
+  for (int w : {3, 4, 8}) {
 #define R(k) run(#k, k, w)
-    R(k_fma); R(k_pk_fma); R(k_xor); R(k_add_u32); R(k_alignbit); R(k_mul_lo); R(k_mul_hi);
-    R(k_mad_u64); R(k_mul_u24); R(k_mul_i32_i24_pk); R(k_log); R(k_sin); R(k_sqrt); R(k_exp); R(k_rcp); R(k_cvt); R(k_fma_f64);
+    R(k_fma); R(k_pk_fma); R(k_xor); R(k_add_u32); R(k_mad_u64); R(k_log); R(k_cvt);
+#if 0
+    R(k_mul_u24);
+#endif
   }
   return 0;
 }

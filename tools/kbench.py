@@ -21,7 +21,8 @@ def load(path):
 def main():
     libs = [a for a in sys.argv[1:] if not a.startswith('--')]
     mass_on = '--mass' in sys.argv
-    C, D, L = 65536, 1024, 10
+    import os
+    C, D, L = 65536, 1024, int(os.environ.get('KB_L', '10'))
     dev = torch.device('cuda', 0)
     logstd = torch.linspace(-1, 1, D, device=dev)
     mean = torch.zeros(D, device=dev)

@@ -21,14 +21,14 @@ for f in find('%s_trace/**/*kernel_stats.csv' % tag):
             if i < 12:
                 lines.append('  ' + ', '.join(row))
 
-for sub in ('pmc_fetch', 'pmc_write', 'pmc_sq', 'pmc_sq2'):
+for sub in ('pmc_fetch', 'pmc_write', 'pmc_sq', 'pmc_sq2', 'pmc_sq3'):
     for f in find('%s_%s/**/*counter_collection.csv' % (tag, sub)):
         agg = {}
         with open(f) as fh:
             rd = csv.DictReader(fh)
             for row in rd:
                 k = row.get('Kernel_Name', '')
-                if 'hmc_diag_normal_kernel' not in k:
+                if 'hmc_diag_normal' not in k:
                     continue
                 c = row.get('Counter_Name')
                 v = float(row.get('Counter_Value', 0))

@@ -37,6 +37,7 @@ PROTOTYPES = {
     'zshmc_last_error': (c_char_p, []),
     'zshmc_version': (c_int, []),
     'zshmc_fused_max_n_data': (c_int64, []),
+    'zshmc_fused_kernel_name': (c_char_p, [c_int64, c_int]),
     'zshmc_hmc_diag_normal_step': (c_int, [
         _p, _p, _p, _p, _p, c_float, c_int64, c_int64, c_int64, c_int,
         c_uint64, c_uint32, c_int, _p, _p, _p, _p, _p, _p, _p, _p]),

@@ -46,6 +46,29 @@ __device__ __forceinline__ float group_sum(float v) {
   return v;
 }
 
+// Sum over the 64 lanes of a wave on the DPP data path (no LDS round trip):
+// inclusive scan inside each row of 16 lanes (row_shr 1,2,4,8), then the row
+// totals are chained with row_bcast15 / row_bcast31 (gfx9 DPP broadcasts), so
+// lane 63 holds the total, which is returned wave-uniform (in an SGPR).
+// The summation tree differs from group_sum<64>'s xor butterfly, so the two
+// agree to rounding, not bit for bit.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int moved = __builtin_amdgcn_update_dpp(
+      0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false);
+  return v + __builtin_bit_cast(float, moved);
+}
+__device__ __forceinline__ float wave_total_dpp(float v) {
+  v = dpp_add<0x111, 0xf>(v);  // row_shr:1
+  v = dpp_add<0x112, 0xf>(v);  // row_shr:2
+  v = dpp_add<0x114, 0xf>(v);  // row_shr:4
+  v = dpp_add<0x118, 0xf>(v);  // row_shr:8
+  v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 -> rows 1, 3
+  v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 -> rows 2, 3
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

@@ -20,37 +20,14 @@
 //
 // HBM traffic per chain: read q (4*D B) + write q (4*D B, only if accepted)
 // + 5 floats of HMCInfo: 8 B per element per transition.
+#include <stdlib.h>
+
 #include "common.h"
 #include "philox.h"
+#include "fused_args.h"
 
 namespace zshmc {
 
-constexpr float kHalfLog2PiNeg = -0.91893853320467274178f;  // -0.5*log(2*pi)
-
-struct FusedArgs {
-  float* q;
-  const float* mean;
-  const float* logstd;
-  const float* mass;
-  const float* step_size_dev;
-  float step_size_host;
-  int64_t n_chains;
-  int64_t n_data;
-  int64_t chain_offset;
-  int n_leapfrogs;
-  uint32_t k0, k1;
-  uint32_t iteration;
-  int commit;
-  float* acceptance_rate;
-  float* orig_hamiltonian;
-  float* hamiltonian;
-  float* orig_log_prob;
-  float* log_prob;
-  double* acc_sum;
-  uint32_t* flags;
-};
-
-typedef float f4 __attribute__((ext_vector_type(4)));
 
 template <bool VEC>
 __device__ __forceinline__ f4 load4(const float* __restrict__ base, int64_t d0,
@@ -102,6 +79,10 @@ __global__ __launch_bounds__(256, ZS_WAVES_PER_EU) void hmc_diag_normal_kernel(
       reinterpret_cast<double*>(s_mean + (HAS_MASS ? 2 : 1) * kPad);
   int* __restrict__ s_bad = reinterpret_cast<int*>(s_acc + 4);
 
+#ifdef ZS_TIMING
+  const unsigned long long t_start = wall_clock64();
+  unsigned long long n_done = 0;
+#endif
   const int lane = threadIdx.x & (kWave - 1);
   const int l = lane % G;    // lane within the chain group
   const int sub = lane / G;  // which chain of this wave
@@ -220,8 +201,13 @@ __global__ __launch_bounds__(256, ZS_WAVES_PER_EU) void hmc_diag_normal_kernel(
     for (int k = 0; k < NCH; ++k) {
       const uint32_t group = (uint32_t)(k * G + l);
       float z0, z1, z2, z3;
+#ifdef ZS_NO_RNG
+      z0 = __uint_as_float(0x3f000000u | ((group * 2654435761u + gchain) & 0x7fffffu));
+      z1 = z0 - 0.75f; z2 = 0.6f - z0; z3 = z0 * z1;
+#else
       normal4(group, gchain, a.iteration, kStreamMomentum, key0, key1, z0, z1,
               z2, z3);
+#endif
       p[k] = f4{z0, z1, z2, z3};
       if (HAS_MASS) {
         p[k] = p[k] * *reinterpret_cast<const f4*>(s_sqrtm + (k * G + l) * 4);
@@ -293,6 +279,9 @@ __global__ __launch_bounds__(256, ZS_WAVES_PER_EU) void hmc_diag_normal_kernel(
     const float u = uniform_chain(gchain, a.iteration, key0, key1);
     const bool accept = u < acc;  // strict, hmc.py:486
 
+#ifdef ZS_TIMING
+    ++n_done;
+#endif
     if (active && l == 0) acc_local += (double)acc;
     if (a.commit && active) {
       if (accept) {
@@ -312,6 +301,17 @@ __global__ __launch_bounds__(256, ZS_WAVES_PER_EU) void hmc_diag_normal_kernel(
     }
   }
 
+#ifdef ZS_TIMING
+  if (a.timing && lane == 0) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned long long* t = a.timing + wave_id * 4;
+    t[0] = t_start;
+    t[1] = wall_clock64();
+    t[2] = xcc & 0xf;
+    t[3] = n_done;
+  }
+#endif
   // ---- sum of acceptance rates: wave shuffle -> LDS -> one atomic/block --
   const double w = wave_sum_f64(acc_local);
   if (lane == 0) s_acc[threadIdx.x / kWave] = w;
@@ -392,6 +392,34 @@ using namespace zshmc;
 
 extern "C" int64_t zshmc_fused_max_n_data(void) { return kFusedMaxData; }
 
+extern "C" const char* zshmc_fused_kernel_name(int64_t n_data, int has_mass) {
+  static thread_local char buf[96];
+  int nch = 0, k = 0;
+  if (fused_ring_enabled() && fused_ring_config(n_data, has_mass != 0, &nch, &k)) {
+    snprintf(buf, sizeof(buf), "hmc_diag_normal_ring_kernel<%d,%d,%s>", nch, k,
+             has_mass ? "true" : "false");
+    return buf;
+  }
+  const int64_t ng = (n_data + 3) / 4;
+  int g = 64;
+  nch = 1;
+  if (ng <= 32) {
+    g = 1;
+    while (g < ng) g *= 2;
+  } else if (ng > 64) {
+    const int steps[] = {2, 3, 4, 6, 8};
+    nch = 8;
+    for (int st : steps)
+      if (ng <= 64 * st) {
+        nch = st;
+        break;
+      }
+  }
+  snprintf(buf, sizeof(buf), "hmc_diag_normal_kernel<%d,%d,%s,%s>", g, nch,
+           n_data % 4 == 0 ? "true" : "false", has_mass ? "true" : "false");
+  return buf;
+}
+
 extern "C" int zshmc_hmc_diag_normal_step(
     float* q, const float* mean, const float* logstd, const float* mass,
     const float* step_size_dev, float step_size_host, int64_t n_chains,
@@ -425,7 +453,7 @@ extern "C" int zshmc_hmc_diag_normal_step(
   a.k0 = (uint32_t)(seed & 0xFFFFFFFFull);
   a.k1 = (uint32_t)(seed >> 32);
   a.iteration = iteration;
-  a.commit = commit;
+  a.commit = commit ? 1 : 0;
   a.acceptance_rate = acceptance_rate;
   a.orig_hamiltonian = orig_hamiltonian;
   a.hamiltonian = hamiltonian;
@@ -433,7 +461,17 @@ extern "C" int zshmc_hmc_diag_normal_step(
   a.log_prob = log_prob;
   a.acc_sum = acc_sum;
   a.flags = flags;
+#ifdef ZS_TIMING
+  a.timing = reinterpret_cast<unsigned long long*>(orig_hamiltonian);  // debug
+  a.orig_hamiltonian = nullptr;
+#endif
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  // rows of more than 128 latents, 16-B aligned: the LDS-DMA ring kernel
+  // (ZSHMC_FUSED_RING=0 keeps the register-prefetch kernel, for A/B runs)
+  if (fused_ring_enabled()) {
+    const int rc = launch_fused_ring(a, s);
+    if (rc != ZSHMC_ERR_UNSUPPORTED) return rc;
+  }
   const int64_t ng = (n_data + 3) / 4;  // 4-element chunks per chain
   if (ng <= 1) return launch_cfg<1, 1>(a, s);
   if (ng <= 2) return launch_cfg<2, 1>(a, s);

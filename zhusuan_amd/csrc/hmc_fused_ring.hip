@@ -1,0 +1,584 @@
+// Fused HMC transition for a diagonal-Normal log-joint on gfx950 (MI355X):
+// the LDS-DMA ring variant for one-wave-per-chain rows (n_data > 128, rows
+// 16-B aligned).  Same arithmetic, same Philox counters and the same per-lane
+// summation order as hmc_fused_normal.hip (results are bit-identical); what
+// changes is how rows travel:
+//
+//   * each wave owns a ring of K row slots in LDS and keeps K rows of q in
+//     flight with `global_load_lds_dwordx4` (HBM -> LDS without touching
+//     VGPRs).  With one register-prefetched row per wave the kernel was
+//     latency-bound (3 waves/SIMD x 4 KiB = 48 KiB/CU in flight only part of
+//     the time); the ring holds K x 4 KiB per wave in flight all the time and
+//     gives the 4*NCH prefetch registers back, which buys a fourth wave/SIMD.
+//   * ONE workgroup per CU (all the waves the register budget allows) owns a
+//     contiguous range of chains and its waves draw the next chain from an
+//     LDS ticket counter.  With a static split the oldest wave of each SIMD
+//     won the VALU arbitration and finished at ~55 % of the kernel, leaving
+//     the SIMD to one latency-bound wave at the end (waves ended between 55 %
+//     and 100 % of the span); tickets make all waves of a CU finish within
+//     one chain of each other.
+//   * rejected chains cost no write: the row store is predicated by EXEC
+//     inside the asm statement (never branched around), so every trip issues
+//     exactly NCH DMA loads + NCH stores and the `s_waitcnt vmcnt(N)` that
+//     guards a slot can be a compile-time count (gfx9 returns VMEM in order;
+//     EXEC=0 VMEM still passes through the counter -- probed on hardware,
+//     tools/glds_probe.hip).
+//
+// vmcnt ledger (per wave; D(i) = NCH DMA loads of the row of trip i, S(i) =
+// NCH row stores + 5 HMCInfo scalar stores, all EXEC-predicated asm):
+//   prologue D0..D(K-1) | trip i: wait D(i); ds_read slot; D(i+K); compute;
+//   S(i).  Issued after D(i) when trip i waits:
+//   S(i-K) D(i+1) S(i-K+1) ... D(i+K-1) S(i-1) = (K-1)*NCH + K*(NCH+5), i >= K
+//   and at least (K-1)*NCH for i < K (the conservative count used there).
+// The kernel body must compile without scratch spills and without any
+// compiler-issued VMEM inside the trip loop (tests/test_build_resources.py).
+//
+// Reference semantics: zhusuan/hmc.py:21-61, :348-372, :479-498;
+// distributions/univariate.py:174-181; distributions/base.py:302-304.
+#include <stdlib.h>
+
+#include "common.h"
+#include "fused_args.h"
+#include "philox.h"
+
+namespace zshmc {
+
+// cache-policy suffixes of the row traffic (A/B knobs; rows are read once and
+// written once per launch, so neither side wants to stay in L2)
+// ZS_LD_POL / ZS_ST_POL: 0 = default, 1 = nt, 2 = sc0 sc1, 3 = sc1
+#ifndef ZS_LD_POL
+#define ZS_LD_POL 0
+#endif
+#ifndef ZS_ST_POL
+#define ZS_ST_POL 0
+#endif
+#define ZS_POL_STR_0 ""
+#define ZS_POL_STR_1 " nt"
+#define ZS_POL_STR_2 " sc0 sc1"
+#define ZS_POL_STR_3 " sc1"
+#define ZS_POL_CAT(x) ZS_POL_STR_##x
+#define ZS_POL(x) ZS_POL_CAT(x)
+#define ZS_LD_POLICY ZS_POL(ZS_LD_POL)
+#define ZS_ST_POLICY ZS_POL(ZS_ST_POL)
+#ifndef ZS_RING_K4
+#define ZS_RING_K4 2  // ring depth at NCH = 4 (n_data 772..1024)
+#endif
+#ifndef ZS_RING_WAVES
+#define ZS_RING_WAVES 4  // waves per SIMD at NCH = 4 without mass
+#endif
+
+// ---- hand-counted VMEM primitives -----------------------------------------
+// global -> LDS, 16 B per lane: LDS[m0 + OFF + lane*16] <- sbase[voff + OFF].
+// The 5 wait states in front cover "VALU wrote an SGPR that VMEM reads".
+// EXEC masks travel as two 32-bit SGPR halves (readfirstlane results), which
+// is the only form hipcc reliably keeps in scalar registers.
+struct Mask {
+  uint32_t lo, hi;
+};
+
+template <int OFF>
+__device__ __forceinline__ void dma16(uint32_t voff, const float* sbase,
+                                      uint32_t lds_addr, Mask mask) {
+  uint32_t keep;
+  uint64_t saved;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b64 %1, exec\n\t"
+      "s_and_b32 exec_lo, exec_lo, %5\n\t"
+      "s_and_b32 exec_hi, exec_hi, %6\n\t"
+      "s_mov_b32 m0, %4\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %2, %3 offset:%7" ZS_LD_POLICY "\n\t"
+      "s_mov_b64 exec, %1\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep), "=&s"(saved)
+      : "v"(voff), "s"(sbase), "s"(lds_addr), "s"(mask.lo), "s"(mask.hi),
+        "n"(OFF)
+      : "memory", "scc");
+}
+
+template <int OFF>
+__device__ __forceinline__ void store16(uint32_t voff, f4 data, float* sbase,
+                                        Mask mask) {
+  uint64_t saved;
+  asm volatile(
+      "s_mov_b64 %0, exec\n\t"
+      "s_and_b32 exec_lo, exec_lo, %4\n\t"
+      "s_and_b32 exec_hi, exec_hi, %5\n\t"
+      "s_nop 1\n\t"
+      "global_store_dwordx4 %1, %2, %3 offset:%6" ZS_ST_POLICY "\n\t"
+      "s_mov_b64 exec, %0"
+      : "=&s"(saved)
+      : "v"(voff), "v"(data), "s"(sbase), "s"(mask.lo), "s"(mask.hi), "n"(OFF)
+      : "memory", "scc");
+}
+
+// the five per-chain HMCInfo scalars: lane 0 only, array k written iff its
+// pointer is non-null and commit01 == 1; always 5 VMEM instructions, so they
+// sit in the ledger like S(i).  (The enables are derived from the kernel
+// arguments inside the statement: hipcc moves pre-computed 0/1 flags to VGPRs.)
+__device__ __forceinline__ void store_info5(uint32_t vc, float v0, float v1,
+                                            float v2, float v3, float v4,
+                                            float* p0, float* p1, float* p2,
+                                            float* p3, float* p4,
+                                            uint32_t commit01) {
+  uint64_t saved;
+  asm volatile(
+      "s_mov_b64 %0, exec\n\t"
+      "s_mov_b32 exec_hi, 0\n\t"
+      "s_cmp_lg_u64 %7, 0\n\t"
+      "s_cselect_b32 exec_lo, %12, 0\n\t"
+      "s_nop 1\n\t"
+      "global_store_dword %1, %2, %7\n\t"
+      "s_cmp_lg_u64 %8, 0\n\t"
+      "s_cselect_b32 exec_lo, %12, 0\n\t"
+      "s_nop 1\n\t"
+      "global_store_dword %1, %3, %8\n\t"
+      "s_cmp_lg_u64 %9, 0\n\t"
+      "s_cselect_b32 exec_lo, %12, 0\n\t"
+      "s_nop 1\n\t"
+      "global_store_dword %1, %4, %9\n\t"
+      "s_cmp_lg_u64 %10, 0\n\t"
+      "s_cselect_b32 exec_lo, %12, 0\n\t"
+      "s_nop 1\n\t"
+      "global_store_dword %1, %5, %10\n\t"
+      "s_cmp_lg_u64 %11, 0\n\t"
+      "s_cselect_b32 exec_lo, %12, 0\n\t"
+      "s_nop 1\n\t"
+      "global_store_dword %1, %6, %11\n\t"
+      "s_mov_b64 exec, %0"
+      : "=&s"(saved)
+      : "v"(vc), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "s"(p0), "s"(p1),
+        "s"(p2), "s"(p3), "s"(p4), "s"(commit01)
+      : "memory", "scc");
+}
+constexpr int kInfoStores = 5;
+
+// pin a wave-uniform value into SGPRs (the "s" asm constraint does not insert
+// the readfirstlane itself)
+__device__ __forceinline__ uint32_t uni32(uint32_t x) {
+  return __builtin_amdgcn_readfirstlane(x);
+}
+__device__ __forceinline__ int64_t uni64(int64_t x) {
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)x >> 32));
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+// all-ones / all-zeros EXEC mask from a wave-uniform condition
+__device__ __forceinline__ Mask mask_if(bool c) {
+#ifdef ZS_NO_MEM  // A/B probe only: VMEM issued with EXEC = 0 (compute-only time)
+  c = false;
+#endif
+  const uint32_t f = uni32(c ? 0xFFFFFFFFu : 0u);
+  return Mask{f, f};
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// chunk k of a row: imm offsets reach 4095 B, so chunks 4..7 go through a
+// second base 4096 B further on (global and LDS side alike)
+template <int NCH, int k = 0>
+__device__ __forceinline__ void issue_row(uint32_t voff, uint32_t voff_last,
+                                          const float* srow, uint32_t slot_addr,
+                                          Mask on) {
+  if constexpr (k < NCH - 1) {
+    dma16<(k & 3) * 1024>(voff, srow + (k >> 2) * 1024,
+                          slot_addr + (k >> 2) * 4096, on);
+    issue_row<NCH, k + 1>(voff, voff_last, srow, slot_addr, on);
+  } else {
+    // last chunk: lanes beyond n_data read the row's first 16 B (in bounds)
+    dma16<0>(voff_last, srow, slot_addr + (NCH - 1) * 1024, on);
+  }
+}
+
+// q' = r + mean, chunk by chunk (mean from the LDS tile)
+template <int NCH, int k = 0>
+__device__ __forceinline__ void store_row(uint32_t voff, uint32_t voff_last,
+                                          const f4* r, const float* s_mean_l,
+                                          float* srow, Mask on,
+                                          Mask on_last) {
+  const f4 out =
+      r[k] + *reinterpret_cast<const f4*>(s_mean_l + k * kWave * 4);
+  if constexpr (k < NCH - 1) {
+    store16<(k & 3) * 1024>(voff, out, srow + (k >> 2) * 1024, on);
+    store_row<NCH, k + 1>(voff, voff_last, r, s_mean_l, srow, on, on_last);
+  } else {
+    store16<0>(voff_last, out, srow, on_last);
+  }
+}
+
+// Waves per SIMD = the register budget that compiles WITHOUT scratch spills
+// (a spill is a VMEM instruction the vmcnt ledger does not know about;
+// tests/test_build_resources.py asserts "VGPRs Spill: 0" per instantiation).
+constexpr int ring_waves_for(int nch, bool has_mass) {
+  return nch <= 3 ? 4
+                  : (nch == 4 ? (has_mass ? 3 : ZS_RING_WAVES)
+                              : (nch == 5 && !has_mass ? 3 : 2));
+}
+
+template <int NCH, int K, bool HAS_MASS>
+__global__ __launch_bounds__(256 * ring_waves_for(NCH, HAS_MASS)) void
+hmc_diag_normal_ring_kernel(FusedArgs a) {
+  constexpr int kRow = NCH * 256;  // padded row length (floats) of one chain
+  constexpr int kRowB = kRow * 4;
+  constexpr int kWavesPerBlock = 4 * ring_waves_for(NCH, HAS_MASS);  // a CU
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* __restrict__ s_mean = reinterpret_cast<float*>(smem);
+  float* __restrict__ s_sqrtm = s_mean + kRow;  // only if HAS_MASS
+  float* __restrict__ s_ring = s_mean + (HAS_MASS ? 2 : 1) * kRow;
+  double* __restrict__ s_acc =
+      reinterpret_cast<double*>(s_ring + kWavesPerBlock * K * kRow);
+  int* __restrict__ s_bad = reinterpret_cast<int*>(s_acc + kWavesPerBlock);
+  int* __restrict__ s_ticket = s_bad + 1;
+
+#ifdef ZS_TIMING
+  const unsigned long long t_start = wall_clock64();
+  const unsigned long long c_start = clock64();
+#endif
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+#ifdef ZS_TIMING
+  const int64_t wave_id = (int64_t)blockIdx.x * kWavesPerBlock + wib;
+#endif
+  const int64_t D = a.n_data;
+  const int64_t C = a.n_chains;
+
+  // ---- stage mean / sqrt(mass) in LDS (zero padding beyond n_data) --------
+  for (int d = threadIdx.x; d < kRow; d += blockDim.x) {
+    s_mean[d] = d < D ? a.mean[d] : 0.f;
+    if (HAS_MASS) s_sqrtm[d] = d < D ? sqrtf(a.mass[d]) : 0.f;
+  }
+  if (threadIdx.x == 0) {
+    *s_bad = 0;
+    *s_ticket = 0;
+  }
+
+  const float eps = a.step_size_dev ? *a.step_size_dev : a.step_size_host;
+  const bool moving = eps != 0.f;
+  const float se = moving ? eps : 1.f;
+  const float inv_se = 1.0f / se;
+
+  // ---- per-latent parameters kept in registers ---------------------------
+  f4 nep[NCH];  // -se * exp(-2*logstd)   (precision: univariate.py:178)
+  f4 eim[NCH];  //  se / mass             (only if HAS_MASS)
+  float logz_part = 0.f;
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    const int64_t d0 = (int64_t)(k * kWave + lane) * 4;
+    const bool valid = d0 < D;  // n_data % 4 == 0: a chunk is all in or out
+    f4 ls = f4{0.f, 0.f, 0.f, 0.f}, m = f4{1.f, 1.f, 1.f, 1.f};
+    if (valid) {
+      ls = *reinterpret_cast<const f4*>(a.logstd + d0);
+      if (HAS_MASS) m = *reinterpret_cast<const f4*>(a.mass + d0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      // padding gets precision 0 and inverse mass 0: no contribution anywhere
+      nep[k][j] = valid ? -se * expf(-2.0f * ls[j]) : 0.f;
+      logz_part += valid ? (kHalfLog2PiNeg - ls[j]) : 0.f;
+      if (HAS_MASS) eim[k][j] = valid ? se / m[j] : 0.f;
+    }
+  }
+  const float logz = wave_total_dpp(logz_part);
+  const int Lr = moving ? a.n_leapfrogs : 0;
+  const float hk = moving ? 0.5f : 0.f;    // first half kick
+  const float hk2 = Lr >= 1 ? 0.5f : 0.f;  // taken back from the last
+  // every compiler-issued load above has been consumed: from here on the
+  // loop's VMEM traffic is the hand-counted asm only
+  __syncthreads();  // LDS tile ready
+
+  // ---- this workgroup's contiguous chain range; tickets index into it ----
+  const int64_t nblk = gridDim.x, blk = blockIdx.x;
+  const int64_t cpb = C / nblk, rem = C % nblk;
+  const int64_t start = uni64(blk * cpb + (blk < rem ? blk : rem));
+  const int count = (int)uni32((uint32_t)(cpb + (blk < rem ? 1 : 0)));
+  const int64_t last_row = C - 1;
+  auto draw = [&]() -> int {  // next ticket of this workgroup (wave-uniform)
+    int t = 0;
+    if (lane == 0) t = atomicAdd(s_ticket, 1);
+    return (int)uni32((uint32_t)t);
+  };
+
+  float* __restrict__ ring_w = s_ring + wib * K * kRow;
+  const uint32_t ring_addr = __builtin_amdgcn_readfirstlane(
+      (uint32_t)reinterpret_cast<uintptr_t>(ring_w));
+  const uint32_t voff = (uint32_t)lane * 16u;
+  const bool valid_last = (int64_t)((NCH - 1) * kWave + lane) * 4 < D;
+  const uint32_t voff_last =
+      valid_last ? (uint32_t)((NCH - 1) * kWave + lane) * 16u : 0u;
+  const uint64_t b_last = __ballot(valid_last);
+  const Mask m_last{uni32((uint32_t)b_last), uni32((uint32_t)(b_last >> 32))};
+
+  // ---- prologue: draw K tickets, fill the ring ---------------------------
+  int tk[K];  // tk[0] = the chain this trip works on, tk[j] = j trips ahead
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    tk[j] = draw();
+    int64_t row = start + tk[j];
+    row = row < last_row ? row : last_row;
+    issue_row<NCH>(voff, voff_last, a.q + uni64(row * D),
+                   ring_addr + j * kRowB, mask_if(tk[j] < count));
+  }
+
+  double acc_local = 0.0;
+  bool bad_old = false;
+#ifdef ZS_TIMING
+  unsigned long long n_done = 0;
+#endif
+  int slot = 0;
+  for (int it = 0; tk[0] < count; ++it) {
+    const int64_t chain = start + tk[0];
+    float* __restrict__ qrow = a.q + uni64(chain * D);
+    const uint32_t gchain = (uint32_t)(chain + a.chain_offset);
+
+    // the ticket for the slot this trip frees (LDS atomic: its latency hides
+    // behind the wait and the slot read)
+    int nt_raw = 0;
+    if (lane == 0) nt_raw = atomicAdd(s_ticket, 1);
+
+    // ---- wait for D(it), r = q - mean, refill the slot with D(it+K) -------
+    if (it < K)
+      wait_vmcnt<(K - 1) * NCH>();
+    else
+      wait_vmcnt<(K - 1) * NCH + K * (NCH + kInfoStores)>();
+    f4 r[NCH], p[NCH];
+    {
+      const float* __restrict__ sl = ring_w + slot * kRow;
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) {
+        const f4 qv = *reinterpret_cast<const f4*>(sl + (k * kWave + lane) * 4);
+        const f4 mu =
+            *reinterpret_cast<const f4*>(s_mean + (k * kWave + lane) * 4);
+        r[k] = qv - mu;
+      }
+      // the slot must be in registers before the DMA may overwrite it
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const int nt = (int)uni32((uint32_t)nt_raw);
+      int64_t nrow = start + nt;
+      nrow = nrow < last_row ? nrow : last_row;
+      issue_row<NCH>(voff, voff_last, a.q + uni64(nrow * D),
+                     uni32(ring_addr + (uint32_t)slot * kRowB),
+                     mask_if(nt < count));
+      slot = slot + 1 == K ? 0 : slot + 1;
+#pragma unroll
+      for (int j = 0; j + 1 < K; ++j) tk[j] = tk[j + 1];
+      tk[K - 1] = nt;
+    }
+
+    // ---- momentum resample (hmc.py:21-23, :458), initial energies and the
+    // first half kick (trip i = 0 of hmc.py:352-364), chunk by chunk.
+    // grad log p = -prec * r; with nep = -eps*prec a kick of s2 is
+    // p += (s2/eps) * (nep * r), a drift is r += eps * p / m.
+    uint32_t key0 = a.k0, key1 = a.k1;
+    asm volatile("" : "+s"(key0), "+s"(key1));
+    f4 ko = f4{0.f, 0.f, 0.f, 0.f}, uo = ko;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const uint32_t group = (uint32_t)(k * kWave + lane);
+      float z0, z1, z2, z3;
+#ifdef ZS_NO_RNG  // A/B probe only: how much of the trip is the generator
+      z0 = __uint_as_float(0x3f000000u | ((group * 2654435761u + gchain) & 0x7fffffu));
+      z1 = z0 - 0.75f; z2 = 0.6f - z0; z3 = z0 * z1;
+#else
+      normal4(group, gchain, a.iteration, kStreamMomentum, key0, key1, z0, z1,
+              z2, z3);
+#endif
+      p[k] = f4{z0, z1, z2, z3};
+      if (HAS_MASS) {
+        p[k] = p[k] *
+               *reinterpret_cast<const f4*>(s_sqrtm + (k * kWave + lane) * 4);
+        ko += (p[k] * p[k]) * eim[k];
+      } else {
+        if (k == NCH - 1 && !valid_last) p[k] = f4{0.f, 0.f, 0.f, 0.f};
+        ko += p[k] * p[k];
+      }
+      const f4 t = nep[k] * r[k];
+      uo += t * r[k];
+      p[k] += hk * t;
+#ifdef ZS_RING_SERIAL_RNG
+      // one generator state live at a time (register budget for 4 waves/SIMD)
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+
+    // ---- leapfrog (hmc.py:348-372): L full drifts + full kicks; half of the
+    // last kick is taken back below ----------------------------------------
+    for (int i = 0; i < Lr; ++i) {
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) {
+        if (HAS_MASS)
+          r[k] += eim[k] * p[k];
+        else
+          r[k] += eps * p[k];
+        p[k] += nep[k] * r[k];
+      }
+    }
+
+    // ---- Hamiltonians (hmc.py:30-35) and acceptance (hmc.py:46-61) -------
+    f4 kn = f4{0.f, 0.f, 0.f, 0.f}, un = kn;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const f4 t = nep[k] * r[k];
+      un += t * r[k];
+      p[k] -= hk2 * t;
+      if (HAS_MASS)
+        kn += (p[k] * p[k]) * eim[k];
+      else
+        kn += p[k] * p[k];
+    }
+    float k_old = (ko[0] + ko[1]) + (ko[2] + ko[3]);
+    float u_old = (uo[0] + uo[1]) + (uo[2] + uo[3]);
+    float k_new = (kn[0] + kn[1]) + (kn[2] + kn[3]);
+    float u_new = (un[0] + un[1]) + (un[2] + un[3]);
+#ifndef ZS_NO_REDUCE  // A/B probe only
+    k_old = wave_total_dpp(k_old);
+    u_old = wave_total_dpp(u_old);
+    k_new = wave_total_dpp(k_new);
+    u_new = wave_total_dpp(u_new);
+#endif
+    if (HAS_MASS) {  // sum p^2/m = (1/se) sum p^2 * (se/m)
+      k_old *= inv_se;
+      k_new *= inv_se;
+    }
+    const float lp_old = logz + 0.5f * inv_se * u_old;
+    const float lp_new = logz + 0.5f * inv_se * u_new;
+    const float h_old = -lp_old + 0.5f * k_old;
+    const float h_new = -lp_new + 0.5f * k_new;
+    const float dh = h_old - h_new;
+    float acc = expf(fminf(dh, 0.0f));
+    // fminf drops a NaN operand: test explicitly (hmc.py:56-59)
+    if (!(dh == dh) || !isfinite(acc) || !isfinite(lp_new)) acc = 0.f;
+    if (!isfinite(lp_old)) bad_old = true;
+
+#ifdef ZS_NO_UNIF  // A/B probe only
+    const float u = 0.5f;
+#else
+    const float u = uniform_chain(gchain, a.iteration, key0, key1);
+#endif
+    const bool accept = u < acc;  // strict, hmc.py:486
+
+    if (lane == 0) acc_local += (double)acc;
+#ifdef ZS_TIMING
+    ++n_done;
+#endif
+
+    // ---- MH select: the accepted row goes back in place (hmc.py:487-497);
+    // EXEC-predicated, so a rejected chain issues the same NCH (empty) stores
+    {
+      const Mask m_acc = mask_if(accept && a.commit != 0);
+      store_row<NCH>(voff, voff_last, r, s_mean + lane * 4, qrow, m_acc,
+                     Mask{m_acc.lo & m_last.lo, m_acc.hi & m_last.hi});
+    }
+
+    // ---- the five HMCInfo scalars of this chain (lane 0; hmc.py:508-517) --
+    store_info5((uint32_t)chain * 4u, acc, h_old, h_new, lp_old,
+                accept ? lp_new : lp_old, a.acceptance_rate,
+                a.orig_hamiltonian, a.hamiltonian, a.orig_log_prob, a.log_prob,
+                (uint32_t)a.commit);
+  }
+  // no DMA may outlive the wave (its LDS would be handed to another block)
+  wait_vmcnt<0>();
+#ifdef ZS_TIMING
+  if (a.timing && lane == 0) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned long long* t = a.timing + wave_id * 4;
+    t[0] = t_start;
+    t[1] = wall_clock64();
+    t[2] = (xcc & 0xf) | ((clock64() - c_start) << 8);
+    t[3] = (unsigned long long)n_done;
+  }
+#endif
+
+  // ---- sum of acceptance rates: wave shuffle -> LDS -> one atomic/block --
+  const double w = wave_sum_f64(acc_local);
+  if (lane == 0) s_acc[wib] = w;
+  if (bad_old) *s_bad = 1;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot = 0.0;
+    for (int i = 0; i < kWavesPerBlock; ++i) tot += s_acc[i];
+    if (a.acc_sum) atomicAdd(a.acc_sum, tot);
+    if (*s_bad && a.flags) atomicOr(a.flags, ZSHMC_FLAG_OLD_LOGPROB_NONFINITE);
+  }
+}
+
+constexpr size_t kLdsLimit = 160 * 1024;
+
+template <int NCH, int K, bool HAS_MASS>
+static int launch_ring_cfg(const FusedArgs& a, hipStream_t stream) {
+  constexpr int kWaves = 4 * ring_waves_for(NCH, HAS_MASS);
+  constexpr size_t lds = (size_t)((HAS_MASS ? 2 : 1) + kWaves * K) * NCH * 1024 +
+                         kWaves * sizeof(double) + 16;
+  static_assert(lds <= kLdsLimit, "ring does not fit in LDS");
+  static bool ready = false;
+  if (!ready) {
+    // the ring needs more than the default 64 KiB dynamic-LDS cap
+    hipError_t e = hipFuncSetAttribute(
+        reinterpret_cast<const void*>(
+            hmc_diag_normal_ring_kernel<NCH, K, HAS_MASS>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return check_hip(e, "ring kernel: LDS size attribute");
+    ready = true;
+  }
+  // one workgroup per CU; fewer when there are not even that many chains
+  const int64_t cus = device_cu_count();
+  const int grid = (int)(a.n_chains < cus ? a.n_chains : cus);
+  hipLaunchKernelGGL((hmc_diag_normal_ring_kernel<NCH, K, HAS_MASS>),
+                     dim3(grid > 0 ? grid : 1), dim3(64 * kWaves), lds, stream,
+                     a);
+  ZS_LAUNCH_CHECK("hmc_diag_normal_ring_kernel launch");
+  return ZSHMC_OK;
+}
+
+template <int NCH, int K>
+static int launch_ring_k(const FusedArgs& a, hipStream_t stream) {
+  return a.mass ? launch_ring_cfg<NCH, K, true>(a, stream)
+                : launch_ring_cfg<NCH, K, false>(a, stream);
+}
+
+bool fused_ring_config(int64_t D, bool has_mass, int* nch_out, int* k_out) {
+  if (D % 4 != 0 || D <= 128 || D > 2048) return false;
+  // NCH = ceil(D / 256) exactly: only the LAST 1 KiB chunk of a row may be
+  // ragged (that is what voff_last / m_last handle)
+  const int nch = (int)((D + 255) / 256);
+  // 8 chunks + mass does not fit 256 VGPRs without scratch spills (VMEM the
+  // ledger cannot count): that shape stays on the register-prefetch kernel
+  if (nch == 8 && has_mass) return false;
+  *nch_out = nch;
+  *k_out = nch <= 3 ? 3 : (nch == 4 ? ZS_RING_K4 : 2);
+  return true;
+}
+
+bool fused_ring_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("ZSHMC_FUSED_RING");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
+int launch_fused_ring(const FusedArgs& a, hipStream_t stream) {
+  int nch = 0, k = 0;
+  const bool ok = fused_ring_config(a.n_data, a.mass != nullptr, &nch, &k) &&
+                  ((reinterpret_cast<uintptr_t>(a.q) & 15) == 0) &&
+                  ((reinterpret_cast<uintptr_t>(a.logstd) & 15) == 0) &&
+                  (!a.mass || (reinterpret_cast<uintptr_t>(a.mass) & 15) == 0) &&
+                  a.n_chains + 0 < (1ll << 30);  // 4*chain fits 32 bits
+  if (!ok) return ZSHMC_ERR_UNSUPPORTED;
+  switch (nch) {
+    case 1: return launch_ring_k<1, 3>(a, stream);
+    case 2: return launch_ring_k<2, 3>(a, stream);
+    case 3: return launch_ring_k<3, 3>(a, stream);
+    case 4: return launch_ring_k<4, ZS_RING_K4>(a, stream);
+    case 5: return launch_ring_k<5, 2>(a, stream);
+    case 6: return launch_ring_k<6, 2>(a, stream);
+    case 7: return launch_ring_k<7, 2>(a, stream);
+    default: return launch_ring_cfg<8, 2, false>(a, stream);
+  }
+}
+
+}  // namespace zshmc
