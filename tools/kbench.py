@@ -34,14 +34,26 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     eps = 0.9 if mass_on else 0.14
 
+    full = os.environ.get('KB_INFO', '1') != '0'   # all HMCInfo outputs, as the API
+    extra = [torch.zeros(C, device=dev) for _ in range(4)]
+    flags = torch.zeros(1, dtype=torch.int32, device=dev)
+    eps_dev = torch.full((1,), eps, device=dev)
+
     def run(fn, q, it):
-        rc = fn(q.data_ptr(), mean.data_ptr(), logstd.data_ptr(),
-                None if mass is None else mass.data_ptr(), None, eps, C, D, 0,
-                L, 1, it, 1, acc.data_ptr(), None, None, None, None,
-                acc_sum.data_ptr(), None, stream)
+        if full:
+            rc = fn(q.data_ptr(), mean.data_ptr(), logstd.data_ptr(),
+                    None if mass is None else mass.data_ptr(), eps_dev.data_ptr(), 0.0, C, D, 0,
+                    L, 1, it, 1, acc.data_ptr(), extra[0].data_ptr(), extra[1].data_ptr(),
+                    extra[2].data_ptr(), extra[3].data_ptr(), acc_sum.data_ptr(), flags.data_ptr(),
+                    stream)
+        else:
+            rc = fn(q.data_ptr(), mean.data_ptr(), logstd.data_ptr(),
+                    None if mass is None else mass.data_ptr(), None, eps, C, D, 0,
+                    L, 1, it, 1, acc.data_ptr(), None, None, None, None,
+                    acc_sum.data_ptr(), None, stream)
         assert rc == 0
     res = {p: [] for p, _ in fns}
-    for rep in range(3):
+    for rep in range(int(os.environ.get("KB_REPS", "3"))):
         for p, fn in fns:
             q = q0.clone()
             for i in range(5):

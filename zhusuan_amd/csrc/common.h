@@ -69,6 +69,33 @@ __device__ __forceinline__ float wave_total_dpp(float v) {
       float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// four totals at once, the scan steps interleaved so that consecutive DPP
+// instructions are independent (a DPP read of a just-written VGPR costs two
+// wait states)
+__device__ __forceinline__ void wave_total4_dpp(float& a, float& b, float& c,
+                                                float& d) {
+#define ZS_DPP_STEP(CTRL, MASK) \
+  a = dpp_add<CTRL, MASK>(a);   \
+  b = dpp_add<CTRL, MASK>(b);   \
+  c = dpp_add<CTRL, MASK>(c);   \
+  d = dpp_add<CTRL, MASK>(d);
+  ZS_DPP_STEP(0x111, 0xf)
+  ZS_DPP_STEP(0x112, 0xf)
+  ZS_DPP_STEP(0x114, 0xf)
+  ZS_DPP_STEP(0x118, 0xf)
+  ZS_DPP_STEP(0x142, 0xa)
+  ZS_DPP_STEP(0x143, 0xc)
+#undef ZS_DPP_STEP
+  a = __builtin_bit_cast(
+      float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), 63));
+  b = __builtin_bit_cast(
+      float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, b), 63));
+  c = __builtin_bit_cast(
+      float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c), 63));
+  d = __builtin_bit_cast(
+      float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), 63));
+}
+
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

@@ -30,6 +30,10 @@ struct FusedArgs {
   float* log_prob;
   double* acc_sum;
   uint32_t* flags;
+  // ring kernel only (set by its launcher): HMCInfo scalars staged in LDS
+  // (info_cap chains per workgroup) or stored straight from the trip loop
+  int info_cap;          // 0 = no staging
+  uint32_t commit_direct;  // commit && !staging: enables the in-loop stores
 #ifdef ZS_TIMING
   unsigned long long* timing;  // [n_waves][4]: start, end, xcc, chains
 #endif

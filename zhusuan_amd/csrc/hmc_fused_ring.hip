@@ -10,9 +10,9 @@
 //     latency-bound (3 waves/SIMD x 4 KiB = 48 KiB/CU in flight only part of
 //     the time); the ring holds K x 4 KiB per wave in flight all the time and
 //     gives the 4*NCH prefetch registers back, which buys a fourth wave/SIMD.
-//   * ONE workgroup per CU (all the waves the register budget allows) owns a
-//     contiguous range of chains and its waves draw the next chain from an
-//     LDS ticket counter.  With a static split the oldest wave of each SIMD
+//   * ONE workgroup per CU (all the waves the register budget allows) owns
+//     every nblk-th run of 16 chains and its waves draw the next chain from
+//     an LDS ticket counter.  With a static split the oldest wave of each SIMD
 //     won the VALU arbitration and finished at ~55 % of the kernel, leaving
 //     the SIMD to one latency-bound wave at the end (waves ended between 55 %
 //     and 100 % of the span); tickets make all waves of a CU finish within
@@ -60,6 +60,9 @@ namespace zshmc {
 #define ZS_POL(x) ZS_POL_CAT(x)
 #define ZS_LD_POLICY ZS_POL(ZS_LD_POL)
 #define ZS_ST_POLICY ZS_POL(ZS_ST_POL)
+#ifndef ZS_RING_GRANULE
+#define ZS_RING_GRANULE 16  // consecutive chains per workgroup turn (16 = one
+#endif                      // 64-B line of each HMCInfo array)
 #ifndef ZS_RING_K4
 #define ZS_RING_K4 2  // ring depth at NCH = 4 (n_data 772..1024)
 #endif
@@ -154,6 +157,25 @@ __device__ __forceinline__ void store_info5(uint32_t vc, float v0, float v1,
 }
 constexpr int kInfoStores = 5;
 
+// next ticket of the workgroup: LDS atomic issued by lane 0 only, NOT waited
+// for -- the caller's next `s_waitcnt lgkmcnt(0)` (which must name the result
+// as an in/out operand) lands it; read it with uni32 afterwards.
+__device__ __forceinline__ uint32_t ticket_issue(uint32_t lds_addr) {
+  uint32_t t;
+  uint64_t saved;
+  asm volatile(
+      "s_mov_b64 %1, exec\n\t"
+      "s_mov_b64 exec, 1\n\t"
+      "v_mov_b32 %0, 1\n\t"
+      "s_nop 0\n\t"
+      "ds_add_rtn_u32 %0, %2, %0\n\t"
+      "s_mov_b64 exec, %1"
+      : "=&v"(t), "=&s"(saved)
+      : "v"(lds_addr)
+      : "memory");
+  return t;
+}
+
 // pin a wave-uniform value into SGPRs (the "s" asm constraint does not insert
 // the readfirstlane itself)
 __device__ __forceinline__ uint32_t uni32(uint32_t x) {
@@ -194,19 +216,15 @@ __device__ __forceinline__ void issue_row(uint32_t voff, uint32_t voff_last,
   }
 }
 
-// q' = r + mean, chunk by chunk (mean from the LDS tile)
 template <int NCH, int k = 0>
 __device__ __forceinline__ void store_row(uint32_t voff, uint32_t voff_last,
-                                          const f4* r, const float* s_mean_l,
-                                          float* srow, Mask on,
+                                          const f4* out, float* srow, Mask on,
                                           Mask on_last) {
-  const f4 out =
-      r[k] + *reinterpret_cast<const f4*>(s_mean_l + k * kWave * 4);
   if constexpr (k < NCH - 1) {
-    store16<(k & 3) * 1024>(voff, out, srow + (k >> 2) * 1024, on);
-    store_row<NCH, k + 1>(voff, voff_last, r, s_mean_l, srow, on, on_last);
+    store16<(k & 3) * 1024>(voff, out[k], srow + (k >> 2) * 1024, on);
+    store_row<NCH, k + 1>(voff, voff_last, out, srow, on, on_last);
   } else {
-    store16<0>(voff_last, out, srow, on_last);
+    store16<0>(voff_last, out[k], srow, on_last);
   }
 }
 
@@ -233,6 +251,7 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
       reinterpret_cast<double*>(s_ring + kWavesPerBlock * K * kRow);
   int* __restrict__ s_bad = reinterpret_cast<int*>(s_acc + kWavesPerBlock);
   int* __restrict__ s_ticket = s_bad + 1;
+  float* __restrict__ s_info = reinterpret_cast<float*>(s_bad + 4);  // [5][cap]
 
 #ifdef ZS_TIMING
   const unsigned long long t_start = wall_clock64();
@@ -292,9 +311,19 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
 
   // ---- this workgroup's contiguous chain range; tickets index into it ----
   const int64_t nblk = gridDim.x, blk = blockIdx.x;
-  const int64_t cpb = C / nblk, rem = C % nblk;
-  const int64_t start = uni64(blk * cpb + (blk < rem ? blk : rem));
-  const int count = (int)uni32((uint32_t)(cpb + (blk < rem ? 1 : 0)));
+  // Workgroups take turns of G consecutive chains: ticket t of workgroup b is
+  // chain ((t / G) * nblk + b) * G + t % G.  At any moment the CUs sweep one
+  // narrow band of q together (the access pattern of a grid-stride copy; a
+  // contiguous range per CU measured 4-8 % slower and less even across CUs),
+  // and G = 16 keeps whole 64-B lines of the HMCInfo arrays in one workgroup.
+  constexpr int G = ZS_RING_GRANULE;
+  const int64_t round = (int64_t)G * nblk;
+  const int64_t full = C / round, tail = C % round - blk * G;
+  const int count = (int)uni32(
+      (uint32_t)(full * G + (tail < 0 ? 0 : (tail > G ? G : tail))));
+  const int64_t start = blk * G;
+#define ZS_CHAIN_OF(t) \
+  (start + (int64_t)((t) / G) * round + (int64_t)((t) % G))
   const int64_t last_row = C - 1;
   auto draw = [&]() -> int {  // next ticket of this workgroup (wave-uniform)
     int t = 0;
@@ -302,6 +331,8 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
     return (int)uni32((uint32_t)t);
   };
 
+  const uint32_t ticket_addr =
+      (uint32_t)reinterpret_cast<uintptr_t>(s_ticket);
   float* __restrict__ ring_w = s_ring + wib * K * kRow;
   const uint32_t ring_addr = __builtin_amdgcn_readfirstlane(
       (uint32_t)reinterpret_cast<uintptr_t>(ring_w));
@@ -317,7 +348,7 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
 #pragma unroll
   for (int j = 0; j < K; ++j) {
     tk[j] = draw();
-    int64_t row = start + tk[j];
+    int64_t row = ZS_CHAIN_OF(tk[j]);
     row = row < last_row ? row : last_row;
     issue_row<NCH>(voff, voff_last, a.q + uni64(row * D),
                    ring_addr + j * kRowB, mask_if(tk[j] < count));
@@ -330,14 +361,14 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
 #endif
   int slot = 0;
   for (int it = 0; tk[0] < count; ++it) {
-    const int64_t chain = start + tk[0];
+    const int t_cur = tk[0];
+    const int64_t chain = ZS_CHAIN_OF(t_cur);
     float* __restrict__ qrow = a.q + uni64(chain * D);
     const uint32_t gchain = (uint32_t)(chain + a.chain_offset);
 
     // the ticket for the slot this trip frees (LDS atomic: its latency hides
     // behind the wait and the slot read)
-    int nt_raw = 0;
-    if (lane == 0) nt_raw = atomicAdd(s_ticket, 1);
+    uint32_t nt_raw = ticket_issue(ticket_addr);
 
     // ---- wait for D(it), r = q - mean, refill the slot with D(it+K) -------
     if (it < K)
@@ -354,10 +385,11 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
             *reinterpret_cast<const f4*>(s_mean + (k * kWave + lane) * 4);
         r[k] = qv - mu;
       }
-      // the slot must be in registers before the DMA may overwrite it
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      const int nt = (int)uni32((uint32_t)nt_raw);
-      int64_t nrow = start + nt;
+      // the slot must be in registers before the DMA may overwrite it (the
+      // same wait lands the ticket)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nt_raw)::"memory");
+      const int nt = (int)uni32(nt_raw);
+      int64_t nrow = ZS_CHAIN_OF(nt);
       nrow = nrow < last_row ? nrow : last_row;
       issue_row<NCH>(voff, voff_last, a.q + uni64(nrow * D),
                      uni32(ring_addr + (uint32_t)slot * kRowB),
@@ -374,6 +406,9 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
     // p += (s2/eps) * (nep * r), a drift is r += eps * p / m.
     uint32_t key0 = a.k0, key1 = a.k1;
     asm volatile("" : "+s"(key0), "+s"(key1));
+#ifdef ZS_PRIO_RNG
+    __builtin_amdgcn_s_setprio(ZS_PRIO_RNG);
+#endif
     f4 ko = f4{0.f, 0.f, 0.f, 0.f}, uo = ko;
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
@@ -406,6 +441,9 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
 
     // ---- leapfrog (hmc.py:348-372): L full drifts + full kicks; half of the
     // last kick is taken back below ----------------------------------------
+#ifdef ZS_PRIO_LF
+    __builtin_amdgcn_s_setprio(ZS_PRIO_LF);
+#endif
     for (int i = 0; i < Lr; ++i) {
 #pragma unroll
       for (int k = 0; k < NCH; ++k) {
@@ -417,6 +455,9 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
       }
     }
 
+#ifdef ZS_PRIO_END
+    __builtin_amdgcn_s_setprio(ZS_PRIO_END);
+#endif
     // ---- Hamiltonians (hmc.py:30-35) and acceptance (hmc.py:46-61) -------
     f4 kn = f4{0.f, 0.f, 0.f, 0.f}, un = kn;
 #pragma unroll
@@ -434,10 +475,7 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
     float k_new = (kn[0] + kn[1]) + (kn[2] + kn[3]);
     float u_new = (un[0] + un[1]) + (un[2] + un[3]);
 #ifndef ZS_NO_REDUCE  // A/B probe only
-    k_old = wave_total_dpp(k_old);
-    u_old = wave_total_dpp(u_old);
-    k_new = wave_total_dpp(k_new);
-    u_new = wave_total_dpp(u_new);
+    wave_total4_dpp(k_old, u_old, k_new, u_new);
 #endif
     if (HAS_MASS) {  // sum p^2/m = (1/se) sum p^2 * (se/m)
       k_old *= inv_se;
@@ -469,15 +507,32 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
     // EXEC-predicated, so a rejected chain issues the same NCH (empty) stores
     {
       const Mask m_acc = mask_if(accept && a.commit != 0);
-      store_row<NCH>(voff, voff_last, r, s_mean + lane * 4, qrow, m_acc,
+      // q' = r + mean in place (r is dead after the store): all the LDS reads
+      // of the mean tile go out together, ahead of the asm statements
+#pragma unroll
+      for (int k = 0; k < NCH; ++k)
+        r[k] += *reinterpret_cast<const f4*>(s_mean + (k * kWave + lane) * 4);
+      store_row<NCH>(voff, voff_last, r, qrow, m_acc,
                      Mask{m_acc.lo & m_last.lo, m_acc.hi & m_last.hi});
     }
 
     // ---- the five HMCInfo scalars of this chain (lane 0; hmc.py:508-517) --
-    store_info5((uint32_t)chain * 4u, acc, h_old, h_new, lp_old,
-                accept ? lp_new : lp_old, a.acceptance_rate,
-                a.orig_hamiltonian, a.hamiltonian, a.orig_log_prob, a.log_prob,
-                (uint32_t)a.commit);
+    // Staged in LDS under the chain's ticket and written back as whole lines
+    // after the loop when the workgroup's share fits (info_cap); otherwise
+    // stored from here.  The five store instructions are issued either way
+    // (EXEC = 0 when staging): the ledger count does not depend on the mode.
+    const float lp_sel = accept ? lp_new : lp_old;
+    if (a.info_cap > 0 && lane == 0) {
+      const int cap = a.info_cap;
+      s_info[t_cur] = acc;
+      s_info[cap + t_cur] = h_old;
+      s_info[2 * cap + t_cur] = h_new;
+      s_info[3 * cap + t_cur] = lp_old;
+      s_info[4 * cap + t_cur] = lp_sel;
+    }
+    store_info5((uint32_t)chain * 4u, acc, h_old, h_new, lp_old, lp_sel,
+                a.acceptance_rate, a.orig_hamiltonian, a.hamiltonian,
+                a.orig_log_prob, a.log_prob, a.commit_direct);
   }
   // no DMA may outlive the wave (its LDS would be handed to another block)
   wait_vmcnt<0>();
@@ -504,32 +559,61 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
     if (a.acc_sum) atomicAdd(a.acc_sum, tot);
     if (*s_bad && a.flags) atomicOr(a.flags, ZSHMC_FLAG_OLD_LOGPROB_NONFINITE);
   }
+  // ---- staged HMCInfo scalars -> global, G consecutive chains per line ----
+  if (a.info_cap > 0 && a.commit) {
+    const int cap = a.info_cap;
+    for (int t = threadIdx.x; t < count; t += blockDim.x) {
+      const int64_t c = ZS_CHAIN_OF(t);
+      if (a.acceptance_rate) a.acceptance_rate[c] = s_info[t];
+      if (a.orig_hamiltonian) a.orig_hamiltonian[c] = s_info[cap + t];
+      if (a.hamiltonian) a.hamiltonian[c] = s_info[2 * cap + t];
+      if (a.orig_log_prob) a.orig_log_prob[c] = s_info[3 * cap + t];
+      if (a.log_prob) a.log_prob[c] = s_info[4 * cap + t];
+    }
+  }
+#undef ZS_CHAIN_OF
 }
 
 constexpr size_t kLdsLimit = 160 * 1024;
 
 template <int NCH, int K, bool HAS_MASS>
-static int launch_ring_cfg(const FusedArgs& a, hipStream_t stream) {
+static int launch_ring_cfg(const FusedArgs& a_in, hipStream_t stream) {
   constexpr int kWaves = 4 * ring_waves_for(NCH, HAS_MASS);
-  constexpr size_t lds = (size_t)((HAS_MASS ? 2 : 1) + kWaves * K) * NCH * 1024 +
-                         kWaves * sizeof(double) + 16;
-  static_assert(lds <= kLdsLimit, "ring does not fit in LDS");
+  constexpr size_t lds_base =
+      (size_t)((HAS_MASS ? 2 : 1) + kWaves * K) * NCH * 1024 +
+      kWaves * sizeof(double) + 16;
+  static_assert(lds_base <= kLdsLimit, "ring does not fit in LDS");
   static bool ready = false;
   if (!ready) {
     // the ring needs more than the default 64 KiB dynamic-LDS cap
     hipError_t e = hipFuncSetAttribute(
         reinterpret_cast<const void*>(
             hmc_diag_normal_ring_kernel<NCH, K, HAS_MASS>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
     if (e != hipSuccess) return check_hip(e, "ring kernel: LDS size attribute");
     ready = true;
   }
-  // one workgroup per CU; fewer when there are not even that many chains
+  // one workgroup per CU; fewer when there are not even that many turns
+  constexpr int G = ZS_RING_GRANULE;
   const int64_t cus = device_cu_count();
-  const int grid = (int)(a.n_chains < cus ? a.n_chains : cus);
+  const int64_t turns = (a_in.n_chains + G - 1) / G;
+  const int64_t grid = turns < cus ? turns : cus;
+  // largest per-workgroup share (workgroup 0); stage the HMCInfo scalars in
+  // LDS when 5 floats per chain of that share fit beside the ring
+  const int64_t round = G * grid;
+  const int64_t tail = a_in.n_chains % round;
+  const int64_t share = (a_in.n_chains / round) * G + (tail > G ? G : tail);
+  FusedArgs a = a_in;
+  const bool any_info = a.acceptance_rate || a.orig_hamiltonian ||
+                        a.hamiltonian || a.orig_log_prob || a.log_prob;
+  const bool stage = a.commit && any_info &&
+                     lds_base + (size_t)share * 20 <= kLdsLimit;
+  a.info_cap = stage ? (int)share : 0;
+  a.commit_direct = (a.commit && !stage) ? 1u : 0u;
+  const size_t lds = lds_base + (stage ? (size_t)share * 20 : 0);
   hipLaunchKernelGGL((hmc_diag_normal_ring_kernel<NCH, K, HAS_MASS>),
-                     dim3(grid > 0 ? grid : 1), dim3(64 * kWaves), lds, stream,
-                     a);
+                     dim3(grid > 0 ? (unsigned)grid : 1u), dim3(64 * kWaves),
+                     lds, stream, a);
   ZS_LAUNCH_CHECK("hmc_diag_normal_ring_kernel launch");
   return ZSHMC_OK;
 }
