@@ -396,8 +396,8 @@ extern "C" const char* zshmc_fused_kernel_name(int64_t n_data, int has_mass) {
   static thread_local char buf[96];
   int nch = 0, k = 0;
   if (fused_ring_enabled() && fused_ring_config(n_data, has_mass != 0, &nch, &k)) {
-    snprintf(buf, sizeof(buf), "hmc_diag_normal_ring_kernel<%d,%d,%s>", nch, k,
-             has_mass ? "true" : "false");
+    snprintf(buf, sizeof(buf), "hmc_diag_normal_ring_kernel<%d,%d,%s,*>", nch,
+             k, has_mass ? "true" : "false");
     return buf;
   }
   const int64_t ng = (n_data + 3) / 4;

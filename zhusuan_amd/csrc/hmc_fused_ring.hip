@@ -237,9 +237,14 @@ constexpr int ring_waves_for(int nch, bool has_mass) {
                               : (nch == 5 && !has_mass ? 3 : 2));
 }
 
-template <int NCH, int K, bool HAS_MASS>
+// STAGE: the workgroup's per-chain scalars (MH uniform in, five HMCInfo values
+// out) live in LDS under the chain's ticket (info_cap of them fit); otherwise
+// the uniform is drawn on the scalar unit and the five values are stored from
+// the trip loop (hand-counted, in the ledger).
+template <int NCH, int K, bool HAS_MASS, bool STAGE>
 __global__ __launch_bounds__(256 * ring_waves_for(NCH, HAS_MASS)) void
 hmc_diag_normal_ring_kernel(FusedArgs a) {
+  constexpr int kLedgerInfo = STAGE ? 0 : kInfoStores;
   constexpr int kRow = NCH * 256;  // padded row length (floats) of one chain
   constexpr int kRowB = kRow * 4;
   constexpr int kWavesPerBlock = 4 * ring_waves_for(NCH, HAS_MASS);  // a CU
@@ -264,6 +269,30 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
 #endif
   const int64_t D = a.n_data;
   const int64_t C = a.n_chains;
+
+  // ---- this workgroup's chains; tickets index into them -------------------
+  const int64_t nblk = gridDim.x, blk = blockIdx.x;
+  // Workgroups take turns of G consecutive chains: ticket t of workgroup b is
+  // chain ((t / G) * nblk + b) * G + t % G.  At any moment the CUs sweep one
+  // narrow band of q together (the access pattern of a grid-stride copy; a
+  // contiguous range per CU measured 4-8 % slower and less even across CUs),
+  // and G = 16 keeps whole 64-B lines of the HMCInfo arrays in one workgroup.
+  constexpr int G = ZS_RING_GRANULE;
+  const int64_t round = (int64_t)G * nblk;
+  const int64_t full = C / round, tail = C % round - blk * G;
+  const int count = (int)uni32(
+      (uint32_t)(full * G + (tail < 0 ? 0 : (tail > G ? G : tail))));
+  const int64_t start = blk * G;
+#define ZS_CHAIN_OF(t) \
+  (start + (int64_t)((t) / G) * round + (int64_t)((t) % G))
+  const int64_t last_row = C - 1;
+  // MH uniforms (hmc.py:485) of all this workgroup's chains, one Philox call
+  // per lane, parked in LDS under the chain's ticket
+  float* __restrict__ s_u = s_info + 5 * a.info_cap;
+  if (STAGE)
+    for (int t = threadIdx.x; t < count; t += blockDim.x)
+      s_u[t] = uniform_chain((uint32_t)(ZS_CHAIN_OF(t) + a.chain_offset),
+                             a.iteration, a.k0, a.k1);
 
   // ---- stage mean / sqrt(mass) in LDS (zero padding beyond n_data) --------
   for (int d = threadIdx.x; d < kRow; d += blockDim.x) {
@@ -309,22 +338,6 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
   // loop's VMEM traffic is the hand-counted asm only
   __syncthreads();  // LDS tile ready
 
-  // ---- this workgroup's contiguous chain range; tickets index into it ----
-  const int64_t nblk = gridDim.x, blk = blockIdx.x;
-  // Workgroups take turns of G consecutive chains: ticket t of workgroup b is
-  // chain ((t / G) * nblk + b) * G + t % G.  At any moment the CUs sweep one
-  // narrow band of q together (the access pattern of a grid-stride copy; a
-  // contiguous range per CU measured 4-8 % slower and less even across CUs),
-  // and G = 16 keeps whole 64-B lines of the HMCInfo arrays in one workgroup.
-  constexpr int G = ZS_RING_GRANULE;
-  const int64_t round = (int64_t)G * nblk;
-  const int64_t full = C / round, tail = C % round - blk * G;
-  const int count = (int)uni32(
-      (uint32_t)(full * G + (tail < 0 ? 0 : (tail > G ? G : tail))));
-  const int64_t start = blk * G;
-#define ZS_CHAIN_OF(t) \
-  (start + (int64_t)((t) / G) * round + (int64_t)((t) % G))
-  const int64_t last_row = C - 1;
   auto draw = [&]() -> int {  // next ticket of this workgroup (wave-uniform)
     int t = 0;
     if (lane == 0) t = atomicAdd(s_ticket, 1);
@@ -374,7 +387,7 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
     if (it < K)
       wait_vmcnt<(K - 1) * NCH>();
     else
-      wait_vmcnt<(K - 1) * NCH + K * (NCH + kInfoStores)>();
+      wait_vmcnt<(K - 1) * NCH + K * (NCH + kLedgerInfo)>();
     f4 r[NCH], p[NCH];
     {
       const float* __restrict__ sl = ring_w + slot * kRow;
@@ -494,7 +507,11 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
 #ifdef ZS_NO_UNIF  // A/B probe only
     const float u = 0.5f;
 #else
-    const float u = uniform_chain(gchain, a.iteration, key0, key1);
+    float u;
+    if (STAGE)
+      u = s_u[t_cur];
+    else
+      u = uniform_chain(gchain, a.iteration, key0, key1);
 #endif
     const bool accept = u < acc;  // strict, hmc.py:486
 
@@ -518,21 +535,22 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
 
     // ---- the five HMCInfo scalars of this chain (lane 0; hmc.py:508-517) --
     // Staged in LDS under the chain's ticket and written back as whole lines
-    // after the loop when the workgroup's share fits (info_cap); otherwise
-    // stored from here.  The five store instructions are issued either way
-    // (EXEC = 0 when staging): the ledger count does not depend on the mode.
+    // after the loop (STAGE), or stored from here as 5 ledger entries.
     const float lp_sel = accept ? lp_new : lp_old;
-    if (a.info_cap > 0 && lane == 0) {
-      const int cap = a.info_cap;
-      s_info[t_cur] = acc;
-      s_info[cap + t_cur] = h_old;
-      s_info[2 * cap + t_cur] = h_new;
-      s_info[3 * cap + t_cur] = lp_old;
-      s_info[4 * cap + t_cur] = lp_sel;
+    if (STAGE) {
+      if (lane == 0) {
+        const int cap = a.info_cap;
+        s_info[t_cur] = acc;
+        s_info[cap + t_cur] = h_old;
+        s_info[2 * cap + t_cur] = h_new;
+        s_info[3 * cap + t_cur] = lp_old;
+        s_info[4 * cap + t_cur] = lp_sel;
+      }
+    } else {
+      store_info5((uint32_t)chain * 4u, acc, h_old, h_new, lp_old, lp_sel,
+                  a.acceptance_rate, a.orig_hamiltonian, a.hamiltonian,
+                  a.orig_log_prob, a.log_prob, a.commit_direct);
     }
-    store_info5((uint32_t)chain * 4u, acc, h_old, h_new, lp_old, lp_sel,
-                a.acceptance_rate, a.orig_hamiltonian, a.hamiltonian,
-                a.orig_log_prob, a.log_prob, a.commit_direct);
   }
   // no DMA may outlive the wave (its LDS would be handed to another block)
   wait_vmcnt<0>();
@@ -560,7 +578,7 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
     if (*s_bad && a.flags) atomicOr(a.flags, ZSHMC_FLAG_OLD_LOGPROB_NONFINITE);
   }
   // ---- staged HMCInfo scalars -> global, G consecutive chains per line ----
-  if (a.info_cap > 0 && a.commit) {
+  if (STAGE && a.commit) {
     const int cap = a.info_cap;
     for (int t = threadIdx.x; t < count; t += blockDim.x) {
       const int64_t c = ZS_CHAIN_OF(t);
@@ -588,8 +606,13 @@ static int launch_ring_cfg(const FusedArgs& a_in, hipStream_t stream) {
     // the ring needs more than the default 64 KiB dynamic-LDS cap
     hipError_t e = hipFuncSetAttribute(
         reinterpret_cast<const void*>(
-            hmc_diag_normal_ring_kernel<NCH, K, HAS_MASS>),
+            hmc_diag_normal_ring_kernel<NCH, K, HAS_MASS, true>),
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(
+          reinterpret_cast<const void*>(
+              hmc_diag_normal_ring_kernel<NCH, K, HAS_MASS, false>),
+          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
     if (e != hipSuccess) return check_hip(e, "ring kernel: LDS size attribute");
     ready = true;
   }
@@ -598,22 +621,24 @@ static int launch_ring_cfg(const FusedArgs& a_in, hipStream_t stream) {
   const int64_t cus = device_cu_count();
   const int64_t turns = (a_in.n_chains + G - 1) / G;
   const int64_t grid = turns < cus ? turns : cus;
-  // largest per-workgroup share (workgroup 0); stage the HMCInfo scalars in
-  // LDS when 5 floats per chain of that share fit beside the ring
+  // largest per-workgroup share (workgroup 0); stage the per-chain scalars in
+  // LDS when they fit beside the ring
   const int64_t round = G * grid;
   const int64_t tail = a_in.n_chains % round;
   const int64_t share = (a_in.n_chains / round) * G + (tail > G ? G : tail);
   FusedArgs a = a_in;
-  const bool any_info = a.acceptance_rate || a.orig_hamiltonian ||
-                        a.hamiltonian || a.orig_log_prob || a.log_prob;
-  const bool stage = a.commit && any_info &&
-                     lds_base + (size_t)share * 20 <= kLdsLimit;
+  // 6 floats per chain: 5 HMCInfo scalars + the MH uniform
+  const bool stage = lds_base + (size_t)share * 24 <= kLdsLimit;
   a.info_cap = stage ? (int)share : 0;
   a.commit_direct = (a.commit && !stage) ? 1u : 0u;
-  const size_t lds = lds_base + (stage ? (size_t)share * 20 : 0);
-  hipLaunchKernelGGL((hmc_diag_normal_ring_kernel<NCH, K, HAS_MASS>),
-                     dim3(grid > 0 ? (unsigned)grid : 1u), dim3(64 * kWaves),
-                     lds, stream, a);
+  const size_t lds = lds_base + (stage ? (size_t)share * 24 : 0);
+  const dim3 gdim(grid > 0 ? (unsigned)grid : 1u), bdim(64 * kWaves);
+  if (stage)
+    hipLaunchKernelGGL((hmc_diag_normal_ring_kernel<NCH, K, HAS_MASS, true>),
+                       gdim, bdim, lds, stream, a);
+  else
+    hipLaunchKernelGGL((hmc_diag_normal_ring_kernel<NCH, K, HAS_MASS, false>),
+                       gdim, bdim, lds, stream, a);
   ZS_LAUNCH_CHECK("hmc_diag_normal_ring_kernel launch");
   return ZSHMC_OK;
 }
