@@ -20,6 +20,8 @@
 // IS the A layout of the second -- no shuffle, no LDS round trip).  Logits
 // never leave registers.  Roofline: MFMA (fp32 157 TFLOP/s);
 // 4*N*D*C flop per call.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace zshmc {
@@ -210,10 +212,273 @@ __global__ __launch_bounds__(256, 1) void linear_bernoulli_kernel(
   }
 }
 
+// global -> LDS, BYTES (4, 8 = 2x4, 16) per lane, LDS dest = dst + lane*BYTES
+template <int BYTES>
+__device__ __forceinline__ void lds_dma_row(const float* src, uint32_t dst,
+                                            uint32_t lane) {
+  if constexpr (BYTES == 16) {
+    const uint32_t voff = lane * 16u;
+    asm volatile(
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %0, %1"
+        :
+        : "v"(voff), "s"(src), "s"(dst)
+        : "memory");
+  } else {
+    const uint32_t voff = lane * 4u;
+    asm volatile(
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dword %0, %1"
+        :
+        : "v"(voff), "s"(src), "s"(dst)
+        : "memory");
+    if constexpr (BYTES == 8)
+      asm volatile(
+          "s_mov_b32 m0, %2\n\t"
+          "s_nop 0\n\t"
+          "global_load_lds_dword %0, %1 offset:256"
+          :
+          : "v"(voff), "s"(src), "s"(dst)
+          : "memory");
+  }
+}
+
+// ---------------------------------------------------------------------------
+// v2: 64-row tiles, W in registers, no K-split.
+//
+// The 4 waves of a workgroup are (a, nb): chain block a (32 chains) x row
+// block nb (32 of the tile's 64 rows).  Each wave keeps ITS chain block of W
+// in registers for the whole kernel (D/2 VGPRs: the B operand of every
+// phase-1 MFMA), accumulates S' over the full K = D itself (no exchange of
+// partial logits through LDS, no mid-tile barrier), and owns a private
+// partial of G[32 chains, D] (D/2 accumulators) for its row block; the two
+// row-block partials are added once, in the epilogue.  LDS holds only the
+// double-buffered X tile (2 x 64 x (D+4) floats), published by plain stores
+// that overlap the MFMAs of the current tile; one barrier per tile.
+// Per wave and tile: D/2 + D/2 MFMAs (32x32x2) = 64 cycles each on its SIMD.
+template <int D>
+__global__ __launch_bounds__(256, 1) void linear_bernoulli_kernel_v2(
+    const float* __restrict__ W, const float* __restrict__ X,
+    const float* __restrict__ y, int64_t C, int64_t N, int64_t ldw,
+    int64_t ldx, float* __restrict__ ll, float* __restrict__ gW) {
+  constexpr int LD = D + 4;          // padded LDS row: conflict-free b128 reads
+  constexpr int kRows = 64;          // data rows per tile
+  constexpr int KK = D / 8;          // phase-1 groups of 4 MFMAs (8 features)
+  constexpr int FBT = D / 32;        // 32-wide feature blocks (2, 4 or 8)
+  constexpr int X4 = kRows * D / 4 / 256;  // float4 per thread per X tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* __restrict__ sX = reinterpret_cast<float*>(smem);  // [2][kRows][LD]
+  float* __restrict__ sY = sX + 2 * kRows * LD;             // [2][kRows]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int a = wave >> 1, nb = wave & 1;
+  const int lo = lane & 31, hi = lane >> 5;
+  const int64_t c0 = (int64_t)blockIdx.x * kMC;
+
+  // ---- this wave's W block -> registers (B operand: k-slot = lane half) ----
+  float wreg[KK * 4];
+  {
+    int64_t cr = c0 + a * 32 + lo;
+    cr = cr < C ? cr : C - 1;
+    const float* __restrict__ wrow = W + cr * ldw + hi * 4;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      const f4 v = *reinterpret_cast<const f4*>(wrow + kk * 8);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) wreg[kk * 4 + m] = v[m];
+    }
+  }
+
+  // ---- X tile: global -> LDS by DMA, one padded row per instruction --------
+  // (global_load_lds writes lane-linear: a row of D floats is D/64 dwords per
+  // lane, and the 4-float pad sits between rows, i.e. between instructions).
+  // Wave w moves rows 16w .. 16w+15; rows past N re-read row N-1 (masked in
+  // the residual).  hipcc does not count these loads: the `s_waitcnt
+  // vmcnt(0)` in front of the tile barrier lands them.
+  constexpr int kDmaB = D / 16;  // bytes per lane per row: 16 (D=256), 8, 4
+  const uint32_t sx_addr = (uint32_t)reinterpret_cast<uintptr_t>(sX);
+  auto dma_tile = [&](int64_t n0, int buf) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int row = __builtin_amdgcn_readfirstlane(wave) * 16 + j;
+      int64_t nr = n0 + row;
+      nr = nr < N ? nr : N - 1;
+      const float* src = X + nr * ldx;
+      const uint32_t dst = __builtin_amdgcn_readfirstlane(
+          sx_addr + (uint32_t)((buf * kRows + row) * LD * 4));
+      lds_dma_row<kDmaB>(src, dst, (uint32_t)lane);
+    }
+  };
+  float yr = 0.f;
+
+  f16v G[FBT];
+#pragma unroll
+  for (int t = 0; t < FBT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) G[t][r] = 0.f;
+  float ll_lane = 0.f;
+
+  const int64_t n_tiles = (N + kRows - 1) / kRows;
+  dma_tile(0, 0);
+  if (tid < kRows) sY[tid] = tid < N ? y[tid] : 0.f;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int64_t tile = 0; tile < n_tiles; ++tile) {
+    const int buf = (int)(tile & 1);
+    const float* __restrict__ xb = sX + buf * kRows * LD;
+    // the other buffer was last read before the previous barrier: stream
+    // tile+1 into it now, under the MFMAs below
+    const bool more = tile + 1 < n_tiles;
+    if (more) {
+      dma_tile((tile + 1) * kRows, buf ^ 1);
+      if (tid < kRows) {
+        const int64_t nr = (tile + 1) * kRows + tid;
+        yr = nr < N ? y[nr] : 0.f;
+      }
+    }
+
+    // ---- phase 1: S'[n, i] = sum_d X[n,d] W[i,d], full K in this wave -------
+    f16v S;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) S[r] = 0.f;
+    {
+      const float* __restrict__ arow = xb + (nb * 32 + lo) * LD + hi * 4;
+      f4 av = *reinterpret_cast<const f4*>(arow);
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        f4 an = av;
+        if (kk + 1 < KK) an = *reinterpret_cast<const f4*>(arow + (kk + 1) * 8);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          S = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], wreg[kk * 4 + m], S, 0,
+                                                   0, 0);
+        av = an;
+      }
+    }
+
+    // ---- sigmoid residual in the accumulator layout -------------------------
+    // lane holds chain i = a*32 + lo, rows n = nb*32 + (r&3) + 8*(r>>2) + 4*hi.
+    // Bernoulli._log_prob (univariate.py:398-403):
+    //   l*y - max(l,0) - log1p(exp(-|l|));   d/dl = y - sigmoid(l).
+    // Three hardware transcendentals per element (v_exp, v_rcp, v_log):
+    // log1p(e) = ln2*log2(1+e) with e in (0,1] is good to ~1e-7 absolute.
+    const int rows_left = (int)((N - tile * kRows) < kRows ? (N - tile * kRows)
+                                                           : kRows);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int nl = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      const bool valid = nl < rows_left;
+      const float sv = S[r];
+      const float yv = sY[buf * kRows + nl];
+      const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * fabsf(sv));
+      const float t1 = 1.0f + e;
+      const float inv = __builtin_amdgcn_rcpf(t1);
+      const float sig = sv >= 0.f ? inv : 1.0f - inv;
+      const float lp = sv * yv - fmaxf(sv, 0.f) -
+                       0.6931471805599453f * __builtin_amdgcn_logf(t1);
+      S[r] = valid ? yv - sig : 0.f;
+      ll_lane += valid ? lp : 0.f;
+    }
+
+    // ---- phase 3: G[i, f] += sum_n R'[n, i] X[n, f], this wave's 32 rows ----
+    // A operand = the residual registers themselves (k-slot = lane half);
+    // lane lo supplies features lo*FBT .. lo*FBT + FBT-1 (one per f-block)
+    if (gW) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int nl = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const float* __restrict__ xrow = xb + nl * LD + lo * FBT;
+        float xv[FBT];
+        if constexpr (FBT >= 4) {
+#pragma unroll
+          for (int q4 = 0; q4 < FBT / 4; ++q4) {
+            const f4 v = *reinterpret_cast<const f4*>(xrow + q4 * 4);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) xv[q4 * 4 + m] = v[m];
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < FBT; ++t) xv[t] = xrow[t];
+        }
+#pragma unroll
+        for (int t = 0; t < FBT; ++t)
+          G[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(S[r], xv[t], G[t], 0, 0, 0);
+      }
+    }
+    if (more && tid < kRows) sY[(buf ^ 1) * kRows + tid] = yr;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA rows landed
+    __syncthreads();  // tile+1 published; this buffer free for tile+2
+  }
+
+  // ---- epilogue: add the two row-block partials, store ---------------------
+  // G[t][r]: chain = c0 + a*32 + (r&3) + 8*(r>>2) + 4*hi, feature = lo*FBT + t
+  float* __restrict__ sG = sX;                 // [2][FBT*16][64] floats
+  float* __restrict__ sL = sX + 2 * FBT * 16 * 64;  // [2][32]
+  const float ll_half = ll_lane + __shfl_xor(ll_lane, 32, 64);
+  if (nb == 1) {
+    if (gW) {
+#pragma unroll
+      for (int t = 0; t < FBT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          sG[((a * FBT + t) * 16 + r) * 64 + lane] = G[t][r];
+    }
+    if (hi == 0) sL[a * 32 + lo] = ll_half;
+  }
+  __syncthreads();
+  if (nb == 0) {
+    if (gW) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t chain = c0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float out[FBT];
+#pragma unroll
+        for (int t = 0; t < FBT; ++t)
+          out[t] = G[t][r] + sG[((a * FBT + t) * 16 + r) * 64 + lane];
+        if (chain < C) {
+          float* __restrict__ dst = gW + chain * ldw + lo * FBT;
+#pragma unroll
+          for (int t = 0; t < FBT; ++t) dst[t] = out[t];
+        }
+      }
+    }
+    if (hi == 0) {
+      const int64_t chain = c0 + a * 32 + lo;
+      if (chain < C) ll[chain] = ll_half + sL[a * 32 + lo];
+    }
+  }
+}
+
 template <int D>
 static int launch_lb(const float* W, const float* X, const float* y, int64_t C,
                      int64_t N, int64_t ldw, int64_t ldx, float* ll, float* gW,
                      hipStream_t s) {
+  static const bool use_v1 = [] {
+    const char* e = getenv("ZSHMC_LB_V1");
+    return e && e[0] == '1';
+  }();
+  if (!use_v1) {
+    constexpr int LD = D + 4;
+    const size_t lds = (size_t)(2 * 64 * LD + 2 * 64) * sizeof(float);
+    static bool attr2 = false;
+    if (!attr2) {
+      hipError_t e = hipFuncSetAttribute(
+          reinterpret_cast<const void*>(linear_bernoulli_kernel_v2<D>),
+          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(LDS)");
+      attr2 = true;
+    }
+    const int grid = (int)((C + kMC - 1) / kMC);
+    hipLaunchKernelGGL(linear_bernoulli_kernel_v2<D>, dim3(grid), dim3(256),
+                       lds, s, W, X, y, C, N, ldw, ldx, ll, gW);
+    ZS_LAUNCH_CHECK("linear_bernoulli_kernel_v2 launch");
+    return ZSHMC_OK;
+  }
   constexpr int LD = D + 4;
   const size_t lds = (size_t)(kMC * LD + 2 * kNT * LD + 2 * kNT + 4 * 16 * 64) *
                      sizeof(float);
