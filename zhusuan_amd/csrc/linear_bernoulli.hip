@@ -246,36 +246,45 @@ __device__ __forceinline__ void lds_dma_row(const float* src, uint32_t dst,
 }
 
 // ---------------------------------------------------------------------------
-// v2: 64-row tiles, W in registers, no K-split.
+// v2: 64-row tiles, W in registers, residual exchange instead of a K-split.
 //
-// The 4 waves of a workgroup are (a, nb): chain block a (32 chains) x row
-// block nb (32 of the tile's 64 rows).  Each wave keeps ITS chain block of W
-// in registers for the whole kernel (D/2 VGPRs: the B operand of every
-// phase-1 MFMA), accumulates S' over the full K = D itself (no exchange of
-// partial logits through LDS, no mid-tile barrier), and owns a private
-// partial of G[32 chains, D] (D/2 accumulators) for its row block; the two
-// row-block partials are added once, in the epilogue.  LDS holds only the
-// double-buffered X tile (2 x 64 x (D+4) floats), published by plain stores
-// that overlap the MFMAs of the current tile; one barrier per tile.
-// Per wave and tile: D/2 + D/2 MFMAs (32x32x2) = 64 cycles each on its SIMD.
-template <int D>
+// The 4 waves of a workgroup are (a, b): chain block a (32 chains) x half b.
+//   phase 1  S'[n, i] = sum_d X[n,d] W[i,d] for the wave's 32 ROWS (b = row
+//            block), full K = D in one accumulator chain.  The wave's chain
+//            block of W stays in registers for the whole kernel (D/2 VGPRs,
+//            the B operand): no LDS traffic for W, no exchange of partial
+//            logits, D/2 MFMAs.
+//   residual R' = y - sigmoid(S') and the log-likelihood terms on the
+//            accumulator registers (3 hardware transcendentals per element),
+//            issued under the MFMAs of phase 3a; R' is also parked in LDS.
+//   phase 3  G[i, f] += sum_n R'[n, i] X[n, f] over ALL 64 rows but only the
+//            wave's HALF of the features (b = feature half): 3a takes the
+//            wave's own 32 rows straight from the residual registers (the
+//            C/D layout of phase 1 IS the A layout of phase 3), 3b the sibling
+//            wave's rows from LDS after the mid-tile barrier.  D/4 + D/4 MFMAs
+//            on D/4 accumulators; every wave stores its own slice of gW.
+// LDS: the double-buffered X tile (2 x 64 x (D+4) floats), streamed by
+// LDS-DMA one padded row per instruction, issued between the MFMAs of phase 1;
+// 16 KB for the residual exchange.  Two barriers per tile.
+template <int D, bool GRAD>
 __global__ __launch_bounds__(256, 1) void linear_bernoulli_kernel_v2(
     const float* __restrict__ W, const float* __restrict__ X,
     const float* __restrict__ y, int64_t C, int64_t N, int64_t ldw,
     int64_t ldx, float* __restrict__ ll, float* __restrict__ gW) {
   constexpr int LD = D + 4;          // padded LDS row: conflict-free b128 reads
   constexpr int kRows = 64;          // data rows per tile
-  constexpr int KK = D / 8;          // phase-1 groups of 4 MFMAs (8 features)
-  constexpr int FBT = D / 32;        // 32-wide feature blocks (2, 4 or 8)
-  constexpr int X4 = kRows * D / 4 / 256;  // float4 per thread per X tile
+  constexpr int KK = D / 8;          // phase-1 steps of 4 MFMAs (8 features)
+  constexpr int HALF = D / 2;        // features per wave in phase 3
+  constexpr int FB = HALF / 32;      // 32-wide feature blocks per half (1,2,4)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* __restrict__ sX = reinterpret_cast<float*>(smem);  // [2][kRows][LD]
   float* __restrict__ sY = sX + 2 * kRows * LD;             // [2][kRows]
+  float* __restrict__ sR = sY + 2 * kRows;                  // [4][4][64][4]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int a = wave >> 1, nb = wave & 1;
+  const int a = wave >> 1, b = wave & 1;
   const int lo = lane & 31, hi = lane >> 5;
   const int64_t c0 = (int64_t)blockIdx.x * kMC;
 
@@ -300,59 +309,70 @@ __global__ __launch_bounds__(256, 1) void linear_bernoulli_kernel_v2(
   // the residual).  hipcc does not count these loads: the `s_waitcnt
   // vmcnt(0)` in front of the tile barrier lands them.
   constexpr int kDmaB = D / 16;  // bytes per lane per row: 16 (D=256), 8, 4
+  // 16 rows per wave and tile, spread over the KK phase-1 steps
+  constexpr int kDmaStep = KK >= 16 ? KK / 16 : 1;
+  constexpr int kDmaPer = KK >= 16 ? 1 : 16 / KK;
   const uint32_t sx_addr = (uint32_t)reinterpret_cast<uintptr_t>(sX);
-  auto dma_tile = [&](int64_t n0, int buf) {
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const int row = __builtin_amdgcn_readfirstlane(wave) * 16 + j;
-      int64_t nr = n0 + row;
-      nr = nr < N ? nr : N - 1;
-      const float* src = X + nr * ldx;
-      const uint32_t dst = __builtin_amdgcn_readfirstlane(
-          sx_addr + (uint32_t)((buf * kRows + row) * LD * 4));
-      lds_dma_row<kDmaB>(src, dst, (uint32_t)lane);
-    }
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  auto dma_row = [&](int64_t n0, int buf, int j) {
+    const int row = wave_u * 16 + j;
+    int64_t nr = n0 + row;
+    nr = nr < N ? nr : N - 1;
+    const float* src = X + nr * ldx;
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(
+        sx_addr + (uint32_t)((buf * kRows + row) * LD * 4));
+    lds_dma_row<kDmaB>(src, dst, (uint32_t)lane);
   };
   float yr = 0.f;
 
-  f16v G[FBT];
+  f16v G[FB];
 #pragma unroll
-  for (int t = 0; t < FBT; ++t)
+  for (int t = 0; t < FB; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) G[t][r] = 0.f;
   float ll_lane = 0.f;
 
   const int64_t n_tiles = (N + kRows - 1) / kRows;
-  dma_tile(0, 0);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) dma_row(0, 0, j);
   if (tid < kRows) sY[tid] = tid < N ? y[tid] : 0.f;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
+  // residual exchange slots: [wave][r>>2][lane][r&3]  (b128, conflict-free)
+  float* __restrict__ sr_mine = sR + (wave * 4 * 64 + lane) * 4;
+  const float* __restrict__ sr_sib = sR + ((wave ^ 1) * 4 * 64 + lane) * 4;
+
   for (int64_t tile = 0; tile < n_tiles; ++tile) {
     const int buf = (int)(tile & 1);
     const float* __restrict__ xb = sX + buf * kRows * LD;
-    // the other buffer was last read before the previous barrier: stream
-    // tile+1 into it now, under the MFMAs below
     const bool more = tile + 1 < n_tiles;
-    if (more) {
-      dma_tile((tile + 1) * kRows, buf ^ 1);
-      if (tid < kRows) {
-        const int64_t nr = (tile + 1) * kRows + tid;
-        yr = nr < N ? y[nr] : 0.f;
-      }
+    // rows of tile+1 (the last tile re-streams itself: clamped rows, unused)
+    const int64_t n_next = (more ? tile + 1 : tile) * kRows;
+    if (tid < kRows) {
+      const int64_t nr = n_next + tid;
+      yr = nr < N ? y[nr] : 0.f;
     }
 
-    // ---- phase 1: S'[n, i] = sum_d X[n,d] W[i,d], full K in this wave -------
+    // ---- phase 1 (own 32 rows, full K) --------------------------------------
+    // Hand-pipelined: the LDS read of step kk+1 and one DMA row of tile+1 go
+    // out in front of the 4 MFMAs of step kk (a lone wave per SIMD has nobody
+    // else to hide its latencies).
     f16v S;
 #pragma unroll
     for (int r = 0; r < 16; ++r) S[r] = 0.f;
     {
-      const float* __restrict__ arow = xb + (nb * 32 + lo) * LD + hi * 4;
+      const float* __restrict__ arow = xb + (b * 32 + lo) * LD + hi * 4;
       f4 av = *reinterpret_cast<const f4*>(arow);
 #pragma unroll
       for (int kk = 0; kk < KK; ++kk) {
         f4 an = av;
         if (kk + 1 < KK) an = *reinterpret_cast<const f4*>(arow + (kk + 1) * 8);
+        if (kk % kDmaStep == 0) {
+#pragma unroll
+          for (int j = 0; j < kDmaPer; ++j)
+            dma_row(n_next, buf ^ 1, (kk / kDmaStep) * kDmaPer + j);
+        }
 #pragma unroll
         for (int m = 0; m < 4; ++m)
           S = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], wreg[kk * 4 + m], S, 0,
@@ -361,17 +381,15 @@ __global__ __launch_bounds__(256, 1) void linear_bernoulli_kernel_v2(
       }
     }
 
-    // ---- sigmoid residual in the accumulator layout -------------------------
-    // lane holds chain i = a*32 + lo, rows n = nb*32 + (r&3) + 8*(r>>2) + 4*hi.
+    // ---- residual on the accumulator layout ----------------------------------
+    // lane holds chain i = a*32 + lo, rows n = b*32 + (r&3) + 8*(r>>2) + 4*hi.
     // Bernoulli._log_prob (univariate.py:398-403):
     //   l*y - max(l,0) - log1p(exp(-|l|));   d/dl = y - sigmoid(l).
-    // Three hardware transcendentals per element (v_exp, v_rcp, v_log):
     // log1p(e) = ln2*log2(1+e) with e in (0,1] is good to ~1e-7 absolute.
     const int rows_left = (int)((N - tile * kRows) < kRows ? (N - tile * kRows)
                                                            : kRows);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int nl = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+    auto residual = [&](int r) {
+      const int nl = b * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
       const bool valid = nl < rows_left;
       const float sv = S[r];
       const float yv = sY[buf * kRows + nl];
@@ -383,74 +401,83 @@ __global__ __launch_bounds__(256, 1) void linear_bernoulli_kernel_v2(
                        0.6931471805599453f * __builtin_amdgcn_logf(t1);
       S[r] = valid ? yv - sig : 0.f;
       ll_lane += valid ? lp : 0.f;
-    }
+    };
+    // B operand of phase 3: X[row][b*HALF + lo*FB .. +FB-1]
+    typedef typename VecF<FB>::type V;
+    auto xrow = [&](int blk, int r) -> V {
+      const int nl = blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      return *reinterpret_cast<const V*>(xb + nl * LD + b * HALF + lo * FB);
+    };
 
-    // ---- phase 3: G[i, f] += sum_n R'[n, i] X[n, f], this wave's 32 rows ----
-    // A operand = the residual registers themselves (k-slot = lane half);
-    // lane lo supplies features lo*FBT .. lo*FBT + FBT-1 (one per f-block)
-    if (gW) {
+    if (GRAD) {
+      // ---- phase 3a: own rows, A = the residual registers; the residual of
+      // group g+1 (VALU) is issued under the MFMAs of group g ----------------
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int nl = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        const float* __restrict__ xrow = xb + nl * LD + lo * FBT;
-        float xv[FBT];
-        if constexpr (FBT >= 4) {
+      for (int r = 0; r < 4; ++r) residual(r);
 #pragma unroll
-          for (int q4 = 0; q4 < FBT / 4; ++q4) {
-            const f4 v = *reinterpret_cast<const f4*>(xrow + q4 * 4);
+      for (int g = 0; g < 4; ++g) {
+        V xv[4];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) xv[q4 * 4 + m] = v[m];
-          }
-        } else {
+        for (int q = 0; q < 4; ++q) xv[q] = xrow(b, g * 4 + q);
+        *reinterpret_cast<f4*>(sr_mine + g * 256) =
+            f4{S[g * 4], S[g * 4 + 1], S[g * 4 + 2], S[g * 4 + 3]};
 #pragma unroll
-          for (int t = 0; t < FBT; ++t) xv[t] = xrow[t];
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int t = 0; t < FB; ++t)
+            G[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                S[g * 4 + q], vget<FB>(xv[q], t), G[t], 0, 0, 0);
+        if (g + 1 < 4) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) residual((g + 1) * 4 + r);
         }
-#pragma unroll
-        for (int t = 0; t < FBT; ++t)
-          G[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(S[r], xv[t], G[t], 0, 0, 0);
       }
+      __syncthreads();  // the sibling's residuals are in LDS
+      // ---- phase 3b: the sibling's rows, A from LDS ----------------------------
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f4 rs = *reinterpret_cast<const f4*>(sr_sib + g * 256);
+        V xv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xv[q] = xrow(b ^ 1, g * 4 + q);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int t = 0; t < FB; ++t)
+            G[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                rs[q], vget<FB>(xv[q], t), G[t], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) residual(r);
     }
-    if (more && tid < kRows) sY[(buf ^ 1) * kRows + tid] = yr;
+    if (tid < kRows) sY[(buf ^ 1) * kRows + tid] = yr;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA rows landed
     __syncthreads();  // tile+1 published; this buffer free for tile+2
   }
 
-  // ---- epilogue: add the two row-block partials, store ---------------------
-  // G[t][r]: chain = c0 + a*32 + (r&3) + 8*(r>>2) + 4*hi, feature = lo*FBT + t
-  float* __restrict__ sG = sX;                 // [2][FBT*16][64] floats
-  float* __restrict__ sL = sX + 2 * FBT * 16 * 64;  // [2][32]
-  const float ll_half = ll_lane + __shfl_xor(ll_lane, 32, 64);
-  if (nb == 1) {
-    if (gW) {
+  // ---- epilogue -----------------------------------------------------------
+  // G[t][r]: chain = c0 + a*32 + (r&3) + 8*(r>>2) + 4*hi,
+  //          feature = b*HALF + lo*FB + t
+  if (GRAD) {
 #pragma unroll
-      for (int t = 0; t < FBT; ++t)
+    for (int r = 0; r < 16; ++r) {
+      const int64_t chain = c0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (chain < C) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          sG[((a * FBT + t) * 16 + r) * 64 + lane] = G[t][r];
-    }
-    if (hi == 0) sL[a * 32 + lo] = ll_half;
-  }
-  __syncthreads();
-  if (nb == 0) {
-    if (gW) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t chain = c0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        float out[FBT];
-#pragma unroll
-        for (int t = 0; t < FBT; ++t)
-          out[t] = G[t][r] + sG[((a * FBT + t) * 16 + r) * 64 + lane];
-        if (chain < C) {
-          float* __restrict__ dst = gW + chain * ldw + lo * FBT;
-#pragma unroll
-          for (int t = 0; t < FBT; ++t) dst[t] = out[t];
-        }
+        for (int t = 0; t < FB; ++t)
+          gW[chain * ldw + b * HALF + lo * FB + t] = G[t][r];
       }
     }
-    if (hi == 0) {
-      const int64_t chain = c0 + a * 32 + lo;
-      if (chain < C) ll[chain] = ll_half + sL[a * 32 + lo];
-    }
+  }
+  // ll of chain a*32+lo: this lane's 16 rows per tile + lane^32's + the
+  // sibling wave's 32 rows (through the exchange slots, now idle)
+  const float ll_half = ll_lane + __shfl_xor(ll_lane, 32, 64);
+  if (hi == 0) sR[wave * 32 + lo] = ll_half;
+  __syncthreads();
+  if (b == 0 && hi == 0) {
+    const int64_t chain = c0 + a * 32 + lo;
+    if (chain < C) ll[chain] = ll_half + sR[(wave ^ 1) * 32 + lo];
   }
 }
 
@@ -464,18 +491,26 @@ static int launch_lb(const float* W, const float* X, const float* y, int64_t C,
   }();
   if (!use_v1) {
     constexpr int LD = D + 4;
-    const size_t lds = (size_t)(2 * 64 * LD + 2 * 64) * sizeof(float);
+    const size_t lds = (size_t)(2 * 64 * LD + 2 * 64 + 4 * 16 * 64) * sizeof(float);
     static bool attr2 = false;
     if (!attr2) {
       hipError_t e = hipFuncSetAttribute(
-          reinterpret_cast<const void*>(linear_bernoulli_kernel_v2<D>),
+          reinterpret_cast<const void*>(linear_bernoulli_kernel_v2<D, true>),
           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(
+            reinterpret_cast<const void*>(linear_bernoulli_kernel_v2<D, false>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(LDS)");
       attr2 = true;
     }
     const int grid = (int)((C + kMC - 1) / kMC);
-    hipLaunchKernelGGL(linear_bernoulli_kernel_v2<D>, dim3(grid), dim3(256),
-                       lds, s, W, X, y, C, N, ldw, ldx, ll, gW);
+    if (gW)
+      hipLaunchKernelGGL((linear_bernoulli_kernel_v2<D, true>), dim3(grid),
+                         dim3(256), lds, s, W, X, y, C, N, ldw, ldx, ll, gW);
+    else
+      hipLaunchKernelGGL((linear_bernoulli_kernel_v2<D, false>), dim3(grid),
+                         dim3(256), lds, s, W, X, y, C, N, ldw, ldx, ll, gW);
     ZS_LAUNCH_CHECK("linear_bernoulli_kernel_v2 launch");
     return ZSHMC_OK;
   }
