@@ -268,6 +268,24 @@ int zshmc_categorical_sample(int32_t* out, const float* logits,
                              int64_t n_samples, int64_t rows, int64_t n_cat,
                              uint64_t seed, uint32_t offset, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Batched effective sample size (zhusuan/diagnostics.py:17-64), the estimator
+ * behind BASELINE.json's "ESS/s".
+ *   draws : [n_draws, n_series] float32, draw-major (one recorded snapshot of
+ *           the flattened [chains, dims] state per draw, burn-in already
+ *           dropped); ess : [n_series].
+ * Per series exactly effective_sample_size_1d (diagnostics.py:17-40): var =
+ * np.var*n/(n-1), lag-t autocovariance = mean over the n-t products, the rho
+ * sum starts at lag 0 and stops at the first negative rho; float64 sums.
+ * zshmc_min_positive_rows then gives diagnostics.py:55-64's "minimum positive
+ * ESS over dimensions" per chain: out[r] = min{v[r, c] : v[r, c] > 0}, +inf
+ * if the row has none.
+ */
+int zshmc_ess_series(const float* draws, int64_t n_draws, int64_t n_series,
+                     float* ess, void* stream);
+int zshmc_min_positive_rows(const float* v, int64_t rows, int64_t cols,
+                            float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

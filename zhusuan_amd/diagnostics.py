@@ -6,11 +6,14 @@ minimum positive ESS over dimensions as a scalar.
 
 `effective_sample_size_batch` is the same estimator vectorised over many
 chains/dimensions with FFT autocovariances (identical up to float64
-rounding), used by bench.py for ESS/s."""
+rounding).  `effective_sample_size_device` runs it on the GPU for every
+(chain, dimension) series of a block of recorded draws
+(csrc/diagnostics.hip); bench.py uses it for ESS/s over the whole chain
+population."""
 import numpy as np
 
 __all__ = ['effective_sample_size', 'effective_sample_size_1d',
-           'effective_sample_size_batch']
+           'effective_sample_size_batch', 'effective_sample_size_device']
 
 
 def effective_sample_size_1d(samples):
@@ -65,3 +68,40 @@ def effective_sample_size_batch(samples, burn_in=100):
     mask = np.arange(n)[:, None] < first_neg[None]
     sum_rho = np.where(mask, rho, 0.0).sum(axis=0)
     return (n / (1 + 2 * sum_rho)).reshape(trailing)
+
+
+def effective_sample_size_device(samples, burn_in=100, per_dimension=False):
+    """The reference estimator on the device.
+
+    :param samples: float32 device tensor ``[M, chain axes..., D]``: M
+        recorded draws of the state (what ``effective_sample_size`` takes as
+        ``[M, D]`` for ONE chain).
+    :param burn_in: rows dropped from the front (diagnostics.py:43 default).
+    :param per_dimension: return the ESS of every series (``[chain axes..., D]``)
+        instead of the minimum positive ESS over the last axis per chain
+        (``[chain axes...]``, diagnostics.py:55-64).
+    """
+    import torch
+    from . import _capi
+    if not (torch.is_tensor(samples) and samples.is_cuda):
+        raise TypeError('effective_sample_size_device needs a device tensor; '
+                        'use effective_sample_size(_batch) on the host')
+    if samples.dim() < 2:
+        raise ValueError('samples must be [M, ..., D]')
+    x = samples[burn_in:].to(torch.float32).contiguous()
+    n = int(x.shape[0])
+    trailing = tuple(x.shape[1:])
+    n_series = 1
+    for t in trailing:
+        n_series *= int(t)
+    ess = torch.empty(n_series, dtype=torch.float32, device=x.device)
+    _capi.call('zshmc_ess_series', x.data_ptr(), n, n_series, ess.data_ptr(),
+               _capi.current_stream())
+    if per_dimension:
+        return ess.reshape(trailing)
+    cols = int(trailing[-1])
+    rows = n_series // cols
+    out = torch.empty(rows, dtype=torch.float32, device=x.device)
+    _capi.call('zshmc_min_positive_rows', ess.data_ptr(), rows, cols,
+               out.data_ptr(), _capi.current_stream())
+    return out.reshape(trailing[:-1])
