@@ -286,6 +286,49 @@ int zshmc_ess_series(const float* draws, int64_t n_draws, int64_t n_series,
 int zshmc_min_positive_rows(const float* v, int64_t rows, int64_t cols,
                             float* out, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Stochastic-gradient MCMC updates (zhusuan/sgmcmc.py), element-wise over a
+ * flat latent of n float32 elements; the caller supplies grad = d log p / dq
+ * of the (mini-batch) log joint (tf.gradients, sgmcmc.py:95-99).  Gaussian
+ * terms are generated in the kernel: Philox counter (i/4 lo, i/4 hi,
+ * iteration, 3 | sub<<4 | latent_id<<8), sub 0 = step noise, 1 = momentum.
+ *
+ * zshmc_sgld_update   SGLD  q += lr/2 g + N(0, lr)              sgmcmc.py:199-204
+ *                     PSGLD (aux != NULL): aux = decay aux + (1-decay) g^2,
+ *                     G = 1/(epsilon + sqrt(aux)), q += lr/2 G g + N(0, lr G)
+ *                                                                sgmcmc.py:221-253
+ * zshmc_sg_momentum   v = N(0, std^2)  (initial value and resampling,
+ *                     std = sqrt(lr))                            sgmcmc.py:310-318
+ * zshmc_sg_half_drift q += v/2 (2nd-order integrators, :341, :463); optionally
+ *                     v2_sum += sum v^2 (scalar-friction SGNHT, :464)
+ * zshmc_sghmc_update  SGHMC._update (:331-349); v2_sum += sum v'^2 (mean_k)
+ * zshmc_sgnht_update  SGNHT._update (:452-481) with a friction per element
+ *                     (alpha_vec) or the scalar alpha_scalar[1]
+ * zshmc_sgnht_scalar  scalar-friction bookkeeping; alpha_scalar = {alpha,
+ *                     alpha of this step}, sums = {sum v_old^2, sum v'^2};
+ *                     phase 0 before, phase 1 after the update kernel
+ */
+int zshmc_sgld_update(float* q, const float* grad, float* aux,
+                      float learning_rate, float decay, float epsilon,
+                      int64_t n, uint64_t seed, uint32_t iteration,
+                      uint32_t latent_id, void* stream);
+int zshmc_sg_momentum(float* v, float std, int64_t n, uint64_t seed,
+                      uint32_t iteration, uint32_t latent_id, void* stream);
+int zshmc_sg_half_drift(float* q, const float* v, int64_t n, double* v2_sum,
+                        void* stream);
+int zshmc_sghmc_update(float* q, float* v, const float* grad, int64_t n,
+                       float learning_rate, float friction, float noise_std,
+                       int second_order, uint64_t seed, uint32_t iteration,
+                       uint32_t latent_id, double* v2_sum, void* stream);
+int zshmc_sgnht_update(float* q, float* v, const float* grad, float* alpha_vec,
+                       const float* alpha_scalar, float* mean_k_vec, int64_t n,
+                       float learning_rate, float tune_rate, float noise_std,
+                       int second_order, uint64_t seed, uint32_t iteration,
+                       uint32_t latent_id, double* v2_sum, void* stream);
+int zshmc_sgnht_scalar(float* alpha_scalar, double* sums, int64_t n,
+                       float learning_rate, float tune_rate, int second_order,
+                       int phase, float* mean_k_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -3,7 +3,8 @@ Python host code over a ctypes C-ABI (include/zshmc.h, libzshmc.so) of
 hand-written HIP kernels.  Same surface as `import zhusuan as zs` for the
 path: zs.HMC, zs.HMCInfo, zs.BayesianNet, zs.meta_bayesian_net,
 zs.distributions.{Normal, Bernoulli, Categorical, UnnormalizedMultinomial},
-zs.diagnostics.effective_sample_size."""
+zs.diagnostics.effective_sample_size, and the callers next to it:
+zs.AIS, zs.SGLD / PSGLD / SGHMC / SGNHT."""
 from . import diagnostics, distributions, evaluation, framework
 from .framework import (BayesianNet, MetaBayesianNet, StochasticTensor,
                         meta_bayesian_net)
@@ -11,11 +12,12 @@ from .distributions import linear_logits
 from .evaluation import AIS
 from .hmc import HMC, HMCInfo, InvalidArgumentError, placeholder
 from .session import Session
+from .sgmcmc import SGMCMC, SGLD, PSGLD, SGHMC, SGNHT
 from .utils import merge_dicts, set_random_seed
 
 __version__ = '0.1.0'
 
-__all__ = ['AIS', 'evaluation', 'HMC', 'HMCInfo', 'InvalidArgumentError', 'placeholder', 'Session',
+__all__ = ['SGMCMC', 'SGLD', 'PSGLD', 'SGHMC', 'SGNHT', 'AIS', 'evaluation', 'HMC', 'HMCInfo', 'InvalidArgumentError', 'placeholder', 'Session',
            'BayesianNet', 'MetaBayesianNet', 'StochasticTensor',
            'meta_bayesian_net', 'distributions', 'diagnostics', 'framework',
            'merge_dicts', 'set_random_seed', 'linear_logits']
