@@ -137,3 +137,47 @@ def test_bayesian_logistic_regression_hmc(env):
         ok = np.abs(ref.last_u01 - rinfo.acceptance_rate) > 2e-2
         np.testing.assert_allclose(wt.cpu().numpy()[ok], wr[ok], atol=5e-4)
         wt.copy_(torch.tensor(wr, device=dev))
+
+
+def test_config3_full_size_properties(env):
+    """BASELINE config 3 at its full size (32 768 chains, 10^6 rows, D = 256;
+    logits would be 131 GB): additivity of the likelihood and its gradient
+    over a split of the rows, and a few chains against float64 NumPy."""
+    zs, torch, dev = env
+    from zhusuan_amd import _capi
+    C, N, D = 32768, 1000000, 256
+    g = torch.Generator(device=dev).manual_seed(0)
+    X = torch.randn(N, D, device=dev, generator=g)
+    w_true = torch.randn(D, device=dev, generator=g)
+    y = (torch.rand(N, device=dev, generator=g) <
+         torch.sigmoid(X @ w_true / D ** 0.5)).float()
+    W = torch.randn(C, D, device=dev, generator=g) * 0.05
+    s = torch.cuda.current_stream().cuda_stream
+
+    def run(x, yy):
+        ll = torch.empty(C, device=dev)
+        gw = torch.empty(C, D, device=dev)
+        _capi.call('zshmc_linear_bernoulli_log_lik', W.data_ptr(), x.data_ptr(),
+                   yy.data_ptr(), C, x.shape[0], D, ll.data_ptr(),
+                   gw.data_ptr(), s)
+        return ll, gw
+
+    ll, gw = run(X, y)
+    h = 400000 + 37                       # ragged split (not a tile multiple)
+    ll_a, gw_a = run(X[:h].contiguous(), y[:h].contiguous())
+    ll_b, gw_b = run(X[h:].contiguous(), y[h:].contiguous())
+    assert bool(torch.isfinite(ll).all()) and bool(torch.isfinite(gw).all())
+    torch.testing.assert_close(ll_a + ll_b, ll, rtol=2e-5, atol=0.5)
+    scale = float(gw.abs().max())
+    torch.testing.assert_close(gw_a + gw_b, gw, rtol=1e-4, atol=2e-5 * scale)
+    # three chains against float64
+    idx = [0, 12345, C - 1]
+    Xh, yh = X.cpu().numpy().astype(np.float64), y.cpu().numpy().astype(np.float64)
+    for c in idx:
+        w = W[c].cpu().numpy().astype(np.float64)
+        l = Xh @ w
+        ll_ref = (yh * l - np.maximum(l, 0) - np.log1p(np.exp(-np.abs(l)))).sum()
+        g_ref = (yh - 1 / (1 + np.exp(-l))) @ Xh
+        np.testing.assert_allclose(float(ll[c]), ll_ref, rtol=2e-5)
+        np.testing.assert_allclose(gw[c].cpu().numpy(), g_ref, rtol=1e-4,
+                                   atol=2e-5 * np.abs(g_ref).max())
