@@ -15,8 +15,12 @@ Pinning status (see DESIGN.md section "Oracle"):
     (oracle/make_golden.py -> tests/golden/ess_fixture.npz).
   * Philox4x32-10 -- PINNED against the Random123 known-answer vectors.
   * HMC transition numerics (leapfrog / MH / dual averaging / mass / step-size
-    search) -- **parity unpinned**: the reference runs on TensorFlow, which is
-    not installable here, and its own tests hold no trajectory-level vectors
-    (only an unseeded KDE bound, tests/test_mcmc.py:55-62).  The restatement
-    follows hmc.py line by line and is validated statistically.
+    search) -- PINNED against traces of the reference's own zhusuan/hmc.py,
+    run unmodified over the eager TensorFlow-API shim oracle/tf_shim.py
+    (oracle/make_golden_hmc.py -> tests/golden/hmc_reference_traces.npz,
+    tests/test_oracle_hmc_reference.py; the device path is held to the same
+    traces in tests/test_gpu_hmc_reference.py).  Not pinnable without a real
+    TensorFlow: its Eigen kernels' last-bit rounding and its random stream.
+  * SGMCMC update numerics (oracle/sgmcmc_ref.py) -- parity unpinned (the
+    reference's tests hold only unseeded KDE bounds, reproduced on the device).
 """

@@ -2,8 +2,16 @@
 TEST INFRASTRUCTURE (see oracle/__init__.py) -- the checker for the HIP path
 and the "port" CPU baseline of bench.py; never imported by zhusuan_amd/.
 
-**Parity unpinned** for the transition numerics: the reference executes on
-TensorFlow (not installable here) and its tests hold no trajectory vectors.
+PINNED (tests/test_oracle_hmc_reference.py) against per-iteration traces
+produced by the reference's OWN zhusuan/hmc.py -- loaded unmodified from
+/root/reference and executed over oracle/tf_shim.py, an eager float32
+torch-CPU stand-in for the TensorFlow symbols hmc.py uses (TensorFlow itself
+is not installable here) -- on four cases covering step-size search, dual
+averaging, EWMV mass adaptation with re-initialisation, fed adaptation
+flags, multi-latent / multi-axis chains (oracle/make_golden_hmc.py ->
+tests/golden/hmc_reference_traces.npz).  What that pins: control flow and
+update equations, by the reference's code; what it cannot pin: TensorFlow's
+Eigen kernels' last-bit rounding and TensorFlow's own random stream.
 Every function below cites the hmc.py lines it restates; the only deliberate
 difference is the random stream (oracle/philox.py), because TensorFlow's
 Philox stream is keyed by graph-level state outside the repository.

@@ -1,0 +1,227 @@
+#!/usr/bin/env python
+"""Golden HMC traces from the reference's OWN implementation.
+
+Runs /root/reference/zhusuan/hmc.py -- unmodified, loaded by file path --
+over oracle/tf_shim.py (an eager float32 torch-CPU stand-in for the ~45
+TensorFlow symbols hmc.py uses; TensorFlow itself is not installable in this
+image) with the Philox stream of oracle/philox.py behind tf.random_normal /
+tf.random_uniform, and records per-iteration HMCInfo + sampler state into
+tests/golden/hmc_reference_traces.npz.  tests/test_oracle_hmc_reference.py
+then pins oracle/hmc_ref.py (and tests/test_gpu_hmc_reference.py the device
+path) to these traces.  Needs /root/reference: run in the build container,
+commit the .npz.
+
+    python -m oracle.make_golden_hmc
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get('ZHUSUAN_REFERENCE', '/root/reference')
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import philox, tf_shim  # noqa: E402
+
+
+def load_reference_hmc():
+    tf = tf_shim.install()
+    pkg = types.ModuleType('zhusuan')
+    pkg.__path__ = [os.path.join(REF, 'zhusuan')]
+    sys.modules['zhusuan'] = pkg
+    mods = {}
+    for name in ('utils', 'hmc'):
+        spec = importlib.util.spec_from_file_location(
+            'zhusuan.' + name, os.path.join(REF, 'zhusuan', name + '.py'))
+        m = importlib.util.module_from_spec(spec)
+        sys.modules['zhusuan.' + name] = m
+        spec.loader.exec_module(m)
+        mods[name] = m
+    return tf, mods['hmc']
+
+
+class Stream(object):
+    """The oracle's Philox mapping behind the shim's random ops."""
+
+    def __init__(self, seed, chain_shape):
+        self.seed, self.chain_shape = seed, tuple(chain_shape)
+        self.n_chains = int(np.prod(chain_shape))
+        self.it, self.k = 0, 0
+
+    def begin(self, it):
+        self.it, self.k = it, 0
+
+    def normal(self, shape):
+        n_data = int(np.prod(shape)) // self.n_chains
+        z = philox.normal_chain_major(self.seed, self.it, self.n_chains,
+                                      n_data, latent_id=self.k)
+        self.k += 1
+        return z.reshape(shape)
+
+    def uniform(self, shape):
+        assert tuple(shape) == self.chain_shape, (shape, self.chain_shape)
+        return philox.uniform_per_chain(self.seed, self.it,
+                                        self.n_chains).reshape(shape)
+
+
+def run_case(tf, ref_hmc, name, make_log_joint, latents, hmc_kwargs, n_iters,
+             flags, seed, chain_shape):
+    """flags(i) -> (adapt_step_size, adapt_mass) values fed at iteration i
+    (None = the sampler was built without that adaptation)."""
+    tf_shim._VARS[:] = []
+    tf_shim.end_replay()
+    kw = dict(hmc_kwargs)
+    ph_ss = ph_m = None
+    if kw.get('adapt_step_size') == 'placeholder':
+        ph_ss = kw['adapt_step_size'] = tf.placeholder(tf.bool, name='adapt_ss')
+    if kw.get('adapt_mass') == 'placeholder':
+        ph_m = kw['adapt_mass'] = tf.placeholder(tf.bool, name='adapt_mass')
+    lat_vars = {k: tf.Variable(np.asarray(v, np.float32), name=k)
+                for k, v in latents.items()}
+    hmc = ref_hmc.HMC(**kw)
+    log_joint = make_log_joint(tf)
+    stream = Stream(seed, chain_shape)
+    tf_shim.set_random_source(stream.normal, stream.uniform)
+    mark = tf_shim.variable_mark()
+    out = {k: [] for k in ('acceptance_rate', 'updated_step_size',
+                           'orig_hamiltonian', 'hamiltonian', 'orig_log_prob',
+                           'log_prob', 'u01_margin')}
+    for k in latents:
+        out['q_' + k] = []
+        out['p0_' + k] = []
+    for i in range(n_iters):
+        f_ss, f_m = flags(i)
+        if ph_ss is not None:
+            ph_ss.feed(bool(f_ss))
+        if ph_m is not None:
+            ph_m.feed(bool(f_m))
+        stream.begin(i + 1)
+        if i > 0:
+            tf_shim.begin_run(mark)
+        _, info = hmc.sample(log_joint, {}, lat_vars)   # = one sess.run
+        tf_shim.end_replay()
+        acc = info.acceptance_rate.detach().numpy()
+        out['acceptance_rate'].append(acc.copy())
+        out['updated_step_size'].append(
+            np.float32(tf_shim._t(info.updated_step_size).detach().numpy()))
+        for f in ('orig_hamiltonian', 'hamiltonian', 'orig_log_prob',
+                  'log_prob'):
+            out[f].append(getattr(info, f).detach().numpy().copy())
+        u = stream.uniform(tuple(chain_shape))
+        out['u01_margin'].append(np.float32(np.abs(u - acc).min()))
+        for k in latents:
+            out['q_' + k].append(lat_vars[k].numpy())
+            out['p0_' + k].append(info.init_momentum[k].detach().numpy().copy())
+    res = {'%s/%s' % (name, k): np.stack(v) for k, v in out.items()}
+    res['%s/t' % name] = np.float32(hmc.t.numpy())
+    print('%-10s iters %d  mean acc %.3f  final eps %.5f  min |u-acc| %.2e' % (
+        name, n_iters, float(np.mean(out['acceptance_rate'][-1])),
+        float(out['updated_step_size'][-1]), float(np.min(out['u01_margin']))))
+    return res
+
+
+# ---- the cases (mirrored in tests/helpers_hmc_cases.py) ----------------------
+def gaussian_log_joint(mean, logstd):
+    """Normal._log_prob (univariate.py:174-181) reduced over the data axis
+    (group_ndims = 1, base.py:302-304), written against the tf API."""
+    def make(tf):
+        m = tf.constant(mean)
+        ls = tf.constant(logstd)
+        c = np.float32(-0.5 * np.log(2 * np.pi))
+
+        def log_joint(obs):
+            x = obs['x']
+            prec = tf.exp(-2 * ls)
+            return tf.reduce_sum(c - ls - 0.5 * prec * tf.square(x - m),
+                                 axis=-1)
+        return log_joint
+    return make
+
+
+def coupled_log_joint(prec_x):
+    """Two latents, chain shape [4, 5]:
+    -0.5 sum prec (x^2) - 0.5 sum y^2 - 0.1 (sum x)(sum y)^2 / 10."""
+    def make(tf):
+        px = tf.constant(prec_x)
+
+        def log_joint(obs):
+            x, y = obs['x'], obs['y']
+            sx = tf.reduce_sum(x, axis=-1)
+            sy = tf.reduce_sum(y, axis=-1)
+            return (-0.5 * tf.reduce_sum(px * tf.square(x), axis=-1)
+                    - 0.5 * tf.reduce_sum(tf.square(y), axis=-1)
+                    - 0.01 * tf.square(sx) * tf.square(sy))
+        return log_joint
+    return make
+
+
+def cases():
+    rng = np.random.RandomState(2024)
+    out = []
+    # A: examples/toy_examples/gaussian.py shape (config 1): step-size AND mass
+    # adaptation fed per run, re-initialisation at t = mass_collect_iters
+    D = 10
+    stdev = (1.0 / (np.arange(D) + 1)).astype(np.float32)
+    out.append(dict(
+        name='gauss_adapt', chain_shape=(24,),
+        make_log_joint=gaussian_log_joint(np.zeros(D, np.float32),
+                                          np.log(stdev).astype(np.float32)),
+        latents={'x': (0.1 * rng.normal(size=(24, D))).astype(np.float32)},
+        hmc_kwargs=dict(step_size=1e-3, n_leapfrogs=5,
+                        adapt_step_size='placeholder', adapt_mass='placeholder',
+                        target_acceptance_rate=0.9),
+        n_iters=22, flags=lambda i: (i < 16, i < 16), seed=11))
+    # B: no adaptation, two latents, two chain axes
+    out.append(dict(
+        name='coupled', chain_shape=(4, 5),
+        make_log_joint=coupled_log_joint(
+            np.linspace(0.5, 2.0, 6).astype(np.float32)),
+        latents={'x': rng.normal(size=(4, 5, 6)).astype(np.float32),
+                 'y': rng.normal(size=(4, 5, 3)).astype(np.float32)},
+        hmc_kwargs=dict(step_size=0.08, n_leapfrogs=7),
+        n_iters=6, flags=lambda i: (None, None), seed=12))
+    # C: step-size adaptation only (constant True), ragged D
+    D = 33
+    out.append(dict(
+        name='gauss_ss', chain_shape=(17,),
+        make_log_joint=gaussian_log_joint(
+            np.linspace(-1, 1, D).astype(np.float32),
+            np.linspace(-0.7, 0.4, D).astype(np.float32)),
+        latents={'x': rng.normal(size=(17, D)).astype(np.float32)},
+        hmc_kwargs=dict(step_size=0.05, n_leapfrogs=4, adapt_step_size=True,
+                        target_acceptance_rate=0.8),
+        n_iters=15, flags=lambda i: (True, None), seed=13))
+    # D: a row length the LDS-DMA ring kernel takes (D % 4 == 0, D > 128,
+    # ragged last 1 KiB chunk), step-size and mass adaptation
+    D = 260
+    out.append(dict(
+        name='gauss_ring', chain_shape=(20,),
+        make_log_joint=gaussian_log_joint(
+            np.linspace(-2, 2, D).astype(np.float32),
+            np.linspace(0.0, 1.2, D).astype(np.float32)),
+        latents={'x': rng.normal(size=(20, D)).astype(np.float32)},
+        hmc_kwargs=dict(step_size=0.02, n_leapfrogs=6,
+                        adapt_step_size='placeholder', adapt_mass='placeholder',
+                        target_acceptance_rate=0.8, mass_collect_iters=4),
+        n_iters=26, flags=lambda i: (i < 22, i < 18), seed=14))
+    return out
+
+
+def main():
+    tf, ref_hmc = load_reference_hmc()
+    res = {}
+    for c in cases():
+        res.update(run_case(tf, ref_hmc, **c))
+        for k, v in c['latents'].items():
+            res['%s/q0_%s' % (c['name'], k)] = v
+    path = os.path.join(ROOT, 'tests', 'golden', 'hmc_reference_traces.npz')
+    np.savez_compressed(path, **res)
+    print('wrote', path, '(%d arrays)' % len(res))
+
+
+if __name__ == '__main__':
+    main()

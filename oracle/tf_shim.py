@@ -1,0 +1,432 @@
+"""A minimal eager stand-in for the TensorFlow-1 API surface that
+/root/reference/zhusuan/hmc.py (and zhusuan/utils.py) touch, backed by
+float32 torch-CPU tensors.  TEST INFRASTRUCTURE (see oracle/__init__.py):
+only oracle/make_golden_hmc.py imports it, in the build container, to run
+the reference's OWN hmc.py -- unmodified, loaded from /root/reference by file
+path -- and record golden HMC traces (tests/golden/hmc_reference_traces.npz)
+that pin oracle/hmc_ref.py.  TensorFlow itself is not installable here
+(requirements-dev.txt:2 "tensorflow>=1.13.0", no wheel, no network).
+
+How a TF-1 *graph* maps onto eager execution:
+
+* `HMC.__init__` runs once and creates the sampler's Variables.
+  `HMC.sample(...)` -- which in TensorFlow only BUILDS the graph that
+  `sess.run(sample_op)` later executes -- is called once PER ITERATION here:
+  every op executes eagerly in program order, so one call is one execution
+  of the graph.  Variables created inside `sample()` (the EWMV state,
+  hmc.py:285-286 -> :118-123) are replayed from a creation-order store on
+  every call after the first (`begin_run`), i.e. they persist like graph
+  variables.
+* `tf.cond` runs only the taken branch, `tf.while_loop` is a Python loop,
+  `tf.control_dependencies` / `tf.name_scope` are no-ops (program order is
+  the order the dependencies request), `tf.gradients` is torch autograd of
+  sum(ys), placeholders are objects whose value is fed before each run.
+* `tf.random_normal` / `tf.random_uniform` draw from the stream the harness
+  installs (`set_random_source`): the Philox mapping of oracle/philox.py, so
+  the reference code, the oracle and the device see identical numbers.
+
+Numerics: float32 torch-CPU kernels stand in for TensorFlow's Eigen kernels
+(same IEEE arithmetic; reductions and exp/log/sqrt may differ in the last
+bit).  What the traces pin is the reference's control flow and update
+equations, executed by the reference's own code.
+"""
+import contextlib
+import sys
+import types
+
+import numpy as np
+import torch
+
+float32 = torch.float32
+float64 = torch.float64
+int32 = torch.int32
+int64 = torch.int64
+bool = torch.bool  # noqa: A001  (tf.bool)
+
+_py_bool = __builtins__['bool'] if isinstance(__builtins__, dict) \
+    else __builtins__.bool
+
+
+class InvalidArgumentError(ArithmeticError):
+    """tf.errors.InvalidArgumentError (raised by check_numerics)."""
+
+
+class TensorShape(object):
+    def __init__(self, dims=()):
+        self.dims = [None if d is None else int(d) for d in dims]
+
+    def __len__(self):
+        return len(self.dims)
+
+    def __bool__(self):
+        return len(self.dims) > 0
+
+    __nonzero__ = __bool__
+
+    def __iter__(self):
+        return iter(self.dims)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return TensorShape(self.dims[i])
+        return self.dims[i]
+
+    def concatenate(self, other):
+        return TensorShape(self.dims + list(other))
+
+    def as_list(self):
+        return list(self.dims)
+
+    def __repr__(self):
+        return 'TensorShape(%r)' % (self.dims,)
+
+
+def _get_shape(t):
+    return TensorShape(tuple(t.shape))
+
+
+# tensors are plain torch tensors; give them the one TF method hmc.py calls
+torch.Tensor.get_shape = _get_shape
+
+
+# ---- variables with graph-like persistence --------------------------------
+_VARS = []
+_CURSOR = [None]      # None = create mode; int = replay index
+
+
+def begin_run(mark):
+    """Call before every re-execution of `sample()` after the first: the
+    Variables it creates are taken from the store starting at `mark`."""
+    _CURSOR[0] = mark
+
+
+def variable_mark():
+    return len(_VARS)
+
+
+def end_replay():
+    _CURSOR[0] = None
+
+
+class Variable(object):
+    def __new__(cls, initial_value=None, name=None, trainable=False,
+                dtype=None, **kw):
+        if _CURSOR[0] is not None:
+            v = _VARS[_CURSOR[0]]
+            _CURSOR[0] += 1
+            return v
+        v = object.__new__(cls)
+        v._init(initial_value, name, dtype)
+        _VARS.append(v)
+        return v
+
+    def __init__(self, *a, **kw):
+        pass
+
+    def _init(self, initial_value, name, dtype):
+        self.name = name
+        self.value = _leaf(convert_to_tensor(initial_value, dtype=dtype))
+
+    # -- TF Variable API used by hmc.py ------------------------------------
+    def assign(self, value):
+        self.value = _leaf(convert_to_tensor(value).to(self.value.dtype))
+        return self.value
+
+    def assign_add(self, delta):
+        return self.assign(self.value.detach() + convert_to_tensor(delta).detach())
+
+    def get_shape(self):
+        return TensorShape(tuple(self.value.shape))
+
+    @property
+    def shape(self):
+        return self.value.shape
+
+    def numpy(self):
+        return self.value.detach().numpy().copy()
+
+    # arithmetic delegates to the current value tensor
+    def __add__(self, o): return self.value + _t(o)
+    def __radd__(self, o): return _t(o) + self.value
+    def __sub__(self, o): return self.value - _t(o)
+    def __rsub__(self, o): return _t(o) - self.value
+    def __mul__(self, o): return self.value * _t(o)
+    def __rmul__(self, o): return _t(o) * self.value
+    def __truediv__(self, o): return self.value / _t(o)
+    def __rtruediv__(self, o): return _t(o) / self.value
+    __div__, __rdiv__ = __truediv__, __rtruediv__
+    def __neg__(self): return -self.value
+    def __pow__(self, o): return self.value ** _t(o)
+    def __lt__(self, o): return self.value < _t(o)
+    def __gt__(self, o): return self.value > _t(o)
+
+
+def _leaf(t):
+    t = t.detach().clone()
+    if t.is_floating_point():
+        t.requires_grad_(True)
+    return t
+
+
+class Placeholder(object):
+    """tf.placeholder: `.feed(v)` before a run."""
+
+    def __init__(self, dtype, shape=None, name=None):
+        self.dtype, self.name, self._v = dtype, name, None
+
+    def feed(self, v):
+        self._v = v
+
+    @property
+    def value(self):
+        assert self._v is not None, 'placeholder %s was not fed' % self.name
+        return torch.as_tensor(self._v, dtype=self.dtype)
+
+
+def placeholder(dtype, shape=None, name=None):
+    return Placeholder(dtype, shape, name)
+
+
+def _t(x):
+    if isinstance(x, Variable):
+        return x.value
+    if isinstance(x, Placeholder):
+        return x.value
+    return x
+
+
+def convert_to_tensor(value, dtype=None, name=None):
+    if isinstance(value, Placeholder):
+        return value                     # resolved where it is consumed
+    if isinstance(value, Variable):
+        value = value.value
+    if isinstance(value, TensorShape):
+        value = value.as_list()
+    if isinstance(value, torch.Tensor):
+        return value if dtype is None or value.dtype == dtype else value.to(dtype)
+    if isinstance(value, np.ndarray):
+        t = torch.from_numpy(np.array(value))
+        return t if dtype is None else t.to(dtype)
+    if dtype is None:
+        dtype = torch.float32 if isinstance(value, float) else (
+            torch.bool if isinstance(value, _py_bool) else (
+                torch.int32 if isinstance(value, int) else torch.float32))
+    return torch.tensor(value, dtype=dtype)
+
+
+def constant(value, dtype=None, name=None, shape=None):
+    return convert_to_tensor(value, dtype=dtype)
+
+
+def cast(x, dtype, name=None):
+    return _t(x).to(dtype)
+
+
+def identity(x, name=None):
+    return _t(x)
+
+
+def stop_gradient(x, name=None):
+    if isinstance(x, (list, tuple)):
+        return [stop_gradient(i) for i in x]
+    return _t(x).detach()
+
+
+def assign(ref, value, name=None):
+    return ref.assign(value)
+
+
+def group(*ops, **kw):
+    return None
+
+
+@contextlib.contextmanager
+def name_scope(name=None, default_name=None, values=None):
+    yield
+
+
+@contextlib.contextmanager
+def control_dependencies(deps):
+    yield
+
+
+def _pred(p):
+    p = _t(p)
+    if isinstance(p, torch.Tensor):
+        return _py_bool(p.item())
+    return _py_bool(p)
+
+
+def cond(pred, true_fn=None, false_fn=None, name=None, fn1=None, fn2=None):
+    true_fn = true_fn or fn1
+    false_fn = false_fn or fn2
+    return true_fn() if _pred(pred) else false_fn()
+
+
+def while_loop(cond, body, loop_vars, back_prop=True, parallel_iterations=10,
+               **kw):
+    lv = list(loop_vars)
+    while _pred(cond(*lv)):
+        lv = list(body(*lv))
+    return lv
+
+
+# ---- element-wise / reductions ---------------------------------------------
+def _axes(axis):
+    if axis is None:
+        return None
+    if isinstance(axis, torch.Tensor):
+        axis = axis.tolist()
+    if isinstance(axis, (list, tuple)):
+        return tuple(int(a) for a in axis)
+    return int(axis)
+
+
+def reduce_sum(x, axis=None, keepdims=False, name=None, **kw):
+    x = _t(x)
+    ax = _axes(axis)
+    if ax is None:
+        return x.sum()
+    if ax == ():
+        return x
+    return x.sum(dim=ax, keepdim=keepdims)
+
+
+def reduce_mean(x, axis=None, keepdims=False, name=None, **kw):
+    x = _t(x)
+    ax = _axes(axis)
+    if ax is None:
+        return x.mean()
+    if ax == ():
+        return x
+    return x.mean(dim=ax, keepdim=keepdims)
+
+
+def add_n(xs, name=None):
+    out = _t(xs[0])
+    for x in xs[1:]:
+        out = out + _t(x)
+    return out
+
+
+def square(x, name=None): return _t(x) * _t(x)
+def sqrt(x, name=None): return torch.sqrt(_t(x))
+def exp(x, name=None): return torch.exp(_t(x))
+def log(x, name=None): return torch.log(_t(x))
+def pow(x, y, name=None): return torch.pow(_tt(x), _tt(y))  # noqa: A001
+def minimum(x, y, name=None): return torch.minimum(_tt(x), _tt(y))
+def less(x, y, name=None): return _tt(x) < _tt(y)
+def equal(x, y, name=None): return _tt(x) == _tt(y)
+def logical_and(x, y, name=None): return torch.logical_and(_tt(x), _tt(y))
+def logical_or(x, y, name=None): return torch.logical_or(_tt(x), _tt(y))
+def logical_xor(x, y, name=None): return torch.logical_xor(_tt(x), _tt(y))
+def logical_not(x, name=None): return torch.logical_not(_tt(x))
+def is_finite(x, name=None): return torch.isfinite(_t(x))
+def abs(x, name=None): return torch.abs(_t(x))  # noqa: A001
+def negative(x, name=None): return -_t(x)
+def add(x, y, name=None): return _tt(x) + _tt(y)
+def subtract(x, y, name=None): return _tt(x) - _tt(y)
+def multiply(x, y, name=None): return _tt(x) * _tt(y)
+def divide(x, y, name=None): return _tt(x) / _tt(y)
+truediv = divide
+
+
+def _tt(x):
+    x = _t(x)
+    return x if isinstance(x, torch.Tensor) else convert_to_tensor(x)
+
+
+def where(condition, x=None, y=None, name=None):
+    return torch.where(_tt(condition), _tt(x), _tt(y))
+
+
+def expand_dims(x, axis, name=None):
+    return _t(x).unsqueeze(axis)
+
+
+def shape(x, name=None):
+    return tuple(_t(x).shape)
+
+
+def _shape_list(s):
+    if isinstance(s, TensorShape):
+        return s.as_list()
+    if isinstance(s, torch.Tensor):
+        return [int(v) for v in s.tolist()]
+    return [int(v) for v in s]
+
+
+def zeros(s, dtype=torch.float32, name=None):
+    return torch.zeros(_shape_list(s), dtype=dtype)
+
+
+def ones(s, dtype=torch.float32, name=None):
+    return torch.ones(_shape_list(s), dtype=dtype)
+
+
+def zeros_like(x, dtype=None, name=None):
+    return torch.zeros_like(_t(x), dtype=dtype)
+
+
+def ones_like(x, dtype=None, name=None):
+    return torch.ones_like(_t(x), dtype=dtype)
+
+
+def range(*a, **kw):  # noqa: A001
+    return torch.arange(*a)
+
+
+def check_numerics(x, message, name=None):
+    x = _t(x)
+    if not _py_bool(torch.isfinite(x).all().item()):
+        raise InvalidArgumentError(message + ' : Tensor had Inf or NaN values')
+    return x
+
+
+def gradients(ys, xs, **kw):
+    """d sum(ys) / d xs (tf.gradients semantics), xs Variables or tensors."""
+    single = not isinstance(xs, (list, tuple))
+    xl = [xs] if single else list(xs)
+    leaves = [_t(x) for x in xl]
+    y = _t(ys)
+    gs = torch.autograd.grad(y.sum(), leaves, allow_unused=True,
+                             retain_graph=True)
+    gs = [torch.zeros_like(l) if g is None else g.detach()
+          for g, l in zip(gs, leaves)]
+    return gs
+
+
+# ---- random ops: the harness installs the source ----------------------------
+_RANDOM = {'normal': None, 'uniform': None}
+
+
+def set_random_source(normal_fn, uniform_fn):
+    """normal_fn(shape) / uniform_fn(shape) -> float32 numpy arrays; called
+    in program order (one random_normal per latent in random_momentum,
+    hmc.py:21-23; one random_uniform in the MH block, :485)."""
+    _RANDOM['normal'], _RANDOM['uniform'] = normal_fn, uniform_fn
+
+
+def random_normal(shape, mean=0.0, stddev=1.0, dtype=torch.float32, seed=None,
+                  name=None):
+    z = torch.from_numpy(np.ascontiguousarray(
+        _RANDOM['normal'](tuple(_shape_list(shape))), dtype=np.float32))
+    return z * stddev + mean
+
+
+def random_uniform(shape, minval=0, maxval=None, dtype=torch.float32,
+                   seed=None, name=None):
+    return torch.from_numpy(np.ascontiguousarray(
+        _RANDOM['uniform'](tuple(_shape_list(shape))), dtype=np.float32))
+
+
+def install():
+    """Register this module as `tensorflow` (only if the real one is absent)."""
+    mod = sys.modules[__name__]
+    if 'tensorflow' in sys.modules and sys.modules['tensorflow'] is not mod:
+        raise RuntimeError('a real tensorflow is importable: use it instead')
+    sys.modules['tensorflow'] = mod
+    errors = types.ModuleType('tensorflow.errors')
+    errors.InvalidArgumentError = InvalidArgumentError
+    mod.errors = errors
+    return mod

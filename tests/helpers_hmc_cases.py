@@ -1,0 +1,78 @@
+"""The three HMC cases of tests/golden/hmc_reference_traces.npz (produced by
+running the reference's own zhusuan/hmc.py, see oracle/make_golden_hmc.py),
+restated for the oracle (NumPy log-joint + analytic gradient)."""
+import numpy as np
+
+F32 = np.float32
+
+
+def gaussian_model(mean, logstd):
+    mean, logstd = mean.astype(F32), logstd.astype(F32)
+    c = F32(-0.5 * np.log(2 * np.pi))
+    prec = np.exp(F32(-2) * logstd).astype(F32)
+
+    def log_joint(qs):
+        x = qs[0]
+        return np.sum(c - logstd - F32(0.5) * prec * np.square(x - mean),
+                      axis=-1, dtype=F32)
+
+    def grad(qs):
+        return [(-prec * (qs[0] - mean)).astype(F32)]
+    return log_joint, grad
+
+
+def coupled_model(prec_x):
+    px = prec_x.astype(F32)
+
+    def log_joint(qs):
+        x, y = qs
+        sx, sy = x.sum(-1, dtype=F32), y.sum(-1, dtype=F32)
+        return (F32(-0.5) * np.sum(px * np.square(x), axis=-1, dtype=F32)
+                - F32(0.5) * np.sum(np.square(y), axis=-1, dtype=F32)
+                - F32(0.01) * np.square(sx) * np.square(sy)).astype(F32)
+
+    def grad(qs):
+        x, y = qs
+        sx, sy = x.sum(-1, dtype=F32), y.sum(-1, dtype=F32)
+        gx = -px * x - (F32(0.02) * sx * np.square(sy))[..., None]
+        gy = -y - (F32(0.02) * np.square(sx) * sy)[..., None]
+        return [gx.astype(F32), gy.astype(F32)]
+    return log_joint, grad
+
+
+def cases():
+    D = 10
+    stdev = (1.0 / (np.arange(D) + 1)).astype(F32)
+    yield dict(name='gauss_adapt', latent_names=['x'],
+               model=gaussian_model(np.zeros(D, F32), np.log(stdev).astype(F32)),
+               params=dict(mean=np.zeros(D, F32), logstd=np.log(stdev).astype(F32)),
+               hmc_kwargs=dict(step_size=1e-3, n_leapfrogs=5,
+                               adapt_step_size=True, adapt_mass=True,
+                               target_acceptance_rate=0.9),
+               n_iters=22, flags=lambda i: (i < 16, i < 16), seed=11)
+    yield dict(name='coupled', latent_names=['x', 'y'],
+               model=coupled_model(np.linspace(0.5, 2.0, 6).astype(F32)),
+               params=dict(prec_x=np.linspace(0.5, 2.0, 6).astype(F32)),
+               hmc_kwargs=dict(step_size=0.08, n_leapfrogs=7),
+               n_iters=6, flags=lambda i: (None, None), seed=12)
+    D = 33
+    yield dict(name='gauss_ss', latent_names=['x'],
+               model=gaussian_model(np.linspace(-1, 1, D).astype(F32),
+                                    np.linspace(-0.7, 0.4, D).astype(F32)),
+               params=dict(mean=np.linspace(-1, 1, D).astype(F32),
+                           logstd=np.linspace(-0.7, 0.4, D).astype(F32)),
+               hmc_kwargs=dict(step_size=0.05, n_leapfrogs=4,
+                               adapt_step_size=True,
+                               target_acceptance_rate=0.8),
+               n_iters=15, flags=lambda i: (True, None), seed=13)
+    D = 260
+    yield dict(name='gauss_ring', latent_names=['x'],
+               model=gaussian_model(np.linspace(-2, 2, D).astype(F32),
+                                    np.linspace(0.0, 1.2, D).astype(F32)),
+               params=dict(mean=np.linspace(-2, 2, D).astype(F32),
+                           logstd=np.linspace(0.0, 1.2, D).astype(F32)),
+               hmc_kwargs=dict(step_size=0.02, n_leapfrogs=6,
+                               adapt_step_size=True, adapt_mass=True,
+                               target_acceptance_rate=0.8,
+                               mass_collect_iters=4),
+               n_iters=26, flags=lambda i: (i < 22, i < 18), seed=14)

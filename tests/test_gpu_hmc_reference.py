@@ -1,0 +1,99 @@
+"""The device path (zhusuan_amd.HMC through the C-ABI: fused register and
+ring kernels, generic plan, on-device adaptation) against traces produced by
+the reference's OWN zhusuan/hmc.py (oracle/make_golden_hmc.py ->
+tests/golden/hmc_reference_traces.npz), on the shared Philox stream."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers_hmc_cases import cases
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def env():
+    import torch
+    import zhusuan_amd as zs
+    assert torch.cuda.is_available()
+    traces = np.load(os.path.join(os.path.dirname(__file__), 'golden',
+                                  'hmc_reference_traces.npz'))
+    return zs, torch, torch.device('cuda', 0), traces
+
+
+def _build(zs, torch, dev, case, qs):
+    """The same model through the product's own front-end."""
+    name = case['name']
+    if name.startswith('gauss'):
+        mean = torch.tensor(case['params']['mean'], device=dev)
+        logstd = torch.tensor(case['params']['logstd'], device=dev)
+        C = qs['x'].shape[0]
+
+        @zs.meta_bayesian_net()
+        def model():
+            bn = zs.BayesianNet()
+            bn.normal('x', mean, logstd=logstd, n_samples=C, group_ndims=1)
+            return bn
+        return model(), 'fused_diag_normal'
+    px = torch.tensor(case['params']['prec_x'], device=dev)
+
+    def log_joint(obs):
+        x, y = obs['x'], obs['y']
+        sx, sy = x.sum(-1), y.sum(-1)
+        return (-0.5 * (px * x ** 2).sum(-1) - 0.5 * (y ** 2).sum(-1)
+                - 0.01 * sx ** 2 * sy ** 2)
+    return log_joint, 'generic'
+
+
+@pytest.mark.parametrize('case', list(cases()), ids=lambda c: c['name'])
+def test_device_reproduces_reference_hmc_traces(env, case):
+    zs, torch, dev, traces = env
+    name = case['name']
+    qs = {k: torch.tensor(traces['%s/q0_%s' % (name, k)], device=dev)
+          for k in case['latent_names']}
+    kw = dict(case['hmc_kwargs'])
+    ph_ss = ph_m = None
+    if kw.get('adapt_step_size') is True and case['flags'](0)[0] is not None \
+            and name != 'gauss_ss':
+        ph_ss = kw['adapt_step_size'] = zs.placeholder(bool)
+    if kw.get('adapt_mass') is True:
+        ph_m = kw['adapt_mass'] = zs.placeholder(bool)
+    hmc = zs.HMC(seed=case['seed'], **kw)
+    model, plan = _build(zs, torch, dev, case, qs)
+    op, info = hmc.sample(model, {}, qs)
+    assert hmc.plan_kind == plan
+    n_flip = n_total = 0
+    for i in range(case['n_iters']):
+        f_ss, f_m = case['flags'](i)
+        feed = {}
+        if ph_ss is not None:
+            feed[ph_ss] = bool(f_ss)
+        if ph_m is not None:
+            feed[ph_m] = bool(f_m)
+        op.run(feed_dict=feed)
+        acc_ref = traces[name + '/acceptance_rate'][i]
+        # energies are O(10..600): hardware log/sin/cos normals + fp32 sums
+        for f in ('orig_hamiltonian', 'hamiltonian', 'orig_log_prob'):
+            want = traces['%s/%s' % (name, f)][i]
+            np.testing.assert_allclose(getattr(info, f).cpu().numpy(), want,
+                                       rtol=1e-4, atol=2e-3,
+                                       err_msg='%s it %d' % (f, i))
+        np.testing.assert_allclose(info.acceptance_rate.cpu().numpy(), acc_ref,
+                                   atol=3e-3)
+        np.testing.assert_allclose(float(info.updated_step_size.item()),
+                                   float(traces[name + '/updated_step_size'][i]),
+                                   rtol=2e-3)
+        # accept decisions: identical except for borderline |u - acc|
+        for k in case['latent_names']:
+            want = traces['%s/q_%s' % (name, k)][i]
+            got = qs[k].cpu().numpy()
+            lead = want.shape[:acc_ref.ndim]
+            diff = np.abs(got - want).reshape(int(np.prod(lead)), -1).max(1)
+            bad = diff > 2e-3 * (1.0 + np.abs(want).max())
+            n_flip += int(bad.sum())
+            n_total += bad.size
+            # continue from the reference's state (teacher forcing)
+            qs[k].copy_(torch.tensor(want, device=dev))
+    assert n_flip <= max(1, n_total // 200), (n_flip, n_total)
+    assert hmc.t == int(traces[name + '/t'])
