@@ -21,6 +21,7 @@ Pinning status (see DESIGN.md section "Oracle"):
     tests/test_oracle_hmc_reference.py; the device path is held to the same
     traces in tests/test_gpu_hmc_reference.py).  Not pinnable without a real
     TensorFlow: its Eigen kernels' last-bit rounding and its random stream.
-  * SGMCMC update numerics (oracle/sgmcmc_ref.py) -- parity unpinned (the
-    reference's tests hold only unseeded KDE bounds, reproduced on the device).
+  * SGMCMC update numerics (oracle/sgmcmc_ref.py) -- PINNED the same way
+    against the reference's own zhusuan/sgmcmc.py (oracle/make_golden_sgmcmc.py
+    -> tests/golden/sgmcmc_reference_traces.npz).
 """

@@ -1,10 +1,14 @@
 """NumPy-float32 restatement of /root/reference/zhusuan/sgmcmc.py (SGLD,
 PSGLD, SGHMC, SGNHT).  TEST INFRASTRUCTURE (see oracle/__init__.py).
 
-PARITY UNPINNED for the update numerics: TensorFlow is not installable here
-and the reference's tests for this module (tests/test_mcmc.py:65-88) hold no
-vectors, only the KDE bounds 0.023 / 0.016 of an unseeded run, which
-tests/test_gpu_sgmcmc.py reproduces on the device path.  The Gaussian terms
+PINNED (tests/test_oracle_sgmcmc_reference.py) against traces of the
+reference's OWN zhusuan/sgmcmc.py, loaded unmodified from /root/reference and
+run over the eager TensorFlow-API shim oracle/tf_shim.py on the stream below
+(oracle/make_golden_sgmcmc.py -> tests/golden/sgmcmc_reference_traces.npz):
+8 sampler configurations (SGLD, PSGLD, SGHMC and SGNHT first/second order,
+vector/scalar friction, momentum resampling), two coupled latents.  The
+reference's statistical tests (tests/test_mcmc.py:65-88, KDE bounds 0.023 /
+0.016) are reproduced on the device path in tests/test_gpu_sgmcmc.py.  The Gaussian terms
 (tf.random_normal, sgmcmc.py:200,250,311,318,326,446,455) come from the
 shared Philox stream oracle/philox.py defines:
     counter (i//4 lo, i//4 hi, iteration, 3 | sub << 4 | latent_id << 8),

@@ -1,10 +1,11 @@
 """A minimal eager stand-in for the TensorFlow-1 API surface that
 /root/reference/zhusuan/hmc.py (and zhusuan/utils.py) touch, backed by
 float32 torch-CPU tensors.  TEST INFRASTRUCTURE (see oracle/__init__.py):
-only oracle/make_golden_hmc.py imports it, in the build container, to run
-the reference's OWN hmc.py -- unmodified, loaded from /root/reference by file
-path -- and record golden HMC traces (tests/golden/hmc_reference_traces.npz)
-that pin oracle/hmc_ref.py.  TensorFlow itself is not installable here
+only oracle/make_golden_hmc.py and oracle/make_golden_sgmcmc.py import it, in
+the build container, to run the reference's OWN hmc.py / sgmcmc.py --
+unmodified, loaded from /root/reference by file path -- and record golden
+traces (tests/golden/{hmc,sgmcmc}_reference_traces.npz) that pin
+oracle/hmc_ref.py and oracle/sgmcmc_ref.py.  TensorFlow itself is not installable here
 (requirements-dev.txt:2 "tensorflow>=1.13.0", no wheel, no network).
 
 How a TF-1 *graph* maps onto eager execution:
@@ -157,6 +158,7 @@ class Variable(object):
     __div__, __rdiv__ = __truediv__, __rtruediv__
     def __neg__(self): return -self.value
     def __pow__(self, o): return self.value ** _t(o)
+    def __mod__(self, o): return torch.remainder(self.value, _t(o))
     def __lt__(self, o): return self.value < _t(o)
     def __gt__(self, o): return self.value > _t(o)
 
@@ -324,6 +326,7 @@ def logical_not(x, name=None): return torch.logical_not(_tt(x))
 def is_finite(x, name=None): return torch.isfinite(_t(x))
 def abs(x, name=None): return torch.abs(_t(x))  # noqa: A001
 def negative(x, name=None): return -_t(x)
+def mod(x, y, name=None): return torch.remainder(_tt(x), _tt(y))
 def add(x, y, name=None): return _tt(x) + _tt(y)
 def subtract(x, y, name=None): return _tt(x) - _tt(y)
 def multiply(x, y, name=None): return _tt(x) * _tt(y)

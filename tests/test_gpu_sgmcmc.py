@@ -156,3 +156,35 @@ def test_sghmc_reference_statistical_test(env, second_order):
                        seed=6)
     e = _sample_error_with(zs, torch, dev, sampler, n_chains=100, n_iters=8000)
     assert e <= 0.016
+
+
+def test_reference_traces(env):
+    """The device path against traces of the reference's OWN zhusuan/sgmcmc.py
+    (oracle/make_golden_sgmcmc.py -> tests/golden/sgmcmc_reference_traces.npz)."""
+    import os
+    from test_oracle_sgmcmc_reference import CASES as REF_CASES, SEED
+    zs, torch, dev = env
+    tr = np.load(os.path.join(os.path.dirname(__file__), 'golden',
+                              'sgmcmc_reference_traces.npz'))
+    log_joint, _ = _model(torch, dev, tr['w0'].shape[1])
+    for name, cls, kw in REF_CASES:
+        wt = torch.tensor(tr['w0'], device=dev)
+        bt = torch.tensor(tr['b0'], device=dev)
+        sampler = getattr(zs, cls)(seed=SEED, **kw)
+        op, info = sampler.sample(log_joint, {}, {'w': wt, 'b': bt})
+        for i in range(tr[name + '/w'].shape[0]):
+            op.run()
+            np.testing.assert_allclose(wt.cpu().numpy(), tr[name + '/w'][i],
+                                       rtol=3e-5, atol=3e-5,
+                                       err_msg='%s w it %d' % (name, i))
+            np.testing.assert_allclose(bt.cpu().numpy(), tr[name + '/b'][i],
+                                       rtol=3e-5, atol=3e-5,
+                                       err_msg='%s b it %d' % (name, i))
+            for f in ('mean_k', 'alpha'):
+                key = '%s/%s_w' % (name, f)
+                if key in tr.files:
+                    for nm in ('w', 'b'):
+                        np.testing.assert_allclose(
+                            getattr(info, f)[nm].cpu().numpy(),
+                            tr['%s/%s_%s' % (name, f, nm)][i], rtol=2e-4,
+                            atol=1e-6, err_msg='%s %s it %d' % (name, f, i))
