@@ -329,6 +329,34 @@ int zshmc_sgnht_scalar(float* alpha_scalar, double* sums, int64_t n,
                        float learning_rate, float tune_rate, int second_order,
                        int phase, float* mean_k_out, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Two-parameter continuous families (zhusuan/distributions/univariate.py):
+ *   kind 0 Laplace(loc, scale) :1164-1277      kind 1 Gamma(alpha, beta) :662-751
+ *   kind 2 InverseGamma(alpha, beta) :1070-1161  kind 3 Beta(alpha, beta) :753-855
+ * Same conventions as zshmc_normal_log_prob[_grad]: x is [rows, cols], a / b are
+ * broadcast per their mode, reduce_cols sums each row (group_ndims,
+ * base.py:302-304); the gradient call fills any of gx / ga / gb that is not
+ * NULL with gout * d log_prob / d(value, a, b) at full [rows, cols] shape.
+ * zshmc_uni2_sample draws n = n_samples * inner values (parameters indexed by
+ * i % inner, FULL over one sample or SCALAR); Gamma-type draws restate
+ * tf.random_gamma (:725-727) as Marsaglia-Tsang rejection on the Philox stream.
+ */
+#define ZSHMC_UNI2_LAPLACE 0
+#define ZSHMC_UNI2_GAMMA 1
+#define ZSHMC_UNI2_INVERSE_GAMMA 2
+#define ZSHMC_UNI2_BETA 3
+int zshmc_uni2_log_prob(int kind, const float* x, const float* a, const float* b,
+                        float* out, int64_t rows, int64_t cols, int a_bcast,
+                        int b_bcast, int reduce_cols, void* stream);
+int zshmc_uni2_log_prob_grad(int kind, const float* x, const float* a,
+                             const float* b, const float* gout, float* gx,
+                             float* ga, float* gb, int64_t rows, int64_t cols,
+                             int a_bcast, int b_bcast, int reduce_cols,
+                             void* stream);
+int zshmc_uni2_sample(int kind, float* out, const float* a, const float* b,
+                      int64_t n, int64_t inner, int a_bcast, int b_bcast,
+                      uint64_t seed, uint32_t offset, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

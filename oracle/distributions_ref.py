@@ -207,3 +207,79 @@ class UnnormalizedMultinomial(object):
             return given.copy()
         soft = np.exp(logits - _logsumexp(logits, axis=-1, keepdims=True))
         return given - np.sum(given, axis=-1, keepdims=True) * soft
+
+
+# ---------------------------------------------------------------------------
+# Two-parameter continuous families.  lgamma /
+# digamma come from scipy.special (float64, rounded once): the closed forms
+# are the reference's, line for line.
+# ---------------------------------------------------------------------------
+class _TwoParam(object):
+    def __init__(self, a, b, group_ndims=0):
+        self.a = np.asarray(a, dtype=F32)
+        self.b = np.asarray(b, dtype=F32)
+        self.group_ndims = group_ndims
+
+    def log_prob(self, given):
+        return _group_sum(self._log_prob(np.asarray(given, dtype=F32)),
+                          self.group_ndims)
+
+
+class Laplace(_TwoParam):
+    """univariate.py:1164-1277; _log_prob :1268-1275."""
+
+    def _log_prob(self, given):
+        return (-np.log(2.) - np.log(self.b.astype(np.float64))
+                - np.abs(given.astype(np.float64) - self.a) / self.b).astype(F32)
+
+    def grads(self, given):
+        d = np.asarray(given, np.float64) - self.a
+        s = np.sign(d)
+        b = self.b.astype(np.float64)
+        return (-s / b), (s / b), (-1 / b + np.abs(d) / b ** 2)
+
+
+class Gamma(_TwoParam):
+    """univariate.py:662-751; _log_prob :735-748 (rate parameter beta)."""
+
+    def _log_prob(self, given):
+        from scipy.special import gammaln
+        a, b, x = (v.astype(np.float64) for v in (self.a, self.b, given))
+        return (a * np.log(b) - gammaln(a) + (a - 1) * np.log(x) - b * x).astype(F32)
+
+    def grads(self, given):
+        from scipy.special import digamma
+        a, b, x = (np.asarray(v, np.float64) for v in (self.a, self.b, given))
+        return ((a - 1) / x - b, np.log(b) - digamma(a) + np.log(x), a / b - x)
+
+
+class InverseGamma(_TwoParam):
+    """univariate.py:1070-1161; _log_prob :1145-1157."""
+
+    def _log_prob(self, given):
+        from scipy.special import gammaln
+        a, b, x = (v.astype(np.float64) for v in (self.a, self.b, given))
+        return (a * np.log(b) - gammaln(a) - (a + 1) * np.log(x) - b / x).astype(F32)
+
+    def grads(self, given):
+        from scipy.special import digamma
+        a, b, x = (np.asarray(v, np.float64) for v in (self.a, self.b, given))
+        return (-(a + 1) / x + b / x ** 2, np.log(b) - digamma(a) - np.log(x),
+                a / b - 1 / x)
+
+
+class Beta(_TwoParam):
+    """univariate.py:753-855; _log_prob :834-853."""
+
+    def _log_prob(self, given):
+        from scipy.special import gammaln
+        a, b, x = (v.astype(np.float64) for v in (self.a, self.b, given))
+        return ((a - 1) * np.log(x) + (b - 1) * np.log1p(-x)
+                - (gammaln(a) + gammaln(b) - gammaln(a + b))).astype(F32)
+
+    def grads(self, given):
+        from scipy.special import digamma
+        a, b, x = (np.asarray(v, np.float64) for v in (self.a, self.b, given))
+        return ((a - 1) / x - (b - 1) / (1 - x),
+                np.log(x) - digamma(a) + digamma(a + b),
+                np.log1p(-x) - digamma(b) + digamma(a + b))

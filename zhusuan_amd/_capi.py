@@ -40,6 +40,14 @@ PROTOTYPES = {
     'zshmc_fused_kernel_name': (c_char_p, [c_int64, c_int]),
     'zshmc_ess_series': (c_int, [_p, c_int64, c_int64, _p, _p]),
     'zshmc_min_positive_rows': (c_int, [_p, c_int64, c_int64, _p, _p]),
+    'zshmc_uni2_log_prob': (c_int, [
+        c_int, _p, _p, _p, _p, c_int64, c_int64, c_int, c_int, c_int, _p]),
+    'zshmc_uni2_log_prob_grad': (c_int, [
+        c_int, _p, _p, _p, _p, _p, _p, _p, c_int64, c_int64, c_int, c_int,
+        c_int, _p]),
+    'zshmc_uni2_sample': (c_int, [
+        c_int, _p, _p, _p, c_int64, c_int64, c_int, c_int, c_uint64, c_uint32,
+        _p]),
     'zshmc_sgld_update': (c_int, [
         _p, _p, _p, c_float, c_float, c_float, c_int64, c_uint64, c_uint32,
         c_uint32, _p]),

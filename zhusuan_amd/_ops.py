@@ -126,6 +126,49 @@ class NormalLogProb(torch.autograd.Function):
                 _sum_to(gs, ss) if need_s else None, None)
 
 
+class Uni2LogProb(torch.autograd.Function):
+    """Laplace / Gamma / InverseGamma / Beta `_log_prob` + group_ndims sum
+    (reference distributions/univariate.py:1268-1275, :735-748, :1145-1157,
+    :834-853; base.py:302-304) and their analytic gradients w.r.t. the value
+    and both parameters (csrc/distributions2.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, a, b, kind, group_ndims):
+        require_device(x, a, b)
+        full = torch.broadcast_shapes(x.shape, a.shape, b.shape)
+        n_col = choose_col_dims(full, group_ndims, a, b)
+        rows, cols = _rows_cols(full, n_col)
+        xf = x.expand(full).contiguous()
+        (pa, ma), (pb, mb) = bcast_plan(full, n_col, a, b)
+        reduce_cols = 1 if group_ndims > 0 else 0
+        out_shape = full[:len(full) - group_ndims] if reduce_cols else full
+        out = torch.empty(out_shape, dtype=_F32, device=x.device)
+        _capi.call('zshmc_uni2_log_prob', int(kind), xf.data_ptr(),
+                   pa.data_ptr(), pb.data_ptr(), out.data_ptr(), rows, cols, ma,
+                   mb, reduce_cols, _capi.current_stream())
+        ctx.save_for_backward(xf, pa, pb)
+        ctx.meta = (int(kind), full, rows, cols, ma, mb, reduce_cols, x.shape,
+                    a.shape, b.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        xf, pa, pb = ctx.saved_tensors
+        kind, full, rows, cols, ma, mb, reduce_cols, xs, as_, bs = ctx.meta
+        need_x, need_a, need_b = ctx.needs_input_grad[:3]
+        gout = gout.contiguous()
+        mk = lambda need: torch.empty(full, dtype=_F32, device=xf.device) \
+            if need else None
+        gx, ga, gb = mk(need_x), mk(need_a), mk(need_b)
+        _capi.call('zshmc_uni2_log_prob_grad', kind, xf.data_ptr(),
+                   pa.data_ptr(), pb.data_ptr(), gout.data_ptr(), _capi.ptr(gx),
+                   _capi.ptr(ga), _capi.ptr(gb), rows, cols, ma, mb,
+                   reduce_cols, _capi.current_stream())
+        return (_sum_to(gx, xs) if need_x else None,
+                _sum_to(ga, as_) if need_a else None,
+                _sum_to(gb, bs) if need_b else None, None, None)
+
+
 class BernoulliLogProb(torch.autograd.Function):
     """Bernoulli._log_prob (reference univariate.py:398-403)."""
 

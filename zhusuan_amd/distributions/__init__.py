@@ -1,8 +1,9 @@
 from .base import Distribution
 from .univariate import (Normal, Bernoulli, Categorical, Discrete,
                          LinearLogits, linear_logits)
+from .univariate2 import Laplace, Gamma, InverseGamma, Beta
 from .multivariate import UnnormalizedMultinomial, BagofCategoricals
 
-__all__ = ['Distribution', 'Normal', 'Bernoulli', 'Categorical', 'Discrete',
+__all__ = ['Distribution', 'Laplace', 'Gamma', 'InverseGamma', 'Beta', 'Normal', 'Bernoulli', 'Categorical', 'Discrete',
            'UnnormalizedMultinomial', 'BagofCategoricals', 'LinearLogits',
            'linear_logits']

@@ -242,6 +242,34 @@ class _BayesianNet(object):
             check_numerics=check_numerics, **kwargs)
         return self.stochastic(name, dist, n_samples=n_samples, **kwargs)
 
+    def laplace(self, name, loc, scale, n_samples=None, group_ndims=0,
+                is_reparameterized=True, check_numerics=False, **kwargs):
+        """bn.py (reference): add a Laplace node."""
+        dist = distributions.Laplace(
+            loc, scale, group_ndims=group_ndims,
+            is_reparameterized=is_reparameterized,
+            check_numerics=check_numerics, **kwargs)
+        return self.stochastic(name, dist, n_samples=n_samples, **kwargs)
+
+    def gamma(self, name, alpha, beta, n_samples=None, group_ndims=0,
+              check_numerics=False, **kwargs):
+        dist = distributions.Gamma(alpha, beta, group_ndims=group_ndims,
+                                   check_numerics=check_numerics, **kwargs)
+        return self.stochastic(name, dist, n_samples=n_samples, **kwargs)
+
+    def inverse_gamma(self, name, alpha, beta, n_samples=None, group_ndims=0,
+                      check_numerics=False, **kwargs):
+        dist = distributions.InverseGamma(
+            alpha, beta, group_ndims=group_ndims,
+            check_numerics=check_numerics, **kwargs)
+        return self.stochastic(name, dist, n_samples=n_samples, **kwargs)
+
+    def beta(self, name, alpha, beta, n_samples=None, group_ndims=0,
+             check_numerics=False, **kwargs):
+        dist = distributions.Beta(alpha, beta, group_ndims=group_ndims,
+                                  check_numerics=check_numerics, **kwargs)
+        return self.stochastic(name, dist, n_samples=n_samples, **kwargs)
+
     def bernoulli(self, name, logits, n_samples=None, group_ndims=0,
                   dtype=torch.int32, **kwargs):
         """bn.py:628-654."""
