@@ -38,6 +38,81 @@ __device__ __forceinline__ float sigmoidf(float l) {
   return 1.0f / (1.0f + expf(-l));
 }
 
+typedef float d4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ d4 fetch4(const float* __restrict__ p, int mode,
+                                     int64_t i, int64_t col) {
+  if (mode == ZSHMC_BCAST_FULL) return *reinterpret_cast<const d4*>(p + i);
+  if (mode == ZSHMC_BCAST_ROW) return *reinterpret_cast<const d4*>(p + col);
+  const float v = p[0];
+  return d4{v, v, v, v};
+}
+
+// 16-B vectorised variants (cols % 4 == 0, every array 16-B aligned): four
+// consecutive columns per lane
+template <int KIND>
+__global__ __launch_bounds__(256) void lp_rowsum_vec_kernel(
+    const float* __restrict__ a, const float* __restrict__ b,
+    const float* __restrict__ c, float* __restrict__ out, int64_t rows,
+    int64_t cols, int mode_b, int mode_c) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+  const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x / 64);
+  for (int64_t r = wave; r < rows; r += n_waves) {
+    float s = 0.f;
+    for (int64_t col = (int64_t)lane * 4; col < cols; col += 256) {
+      const int64_t i = r * cols + col;
+      if (KIND == 0) {
+        const d4 x = *reinterpret_cast<const d4*>(a + i);
+        const d4 m = fetch4(b, mode_b, i, col), ls = fetch4(c, mode_c, i, col);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += normal_lp(x[j], m[j], ls[j]);
+      } else {
+        const d4 l = fetch4(a, mode_b, i, col), z = fetch4(b, mode_c, i, col);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += bernoulli_lp(l[j], z[j]);
+      }
+    }
+    s = group_sum<64>(s);
+    if (lane == 0) out[r] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void normal_grad_vec_kernel(
+    const float* __restrict__ x, const float* __restrict__ mean,
+    const float* __restrict__ logstd, const float* __restrict__ gout,
+    float* __restrict__ gx, float* __restrict__ gmean,
+    float* __restrict__ glogstd, int64_t n, int64_t cols, int mode_m,
+    int mode_s, int reduce_cols) {
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n;
+       i += (int64_t)gridDim.x * blockDim.x * 4) {
+    const int64_t col = i % cols;  // cols % 4 == 0: the group stays in one row
+    d4 g;
+    if (reduce_cols) {
+      const float gr = gout[i / cols];
+      g = d4{gr, gr, gr, gr};
+    } else {
+      g = *reinterpret_cast<const d4*>(gout + i);
+    }
+    const d4 ls = fetch4(logstd, mode_s, i, col);
+    const d4 m = fetch4(mean, mode_m, i, col);
+    const d4 xv = *reinterpret_cast<const d4*>(x + i);
+    d4 ox, om, os;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float prec = expf(-2.0f * ls[j]);
+      const float d = xv[j] - m[j];
+      const float pd = prec * d;
+      ox[j] = -g[j] * pd;
+      om[j] = g[j] * pd;
+      os[j] = g[j] * (pd * d - 1.0f);
+    }
+    if (gx) *reinterpret_cast<d4*>(gx + i) = ox;
+    if (gmean) *reinterpret_cast<d4*>(gmean + i) = om;
+    if (glogstd) *reinterpret_cast<d4*>(glogstd + i) = os;
+  }
+}
+
 // ---- element-wise forward (reduce_cols == 0) -----------------------------
 template <int KIND>  // 0 normal, 1 bernoulli
 __global__ __launch_bounds__(256) void lp_elementwise_kernel(
@@ -255,6 +330,9 @@ static inline int wave_row_grid(int64_t rows) {
   if (b > cap) b = cap;
   return (int)(b > 0 ? b : 1);
 }
+static inline bool al16(const void* p) {
+  return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+}
 static inline bool mode_ok(int m) {
   return m == ZSHMC_BCAST_FULL || m == ZSHMC_BCAST_ROW || m == ZSHMC_BCAST_SCALAR;
 }
@@ -274,7 +352,12 @@ extern "C" int zshmc_normal_log_prob(const float* x, const float* mean,
   ZS_REQUIRE(rows >= 0 && cols >= 1, "zshmc_normal_log_prob: bad shape");
   ZS_REQUIRE(mode_ok(mean_bcast) && mode_ok(logstd_bcast),
              "zshmc_normal_log_prob: bad broadcast mode");
-  if (reduce_cols)
+  const bool vec = cols % 4 == 0 && al16(x) && al16(mean) && al16(logstd);
+  if (reduce_cols && vec)
+    hipLaunchKernelGGL(lp_rowsum_vec_kernel<0>, dim3(wave_row_grid(rows)),
+                       dim3(256), 0, ZS_STREAM, x, mean, logstd, out, rows, cols,
+                       mean_bcast, logstd_bcast);
+  else if (reduce_cols)
     hipLaunchKernelGGL(lp_rowsum_kernel<0>, dim3(wave_row_grid(rows)), dim3(256),
                        0, ZS_STREAM, x, mean, logstd, out, rows, cols,
                        mean_bcast, logstd_bcast);
@@ -295,9 +378,18 @@ extern "C" int zshmc_normal_log_prob_grad(
   ZS_REQUIRE(rows >= 0 && cols >= 1, "zshmc_normal_log_prob_grad: bad shape");
   ZS_REQUIRE(mode_ok(mean_bcast) && mode_ok(logstd_bcast),
              "zshmc_normal_log_prob_grad: bad broadcast mode");
-  hipLaunchKernelGGL(normal_grad_kernel, dim3(flat_grid(rows * cols)), dim3(256),
-                     0, ZS_STREAM, x, mean, logstd, gout, gx, gmean, glogstd,
-                     rows * cols, cols, mean_bcast, logstd_bcast, reduce_cols);
+  const bool vec = cols % 4 == 0 && al16(x) && al16(mean) && al16(logstd) &&
+                   al16(gout) && al16(gx) && al16(gmean) && al16(glogstd);
+  if (vec)
+    hipLaunchKernelGGL(normal_grad_vec_kernel, dim3(flat_grid(rows * cols / 4)),
+                       dim3(256), 0, ZS_STREAM, x, mean, logstd, gout, gx, gmean,
+                       glogstd, rows * cols, cols, mean_bcast, logstd_bcast,
+                       reduce_cols);
+  else
+    hipLaunchKernelGGL(normal_grad_kernel, dim3(flat_grid(rows * cols)),
+                       dim3(256), 0, ZS_STREAM, x, mean, logstd, gout, gx, gmean,
+                       glogstd, rows * cols, cols, mean_bcast, logstd_bcast,
+                       reduce_cols);
   ZS_LAUNCH_CHECK("normal_grad_kernel launch");
   return ZSHMC_OK;
 }
@@ -311,7 +403,11 @@ extern "C" int zshmc_bernoulli_log_prob(const float* logits, const float* given,
   ZS_REQUIRE(rows >= 0 && cols >= 1, "zshmc_bernoulli_log_prob: bad shape");
   ZS_REQUIRE(mode_ok(logits_bcast) && mode_ok(given_bcast),
              "zshmc_bernoulli_log_prob: bad broadcast mode");
-  if (reduce_cols)
+  if (reduce_cols && cols % 4 == 0 && al16(logits) && al16(given))
+    hipLaunchKernelGGL(lp_rowsum_vec_kernel<1>, dim3(wave_row_grid(rows)),
+                       dim3(256), 0, ZS_STREAM, logits, given, nullptr, out,
+                       rows, cols, logits_bcast, given_bcast);
+  else if (reduce_cols)
     hipLaunchKernelGGL(lp_rowsum_kernel<1>, dim3(wave_row_grid(rows)), dim3(256),
                        0, ZS_STREAM, logits, given, nullptr, out, rows, cols,
                        logits_bcast, given_bcast);

@@ -20,6 +20,10 @@ namespace zshmc {
 
 __device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
 
+typedef float g4 __attribute__((ext_vector_type(4)));
+
+// VEC: rows are 16-B aligned multiples of 4 floats -> one 16-B access per lane
+template <bool VEC>
 __global__ __launch_bounds__(256) void momentum_kernel(
     float* __restrict__ p, const float* __restrict__ mass, int64_t n_chains,
     int64_t n_data, int64_t chain_offset, uint32_t k0, uint32_t k1,
@@ -36,14 +40,30 @@ __global__ __launch_bounds__(256) void momentum_kernel(
       float z[4];
       normal4((uint32_t)g, gchain, iteration, stream_word, k0, k1, z[0], z[1],
               z[2], z[3]);
+      if (VEC) {
+        g4 v = g4{z[0], z[1], z[2], z[3]};
+        if (mass) {
+          const g4 m = *reinterpret_cast<const g4*>(mass + g * 4);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int64_t d = g * 4 + j;
-        if (d < n_data) {
-          const float m = mass ? mass[d] : 1.0f;
-          const float v = z[j] * sqrtf(m);
-          row[d] = v;
-          kin += v * v / m;
+          for (int j = 0; j < 4; ++j) {
+            v[j] *= sqrtf(m[j]);
+            kin += v[j] * v[j] / m[j];
+          }
+        } else {
+          const g4 sq = v * v;
+          kin += (sq[0] + sq[1]) + (sq[2] + sq[3]);
+        }
+        *reinterpret_cast<g4*>(row + g * 4) = v;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int64_t d = g * 4 + j;
+          if (d < n_data) {
+            const float m = mass ? mass[d] : 1.0f;
+            const float v = z[j] * sqrtf(m);
+            row[d] = v;
+            kin += v * v / m;
+          }
         }
       }
     }
@@ -54,6 +74,7 @@ __global__ __launch_bounds__(256) void momentum_kernel(
   }
 }
 
+template <bool VEC>
 __global__ __launch_bounds__(256) void kick_drift_kernel(
     float* __restrict__ q, float* __restrict__ p,
     const float* __restrict__ grad, const float* __restrict__ mass,
@@ -69,14 +90,34 @@ __global__ __launch_bounds__(256) void kick_drift_kernel(
   for (int64_t c = wave; c < n_chains; c += n_waves) {
     const int64_t off = c * n_data;
     float kin = 0.f;
-    for (int64_t d = lane; d < n_data; d += 64) {
-      const float m = mass ? mass[d] : 1.0f;
-      // p = p + step_size2 * grad           (hmc.py:42)
-      const float pv = p[off + d] + s2 * grad[off + d];
-      p[off + d] = pv;
-      // q = q + step_size1 * (p / mass)     (hmc.py:39, :26-27)
-      if (drift_scale != 0.f) q[off + d] = q[off + d] + s1 * (pv / m);
-      kin += pv * pv / m;
+    if (VEC) {
+      for (int64_t d = (int64_t)lane * 4; d < n_data; d += 256) {
+        g4 m = g4{1.f, 1.f, 1.f, 1.f};
+        if (mass) m = *reinterpret_cast<const g4*>(mass + d);
+        // p = p + step_size2 * grad           (hmc.py:42)
+        const g4 pv = *reinterpret_cast<const g4*>(p + off + d) +
+                      s2 * *reinterpret_cast<const g4*>(grad + off + d);
+        *reinterpret_cast<g4*>(p + off + d) = pv;
+        // q = q + step_size1 * (p / mass)     (hmc.py:39, :26-27)
+        g4 vel = pv;
+        if (mass) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) vel[j] = pv[j] / m[j];
+        }
+        if (drift_scale != 0.f)
+          *reinterpret_cast<g4*>(q + off + d) =
+              *reinterpret_cast<const g4*>(q + off + d) + s1 * vel;
+        const g4 e = pv * vel;
+        kin += (e[0] + e[1]) + (e[2] + e[3]);
+      }
+    } else {
+      for (int64_t d = lane; d < n_data; d += 64) {
+        const float m = mass ? mass[d] : 1.0f;
+        const float pv = p[off + d] + s2 * grad[off + d];
+        p[off + d] = pv;
+        if (drift_scale != 0.f) q[off + d] = q[off + d] + s1 * (pv / m);
+        kin += pv * pv / m;
+      }
     }
     if (kinetic) {
       kin = wave_sum(kin);
@@ -134,6 +175,10 @@ __global__ __launch_bounds__(256) void select_rows_kernel(
   }
 }
 
+static inline bool aligned16(const void* p) {
+  return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+}
+
 static inline int row_grid(int64_t n_rows) {
   const int64_t need = (n_rows + 3) / 4;  // 4 waves per block
   const int64_t cap = (int64_t)device_cu_count() * 8;
@@ -156,11 +201,19 @@ extern "C" int zshmc_momentum(float* p, const float* mass, int64_t n_chains,
   ZS_REQUIRE(n_chains + chain_offset <= 0xFFFFFFFFll,
              "zshmc_momentum: global chain index exceeds 2^32");
   if (n_chains == 0) return ZSHMC_OK;
-  hipLaunchKernelGGL(momentum_kernel, dim3(row_grid(n_chains)), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), p, mass, n_chains,
-                     n_data, chain_offset, (uint32_t)(seed & 0xFFFFFFFFull),
-                     (uint32_t)(seed >> 32), iteration,
-                     kStreamMomentum | (latent_id << 8), kinetic);
+  const bool vec = n_data % 4 == 0 && aligned16(p) && aligned16(mass);
+  if (vec)
+    hipLaunchKernelGGL(momentum_kernel<true>, dim3(row_grid(n_chains)),
+                       dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p,
+                       mass, n_chains, n_data, chain_offset,
+                       (uint32_t)(seed & 0xFFFFFFFFull), (uint32_t)(seed >> 32),
+                       iteration, kStreamMomentum | (latent_id << 8), kinetic);
+  else
+    hipLaunchKernelGGL(momentum_kernel<false>, dim3(row_grid(n_chains)),
+                       dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p,
+                       mass, n_chains, n_data, chain_offset,
+                       (uint32_t)(seed & 0xFFFFFFFFull), (uint32_t)(seed >> 32),
+                       iteration, kStreamMomentum | (latent_id << 8), kinetic);
   ZS_LAUNCH_CHECK("momentum_kernel launch");
   return ZSHMC_OK;
 }
@@ -173,10 +226,18 @@ extern "C" int zshmc_kick_drift(float* q, float* p, const float* grad,
   ZS_REQUIRE(q && p && grad, "zshmc_kick_drift: null q/p/grad");
   ZS_REQUIRE(n_chains >= 0 && n_data >= 1, "zshmc_kick_drift: bad shape");
   if (n_chains == 0) return ZSHMC_OK;
-  hipLaunchKernelGGL(kick_drift_kernel, dim3(row_grid(n_chains)), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), q, p, grad, mass,
-                     step_size_dev, step_size_host, kick_scale, drift_scale,
-                     n_chains, n_data, kinetic);
+  const bool vec = n_data % 4 == 0 && aligned16(q) && aligned16(p) &&
+                   aligned16(grad) && aligned16(mass);
+  if (vec)
+    hipLaunchKernelGGL(kick_drift_kernel<true>, dim3(row_grid(n_chains)),
+                       dim3(256), 0, reinterpret_cast<hipStream_t>(stream), q, p,
+                       grad, mass, step_size_dev, step_size_host, kick_scale,
+                       drift_scale, n_chains, n_data, kinetic);
+  else
+    hipLaunchKernelGGL(kick_drift_kernel<false>, dim3(row_grid(n_chains)),
+                       dim3(256), 0, reinterpret_cast<hipStream_t>(stream), q, p,
+                       grad, mass, step_size_dev, step_size_host, kick_scale,
+                       drift_scale, n_chains, n_data, kinetic);
   ZS_LAUNCH_CHECK("kick_drift_kernel launch");
   return ZSHMC_OK;
 }

@@ -34,57 +34,96 @@ static inline int sg_grid(int64_t n_groups) {
   return (int)(g > 0 ? g : 1);
 }
 
-// grid-stride over 4-element groups; `body(i, z)` per element with its N(0,1)
-#define ZS_SG_FOREACH(n, word, BODY)                                          \
+typedef float sg4 __attribute__((ext_vector_type(4)));
+
+// 4 consecutive elements starting at 4g: one 16-B access when the group is
+// whole and the array 16-B aligned (VEC), element-wise otherwise
+template <bool VEC>
+__device__ __forceinline__ sg4 sg_load(const float* __restrict__ p, int64_t i0,
+                                       int64_t n) {
+  if (VEC && i0 + 3 < n) return *reinterpret_cast<const sg4*>(p + i0);
+  sg4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (i0 + j < n) v[j] = p[i0 + j];
+  return v;
+}
+template <bool VEC>
+__device__ __forceinline__ void sg_store(float* __restrict__ p, int64_t i0,
+                                         int64_t n, sg4 v) {
+  if (VEC && i0 + 3 < n) {
+    *reinterpret_cast<sg4*>(p + i0) = v;
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (i0 + j < n) p[i0 + j] = v[j];
+}
+
+// grid-stride over 4-element groups: `z` holds the group's four N(0,1), `i0`
+// its first flat index
+#define ZS_SG_FOREACH4(n, word, BODY)                                         \
   const int64_t n_groups_ = ((n) + 3) / 4;                                    \
   for (int64_t g_ = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;           \
        g_ < n_groups_; g_ += (int64_t)gridDim.x * blockDim.x) {               \
-    float z_[4];                                                              \
-    normal4((uint32_t)g_, (uint32_t)((uint64_t)g_ >> 32), iteration, (word),  \
-            k0, k1, z_[0], z_[1], z_[2], z_[3]);                              \
-    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                        \
-      const int64_t i = g_ * 4 + j_;                                          \
-      if (i < (n)) {                                                          \
-        const float z = z_[j_];                                               \
-        BODY                                                                  \
-      }                                                                       \
+    sg4 z;                                                                    \
+    {                                                                         \
+      float z0_, z1_, z2_, z3_;                                               \
+      normal4((uint32_t)g_, (uint32_t)((uint64_t)g_ >> 32), iteration,        \
+              (word), k0, k1, z0_, z1_, z2_, z3_);                            \
+      z = sg4{z0_, z1_, z2_, z3_};                                            \
     }                                                                         \
+    const int64_t i0 = g_ * 4;                                                \
+    BODY                                                                      \
   }
 
+template <bool VEC>
 __global__ __launch_bounds__(256) void sgld_kernel(
     float* __restrict__ q, const float* __restrict__ grad,
     float* __restrict__ aux, float lr, float decay, float epsilon, int64_t n,
     uint32_t k0, uint32_t k1, uint32_t iteration, uint32_t latent_id) {
   const float sqrt_lr = sqrtf(lr);
-  ZS_SG_FOREACH(n, sg_word(kSubNoise, latent_id), {
-    const float g = grad[i];
+  ZS_SG_FOREACH4(n, sg_word(kSubNoise, latent_id), {
+    const sg4 g = sg_load<VEC>(grad, i0, n);
+    sg4 qv = sg_load<VEC>(q, i0, n);
     if (aux) {  // PSGLD, RMSprop preconditioner (sgmcmc.py:233-236, :247-250)
-      const float a = decay * aux[i] + (1.0f - decay) * (g * g);
-      aux[i] = a;
-      const float pre = 1.0f / (epsilon + sqrtf(a));
-      q[i] = q[i] + 0.5f * lr * pre * g + z * sqrtf(lr * pre);
+      sg4 a = sg_load<VEC>(aux, i0, n);
+      a = decay * a + (1.0f - decay) * (g * g);
+      sg_store<VEC>(aux, i0, n, a);
+_Pragma("unroll")
+      for (int j = 0; j < 4; ++j) {
+        const float pre = 1.0f / (epsilon + sqrtf(a[j]));
+        qv[j] = qv[j] + 0.5f * lr * pre * g[j] + z[j] * sqrtf(lr * pre);
+      }
     } else {    // SGLD (sgmcmc.py:200-201)
-      q[i] = q[i] + 0.5f * lr * g + z * sqrt_lr;
+      qv = qv + (0.5f * lr) * g + z * sqrt_lr;
     }
+    sg_store<VEC>(q, i0, n, qv);
   })
 }
 
+template <bool VEC>
 __global__ __launch_bounds__(256) void sg_momentum_kernel(
     float* __restrict__ v, float std, int64_t n, uint32_t k0, uint32_t k1,
     uint32_t iteration, uint32_t latent_id) {
-  ZS_SG_FOREACH(n, sg_word(kSubMomentum, latent_id), { v[i] = z * std; })
+  ZS_SG_FOREACH4(n, sg_word(kSubMomentum, latent_id),
+                 { sg_store<VEC>(v, i0, n, z * std); })
 }
 
 // q <- q + 0.5*v ; optionally sum(v^2) for the scalar-friction thermostat
+template <bool VEC>
 __global__ __launch_bounds__(256) void sg_half_drift_kernel(
     float* __restrict__ q, const float* __restrict__ v, int64_t n,
     double* __restrict__ v2_sum) {
   double acc = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const float vv = v[i];
-    q[i] = q[i] + 0.5f * vv;
-    acc += (double)vv * (double)vv;
+  const int64_t n_groups = (n + 3) / 4;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_groups;
+       g += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i0 = g * 4;
+    const sg4 vv = sg_load<VEC>(v, i0, n);
+    sg_store<VEC>(q, i0, n, sg_load<VEC>(q, i0, n) + 0.5f * vv);
+    const sg4 sq = vv * vv;  // elements past n were loaded as 0
+    acc += (double)((sq[0] + sq[1]) + (sq[2] + sq[3]));
   }
   if (v2_sum) {
     const double w = wave_sum_f64(acc);
@@ -95,6 +134,7 @@ __global__ __launch_bounds__(256) void sg_half_drift_kernel(
 // SGHMC (sgmcmc.py:331-349).  First order: v' = (1-alpha) v + lr g + noise,
 // q' = q + v'.  Second order (q already holds q1 = q + v/2): v' = d (d v +
 // lr g + noise), d = exp(-alpha/2), q' = q1 + v'/2.  sum(v'^2) -> v2_sum.
+template <bool VEC>
 __global__ __launch_bounds__(256) void sghmc_kernel(
     float* __restrict__ q, float* __restrict__ v,
     const float* __restrict__ grad, int64_t n, float lr, float alpha,
@@ -102,18 +142,23 @@ __global__ __launch_bounds__(256) void sghmc_kernel(
     uint32_t iteration, uint32_t latent_id, double* __restrict__ v2_sum) {
   const float dh = expf(-0.5f * alpha);
   double acc = 0.0;
-  ZS_SG_FOREACH(n, sg_word(kSubNoise, latent_id), {
-    const float noise = z * noise_std;
-    float nv;
+  ZS_SG_FOREACH4(n, sg_word(kSubNoise, latent_id), {
+    const sg4 noise = z * noise_std;
+    const sg4 ov = sg_load<VEC>(v, i0, n);
+    const sg4 g = sg_load<VEC>(grad, i0, n);
+    const sg4 qv = sg_load<VEC>(q, i0, n);
+    sg4 nv;
     if (second_order) {
-      nv = dh * (dh * v[i] + lr * grad[i] + noise);
-      q[i] = q[i] + 0.5f * nv;
+      nv = dh * (dh * ov + lr * g + noise);
+      sg_store<VEC>(q, i0, n, qv + 0.5f * nv);
     } else {
-      nv = (1.0f - alpha) * v[i] + lr * grad[i] + noise;
-      q[i] = q[i] + nv;
+      nv = (1.0f - alpha) * ov + lr * g + noise;
+      sg_store<VEC>(q, i0, n, qv + nv);
     }
-    v[i] = nv;
-    acc += (double)nv * (double)nv;
+    sg_store<VEC>(v, i0, n, nv);
+_Pragma("unroll")
+    for (int j = 0; j < 4; ++j)
+      if (i0 + j < n) acc += (double)nv[j] * (double)nv[j];
   })
   if (v2_sum) {
     const double w = wave_sum_f64(acc);
@@ -123,8 +168,9 @@ __global__ __launch_bounds__(256) void sghmc_kernel(
 
 // SGNHT (sgmcmc.py:452-481).  alpha_vec != NULL: one friction per element,
 // everything element-wise.  alpha_vec == NULL: scalar friction alpha1 read
-// from alpha_scalar[1] (prepared by sgnht_scalar_finalize / prepare) and
-// sum(v'^2) accumulated for the finalize kernel.
+// from alpha_scalar[1] (prepared by sgnht_scalar_kernel) and sum(v'^2)
+// accumulated for its second phase.
+template <bool VEC>
 __global__ __launch_bounds__(256) void sgnht_kernel(
     float* __restrict__ q, float* __restrict__ v,
     const float* __restrict__ grad, float* __restrict__ alpha_vec,
@@ -137,35 +183,43 @@ __global__ __launch_bounds__(256) void sgnht_kernel(
   const float a_s = alpha_scalar ? alpha_scalar[1] : 0.f;
   const float dh_s = expf(-0.5f * a_s);
   double acc = 0.0;
-  ZS_SG_FOREACH(n, sg_word(kSubNoise, latent_id), {
-    const float noise = z * noise_std;
-    const float ov = v[i];
-    float nv;
+  ZS_SG_FOREACH4(n, sg_word(kSubNoise, latent_id), {
+    const sg4 noise = z * noise_std;
+    const sg4 ov = sg_load<VEC>(v, i0, n);
+    const sg4 g = sg_load<VEC>(grad, i0, n);
+    const sg4 qv = sg_load<VEC>(q, i0, n);
+    sg4 nv;
     if (alpha_vec) {
-      const float al = alpha_vec[i];
+      const sg4 al = sg_load<VEC>(alpha_vec, i0, n);
+      sg4 na;
       if (second_order) {
-        const float a1 = al + 0.5f * tune_rate * (ov * ov - lr);
-        const float dh = expf(-0.5f * a1);
-        nv = dh * (dh * ov + lr * grad[i] + noise);
-        q[i] = q[i] + 0.5f * nv;
-        alpha_vec[i] = a1 + 0.5f * tune_rate * (nv * nv - lr);
+        const sg4 a1 = al + (0.5f * tune_rate) * (ov * ov - lr);
+        sg4 dh;
+_Pragma("unroll")
+        for (int j = 0; j < 4; ++j) dh[j] = expf(-0.5f * a1[j]);
+        nv = dh * (dh * ov + lr * g + noise);
+        sg_store<VEC>(q, i0, n, qv + 0.5f * nv);
+        na = a1 + (0.5f * tune_rate) * (nv * nv - lr);
       } else {
-        nv = (1.0f - al) * ov + lr * grad[i] + noise;
-        q[i] = q[i] + nv;
-        alpha_vec[i] = al + tune_rate * (nv * nv - lr);
+        nv = (1.0f - al) * ov + lr * g + noise;
+        sg_store<VEC>(q, i0, n, qv + nv);
+        na = al + tune_rate * (nv * nv - lr);
       }
-      if (mean_k_vec) mean_k_vec[i] = nv * nv;
+      sg_store<VEC>(alpha_vec, i0, n, na);
+      if (mean_k_vec) sg_store<VEC>(mean_k_vec, i0, n, nv * nv);
     } else {
       if (second_order) {
-        nv = dh_s * (dh_s * ov + lr * grad[i] + noise);
-        q[i] = q[i] + 0.5f * nv;
+        nv = dh_s * (dh_s * ov + lr * g + noise);
+        sg_store<VEC>(q, i0, n, qv + 0.5f * nv);
       } else {
-        nv = (1.0f - a_s) * ov + lr * grad[i] + noise;
-        q[i] = q[i] + nv;
+        nv = (1.0f - a_s) * ov + lr * g + noise;
+        sg_store<VEC>(q, i0, n, qv + nv);
       }
     }
-    v[i] = nv;
-    acc += (double)nv * (double)nv;
+    sg_store<VEC>(v, i0, n, nv);
+_Pragma("unroll")
+    for (int j = 0; j < 4; ++j)
+      if (i0 + j < n) acc += (double)nv[j] * (double)nv[j];
   })
   if (v2_sum) {
     const double w = wave_sum_f64(acc);
@@ -206,6 +260,20 @@ using namespace zshmc;
 
 #define ZS_SG_KEYS (uint32_t)(seed & 0xFFFFFFFFull), (uint32_t)(seed >> 32)
 
+static inline bool al16(const void* p) {
+  return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+}
+// launch KERNEL<true> when every array is 16-B aligned, else KERNEL<false>
+#define ZS_SG_LAUNCH(KERNEL, vec, grid, strm, ...)                             \
+  do {                                                                         \
+    if (vec)                                                                   \
+      hipLaunchKernelGGL(KERNEL<true>, dim3(grid), dim3(256), 0, strm,         \
+                         __VA_ARGS__);                                         \
+    else                                                                       \
+      hipLaunchKernelGGL(KERNEL<false>, dim3(grid), dim3(256), 0, strm,        \
+                         __VA_ARGS__);                                         \
+  } while (0)
+
 extern "C" int zshmc_sgld_update(float* q, const float* grad, float* aux,
                                  float learning_rate, float decay, float epsilon,
                                  int64_t n, uint64_t seed, uint32_t iteration,
@@ -213,10 +281,10 @@ extern "C" int zshmc_sgld_update(float* q, const float* grad, float* aux,
   if (n == 0) return ZSHMC_OK;
   ZS_REQUIRE(q && grad && n > 0, "zshmc_sgld_update: bad arguments");
   ZS_REQUIRE(learning_rate >= 0.f, "zshmc_sgld_update: learning_rate < 0");
-  hipLaunchKernelGGL(sgld_kernel, dim3(sg_grid((n + 3) / 4)), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), q, grad, aux,
-                     learning_rate, decay, epsilon, n, ZS_SG_KEYS, iteration,
-                     latent_id);
+  ZS_SG_LAUNCH(sgld_kernel, al16(q) && al16(grad) && al16(aux),
+               sg_grid((n + 3) / 4), reinterpret_cast<hipStream_t>(stream), q,
+               grad, aux, learning_rate, decay, epsilon, n, ZS_SG_KEYS,
+               iteration, latent_id);
   ZS_LAUNCH_CHECK("sgld_kernel launch");
   return ZSHMC_OK;
 }
@@ -226,9 +294,9 @@ extern "C" int zshmc_sg_momentum(float* v, float std, int64_t n, uint64_t seed,
                                  void* stream) {
   if (n == 0) return ZSHMC_OK;
   ZS_REQUIRE(v && n > 0, "zshmc_sg_momentum: bad arguments");
-  hipLaunchKernelGGL(sg_momentum_kernel, dim3(sg_grid((n + 3) / 4)), dim3(256),
-                     0, reinterpret_cast<hipStream_t>(stream), v, std, n,
-                     ZS_SG_KEYS, iteration, latent_id);
+  ZS_SG_LAUNCH(sg_momentum_kernel, al16(v), sg_grid((n + 3) / 4),
+               reinterpret_cast<hipStream_t>(stream), v, std, n, ZS_SG_KEYS,
+               iteration, latent_id);
   ZS_LAUNCH_CHECK("sg_momentum_kernel launch");
   return ZSHMC_OK;
 }
@@ -237,8 +305,8 @@ extern "C" int zshmc_sg_half_drift(float* q, const float* v, int64_t n,
                                    double* v2_sum, void* stream) {
   if (n == 0) return ZSHMC_OK;
   ZS_REQUIRE(q && v && n > 0, "zshmc_sg_half_drift: bad arguments");
-  hipLaunchKernelGGL(sg_half_drift_kernel, dim3(sg_grid(n)), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), q, v, n, v2_sum);
+  ZS_SG_LAUNCH(sg_half_drift_kernel, al16(q) && al16(v), sg_grid((n + 3) / 4),
+               reinterpret_cast<hipStream_t>(stream), q, v, n, v2_sum);
   ZS_LAUNCH_CHECK("sg_half_drift_kernel launch");
   return ZSHMC_OK;
 }
@@ -251,10 +319,10 @@ extern "C" int zshmc_sghmc_update(float* q, float* v, const float* grad,
                                   void* stream) {
   if (n == 0) return ZSHMC_OK;
   ZS_REQUIRE(q && v && grad && n > 0, "zshmc_sghmc_update: bad arguments");
-  hipLaunchKernelGGL(sghmc_kernel, dim3(sg_grid((n + 3) / 4)), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), q, v, grad, n,
-                     learning_rate, friction, noise_std, second_order,
-                     ZS_SG_KEYS, iteration, latent_id, v2_sum);
+  ZS_SG_LAUNCH(sghmc_kernel, al16(q) && al16(v) && al16(grad),
+               sg_grid((n + 3) / 4), reinterpret_cast<hipStream_t>(stream), q, v,
+               grad, n, learning_rate, friction, noise_std, second_order,
+               ZS_SG_KEYS, iteration, latent_id, v2_sum);
   ZS_LAUNCH_CHECK("sghmc_kernel launch");
   return ZSHMC_OK;
 }
@@ -273,11 +341,13 @@ extern "C" int zshmc_sgnht_update(float* q, float* v, const float* grad,
              "zshmc_sgnht_update: exactly one of alpha_vec / alpha_scalar");
   ZS_REQUIRE(alpha_vec || v2_sum,
              "zshmc_sgnht_update: scalar friction needs v2_sum");
-  hipLaunchKernelGGL(sgnht_kernel, dim3(sg_grid((n + 3) / 4)), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), q, v, grad,
-                     alpha_vec, alpha_scalar, mean_k_vec, n, learning_rate,
-                     tune_rate, noise_std, second_order, ZS_SG_KEYS, iteration,
-                     latent_id, v2_sum);
+  ZS_SG_LAUNCH(sgnht_kernel,
+               al16(q) && al16(v) && al16(grad) && al16(alpha_vec) &&
+                   al16(mean_k_vec),
+               sg_grid((n + 3) / 4), reinterpret_cast<hipStream_t>(stream), q, v,
+               grad, alpha_vec, alpha_scalar, mean_k_vec, n, learning_rate,
+               tune_rate, noise_std, second_order, ZS_SG_KEYS, iteration,
+               latent_id, v2_sum);
   ZS_LAUNCH_CHECK("sgnht_kernel launch");
   return ZSHMC_OK;
 }
