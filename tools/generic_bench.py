@@ -58,3 +58,21 @@ timeit('sgld_update (rw q, r grad)', 12, lambda: _capi.call(
 timeit('sghmc_update (rw q, rw v, r grad)', 20, lambda: _capi.call(
     'zshmc_sghmc_update', q.data_ptr(), p.data_ptr(), g.data_ptr(), N, 1e-4, 0.1,
     1e-3, 1, 1, 0, 0, None, s))
+
+# adaptation / softmax-family kernels
+em = torch.zeros(D, device=dev)
+colsum = torch.zeros(2 * D, dtype=torch.float64, device=dev)
+timeit('mass_colstats (r q)', 4, lambda: _capi.call(
+    'zshmc_mass_colstats', q.data_ptr(), em.data_ptr(), C, D, colsum.data_ptr(), s))
+labels = torch.randint(0, D, (C,), device=dev, dtype=torch.int64)
+timeit('categorical_log_prob (r logits)', 4, lambda: _capi.call(
+    'zshmc_categorical_log_prob', q.data_ptr(), labels.data_ptr(), lp.data_ptr(), C, D, s))
+timeit('categorical_log_prob_grad (r,w)', 8, lambda: _capi.call(
+    'zshmc_categorical_log_prob_grad', q.data_ptr(), labels.data_ptr(), gout.data_ptr(),
+    g.data_ptr(), C, D, s))
+timeit('unnorm_multinomial_lp (r l, r x)', 8, lambda: _capi.call(
+    'zshmc_unnormalized_multinomial_log_prob', q.data_ptr(), p.data_ptr(), lp.data_ptr(),
+    C, D, 1, s))
+timeit('unnorm_multinomial_grad (r,r,w)', 12, lambda: _capi.call(
+    'zshmc_unnormalized_multinomial_log_prob_grad', q.data_ptr(), p.data_ptr(),
+    gout.data_ptr(), g.data_ptr(), C, D, 1, s))

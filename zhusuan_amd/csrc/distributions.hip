@@ -249,6 +249,129 @@ __global__ __launch_bounds__(256) void softmax_family_kernel(
   }
 }
 
+// Register-resident variant for rows of up to NPL*256 categories that are
+// 16-B aligned multiples of 4: the logits row is read ONCE into NPL float4 per
+// lane (chunk layout (k*64 + lane)*4), max / logsumexp / outputs come from
+// registers.  MODE as softmax_family_kernel.
+template <int MODE, int NPL>
+__global__ __launch_bounds__(256) void softmax_family_reg_kernel(
+    const float* __restrict__ logits, const int64_t* __restrict__ labels,
+    const float* __restrict__ given, const float* __restrict__ gout,
+    float* __restrict__ out, int64_t rows, int64_t n_cat, int normalize) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+  const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x / 64);
+  for (int64_t r = wave; r < rows; r += n_waves) {
+    const float* __restrict__ row = logits + r * n_cat;
+    d4 x[NPL];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+      const int64_t j0 = (int64_t)(k * 64 + lane) * 4;
+      if (j0 < n_cat) {
+        x[k] = *reinterpret_cast<const d4*>(row + j0);
+        mx = fmaxf(mx, fmaxf(fmaxf(x[k][0], x[k][1]), fmaxf(x[k][2], x[k][3])));
+      } else {
+        x[k] = d4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      }
+    }
+    float lse = 0.f;
+    if (MODE < 2 || normalize) {
+      mx = wave_max(mx);
+      const float shift = isfinite(mx) ? mx : 0.f;
+      float se = 0.f;
+#pragma unroll
+      for (int k = 0; k < NPL; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) se += expf(x[k][j] - shift);
+      se = group_sum<64>(se);
+      lse = shift + logf(se);
+    }
+    if (MODE == 0) {
+      if (lane == 0) {
+        const int64_t kk = labels[r];
+        out[r] = (kk >= 0 && kk < n_cat) ? row[kk] - lse : NAN;
+      }
+    } else if (MODE == 1) {
+      const int64_t kk = labels[r];
+      const float g = gout[r];
+#pragma unroll
+      for (int k = 0; k < NPL; ++k) {
+        const int64_t j0 = (int64_t)(k * 64 + lane) * 4;
+        if (j0 < n_cat) {
+          d4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            o[j] = g * ((j0 + j == kk ? 1.0f : 0.0f) - expf(x[k][j] - lse));
+          *reinterpret_cast<d4*>(out + r * n_cat + j0) = o;
+        }
+      }
+    } else {
+      d4 gv[NPL];
+      float tot = 0.f, sdot = 0.f;
+#pragma unroll
+      for (int k = 0; k < NPL; ++k) {
+        const int64_t j0 = (int64_t)(k * 64 + lane) * 4;
+        gv[k] = d4{0.f, 0.f, 0.f, 0.f};
+        if (j0 < n_cat) {
+          gv[k] = *reinterpret_cast<const d4*>(given + r * n_cat + j0);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            tot += gv[k][j];
+            sdot += gv[k][j] * (x[k][j] - lse);
+          }
+        }
+      }
+      if (MODE == 2) {
+        sdot = group_sum<64>(sdot);
+        if (lane == 0) out[r] = sdot;
+      } else {
+        const float g = gout[r];
+        if (normalize) tot = group_sum<64>(tot);
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+          const int64_t j0 = (int64_t)(k * 64 + lane) * 4;
+          if (j0 < n_cat) {
+            d4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float v = gv[k][j];
+              if (normalize) v -= tot * expf(x[k][j] - lse);
+              o[j] = g * v;
+            }
+            *reinterpret_cast<d4*>(out + r * n_cat + j0) = o;
+          }
+        }
+      }
+    }
+  }
+}
+
+static inline int wave_row_grid(int64_t rows);
+
+template <int MODE>
+static bool launch_softmax_reg(const float* logits, const int64_t* labels,
+                               const float* given, const float* gout, float* out,
+                               int64_t rows, int64_t n_cat, int normalize,
+                               hipStream_t s, int grid) {
+  const bool ok = n_cat % 4 == 0 && n_cat <= 2048 &&
+                  (reinterpret_cast<uintptr_t>(logits) & 15) == 0 &&
+                  (!given || (reinterpret_cast<uintptr_t>(given) & 15) == 0) &&
+                  (MODE == 0 || MODE == 2 ||
+                   (reinterpret_cast<uintptr_t>(out) & 15) == 0);
+  if (!ok) return false;
+#define ZS_SMX(NPL)                                                            \
+  hipLaunchKernelGGL((softmax_family_reg_kernel<MODE, NPL>), dim3(grid),       \
+                     dim3(256), 0, s, logits, labels, given, gout, out, rows,  \
+                     n_cat, normalize)
+  if (n_cat <= 256) ZS_SMX(1);
+  else if (n_cat <= 512) ZS_SMX(2);
+  else if (n_cat <= 1024) ZS_SMX(4);
+  else ZS_SMX(8);
+#undef ZS_SMX
+  return true;
+}
+
 // ---- sampling ---------------------------------------------------------------
 __global__ __launch_bounds__(256) void normal_sample_kernel(
     float* __restrict__ out, const float* __restrict__ mean,
@@ -443,9 +566,10 @@ extern "C" int zshmc_categorical_log_prob(const float* logits,
   if (rows == 0) return ZSHMC_OK;
   ZS_REQUIRE(logits && labels && out, "zshmc_categorical_log_prob: null pointer");
   ZS_REQUIRE(rows >= 0 && n_cat >= 1, "zshmc_categorical_log_prob: bad shape");
-  hipLaunchKernelGGL(softmax_family_kernel<0>, dim3(wave_row_grid(rows)),
-                     dim3(256), 0, ZS_STREAM, logits, labels, nullptr, nullptr,
-                     out, rows, n_cat, 1);
+  if (!launch_softmax_reg<0>(logits, labels, nullptr, nullptr, out, rows, n_cat, 1, ZS_STREAM,
+                              wave_row_grid(rows)))
+    hipLaunchKernelGGL(softmax_family_kernel<0>, dim3(wave_row_grid(rows)),
+                       dim3(256), 0, ZS_STREAM, logits, labels, nullptr, nullptr, out, rows, n_cat, 1);
   ZS_LAUNCH_CHECK("categorical_log_prob launch");
   return ZSHMC_OK;
 }
@@ -459,9 +583,10 @@ extern "C" int zshmc_categorical_log_prob_grad(const float* logits,
   ZS_REQUIRE(logits && labels && gout && glogits,
              "zshmc_categorical_log_prob_grad: null pointer");
   ZS_REQUIRE(rows >= 0 && n_cat >= 1, "zshmc_categorical_log_prob_grad: bad shape");
-  hipLaunchKernelGGL(softmax_family_kernel<1>, dim3(wave_row_grid(rows)),
-                     dim3(256), 0, ZS_STREAM, logits, labels, nullptr, gout,
-                     glogits, rows, n_cat, 1);
+  if (!launch_softmax_reg<1>(logits, labels, nullptr, gout, glogits, rows, n_cat, 1, ZS_STREAM,
+                              wave_row_grid(rows)))
+    hipLaunchKernelGGL(softmax_family_kernel<1>, dim3(wave_row_grid(rows)),
+                       dim3(256), 0, ZS_STREAM, logits, labels, nullptr, gout, glogits, rows, n_cat, 1);
   ZS_LAUNCH_CHECK("categorical_log_prob_grad launch");
   return ZSHMC_OK;
 }
@@ -474,9 +599,10 @@ extern "C" int zshmc_unnormalized_multinomial_log_prob(
              "zshmc_unnormalized_multinomial_log_prob: null pointer");
   ZS_REQUIRE(rows >= 0 && n_cat >= 1,
              "zshmc_unnormalized_multinomial_log_prob: bad shape");
-  hipLaunchKernelGGL(softmax_family_kernel<2>, dim3(wave_row_grid(rows)),
-                     dim3(256), 0, ZS_STREAM, logits, nullptr, given, nullptr,
-                     out, rows, n_cat, normalize);
+  if (!launch_softmax_reg<2>(logits, nullptr, given, nullptr, out, rows, n_cat, normalize, ZS_STREAM,
+                              wave_row_grid(rows)))
+    hipLaunchKernelGGL(softmax_family_kernel<2>, dim3(wave_row_grid(rows)),
+                       dim3(256), 0, ZS_STREAM, logits, nullptr, given, nullptr, out, rows, n_cat, normalize);
   ZS_LAUNCH_CHECK("unnormalized_multinomial_log_prob launch");
   return ZSHMC_OK;
 }
@@ -489,9 +615,10 @@ extern "C" int zshmc_unnormalized_multinomial_log_prob_grad(
              "zshmc_unnormalized_multinomial_log_prob_grad: null pointer");
   ZS_REQUIRE(rows >= 0 && n_cat >= 1,
              "zshmc_unnormalized_multinomial_log_prob_grad: bad shape");
-  hipLaunchKernelGGL(softmax_family_kernel<3>, dim3(wave_row_grid(rows)),
-                     dim3(256), 0, ZS_STREAM, logits, nullptr, given, gout,
-                     glogits, rows, n_cat, normalize);
+  if (!launch_softmax_reg<3>(logits, nullptr, given, gout, glogits, rows, n_cat, normalize, ZS_STREAM,
+                              wave_row_grid(rows)))
+    hipLaunchKernelGGL(softmax_family_kernel<3>, dim3(wave_row_grid(rows)),
+                       dim3(256), 0, ZS_STREAM, logits, nullptr, given, gout, glogits, rows, n_cat, normalize);
   ZS_LAUNCH_CHECK("unnormalized_multinomial_log_prob_grad launch");
   return ZSHMC_OK;
 }
