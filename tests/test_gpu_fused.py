@@ -267,3 +267,51 @@ def test_full_size_properties(env):
     op3.run()
     dH = (i3.hamiltonian - i3.orig_hamiltonian).abs().max().item()
     assert dH < 0.05 and float(i3.acceptance_rate.min().item()) > 0.95  # (2)
+
+
+def test_ring_kernel_staged_and_unstaged_paths_agree(tmp_path):
+    """The ring kernel keeps the per-chain scalars (MH uniform in, HMCInfo out)
+    in LDS when a workgroup's share fits and falls back to scalar-unit
+    uniforms + in-loop stores otherwise (> ~300k chains at D = 1024).  Force
+    the fallback with ZSHMC_RING_STAGE=0 in a child process and require
+    bit-identical results; also cover a chain count that takes the fallback by
+    itself."""
+    import os
+    import subprocess
+    import sys
+    script = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from zhusuan_amd import _capi
+dev = torch.device('cuda', 0)
+out = {}
+for C, D, mass in ((3001, 1024, False), (777, 516, True), (310000, 1024, False)):
+    g = torch.Generator(device='cpu').manual_seed(C)
+    logstd = torch.linspace(-1, 1, D).to(dev)
+    mean = torch.randn(D, generator=g).to(dev)
+    m = torch.exp(-2 * logstd) if mass else None
+    q = (torch.randn(min(C, 4096), D, generator=g).repeat((C + 4095) // 4096, 1)[:C]
+         * torch.exp(logstd.cpu()) + mean.cpu()).to(dev)
+    info = [torch.zeros(C, device=dev) for _ in range(5)]
+    acc_sum = torch.zeros(1, dtype=torch.float64, device=dev)
+    flags = torch.zeros(1, dtype=torch.int32, device=dev)
+    for t in range(2):
+        _capi.call('zshmc_hmc_diag_normal_step', q.data_ptr(), mean.data_ptr(),
+                   logstd.data_ptr(), None if m is None else m.data_ptr(), None,
+                   0.14, C, D, 7, 5, 99, t, 1, *[x.data_ptr() for x in info],
+                   acc_sum.data_ptr(), flags.data_ptr(),
+                   torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    h = torch.cat([q.reshape(-1)[::97].double().cumsum(0)[-1:]] +
+                  [x.double().sum().reshape(1) for x in info] + [acc_sum]).cpu().numpy()
+    out['%%d_%%d' %% (C, D)] = h
+np.savez(sys.argv[1], **out)
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for stage in ('1', '0'):
+        path = str(tmp_path / ('stage%s.npz' % stage))
+        env = dict(os.environ, ZSHMC_RING_STAGE=stage)
+        subprocess.check_call([sys.executable, '-c', script, path], env=env)
+        res[stage] = np.load(path)
+    for k in res['1'].files:
+        np.testing.assert_array_equal(res['1'][k], res['0'][k], err_msg=k)

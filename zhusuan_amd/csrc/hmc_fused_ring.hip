@@ -628,7 +628,12 @@ static int launch_ring_cfg(const FusedArgs& a_in, hipStream_t stream) {
   const int64_t share = (a_in.n_chains / round) * G + (tail > G ? G : tail);
   FusedArgs a = a_in;
   // 6 floats per chain: 5 HMCInfo scalars + the MH uniform
-  const bool stage = lds_base + (size_t)share * 24 <= kLdsLimit;
+  // ZSHMC_RING_STAGE=0 forces the in-loop path (tests exercise both)
+  static const bool allow_stage = [] {
+    const char* e = getenv("ZSHMC_RING_STAGE");
+    return !(e && e[0] == '0');
+  }();
+  const bool stage = allow_stage && lds_base + (size_t)share * 24 <= kLdsLimit;
   a.info_cap = stage ? (int)share : 0;
   a.commit_direct = (a.commit && !stage) ? 1u : 0u;
   const size_t lds = lds_base + (stage ? (size_t)share * 24 : 0);
