@@ -170,6 +170,9 @@ class HMC(object):
         self.sharding = sharding
         self._plan = None
         self._pending_check = False
+        # list collecting (start, end) HIP-event pairs around the fused
+        # transition kernel of every run while it is set (bench.py)
+        self.kernel_timer = None
 
     # -- sample(): builds the execution plan (hmc.py:382-522) -------------
     def sample(self, meta_bn, observed, latent):
@@ -481,7 +484,17 @@ class _FusedDiagNormalPlan(_PlanBase):
 
     def transition(self, t, eps_host, stream):
         self.last_t = t
+        timer = self.hmc.kernel_timer
+        if timer is None:
+            self._launch(t, eps_host, 1, self.hmc.n_leapfrogs, stream)
+            return
+        # bench.py: HIP events on the launch stream around the fused kernel
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
         self._launch(t, eps_host, 1, self.hmc.n_leapfrogs, stream)
+        e1.record()
+        timer.append((e0, e1))
 
 
 class _GenericPlan(_PlanBase):
