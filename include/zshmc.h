@@ -269,6 +269,29 @@ int zshmc_categorical_sample(int32_t* out, const float* logits,
                              uint64_t seed, uint32_t offset, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Fused mixture-multinomial likelihood + gradient (fp32 MFMA), the E-step
+ * likelihood of the logistic-normal topic model
+ * (examples/topic_models/lntm_mcem.py:33-48): for every row r
+ *   ll[r]   = sum_v counts[r % count_rows, v] * log( sum_k theta[r,k] phi_t[v,k] )
+ *           = UnnormalizedMultinomial(log(theta.phi), normalize_logits=False)
+ *             .log_prob(counts)                     multivariate.py:435-443
+ *   grad_theta[r,k] = sum_v counts[.,v] * phi_t[v,k] / (theta.phi)[r,v]
+ * theta [n_rows, n_topics], phi_t = phi^T [n_vocab, n_topics] (n_topics 64,
+ * 128 or 256: zero-pad), counts [count_rows, n_vocab] shared by the rows with
+ * period count_rows.  The [n_rows, n_vocab] product never reaches memory.
+ * grad_theta may be NULL.  n_splits > 1 splits the vocabulary into that many
+ * row ranges handled by separate workgroups (for n_rows / 64 < #CUs) whose
+ * partial sums land in `workspace` (n_splits * n_rows * (n_topics + 1) floats,
+ * caller-owned) and are reduced in a fixed order; n_splits = 1: workspace NULL.
+ */
+int zshmc_linear_multinomial_log_lik(const float* theta, const float* phi_t,
+                                     const float* counts, int64_t count_rows,
+                                     int64_t n_rows, int64_t n_vocab,
+                                     int64_t n_topics, float* log_lik,
+                                     float* grad_theta, int n_splits,
+                                     float* workspace, void* stream);
+
+/* ------------------------------------------------------------------------
  * Batched effective sample size (zhusuan/diagnostics.py:17-64), the estimator
  * behind BASELINE.json's "ESS/s".
  *   draws : [n_draws, n_series] float32, draw-major (one recorded snapshot of

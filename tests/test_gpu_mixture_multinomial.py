@@ -1,0 +1,141 @@
+"""GPU parity of the fused mixture-multinomial kernel (csrc/linear_bernoulli.hip,
+multinomial mode; BASELINE config 5, the LNTM E-step likelihood) against the
+float64 dense evaluation, its front-end `zs.log_mixture`, and an HMC E-step
+run against the same model with materialised logits."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def env():
+    import torch
+    import zhusuan_amd as zs
+    assert torch.cuda.is_available()
+    return zs, torch, torch.device('cuda', 0)
+
+
+def _softmax(a):
+    e = np.exp(a - a.max(-1, keepdims=True))
+    return e / e.sum(-1, keepdims=True)
+
+
+def _data(n_chains, n_docs, K, V, seed):
+    rng = np.random.RandomState(seed)
+    phi = _softmax(rng.normal(size=(K, V)))
+    x = np.stack([rng.multinomial(80, phi[rng.randint(K)])
+                  for _ in range(n_docs)]).astype(np.float32)
+    eta = rng.normal(size=(n_chains, n_docs, K))
+    return phi.astype(np.float32), x, _softmax(eta).astype(np.float32)
+
+
+# ragged V (not a multiple of 4 / 64), K padded to 64 / 128 / 256, rows not a
+# multiple of 64, counts shared across the chain axis
+@pytest.mark.parametrize('n_chains,n_docs,K,V', [(3, 7, 5, 40), (2, 50, 100, 1003),
+                                                  (1, 130, 128, 777), (4, 33, 200, 129),
+                                                  (1, 1, 3, 1)])
+def test_loglik_and_grad_match_float64(env, n_chains, n_docs, K, V):
+    zs, torch, dev = env
+    phi, x, theta = _data(n_chains, n_docs, K, V, seed=K + V)
+    tt = torch.tensor(theta, device=dev, requires_grad=True)
+    d = zs.distributions.UnnormalizedMultinomial(
+        zs.log_mixture(tt, torch.tensor(phi, device=dev)),
+        normalize_logits=False, dtype=torch.float32)
+    ll = d.log_prob(torch.tensor(x, device=dev))
+    assert tuple(ll.shape) == (n_chains, n_docs)
+    dw = theta.astype(np.float64) @ phi.astype(np.float64)
+    ll_ref = (x[None] * np.log(dw)).sum(-1)
+    np.testing.assert_allclose(ll.detach().cpu().numpy(), ll_ref, rtol=3e-5,
+                               atol=3e-4)
+    coef = torch.linspace(0.5, 1.5, n_chains * n_docs, device=dev).reshape(
+        n_chains, n_docs)
+    (ll * coef).sum().backward()
+    g_ref = ((x[None] / dw) @ phi.astype(np.float64).T) * \
+        coef.cpu().numpy()[..., None]
+    np.testing.assert_allclose(tt.grad.cpu().numpy(), g_ref, rtol=2e-4,
+                               atol=2e-4 * np.abs(g_ref).max())
+    # the dense path (materialised logits through the element-wise kernel) agrees
+    dense = zs.distributions.UnnormalizedMultinomial(
+        torch.log(tt.detach() @ torch.tensor(phi, device=dev)),
+        normalize_logits=False, dtype=torch.float32).log_prob(
+            torch.tensor(x, device=dev))
+    np.testing.assert_allclose(ll.detach().cpu().numpy(), dense.cpu().numpy(),
+                               rtol=3e-5, atol=3e-4)
+
+
+def test_fallbacks(env):
+    zs, torch, dev = env
+    phi, x, theta = _data(2, 6, 5, 24, seed=1)
+    tt, pt, xt = (torch.tensor(v, device=dev) for v in (theta, phi, x))
+    # normalize_logits=True and a gradient through phi use the dense logits
+    a = zs.distributions.UnnormalizedMultinomial(
+        zs.log_mixture(tt, pt), normalize_logits=True,
+        dtype=torch.float32).log_prob(xt)
+    b = zs.distributions.UnnormalizedMultinomial(
+        torch.log(tt @ pt), normalize_logits=True,
+        dtype=torch.float32).log_prob(xt)
+    np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-6)
+    pg = pt.clone().requires_grad_(True)
+    zs.distributions.UnnormalizedMultinomial(
+        zs.log_mixture(tt, pg), normalize_logits=False,
+        dtype=torch.float32).log_prob(xt).sum().backward()
+    assert pg.grad is not None and bool(torch.isfinite(pg.grad).all())
+
+
+def test_lntm_estep_fused_equals_dense_model(env):
+    """lntm_mcem.py:33-48,97-102 with the fused likelihood vs the same model
+    with materialised log(theta.phi): identical sampler traces."""
+    zs, torch, dev = env
+    n_chains, n_docs, K, V = 2, 40, 20, 300
+    phi, x, _ = _data(n_chains, n_docs, K, V, seed=9)
+    T = lambda a: torch.tensor(a, device=dev)
+    phi_t, x_t = T(phi), T(x)
+    eta0 = (0.1 * np.random.RandomState(0).normal(
+        size=(n_chains, n_docs, K))).astype(np.float32)
+
+    def build(fused):
+        @zs.meta_bayesian_net()
+        def lntm():
+            bn = zs.BayesianNet()
+            eta = bn.normal('eta', torch.zeros(n_docs, K, device=dev),
+                            logstd=torch.zeros(K, device=dev),
+                            n_samples=n_chains, group_ndims=1)
+            theta = torch.softmax(eta.tensor, dim=-1)
+            logits = zs.log_mixture(theta, phi_t) if fused else \
+                torch.log(theta.reshape(-1, K).matmul(phi_t).reshape(
+                    eta.tensor.shape[0], n_docs, V))
+            bn.unnormalized_multinomial('x', logits, normalize_logits=False,
+                                        dtype=torch.float32)
+            return bn
+        m = lntm()
+        m.log_joint = lambda bn: (bn.cond_log_prob('eta') +
+                                  bn.cond_log_prob('x'))
+        return m
+
+    runs = []
+    for fused in (True, False):
+        eta = T(eta0)
+        hmc = zs.HMC(step_size=1e-3, n_leapfrogs=6, adapt_step_size=True,
+                     adapt_mass=True, target_acceptance_rate=0.6, seed=4)
+        op, info = hmc.sample(build(fused), {'x': x_t}, {'eta': eta})
+        runs.append((eta, op, info))
+    (eta_a, op_a, info_a), (eta_b, op_b, info_b) = runs
+    for it in range(8):
+        op_a.run()
+        op_b.run()
+        # two float32 evaluation orders of the same log-joint
+        np.testing.assert_allclose(info_a.orig_log_prob.cpu().numpy(),
+                                   info_b.orig_log_prob.cpu().numpy(),
+                                   rtol=2e-5, atol=2e-3)
+        acc_a = info_a.acceptance_rate.cpu().numpy()
+        acc_b = info_b.acceptance_rate.cpu().numpy()
+        np.testing.assert_allclose(acc_a, acc_b, atol=5e-3)
+        np.testing.assert_allclose(float(info_a.updated_step_size.item()),
+                                   float(info_b.updated_step_size.item()),
+                                   rtol=5e-3)
+        # same accept decisions except borderline ones; then continue both
+        # samplers from the same state so rounding does not compound
+        same = (eta_a - eta_b).abs().amax(-1) < 1e-3
+        assert float(same.float().mean()) > 0.97
+        eta_b.copy_(eta_a)

@@ -8,7 +8,7 @@ zs.AIS, zs.SGLD / PSGLD / SGHMC / SGNHT."""
 from . import diagnostics, distributions, evaluation, framework
 from .framework import (BayesianNet, MetaBayesianNet, StochasticTensor,
                         meta_bayesian_net)
-from .distributions import linear_logits
+from .distributions import linear_logits, log_mixture
 from .evaluation import AIS
 from .hmc import HMC, HMCInfo, InvalidArgumentError, placeholder
 from .session import Session
@@ -20,4 +20,4 @@ __version__ = '0.1.0'
 __all__ = ['SGMCMC', 'SGLD', 'PSGLD', 'SGHMC', 'SGNHT', 'AIS', 'evaluation', 'HMC', 'HMCInfo', 'InvalidArgumentError', 'placeholder', 'Session',
            'BayesianNet', 'MetaBayesianNet', 'StochasticTensor',
            'meta_bayesian_net', 'distributions', 'diagnostics', 'framework',
-           'merge_dicts', 'set_random_seed', 'linear_logits']
+           'merge_dicts', 'set_random_seed', 'linear_logits', 'log_mixture']

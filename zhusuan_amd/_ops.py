@@ -322,3 +322,62 @@ class LinearBernoulliLogLik(torch.autograd.Function):
         d = ctx.w_shape[-1]
         g = gw[:, :d] * gout.reshape(-1, 1)
         return g.reshape(ctx.w_shape), None, None
+
+
+_phi_cache = {}
+
+
+def _padded_phi_t(phi, width):
+    """phi [K, V] -> contiguous zero-padded phi^T [V, width], cached per
+    tensor version (the model builder re-runs on every joint evaluation)."""
+    key = (phi.data_ptr(), tuple(phi.shape), phi._version, width)
+    hit = _phi_cache.get('phi')
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    pt = _pad_features(phi.detach().to(_F32).t().contiguous(), width)
+    _phi_cache['phi'] = (key, pt)
+    return pt
+
+
+class MixtureMultinomialLogLik(torch.autograd.Function):
+    """ll[r] = sum_v x[r % R0, v] log((theta . phi)[r, v]) and d/dtheta in one
+    pass over phi (the [rows, V] product is never materialised): the fused
+    fp32-MFMA kernel of csrc/linear_bernoulli.hip in its multinomial mode.
+    theta [..., K]; phi [K, V] (no gradient through this op); x [R0, V] with
+    prod(theta.shape[:-1]) a multiple of R0."""
+
+    @staticmethod
+    def forward(ctx, theta, phi, x):
+        require_device(theta, phi, x)
+        k = theta.shape[-1]
+        width = next(v for v in LINEAR_BERNOULLI_WIDTHS if v >= k)
+        t2 = _pad_features(theta.detach().reshape(-1, k).to(_F32), width)
+        pt = _padded_phi_t(phi, width)
+        xf = x.detach().to(_F32).contiguous().reshape(-1, x.shape[-1])
+        rows, vocab = t2.shape[0], pt.shape[0]
+        ll = torch.empty(rows, dtype=_F32, device=theta.device)
+        need_grad = ctx.needs_input_grad[0]
+        gt = torch.empty_like(t2) if need_grad else None
+        # fewer 64-row chain blocks than CUs: split the vocabulary range
+        n_wg = (rows + 63) // 64
+        cus = torch.cuda.get_device_properties(theta.device).multi_processor_count
+        splits = 1
+        if n_wg < cus:
+            splits = max(1, min(16, (2 * cus) // n_wg, (vocab + 511) // 512))
+        ws = torch.empty(splits * rows * (width + 1), dtype=_F32,
+                         device=theta.device) if splits > 1 else None
+        _capi.call('zshmc_linear_multinomial_log_lik', t2.data_ptr(),
+                   pt.data_ptr(), xf.data_ptr(), xf.shape[0], rows, vocab,
+                   width, ll.data_ptr(), _capi.ptr(gt), splits, _capi.ptr(ws),
+                   _capi.current_stream())
+        ctx.t_shape = tuple(theta.shape)
+        if need_grad:
+            ctx.save_for_backward(gt)
+        return ll.reshape(theta.shape[:-1])
+
+    @staticmethod
+    def backward(ctx, gout):
+        (gt,) = ctx.saved_tensors
+        k = ctx.t_shape[-1]
+        g = gt[:, :k] * gout.reshape(-1, 1)
+        return g.reshape(ctx.t_shape), None, None

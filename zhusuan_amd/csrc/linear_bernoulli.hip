@@ -266,11 +266,21 @@ __device__ __forceinline__ void lds_dma_row(const float* src, uint32_t dst,
 // LDS: the double-buffered X tile (2 x 64 x (D+4) floats), streamed by
 // LDS-DMA one padded row per instruction, issued between the MFMAs of phase 1;
 // 16 KB for the residual exchange.  Two barriers per tile.
-template <int D, bool GRAD>
+//
+// OP selects the element-wise stage between the two GEMMs:
+//   OP = 0  Bernoulli with dense logits (config 3): term = l*y - max(l,0) -
+//           log1p(exp(-|l|)), residual = y - sigmoid(l), y[n] per data row.
+//   OP = 1  UnnormalizedMultinomial over a mixture (config 5, the LNTM E-step,
+//           lntm_mcem.py:33-48): W = theta [rows, K], X = phi^T [V, K], the
+//           "logits" are log(theta.phi) (multivariate.py:435-443 with
+//           normalize_logits = False): term = x*log(S), residual = x / S with
+//           the counts x[c, n] streamed from `yc` [C, N] (chain-major).
+template <int D, bool GRAD, int OP>
 __global__ __launch_bounds__(256, 1) void linear_bernoulli_kernel_v2(
     const float* __restrict__ W, const float* __restrict__ X,
-    const float* __restrict__ y, int64_t C, int64_t N, int64_t ldw,
-    int64_t ldx, float* __restrict__ ll, float* __restrict__ gW) {
+    const float* __restrict__ y, const float* __restrict__ yc,
+    int64_t yc_rows, int64_t C, int64_t N, int64_t ldw, int64_t ldx,
+    float* __restrict__ ll, float* __restrict__ gW) {
   constexpr int LD = D + 4;          // padded LDS row: conflict-free b128 reads
   constexpr int kRows = 64;          // data rows per tile
   constexpr int KK = D / 8;          // phase-1 steps of 4 MFMAs (8 features)
@@ -332,10 +342,25 @@ __global__ __launch_bounds__(256, 1) void linear_bernoulli_kernel_v2(
     for (int r = 0; r < 16; ++r) G[t][r] = 0.f;
   float ll_lane = 0.f;
 
-  const int64_t n_tiles = (N + kRows - 1) / kRows;
+  // gridDim.y > 1: the data rows are split into gridDim.y contiguous ranges of
+  // whole tiles and this workgroup writes PARTIAL sums (reduced afterwards by
+  // lb_reduce_splits_kernel) -- for shapes with fewer chain blocks than CUs
+  const int64_t n_tiles_all = (N + kRows - 1) / kRows;
+  const int64_t tiles_per_split = (n_tiles_all + gridDim.y - 1) / gridDim.y;
+  const int64_t tile_begin = (int64_t)blockIdx.y * tiles_per_split;
+  const int64_t n_tiles = tile_begin + tiles_per_split < n_tiles_all
+                              ? tile_begin + tiles_per_split
+                              : n_tiles_all;
+  if (gridDim.y > 1) {
+    ll += (int64_t)blockIdx.y * C;
+    if (GRAD) gW += (int64_t)blockIdx.y * C * ldw;
+  }
 #pragma unroll
-  for (int j = 0; j < 16; ++j) dma_row(0, 0, j);
-  if (tid < kRows) sY[tid] = tid < N ? y[tid] : 0.f;
+  for (int j = 0; j < 16; ++j) dma_row(tile_begin * kRows, 0, j);
+  if (OP == 0 && tid < kRows) {
+    const int64_t nr = tile_begin * kRows + tid;
+    sY[tid] = nr < N ? y[nr] : 0.f;
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -343,15 +368,31 @@ __global__ __launch_bounds__(256, 1) void linear_bernoulli_kernel_v2(
   float* __restrict__ sr_mine = sR + (wave * 4 * 64 + lane) * 4;
   const float* __restrict__ sr_sib = sR + ((wave ^ 1) * 4 * 64 + lane) * 4;
 
-  for (int64_t tile = 0; tile < n_tiles; ++tile) {
-    const int buf = (int)(tile & 1);
+  for (int64_t tile = tile_begin; tile < n_tiles; ++tile) {
+    const int buf = (int)((tile - tile_begin) & 1);
     const float* __restrict__ xb = sX + buf * kRows * LD;
     const bool more = tile + 1 < n_tiles;
     // rows of tile+1 (the last tile re-streams itself: clamped rows, unused)
     const int64_t n_next = (more ? tile + 1 : tile) * kRows;
-    if (tid < kRows) {
+    if (OP == 0 && tid < kRows) {
       const int64_t nr = n_next + tid;
       yr = nr < N ? y[nr] : 0.f;
+    }
+    // OP 1: this lane's 16 counts of the CURRENT tile (chain a*32+lo, rows
+    // b*32 + 8j + 4hi .. +3): four 16-B groups of its own row of yc
+    float xcnt[16];
+    if (OP == 1) {
+      int64_t cr = c0 + a * 32 + lo;
+      cr = cr < C ? cr : C - 1;
+      // counts rows repeat with period yc_rows (x[n_docs, V] shared by chains)
+      const float* __restrict__ xrow0 =
+          yc + (cr % yc_rows) * N + tile * kRows + b * 32 + 4 * hi;
+      const int64_t left = N - (tile * kRows + b * 32 + 4 * hi);  // may be <= 0
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          xcnt[j * 4 + m] = (8 * j + m < left) ? xrow0[8 * j + m] : 0.f;
     }
 
     // ---- phase 1 (own 32 rows, full K) --------------------------------------
@@ -392,15 +433,25 @@ __global__ __launch_bounds__(256, 1) void linear_bernoulli_kernel_v2(
       const int nl = b * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
       const bool valid = nl < rows_left;
       const float sv = S[r];
-      const float yv = sY[buf * kRows + nl];
-      const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * fabsf(sv));
-      const float t1 = 1.0f + e;
-      const float inv = __builtin_amdgcn_rcpf(t1);
-      const float sig = sv >= 0.f ? inv : 1.0f - inv;
-      const float lp = sv * yv - fmaxf(sv, 0.f) -
-                       0.6931471805599453f * __builtin_amdgcn_logf(t1);
-      S[r] = valid ? yv - sig : 0.f;
-      ll_lane += valid ? lp : 0.f;
+      if (OP == 0) {
+        const float yv = sY[buf * kRows + nl];
+        const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * fabsf(sv));
+        const float t1 = 1.0f + e;
+        const float inv = __builtin_amdgcn_rcpf(t1);
+        const float sig = sv >= 0.f ? inv : 1.0f - inv;
+        const float lp = sv * yv - fmaxf(sv, 0.f) -
+                         0.6931471805599453f * __builtin_amdgcn_logf(t1);
+        S[r] = valid ? yv - sig : 0.f;
+        ll_lane += valid ? lp : 0.f;
+      } else {
+        // sum_v x_v log((theta.phi)_v) and d/d(theta.phi) = x / (theta.phi);
+        // x = 0 contributes nothing (also where the product underflows)
+        const float xv = xcnt[r];
+        const bool on = valid && xv != 0.f;
+        const float lp = xv * (0.6931471805599453f * __builtin_amdgcn_logf(sv));
+        S[r] = on ? xv * __builtin_amdgcn_rcpf(sv) : 0.f;
+        ll_lane += on ? lp : 0.f;
+      }
     };
     // B operand of phase 3: X[row][b*HALF + lo*FB .. +FB-1]
     typedef typename VecF<FB>::type V;
@@ -451,7 +502,7 @@ __global__ __launch_bounds__(256, 1) void linear_bernoulli_kernel_v2(
 #pragma unroll
       for (int r = 0; r < 16; ++r) residual(r);
     }
-    if (tid < kRows) sY[(buf ^ 1) * kRows + tid] = yr;
+    if (OP == 0 && tid < kRows) sY[(buf ^ 1) * kRows + tid] = yr;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA rows landed
     __syncthreads();  // tile+1 published; this buffer free for tile+2
   }
@@ -481,6 +532,71 @@ __global__ __launch_bounds__(256, 1) void linear_bernoulli_kernel_v2(
   }
 }
 
+// out[c(, f)] = sum over the S row-range partials written by a split launch
+__global__ __launch_bounds__(256) void lb_reduce_splits_kernel(
+    const float* __restrict__ ws, int64_t C, int64_t ldw, int S,
+    float* __restrict__ ll, float* __restrict__ gW) {
+  const int64_t n_ll = C, n_g = gW ? C * ldw : 0;
+  const float* __restrict__ gpart = ws + (int64_t)S * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_ll + n_g;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float acc = 0.f;
+    if (i < n_ll) {
+      for (int s = 0; s < S; ++s) acc += ws[(int64_t)s * C + i];
+      ll[i] = acc;
+    } else {
+      const int64_t j = i - n_ll;
+      for (int s = 0; s < S; ++s) acc += gpart[(int64_t)s * C * ldw + j];
+      gW[j] = acc;
+    }
+  }
+}
+
+template <int D, int OP>
+static int launch_v2(const float* W, const float* X, const float* y,
+                     const float* yc, int64_t yc_rows, int64_t C, int64_t N,
+                     int64_t ldw, int64_t ldx, float* ll, float* gW,
+                     hipStream_t s, int n_splits = 1,
+                     float* workspace = nullptr) {
+  constexpr int LD = D + 4;
+  const size_t lds = (size_t)(2 * 64 * LD + 2 * 64 + 4 * 16 * 64) * sizeof(float);
+  static bool attr2 = false;
+  if (!attr2) {
+    hipError_t e = hipFuncSetAttribute(
+        reinterpret_cast<const void*>(linear_bernoulli_kernel_v2<D, true, OP>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(
+          reinterpret_cast<const void*>(linear_bernoulli_kernel_v2<D, false, OP>),
+          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(LDS)");
+    attr2 = true;
+  }
+  const int gx = (int)((C + kMC - 1) / kMC);
+  const int S = (n_splits > 1 && workspace) ? n_splits : 1;
+  float* ll_out = S > 1 ? workspace : ll;
+  float* g_out = S > 1 ? (gW ? workspace + (int64_t)S * C : nullptr) : gW;
+  const dim3 grid(gx, S);
+  if (gW)
+    hipLaunchKernelGGL((linear_bernoulli_kernel_v2<D, true, OP>), grid,
+                       dim3(256), lds, s, W, X, y, yc, yc_rows, C, N, ldw, ldx,
+                       ll_out, g_out);
+  else
+    hipLaunchKernelGGL((linear_bernoulli_kernel_v2<D, false, OP>), grid,
+                       dim3(256), lds, s, W, X, y, yc, yc_rows, C, N, ldw, ldx,
+                       ll_out, g_out);
+  ZS_LAUNCH_CHECK("linear_bernoulli_kernel_v2 launch");
+  if (S > 1) {
+    const int64_t n = C + (gW ? C * ldw : 0);
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(lb_reduce_splits_kernel, dim3((int)blocks), dim3(256), 0, s,
+                       workspace, C, ldw, S, ll, gW);
+    ZS_LAUNCH_CHECK("lb_reduce_splits_kernel launch");
+  }
+  return ZSHMC_OK;
+}
+
 template <int D>
 static int launch_lb(const float* W, const float* X, const float* y, int64_t C,
                      int64_t N, int64_t ldw, int64_t ldx, float* ll, float* gW,
@@ -489,31 +605,8 @@ static int launch_lb(const float* W, const float* X, const float* y, int64_t C,
     const char* e = getenv("ZSHMC_LB_V1");
     return e && e[0] == '1';
   }();
-  if (!use_v1) {
-    constexpr int LD = D + 4;
-    const size_t lds = (size_t)(2 * 64 * LD + 2 * 64 + 4 * 16 * 64) * sizeof(float);
-    static bool attr2 = false;
-    if (!attr2) {
-      hipError_t e = hipFuncSetAttribute(
-          reinterpret_cast<const void*>(linear_bernoulli_kernel_v2<D, true>),
-          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e == hipSuccess)
-        e = hipFuncSetAttribute(
-            reinterpret_cast<const void*>(linear_bernoulli_kernel_v2<D, false>),
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(LDS)");
-      attr2 = true;
-    }
-    const int grid = (int)((C + kMC - 1) / kMC);
-    if (gW)
-      hipLaunchKernelGGL((linear_bernoulli_kernel_v2<D, true>), dim3(grid),
-                         dim3(256), lds, s, W, X, y, C, N, ldw, ldx, ll, gW);
-    else
-      hipLaunchKernelGGL((linear_bernoulli_kernel_v2<D, false>), dim3(grid),
-                         dim3(256), lds, s, W, X, y, C, N, ldw, ldx, ll, gW);
-    ZS_LAUNCH_CHECK("linear_bernoulli_kernel_v2 launch");
-    return ZSHMC_OK;
-  }
+  if (!use_v1)
+    return launch_v2<D, 0>(W, X, y, nullptr, 1, C, N, ldw, ldx, ll, gW, s);
   constexpr int LD = D + 4;
   const size_t lds = (size_t)(kMC * LD + 2 * kNT * LD + 2 * kNT + 4 * 16 * 64) *
                      sizeof(float);
@@ -560,5 +653,47 @@ extern "C" int zshmc_linear_bernoulli_log_lik(const float* W, const float* X,
       return launch_lb<128>(W, X, y, n_chains, n_rows, 128, 128, log_lik, grad_w, s);
     default:
       return launch_lb<256>(W, X, y, n_chains, n_rows, 256, 256, log_lik, grad_w, s);
+  }
+}
+
+extern "C" int zshmc_linear_multinomial_log_lik(const float* theta,
+                                                const float* phi_t,
+                                                const float* counts,
+                                                int64_t count_rows,
+                                                int64_t n_rows, int64_t n_vocab,
+                                                int64_t n_topics, float* log_lik,
+                                                float* grad_theta, int n_splits,
+                                                float* workspace, void* stream) {
+  if (n_rows == 0) return ZSHMC_OK;
+  ZS_REQUIRE(theta && phi_t && counts && log_lik,
+             "zshmc_linear_multinomial_log_lik: null pointer");
+  ZS_REQUIRE(n_rows > 0 && n_vocab > 0 && count_rows > 0 &&
+                 n_rows % count_rows == 0,
+             "zshmc_linear_multinomial_log_lik: bad shape");
+  ZS_REQUIRE(n_topics == 64 || n_topics == 128 || n_topics == 256,
+             "zshmc_linear_multinomial_log_lik: n_topics must be 64, 128 or 256 "
+             "(zero-pad theta and phi^T), got %lld", (long long)n_topics);
+  ZS_REQUIRE((reinterpret_cast<uintptr_t>(theta) & 15) == 0 &&
+                 (reinterpret_cast<uintptr_t>(phi_t) & 15) == 0,
+             "zshmc_linear_multinomial_log_lik: theta and phi^T must be 16-byte aligned");
+  ZS_REQUIRE(n_splits >= 1 && n_splits <= 64 && (n_splits == 1 || workspace),
+             "zshmc_linear_multinomial_log_lik: 1 <= n_splits <= 64 and a "
+             "workspace of n_splits*n_rows*(n_topics+1) floats when > 1");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  switch (n_topics) {
+    case 64:
+      return launch_v2<64, 1>(theta, phi_t, nullptr, counts, count_rows, n_rows,
+                              n_vocab, 64,
+                              64, log_lik, grad_theta, s, n_splits, workspace);
+    case 128:
+      return launch_v2<128, 1>(theta, phi_t, nullptr, counts, count_rows, n_rows,
+                              n_vocab,
+                               128, 128, log_lik, grad_theta, s, n_splits,
+                               workspace);
+    default:
+      return launch_v2<256, 1>(theta, phi_t, nullptr, counts, count_rows, n_rows,
+                              n_vocab,
+                               256, 256, log_lik, grad_theta, s, n_splits,
+                               workspace);
   }
 }

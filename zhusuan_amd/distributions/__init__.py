@@ -2,8 +2,10 @@ from .base import Distribution
 from .univariate import (Normal, Bernoulli, Categorical, Discrete,
                          LinearLogits, linear_logits)
 from .univariate2 import Laplace, Gamma, InverseGamma, Beta
-from .multivariate import UnnormalizedMultinomial, BagofCategoricals
+from .multivariate import (UnnormalizedMultinomial, BagofCategoricals,
+                           LogMixture, log_mixture)
 
 __all__ = ['Distribution', 'Laplace', 'Gamma', 'InverseGamma', 'Beta', 'Normal', 'Bernoulli', 'Categorical', 'Discrete',
            'UnnormalizedMultinomial', 'BagofCategoricals', 'LinearLogits',
+           'LogMixture', 'log_mixture',
            'linear_logits']
