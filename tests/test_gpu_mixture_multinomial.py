@@ -139,3 +139,28 @@ def test_lntm_estep_fused_equals_dense_model(env):
         same = (eta_a - eta_b).abs().amax(-1) < 1e-3
         assert float(same.float().mean()) > 0.97
         eta_b.copy_(eta_a)
+
+
+def test_recomputed_phi_never_hits_a_stale_pad_cache(env):
+    """A model builder recomputes phi = softmax(beta) per evaluation; the
+    caching allocator may give the new phi the address of the freed old one.
+    The padded-transpose cache must not serve the old contents."""
+    zs, torch, dev = env
+    K, V, R = 20, 300, 64
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.poisson(torch.full((R, V), 0.3, device=dev), generator=g)
+    theta = torch.softmax(torch.randn(R, K, device=dev, generator=g), -1)
+    beta = torch.randn(K, V, device=dev, generator=g)
+
+    def ll():
+        phi = torch.softmax(beta, -1)          # fresh tensor every call
+        d = zs.distributions.UnnormalizedMultinomial(
+            zs.log_mixture(theta, phi), normalize_logits=False,
+            dtype=torch.float32)
+        return d.log_prob(x), (x * torch.log(theta @ phi)).sum(-1)
+
+    for _ in range(4):
+        got, want = ll()
+        np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(),
+                                   rtol=2e-4)
+        beta.add_(torch.randn(K, V, device=dev, generator=g))

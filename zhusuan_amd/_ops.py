@@ -283,12 +283,14 @@ def _padded_x(X, width):
     version (the model builder re-runs on every joint evaluation)."""
     if X.shape[-1] == width and X.is_contiguous() and X.dtype == _F32:
         return X
-    key = (X.data_ptr(), tuple(X.shape), X._version, width)
+    key = (X.data_ptr(), tuple(X.shape), tuple(X.stride()), X._version, width)
     hit = _x_cache.get('x')
     if hit is not None and hit[0] == key:
         return hit[1]
     Xp = _pad_features(X.detach().to(_F32), width)
-    _x_cache['x'] = (key, Xp)
+    # the entry holds X itself: while it lives, no other tensor can be handed
+    # X's address, so (address, version) identifies the contents
+    _x_cache['x'] = (key, Xp, X)
     return Xp
 
 
@@ -328,14 +330,19 @@ _phi_cache = {}
 
 
 def _padded_phi_t(phi, width):
-    """phi [K, V] -> contiguous zero-padded phi^T [V, width], cached per
-    tensor version (the model builder re-runs on every joint evaluation)."""
-    key = (phi.data_ptr(), tuple(phi.shape), phi._version, width)
+    """phi [K, V] -> contiguous zero-padded phi^T [V, width], cached for as
+    long as the SAME tensor (same storage, same version counter) is passed
+    again.  The cache entry keeps `phi` alive, so its address cannot be handed
+    to a different tensor while the entry exists; a model builder that
+    recomputes phi = softmax(beta) on every joint evaluation simply misses
+    (one K x V transpose, noise next to the likelihood kernel)."""
+    key = (phi.data_ptr(), tuple(phi.shape), tuple(phi.stride()),
+           phi._version, width)
     hit = _phi_cache.get('phi')
     if hit is not None and hit[0] == key:
         return hit[1]
     pt = _pad_features(phi.detach().to(_F32).t().contiguous(), width)
-    _phi_cache['phi'] = (key, pt)
+    _phi_cache['phi'] = (key, pt, phi)
     return pt
 
 
