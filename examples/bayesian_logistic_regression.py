@@ -7,7 +7,7 @@ chains and its gradient then run in the fused fp32-MFMA kernel -- X is read
 once per evaluation and the [n_chains, N] logits never exist in memory.
 
     python examples/bayesian_logistic_regression.py [--n 1000000] [--d 256]
-        [--chains 32768] [--iters 60]
+        [--chains 32768] [--iters 100]
 """
 import argparse
 import os
@@ -26,7 +26,7 @@ if __name__ == "__main__":
     ap.add_argument('--n', type=int, default=100000)
     ap.add_argument('--d', type=int, default=256)
     ap.add_argument('--chains', type=int, default=4096)
-    ap.add_argument('--iters', type=int, default=60)
+    ap.add_argument('--iters', type=int, default=100)
     ap.add_argument('--leapfrogs', type=int, default=10)
     args = ap.parse_args()
     zs.set_random_seed(7)

@@ -248,11 +248,16 @@ int zshmc_unnormalized_multinomial_log_prob_grad(
  * never materialised.  W [n_chains, n_features], X [n_rows, n_features]
  * row-major, 16-byte aligned; y [n_rows] float (0/1); n_features in
  * {64, 128, 256} (zero-pad otherwise); grad_w may be NULL.
+ * n_splits > 1 cuts the n_rows range into that many slices per 64-chain block
+ * (for chain counts that would otherwise leave compute units idle); the
+ * partial sums go to `workspace` (n_splits * n_chains * (n_features + 1)
+ * floats) and are added in a fixed order, so the result is deterministic.
  */
 int zshmc_linear_bernoulli_log_lik(const float* W, const float* X,
                                    const float* y, int64_t n_chains,
                                    int64_t n_rows, int64_t n_features,
-                                   float* log_lik, float* grad_w, void* stream);
+                                   float* log_lik, float* grad_w, int n_splits,
+                                   float* workspace, void* stream);
 
 /* Sampling (Normal._sample univariate.py:161-172, Bernoulli._sample
  * :386-396, Categorical._sample :478-494) on Philox stream STREAM_DIST with

@@ -1,0 +1,45 @@
+"""The example scripts (ports of the reference's examples/ that exercise the
+hot path) run end to end on the device and meet their own statistical
+assertions."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*argv):
+    r = subprocess.run([sys.executable] + list(argv), cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return r.stdout
+
+
+def test_gaussian_example():
+    out = _run('examples/gaussian.py')
+    assert 'plan: fused_diag_normal' in out or 'plan:' in out
+    assert 'Relative error of stdev' in out
+
+
+def test_mixture_sgnht_example():
+    out = _run('examples/mixture_sgnht.py', '6000')
+    rel = float(out.split('Relative error of stdev = ')[1].split()[0])
+    assert abs(rel) < 0.05
+
+
+def test_logistic_regression_example():
+    out = _run('examples/bayesian_logistic_regression.py', '--n', '20000',
+               '--chains', '512', '--iters', '60')
+    assert '|posterior mean - MAP|' in out
+
+
+def test_lntm_example():
+    out = _run('examples/lntm_mcem.py', '--small', '--epochs', '4')
+    perp = [float(l.split('Perplexity = ')[1].split(',')[0])
+            for l in out.splitlines() if 'Perplexity' in l]
+    assert len(perp) == 4 and perp[-1] < 0.6 * perp[0]
+    test_perp = float(out.split('perplexity = ')[-1].split()[0])
+    assert test_perp < 500      # uniform model: 1000

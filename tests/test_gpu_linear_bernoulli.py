@@ -159,7 +159,7 @@ def test_config3_full_size_properties(env):
         gw = torch.empty(C, D, device=dev)
         _capi.call('zshmc_linear_bernoulli_log_lik', W.data_ptr(), x.data_ptr(),
                    yy.data_ptr(), C, x.shape[0], D, ll.data_ptr(),
-                   gw.data_ptr(), s)
+                   gw.data_ptr(), 1, None, s)
         return ll, gw
 
     ll, gw = run(X, y)
@@ -181,3 +181,45 @@ def test_config3_full_size_properties(env):
         np.testing.assert_allclose(float(ll[c]), ll_ref, rtol=2e-5)
         np.testing.assert_allclose(gw[c].cpu().numpy(), g_ref, rtol=1e-4,
                                    atol=2e-5 * np.abs(g_ref).max())
+
+
+@pytest.mark.parametrize('D', [64, 256])
+def test_row_range_splits_match_single_pass(D):
+    """n_splits > 1 (small chain counts) is the same sum in a different, fixed
+    association: equal to the unsplit launch within fp32 re-association, and
+    bit-identical run to run."""
+    import torch
+    from zhusuan_amd import _capi
+    dev = torch.device('cuda', 0)
+    g = torch.Generator(device=dev).manual_seed(11)
+    C, N = 130, 5037
+    X = torch.randn(N, D, device=dev, generator=g)
+    y = (torch.rand(N, device=dev, generator=g) < 0.4).float()
+    W = torch.randn(C, D, device=dev, generator=g) * 0.1
+    s = torch.cuda.current_stream().cuda_stream
+
+    def run(splits, grad=True):
+        ll = torch.empty(C, device=dev)
+        gw = torch.empty(C, D, device=dev) if grad else None
+        ws = torch.empty(splits * C * (D + 1), device=dev) if splits > 1 else None
+        _capi.call('zshmc_linear_bernoulli_log_lik', W.data_ptr(), X.data_ptr(),
+                   y.data_ptr(), C, N, D, ll.data_ptr(), _capi.ptr(gw), splits,
+                   _capi.ptr(ws), s)
+        return ll, gw
+
+    ll1, g1 = run(1)
+    z = (W.double() @ X.double().t())
+    want = (y.double() * z - torch.nn.functional.softplus(z)).sum(-1)
+    torch.testing.assert_close(ll1.double(), want, rtol=1e-5, atol=1e-2)
+    for splits in (2, 3, 7, 16):
+        ll, gw = run(splits)
+        torch.testing.assert_close(ll, ll1, rtol=1e-5, atol=1e-2)
+        torch.testing.assert_close(gw, g1, rtol=1e-4, atol=1e-3)
+        ll_b, gw_b = run(splits)
+        assert torch.equal(ll, ll_b) and torch.equal(gw, gw_b)
+        ll_n, _ = run(splits, grad=False)
+        torch.testing.assert_close(ll_n, ll1, rtol=1e-5, atol=1e-2)
+    with pytest.raises(_capi.ZshmcError):
+        ll = torch.empty(C, device=dev)
+        _capi.call('zshmc_linear_bernoulli_log_lik', W.data_ptr(), X.data_ptr(),
+                   y.data_ptr(), C, N, D, ll.data_ptr(), None, 4, None, s)

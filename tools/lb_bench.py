@@ -17,11 +17,14 @@ y = (torch.rand(N, device=dev) < 0.5).float()
 ll = torch.empty(C, device=dev)
 g = torch.empty(C, D, device=dev)
 s = torch.cuda.current_stream().cuda_stream
+SPLITS = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+ws = torch.empty(SPLITS * C * (D + 1), device=dev) if SPLITS > 1 else None
 
 
 def run():
     _capi.call('zshmc_linear_bernoulli_log_lik', W.data_ptr(), X.data_ptr(),
-               y.data_ptr(), C, N, D, ll.data_ptr(), g.data_ptr(), s)
+               y.data_ptr(), C, N, D, ll.data_ptr(), g.data_ptr(), SPLITS,
+               _capi.ptr(ws), s)
 
 
 run()

@@ -294,6 +294,17 @@ def _padded_x(X, width):
     return Xp
 
 
+def _row_splits(n_blocks_rows, n_inner, device):
+    """Fewer 64-row chain blocks than compute units: cut the inner (data row /
+    vocabulary) range so that about two workgroups land on every CU, at least
+    512 inner rows per slice."""
+    n_wg = (n_blocks_rows + 63) // 64
+    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    if n_wg >= cus:
+        return 1
+    return max(1, min(16, (2 * cus) // n_wg, (n_inner + 511) // 512))
+
+
 class LinearBernoulliLogLik(torch.autograd.Function):
     """ll[c] = sum_n Bernoulli(w_c . x_n).log_prob(y_n) and its gradient in one
     pass over X (logits are never materialised)."""
@@ -310,9 +321,13 @@ class LinearBernoulliLogLik(torch.autograd.Function):
         ll = torch.empty(C, dtype=_F32, device=w.device)
         need_grad = ctx.needs_input_grad[0]
         gw = torch.empty_like(w2) if need_grad else None
+        splits = _row_splits(C, N, w.device)
+        ws = torch.empty(splits * C * (width + 1), dtype=_F32,
+                         device=w.device) if splits > 1 else None
         _capi.call('zshmc_linear_bernoulli_log_lik', w2.data_ptr(),
                    Xp.data_ptr(), yf.data_ptr(), C, N, width, ll.data_ptr(),
-                   _capi.ptr(gw), _capi.current_stream())
+                   _capi.ptr(gw), splits, _capi.ptr(ws),
+                   _capi.current_stream())
         ctx.w_shape = tuple(w.shape)
         if need_grad:
             ctx.save_for_backward(gw)
@@ -366,11 +381,7 @@ class MixtureMultinomialLogLik(torch.autograd.Function):
         need_grad = ctx.needs_input_grad[0]
         gt = torch.empty_like(t2) if need_grad else None
         # fewer 64-row chain blocks than CUs: split the vocabulary range
-        n_wg = (rows + 63) // 64
-        cus = torch.cuda.get_device_properties(theta.device).multi_processor_count
-        splits = 1
-        if n_wg < cus:
-            splits = max(1, min(16, (2 * cus) // n_wg, (vocab + 511) // 512))
+        splits = _row_splits(rows, vocab, theta.device)
         ws = torch.empty(splits * rows * (width + 1), dtype=_F32,
                          device=theta.device) if splits > 1 else None
         _capi.call('zshmc_linear_multinomial_log_lik', t2.data_ptr(),

@@ -600,13 +600,14 @@ static int launch_v2(const float* W, const float* X, const float* y,
 template <int D>
 static int launch_lb(const float* W, const float* X, const float* y, int64_t C,
                      int64_t N, int64_t ldw, int64_t ldx, float* ll, float* gW,
-                     hipStream_t s) {
+                     hipStream_t s, int n_splits, float* workspace) {
   static const bool use_v1 = [] {
     const char* e = getenv("ZSHMC_LB_V1");
     return e && e[0] == '1';
   }();
   if (!use_v1)
-    return launch_v2<D, 0>(W, X, y, nullptr, 1, C, N, ldw, ldx, ll, gW, s);
+    return launch_v2<D, 0>(W, X, y, nullptr, 1, C, N, ldw, ldx, ll, gW, s,
+                           n_splits, workspace);
   constexpr int LD = D + 4;
   const size_t lds = (size_t)(kMC * LD + 2 * kNT * LD + 2 * kNT + 4 * 16 * 64) *
                      sizeof(float);
@@ -633,6 +634,7 @@ extern "C" int zshmc_linear_bernoulli_log_lik(const float* W, const float* X,
                                               const float* y, int64_t n_chains,
                                               int64_t n_rows, int64_t n_features,
                                               float* log_lik, float* grad_w,
+                                              int n_splits, float* workspace,
                                               void* stream) {
   if (n_chains == 0) return ZSHMC_OK;
   ZS_REQUIRE(W && X && y && log_lik, "zshmc_linear_bernoulli_log_lik: null pointer");
@@ -645,14 +647,20 @@ extern "C" int zshmc_linear_bernoulli_log_lik(const float* W, const float* X,
                  (reinterpret_cast<uintptr_t>(X) & 15) == 0 &&
                  (!grad_w || (reinterpret_cast<uintptr_t>(grad_w) & 3) == 0),
              "zshmc_linear_bernoulli_log_lik: W and X must be 16-byte aligned");
+  ZS_REQUIRE(n_splits >= 1 && n_splits <= 64 && (n_splits == 1 || workspace),
+             "zshmc_linear_bernoulli_log_lik: 1 <= n_splits <= 64 and a "
+             "workspace of n_splits*n_chains*(n_features+1) floats when > 1");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   switch (n_features) {
     case 64:
-      return launch_lb<64>(W, X, y, n_chains, n_rows, 64, 64, log_lik, grad_w, s);
+      return launch_lb<64>(W, X, y, n_chains, n_rows, 64, 64, log_lik, grad_w, s,
+                           n_splits, workspace);
     case 128:
-      return launch_lb<128>(W, X, y, n_chains, n_rows, 128, 128, log_lik, grad_w, s);
+      return launch_lb<128>(W, X, y, n_chains, n_rows, 128, 128, log_lik, grad_w,
+                            s, n_splits, workspace);
     default:
-      return launch_lb<256>(W, X, y, n_chains, n_rows, 256, 256, log_lik, grad_w, s);
+      return launch_lb<256>(W, X, y, n_chains, n_rows, 256, 256, log_lik, grad_w,
+                            s, n_splits, workspace);
   }
 }
 
