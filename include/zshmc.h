@@ -274,6 +274,31 @@ int zshmc_categorical_sample(int32_t* out, const float* logits,
                              uint64_t seed, uint32_t offset, void* stream);
 
 /* ------------------------------------------------------------------------
+ * MultivariateNormalCholesky (zhusuan/distributions/
+ * multivariate.py:41-193).  x [n_rows, n_dim]; row r uses
+ * mean[r % mean_rows, :] and the lower-triangular factor
+ * tril[r % tril_count, :, :] (row-major [n_dim, n_dim]; the strict upper
+ * triangle is never read).  1 <= n_dim <= 512.
+ *   log_prob[r] = -n_dim/2 log(2 pi) - sum_i log L_ii - 1/2 |z|^2,
+ *                 z = L^{-1} (x_r - mean)                    (_log_prob :166-188)
+ *   grad_x[r,:] = -L^{-T} z     (what tf.gradients gives w.r.t. `given`; NULL
+ *                                to skip the back substitution)
+ *   z_out[r,:]  = z             (optional; the parameter gradients are
+ *                                d/dmean = -grad_x, d/dL = tril(-grad_x z^T) - diag(1/L_ii))
+ * zshmc_mvn_tril_sample: out[r,:] = mean + L . n, n ~ N(0, I) (_sample
+ * :141-164) on Philox stream STREAM_DIST, noise element i = r * n_dim + c
+ * taken from counter (i / 4, offset) word i % 4, as zshmc_normal_sample. */
+int zshmc_mvn_tril_log_prob(const float* x, const float* mean,
+                            const float* tril, int64_t n_rows, int64_t n_dim,
+                            int64_t mean_rows, int64_t tril_count,
+                            float* log_prob, float* grad_x, float* z_out,
+                            void* stream);
+int zshmc_mvn_tril_sample(float* out, const float* mean, const float* tril,
+                          int64_t n_rows, int64_t n_dim, int64_t mean_rows,
+                          int64_t tril_count, uint64_t seed, uint32_t offset,
+                          void* stream);
+
+/* ------------------------------------------------------------------------
  * Fused mixture-multinomial likelihood + gradient (fp32 MFMA), the E-step
  * likelihood of the logistic-normal topic model
  * (examples/topic_models/lntm_mcem.py:33-48): for every row r

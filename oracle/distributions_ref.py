@@ -283,3 +283,73 @@ class Beta(_TwoParam):
         return ((a - 1) / x - (b - 1) / (1 - x),
                 np.log(x) - digamma(a) + digamma(a + b),
                 np.log1p(-x) - digamma(b) + digamma(a + b))
+
+
+class MultivariateNormalCholesky(object):
+    """zhusuan/distributions/multivariate.py:41-193.  float32 restatement:
+    forward substitution for matrix_triangular_solve (:183), log_z as :169-174,
+    sample = L . noise + mean (:155-157) on the shared Philox stream."""
+
+    def __init__(self, mean, cov_tril, group_ndims=0, dtype=np.float32):
+        """dtype=np.float64 evaluates the same restatement in double (the
+        reference's own test feeds float64 parameters, test_multivariate.py:
+        56), which is how the algorithm is pinned to the scipy vectors; the
+        device path is float32."""
+        self.dt = np.dtype(dtype).type
+        self.mean = np.asarray(mean, self.dt)
+        self.cov_tril = np.asarray(cov_tril, self.dt)
+        self.n_dim = self.mean.shape[-1]
+        assert self.cov_tril.shape == self.mean.shape + (self.n_dim,)
+        self.group_ndims = group_ndims
+
+    def _solve_lower(self, L, y):
+        """Row-by-row forward substitution, batched over leading axes."""
+        D = y.shape[-1]
+        z = np.zeros(np.broadcast_shapes(L.shape[:-2], y.shape[:-1]) + (D,),
+                     self.dt)
+        for i in range(D):
+            acc = y[..., i] - (L[..., i, :i] * z[..., :i]).sum(-1,
+                                                              dtype=self.dt)
+            z[..., i] = acc / L[..., i, i]
+        return z
+
+    def _solve_upper_t(self, L, z):
+        """w = L^-T z."""
+        D = z.shape[-1]
+        w = np.zeros_like(z)
+        for i in range(D - 1, -1, -1):
+            acc = z[..., i] - (L[..., i + 1:, i] * w[..., i + 1:]).sum(
+                -1, dtype=self.dt)
+            w[..., i] = acc / L[..., i, i]
+        return w
+
+    def _log_prob(self, given):
+        given = np.asarray(given, self.dt)
+        L = self.cov_tril
+        log_det = 2 * np.log(np.diagonal(L, axis1=-2, axis2=-1)).sum(
+            -1, dtype=self.dt)                                   # :169-170
+        log_z = (-self.dt(self.n_dim) / 2 * np.log(
+            self.dt(2 * np.pi)) - log_det / 2).astype(self.dt)  # :172-173
+        z = self._solve_lower(L, given - self.mean)                 # :180-184
+        stoc = -0.5 * np.square(z).sum(-1, dtype=self.dt)        # :185
+        return (log_z + stoc).astype(self.dt)
+
+    def log_prob(self, given):
+        return _group_sum(self._log_prob(given), self.group_ndims)
+
+    def grad_given(self, given):
+        given = np.asarray(given, self.dt)
+        z = self._solve_lower(self.cov_tril, given - self.mean)
+        return (-self._solve_upper_t(self.cov_tril, z)).astype(self.dt)
+
+    def sample(self, n_samples=None, seed=0, offset=0):
+        n = 1 if n_samples is None else int(n_samples)
+        shape = (n,) + self.mean.shape
+        noise = philox.normal_flat(seed, offset, int(np.prod(shape))).reshape(
+            shape)
+        out = np.zeros(shape, self.dt)
+        for i in range(self.n_dim):
+            out[..., i] = (self.cov_tril[..., i, :i + 1] *
+                           noise[..., :i + 1]).sum(-1, dtype=self.dt)
+        out = out + self.mean
+        return out[0] if n_samples is None else out

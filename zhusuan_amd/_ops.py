@@ -169,6 +169,62 @@ class Uni2LogProb(torch.autograd.Function):
                 _sum_to(gb, bs) if need_b else None, None, None)
 
 
+class MvnTrilLogProb(torch.autograd.Function):
+    """MultivariateNormalCholesky._log_prob (reference distributions/
+    multivariate.py:166-188) and its gradients: d/dgiven = -L^-T z from the
+    kernel's back substitution; d/dmean = -d/dgiven; d/dL = tril(w z^T) -
+    diag(1/L_ii) with w = L^-T z (csrc/mvn.hip).
+    x [..., D] already broadcast to its full shape; mean [*mb, D] and
+    tril [*mb, D, D] with `mb` a suffix of x's batch axes (shared by the
+    leading axes through a row period)."""
+
+    @staticmethod
+    def forward(ctx, x, mean, tril):
+        require_device(x, mean, tril)
+        D = x.shape[-1]
+        xf = x.detach().to(_F32).contiguous()
+        mf = mean.detach().to(_F32).contiguous()
+        tf_ = tril.detach().to(_F32).contiguous()
+        rows = xf.numel() // D if D else 0
+        mean_rows = max(mf.numel() // D, 1)
+        tril_count = max(tf_.numel() // (D * D), 1)
+        out = torch.empty(x.shape[:-1], dtype=_F32, device=x.device)
+        need = any(ctx.needs_input_grad[:3])
+        need_p = ctx.needs_input_grad[2]
+        gx = torch.empty_like(xf) if need else None
+        z = torch.empty_like(xf) if need_p else None
+        _capi.call('zshmc_mvn_tril_log_prob', xf.data_ptr(), mf.data_ptr(),
+                   tf_.data_ptr(), rows, D, mean_rows, tril_count,
+                   out.data_ptr(), _capi.ptr(gx), _capi.ptr(z),
+                   _capi.current_stream())
+        ctx.shapes = (tuple(x.shape), tuple(mean.shape), tuple(tril.shape))
+        if need:
+            ctx.save_for_backward(gx, z, tf_) if need_p else \
+                ctx.save_for_backward(gx)
+        ctx.need_p = need_p
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        xs, ms, ts = ctx.shapes
+        if ctx.need_p:
+            gx, z, tril = ctx.saved_tensors
+        else:
+            (gx,) = ctx.saved_tensors
+        g = gx * gout.unsqueeze(-1)
+        need_x, need_m, need_t = ctx.needs_input_grad[:3]
+        gm = _sum_to(-g, ms) if need_m else None
+        gt = None
+        if need_t:
+            # d/dL = gout * (tril(w z^T) - diag(1/L_ii)), w = -gx
+            outer = torch.tril((-g).unsqueeze(-1) * z.unsqueeze(-2))
+            diag = torch.diag_embed(
+                gout.unsqueeze(-1) / torch.diagonal(tril, dim1=-2, dim2=-1)
+                .expand(xs))
+            gt = _sum_to(outer - diag, ts)
+        return (g if need_x else None), gm, gt
+
+
 class BernoulliLogProb(torch.autograd.Function):
     """Bernoulli._log_prob (reference univariate.py:398-403)."""
 

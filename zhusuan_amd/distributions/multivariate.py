@@ -1,15 +1,124 @@
-"""UnnormalizedMultinomial -- on the HMC path only because the
-logistic-normal topic model needs it (reference
-examples/topic_models/lntm_mcem.py:46).  Mirrors
-zhusuan/distributions/multivariate.py:339-449."""
+"""Multivariate distributions on the HMC path: UnnormalizedMultinomial (the
+logistic-normal topic model needs it, reference
+examples/topic_models/lntm_mcem.py:46; zhusuan/distributions/
+multivariate.py:339-449) and MultivariateNormalCholesky (SURVEY 8f-4;
+multivariate.py:41-193)."""
 import torch
 
-from .. import _ops
+from .. import _capi, _ops
+from ..utils import next_op_offset
 from .base import Distribution, as_tensor, common_device, default_device
 from .univariate import _assert_same_float_dtype, _require_f32, _FLOATS, _INTS
 
 __all__ = ['UnnormalizedMultinomial', 'BagofCategoricals', 'LogMixture',
-           'log_mixture']
+           'log_mixture', 'MultivariateNormalCholesky']
+
+
+class MultivariateNormalCholesky(Distribution):
+    """Multivariate normal with covariance L L^T given by its lower-triangular
+    Cholesky factor (multivariate.py:41-193; same arguments, shape rules and
+    error messages).  `mean [..., n_dim]`, `cov_tril [..., n_dim, n_dim]`;
+    log_prob, its gradients and sampling run in csrc/mvn.hip."""
+
+    def __init__(self, mean, cov_tril, group_ndims=0, is_reparameterized=True,
+                 use_path_derivative=False, check_numerics=False, **kwargs):
+        self._check_numerics = check_numerics
+        dev = common_device(mean, cov_tril) or default_device()
+        f32 = torch.float32
+        self._mean = as_tensor(mean, dtype=None if isinstance(
+            mean, torch.Tensor) else f32, device=dev)
+        if self._mean.dim() < 1:                              # :83-84
+            raise ValueError("MultivariateNormalCholesky.mean should have "
+                             "rank >= 1, got a scalar.")
+        self._n_dim = int(self._mean.shape[-1])
+        self._cov_tril = as_tensor(cov_tril, dtype=None if isinstance(
+            cov_tril, torch.Tensor) else f32, device=dev)
+        if self._cov_tril.dim() < 2:                          # :87-88
+            raise ValueError("MultivariateNormalCholesky.cov_tril should "
+                             "have rank >= 2, got rank {}."
+                             .format(self._cov_tril.dim()))
+        expected = tuple(self._mean.shape) + (self._n_dim,)   # :90-103
+        if tuple(self._cov_tril.shape) != expected:
+            raise ValueError(
+                "MultivariateNormalCholesky.cov_tril should have compatible "
+                "shape with mean. Expected {} got {}".format(
+                    expected, tuple(self._cov_tril.shape)))
+        dtype = _assert_same_float_dtype(
+            [(self._mean, 'MultivariateNormalCholesky.mean'),
+             (self._cov_tril, 'MultivariateNormalCholesky.cov_tril')])
+        _require_f32(dtype, 'MultivariateNormalCholesky')
+        if self._n_dim > 512:
+            raise ValueError("MultivariateNormalCholesky: n_dim <= 512 on "
+                             "this device path, got {}".format(self._n_dim))
+        super(MultivariateNormalCholesky, self).__init__(
+            dtype=dtype, param_dtype=dtype, is_continuous=True,
+            is_reparameterized=is_reparameterized,
+            use_path_derivative=use_path_derivative,
+            group_ndims=group_ndims, **kwargs)
+
+    @property
+    def mean(self):
+        return self._mean
+
+    @property
+    def cov_tril(self):
+        return self._cov_tril
+
+    def _device(self):
+        return self._mean.device
+
+    def _get_value_shape(self):
+        return torch.Size([self._n_dim])
+
+    def _get_batch_shape(self):
+        return self._mean.shape[:-1]
+
+    def _sample(self, n_samples):
+        """multivariate.py:141-164: mean + L . N(0, I)."""
+        mean, tril = self._mean, self._cov_tril
+        if not self.is_reparameterized:
+            mean, tril = mean.detach(), tril.detach()
+        _ops.require_device(mean, tril)
+        n, D = int(n_samples), self._n_dim
+        batch = tuple(self._get_batch_shape())
+        b = 1
+        for d in batch:
+            b *= int(d)
+        shape = (n,) + batch + (D,)
+        seed, offset = next_op_offset()
+        stream = _capi.current_stream()
+        if mean.requires_grad or tril.requires_grad:
+            # reparameterisation: draw the N(0, I) block with the kernel and
+            # let autograd see  mean + L . eps
+            eps = torch.empty(shape, dtype=torch.float32, device=mean.device)
+            one = torch.ones(1, device=mean.device)
+            zero = torch.zeros(1, device=mean.device)
+            _capi.call('zshmc_normal_sample', eps.data_ptr(), zero.data_ptr(),
+                       one.data_ptr(), eps.numel(), 1, _capi.BCAST_SCALAR,
+                       _capi.BCAST_SCALAR, seed, offset, stream)
+            return mean + (tril @ eps.unsqueeze(-1)).squeeze(-1)
+        out = torch.empty(shape, dtype=torch.float32, device=mean.device)
+        m, t = mean.detach().contiguous(), tril.detach().contiguous()
+        _capi.call('zshmc_mvn_tril_sample', out.data_ptr(), m.data_ptr(),
+                   t.data_ptr(), n * b, D, max(b, 1), max(b, 1), seed, offset,
+                   stream)
+        return out
+
+    def _log_prob(self, given):
+        mean = self.path_param(self._mean)
+        tril = self.path_param(self._cov_tril)
+        full = torch.broadcast_shapes(given.shape, mean.shape)
+        x = given if tuple(given.shape) == tuple(full) else given.expand(full)
+        mb = tuple(mean.shape[:-1])
+        if len(mb) and tuple(full[len(full) - 1 - len(mb):-1]) != mb:
+            # `given` broadcasts INTO the batch axes: materialise parameters
+            mean = mean.expand(full)
+            tril = tril.expand(tuple(full) + (self._n_dim,))
+        out = _ops.MvnTrilLogProb.apply(x, mean, tril)
+        if self._check_numerics and not bool(torch.isfinite(out).all()):
+            raise FloatingPointError(
+                "MultivariateNormalCholesky.log_prob: Tensor had Inf or NaN")
+        return out
 
 
 class LogMixture(object):

@@ -296,6 +296,17 @@ class _BayesianNet(object):
 
     bag_of_categoricals = unnormalized_multinomial
 
+    def multivariate_normal_cholesky(self, name, mean, cov_tril,
+                                     n_samples=None, group_ndims=0,
+                                     is_reparameterized=True,
+                                     check_numerics=False, **kwargs):
+        """bn.py:840-870."""
+        dist = distributions.MultivariateNormalCholesky(
+            mean, cov_tril, group_ndims=group_ndims,
+            is_reparameterized=is_reparameterized,
+            check_numerics=check_numerics, **kwargs)
+        return self.stochastic(name, dist, n_samples=n_samples, **kwargs)
+
 
 class BayesianNet(_BayesianNet, Context):
     """bn.py:481-520 (the deprecated context-manager / `observed=` /
