@@ -274,6 +274,29 @@ int zshmc_categorical_sample(int32_t* out, const float* logits,
                              uint64_t seed, uint32_t offset, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Gathered row dot products (the rating logits of
+ * examples/probabilistic_matrix_factorization/pmf_hmc.py:26-28):
+ *   out[k, e] = sum_d u[k, select_u[e], d] * v[k, select_v[e], d]
+ * u [n_chains, n_u, n_dim], v [n_chains, n_v, n_dim] row-major, indices int32
+ * in range (the caller validates them), out [n_chains, n_pairs].  Replaces
+ * tf.gather(u, select_u, axis=1) * tf.gather(v, select_v, axis=1) summed over
+ * axis 2 without materialising the [K, E, D] gathers.
+ * zshmc_gather_dot_grad is what tf.gradients gives for ONE side:
+ *   grad[k, i, :] = sum_{e : own_index[e] = i} gout[k, e] * other[k, other_index[e], :]
+ * over a CSR view of the pair list: `order` lists the pair ids grouped by
+ * own_index, `seg_ptr[i] .. seg_ptr[i+1]` is row i's slice of it
+ * (n_rows + 1 offsets).  No atomics: deterministic. */
+int zshmc_gather_dot(const float* u, const float* v, const int32_t* select_u,
+                     const int32_t* select_v, int64_t n_chains, int64_t n_u,
+                     int64_t n_v, int64_t n_pairs, int64_t n_dim, float* out,
+                     void* stream);
+int zshmc_gather_dot_grad(const float* other, const float* gout,
+                          const int32_t* seg_ptr, const int32_t* order,
+                          const int32_t* other_index, int64_t n_chains,
+                          int64_t n_rows, int64_t n_other, int64_t n_pairs,
+                          int64_t n_dim, float* grad, void* stream);
+
+/* ------------------------------------------------------------------------
  * MultivariateNormalCholesky (zhusuan/distributions/
  * multivariate.py:41-193).  x [n_rows, n_dim]; row r uses
  * mean[r % mean_rows, :] and the lower-triangular factor

@@ -43,3 +43,11 @@ def test_lntm_example():
     assert len(perp) == 4 and perp[-1] < 0.6 * perp[0]
     test_perp = float(out.split('perplexity = ')[-1].split()[0])
     assert test_perp < 500      # uniform model: 1000
+
+
+def test_pmf_example():
+    out = _run('examples/pmf_hmc.py', '--small', '--epochs', '5',
+               '--step-size', '0.01')
+    tr = [float(l.split('rmse = ')[1]) for l in out.splitlines()
+          if 'Train: rmse' in l]
+    assert len(tr) == 5 and tr[-1] < 0.8 * tr[0]

@@ -102,6 +102,11 @@ PROTOTYPES = {
         _p, _p, _p, _p, c_int64, c_int64, c_int, _p]),
     'zshmc_linear_bernoulli_log_lik': (c_int, [
         _p, _p, _p, c_int64, c_int64, c_int64, _p, _p, c_int, _p, _p]),
+    'zshmc_gather_dot': (c_int, [
+        _p, _p, _p, _p, c_int64, c_int64, c_int64, c_int64, c_int64, _p, _p]),
+    'zshmc_gather_dot_grad': (c_int, [
+        _p, _p, _p, _p, _p, c_int64, c_int64, c_int64, c_int64, c_int64, _p,
+        _p]),
     'zshmc_mvn_tril_log_prob': (c_int, [
         _p, _p, _p, c_int64, c_int64, c_int64, c_int64, _p, _p, _p, _p]),
     'zshmc_mvn_tril_sample': (c_int, [

@@ -169,6 +169,101 @@ class Uni2LogProb(torch.autograd.Function):
                 _sum_to(gb, bs) if need_b else None, None, None)
 
 
+_csr_cache = {}
+
+
+def _pair_csr(index, n_rows, slot):
+    """CSR view of a 1-D index tensor: (int32 index, seg_ptr [n_rows + 1],
+    order [E]) with `order` the pair ids stably sorted by the row they point
+    at.  Validates the range once per tensor version (torch.gather semantics:
+    out-of-range is an error, not a wrap).  Cached while the same tensor is
+    passed again -- every leapfrog step of a transition reuses the pair list;
+    the entry pins the tensor so its address cannot be recycled."""
+    key = (index.data_ptr(), tuple(index.shape), index._version, int(n_rows),
+           index.dtype)
+    hit = _csr_cache.get(slot)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    if index.dim() != 1 or index.dtype not in (torch.int32, torch.int64):
+        raise TypeError("gathered_dot: indices must be 1-D int32/int64 "
+                        "tensors, got {} {}".format(tuple(index.shape),
+                                                    index.dtype))
+    if index.numel() and (int(index.min()) < 0 or
+                          int(index.max()) >= n_rows):
+        raise IndexError("gathered_dot: index out of range [0, {})"
+                         .format(n_rows))
+    i32 = index.to(torch.int32).contiguous()
+    order = torch.sort(index.to(torch.int64), stable=True)[1].to(torch.int32)
+    counts = torch.bincount(index.to(torch.int64), minlength=n_rows)
+    seg = torch.zeros(n_rows + 1, dtype=torch.int32, device=index.device)
+    seg[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    val = (i32, seg, order.contiguous())
+    _csr_cache[slot] = (key, val, index)
+    return val
+
+
+class GatheredDot(torch.autograd.Function):
+    """out[..., e] = sum_d u[..., su[e], d] * v[..., sv[e], d]
+    (examples/probabilistic_matrix_factorization/pmf_hmc.py:26-28 without the
+    [K, E, D] gathers) and its gradients by deterministic segmented sums
+    (csrc/gather_dot.hip)."""
+
+    @staticmethod
+    def forward(ctx, u, su, v, sv):
+        require_device(u, v, su, sv)
+        if u.dim() < 2 or v.dim() < 2 or u.shape[:-2] != v.shape[:-2] or \
+                u.shape[-1] != v.shape[-1]:
+            raise ValueError("gathered_dot: u [..., n, D] and v [..., m, D] "
+                             "with equal leading axes expected, got {} and {}"
+                             .format(tuple(u.shape), tuple(v.shape)))
+        if su.shape != sv.shape:
+            raise ValueError("gathered_dot: select_u and select_v differ in "
+                             "shape")
+        n_u, n_v, D = u.shape[-2], v.shape[-2], u.shape[-1]
+        uf = u.detach().to(_F32).contiguous()
+        vf = v.detach().to(_F32).contiguous()
+        K = uf.numel() // max(n_u * D, 1)
+        csr_u = _pair_csr(su, n_u, 'u')
+        csr_v = _pair_csr(sv, n_v, 'v')
+        E = csr_u[0].numel()
+        out = torch.empty(tuple(u.shape[:-2]) + (E,), dtype=_F32,
+                          device=u.device)
+        _capi.call('zshmc_gather_dot', uf.data_ptr(), vf.data_ptr(),
+                   csr_u[0].data_ptr(), csr_v[0].data_ptr(), K, n_u, n_v, E, D,
+                   out.data_ptr(), _capi.current_stream())
+        ctx.save_for_backward(uf, vf, *csr_u, *csr_v)
+        ctx.dims = (K, n_u, n_v, E, D, tuple(u.shape), tuple(v.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        uf, vf, iu, seg_u, ord_u, iv, seg_v, ord_v = ctx.saved_tensors
+        K, n_u, n_v, E, D, us, vs = ctx.dims
+        g = gout.to(_F32).contiguous()
+        stream = _capi.current_stream()
+        gu = gv = None
+        if ctx.needs_input_grad[0]:
+            gu = torch.empty(us, dtype=_F32, device=g.device)
+            _capi.call('zshmc_gather_dot_grad', vf.data_ptr(), g.data_ptr(),
+                       seg_u.data_ptr(), ord_u.data_ptr(), iv.data_ptr(), K,
+                       n_u, n_v, E, D, gu.data_ptr(), stream)
+        if ctx.needs_input_grad[2]:
+            gv = torch.empty(vs, dtype=_F32, device=g.device)
+            _capi.call('zshmc_gather_dot_grad', uf.data_ptr(), g.data_ptr(),
+                       seg_v.data_ptr(), ord_v.data_ptr(), iu.data_ptr(), K,
+                       n_v, n_u, E, D, gv.data_ptr(), stream)
+        return gu, None, gv, None
+
+
+def gathered_dot(u, select_u, v, select_v):
+    """`reduce_sum(gather(u, select_u, axis=-2) * gather(v, select_v, axis=-2),
+    axis=-1)`: u [..., n, D], v [..., m, D] with equal leading (chain) axes,
+    1-D integer index tensors of equal length E; returns [..., E]."""
+    u = u.tensor if hasattr(u, 'tensor') else u
+    v = v.tensor if hasattr(v, 'tensor') else v
+    return GatheredDot.apply(u, select_u, v, select_v)
+
+
 class MvnTrilLogProb(torch.autograd.Function):
     """MultivariateNormalCholesky._log_prob (reference distributions/
     multivariate.py:166-188) and its gradients: d/dgiven = -L^-T z from the

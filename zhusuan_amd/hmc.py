@@ -34,7 +34,7 @@ from .framework.bn import StochasticTensor
 from .framework.meta_bn import MetaBayesianNet
 from .utils import merge_dicts, next_sampler_seed
 
-__all__ = ['HMCInfo', 'HMC', 'placeholder', 'InvalidArgumentError']
+__all__ = ['deferred', 'HMCInfo', 'HMC', 'placeholder', 'InvalidArgumentError']
 
 OLD_LOG_PROB_MSG = ('HMC: old_log_prob has numeric errors! Try better '
                     'initialization.')
@@ -46,16 +46,66 @@ class InvalidArgumentError(ArithmeticError):
 
 
 class placeholder(object):
-    """Per-run feedable flag: `flag = placeholder(bool)`;
-    `sample_op.run(feed_dict={flag: i < burnin})`."""
+    """Per-run feedable value (the reference's tf.placeholder as far as the
+    sampling path uses it).
+      * flags: `flag = placeholder(bool)`;
+        `sample_op.run(feed_dict={flag: i < burnin})` (gaussian.py:40-41,57-58);
+      * tensors: `x = placeholder(torch.float32, name='x')` may stand in
+        `observed` or be read as `x.value` inside a model function; the value
+        fed to the latest `sample_op.run(feed_dict={x: ...})` (NumPy array,
+        list or tensor; moved to the sampler's device) stays bound until fed
+        again (pmf_hmc.py:84-87,186-192).  `default` is the value before the
+        first feed (needed if HMC.sample has to evaluate the model to derive
+        the chain shape)."""
 
     def __init__(self, dtype=bool, shape=None, name=None, default=None):
         self.dtype = dtype
+        self.shape = shape
         self.name = name
         self.default = default
+        self._value = default
 
     def __repr__(self):
         return 'placeholder(%s)' % (self.name or hex(id(self)))
+
+    @property
+    def value(self):
+        if self._value is None:
+            raise ValueError(
+                "You must feed a value for placeholder %r" % (self,))
+        return self._value
+
+    def feed(self, value, device=None):
+        if isinstance(self.dtype, torch.dtype):
+            value = torch.as_tensor(value, dtype=self.dtype).to(
+                device if device is not None else default_feed_device())
+        self._value = value
+
+
+class deferred(object):
+    """An `observed` value computed at run time from fed placeholders -- what
+    a graph expression of placeholders is in the reference
+    (`(true_rating - 1.0) / 4.0`, `tf.gather(V, neighbor_v, axis=1)`,
+    pmf_hmc.py:113,121-122): `deferred(lambda: (true_rating.value - 1) / 4)`."""
+
+    def __init__(self, fn):
+        self._fn = fn
+
+    @property
+    def value(self):
+        return self._fn()
+
+
+def default_feed_device():
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def bind_feed(feed_dict, device=None):
+    """Bind every placeholder key of `feed_dict` to its value."""
+    if feed_dict:
+        for k, v in feed_dict.items():
+            if isinstance(k, placeholder):
+                k.feed(v, device)
 
 
 def _flag_value(flag, feed_dict, what):
@@ -246,8 +296,13 @@ class HMC(object):
         return _SampleOp(self), info
 
     def _eval_log_joint(self, names, values):
-        joint_obs = merge_dicts(dict(zip(names, values)), self._observed)
+        joint_obs = merge_dicts(dict(zip(names, values)),
+                                self._resolved_observed())
         return self._log_joint(joint_obs)                # hmc.py:426-428
+
+    def _resolved_observed(self):
+        return {k: (v.value if isinstance(v, (placeholder, deferred)) else v)
+                for k, v in self._observed.items()}
 
     @property
     def plan_kind(self):
@@ -256,6 +311,7 @@ class HMC(object):
     # -- one execution of sample_op ----------------------------------------
     def _run(self, feed_dict, sync):
         plan = self._plan
+        bind_feed(feed_dict, plan.device)
         self.t += 1                                       # hmc.py:418
         t = self.t
         adapt_ss = None if self.adapt_step_size is None else _flag_value(
@@ -636,7 +692,8 @@ def _try_fused_plan(hmc, meta_bn, names, values, chain_shape, device):
     if n_data > int(_capi.load().zshmc_fused_max_n_data()):
         return None
     probe = q.detach().requires_grad_(True)
-    bn = meta_bn.observe(**merge_dicts({name: probe}, hmc._observed))
+    bn = meta_bn.observe(**merge_dicts({name: probe},
+                                      hmc._resolved_observed()))
     stoch = [n for n in bn.nodes.values() if isinstance(n, StochasticTensor)]
     if len(stoch) != 1 or stoch[0].name != name:
         return None
