@@ -41,7 +41,8 @@ def test_lntm_example():
     perp = [float(l.split('Perplexity = ')[1].split(',')[0])
             for l in out.splitlines() if 'Perplexity' in l]
     assert len(perp) == 4 and perp[-1] < 0.6 * perp[0]
-    test_perp = float(out.split('perplexity = ')[-1].split()[0])
+    line = [l for l in out.splitlines() if l.startswith('>> Test')][0]
+    test_perp = float(line.split('perplexity = ')[1].split()[0])
     assert test_perp < 500      # uniform model: 1000
 
 

@@ -96,6 +96,43 @@ __device__ __forceinline__ void wave_total4_dpp(float& a, float& b, float& c,
       float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d), 63));
 }
 
+// Four wave totals through the gfx950 half / row exchanges instead of four
+// separate DPP scans (24 DPP + 8 moves + 8 adds + 4 readlanes -> 3 swaps +
+// 3 adds + 4 DPP + 4 readlanes; DPP and SGPR-operand VALU ops issue at half
+// the rate of plain ones, tools/instr_bench.hip):
+//   v_permlane32_swap(a, b): lanes 32-63 of a <-> lanes 0-31 of b, so
+//     a' + b' folds a onto lanes 0-31 and b onto lanes 32-63;
+//   v_permlane16_swap(ab, cd): odd rows of ab <-> even rows of cd, so
+//     ab' + cd' leaves one value per row of 16 lanes (rows: a, c, b, d);
+//   one row_shr scan then finishes all four at once.
+__device__ __forceinline__ void wave_total4_swap(float& a, float& b, float& c,
+                                                 float& d) {
+  // inline asm, operands updated in place; the two wait states the swaps
+  // need after a VALU write of an operand are inside the string (hipcc's
+  // builtin mis-pairs the two results when both feed one add)
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_permlane32_swap_b32 %0, %1\n\t"
+      "v_permlane32_swap_b32 %2, %3"
+      : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+  float sab = a + b;
+  float scd = c + d;
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_permlane16_swap_b32 %0, %1"
+      : "+v"(sab), "+v"(scd));
+  float v = sab + scd;
+  v = dpp_add<0x111, 0xf>(v);  // row_shr:1
+  v = dpp_add<0x112, 0xf>(v);  // row_shr:2
+  v = dpp_add<0x114, 0xf>(v);  // row_shr:4
+  v = dpp_add<0x118, 0xf>(v);  // row_shr:8
+  const int vi = __builtin_bit_cast(int, v);
+  a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 15));
+  c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 31));
+  b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 47));
+  d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 63));
+}
+
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

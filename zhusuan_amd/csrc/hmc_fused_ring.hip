@@ -187,6 +187,23 @@ __device__ __forceinline__ int64_t uni64(int64_t x) {
   return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 // all-ones / all-zeros EXEC mask from a wave-uniform condition
+// mask ? a : b / mask ? v : 0 as v_cndmask_b32_e64 with the lane mask in an
+// SGPR pair that is not VCC.  hipcc's hazard recognizer does not look inside
+// inline asm: the wait state a VALU read of a transcendental result needs on
+// gfx940+ (v_exp_f32 feeds keep_if) is spelled out in the string.
+__device__ __forceinline__ float select_e64(uint64_t mask, float a, float b) {
+  float r;
+  asm("s_nop 1\n\tv_cndmask_b32_e64 %0, %1, %2, %3"
+      : "=v"(r)
+      : "v"(b), "v"(a), "s"(mask));
+  return r;
+}
+__device__ __forceinline__ float keep_if(float v, uint64_t mask) {
+  float r;
+  asm("s_nop 1\n\tv_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(v), "s"(mask));
+  return r;
+}
+
 __device__ __forceinline__ Mask mask_if(bool c) {
 #ifdef ZS_NO_MEM  // A/B probe only: VMEM issued with EXEC = 0 (compute-only time)
   c = false;
@@ -488,7 +505,11 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
     float k_new = (kn[0] + kn[1]) + (kn[2] + kn[3]);
     float u_new = (un[0] + un[1]) + (un[2] + un[3]);
 #ifndef ZS_NO_REDUCE  // A/B probe only
+#ifdef ZS_SLOW_TAIL
     wave_total4_dpp(k_old, u_old, k_new, u_new);
+#else
+    wave_total4_swap(k_old, u_old, k_new, u_new);
+#endif
 #endif
     if (HAS_MASS) {  // sum p^2/m = (1/se) sum p^2 * (se/m)
       k_old *= inv_se;
@@ -499,9 +520,21 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
     const float h_old = -lp_old + 0.5f * k_old;
     const float h_new = -lp_new + 0.5f * k_new;
     const float dh = h_old - h_new;
+#ifdef ZS_SLOW_TAIL  // A/B probe only: libm expf + compiler-chosen selects
     float acc = expf(fminf(dh, 0.0f));
     // fminf drops a NaN operand: test explicitly (hmc.py:56-59)
     if (!(dh == dh) || !isfinite(acc) || !isfinite(lp_new)) acc = 0.f;
+#else
+    // exp(min(dh, 0)) on v_exp_f32 (argument <= 0: no overflow, underflow
+    // flushes to 0), then the guards of hmc.py:56-59.  fminf drops a NaN
+    // operand, so NaN is tested explicitly; exp of a non-positive finite
+    // number is finite.  The select is forced into its e64 form with the lane
+    // mask in a plain SGPR pair: the e32 form hipcc picks (mask in VCC) issues
+    // ~5x slower than any other VALU op on gfx950 (tools/instr_bench.hip).
+    const float acc = keep_if(
+        __builtin_amdgcn_exp2f(fminf(dh, 0.0f) * 1.4426950408889634f),
+        __builtin_amdgcn_ballot_w64((dh == dh) && isfinite(lp_new)));
+#endif
     if (!isfinite(lp_old)) bad_old = true;
 
 #ifdef ZS_NO_UNIF  // A/B probe only
@@ -536,7 +569,12 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
     // ---- the five HMCInfo scalars of this chain (lane 0; hmc.py:508-517) --
     // Staged in LDS under the chain's ticket and written back as whole lines
     // after the loop (STAGE), or stored from here as 5 ledger entries.
+#ifdef ZS_SLOW_TAIL
     const float lp_sel = accept ? lp_new : lp_old;
+#else
+    const float lp_sel =
+        select_e64(__builtin_amdgcn_ballot_w64(accept), lp_new, lp_old);
+#endif
     if (STAGE) {
       if (lane == 0) {
         const int cap = a.info_cap;
