@@ -164,3 +164,62 @@ def test_recomputed_phi_never_hits_a_stale_pad_cache(env):
         np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(),
                                    rtol=2e-4)
         beta.add_(torch.randn(K, V, device=dev, generator=g))
+
+
+def test_config5_full_size_properties(env):
+    """BASELINE config 5 shape (8 192 (chain, doc) rows x K = 128 topics x
+    V = 12 419 words): size-independent properties of the fused likelihood,
+    plus float64 spot checks of a few rows."""
+    zs, torch, dev = env
+    CH, R0, K, V = 2, 4096, 128, 12419
+    g = torch.Generator(device=dev).manual_seed(0)
+    phi = torch.softmax(torch.randn(K, V, device=dev, generator=g), -1)
+    x1 = torch.poisson(torch.full((R0, V), 0.05, device=dev), generator=g)
+    x2 = torch.poisson(torch.full((R0, V), 0.03, device=dev), generator=g)
+    theta = torch.softmax(torch.randn(CH, R0, K, device=dev, generator=g), -1)
+
+    def ll_and_grad(th, ph, x):
+        t = th.detach().clone().requires_grad_(True)
+        d = zs.distributions.UnnormalizedMultinomial(
+            zs.log_mixture(t, ph), normalize_logits=False, dtype=torch.float32)
+        ll = d.log_prob(x)
+        ll.sum().backward()
+        return ll.detach(), t.grad
+
+    ll1, g1 = ll_and_grad(theta, phi, x1)
+    ll2, g2 = ll_and_grad(theta, phi, x2)
+    ll12, g12 = ll_and_grad(theta, phi, x1 + x2)
+    assert tuple(ll1.shape) == (CH, R0) and bool(torch.isfinite(ll12).all())
+    # linear in the counts
+    torch.testing.assert_close(ll1 + ll2, ll12, rtol=2e-5, atol=2e-2)
+    torch.testing.assert_close(g1 + g2, g12, rtol=2e-4,
+                               atol=2e-5 * float(g12.abs().max()))
+    # additive over a split of the vocabulary (ragged cut)
+    h = 7001
+    lla, ga = ll_and_grad(theta, phi[:, :h].contiguous(), x1[:, :h].contiguous())
+    llb, gb = ll_and_grad(theta, phi[:, h:].contiguous(), x1[:, h:].contiguous())
+    torch.testing.assert_close(lla + llb, ll1, rtol=2e-5, atol=2e-2)
+    torch.testing.assert_close(ga + gb, g1, rtol=2e-4,
+                               atol=2e-5 * float(g1.abs().max()))
+    # a one-hot theta picks one topic: ll = sum_v x_v log phi[k, v]
+    onehot = torch.zeros(1, R0, K, device=dev)
+    ks = torch.arange(R0, device=dev) % K
+    onehot[0, torch.arange(R0, device=dev), ks] = 1.0
+    llo, _ = ll_and_grad(onehot, phi, x1)
+    want = (x1.double() * torch.log(phi.double())[ks]).sum(-1)
+    torch.testing.assert_close(llo[0].double(), want, rtol=1e-5, atol=1e-2)
+    # Euler's identity: the mixture is homogeneous of degree 1 in theta, so
+    # theta . d ll / d theta = number of tokens of the document
+    tok = x1.sum(-1)
+    torch.testing.assert_close((theta * g1).sum(-1), tok.expand(CH, R0),
+                               rtol=2e-4, atol=1e-2)
+    # float64 spot checks
+    for c, r in ((0, 0), (1, 1234), (1, R0 - 1)):
+        dw = theta[c, r].double() @ phi.double()
+        np.testing.assert_allclose(float(ll1[c, r]),
+                                   float((x1[r].double() * torch.log(dw)).sum()),
+                                   rtol=1e-5)
+        np.testing.assert_allclose(
+            g1[c, r].cpu().numpy(),
+            ((x1[r].double() / dw) @ phi.double().t()).cpu().numpy(),
+            rtol=2e-4, atol=1e-3)
