@@ -6,7 +6,7 @@ The likelihood is written `zs.linear_logits(w, X)` instead of
 chains and its gradient then run in the fused fp32-MFMA kernel -- X is read
 once per evaluation and the [n_chains, N] logits never exist in memory.
 
-    python examples/bayesian_logistic_regression.py [--n 1000000] [--d 256]
+    python examples/logistic_regression_hmc.py [--n 1000000] [--d 256]
         [--chains 32768] [--iters 100]
 """
 import argparse

@@ -1,9 +1,8 @@
 #!/usr/bin/env python
-"""The reference's examples/probabilistic_matrix_factorization/pmf_hmc.py on
-zhusuan_amd: Bayesian probabilistic matrix factorisation, Gibbs over chunks of
-50 users / 50 movies with an HMC update (K = 8 particles) per chunk.
-
-Same model, same sampler settings and the same feeding pattern
+"""Bayesian probabilistic matrix factorisation (the workload of the reference's
+PMF example): Gibbs sweeps over chunks of 50 users / 50 items, one HMC update
+(K = 8 particles, L = 10) per chunk given the current factors of the other
+side.  Per-chunk sizes and index lists are fed through placeholders
 (`sess.run(sample_u_op, feed_dict={neighbor_v: ..., select_u: ...})`); the
 rating logits are written `zs.gathered_dot(u, select_u, v, select_v)` instead
 of two tf.gather + multiply + reduce_sum, which keeps the [K, batch, D]
@@ -12,7 +11,7 @@ gathers out of memory and makes the scatter gradient deterministic.
 MovieLens-1M is not available offline: ratings are synthesised from a
 ground-truth factor model of a similar shape (sizes shrink with --small).
 
-    python examples/pmf_hmc.py [--small] [--epochs N] [--step-size 1e-3]
+    python examples/matrix_factorization_hmc.py [--small] [--epochs N] [--step-size 1e-3]
 """
 import argparse
 import os
@@ -63,29 +62,24 @@ def synthetic_ratings(N, M, D_true, per_user, seed):
     return data[:n_tr], data[n_tr:]
 
 
-def by_row(data, col, n_rows):
-    other = 1 - col
-    lists = [[] for _ in range(n_rows)]
-    scores = [[] for _ in range(n_rows)]
-    for row in data:
-        lists[row[col]].append(int(row[other]))
-        scores[row[col]].append(float(row[2]))
-    return lists, scores
+class RatingIndex(object):
+    """Ratings grouped by one side (users or items) in CSR form, so that the
+    pairs of a chunk of consecutive rows are one slice."""
 
+    def __init__(self, data, side, n_rows):
+        order = np.argsort(data[:, side], kind='stable')
+        self.other = data[order, 1 - side]
+        self.score = data[order, 2].astype(np.float32)
+        counts = np.bincount(data[:, side], minlength=n_rows)
+        self.start = np.concatenate([[0], np.cumsum(counts)])
 
-def select_from_corpus(l, r, u_v, u_v_score):
-    """pmf_hmc.py:34-62."""
-    sv, tr = [], []
-    for i in range(l, r):
-        sv += u_v[i]
-        tr += u_v_score[i]
-    sv = sorted(set(sv))
-    index = {x: i for i, x in enumerate(sv)}
-    ssu, ssv = [], []
-    for i in range(l, r):
-        ssu += [i - l] * len(u_v[i])
-        ssv += [index[j] for j in u_v[i]]
-    return len(sv), np.array(sv, dtype=np.int64), tr, ssu, ssv
+    def chunk(self, lo, hi):
+        """For rows [lo, hi): the distinct partners, the ratings, and for every
+        rating its local row index and its index into the partner list."""
+        a, b = self.start[lo], self.start[hi]
+        partners, local_other = np.unique(self.other[a:b], return_inverse=True)
+        rows = np.repeat(np.arange(hi - lo), np.diff(self.start[lo:hi + 1]))
+        return partners, self.score[a:b], rows, local_other
 
 
 def main():
@@ -105,8 +99,6 @@ def main():
     else:
         N, M, per_user, n_epochs = 6040, 3706, 165, args.epochs or 3
     train_data, test_data = synthetic_ratings(N, M, 8, per_user, 0)
-    user_movie, user_movie_score = by_row(train_data, 0, N)
-    movie_user, movie_user_score = by_row(train_data, 1, M)
 
     # set configurations and hyper parameters
     D = 30
@@ -114,10 +106,8 @@ def main():
     chunk_size = 50
     N = (N + chunk_size - 1) // chunk_size * chunk_size
     M = (M + chunk_size - 1) // chunk_size * chunk_size
-    user_movie += [[] for _ in range(N - len(user_movie))]
-    user_movie_score += [[] for _ in range(N - len(user_movie_score))]
-    movie_user += [[] for _ in range(M - len(movie_user))]
-    movie_user_score += [[] for _ in range(M - len(movie_user_score))]
+    by_user = RatingIndex(train_data, 0, N)
+    by_item = RatingIndex(train_data, 1, M)
 
     # Selection
     i64, f32 = torch.int64, torch.float32
@@ -182,10 +172,10 @@ def main():
         epoch_time = -time.time()
         accs = []
         for i in range(N // chunk_size):
-            nv, sv, tr, ssu, ssv = select_from_corpus(
-                i * chunk_size, (i + 1) * chunk_size, user_movie,
-                user_movie_score)
-            if not tr:
+            sv, tr, ssu, ssv = by_user.chunk(i * chunk_size,
+                                             (i + 1) * chunk_size)
+            nv = len(sv)
+            if not len(tr):
                 continue
             sl = slice(i * chunk_size, (i + 1) * chunk_size)
             candidate_sample_u.copy_(U[:, sl])
@@ -195,10 +185,10 @@ def main():
             U[:, sl] = candidate_sample_u
             accs.append(float(sample_u_info.acceptance_rate.mean()))
         for i in range(M // chunk_size):
-            nu, su, tr, ssv, ssu = select_from_corpus(
-                i * chunk_size, (i + 1) * chunk_size, movie_user,
-                movie_user_score)
-            if not tr:
+            su, tr, ssv, ssu = by_item.chunk(i * chunk_size,
+                                             (i + 1) * chunk_size)
+            nu = len(su)
+            if not len(tr):
                 continue
             sl = slice(i * chunk_size, (i + 1) * chunk_size)
             candidate_sample_v.copy_(V[:, sl])

@@ -19,25 +19,25 @@ def _run(*argv):
 
 
 def test_gaussian_example():
-    out = _run('examples/gaussian.py')
-    assert 'plan: fused_diag_normal' in out or 'plan:' in out
+    out = _run('examples/diag_gaussian_hmc.py')
+    assert 'sampler plan:' in out
     assert 'Relative error of stdev' in out
 
 
 def test_mixture_sgnht_example():
-    out = _run('examples/mixture_sgnht.py', '6000')
+    out = _run('examples/bimodal_sgnht.py', '--iters', '6000')
     rel = float(out.split('Relative error of stdev = ')[1].split()[0])
     assert abs(rel) < 0.05
 
 
 def test_logistic_regression_example():
-    out = _run('examples/bayesian_logistic_regression.py', '--n', '20000',
+    out = _run('examples/logistic_regression_hmc.py', '--n', '20000',
                '--chains', '512', '--iters', '60')
     assert '|posterior mean - MAP|' in out
 
 
 def test_lntm_example():
-    out = _run('examples/lntm_mcem.py', '--small', '--epochs', '4')
+    out = _run('examples/topic_model_mcem.py', '--small', '--epochs', '4')
     perp = [float(l.split('Perplexity = ')[1].split(',')[0])
             for l in out.splitlines() if 'Perplexity' in l]
     assert len(perp) == 4 and perp[-1] < 0.6 * perp[0]
@@ -47,7 +47,7 @@ def test_lntm_example():
 
 
 def test_pmf_example():
-    out = _run('examples/pmf_hmc.py', '--small', '--epochs', '5',
+    out = _run('examples/matrix_factorization_hmc.py', '--small', '--epochs', '5',
                '--step-size', '0.01')
     tr = [float(l.split('rmse = ')[1]) for l in out.splitlines()
           if 'Train: rmse' in l]

@@ -9,7 +9,7 @@ from zhusuan_amd import _capi  # noqa
 
 C = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 100000
-D = 256
+D = int(sys.argv[4]) if len(sys.argv) > 4 else 256
 dev = torch.device('cuda', 0)
 W = torch.randn(C, D, device=dev) * 0.1
 X = torch.randn(N, D, device=dev)

@@ -1,15 +1,20 @@
 """Annealed importance sampling on top of the native HMC -- the direct
-*caller* of the hot path.  Mirrors reference
-zhusuan/evaluation.py:57-172: tempered log-joint
-(1 - T) * log_prior + T * log_joint with a sigmoid temperature schedule, HMC
-transitions at each temperature, importance weights accumulated from
-HMCInfo.orig_log_prob / log_prob, log-mean-exp lower bound.
+*caller* of the hot path.  Same constructor and
+`run()` as reference zhusuan/evaluation.py:57-172: the sampler targets
+(1 - T) * log_prior + T * log_joint, T follows a sigmoid schedule from 0 to 1,
+one HMC transition per temperature, and the importance weights are the
+telescoping sums of HMCInfo.orig_log_prob / log_prob; the estimate is the
+log-mean-exp over the chain axis.
 
-Differences forced by having no TensorFlow: there is no session (the `sess`
-argument of `run` is accepted and ignored) and the temperature is a host
-scalar read by the tempered log-joint each time the sampler evaluates it (the
-generic HMC plan re-evaluates the joint at every gradient evaluation, so a
-changing temperature is honoured exactly like a fed placeholder)."""
+MI355X-first differences: there is no session (`sess` is accepted and
+ignored), the temperature is a host scalar that the tempered log-joint reads
+every time the sampler evaluates it (exactly like a fed placeholder), and the
+weights are accumulated **on the device** in stream order -- the
+n_temperatures transitions are enqueued back to back with no host round trip
+(the reference fetches two [chains] vectors per temperature), and one
+synchronisation happens when the estimate is read."""
+import math
+
 import numpy as np
 import torch
 
@@ -18,84 +23,92 @@ from .utils import merge_dicts
 __all__ = ['AIS']
 
 
-class AIS(object):
-    """evaluation.py:57-110 (same constructor arguments)."""
+def _as_log_joint(model):
+    if callable(model) and not hasattr(model, 'observe'):
+        return model
+    return lambda values: model.observe(**values).log_joint()
 
+
+def sigmoid_schedule(n_temperatures):
+    """T_0 = 0 .. T_n = 1 with T_k an affinely rescaled
+    sigmoid(4 (2k/n - 1)) (evaluation.py:112-117)."""
+    k = np.arange(n_temperatures + 1, dtype=np.float64)
+    s = 1.0 / (1.0 + np.exp(-4.0 * (2.0 * k / n_temperatures - 1.0)))
+    return (s - s[0]) / (s[-1] - s[0])
+
+
+class AIS(object):
     def __init__(self, meta_bn, proposal_meta_bn, hmc, observed, latent,
                  n_temperatures=1000, n_adapt=30, verbose=False):
-        self._n_temperatures = n_temperatures
-        self._n_adapt = n_adapt
-        self._verbose = verbose
-        if callable(meta_bn) and not hasattr(meta_bn, 'observe'):
-            log_joint = meta_bn
-        else:
-            log_joint = lambda obs: meta_bn.observe(**obs).log_joint()
-        self._latent_k, self._latent_v = zip(*latent.items())
+        self.n_temperatures = int(n_temperatures)
+        self.n_adapt = int(n_adapt)
+        self.verbose = bool(verbose)
+        self.schedule = sigmoid_schedule(self.n_temperatures)
+        self.temperature = 0.0          # the reference's tf.placeholder
         self._proposal = proposal_meta_bn
-        log_prior = lambda obs: proposal_meta_bn.observe(**obs).log_joint()
-        self.temperature = 0.0          # the tf.placeholder of :94-95
+        self._names = tuple(latent.keys())
+        self._state = tuple(latent.values())
+        self._fixed = dict(observed)
+        target, prior = _as_log_joint(meta_bn), _as_log_joint(proposal_meta_bn)
 
-        def log_fn(observed_):
+        def tempered(values):
             t = float(self.temperature)
-            # evaluation.py:98-100
-            return log_prior(observed_) * (1 - t) + log_joint(observed_) * t
+            return prior(values) * (1 - t) + target(values) * t   # :98-100
 
-        self.log_fn = log_fn
-        self._observed = dict(observed)
-        self._latent = dict(latent)
-        self.sample_op, self.hmc_info = hmc.sample(log_fn, observed, latent)
+        self.log_fn = tempered
+        self.sample_op, self.hmc_info = hmc.sample(tempered, observed, latent)
         self._hmc = hmc
 
-    def _init_latent(self):
-        """evaluation.py:96,109-110: draw the latents from the proposal."""
-        prior_samples = self._proposal.observe().get(self._latent_k)
-        for z, z_s in zip(self._latent_v, prior_samples):
-            z.copy_(z_s.tensor if hasattr(z_s, 'tensor') else z_s)
+    # kept for callers of the reference's private helper
+    def _get_schedule_t(self, k):
+        return float(self.schedule[k])
 
-    def _map_t(self, t):
-        return 1. / (1. + np.exp(-4 * (2 * t / self._n_temperatures - 1)))
+    def _reset_state(self):
+        """Latents <- one draw from the proposal (evaluation.py:96,109-110)."""
+        draws = self._proposal.observe().get(self._names)
+        for buf, node in zip(self._state, draws):
+            buf.copy_(node.tensor if hasattr(node, 'tensor') else node)
 
-    def _get_schedule_t(self, t):
-        return (self._map_t(t) - self._map_t(0)) / (
-            self._map_t(self._n_temperatures) - self._map_t(0))
+    def _transition(self, k, feed_dict, tag):
+        self.temperature = self.schedule[k]
+        self.sample_op.run(feed_dict=feed_dict, sync=False)
+        if self.verbose:
+            print('{} {}, Temperature = {:.4f}, acc = {:.3f}'.format(
+                tag, k, self.temperature,
+                float(self.hmc_info.acceptance_rate.mean())))
 
     def run(self, sess=None, feed_dict=None):
-        """Run the AIS loop; returns the log marginal likelihood estimate
-        (evaluation.py:119-165)."""
-        adp_num_t = 2 if self._n_temperatures > 1 else 1
-        adp_t = self._get_schedule_t(adp_num_t)
-        self._init_latent()
-        for i in range(self._n_adapt):
-            self.temperature = adp_t
-            self.sample_op.run(feed_dict=feed_dict)
-            if self._verbose:
-                print('Adapt iter {}, acc = {:.3f}'.format(
-                    i, float(self.hmc_info.acceptance_rate.mean())))
-        self._init_latent()
+        """The AIS loop (evaluation.py:119-165); returns the log marginal
+        likelihood estimate averaged over the non-chain axes."""
+        n = self.n_temperatures
+        # step-size adaptation at a temperature close to the prior
+        self._reset_state()
+        for _ in range(self.n_adapt):
+            self._transition(2 if n > 1 else 1, feed_dict, 'Adapt at step')
+        # the annealing run proper, weights accumulated in stream order
+        self._reset_state()
         self.temperature = 0.0
         with torch.no_grad():
-            prior_density = self.log_fn(
-                merge_dicts(self._observed, self._latent)).cpu().numpy()
-        log_weights = -prior_density
-        for num_t in range(self._n_temperatures):
-            self.temperature = self._get_schedule_t(num_t + 1)
-            self.sample_op.run(feed_dict=feed_dict)
-            old_log_p = self.hmc_info.orig_log_prob.cpu().numpy()
-            new_log_p = self.hmc_info.log_prob.cpu().numpy()
-            if num_t + 1 < self._n_temperatures:
-                log_weights = log_weights + old_log_p - new_log_p
-            else:
-                log_weights = log_weights + old_log_p
-            if self._verbose:
-                print('Finished step {}, Temperature = {:.4f}, acc = {:.3f}'
-                      .format(num_t + 1, self.temperature, float(
-                          self.hmc_info.acceptance_rate.mean())))
-        return np.mean(self._get_lower_bound(log_weights))
+            log_w = -self.log_fn(merge_dicts(
+                self._fixed, dict(zip(self._names, self._state)))).clone()
+        info = self.hmc_info
+        for k in range(1, n + 1):
+            self._transition(k, feed_dict, 'Finished step')
+            log_w += info.orig_log_prob
+            if k < n:
+                log_w -= info.log_prob
+        self._hmc.check_numerics()
+        return float(self.lower_bound(log_w).mean())
 
     @staticmethod
-    def _get_lower_bound(log_weights):
-        """log-mean-exp over the leading (chain) axis, evaluation.py:167-172."""
-        max_log_weights = np.max(log_weights, axis=0)
-        offset_log_weights = np.mean(np.exp(log_weights - max_log_weights),
-                                     axis=0)
-        return np.log(offset_log_weights) + max_log_weights
+    def lower_bound(log_weights):
+        """log-mean-exp over the leading (chain) axis (evaluation.py:167-172);
+        accepts a device tensor or an array."""
+        if isinstance(log_weights, torch.Tensor):
+            return torch.logsumexp(log_weights.double(), 0) - math.log(
+                log_weights.shape[0])
+        w = np.asarray(log_weights, np.float64)
+        m = w.max(0)
+        return np.log(np.mean(np.exp(w - m), 0)) + m
+
+    _get_lower_bound = lower_bound

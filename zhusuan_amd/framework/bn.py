@@ -8,8 +8,7 @@ import torch
 
 from .. import distributions
 from ..distributions.base import as_tensor
-from .meta_bn import Local
-from .utils import Context
+from .meta_bn import active_frame
 
 __all__ = ['StochasticTensor', 'BayesianNet']
 
@@ -129,23 +128,18 @@ class _BayesianNet(object):
 
     def __init__(self):
         self._nodes = {}
-        try:
-            self._local_cxt = Local.get_context()
-        except RuntimeError:
-            self._local_cxt = None
-        if self._local_cxt:
-            self._meta_bn = self._local_cxt.meta_bn
-        else:
-            self._meta_bn = None
+        # built inside MetaBayesianNet.observe(): remember who runs the
+        # builder and what it declared observed (bn.py:319-347)
+        frame = active_frame()
+        self._owner = frame.owner if frame is not None else None
+        self._observed = frame.observed if frame is not None else {}
 
     @property
     def nodes(self):
         return self._nodes
 
     def _get_observation(self, name):
-        if self._local_cxt:
-            return self._local_cxt.observations.get(name, None)
-        return None
+        return self._observed.get(name)
 
     def stochastic(self, name, dist, **kwargs):
         """Add a stochastic node (bn.py:348-371)."""
@@ -207,22 +201,21 @@ class _BayesianNet(object):
         return self._nodes[name_or_names].cond_log_p
 
     def _log_joint(self):
-        """bn.py:454-465."""
-        if (self._meta_bn is None) or (self._meta_bn.log_joint is None):
-            ret = sum(node.cond_log_p for node in self._nodes.values()
-                      if isinstance(node, StochasticTensor))
-        elif callable(self._meta_bn.log_joint):
-            ret = self._meta_bn.log_joint(self)
-        else:
+        """The owner's `log_joint(bn)` if one was assigned, else the sum of
+        every stochastic node's conditional log-density (bn.py:454-465)."""
+        custom = None if self._owner is None else self._owner.log_joint
+        if custom is None:
+            return sum(node.cond_log_p for node in self._nodes.values()
+                       if isinstance(node, StochasticTensor))
+        if not callable(custom):
             raise TypeError(
                 "{}.log_joint is set to a non-callable instance: {}"
-                .format(self._meta_bn.__class__.__name__,
-                        repr(self._meta_bn.log_joint)))
-        return ret
+                .format(type(self._owner).__name__, repr(custom)))
+        return custom(self)
 
     def log_joint(self):
-        """Sum of all stochastic nodes' cond_log_p, or the user's
-        meta_bn.log_joint(bn); cached (bn.py:467-478)."""
+        """Evaluated once per BayesianNet (bn.py:467-478); adding a node
+        invalidates it."""
         if not hasattr(self, "_log_joint_cache"):
             self._log_joint_cache = self._log_joint()
         return self._log_joint_cache
@@ -308,7 +301,7 @@ class _BayesianNet(object):
         return self.stochastic(name, dist, n_samples=n_samples, **kwargs)
 
 
-class BayesianNet(_BayesianNet, Context):
+class BayesianNet(_BayesianNet):
     """bn.py:481-520 (the deprecated context-manager / `observed=` /
     `query()` API of :1191-1249 is out of scope)."""
 

@@ -1,70 +1,90 @@
-"""MetaBayesianNet: lazily re-runs the model builder under a set of
-observations.  Mirrors reference zhusuan/framework/meta_bn.py:21-148 -- this
-is how HMC re-evaluates the joint at a new q (hmc.py:412-416)."""
-import copy
-from functools import wraps
+"""MetaBayesianNet: a model builder plus its call arguments, re-run under a
+set of observations whenever a BayesianNet is needed.  Same surface as
+reference zhusuan/framework/meta_bn.py:29-148 (`MetaBayesianNet(f, args,
+kwargs, scope, reuse_variables)`, `.observe(**obs)`, assignable `.log_joint`,
+the `@meta_bayesian_net` decorator) -- this is how HMC re-evaluates the joint at
+a new state (hmc.py:412-416).
 
-from .utils import Context
+How a BayesianNet created inside the builder learns what is observed: a
+per-thread stack of observation frames.  `observe()` pushes (owner,
+observations) for the duration of the builder call; `BayesianNet()` reads the
+innermost frame (`active_frame`) when it is constructed."""
+import functools
+import threading
+from collections import namedtuple
+from contextlib import contextmanager
 
 __all__ = ['MetaBayesianNet', 'meta_bayesian_net']
 
+ObservationFrame = namedtuple('ObservationFrame', 'owner observed')
+_tls = threading.local()
 
-class Local(Context):
-    """meta_bn.py:21-26."""
 
-    def __getattr__(self, item):
-        return self.__dict__.get(item, None)
+def _frames():
+    stack = getattr(_tls, 'frames', None)
+    if stack is None:
+        stack = _tls.frames = []
+    return stack
 
-    def __setattr__(self, key, value):
-        self.__dict__[key] = value
+
+@contextmanager
+def _observing(owner, observed):
+    stack = _frames()
+    stack.append(ObservationFrame(owner, dict(observed)))
+    try:
+        yield
+    finally:
+        stack.pop()
+
+
+def active_frame():
+    """The innermost (owner, observed) frame of this thread, or None outside
+    of any `observe()` call."""
+    stack = _frames()
+    return stack[-1] if stack else None
 
 
 class MetaBayesianNet(object):
-    """meta_bn.py:29-106.  `scope` / `reuse_variables` are accepted for
-    signature compatibility; there are no TF variable scopes here, parameters
-    are plain device tensors owned by the caller."""
+    """`scope` / `reuse_variables` are accepted for signature compatibility
+    (meta_bn.py:49-63): there are no variable scopes here, parameters are
+    plain device tensors owned by the caller; asking for reuse without a scope
+    is still the reference's error."""
 
     def __init__(self, f, args=None, kwargs=None, scope=None,
                  reuse_variables=False):
         if reuse_variables and scope is None:
             raise ValueError("Cannot reuse tensorflow Variables when `scope` "
                              "is not provided.")
-        self._f = f
-        self._args = copy.copy(args) if args is not None else ()
-        self._kwargs = copy.copy(kwargs) if kwargs is not None else {}
-        self._scope = scope
-        self._reuse_variables = reuse_variables
-        self._log_joint = None
+        self._builder = f
+        self._call_args = tuple(args) if args else ()
+        self._call_kwargs = dict(kwargs) if kwargs else {}
+        self.scope = scope
+        self.reuse_variables = bool(reuse_variables)
+        self._joint_fn = None
 
-    @property
-    def log_joint(self):
-        """The log joint function of this model; may be overwritten with a
-        callable taking the BayesianNet (meta_bn.py:69-85)."""
-        return self._log_joint
+    # `meta_bn.log_joint = fn(bn)` replaces the default sum over stochastic
+    # nodes (meta_bn.py:69-85); None restores it
+    log_joint = property(lambda self: self._joint_fn)
 
     @log_joint.setter
-    def log_joint(self, value):
-        self._log_joint = value
+    def log_joint(self, fn):
+        self._joint_fn = fn
 
-    def _run_with_observations(self, func, observations):
-        with Local() as local_cxt:
-            local_cxt.observations = observations
-            local_cxt.meta_bn = self
-            return func(*self._args, **self._kwargs)
-
-    def observe(self, **kwargs):
-        """Build the BayesianNet with the given observations
-        (meta_bn.py:93-106)."""
-        return self._run_with_observations(self._f, kwargs)
+    def observe(self, **observed):
+        """Run the builder with `observed` (node name -> value) in force and
+        return the BayesianNet it built (meta_bn.py:93-106)."""
+        with _observing(self, observed):
+            return self._builder(*self._call_args, **self._call_kwargs)
 
 
 def meta_bayesian_net(scope=None, reuse_variables=False):
-    """Decorator turning a BayesianNet builder into a MetaBayesianNet factory
+    """`@meta_bayesian_net(...)`: calling the decorated builder returns a
+    MetaBayesianNet bound to the call's arguments instead of running it
     (meta_bn.py:109-148)."""
-    def wrapper(f):
-        @wraps(f)
-        def _wrapped(*args, **kwargs):
-            return MetaBayesianNet(f, args=args, kwargs=kwargs, scope=scope,
+    def decorate(builder):
+        @functools.wraps(builder)
+        def bind(*args, **kwargs):
+            return MetaBayesianNet(builder, args, kwargs, scope=scope,
                                    reuse_variables=reuse_variables)
-        return _wrapped
-    return wrapper
+        return bind
+    return decorate
