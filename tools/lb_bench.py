@@ -21,7 +21,19 @@ SPLITS = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 ws = torch.empty(SPLITS * C * (D + 1), device=dev) if SPLITS > 1 else None
 
 
+import ctypes, os  # noqa
+_fn = None
+if os.environ.get('LB_LIB'):          # A/B: a variant library instead of the product's
+    _fn = ctypes.CDLL(os.environ['LB_LIB']).zshmc_linear_bernoulli_log_lik
+    _fn.restype, _fn.argtypes = _capi.PROTOTYPES['zshmc_linear_bernoulli_log_lik']
+
+
 def run():
+    if _fn is not None:
+        rc = _fn(W.data_ptr(), X.data_ptr(), y.data_ptr(), C, N, D, ll.data_ptr(),
+                 g.data_ptr(), SPLITS, _capi.ptr(ws), s)
+        assert rc == 0
+        return
     _capi.call('zshmc_linear_bernoulli_log_lik', W.data_ptr(), X.data_ptr(),
                y.data_ptr(), C, N, D, ll.data_ptr(), g.data_ptr(), SPLITS,
                _capi.ptr(ws), s)

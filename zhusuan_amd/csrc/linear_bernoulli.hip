@@ -275,6 +275,9 @@ __device__ __forceinline__ void lds_dma_row(const float* src, uint32_t dst,
 //           "logits" are log(theta.phi) (multivariate.py:435-443 with
 //           normalize_logits = False): term = x*log(S), residual = x / S with
 //           the counts x[c, n] streamed from `yc` [C, N] (chain-major).
+#ifndef ZS_LB_BUF
+#define ZS_LB_BUF(D) ((D) == 128 ? 1 : 2)
+#endif
 template <int D, bool GRAD, int OP>
 __global__ __launch_bounds__(256, 1) void linear_bernoulli_kernel_v2(
     const float* __restrict__ W, const float* __restrict__ X,
@@ -287,8 +290,13 @@ __global__ __launch_bounds__(256, 1) void linear_bernoulli_kernel_v2(
   constexpr int HALF = D / 2;        // features per wave in phase 3
   constexpr int FB = HALF / 32;      // 32-wide feature blocks per half (1,2,4)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* __restrict__ sX = reinterpret_cast<float*>(smem);  // [2][kRows][LD]
-  float* __restrict__ sY = sX + 2 * kRows * LD;             // [2][kRows]
+  // X tile buffers: two (the DMA of tile t+1 runs under the compute of tile
+  // t) where only one workgroup fits a CU anyway; ONE for D = 128, where the
+  // smaller footprint (50 KB) lets a second workgroup share the CU and its
+  // MFMAs fill this one's bubbles -- DMA latency included (ZS_LB_BUF)
+  constexpr int kBuf = ZS_LB_BUF(D);
+  float* __restrict__ sX = reinterpret_cast<float*>(smem);  // [kBuf][kRows][LD]
+  float* __restrict__ sY = sX + kBuf * kRows * LD;          // [2][kRows]
   float* __restrict__ sR = sY + 2 * kRows;                  // [4][4][64][4]
 
   const int tid = threadIdx.x;
@@ -324,14 +332,28 @@ __global__ __launch_bounds__(256, 1) void linear_bernoulli_kernel_v2(
   constexpr int kDmaPer = KK >= 16 ? 1 : 16 / KK;
   const uint32_t sx_addr = (uint32_t)reinterpret_cast<uintptr_t>(sX);
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  auto dma_row = [&](int64_t n0, int buf, int j) {
+  // Row j of this wave's 16: all address arithmetic is scalar and cheap -- the
+  // tile's first row pointer and the last valid row offset are formed once per
+  // tile (tile_src); a row then costs one s_min, one 32-bit s_mul and a 64-bit
+  // add (ldx <= 256 and row < 64, so the element offset fits 32 bits).
+  const uint32_t dst_wave = __builtin_amdgcn_readfirstlane(
+      sx_addr + (uint32_t)(wave_u * 16 * LD * 4));
+  const int ldx32 = (int)ldx;
+  struct TileSrc {
+    const float* base;  // &X[n0, 0]
+    int last;           // min(N - 1 - n0, kRows - 1): rows past N re-read row N-1
+    uint32_t dst;       // LDS address of this wave's row 0 in the target buffer
+  };
+  auto tile_src = [&](int64_t n0, int buf) {
+    const int64_t left = N - 1 - n0;
+    return TileSrc{X + n0 * ldx, (int)(left < kRows - 1 ? left : kRows - 1),
+                   dst_wave + (uint32_t)(buf * kRows * LD * 4)};
+  };
+  auto dma_row = [&](const TileSrc& t, int j) {
     const int row = wave_u * 16 + j;
-    int64_t nr = n0 + row;
-    nr = nr < N ? nr : N - 1;
-    const float* src = X + nr * ldx;
-    const uint32_t dst = __builtin_amdgcn_readfirstlane(
-        sx_addr + (uint32_t)((buf * kRows + row) * LD * 4));
-    lds_dma_row<kDmaB>(src, dst, (uint32_t)lane);
+    const int r = row < t.last ? row : t.last;
+    lds_dma_row<kDmaB>(t.base + r * ldx32, t.dst + (uint32_t)(j * LD * 4),
+                       (uint32_t)lane);
   };
   float yr = 0.f;
 
@@ -355,8 +377,11 @@ __global__ __launch_bounds__(256, 1) void linear_bernoulli_kernel_v2(
     ll += (int64_t)blockIdx.y * C;
     if (GRAD) gW += (int64_t)blockIdx.y * C * ldw;
   }
+  {
+    const TileSrc t0 = tile_src(tile_begin * kRows, 0);
 #pragma unroll
-  for (int j = 0; j < 16; ++j) dma_row(tile_begin * kRows, 0, j);
+    for (int j = 0; j < 16; ++j) dma_row(t0, j);
+  }
   if (OP == 0 && tid < kRows) {
     const int64_t nr = tile_begin * kRows + tid;
     sY[tid] = nr < N ? y[nr] : 0.f;
@@ -368,12 +393,26 @@ __global__ __launch_bounds__(256, 1) void linear_bernoulli_kernel_v2(
   float* __restrict__ sr_mine = sR + (wave * 4 * 64 + lane) * 4;
   const float* __restrict__ sr_sib = sR + ((wave ^ 1) * 4 * 64 + lane) * 4;
 
+#ifdef ZS_LB_TIMING  // debug: per-phase shader clocks of wave 0 of block 0
+  long long tacc[6] = {0, 0, 0, 0, 0, 0};
+  long long tmark = clock64();
+#define ZS_LB_MARK(i)                        \
+  {                                          \
+    const long long _t = clock64();          \
+    tacc[i] += _t - tmark;                   \
+    tmark = _t;                              \
+  }
+#else
+#define ZS_LB_MARK(i)
+#endif
   for (int64_t tile = tile_begin; tile < n_tiles; ++tile) {
-    const int buf = (int)((tile - tile_begin) & 1);
-    const float* __restrict__ xb = sX + buf * kRows * LD;
+    const int buf = (int)((tile - tile_begin) & 1);       // sY slot
+    const int xbuf = kBuf == 2 ? buf : 0;                 // sX slot
+    const float* __restrict__ xb = sX + xbuf * kRows * LD;
     const bool more = tile + 1 < n_tiles;
     // rows of tile+1 (the last tile re-streams itself: clamped rows, unused)
     const int64_t n_next = (more ? tile + 1 : tile) * kRows;
+    const TileSrc tnext = tile_src(n_next, kBuf == 2 ? (xbuf ^ 1) : 0);
     if (OP == 0 && tid < kRows) {
       const int64_t nr = n_next + tid;
       yr = nr < N ? y[nr] : 0.f;
@@ -409,19 +448,29 @@ __global__ __launch_bounds__(256, 1) void linear_bernoulli_kernel_v2(
       for (int kk = 0; kk < KK; ++kk) {
         f4 an = av;
         if (kk + 1 < KK) an = *reinterpret_cast<const f4*>(arow + (kk + 1) * 8);
-        if (kk % kDmaStep == 0) {
+        if (kBuf == 2 && kk % kDmaStep == 0) {
 #pragma unroll
           for (int j = 0; j < kDmaPer; ++j)
-            dma_row(n_next, buf ^ 1, (kk / kDmaStep) * kDmaPer + j);
+            dma_row(tnext, (kk / kDmaStep) * kDmaPer + j);
         }
+#ifndef ZS_LB_NO_SCHED
+        // keep the next step's LDS read and the DMA row IN FRONT of this
+        // step's MFMAs (hipcc otherwise reuses the A registers and sinks the
+        // read behind the last MFMA, exposing the LDS latency every step)
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (int m = 0; m < 4; ++m)
           S = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], wreg[kk * 4 + m], S, 0,
                                                    0, 0);
+#ifndef ZS_LB_NO_SCHED
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         av = an;
       }
     }
 
+    ZS_LB_MARK(0)  // head + phase 1
     // ---- residual on the accumulator layout ----------------------------------
     // lane holds chain i = a*32 + lo, rows n = b*32 + (r&3) + 8*(r>>2) + 4*hi.
     // Bernoulli._log_prob (univariate.py:398-403):
@@ -465,6 +514,7 @@ __global__ __launch_bounds__(256, 1) void linear_bernoulli_kernel_v2(
       // group g+1 (VALU) is issued under the MFMAs of group g ----------------
 #pragma unroll
       for (int r = 0; r < 4; ++r) residual(r);
+      ZS_LB_MARK(1)  // first residual group
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         V xv[4];
@@ -483,7 +533,9 @@ __global__ __launch_bounds__(256, 1) void linear_bernoulli_kernel_v2(
           for (int r = 0; r < 4; ++r) residual((g + 1) * 4 + r);
         }
       }
+      ZS_LB_MARK(2)  // phase 3a
       __syncthreads();  // the sibling's residuals are in LDS
+      ZS_LB_MARK(3)  // barrier 1
       // ---- phase 3b: the sibling's rows, A from LDS ----------------------------
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -502,10 +554,26 @@ __global__ __launch_bounds__(256, 1) void linear_bernoulli_kernel_v2(
 #pragma unroll
       for (int r = 0; r < 16; ++r) residual(r);
     }
+    ZS_LB_MARK(4)  // phase 3b
     if (OP == 0 && tid < kRows) sY[(buf ^ 1) * kRows + tid] = yr;
+    if (kBuf == 1) {
+      __syncthreads();  // every wave is done reading the only X buffer
+      if (more) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) dma_row(tnext, j);
+      }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA rows landed
     __syncthreads();  // tile+1 published; this buffer free for tile+2
+    ZS_LB_MARK(5)  // DMA wait + barrier 2
   }
+#ifdef ZS_LB_TIMING
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && GRAD) {
+    for (int i = 0; i < 6; ++i) gW[i] = (float)tacc[i];
+    gW[6] = (float)(n_tiles - tile_begin);
+  }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && GRAD) return;
+#endif
 
   // ---- epilogue -----------------------------------------------------------
   // G[t][r]: chain = c0 + a*32 + (r&3) + 8*(r>>2) + 4*hi,
@@ -559,7 +627,8 @@ static int launch_v2(const float* W, const float* X, const float* y,
                      hipStream_t s, int n_splits = 1,
                      float* workspace = nullptr) {
   constexpr int LD = D + 4;
-  const size_t lds = (size_t)(2 * 64 * LD + 2 * 64 + 4 * 16 * 64) * sizeof(float);
+  const size_t lds =
+      (size_t)(ZS_LB_BUF(D) * 64 * LD + 2 * 64 + 4 * 16 * 64) * sizeof(float);
   static bool attr2 = false;
   if (!attr2) {
     hipError_t e = hipFuncSetAttribute(
