@@ -26,7 +26,11 @@ for _ in range(2):
             g.data_ptr(), 1, None, s)
     assert rc == 0
 torch.cuda.synchronize()
-t = g[0, :7].cpu().numpy()
+tall = g[0, :32].cpu().numpy().reshape(4, 8)
+print('per-wave clocks/tile by phase (waves (a,b) = 00 01 10 11):')
+for w in range(4):
+    print('  wave %d: ' % w + ' '.join('%7.0f' % (v / tall[w, 6]) for v in tall[w, :6]))
+t = tall[0, :7]
 names = ['head+phase1', 'residual g0', 'phase 3a', 'barrier 1', 'phase 3b',
          'dma wait+barrier 2']
 tiles = t[6]

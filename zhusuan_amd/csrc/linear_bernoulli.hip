@@ -328,7 +328,6 @@ __global__ __launch_bounds__(256, 1) void linear_bernoulli_kernel_v2(
   // vmcnt(0)` in front of the tile barrier lands them.
   constexpr int kDmaB = D / 16;  // bytes per lane per row: 16 (D=256), 8, 4
   // 16 rows per wave and tile, spread over the KK phase-1 steps
-  constexpr int kDmaStep = KK >= 16 ? KK / 16 : 1;
   constexpr int kDmaPer = KK >= 16 ? 1 : 16 / KK;
   const uint32_t sx_addr = (uint32_t)reinterpret_cast<uintptr_t>(sX);
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -448,24 +447,18 @@ __global__ __launch_bounds__(256, 1) void linear_bernoulli_kernel_v2(
       for (int kk = 0; kk < KK; ++kk) {
         f4 an = av;
         if (kk + 1 < KK) an = *reinterpret_cast<const f4*>(arow + (kk + 1) * 8);
-        if (kBuf == 2 && kk % kDmaStep == 0) {
+        // one DMA row of tile t+1 per step over the first 16 steps (KK >= 16)
+        // or kDmaPer rows per step (KK = 8): issued as early as the buffer is
+        // free, in front of the step's MFMAs
+        if (kBuf == 2 && KK >= 16 && kk < 16) dma_row(tnext, kk);
+        if (kBuf == 2 && KK < 16) {
 #pragma unroll
-          for (int j = 0; j < kDmaPer; ++j)
-            dma_row(tnext, (kk / kDmaStep) * kDmaPer + j);
+          for (int j = 0; j < kDmaPer; ++j) dma_row(tnext, kk * kDmaPer + j);
         }
-#ifndef ZS_LB_NO_SCHED
-        // keep the next step's LDS read and the DMA row IN FRONT of this
-        // step's MFMAs (hipcc otherwise reuses the A registers and sinks the
-        // read behind the last MFMA, exposing the LDS latency every step)
-        __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
         for (int m = 0; m < 4; ++m)
           S = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], wreg[kk * 4 + m], S, 0,
                                                    0, 0);
-#ifndef ZS_LB_NO_SCHED
-        __builtin_amdgcn_sched_barrier(0);
-#endif
         av = an;
       }
     }
@@ -531,6 +524,18 @@ __global__ __launch_bounds__(256, 1) void linear_bernoulli_kernel_v2(
         if (g + 1 < 4) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) residual((g + 1) * 4 + r);
+#ifndef ZS_LB_NO_SGB
+          // A wave issues in order: left alone, hipcc emits the 4*FB MFMAs of
+          // this group back to back and the ~60 VALU / transcendental ops of the
+          // next group's residual after them, where only the last MFMA is
+          // left to hide them.  Ask for one MFMA, then a slice of the VALU.
+#pragma unroll
+          for (int i = 0; i < 4 * FB; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 16 / FB, 0);       // VALU
+            __builtin_amdgcn_sched_group_barrier(0x400, (2 + FB) / FB, 0);  // trans
+          }
+#endif
         }
       }
       ZS_LB_MARK(2)  // phase 3a
@@ -568,9 +573,9 @@ __global__ __launch_bounds__(256, 1) void linear_bernoulli_kernel_v2(
     ZS_LB_MARK(5)  // DMA wait + barrier 2
   }
 #ifdef ZS_LB_TIMING
-  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && GRAD) {
-    for (int i = 0; i < 6; ++i) gW[i] = (float)tacc[i];
-    gW[6] = (float)(n_tiles - tile_begin);
+  if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && GRAD) {
+    for (int i = 0; i < 6; ++i) gW[wave * 8 + i] = (float)tacc[i];
+    gW[wave * 8 + 6] = (float)(n_tiles - tile_begin);
   }
   if (blockIdx.x == 0 && blockIdx.y == 0 && GRAD) return;
 #endif
