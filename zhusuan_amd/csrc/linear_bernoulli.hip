@@ -276,10 +276,13 @@ __device__ __forceinline__ void lds_dma_row(const float* src, uint32_t dst,
 //           normalize_logits = False): term = x*log(S), residual = x / S with
 //           the counts x[c, n] streamed from `yc` [C, N] (chain-major).
 #ifndef ZS_LB_BUF
-#define ZS_LB_BUF(D) ((D) == 128 ? 1 : 2)
+#define ZS_LB_BUF(D) ((D) <= 128 ? 1 : 2)
+#endif
+#ifndef ZS_LB_MINW  // min waves per SIMD: D = 64 fits three workgroups per CU
+#define ZS_LB_MINW(D) ((D) == 64 ? 3 : 1)
 #endif
 template <int D, bool GRAD, int OP>
-__global__ __launch_bounds__(256, 1) void linear_bernoulli_kernel_v2(
+__global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2(
     const float* __restrict__ W, const float* __restrict__ X,
     const float* __restrict__ y, const float* __restrict__ yc,
     int64_t yc_rows, int64_t C, int64_t N, int64_t ldw, int64_t ldx,
@@ -291,9 +294,9 @@ __global__ __launch_bounds__(256, 1) void linear_bernoulli_kernel_v2(
   constexpr int FB = HALF / 32;      // 32-wide feature blocks per half (1,2,4)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // X tile buffers: two (the DMA of tile t+1 runs under the compute of tile
-  // t) where only one workgroup fits a CU anyway; ONE for D = 128, where the
-  // smaller footprint (50 KB) lets a second workgroup share the CU and its
-  // MFMAs fill this one's bubbles -- DMA latency included (ZS_LB_BUF)
+  // t) where only one workgroup fits a CU anyway; ONE for D <= 128, where the
+  // smaller footprint (50 KB / 34 KB) lets a second (third) workgroup share
+  // the CU and its MFMAs fill this one's bubbles -- DMA latency included
   constexpr int kBuf = ZS_LB_BUF(D);
   float* __restrict__ sX = reinterpret_cast<float*>(smem);  // [kBuf][kRows][LD]
   float* __restrict__ sY = sX + kBuf * kRows * LD;          // [2][kRows]
