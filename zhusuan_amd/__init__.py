@@ -9,7 +9,7 @@ from . import diagnostics, distributions, evaluation, framework
 from .framework import (BayesianNet, MetaBayesianNet, StochasticTensor,
                         meta_bayesian_net)
 from .distributions import linear_logits, log_mixture
-from ._ops import gathered_dot
+from ._ops import gathered_dot, clear_caches
 from .evaluation import AIS
 from .hmc import (HMC, HMCInfo, InvalidArgumentError, placeholder,
                   deferred)
@@ -22,4 +22,4 @@ __version__ = '0.1.0'
 __all__ = ['SGMCMC', 'SGLD', 'PSGLD', 'SGHMC', 'SGNHT', 'AIS', 'evaluation', 'HMC', 'HMCInfo', 'InvalidArgumentError', 'placeholder', 'deferred', 'Session',
            'BayesianNet', 'MetaBayesianNet', 'StochasticTensor',
            'meta_bayesian_net', 'distributions', 'diagnostics', 'framework',
-           'merge_dicts', 'set_random_seed', 'linear_logits', 'log_mixture', 'gathered_dot']
+           'merge_dicts', 'set_random_seed', 'linear_logits', 'log_mixture', 'gathered_dot', 'clear_caches']

@@ -255,6 +255,17 @@ class GatheredDot(torch.autograd.Function):
         return gu, None, gv, None
 
 
+def clear_caches():
+    """Drop the single-entry operand caches (padded design matrix, padded
+    phi^T, CSR views of index lists).  Each entry pins the tensor it was built
+    from so that an address is never mistaken for another tensor's; call this
+    to release those references (e.g. a 1 GB design matrix) when a model is
+    done."""
+    _x_cache.clear()
+    _phi_cache.clear()
+    _csr_cache.clear()
+
+
 def gathered_dot(u, select_u, v, select_v):
     """`reduce_sum(gather(u, select_u, axis=-2) * gather(v, select_v, axis=-2),
     axis=-1)`: u [..., n, D], v [..., m, D] with equal leading (chain) axes,
