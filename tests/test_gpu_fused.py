@@ -315,3 +315,58 @@ np.savez(sys.argv[1], **out)
         res[stage] = np.load(path)
     for k in res['1'].files:
         np.testing.assert_array_equal(res['1'][k], res['0'][k], err_msg=k)
+
+
+def test_steady_nonadaptive_phase_is_a_pure_elision(monkeypatch):
+    """With the adapt flag off the reference re-assigns
+    step_size <- exp(log_epsilon_bar) every iteration (hmc.py:108-110).  After
+    two such updates the sampler state is at its fixed point and the front-end
+    stops launching the update kernel / collecting the mean acceptance: states,
+    HMCInfo and step size must be bit-identical to a run that never elides,
+    also across a switch back to adaptation and across set_state."""
+    import torch
+    import zhusuan_amd as zs
+    from zhusuan_amd import hmc as hmc_mod
+    dev = torch.device('cuda', 0)
+    C, D = 3000, 512
+    logstd = torch.linspace(-1, 1, D, device=dev)
+
+    def run(elide):
+        monkeypatch.setattr(hmc_mod._FusedDiagNormalPlan, 'can_skip_acc', elide)
+
+        @zs.meta_bayesian_net()
+        def model():
+            bn = zs.BayesianNet()
+            bn.normal('x', torch.zeros(D, device=dev), logstd=logstd,
+                      n_samples=C, group_ndims=1)
+            return bn
+        flag = zs.placeholder(bool)
+        h = zs.HMC(step_size=0.05, n_leapfrogs=4, adapt_step_size=flag,
+                   seed=3)
+        x = torch.zeros(C, D, device=dev)
+        op, info = h.sample(model(), {}, {'x': x})
+        assert h.plan_kind == 'fused_diag_normal'
+        out = []
+        launches = []
+        schedule = [True] * 6 + [False] * 7 + [True] * 3 + [False] * 4
+        for i, a in enumerate(schedule):
+            if i == 18:                       # checkpoint / resume mid-way
+                h.set_state(h.get_state())
+            op.run(feed_dict={flag: a})
+            launches.append(h._plan.collect_acc)
+            out.append((x.clone(), info.acceptance_rate.clone(),
+                        info.log_prob.clone(),
+                        float(info.updated_step_size)))
+        return out, launches
+
+    ref, l_ref = run(False)
+    got, l_got = run(True)
+    assert all(l_ref)
+    # elided exactly from the third consecutive non-adaptive iteration on
+    assert l_got == [True] * 8 + [False] * 5 + [True] * 5 + [False] * 0 + \
+        [True] * 2 or l_got.count(False) >= 5
+    assert l_got[:8] == [True] * 8 and l_got[8:13] == [False] * 5
+    assert l_got[13:18] == [True] * 5            # adaptation back on, then 2 updates
+    for (xa, aa, la, sa), (xb, ab, lb, sb) in zip(ref, got):
+        assert torch.equal(xa, xb) and torch.equal(aa, ab) and torch.equal(la, lb)
+        assert sa == sb

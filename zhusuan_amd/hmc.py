@@ -203,6 +203,7 @@ class HMC(object):
         self.n_leapfrogs = int(n_leapfrogs)
         self.target_acceptance_rate = float(target_acceptance_rate)
         self.t = 0                                     # hmc.py:264
+        self._nonadaptive_streak = 0
         self.adapt_step_size = adapt_step_size
         self.gamma, self.t0, self.kappa = float(gamma), float(t0), float(kappa)
         if adapt_mass is not None:
@@ -222,7 +223,8 @@ class HMC(object):
         self._pending_check = False
         # list collecting (start, end) HIP-event pairs around the fused
         # transition kernel of every run while it is set (bench.py)
-        self.kernel_timer = None
+        self.kernel_timer = None         # bench.py: list collecting (start, end) events
+        self.kernel_timer_stride = 1      # time every n-th fused launch
 
     # -- sample(): builds the execution plan (hmc.py:382-522) -------------
     def sample(self, meta_bn, observed, latent):
@@ -338,9 +340,23 @@ class HMC(object):
                 eps_host = self._search_step_size(plan, stream, sh)
         self.last_init = init
 
+        # With the adapt flag off, hmc.py:108-110 re-assigns
+        # step_size <- exp(log_epsilon_bar) every iteration: after two such
+        # updates in a row the whole sampler state is at its fixed point, so
+        # neither the mean acceptance (and its all-reduce) nor the update
+        # kernel has anything left to do -- the transition is then exactly one
+        # kernel launch.  (ST_MEAN_ACCEPT, a diagnostic slot, keeps the value of
+        # the last update launch.)
+        steady = (self.adapt_step_size is not None and not adapt_ss and
+                  not init and self._nonadaptive_streak >= 2 and
+                  getattr(plan, 'can_skip_acc', False))
+        plan.collect_acc = not steady
+
         plan.transition(t, eps_host, stream)              # leapfrog + MH
 
-        if self.adapt_step_size is not None:              # hmc.py:501-505
+        if self.adapt_step_size is not None and not steady:   # hmc.py:501-505
+            self._nonadaptive_streak = 0 if (adapt_ss or init) else \
+                self._nonadaptive_streak + 1
             if sh is not None:
                 sh.all_reduce_sum(plan.acc_sum)
             _capi.call('zshmc_stepsize_update', plan.state.data_ptr(),
@@ -415,6 +431,7 @@ class HMC(object):
 
     def set_state(self, state):
         plan = self._plan
+        self._nonadaptive_streak = 0
         self.t = int(state['t'])
         self.seed = int(state['seed'])
         plan.state.copy_(state['state'])
@@ -508,6 +525,8 @@ class _PlanBase(object):
 class _FusedDiagNormalPlan(_PlanBase):
     """One kernel per transition (csrc/hmc_fused_normal.hip)."""
     kind = 'fused_diag_normal'
+    can_skip_acc = True      # the kernel skips its acceptance sum on acc_sum=NULL
+    collect_acc = True
 
     def __init__(self, hmc, names, values, chain_shape, device, mean, logstd):
         super(_FusedDiagNormalPlan, self).__init__(hmc, names, values,
@@ -529,7 +548,8 @@ class _FusedDiagNormalPlan(_PlanBase):
             self.hamiltonian.data_ptr() if info else None,
             self.orig_log_prob.data_ptr() if info else None,
             self.log_prob.data_ptr() if info else None,
-            self.acc_sum.data_ptr(), self.flags.data_ptr(), stream)
+            self.acc_sum.data_ptr() if (self.collect_acc or not commit)
+            else None, self.flags.data_ptr(), stream)
 
     def begin_search(self, t, stream):
         pass
@@ -541,7 +561,8 @@ class _FusedDiagNormalPlan(_PlanBase):
     def transition(self, t, eps_host, stream):
         self.last_t = t
         timer = self.hmc.kernel_timer
-        if timer is None:
+        self._timer_tick = getattr(self, '_timer_tick', 0) + 1
+        if timer is None or self._timer_tick % self.hmc.kernel_timer_stride:
             self._launch(t, eps_host, 1, self.hmc.n_leapfrogs, stream)
             return
         # bench.py: HIP events on the launch stream around the fused kernel
