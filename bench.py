@@ -211,6 +211,33 @@ def main():
     total_chains = C * world
     value = total_chains * L * args.steps / elapsed
 
+    # the other adaptation mode, for a like-for-like reading across N: the
+    # headline region runs adaptation off at N = 1 (config 2) and on at N > 1
+    # (config 4: all-reduce + update kernel in the loop)
+    saved = hmc.get_state()
+    other_feed = {adapt: not adapt_timed}
+    for _ in range(5):
+        sample_op.run(feed_dict=other_feed, sync=False)
+    barrier()
+    t1 = time.perf_counter()
+    n_other = max(20, min(args.steps, 100))
+    for _ in range(n_other):
+        sample_op.run(feed_dict=other_feed, sync=False)
+    barrier()
+    other_elapsed = time.perf_counter() - t1
+    if world > 1:
+        tt = torch.tensor([other_elapsed], dtype=torch.float64,
+                          device=dev if backend == 'nccl' else 'cpu')
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        other_elapsed = float(tt.item())
+    hmc.set_state(saved)
+    other_mode = {
+        'adaptation': 'off' if adapt_timed else 'on',
+        'ms_per_step': other_elapsed / n_other * 1e3,
+        'value': total_chains * L * n_other / other_elapsed,
+        'steps': n_other,
+    }
+
     # ESS/s (reference estimator, zhusuan/diagnostics.py:17-64) over EVERY
     # chain of this rank: record n_draws snapshots of the state on the device,
     # batched ESS kernel (csrc/diagnostics.hip), minimum over dimensions per
@@ -277,6 +304,7 @@ def main():
             },
             'elem_leapfrog_steps_per_sec': value * D,
             'mean_acceptance': acc_mean,
+            'other_adaptation_mode': other_mode,
             'step_size': eps,
             'roofline': {
                 'bound': 'hbm',
