@@ -177,3 +177,14 @@ def test_pmf_hmc_fused_vs_dense_vs_oracle(env):
     # the chain moves towards the data: likelihood term improves
     assert float(runs[True][3].log_prob.mean()) > float(
         pmf_ref.log_joint(u0, v, su, sv, r, alpha_u, alpha_v, alpha_pred).mean())
+
+
+def test_empty_pair_list(env):
+    zs, torch, dev = env
+    u = torch.randn(3, 4, 5, device=dev, requires_grad=True)
+    v = torch.randn(3, 6, 5, device=dev, requires_grad=True)
+    e = torch.zeros(0, dtype=torch.int64, device=dev)
+    out = zs.gathered_dot(u, e, v, e)
+    assert tuple(out.shape) == (3, 0)
+    out.sum().backward()
+    assert not u.grad.any() and not v.grad.any()

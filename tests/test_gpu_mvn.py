@@ -206,3 +206,12 @@ def test_hmc_with_mvn_prior_recovers_covariance(env):
     s = x.cpu().numpy()
     np.testing.assert_allclose(s.mean(0), mean, atol=0.08)
     np.testing.assert_allclose(np.cov(s.T), cov, atol=0.12)
+
+
+def test_zero_rows(env):
+    zs, torch, dev = env
+    d = zs.distributions.MultivariateNormalCholesky(
+        torch.zeros(3, device=dev), torch.eye(3, device=dev))
+    lp = d.log_prob(torch.zeros(0, 3, device=dev))
+    assert tuple(lp.shape) == (0,)
+    assert tuple(d.sample(0).shape) == (0, 3)

@@ -228,11 +228,13 @@ class GatheredDot(torch.autograd.Function):
         E = csr_u[0].numel()
         out = torch.empty(tuple(u.shape[:-2]) + (E,), dtype=_F32,
                           device=u.device)
+        ctx.save_for_backward(uf, vf, *csr_u, *csr_v)
+        ctx.dims = (K, n_u, n_v, E, D, tuple(u.shape), tuple(v.shape))
+        if out.numel() == 0:          # no pairs (or no chains): nothing to launch
+            return out
         _capi.call('zshmc_gather_dot', uf.data_ptr(), vf.data_ptr(),
                    csr_u[0].data_ptr(), csr_v[0].data_ptr(), K, n_u, n_v, E, D,
                    out.data_ptr(), _capi.current_stream())
-        ctx.save_for_backward(uf, vf, *csr_u, *csr_v)
-        ctx.dims = (K, n_u, n_v, E, D, tuple(u.shape), tuple(v.shape))
         return out
 
     @staticmethod
@@ -242,6 +244,11 @@ class GatheredDot(torch.autograd.Function):
         g = gout.to(_F32).contiguous()
         stream = _capi.current_stream()
         gu = gv = None
+        if E == 0 or K == 0:
+            return (torch.zeros(us, dtype=_F32, device=g.device)
+                    if ctx.needs_input_grad[0] else None, None,
+                    torch.zeros(vs, dtype=_F32, device=g.device)
+                    if ctx.needs_input_grad[2] else None, None)
         if ctx.needs_input_grad[0]:
             gu = torch.empty(us, dtype=_F32, device=g.device)
             _capi.call('zshmc_gather_dot_grad', vf.data_ptr(), g.data_ptr(),
