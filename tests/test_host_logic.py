@@ -182,3 +182,70 @@ def test_product_ess_matches_reference_fixture(golden_dir):
         np.testing.assert_allclose(
             zs.diagnostics.effective_sample_size_batch(s, burn_in=0),
             fx[case + '_ess1d'], rtol=1e-6)
+
+
+def test_observation_frames_nest_unwind_and_are_per_thread():
+    """MetaBayesianNet.observe pushes an (owner, observed) frame for the
+    duration of the builder call: nested models see their own frame, an
+    exception unwinds it, other threads see none."""
+    import threading
+    from zhusuan_amd.framework.meta_bn import active_frame
+
+    @zs.meta_bayesian_net()
+    def inner():
+        bn = zs.BayesianNet()
+        bn.stochastic('z', _FakeDist())
+        return bn
+
+    seen = {}
+
+    @zs.meta_bayesian_net()
+    def outer(fail):
+        bn = zs.BayesianNet()
+        bn.stochastic('x', _FakeDist())
+        seen['inner'] = inner().observe(z=torch.ones(2))
+        seen['frame_after_inner'] = active_frame().observed
+        if fail:
+            raise RuntimeError('boom')
+        t = threading.Thread(target=lambda: seen.update(other=active_frame()))
+        t.start()
+        t.join()
+        return bn
+
+    assert active_frame() is None
+    bn = outer(False).observe(x=torch.zeros(2))
+    assert bn['x'].is_observed() and 'z' not in bn.nodes
+    assert seen['inner']['z'].is_observed()
+    assert set(seen['frame_after_inner']) == {'x'}
+    assert seen['other'] is None and active_frame() is None
+    with pytest.raises(RuntimeError, match='boom'):
+        outer(True).observe(x=torch.zeros(2))
+    assert active_frame() is None
+    # a BayesianNet built outside any observe() has no owner: default joint
+    free = zs.BayesianNet()
+    free.stochastic('a', _FakeDist())
+    assert not free['a'].is_observed()
+
+
+def test_placeholder_deferred_and_session_fetch_structure():
+    from collections import namedtuple
+    flag = zs.placeholder(bool, name='flag')
+    with pytest.raises(ValueError, match='must feed'):
+        flag.value
+    n = zs.placeholder(int, default=3)
+    assert n.value == 3
+    n.feed(5)
+    assert n.value == 5
+    from zhusuan_amd.hmc import bind_feed
+    bind_feed({n: 7, 'not a placeholder': 1})
+    assert n.value == 7
+    d = zs.deferred(lambda: n.value * 2)
+    assert d.value == 14
+    Info = namedtuple('Info', 'q alpha')
+    fetched = zs.Session().run(
+        [Info(q={'x': torch.ones(2)}, alpha=[torch.zeros(1), 4]), torch.ones(1)])
+    assert isinstance(fetched[0], Info)
+    np.testing.assert_array_equal(fetched[0].q['x'], np.ones(2))
+    assert fetched[0].alpha[1] == 4 and isinstance(fetched[0].alpha[0], np.ndarray)
+    single = zs.Session().run(Info(q=torch.ones(1), alpha=None))
+    assert isinstance(single, Info) and single.alpha is None
