@@ -398,11 +398,16 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2
 #ifdef ZS_LB_TIMING  // debug: per-phase shader clocks of wave 0 of block 0
   long long tacc[6] = {0, 0, 0, 0, 0, 0};
   long long tmark = clock64();
-#define ZS_LB_MARK(i)                        \
-  {                                          \
-    const long long _t = clock64();          \
-    tacc[i] += _t - tmark;                   \
-    tmark = _t;                              \
+  // fenced: nothing is scheduled across a mark, and the accumulators are
+  // forced complete (an MFMA is asynchronous) so that a phase owns its MFMAs
+#define ZS_LB_MARK(i)                                        \
+  {                                                          \
+    __builtin_amdgcn_sched_barrier(0);                       \
+    asm volatile("" ::"v"(S[0]), "v"(G[0][0]), "v"(G[FB - 1][15])); \
+    const long long _t = clock64();                          \
+    tacc[i] += _t - tmark;                                   \
+    tmark = _t;                                              \
+    __builtin_amdgcn_sched_barrier(0);                       \
   }
 #else
 #define ZS_LB_MARK(i)
