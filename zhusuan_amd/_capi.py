@@ -7,8 +7,8 @@ Build the library with ``python -c "import __graft_entry__ as g; g.build()"``
 """
 import ctypes
 import os
-from ctypes import (POINTER, c_char_p, c_double, c_float, c_int, c_int32,
-                    c_int64, c_uint8, c_uint32, c_uint64, c_void_p)
+from ctypes import (c_char_p, c_float, c_int, c_int64, c_uint32, c_uint64,
+                    c_void_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libzshmc.so')

@@ -24,7 +24,6 @@ Two execution plans, chosen in `sample()`:
              kernels of csrc/hmc_generic.hip.
 Both use the same RNG counters and the same on-device adaptation state.
 """
-import math
 
 import torch
 
