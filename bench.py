@@ -85,6 +85,40 @@ def cpu_baseline(n_data, n_leapfrogs, budget_s):
     }
 
 
+def cpu_baseline_parallel(n_data, n_leapfrogs, budget_s):
+    """The same transition as a chain-fused C + OpenMP restatement
+    (oracle/c/hmc_diag_normal_port.c, held to the NumPy oracle by
+    tests/test_oracle_c_port.py) on ALL host cores: the strongest CPU
+    formulation of the path, next to the op-for-op NumPy port above."""
+    from oracle import hmc_c
+    threads = hmc_c.max_threads()
+    C = 256 * max(threads, 1)
+    logstd = np.linspace(-1.0, 1.0, n_data).astype(np.float32)
+    mean = np.zeros(n_data, np.float32)
+    q = (np.random.RandomState(0).normal(size=(C, n_data)) *
+         np.exp(logstd)).astype(np.float32)
+    hmc_c.step(q, mean, logstd, n_leapfrogs, 0.14, 1, 0, want_info=False)
+    iters = 0
+    t0 = time.perf_counter()
+    while True:
+        hmc_c.step(q, mean, logstd, n_leapfrogs, 0.14, 1, iters + 1,
+                   want_info=False)
+        iters += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or iters >= 2000:
+            break
+    return {
+        'value': C * n_leapfrogs * iters / el,
+        'unit': 'chain-leapfrog-steps/s',
+        'cores': threads,
+        'kind': 'port',
+        'sample': '%d chains x %d latents, L=%d, %d transitions in %.1f s '
+                  '(C + OpenMP restatement, one chain\'s trajectory kept in '
+                  'cache, %d threads)' % (C, n_data, n_leapfrogs, iters, el,
+                                          threads),
+    }
+
+
 def main():
     args = parse()
     import torch
@@ -333,6 +367,11 @@ def main():
             out['ess'] = ess
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(D, L, args.cpu_seconds)
+            try:
+                out['cpu_baseline_parallel'] = cpu_baseline_parallel(
+                    D, L, min(args.cpu_seconds, 8.0))
+            except Exception as e:           # no gcc / OpenMP on the box
+                out['cpu_baseline_parallel'] = {'error': str(e)[:200]}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -6,6 +6,11 @@ It exists to CHECK the HIP path.  Only ``tests/``, ``__graft_entry__.smoke()``
 and ``bench.py``'s ``cpu_baseline`` leg may import it; nothing under
 ``zhusuan_amd/`` does (tests/test_no_oracle_in_product.py enforces that).
 
+A second, independent restatement of the diag-Normal transition in C + OpenMP
+(oracle/c/hmc_diag_normal_port.c, wrapper oracle/hmc_c.py) serves as the
+all-cores CPU baseline of bench.py; it is held to this NumPy oracle by
+tests/test_oracle_c_port.py.
+
 Pinning status (see DESIGN.md section "Oracle"):
   * log_prob closed forms (Normal/Bernoulli/Categorical/UnnormalizedMultinomial)
     -- PINNED against the reference's own test vectors (scipy oracle), see

@@ -23,7 +23,9 @@ def test_product_never_touches_oracle():
 def test_bench_uses_oracle_only_in_cpu_baseline():
     src = open(os.path.join(ROOT, 'bench.py')).read()
     uses = [m.start() for m in re.finditer(r'from oracle', src)]
-    assert len(uses) == 1
+    # the NumPy port (cpu_baseline) and the C + OpenMP port
+    # (cpu_baseline_parallel): both inside the CPU-baseline functions only
+    assert len(uses) == 2
     start = src.index('def cpu_baseline')
     end = src.index('def main')
-    assert start < uses[0] < end
+    assert all(start < u < end for u in uses)
