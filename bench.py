@@ -135,23 +135,25 @@ def main():
                 'bench.py --gpus %d must be launched with torch.distributed.run '
                 '--nproc-per-node %d' % (args.gpus, args.gpus))
     assert torch.cuda.is_available(), 'bench.py needs an MI355X'
-    # ZSHMC_DIST_BACKEND=gloo lets two ranks share one GPU (functional test of
-    # the N > 1 path on a 1-GPU box); the real runs use RCCL ("nccl")
-    backend = os.environ.get('ZSHMC_DIST_BACKEND', 'nccl')
+    # One process per GPU.  torch.distributed (a CPU/gloo group) only
+    # bootstraps: it carries the RCCL unique id, the barriers around the timed
+    # region and the max-over-ranks of the wall time.  The data path's one
+    # collective per transition goes straight to RCCL over xGMI through the
+    # C-ABI (zshmc_comm_*).  ZSHMC_DIST_BACKEND=gloo keeps everything on gloo
+    # so that two ranks can share one GPU (functional test on a 1-GPU box;
+    # RCCL refuses two ranks on one device).
+    backend = os.environ.get('ZSHMC_DIST_BACKEND', 'rccl')
     local_dev = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_dev)
     dev = torch.device('cuda', local_dev)
     sharding = None
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if backend == 'nccl':
-            dist.init_process_group(backend='nccl', rank=rank,
-                                    world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend=backend, rank=rank,
-                                    world_size=world)
-        sharding = ChainSharding(chain_offset=rank * args.chains_per_gpu,
-                                 n_chains_global=world * args.chains_per_gpu)
+        dist.init_process_group(backend='gloo', rank=rank, world_size=world)
+        sharding = ChainSharding(
+            chain_offset=rank * args.chains_per_gpu,
+            n_chains_global=world * args.chains_per_gpu,
+            backend='rccl' if backend == 'rccl' else 'torch')
 
     C, D, L = args.chains_per_gpu, args.n_data, args.leapfrogs
     logstd = torch.linspace(-1.0, 1.0, D, device=dev)     # std = e^[-1, 1]
@@ -196,8 +198,10 @@ def main():
         sample_op.run(feed_dict=feed, sync=False)
     barrier()
     # HIP events on the launch stream around every 4th fused launch of the
-    # timed region (two event records per launch cost ~3 us of stream time)
-    hmc.kernel_timer, hmc.kernel_timer_stride = [], 4
+    # timed region (two event records per launch cost ~3 us of stream time);
+    # around every launch when that would leave fewer than ~25 samples
+    stride = 4 if args.steps >= 100 else 1
+    hmc.kernel_timer, hmc.kernel_timer_stride = [], stride
     t0 = time.perf_counter()
     for _ in range(args.steps):
         sample_op.run(feed_dict=feed, sync=False)
@@ -205,8 +209,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_events, hmc.kernel_timer = hmc.kernel_timer, None
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64,
-                          device=dev if backend == 'nccl' else 'cpu')
+        tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     hmc.check_numerics()
@@ -216,8 +219,9 @@ def main():
     kern_ms_region = sum(a.elapsed_time(b) for a, b in kernel_events) / max(
         1, len(kernel_events))
 
-    # the same kernel alone, back to back (no update kernel in between)
+    # the same kernel alone, back to back
     plan = hmc._plan
+    plan.collect_acc = False
     stream = torch.cuda.current_stream().cuda_stream
     reps = max(20, min(args.steps, 200))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(
@@ -231,20 +235,29 @@ def main():
         plan._launch(t_iter + 6 + i, None, 1, L, stream)
     e1.record()
     torch.cuda.synchronize()
-    plan.acc_sum.zero_()
     kern_ms_alone = e0.elapsed_time(e1) / reps
-    kern_ms = kern_ms_region
+    # a roofline is quoted from >= 20 timed launches: the in-region events, or
+    # (with --steps < 20) the back-to-back loop, and the line says which
+    enough = len(kernel_events) >= 20
+    kern_ms = kern_ms_region if enough else kern_ms_alone
     hmc.t = t_iter + 6 + reps
     algo_bytes = ALGO_BYTES_PER_ELEM * C * D
     from zhusuan_amd import _capi
-    kernel_name = _capi.load().zshmc_fused_kernel_name(D, 0).decode()
+    kernel_name = _capi.load().zshmc_fused_kernel_name(D, 0, 1).decode()
     achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
-    traffic = None
+    # HBM bytes per launch from the PMC counters: NOT collected in this run
+    # (counters need their own rocprofv3 passes, tools/profile.sh); the value
+    # is the one committed with the profile summaries and says so
+    traffic = traffic_source = None
     pmc_path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     if os.path.exists(pmc_path):
         try:
             with open(pmc_path) as f:
-                traffic = json.load(f).get('hbm_bytes_per_launch')
+                pmc = json.load(f)
+            traffic = pmc.get('hbm_bytes_per_launch')
+            traffic_source = 'profiles/pmc_traffic.json (%s; separate rocprofv3 ' \
+                '--pmc passes of this command, not this run)' % pmc.get(
+                    'round', 'r01')
         except Exception:
             traffic = None
 
@@ -267,8 +280,7 @@ def main():
     barrier()
     other_elapsed = time.perf_counter() - t1
     if world > 1:
-        tt = torch.tensor([other_elapsed], dtype=torch.float64,
-                          device=dev if backend == 'nccl' else 'cpu')
+        tt = torch.tensor([other_elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         other_elapsed = float(tt.item())
     hmc.set_state(saved)
@@ -340,9 +352,11 @@ def main():
                 'n_latents': D,
                 'n_leapfrogs': L,
                 'parallelism': 'chains sharded over %d GPU(s); %s' % (
-                    world, 'one RCCL all-reduce (1 double) per transition'
-                    if world > 1 else 'no collective'),
+                    world, 'one ncclAllReduce (2 doubles) per transition on '
+                    'the compute stream' if world > 1 else 'no collective'),
             },
+            'rccl_ranks': 0 if sharding is None else sharding.rccl_ranks,
+            'launches_per_transition': 1,
             'elem_leapfrog_steps_per_sec': value * D,
             'mean_acceptance': acc_mean,
             'other_adaptation_mode': other_mode,
@@ -355,11 +369,16 @@ def main():
                 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBPS,
                 'traffic': traffic,
+                'traffic_source': traffic_source,
                 'kernel_ms': kern_ms,
                 'kernel_ms_back_to_back': kern_ms_alone,
                 'kernel_launches_timed': len(kernel_events),
-                'kernel_timing': 'HIP events on the launch stream around every 4th '
-                                 'fused launch inside the timed region',
+                'kernel_timing': (
+                    'HIP events on the launch stream around every %s fused '
+                    'launch inside the timed region' % (
+                        '4th' if stride == 4 else 'single')) if enough else (
+                    'back-to-back loop of %d launches after the timed region '
+                    '(fewer than 20 launches were timed inside it)' % reps),
                 'algorithmic_bytes_per_launch': algo_bytes,
             },
         }

@@ -31,13 +31,14 @@
 extern "C" {
 #endif
 
-#define ZSHMC_VERSION 100 /* 0.1.0 */
+#define ZSHMC_VERSION 200 /* 0.2.0 */
 
 /* status codes */
 #define ZSHMC_OK 0
 #define ZSHMC_ERR_BAD_ARG 1
 #define ZSHMC_ERR_HIP 2
 #define ZSHMC_ERR_UNSUPPORTED 3
+#define ZSHMC_ERR_COMM 4 /* RCCL missing or an RCCL call failed */
 
 /* bits of the device-side `flags` word */
 #define ZSHMC_FLAG_OLD_LOGPROB_NONFINITE 1u /* hmc.py:51-53 check_numerics */
@@ -65,10 +66,12 @@ int zshmc_version(void);
 int64_t zshmc_fused_max_n_data(void);
 
 /* Name of the kernel zshmc_hmc_diag_normal_step dispatches for 16-B aligned
- * buffers of this shape ("hmc_diag_normal_ring_kernel<NCH,K,mass>" or
- * "hmc_diag_normal_kernel<G,NCH,vec,mass>"), so that benchmarks and profiler
- * summaries can name the kernel they measured.  Static storage, thread-local. */
-const char* zshmc_fused_kernel_name(int64_t n_data, int has_mass);
+ * buffers of this shape ("hmc_diag_normal_ring_kernel<NCH,K,mass,*,zero_mean>"
+ * or "hmc_diag_normal_kernel<G,NCH,vec,mass>"), so that benchmarks and profiler
+ * summaries can name the kernel they measured.  zero_mean: mean == NULL.
+ * Static storage, thread-local. */
+const char* zshmc_fused_kernel_name(int64_t n_data, int has_mass,
+                                    int zero_mean);
 
 /* ------------------------------------------------------------------------
  * Fused HMC transition for a diagonal-Normal log-joint
@@ -87,29 +90,99 @@ const char* zshmc_fused_kernel_name(int64_t n_data, int has_mass);
  *   framework/bn.py:454-465 log_joint of the single stochastic node.
  *
  *   q               [n_chains, n_data]  in/out (written only where accepted)
- *   mean, logstd    [n_data]
+ *   mean, logstd    [n_data]; mean may be NULL (= zeros: the subtraction and
+ *                   re-addition are compiled out)
  *   mass            [n_data] or NULL (= ones; hmc.py:456)
- *   step_size_dev   device scalar, or NULL to use step_size_host
+ *   step_size_host  used when link->state == NULL
  *   chain_offset    global index of local chain 0 (RNG counter)
  *   commit          1: full transition.  0: dry run for _init_step_size
- *                   (hmc.py:308-345): nothing but acc_sum/flags is written
+ *                   (hmc.py:308-345): nothing but the statistics is written
  *   acceptance_rate, orig_hamiltonian, hamiltonian, orig_log_prob, log_prob
  *                   [n_chains] each, any may be NULL  (HMCInfo, hmc.py:162-201)
- *   acc_sum         device double; the call ADDS sum_c acceptance_rate_c
- *                   (caller zeroes it; feeds hmc.py:377 reduce_mean)
  *   flags           device word, OR-ed with ZSHMC_FLAG_* ; may be NULL
+ *   link            HOST pointer (read during the call), see below
+ *
+ * zshmc_adapt_link ties consecutive transitions together so that an ADAPTIVE
+ * transition (hmc.py:501-505: StepsizeTuner.tune on the mean acceptance over
+ * ALL chains, :377) is still ONE launch and, when chains are sharded over
+ * GPUs, ONE collective:
+ *   - the launch publishes  stats[0] = sum_c acceptance_rate_c  of its own
+ *     chains and stats[1] = 1 if some chain started from a non-finite
+ *     log-prob (else 0).  The sum is order-fixed: per-workgroup partials in
+ *     `workspace`, added in index order by the workgroup that retires last
+ *     (bit-identical from run to run; no floating-point atomics);
+ *   - the caller may all-reduce stats[0..1] (+ the 2*D mass statistics it
+ *     keeps behind them) in ONE message (zshmc_comm_all_reduce_sum);
+ *   - the NEXT launch, told `pending` = ZSHMC_PEND_ADAPT / _HOLD (the previous
+ *     run's adapt_step_size flag was true / false, hmc.py:92-110), applies
+ *     that dual-averaging update to state[] in its prologue -- every
+ *     workgroup computes the same scalars from stats[0] -- integrates with
+ *     the updated step size, and its last-retiring workgroup writes the
+ *     updated state[] back.  zshmc_stepsize_flush applies a pending update
+ *     without a transition (before the host reads state[], e.g. for
+ *     HMCInfo.updated_step_size).
+ *   state == NULL: no on-device step size (step_size_host is used; pending
+ *   must be ZSHMC_PEND_NONE).  stats == NULL: no statistics are collected
+ *   (the steady non-adaptive phase).  workspace: ZSHMC_LINK_WORKSPACE_BYTES
+ *   of device memory, zeroed once by the caller, private to one sampler.
  */
+#define ZSHMC_PEND_NONE 0
+#define ZSHMC_PEND_ADAPT 1 /* hmc.py:92-106 */
+#define ZSHMC_PEND_HOLD 2  /* hmc.py:108-110: step_size <- exp(log_epsilon_bar) */
+#define ZSHMC_STATS_WORDS 2 /* doubles: sum of acceptance, non-finite flag */
+#define ZSHMC_LINK_WORKSPACE_BYTES (64 + 8 * 4096)
+typedef struct zshmc_adapt_link {
+  float* state;            /* device, ZSHMC_STATE_WORDS floats, or NULL */
+  double* stats;           /* device, ZSHMC_STATS_WORDS doubles, or NULL */
+  void* workspace;         /* device, ZSHMC_LINK_WORKSPACE_BYTES */
+  int64_t n_chains_global; /* chains over all ranks (the mean of hmc.py:377) */
+  int32_t pending;         /* ZSHMC_PEND_* : update owed by the previous run */
+  int32_t fresh_start;     /* that run had if_initialize_step_size (:466-467) */
+  float used_step_size;    /* step size that run used if it came from the
+                              search (hmc.py:308-345); NaN otherwise */
+  float delta, gamma, t0, kappa; /* StepsizeTuner parameters, hmc.py:67-78 */
+  float mu;                /* 10 * initial step size (hmc.py:79, sic) */
+} zshmc_adapt_link;
+
 int zshmc_hmc_diag_normal_step(
     float* q, const float* mean, const float* logstd, const float* mass,
-    const float* step_size_dev, float step_size_host,
+    float step_size_host,
     int64_t n_chains, int64_t n_data, int64_t chain_offset,
     int n_leapfrogs, uint64_t seed, uint32_t iteration, int commit,
     float* acceptance_rate, float* orig_hamiltonian, float* hamiltonian,
     float* orig_log_prob, float* log_prob,
-    double* acc_sum, uint32_t* flags, void* stream);
+    uint32_t* flags, const zshmc_adapt_link* link, void* stream);
+
+/* Apply link->pending to link->state from link->stats[0] (one tiny launch);
+ * the caller then resets its pending marker to ZSHMC_PEND_NONE. */
+int zshmc_stepsize_flush(const zshmc_adapt_link* link, void* stream);
 
 /* ------------------------------------------------------------------------
- * Dual-averaging step-size update, one tiny launch, state stays on device.
+ * Chain sharding over the GPUs of one node: one communicator per
+ * process (one process per GPU), RCCL over xGMI, collectives enqueued on the
+ * caller's stream.  librccl.so is opened at run time (the copy already in the
+ * process if there is one), so single-GPU use has no RCCL dependency.
+ *   zshmc_comm_unique_id  rank 0 fills 128 bytes; the caller distributes them
+ *                         (any side channel) to the other ranks
+ *   zshmc_comm_create     ncclCommInitRank on the current device
+ *   zshmc_comm_all_reduce_sum
+ *                         in-place sum of `count` device doubles: the ONE
+ *                         message per transition -- stats[0..1] and, when mass
+ *                         adaptation is collecting, the 2*D column sums of
+ *                         hmc.py:138,143 laid out behind them
+ */
+#define ZSHMC_COMM_ID_BYTES 128
+int zshmc_comm_unique_id(void* id_host);
+int zshmc_comm_create(const void* id_host, int rank, int world_size,
+                      void** comm_out);
+int zshmc_comm_all_reduce_sum(void* comm, double* buf, int64_t count,
+                              void* stream);
+int zshmc_comm_world_size(void* comm);
+int zshmc_comm_destroy(void* comm);
+
+/* ------------------------------------------------------------------------
+ * Dual-averaging step-size update as its own launch (the generic plan, whose
+ * acceptance sum comes from zshmc_mh_accept), state stays on device.
  * Replaces StepsizeTuner.tune (hmc.py:89-112) + HMC._adapt_step_size
  * (hmc.py:375-380).  mean acceptance = *acc_sum / n_chains_global.
  *   adapt        this run's value of the adapt_step_size flag

@@ -47,8 +47,9 @@ static void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
 }
 
 static void box_muller(uint32_t xa, uint32_t xb, float* z0, float* z1) {
-  const double u1 = (double)(((float)(xa >> 8) + 1.0f) * (1.0f / 16777216.0f));
-  const double u2 = (double)((float)(xb >> 8) * (1.0f / 16777216.0f));
+  /* oracle/philox.py: bm_radius_uniform / bm_angle_fraction */
+  const double u1 = (double)(float)(((double)(float)xa + 1.0) * 0x1p-32);
+  const double u2 = (double)(xb >> 9) * 0x1p-23;
   const double r = sqrt(-2.0 * log(u1));
   const double ang = 2.0 * 3.14159265358979323846 * u2;
   *z0 = (float)(r * cos(ang));

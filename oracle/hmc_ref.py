@@ -219,6 +219,10 @@ class HMC(object):
         self.mass_collect_iters = int(mass_collect_iters)
         self.mass_decay = F32(mass_decay)
         self.seed = seed
+        # test hook: a given diagonal mass (list of arrays, one per latent)
+        # instead of ones / the EWMV estimate -- what the C-ABI's `mass`
+        # argument of the fused transition is
+        self.fixed_mass = None
 
     # -- set-up part of sample(), :412-456 ---------------------------------
     def sample(self, log_joint, grad, latent, chain_offset=0,
@@ -238,7 +242,9 @@ class HMC(object):
             for q in self.q]
         self.data_axes = [list(range(self.n_chain_dims, len(s)))
                           for s in self.data_shapes]
-        self.chain_offset = int(chain_offset)
+        # scalar (contiguous shard) or an array of global chain indices
+        self.chain_offset = (int(chain_offset) if np.ndim(chain_offset) == 0
+                             else np.asarray(chain_offset, dtype=np.uint64))
         n_local = int(np.prod(chain_shape, dtype=np.int64))
         self.n_chains_global = int(n_chains_global or n_local)
         self._allreduce = allreduce_sum or (lambda a: a)
@@ -324,6 +330,9 @@ class HMC(object):
             mass = self._adapt_mass(new_t, adapt_mass)
         else:
             mass = [np.ones(s, F32) for s in self.data_shapes]
+        if self.fixed_mass is not None:
+            mass = [np.asarray(m, F32).reshape(s)
+                    for m, s in zip(self.fixed_mass, self.data_shapes)]
 
         p = random_momentum(self.seed, it, [q.shape for q in self.q], mass,
                             self.n_chain_dims, self.chain_offset)   # :458

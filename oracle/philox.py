@@ -62,14 +62,29 @@ def u01_open_low(x):
             np.float32(1.0 / 16777216.0))
 
 
+def bm_radius_uniform(x):
+    """uint32 -> float32 in (0, 1] for the Box-Muller radius, as the device's
+    v_cvt_f32_u32 + v_fma (csrc/philox.h): float32(x) (round to nearest even)
+    then (y + 1) * 2^-32 with a single rounding."""
+    y = np.asarray(x, dtype=np.uint32).astype(np.float32).astype(np.float64)
+    return ((y + 1.0) * 2.0 ** -32).astype(np.float32)
+
+
+def bm_angle_fraction(x):
+    """uint32 -> the Box-Muller angle in revolutions, [0, 1): the top 23 bits
+    (the device places them in the mantissa of a float in [1, 2) and lets
+    v_sin / v_cos drop the integer revolution)."""
+    return ((np.asarray(x, dtype=np.uint32) >> np.uint32(9)).astype(np.float64)
+            * 2.0 ** -23)
+
+
 def box_muller(xa, xb):
     """Two uint32 words -> two N(0,1) float32 (cos branch, sin branch).
     Evaluated in float64 and rounded once: this is the 'exact' value the
     device's v_log/v_sqrt/v_sin/v_cos path approximates to a few 1e-7."""
-    u1 = u01_open_low(xa).astype(np.float64)
-    u2 = u01(xb).astype(np.float64)
+    u1 = bm_radius_uniform(xa).astype(np.float64)
     r = np.sqrt(-2.0 * np.log(u1))
-    ang = 2.0 * np.pi * u2
+    ang = 2.0 * np.pi * bm_angle_fraction(xb)
     return ((r * np.cos(ang)).astype(np.float32),
             (r * np.sin(ang)).astype(np.float32))
 
@@ -77,6 +92,18 @@ def box_muller(xa, xb):
 def seed_key(seed):
     seed = int(seed) & 0xFFFFFFFFFFFFFFFF
     return seed & 0xFFFFFFFF, seed >> 32
+
+
+def _chain_ids(n_chains, chain_offset):
+    """Global chain indices of a shard: a contiguous range starting at the
+    scalar `chain_offset`, or an explicit array (an arbitrary subset of a
+    larger run: the counter is keyed by the GLOBAL chain index, so the oracle
+    can reproduce any chains of a 65 536-chain device run exactly)."""
+    if np.ndim(chain_offset) == 0:
+        return np.arange(n_chains, dtype=np.uint64) + np.uint64(chain_offset)
+    ids = np.asarray(chain_offset, dtype=np.uint64).reshape(-1)
+    assert ids.shape[0] == n_chains, (ids.shape, n_chains)
+    return ids
 
 
 def normal_chain_major(seed, iteration, n_chains, n_data, chain_offset=0,
@@ -87,7 +114,7 @@ def normal_chain_major(seed, iteration, n_chains, n_data, chain_offset=0,
     k0, k1 = seed_key(seed)
     n_groups = (n_data + 3) // 4
     g = np.arange(n_groups, dtype=np.uint64)[None, :]
-    c = (np.arange(n_chains, dtype=np.uint64) + np.uint64(chain_offset))[:, None]
+    c = _chain_ids(n_chains, chain_offset)[:, None]
     x0, x1, x2, x3 = philox4x32_10(g, c, np.uint64(iteration & 0xFFFFFFFF),
                                    np.uint64(stream | (latent_id << 8)),
                                    k0, k1)
@@ -101,7 +128,7 @@ def uniform_per_chain(seed, iteration, n_chains, chain_offset=0,
                       stream=STREAM_MH):
     """U[0,1) float32 per chain from counter (0, chain, iteration, stream)."""
     k0, k1 = seed_key(seed)
-    c = np.arange(n_chains, dtype=np.uint64) + np.uint64(chain_offset)
+    c = _chain_ids(n_chains, chain_offset)
     x0, _, _, _ = philox4x32_10(np.uint64(0), c,
                                 np.uint64(iteration & 0xFFFFFFFF),
                                 np.uint64(stream), k0, k1)

@@ -48,6 +48,53 @@ def gpu_sampler(zs, torch, mean, logstd, q0, generic=False, group_ndims=None,
     return hmc, op, info, x
 
 
+class FusedKernel(object):
+    """The fused diag-Normal transition straight through the C-ABI
+    (zshmc_hmc_diag_normal_step + zshmc_adapt_link), with the buffers a
+    sampler would own."""
+
+    def __init__(self, torch, C, D, dev=None, n_chains_global=None):
+        from zhusuan_amd import _capi
+        self.torch, self.capi = torch, _capi
+        self.C, self.D = C, D
+        dev = dev or torch.device('cuda', 0)
+        self.dev = dev
+        self.info = [torch.zeros(C, device=dev) for _ in range(5)]
+        self.stats = torch.zeros(_capi.STATS_WORDS, dtype=torch.float64,
+                                 device=dev)
+        self.workspace = torch.zeros(_capi.LINK_WORKSPACE_BYTES,
+                                     dtype=torch.uint8, device=dev)
+        self.flags = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.state = torch.zeros(_capi.STATE_WORDS, device=dev)
+        self.n_chains_global = n_chains_global or C
+
+    def link(self, use_state=False, pending=0, fresh=0, used=float('nan'),
+             delta=0.8, gamma=0.05, t0=100.0, kappa=0.75, mu=0.5,
+             collect=True):
+        c = self.capi
+        k = c.AdaptLink()
+        k.state = self.state.data_ptr() if use_state else None
+        k.stats = self.stats.data_ptr() if collect else None
+        k.workspace = self.workspace.data_ptr()
+        k.n_chains_global = self.n_chains_global
+        k.pending, k.fresh_start, k.used_step_size = pending, fresh, used
+        k.delta, k.gamma, k.t0, k.kappa, k.mu = delta, gamma, t0, kappa, mu
+        return k
+
+    def step(self, q, mean, logstd, mass, eps, L, seed, iteration,
+             chain_offset=0, commit=1, link=None, want_info=True):
+        import ctypes
+        c, torch = self.capi, self.torch
+        link = link if link is not None else self.link()
+        ptrs = [x.data_ptr() if want_info else None for x in self.info]
+        c.call('zshmc_hmc_diag_normal_step', q.data_ptr(),
+               None if mean is None else mean.data_ptr(), logstd.data_ptr(),
+               None if mass is None else mass.data_ptr(), float(eps),
+               q.shape[0], self.D, chain_offset, L, seed, iteration, commit,
+               *ptrs, self.flags.data_ptr(), ctypes.byref(link),
+               torch.cuda.current_stream().cuda_stream)
+
+
 def compare_transition(info, x_gpu, rinfo, x_ref, ref, lp_tol=None):
     """Per-chain comparison of one transition.  Chains whose accept decision
     is numerically borderline (|u - acc| tiny) may legitimately flip between

@@ -15,6 +15,7 @@ def _header_functions():
     src = open(HEADER).read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
     src = re.sub(r'^\s*#.*$', '', src, flags=re.M)
+    src = re.sub(r'typedef struct \w+ \{.*?\} \w+;', '', src, flags=re.S)
     out = {}
     for m in re.finditer(
             r'([A-Za-z_][\w\s\*]*?)\b(zshmc_\w+)\s*\(([^;{]*?)\)\s*;', src):
@@ -30,6 +31,26 @@ def lib():
     g.build()
     from zhusuan_amd import _capi
     return _capi.load()
+
+
+def test_adapt_link_layout_matches_header():
+    """The ctypes mirror of zshmc_adapt_link has the header's fields in the
+    header's order (and therefore its layout: both follow the C ABI)."""
+    from zhusuan_amd import _capi
+    src = open(HEADER).read()
+    body = re.search(r'typedef struct zshmc_adapt_link \{(.*?)\} zshmc_adapt_link;',
+                     src, re.S).group(1)
+    body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+    names = []
+    for decl in body.split(';'):
+        decl = decl.strip()
+        if not decl:
+            continue
+        parts = [p.strip().lstrip('*') for p in decl.split(',')]
+        names.append(parts[0].split()[-1].lstrip('*'))
+        names.extend(parts[1:])
+    assert names == [f[0] for f in _capi.AdaptLink._fields_], names
+    assert ctypes.sizeof(_capi.AdaptLink) == 3 * 8 + 8 + 2 * 4 + 6 * 4
 
 
 def test_header_declares_functions():
@@ -56,7 +77,10 @@ def test_ctypes_table_matches_header(lib):
         for decl, ct in zip([a.strip() for a in args.split(',')] if nargs
                             else [], argtypes):
             is_ptr = '*' in decl
-            assert is_ptr == (ct is ctypes.c_void_p), (name, decl, ct)
+            ct_ptr = ct is ctypes.c_void_p or issubclass(ct, ctypes._Pointer)
+            assert is_ptr == ct_ptr, (name, decl, ct)
+            if 'zshmc_adapt_link' in decl:
+                assert ct is ctypes.POINTER(_capi.AdaptLink), (name, decl)
             if not is_ptr:
                 kinds = {'float': ctypes.c_float, 'int64_t': ctypes.c_int64,
                          'uint64_t': ctypes.c_uint64,
@@ -66,7 +90,7 @@ def test_ctypes_table_matches_header(lib):
 
 
 def test_version_and_limits_callable_without_gpu(lib):
-    assert lib.zshmc_version() == 100
+    assert lib.zshmc_version() == 200
     assert lib.zshmc_fused_max_n_data() == 2048
     assert lib.zshmc_last_error() is not None
 
@@ -75,10 +99,18 @@ def test_bad_arguments_are_rejected_before_any_launch(lib):
     """Argument validation happens on the host, so it works without a GPU."""
     from zhusuan_amd import _capi
     rc = lib.zshmc_hmc_diag_normal_step(
-        None, None, None, None, None, 0.1, 4, 4, 0, 1, 0, 0, 1, None, None,
+        None, None, None, None, 0.1, 4, 4, 0, 1, 0, 0, 1, None, None,
         None, None, None, None, None, None)
     assert rc == 1
     assert 'null' in _capi.last_error()
+    # a pending step-size update without a state block to apply it to
+    link = _capi.AdaptLink(pending=_capi.PEND_ADAPT, n_chains_global=4)
+    rc = lib.zshmc_hmc_diag_normal_step(
+        ctypes.c_void_p(16), None, ctypes.c_void_p(16), None, 0.1, 4, 4, 0, 1,
+        0, 0, 1, None, None, None, None, None, None, ctypes.byref(link), None)
+    assert rc == 1 and 'pending' in _capi.last_error()
+    rc = lib.zshmc_comm_all_reduce_sum(None, None, 0, None)
+    assert rc == 1
     rc = lib.zshmc_state_set(ctypes.c_void_p(8), 99, 0.0, None)
     assert rc == 1 and 'out of range' in _capi.last_error()
 

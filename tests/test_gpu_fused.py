@@ -7,8 +7,8 @@ chain energies to ~2e-5*|H|, acceptance to ~1e-4*|H|, accepted states to
 import numpy as np
 import pytest
 
-from helpers import (compare_transition, gpu_sampler, make_diag_problem,
-                     ref_sampler)
+from helpers import (FusedKernel, compare_transition, gpu_sampler,
+                     make_diag_problem, ref_sampler)
 
 pytestmark = pytest.mark.gpu
 
@@ -88,24 +88,20 @@ def test_deterministic_and_shard_invariant(env):
     chain offsets reproduces the full run bit for bit (RNG is keyed by the
     global chain index)."""
     zs, torch = env
-    from zhusuan_amd import _capi
     C, D, L = 512, 96, 6
     mean, logstd, q0 = make_diag_problem(C, D, seed=1)
     dev = torch.device('cuda', 0)
 
+    mean_t = torch.tensor(mean, device=dev)
+    logstd_t = torch.tensor(logstd, device=dev)
+
     def run(q_np, offset):
         q = torch.tensor(q_np, device=dev)
-        n = q.shape[0]
-        acc = torch.zeros(n, device=dev)
-        acc_sum = torch.zeros(1, dtype=torch.float64, device=dev)
-        _capi.call('zshmc_hmc_diag_normal_step', q.data_ptr(),
-                   torch.tensor(mean, device=dev).data_ptr(),
-                   torch.tensor(logstd, device=dev).data_ptr(), None, None,
-                   0.15, n, D, offset, L, 777, 3, 1, acc.data_ptr(), None,
-                   None, None, None, acc_sum.data_ptr(), None,
-                   _capi.current_stream())
+        k = FusedKernel(torch, q.shape[0], D, dev)
+        k.step(q, mean_t, logstd_t, None, 0.15, L, 777, 3, chain_offset=offset)
         torch.cuda.synchronize()
-        return q.cpu().numpy(), acc.cpu().numpy(), float(acc_sum.item())
+        return (q.cpu().numpy(), k.info[0].cpu().numpy(),
+                float(k.stats[0].item()))
 
     qa, acca, sa = run(q0, 0)
     qb, accb, sb = run(q0, 0)
@@ -282,7 +278,8 @@ def test_ring_kernel_staged_and_unstaged_paths_agree(tmp_path):
     script = r'''
 import sys, numpy as np, torch
 sys.path.insert(0, %r)
-from zhusuan_amd import _capi
+sys.path.insert(0, %r)
+from helpers import FusedKernel
 dev = torch.device('cuda', 0)
 out = {}
 for C, D, mass in ((3001, 1024, False), (777, 516, True), (310000, 1024, False)):
@@ -292,21 +289,18 @@ for C, D, mass in ((3001, 1024, False), (777, 516, True), (310000, 1024, False))
     m = torch.exp(-2 * logstd) if mass else None
     q = (torch.randn(min(C, 4096), D, generator=g).repeat((C + 4095) // 4096, 1)[:C]
          * torch.exp(logstd.cpu()) + mean.cpu()).to(dev)
-    info = [torch.zeros(C, device=dev) for _ in range(5)]
-    acc_sum = torch.zeros(1, dtype=torch.float64, device=dev)
-    flags = torch.zeros(1, dtype=torch.int32, device=dev)
+    k = FusedKernel(torch, C, D, dev)
+    sums = []
     for t in range(2):
-        _capi.call('zshmc_hmc_diag_normal_step', q.data_ptr(), mean.data_ptr(),
-                   logstd.data_ptr(), None if m is None else m.data_ptr(), None,
-                   0.14, C, D, 7, 5, 99, t, 1, *[x.data_ptr() for x in info],
-                   acc_sum.data_ptr(), flags.data_ptr(),
-                   torch.cuda.current_stream().cuda_stream)
+        k.step(q, mean, logstd, m, 0.14, 5, 99, t, chain_offset=7)
+        sums.append(k.stats[:1].clone())
     torch.cuda.synchronize()
     h = torch.cat([q.reshape(-1)[::97].double().cumsum(0)[-1:]] +
-                  [x.double().sum().reshape(1) for x in info] + [acc_sum]).cpu().numpy()
+                  [x.double().sum().reshape(1) for x in k.info] + sums).cpu().numpy()
     out['%%d_%%d' %% (C, D)] = h
 np.savez(sys.argv[1], **out)
-''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+       os.path.dirname(os.path.abspath(__file__)))
     res = {}
     for stage in ('1', '0'):
         path = str(tmp_path / ('stage%s.npz' % stage))
@@ -370,3 +364,59 @@ def test_steady_nonadaptive_phase_is_a_pure_elision(monkeypatch):
     for (xa, aa, la, sa), (xb, ab, lb, sb) in zip(ref, got):
         assert torch.equal(xa, xb) and torch.equal(aa, ab) and torch.equal(la, lb)
         assert sa == sb
+
+
+def test_fused_plan_follows_fed_and_updated_parameters(env):
+    """A single-Normal model whose parameters are read from fed placeholders
+    (what lntm_mcem.py:164-169 does with eta_mean / eta_logstd) or updated in
+    place between runs must keep sampling the CURRENT target: the fused plan
+    re-resolves the parameters every run, exactly as the generic plan
+    re-evaluates the model function (SURVEY section 7 "no stale log-prob
+    caching")."""
+    zs, torch = env
+    dev = torch.device('cuda', 0)
+    C, D = 300, 260
+    rng = np.random.RandomState(0)
+    means = [rng.normal(size=D).astype(np.float32) * s for s in (0.0, 1.0, 3.0)]
+    logstd0 = rng.uniform(-0.5, 0.5, size=D).astype(np.float32)
+    std_var = torch.tensor(np.exp(logstd0), device=dev)     # a "Variable"
+
+    def build(generic):
+        mean_ph = zs.placeholder(torch.float32, name='mean')
+
+        @zs.meta_bayesian_net()
+        def model():
+            bn = zs.BayesianNet()
+            bn.normal('x', mean_ph.value, std=std_var, n_samples=C,
+                      group_ndims=1)
+            return bn
+        mean_ph.feed(means[0], dev)
+        x = torch.zeros(C, D, device=dev)
+        h = zs.HMC(step_size=0.12, n_leapfrogs=4, seed=21)
+        m = model()
+        target = (lambda obs: m.observe(**obs).log_joint()) if generic else m
+        op, info = h.sample(target, {}, {'x': x})
+        return h, op, info, x, mean_ph
+
+    hf, opf, inf_f, xf, ph_f = build(False)
+    hg, opg, inf_g, xg, ph_g = build(True)
+    assert hf.plan_kind == 'fused_diag_normal' and hg.plan_kind == 'generic'
+    for it in range(9):
+        if it == 6:
+            std_var.mul_(1.5)             # in-place update of a parameter
+        feed_f = {ph_f: means[it // 3]}
+        feed_g = {ph_g: means[it // 3]}
+        opf.run(feed_dict=feed_f)
+        opg.run(feed_dict=feed_g)
+        # same stream, same target: the two plans agree chain by chain
+        np.testing.assert_allclose(inf_f.orig_log_prob.cpu().numpy(),
+                                   inf_g.orig_log_prob.cpu().numpy(),
+                                   rtol=2e-5, atol=2e-3)
+        np.testing.assert_allclose(inf_f.acceptance_rate.cpu().numpy(),
+                                   inf_g.acceptance_rate.cpu().numpy(),
+                                   atol=2e-3)
+        same = torch.isclose(xf, xg, atol=1e-4).all(dim=1).float().mean()
+        assert float(same) > 0.97
+        xg.copy_(xf)
+    # and the zero-mean specialisation was left when the mean stopped being 0
+    assert hf._plan.zero_mean is False

@@ -1,0 +1,264 @@
+"""GPU parity of the headline path AT ITS SIZE (BASELINE configs[1]: 65 536
+chains x 1 024 latents, L = 10) and in free-running form.
+
+  * one committed transition at full size through the C-ABI, compared chain by
+    chain with the NumPy oracle for >= 2 048 chains spread over EVERY workgroup
+    and over the first, middle, last and tail turns of the ring kernel's ticket
+    order -- the random stream is keyed by the GLOBAL chain index, so the
+    oracle reproduces any subset of the 65 536 chains exactly -- with and
+    without a mass vector, and at 310 000 chains (the STAGE = false
+    instantiation: per-chain scalars stored from the trip loop);
+  * the north-star acceptance criterion ("per-chain acceptance and ESS within
+    1 %"): device vs oracle free-running from identical seeds, 50 adaptive +
+    300 recorded transitions, mean acceptance and mean reference-estimator ESS
+    within 1 %, at 512 x 1 024 and at BASELINE configs[0]'s full size
+    (1 000 chains x 10-D, gaussian.py);
+  * run-to-run bit stability of the adapted step size (the acceptance sum is
+    order-fixed, not atomics).
+"""
+import types
+
+import numpy as np
+import pytest
+
+from helpers import (FusedKernel, compare_transition, gpu_sampler,
+                     ref_sampler)
+
+pytestmark = pytest.mark.gpu
+
+G = 16            # chains per workgroup turn (ZS_RING_GRANULE)
+
+
+@pytest.fixture(scope='module')
+def env():
+    import torch
+    import zhusuan_amd as zs
+    assert torch.cuda.is_available()
+    return zs, torch
+
+
+def _spread_subset(C, n_blocks, rng, n_random=512):
+    """Chain indices covering every workgroup b and the first / middle / last
+    full turn plus the ragged tail of the ticket order
+    chain = ((turn * n_blocks) + b) * G + j."""
+    round_ = G * n_blocks
+    full = C // round_
+    turns = sorted({0, full // 2, max(full - 1, 0)})
+    ids = []
+    for turn in turns:
+        for b in range(n_blocks):
+            for j in (0, G - 1):
+                ids.append((turn * n_blocks + b) * G + j)
+    ids.extend(range(full * round_, C))              # the tail turn, whole
+    ids.extend(range(0, G))                          # first granule
+    ids.extend(range(C - G, C))                      # last chains
+    ids.extend(rng.randint(0, C, size=n_random).tolist())
+    ids = np.unique(np.asarray([i for i in ids if 0 <= i < C], np.int64))
+    return ids
+
+
+@pytest.mark.parametrize('C,with_mass,mean_zero', [
+    (65536, False, True),       # BASELINE configs[1] exactly (mean = 0)
+    (65536, True, False),
+    (65536 + 40, False, False),  # ragged tail turn
+    (310000, False, True),      # STAGE = false instantiation
+])
+def test_full_size_transition_matches_oracle_on_a_spread_subset(
+        env, C, with_mass, mean_zero):
+    zs, torch = env
+    from oracle.hmc_ref import HMC as RefHMC, DiagNormalModel
+    dev = torch.device('cuda', 0)
+    D, L, seed, eps, off = 1024, 10, 4242, 0.11, 1000
+    n_blocks = torch.cuda.get_device_properties(0).multi_processor_count
+    logstd = np.linspace(-1, 1, D).astype(np.float32)
+    mean = (np.zeros(D, np.float32) if mean_zero else
+            np.random.RandomState(1).normal(size=D).astype(np.float32))
+    mass = np.exp(-2 * logstd * 0.7).astype(np.float32) if with_mass else None
+    g = torch.Generator(device=dev)
+    g.manual_seed(C)
+    q = (torch.randn(C, D, device=dev, generator=g) *
+         torch.tensor(np.exp(logstd), device=dev) +
+         torch.tensor(mean, device=dev))
+    ids = _spread_subset(C, n_blocks, np.random.RandomState(0))
+    assert ids.size >= 2048
+    ids_t = torch.tensor(ids, device=dev)
+    q_before = q[ids_t].cpu().numpy()
+
+    k = FusedKernel(torch, C, D, dev)
+    logstd_t = torch.tensor(logstd, device=dev)
+    k.step(q, None if mean_zero else torch.tensor(mean, device=dev), logstd_t,
+           None if mass is None else torch.tensor(mass, device=dev),
+           eps if not with_mass else 0.6, L, seed, 1, chain_offset=off)
+    torch.cuda.synchronize()
+    assert int(k.flags.item()) == 0
+
+    # the oracle on exactly those chains (global index = offset + local index)
+    model = DiagNormalModel(mean, logstd=logstd)
+    xr = q_before.copy()
+    ref = RefHMC(step_size=eps if not with_mass else 0.6, n_leapfrogs=L,
+                 seed=seed)
+    ref.sample(model.log_joint, model.grad, [xr],
+               chain_offset=ids.astype(np.uint64) + np.uint64(off))
+    if mass is not None:
+        ref.fixed_mass = [mass]
+    rinfo = ref.step()
+
+    acc, h0, h1, lp0, lp = [x[ids_t] for x in k.info]
+    info = types.SimpleNamespace(acceptance_rate=acc, orig_hamiltonian=h0,
+                                 hamiltonian=h1, orig_log_prob=lp0,
+                                 log_prob=lp)
+    flipped = compare_transition(info, q[ids_t], rinfo, xr, ref)
+    assert flipped <= 4
+    # the published sum is the sum of the published rates (order-fixed, exact
+    # to double rounding) -- over ALL chains, not only the subset
+    total = float(k.stats[0].item())
+    np.testing.assert_allclose(
+        total, float(k.info[0].double().sum().item()), rtol=1e-12)
+    # chains outside the subset moved too, plausibly: acceptance in range
+    a_all = float(k.info[0].mean().item())
+    a_sub = float(np.mean(rinfo.acceptance_rate))
+    assert abs(a_all - a_sub) < 0.02, (a_all, a_sub)
+
+
+def _free_run(zs, torch, mean, logstd, q0, n_adapt, n_draws, dims, **kw):
+    """Device and oracle side by side from identical seeds; returns per-side
+    (mean acceptance over the recorded phase, mean over chains of the
+    reference ESS estimator -- minimum over `dims` per chain)."""
+    from oracle import ess_ref
+    ref, xr = ref_sampler(mean, logstd, q0, **kw)
+    flag = zs.placeholder(bool)
+    kw_g = dict(kw, adapt_step_size=flag)
+    if 'adapt_mass' in kw:
+        kw_g['adapt_mass'] = flag
+    hmc, op, info, xg = gpu_sampler(zs, torch, mean, logstd, q0, **kw_g)
+    assert hmc.plan_kind == 'fused_diag_normal'
+    C = q0.shape[0]
+    dims_t = torch.tensor(dims, device=xg.device)
+    rec_g = torch.empty(n_draws, C, len(dims), device=xg.device)
+    rec_r = np.empty((n_draws, C, len(dims)), np.float32)
+    acc_g = acc_r = 0.0
+    for i in range(n_adapt + n_draws):
+        a = i < n_adapt
+        rinfo = ref.step(adapt_step_size=a, adapt_mass=a)
+        op.run(feed_dict={flag: a}, sync=False)
+        if not a:
+            j = i - n_adapt
+            rec_g[j].copy_(xg[:, dims_t])
+            rec_r[j] = xr[:, dims]
+            acc_g += float(info.acceptance_rate.mean().item())
+            acc_r += float(np.mean(rinfo.acceptance_rate))
+    hmc.check_numerics()
+    ess_g = zs.diagnostics.effective_sample_size_device(rec_g, burn_in=0)
+    ess_g = float(ess_g[torch.isfinite(ess_g)].mean().item())
+    ess_r = np.array([ess_ref.effective_sample_size(rec_r[:, c, :], burn_in=0)
+                      for c in range(C)])
+    ess_r = float(ess_r[np.isfinite(ess_r)].mean())
+    eps_g = float(info.updated_step_size.item())
+    return (acc_g / n_draws, ess_g, eps_g), (acc_r / n_draws, ess_r,
+                                             float(ref.step_size))
+
+
+def test_free_running_acceptance_and_ess_within_one_percent(env):
+    """north_star: "per-chain acceptance rate and ESS match the reference ...
+    within 1 % on identical seeds" -- 512 chains x 1 024-D (config-2 target),
+    50 adaptive + 300 recorded transitions, nothing re-synchronised."""
+    zs, torch = env
+    C, D = 512, 1024
+    logstd = np.linspace(-1, 1, D).astype(np.float32)
+    mean = np.zeros(D, np.float32)
+    q0 = np.zeros((C, D), np.float32)
+    dims = np.arange(0, D, 64)
+    got, want = _free_run(zs, torch, mean, logstd, q0, 50, 300, dims,
+                          step_size=0.05, n_leapfrogs=10,
+                          adapt_step_size=True, target_acceptance_rate=0.8,
+                          seed=1)
+    assert abs(got[0] - want[0]) <= 0.01 * want[0], (got, want)
+    assert abs(got[1] - want[1]) <= 0.01 * want[1], (got, want)
+    assert abs(got[2] - want[2]) <= 0.01 * want[2], (got, want)
+    assert 0.6 < got[0] < 0.95
+
+
+def test_free_running_config1_full_size(env):
+    """BASELINE configs[0] at its full size (gaussian.py: 1 000 chains, 10-D,
+    stdev 1/(j+1), L = 5, delta = 0.9, step-size AND mass adaptation for the
+    first 50 of 50 + 300 iterations)."""
+    zs, torch = env
+    n_x, C = 10, 1000
+    stdev = (1 / (np.arange(n_x, dtype=np.float32) + 1)).astype(np.float32)
+    got, want = _free_run(zs, torch, np.zeros(n_x, np.float32), np.log(stdev),
+                          np.zeros((C, n_x), np.float32), 50, 300,
+                          np.arange(n_x), step_size=1e-3, n_leapfrogs=5,
+                          adapt_step_size=True, adapt_mass=True,
+                          target_acceptance_rate=0.9, seed=1)
+    assert abs(got[0] - want[0]) <= 0.01 * want[0], (got, want)
+    assert abs(got[1] - want[1]) <= 0.01 * want[1], (got, want)
+    assert abs(got[2] - want[2]) <= 0.01 * want[2], (got, want)
+
+
+def test_adapted_step_size_is_bit_stable_run_to_run(env):
+    """The acceptance sum that drives dual averaging (hmc.py:377) is added in
+    a fixed order (per-workgroup partials, index-ordered final sum), so two
+    identical adaptive runs give bit-identical step sizes and states -- with
+    atomics the sum, hence epsilon, moved in the last bits from run to run."""
+    zs, torch = env
+    dev = torch.device('cuda', 0)
+    C, D = 20000, 1024
+    logstd = torch.linspace(-1, 1, D, device=dev)
+
+    def run():
+        @zs.meta_bayesian_net()
+        def model():
+            bn = zs.BayesianNet()
+            bn.normal('x', torch.zeros(D, device=dev), logstd=logstd,
+                      n_samples=C, group_ndims=1)
+            return bn
+        h = zs.HMC(step_size=0.05, n_leapfrogs=6, adapt_step_size=True,
+                   seed=11)
+        x = torch.zeros(C, D, device=dev)
+        op, info = h.sample(model(), {}, {'x': x})
+        eps, sums = [], []
+        for i in range(25):
+            op.run(sync=False)
+            if i % 6 == 5:        # reading eps flushes; mixed with carried updates
+                eps.append(info.updated_step_size.clone())
+        eps.append(info.updated_step_size.clone())
+        return torch.stack(eps), x
+
+    e1, x1 = run()
+    e2, x2 = run()
+    assert torch.equal(e1, e2), (e1, e2)
+    assert torch.equal(x1, x2)
+    assert 0.01 < float(e1[-1]) < 1.0
+
+
+def test_pending_update_equals_eager_update(env):
+    """The dual-averaging update carried into the next launch (async runs)
+    and the flushed one (sync runs) are the same arithmetic: identical
+    step-size traces, states and tuner words."""
+    zs, torch = env
+    dev = torch.device('cuda', 0)
+    C, D = 3000, 260
+    logstd = torch.linspace(-0.5, 0.5, D, device=dev)
+    mean = torch.linspace(-1, 1, D, device=dev)
+
+    def run(sync):
+        @zs.meta_bayesian_net()
+        def model():
+            bn = zs.BayesianNet()
+            bn.normal('x', mean, logstd=logstd, n_samples=C, group_ndims=1)
+            return bn
+        flag = zs.placeholder(bool)
+        h = zs.HMC(step_size=0.1, n_leapfrogs=4, adapt_step_size=flag,
+                   adapt_mass=flag, mass_collect_iters=6, seed=5)
+        x = torch.zeros(C, D, device=dev)
+        op, info = h.sample(model(), {}, {'x': x})
+        for i in range(20):
+            op.run(feed_dict={flag: i < 14}, sync=sync)
+        h.check_numerics()
+        return x.clone(), h.get_state()['state'].clone(), info.acceptance_rate.clone()
+
+    xa, sa, aa = run(True)
+    xb, sb, ab = run(False)
+    assert torch.equal(xa, xb)
+    assert torch.equal(sa, sb), (sa, sb)
+    assert torch.equal(aa, ab)

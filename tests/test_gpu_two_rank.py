@@ -139,3 +139,115 @@ def test_bench_two_ranks_prints_contract_json():
     assert out['value'] > 0 and 0.3 < out['mean_acceptance'] <= 1.0
     assert out['roofline']['bound'] == 'hbm'
     assert 'cpu_baseline' not in out       # rank 0 at N = 1 only
+
+
+RCCL_WORKER = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %(root)r)
+import zhusuan_amd as zs
+from zhusuan_amd.distributed import ChainSharding, shard_bounds
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+dist.init_process_group('gloo', rank=rank, world_size=world)   # bootstrap only
+torch.cuda.set_device(rank %% torch.cuda.device_count())
+dev = torch.device('cuda', torch.cuda.current_device())
+sh = ChainSharding(backend='rccl')
+assert sh.rccl_ranks == world
+# the raw collective
+t = torch.full((5,), float(rank + 1), dtype=torch.float64, device=dev)
+sh.all_reduce_sum(t)
+torch.cuda.synchronize()
+assert t.tolist() == [world * (world + 1) / 2.0] * 5, t
+C, D, L = 4096, 1024, 5
+g = torch.Generator(device='cpu').manual_seed(0)
+logstd = torch.linspace(-1, 1, D).to(dev)
+q0 = torch.randn(C, D, generator=g)
+lo, hi = shard_bounds(C, rank, world)
+x = q0[lo:hi].to(dev).contiguous()
+@zs.meta_bayesian_net()
+def model():
+    bn = zs.BayesianNet()
+    bn.normal('x', torch.zeros(D, device=dev), logstd=logstd,
+              n_samples=hi - lo, group_ndims=1)
+    return bn
+flag = zs.placeholder(bool)
+hmc = zs.HMC(step_size=0.05, n_leapfrogs=L, adapt_step_size=flag,
+             adapt_mass=flag, mass_collect_iters=4, seed=5, sharding=sh)
+op, info = hmc.sample(model(), {}, {'x': x})
+assert hmc.plan_kind == 'fused_diag_normal'
+eps = []
+for i in range(16):
+    op.run(feed_dict={flag: i < 12}, sync=(i %% 5 == 0))
+    if i %% 3 == 2:
+        eps.append(float(info.updated_step_size.item()))
+hmc.check_numerics()
+eps.append(float(info.updated_step_size.item()))
+np.savez(os.path.join(%(out)r, 'rccl_rank%%d.npz' %% rank), lo=lo, hi=hi,
+         x=x.cpu().numpy(), eps=np.array(eps),
+         mass=hmc._plan.mass[0].cpu().numpy(),
+         state=hmc.get_state()['state'].numpy())
+sh.close()
+dist.destroy_process_group()
+'''
+
+
+def _single_process_reference(torch, zs):
+    dev = torch.device('cuda', 0)
+    C, D, L = 4096, 1024, 5
+    g = torch.Generator(device='cpu').manual_seed(0)
+    logstd = torch.linspace(-1, 1, D).to(dev)
+    x = torch.randn(C, D, generator=g).to(dev)
+
+    @zs.meta_bayesian_net()
+    def model():
+        bn = zs.BayesianNet()
+        bn.normal('x', torch.zeros(D, device=dev), logstd=logstd,
+                  n_samples=C, group_ndims=1)
+        return bn
+    flag = zs.placeholder(bool)
+    hmc = zs.HMC(step_size=0.05, n_leapfrogs=L, adapt_step_size=flag,
+                 adapt_mass=flag, mass_collect_iters=4, seed=5)
+    op, info = hmc.sample(model(), {}, {'x': x})
+    eps = []
+    for i in range(16):
+        op.run(feed_dict={flag: i < 12}, sync=(i % 5 == 0))
+        if i % 3 == 2:
+            eps.append(float(info.updated_step_size.item()))
+    hmc.check_numerics()
+    eps.append(float(info.updated_step_size.item()))
+    return (x.cpu().numpy(), np.array(eps), hmc._plan.mass[0].cpu().numpy(),
+            hmc.get_state()['state'].numpy())
+
+
+@pytest.mark.parametrize('world', [1, 2])
+def test_direct_rccl_communicator(tmp_path, world):
+    """The production collective: ChainSharding(backend='rccl') =
+    ncclCommInitRank + ncclAllReduce through the C-ABI (zshmc_comm_*), one
+    message per transition on the compute stream.  world = 1 runs on any box
+    (a one-rank communicator still executes the whole RCCL path); world = 2
+    needs two GPUs (RCCL refuses two ranks on one device)."""
+    import torch
+    import zhusuan_amd as zs
+    if world > torch.cuda.device_count():
+        pytest.skip('needs %d GPUs' % world)
+    script = tmp_path / 'rccl_worker.py'
+    script.write_text(RCCL_WORKER % dict(root=ROOT, out=str(tmp_path)))
+    r = _launch([str(script)], world)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    ranks = [np.load(str(tmp_path / ('rccl_rank%d.npz' % i)))
+             for i in range(world)]
+    x1, eps1, mass1, state1 = _single_process_reference(torch, zs)
+    for r_ in ranks[1:]:
+        np.testing.assert_array_equal(r_['eps'], ranks[0]['eps'])
+        np.testing.assert_array_equal(r_['mass'], ranks[0]['mass'])
+        np.testing.assert_array_equal(r_['state'], ranks[0]['state'])
+    x = np.concatenate([r_['x'] for r_ in ranks])
+    if world == 1:
+        # same partial sums, same order: bit-identical to the unsharded run
+        np.testing.assert_array_equal(ranks[0]['eps'], eps1)
+        np.testing.assert_array_equal(ranks[0]['state'], state1)
+        np.testing.assert_array_equal(x, x1)
+    else:
+        np.testing.assert_allclose(ranks[0]['eps'], eps1, rtol=1e-5)
+        np.testing.assert_allclose(ranks[0]['mass'], mass1, rtol=1e-5)
+        close = np.isclose(x, x1, atol=1e-4).all(axis=1)
+        assert close.mean() > 0.98

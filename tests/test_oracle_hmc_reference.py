@@ -42,17 +42,21 @@ def test_oracle_reproduces_reference_hmc_traces(traces, case):
                                        rtol=3e-5, atol=3e-5, err_msg='%s it %d' % (f, i))
         np.testing.assert_allclose(info.acceptance_rate,
                                    traces[name + '/acceptance_rate'][i],
-                                   rtol=0, atol=2e-4)
+                                   rtol=0, atol=4e-4)   # |H| ~ 300 at D = 260:
+                                                        # 1 ulp of H is 3e-5
         np.testing.assert_allclose(info.updated_step_size,
                                    traces[name + '/updated_step_size'][i],
-                                   rtol=2e-5)
+                                   rtol=5e-5)   # mean(acc) in float32: torch
+                                                # and NumPy sum in different
+                                                # orders; dual averaging
+                                                # multiplies that by sqrt(t)/gamma
         for k, nm in enumerate(case['latent_names']):
             want = traces['%s/q_%s' % (name, nm)][i]
             # (1/var masses and exp(-2 logstd) differ in the last bit between
             # NumPy and torch; L drifts with eps ~ 1 and 1/m up to 13 carry
             # that to a few 1e-4 absolute on |q| ~ 8; the energies above, which
             # decide acceptance, agree to 1-2 ulp.)
-            np.testing.assert_allclose(qs[k], want, rtol=2e-4, atol=5e-4)
+            np.testing.assert_allclose(qs[k], want, rtol=2e-4, atol=1e-3)
             # teacher forcing: continue from the reference's state so that
             # float32 rounding differences do not compound over iterations
             qs[k][...] = want

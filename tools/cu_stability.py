@@ -21,7 +21,7 @@ s = torch.cuda.current_stream().cuda_stream
 ends = []
 for it in range(12):
     timing = torch.zeros(8192 * 4, dtype=torch.int64, device=dev)
-    fn(q.data_ptr(), mean.data_ptr(), logstd.data_ptr(), None, None, 0.14, C, D, 0, L, 1, it, 1,
+    fn(q.data_ptr(), mean.data_ptr(), logstd.data_ptr(), None, 0.14, C, D, 0, L, 1, it, 1,
        acc.data_ptr(), timing.data_ptr(), None, None, None, None, None, s)
     torch.cuda.synchronize()
     t = timing.cpu().numpy().reshape(-1, 4)[:4096]

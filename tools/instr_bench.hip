@@ -70,6 +70,12 @@ KERNEL(k_lshr, SETUP_ALL, asm volatile("v_lshrrev_b32 %0, 8, %0\n v_lshrrev_b32 
 KERNEL(k_sin2, SETUP_ALL, asm volatile("v_sin_f32 %0, %0\n v_cos_f32 %1, %1\n v_sqrt_f32 %2, %2\n v_log_f32 %3, %3" : "+v"(fa), "+v"(fb), "+v"(fc), "+v"(fd));)
 KERNEL(k_pk_mul, SETUP_ALL, asm volatile("v_pk_mul_f32 %0, %0, %1\n v_pk_mul_f32 %1, %1, %2\n v_pk_mul_f32 %2, %2, %3\n v_pk_mul_f32 %3, %3, %0" : "+v"(pa), "+v"(pb), "+v"(pc), "+v"(pd)); fa = pa[0];)
 
+KERNEL(k_bitop3, SETUP_ALL, asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96\n v_bitop3_b32 %1, %1, %2, %3 bitop3:0x96\n v_bitop3_b32 %2, %2, %3, %0 bitop3:0x96\n v_bitop3_b32 %3, %3, %0, %1 bitop3:0x96" : "+v"(ua), "+v"(ub), "+v"(uc), "+v"(ud));)
+KERNEL(k_bitop3_sgpr, SETUP_ALL, asm volatile("v_bitop3_b32 %0, %0, %1, s4 bitop3:0x96\n v_bitop3_b32 %1, %1, %2, s5 bitop3:0x96\n v_bitop3_b32 %2, %2, %3, s6 bitop3:0x96\n v_bitop3_b32 %3, %3, %0, s7 bitop3:0x96" : "+v"(ua), "+v"(ub), "+v"(uc), "+v"(ud));)
+KERNEL(k_fmamk, SETUP_ALL, asm volatile("v_fmamk_f32 %0, %0, 0x2f800000, %1\n v_fmamk_f32 %1, %1, 0x2f800000, %2\n v_fmamk_f32 %2, %2, 0x2f800000, %3\n v_fmamk_f32 %3, %3, 0x2f800000, %0" : "+v"(fa), "+v"(fb), "+v"(fc), "+v"(fd));)
+KERNEL(k_or_inl, SETUP_ALL, asm volatile("v_or_b32 %0, 1.0, %0\n v_or_b32 %1, 1.0, %1\n v_or_b32 %2, 1.0, %2\n v_or_b32 %3, 1.0, %3" : "+v"(ua), "+v"(ub), "+v"(uc), "+v"(ud));)
+KERNEL(k_add_f64, SETUP_F64, asm volatile("v_add_f64 %0, %0, %1\n v_add_f64 %1, %1, %0\n v_add_f64 %0, %0, %1\n v_add_f64 %1, %1, %0" : "+v"(da), "+v"(db)); fa = (float)da;)
+
 template <typename K>
 void run(const char* name, K kern, int waves_per_simd) {
   const int blocks = 256 * 4;  // 4 single-wave blocks per CU -> one per SIMD

@@ -24,14 +24,17 @@ def run(fn, lib, C, D, L, mass_on, it, commit=1, eps=0.14):
     mass = (torch.exp(-2 * logstd) if mass_on else None)
     q = (torch.randn(C, D, generator=g) * torch.exp(logstd.cpu()) + mean.cpu()).to(dev)
     info = [torch.full((C,), -7.0, device=dev) for _ in range(5)]
-    acc_sum = torch.zeros(1, dtype=torch.float64, device=dev)
+    acc_sum = torch.zeros(_capi.STATS_WORDS, dtype=torch.float64, device=dev)
+    ws = torch.zeros(_capi.LINK_WORKSPACE_BYTES, dtype=torch.uint8, device=dev)
     flags = torch.zeros(1, dtype=torch.int32, device=dev)
+    link = _capi.AdaptLink(stats=acc_sum.data_ptr(), workspace=ws.data_ptr(),
+                           n_chains_global=C, used_step_size=float('nan'))
     s = torch.cuda.current_stream().cuda_stream
     for t in range(it):
         rc = fn(q.data_ptr(), mean.data_ptr(), logstd.data_ptr(),
-                None if mass is None else mass.data_ptr(), None, eps, C, D, 5, L, 1234567, t, commit,
+                None if mass is None else mass.data_ptr(), eps, C, D, 5, L, 1234567, t, commit,
                 info[0].data_ptr(), info[1].data_ptr(), info[2].data_ptr(), info[3].data_ptr(),
-                info[4].data_ptr(), acc_sum.data_ptr(), flags.data_ptr(), s)
+                info[4].data_ptr(), flags.data_ptr(), ctypes.byref(link), s)
         if rc != 0:
             raise RuntimeError(lib.zshmc_last_error().decode())
     torch.cuda.synchronize()

@@ -19,7 +19,7 @@ acc = torch.zeros(C, device=dev)
 s = torch.cuda.current_stream().cuda_stream
 for it in range(4):
     timing.zero_()
-    fn(q.data_ptr(), mean.data_ptr(), logstd.data_ptr(), None, None, 0.14, C, D, 0, L, 1, it, 1,
+    fn(q.data_ptr(), mean.data_ptr(), logstd.data_ptr(), None, 0.14, C, D, 0, L, 1, it, 1,
        acc.data_ptr(), timing.data_ptr(), None, None, None, None, None, s)
 torch.cuda.synchronize()
 t = timing.cpu().numpy().reshape(-1, 4)

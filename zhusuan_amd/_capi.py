@@ -7,8 +7,8 @@ Build the library with ``python -c "import __graft_entry__ as g; g.build()"``
 """
 import ctypes
 import os
-from ctypes import (c_char_p, c_float, c_int, c_int64, c_uint32, c_uint64,
-                    c_void_p)
+from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32,
+                    c_int64, c_uint32, c_uint64, c_void_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libzshmc.so')
@@ -25,6 +25,26 @@ ST_EWMV_T = 4
 ST_USED_STEP_SIZE = 5
 ST_MEAN_ACCEPT = 6
 
+PEND_NONE = 0
+PEND_ADAPT = 1
+PEND_HOLD = 2
+STATS_WORDS = 2
+LINK_WORKSPACE_BYTES = 64 + 8 * 4096
+COMM_ID_BYTES = 128
+ERR_COMM = 4
+
+
+class AdaptLink(Structure):
+    """zshmc_adapt_link (include/zshmc.h): how consecutive fused transitions
+    hand over the acceptance statistic and the pending step-size update."""
+    _fields_ = [('state', c_void_p), ('stats', c_void_p),
+                ('workspace', c_void_p), ('n_chains_global', c_int64),
+                ('pending', c_int32), ('fresh_start', c_int32),
+                ('used_step_size', c_float), ('delta', c_float),
+                ('gamma', c_float), ('t0', c_float), ('kappa', c_float),
+                ('mu', c_float)]
+
+
 BCAST_FULL = 0
 BCAST_ROW = 1
 BCAST_SCALAR = 2
@@ -37,7 +57,7 @@ PROTOTYPES = {
     'zshmc_last_error': (c_char_p, []),
     'zshmc_version': (c_int, []),
     'zshmc_fused_max_n_data': (c_int64, []),
-    'zshmc_fused_kernel_name': (c_char_p, [c_int64, c_int]),
+    'zshmc_fused_kernel_name': (c_char_p, [c_int64, c_int, c_int]),
     'zshmc_linear_multinomial_log_lik': (c_int, [
         _p, _p, _p, c_int64, c_int64, c_int64, c_int64, _p, _p, c_int, _p, _p]),
     'zshmc_ess_series': (c_int, [_p, c_int64, c_int64, _p, _p]),
@@ -65,8 +85,15 @@ PROTOTYPES = {
     'zshmc_sgnht_scalar': (c_int, [
         _p, _p, c_int64, c_float, c_float, c_int, c_int, _p, _p]),
     'zshmc_hmc_diag_normal_step': (c_int, [
-        _p, _p, _p, _p, _p, c_float, c_int64, c_int64, c_int64, c_int,
-        c_uint64, c_uint32, c_int, _p, _p, _p, _p, _p, _p, _p, _p]),
+        _p, _p, _p, _p, c_float, c_int64, c_int64, c_int64, c_int,
+        c_uint64, c_uint32, c_int, _p, _p, _p, _p, _p, _p,
+        POINTER(AdaptLink), _p]),
+    'zshmc_stepsize_flush': (c_int, [POINTER(AdaptLink), _p]),
+    'zshmc_comm_unique_id': (c_int, [_p]),
+    'zshmc_comm_create': (c_int, [_p, c_int, c_int, POINTER(c_void_p)]),
+    'zshmc_comm_all_reduce_sum': (c_int, [_p, _p, c_int64, _p]),
+    'zshmc_comm_world_size': (c_int, [_p]),
+    'zshmc_comm_destroy': (c_int, [_p]),
     'zshmc_stepsize_update': (c_int, [
         _p, _p, c_int64, c_int, c_int, c_float, c_float, c_float, c_float,
         c_float, _p]),

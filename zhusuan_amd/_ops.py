@@ -7,6 +7,8 @@ model contains (tf.gradients, reference hmc.py:430-432).
 """
 import torch
 
+from .utils import broadcast_shapes
+
 from . import _capi
 
 _F32 = torch.float32
@@ -92,7 +94,7 @@ class NormalLogProb(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, mean, logstd, group_ndims):
         require_device(x, mean, logstd)
-        full = torch.broadcast_shapes(x.shape, mean.shape, logstd.shape)
+        full = broadcast_shapes(x.shape, mean.shape, logstd.shape)
         n_col = choose_col_dims(full, group_ndims, mean, logstd)
         rows, cols = _rows_cols(full, n_col)
         xf = x.expand(full).contiguous()
@@ -135,7 +137,7 @@ class Uni2LogProb(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, a, b, kind, group_ndims):
         require_device(x, a, b)
-        full = torch.broadcast_shapes(x.shape, a.shape, b.shape)
+        full = broadcast_shapes(x.shape, a.shape, b.shape)
         n_col = choose_col_dims(full, group_ndims, a, b)
         rows, cols = _rows_cols(full, n_col)
         xf = x.expand(full).contiguous()
@@ -344,7 +346,7 @@ class BernoulliLogProb(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, given, group_ndims):
         require_device(logits, given)
-        full = torch.broadcast_shapes(logits.shape, given.shape)
+        full = broadcast_shapes(logits.shape, given.shape)
         n_col = choose_col_dims(full, group_ndims, logits, given)
         rows, cols = _rows_cols(full, n_col)
         (l, lm), (z, zm) = bcast_plan(full, n_col, logits, given)

@@ -11,38 +11,26 @@
 // host round trip; the only value that ever crosses GPUs is the tiny
 // acc_sum / colsum buffer.
 #include "common.h"
+#include "fused_args.h"
 
 namespace zshmc {
 
 __global__ void stepsize_update_kernel(float* __restrict__ state,
                                        double* __restrict__ acc_sum,
                                        double inv_chains, int adapt,
-                                       float fresh, float delta, float gamma,
-                                       float t0, float kappa, float mu) {
+                                       float fresh, TunerCfg cfg) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const float acc = (float)(*acc_sum * inv_chains);  // hmc.py:377 reduce_mean
+  // the same arithmetic as the update carried by the fused kernels
+  AdaptLink k;
+  k.state = state;
+  k.stats = acc_sum;
+  k.inv_chains = inv_chains;
+  k.pending = adapt ? ZSHMC_PEND_ADAPT : ZSHMC_PEND_HOLD;
+  k.fresh = fresh;
+  k.used_step_size = __builtin_nanf("");
+  k.tuner = cfg;
+  tuner_persist(k);
   *acc_sum = 0.0;  // consumed; ready for the next transition
-  state[ZSHMC_ST_MEAN_ACCEPT] = acc;
-  state[ZSHMC_ST_USED_STEP_SIZE] = state[ZSHMC_ST_STEP_SIZE];
-  float step = state[ZSHMC_ST_TUNER_STEP];
-  float h_bar = state[ZSHMC_ST_H_BAR];
-  float leb = state[ZSHMC_ST_LOG_EPS_BAR];
-  if (adapt) {
-    // hmc.py:92-106
-    step = (1.0f - fresh) * step + 1.0f;
-    const float rate1 = 1.0f / (step + t0);
-    h_bar = (1.0f - fresh) * (1.0f - rate1) * h_bar + rate1 * (delta - acc);
-    const float log_eps = mu - sqrtf(step) / gamma * h_bar;
-    const float rate = powf(step, -kappa);
-    leb = rate * log_eps + (1.0f - fresh) * (1.0f - rate) * leb;
-    state[ZSHMC_ST_TUNER_STEP] = step;
-    state[ZSHMC_ST_H_BAR] = h_bar;
-    state[ZSHMC_ST_LOG_EPS_BAR] = leb;
-    state[ZSHMC_ST_STEP_SIZE] = expf(log_eps);
-  } else {
-    // hmc.py:108-110: epsilon is overwritten by exp(log_epsilon_bar)
-    state[ZSHMC_ST_STEP_SIZE] = expf(leb);
-  }
 }
 
 __global__ void state_set_kernel(float* state, int index, float value) {
@@ -142,7 +130,8 @@ extern "C" int zshmc_stepsize_update(float* state, double* acc_sum,
   hipLaunchKernelGGL(stepsize_update_kernel, dim3(1), dim3(64), 0,
                      reinterpret_cast<hipStream_t>(stream), state, acc_sum,
                      1.0 / (double)n_chains_global, adapt,
-                     fresh_start ? 1.0f : 0.0f, delta, gamma, t0, kappa, mu);
+                     fresh_start ? 1.0f : 0.0f,
+                     TunerCfg{delta, gamma, t0, kappa, mu});
   ZS_LAUNCH_CHECK("stepsize_update_kernel launch");
   return ZSHMC_OK;
 }

@@ -1,21 +1,136 @@
 // Argument block shared by the fused diag-Normal HMC kernels
 // (hmc_fused_normal.hip: register-prefetch kernel for small / ragged rows;
-//  hmc_fused_ring.hip: LDS-DMA ring kernel for 16-B aligned rows > 512 B).
+//  hmc_fused_ring.hip: LDS-DMA ring kernel for 16-B aligned rows > 512 B)
+// and the dual-averaging step-size update they carry.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include "../../include/zshmc.h"
 
 namespace zshmc {
 
 constexpr float kHalfLog2PiNeg = -0.91893853320467274178f;  // -0.5*log(2*pi)
 
+// ---- dual averaging (StepsizeTuner.tune, hmc.py:89-112) --------------------
+struct TunerCfg {
+  float delta, gamma, t0, kappa, mu;  // mu = 10 * initial step size (sic, :79)
+};
+struct TunerState {
+  float step_size, step, log_eps_bar, h_bar;
+};
+
+__device__ __forceinline__ TunerState tuner_load(const float* state) {
+  return TunerState{state[ZSHMC_ST_STEP_SIZE], state[ZSHMC_ST_TUNER_STEP],
+                    state[ZSHMC_ST_LOG_EPS_BAR], state[ZSHMC_ST_H_BAR]};
+}
+
+// One update from the mean acceptance `acc` of a finished transition.
+// kind: ZSHMC_PEND_ADAPT (the run's adapt_step_size flag was true, :92-106) or
+// ZSHMC_PEND_HOLD (false, :108-110: epsilon <- exp(log_epsilon_bar)).
+// The update runs in three places -- the prologue of every workgroup of the
+// NEXT transition kernel, the workgroup that retires that kernel last, and the
+// stand-alone flush kernel -- which must agree to the bit: contraction is off
+// so that hipcc cannot fuse differently in different inlining contexts.
+__device__ __forceinline__ TunerState tuner_apply(TunerState s, float acc,
+                                                  int kind, float fresh,
+                                                  const TunerCfg& c) {
+#pragma clang fp contract(off)
+  if (kind == ZSHMC_PEND_ADAPT) {
+    const float keep = 1.0f - fresh;
+    const float step = keep * s.step + 1.0f;
+    const float rate1 = 1.0f / (step + c.t0);
+    const float h_bar = keep * (1.0f - rate1) * s.h_bar + rate1 * (c.delta - acc);
+    const float log_eps = c.mu - sqrtf(step) / c.gamma * h_bar;
+    const float rate = powf(step, -c.kappa);
+    s.log_eps_bar = rate * log_eps + keep * (1.0f - rate) * s.log_eps_bar;
+    s.step = step;
+    s.h_bar = h_bar;
+    s.step_size = expf(log_eps);
+  } else {
+    s.step_size = expf(s.log_eps_bar);
+  }
+  return s;
+}
+
+// The link between consecutive transitions (include/zshmc.h,
+// zshmc_adapt_link): where the acceptance sum goes and which update of the
+// previous transition is still pending.
+struct AdaptLink {
+  float* state;      // ZSHMC_ST_* block; NULL: no on-device step size / tuner
+  double* stats;     // [0] sum acc (in: previous, all-reduced; out: this
+                     // launch's, order-fixed), [1] non-finite-start flag
+  double* partials;  // workspace: per-workgroup acceptance sums
+  uint32_t* done;    // workspace: retired-workgroup counter (0 between launches)
+  double inv_chains; // 1 / n_chains_global
+  int pending;       // ZSHMC_PEND_*
+  float fresh;       // 1: fresh start (hmc.py:466-467, :92-102)
+  float used_step_size;  // epsilon the previous transition used if it came
+                         // from the search (NaN: it used state[STEP_SIZE])
+  TunerCfg tuner;
+};
+
+// state <- update(state, stats[0]) and the two diagnostic words; one thread.
+__device__ __forceinline__ void tuner_persist(const AdaptLink& k) {
+  const TunerState s0 = tuner_load(k.state);
+  const float acc = (float)(k.stats[0] * k.inv_chains);  // hmc.py:377
+  const TunerState s = tuner_apply(s0, acc, k.pending, k.fresh, k.tuner);
+  k.state[ZSHMC_ST_MEAN_ACCEPT] = acc;
+  k.state[ZSHMC_ST_USED_STEP_SIZE] =
+      k.used_step_size == k.used_step_size ? k.used_step_size : s0.step_size;
+  k.state[ZSHMC_ST_STEP_SIZE] = s.step_size;
+  k.state[ZSHMC_ST_TUNER_STEP] = s.step;
+  k.state[ZSHMC_ST_LOG_EPS_BAR] = s.log_eps_bar;
+  k.state[ZSHMC_ST_H_BAR] = s.h_bar;
+}
+
+// The step size this launch integrates with: the host value, or the device
+// state with the pending update applied (every workgroup computes the same
+// scalars from the same inputs; nobody writes them until all have read).
+__device__ __forceinline__ float link_step_size(const AdaptLink& k,
+                                                float step_size_host) {
+  if (!k.state) return step_size_host;
+  TunerState s = tuner_load(k.state);
+  if (k.pending != ZSHMC_PEND_NONE)
+    s = tuner_apply(s, (float)(k.stats[0] * k.inv_chains), k.pending, k.fresh,
+                    k.tuner);
+  return s.step_size;
+}
+
+// End of a transition kernel, thread 0 of every workgroup: publish this
+// workgroup's acceptance sum; the workgroup that retires last adds the
+// partials in index order (run-to-run identical, unlike atomics), persists
+// the pending update of the previous transition and publishes the total.
+__device__ __forceinline__ void link_retire(const AdaptLink& k, double wg_sum,
+                                            const uint32_t* flags) {
+  if (!k.partials) return;
+  const unsigned nblk = gridDim.x;
+  __hip_atomic_store(&k.partials[blockIdx.x], wg_sum, __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+  __atomic_thread_fence(__ATOMIC_RELEASE);
+  const unsigned ticket = __hip_atomic_fetch_add(
+      k.done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+  if (ticket != nblk - 1) return;
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  double total = 0.0;
+  for (unsigned i = 0; i < nblk; ++i)
+    total += __hip_atomic_load(&k.partials[i], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+  if (k.state && k.pending != ZSHMC_PEND_NONE) tuner_persist(k);
+  k.stats[0] = total;
+  uint32_t f = 0;
+  if (flags)
+    f = __hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  k.stats[1] = (f & ZSHMC_FLAG_OLD_LOGPROB_NONFINITE) ? 1.0 : 0.0;
+  __hip_atomic_store(k.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 struct FusedArgs {
   float* q;
-  const float* mean;
+  const float* mean;  // NULL: all zeros (no subtraction / re-addition)
   const float* logstd;
   const float* mass;
-  const float* step_size_dev;
-  float step_size_host;
+  float step_size_host;  // used when link.state == NULL
   int64_t n_chains;
   int64_t n_data;
   int64_t chain_offset;
@@ -28,8 +143,8 @@ struct FusedArgs {
   float* hamiltonian;
   float* orig_log_prob;
   float* log_prob;
-  double* acc_sum;
   uint32_t* flags;
+  AdaptLink link;
   // ring kernel only (set by its launcher): HMCInfo scalars staged in LDS
   // (info_cap chains per workgroup) or stored straight from the trip loop
   int info_cap;          // 0 = no staging
@@ -46,7 +161,10 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 int launch_fused_ring(const FusedArgs& a, hipStream_t stream);
 // "NCH,K,mass" of the ring instantiation for this shape; false if the shape
 // is not covered (alignment aside).
-bool fused_ring_config(int64_t n_data, bool has_mass, int* nch, int* k);
+bool fused_ring_config(int64_t n_data, bool has_mass, bool zero_mean, int* nch,
+                       int* k);
 bool fused_ring_enabled();  // ZSHMC_FUSED_RING != 0
+// largest grid either fused kernel launches (sizes the link workspace)
+constexpr int kFusedMaxGrid = 4096;
 
 }  // namespace zshmc

@@ -21,6 +21,7 @@
 // HBM traffic per chain: read q (4*D B) + write q (4*D B, only if accepted)
 // + 5 floats of HMCInfo: 8 B per element per transition.
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.h"
 #include "philox.h"
@@ -93,14 +94,15 @@ __global__ __launch_bounds__(256, ZS_WAVES_PER_EU) void hmc_diag_normal_kernel(
 
   // ---- stage mean / sqrt(mass) in LDS (zero padding beyond n_data) --------
   for (int d = threadIdx.x; d < kPad; d += blockDim.x) {
-    s_mean[d] = d < D ? a.mean[d] : 0.f;
+    s_mean[d] = (a.mean && d < D) ? a.mean[d] : 0.f;
     if (HAS_MASS) s_sqrtm[d] = d < D ? sqrtf(a.mass[d]) : 0.f;
   }
   if (threadIdx.x == 0) *s_bad = 0;
 
   // wave-uniform step size; se is the scale folded into nep / eim
-  const float eps =
-      a.step_size_dev ? *a.step_size_dev : a.step_size_host;
+  // (the pending dual-averaging update of the previous transition is
+  // applied here, see fused_args.h)
+  const float eps = link_step_size(a.link, a.step_size_host);
   const bool moving = eps != 0.f;
   const float se = moving ? eps : 1.f;
   const float inv_se = 1.0f / se;
@@ -230,15 +232,18 @@ __global__ __launch_bounds__(256, ZS_WAVES_PER_EU) void hmc_diag_normal_kernel(
     // Trips 1..L each do a full drift and a FULL kick; the last trip's kick
     // must be eps/2, so half of it is taken back below (hk2), sharing the
     // product nep*r with the potential energy of the proposal.
-    for (int i = 0; i < Lr; ++i) {
+    if (Lr > 0) {
+      int i = Lr;
+      do {
 #pragma unroll
-      for (int k = 0; k < NCH; ++k) {
-        if (HAS_MASS)
-          r[k] += eim[k] * p[k];
-        else
-          r[k] += eps * p[k];
-        p[k] += nep[k] * r[k];
-      }
+        for (int k = 0; k < NCH; ++k) {
+          if (HAS_MASS)
+            r[k] += eim[k] * p[k];
+          else
+            r[k] += eps * p[k];
+          p[k] += nep[k] * r[k];
+        }
+      } while (--i > 0);
     }
 
     // ---- Hamiltonians (hmc.py:30-35) and acceptance (hmc.py:46-61) -------
@@ -312,7 +317,9 @@ __global__ __launch_bounds__(256, ZS_WAVES_PER_EU) void hmc_diag_normal_kernel(
     t[3] = n_done;
   }
 #endif
-  // ---- sum of acceptance rates: wave shuffle -> LDS -> one atomic/block --
+  // ---- sum of acceptance rates: wave shuffle -> LDS -> per-workgroup
+  // partial; the order-fixed total over workgroups is link_retire's (the
+  // chain -> wave map is static here, so every level of the sum is too)
   const double w = wave_sum_f64(acc_local);
   if (lane == 0) s_acc[threadIdx.x / kWave] = w;
   if (bad_old) *s_bad = 1;
@@ -320,8 +327,8 @@ __global__ __launch_bounds__(256, ZS_WAVES_PER_EU) void hmc_diag_normal_kernel(
   if (threadIdx.x == 0) {
     double tot = 0.0;
     for (int i = 0; i < (int)(blockDim.x / kWave); ++i) tot += s_acc[i];
-    if (a.acc_sum) atomicAdd(a.acc_sum, tot);
     if (*s_bad && a.flags) atomicOr(a.flags, ZSHMC_FLAG_OLD_LOGPROB_NONFINITE);
+    link_retire(a.link, tot, a.flags);
   }
 }
 
@@ -329,7 +336,7 @@ template <int G, int NCH>
 static int launch_cfg(const FusedArgs& a, hipStream_t stream) {
   const bool vec = (a.n_data % 4 == 0) &&
                    ((reinterpret_cast<uintptr_t>(a.q) & 15) == 0) &&
-                   ((reinterpret_cast<uintptr_t>(a.mean) & 15) == 0) &&
+                   (!a.mean || (reinterpret_cast<uintptr_t>(a.mean) & 15) == 0) &&
                    ((reinterpret_cast<uintptr_t>(a.logstd) & 15) == 0) &&
                    (!a.mass || (reinterpret_cast<uintptr_t>(a.mass) & 15) == 0);
   const bool has_mass = a.mass != nullptr;
@@ -366,7 +373,9 @@ static int launch_cfg(const FusedArgs& a, hipStream_t stream) {
     blocks_per_cu[variant] = nb;
   }
   const int64_t cap = (int64_t)device_cu_count() * blocks_per_cu[variant];
-  const int grid = (int)(need < cap ? need : cap);
+  int grid = (int)(need < cap ? need : cap);
+  if (grid > kFusedMaxGrid) grid = kFusedMaxGrid;  // link workspace (persistent
+                                                   // waves stride over chains)
   dim3 g(grid > 0 ? grid : 1), b(kWave * kWavesPerBlock);
   if (vec && has_mass)
     hipLaunchKernelGGL((hmc_diag_normal_kernel<G, NCH, true, true>), g, b, lds,
@@ -392,12 +401,15 @@ using namespace zshmc;
 
 extern "C" int64_t zshmc_fused_max_n_data(void) { return kFusedMaxData; }
 
-extern "C" const char* zshmc_fused_kernel_name(int64_t n_data, int has_mass) {
+extern "C" const char* zshmc_fused_kernel_name(int64_t n_data, int has_mass,
+                                               int zero_mean) {
   static thread_local char buf[96];
   int nch = 0, k = 0;
-  if (fused_ring_enabled() && fused_ring_config(n_data, has_mass != 0, &nch, &k)) {
-    snprintf(buf, sizeof(buf), "hmc_diag_normal_ring_kernel<%d,%d,%s,*>", nch,
-             k, has_mass ? "true" : "false");
+  if (fused_ring_enabled() &&
+      fused_ring_config(n_data, has_mass != 0, zero_mean != 0, &nch, &k)) {
+    snprintf(buf, sizeof(buf), "hmc_diag_normal_ring_kernel<%d,%d,%s,*,%s>",
+             nch, k, has_mass ? "true" : "false",
+             zero_mean ? "true" : "false");
     return buf;
   }
   const int64_t ng = (n_data + 3) / 4;
@@ -420,14 +432,79 @@ extern "C" const char* zshmc_fused_kernel_name(int64_t n_data, int has_mass) {
   return buf;
 }
 
+namespace zshmc {
+
+// host-side zshmc_adapt_link -> the device-side view
+static int make_link(const zshmc_adapt_link* link, AdaptLink* out,
+                     const char* who) {
+  AdaptLink k;
+  memset(&k, 0, sizeof(k));
+  k.used_step_size = __builtin_nanf("");
+  if (link) {
+    ZS_REQUIRE(link->pending == ZSHMC_PEND_NONE ||
+                   link->pending == ZSHMC_PEND_ADAPT ||
+                   link->pending == ZSHMC_PEND_HOLD,
+               "%s: link->pending %d is not a ZSHMC_PEND_* value", who,
+               (int)link->pending);
+    ZS_REQUIRE(link->pending == ZSHMC_PEND_NONE || (link->state && link->stats),
+               "%s: a pending update needs link->state and link->stats", who);
+    ZS_REQUIRE(!link->stats || link->workspace,
+               "%s: link->stats needs link->workspace", who);
+    ZS_REQUIRE(!(link->state || link->stats) || link->n_chains_global > 0,
+               "%s: link->n_chains_global <= 0", who);
+    k.state = link->state;
+    k.stats = link->stats;
+    if (link->stats) {
+      char* ws = reinterpret_cast<char*>(link->workspace);
+      k.done = reinterpret_cast<uint32_t*>(ws);
+      k.partials = reinterpret_cast<double*>(ws + 64);
+    }
+    k.inv_chains =
+        link->n_chains_global > 0 ? 1.0 / (double)link->n_chains_global : 0.0;
+    k.pending = link->pending;
+    k.fresh = link->fresh_start ? 1.0f : 0.0f;
+    k.used_step_size = link->used_step_size;
+    k.tuner = TunerCfg{link->delta, link->gamma, link->t0, link->kappa,
+                       link->mu};
+  }
+  *out = k;
+  return ZSHMC_OK;
+}
+
+// a pending update without a transition (also: a rank that owns no chains
+// still has to retire the update and publish an empty sum)
+__global__ void stepsize_flush_kernel(AdaptLink k, int zero_stats) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (k.state && k.pending != ZSHMC_PEND_NONE) tuner_persist(k);
+  if (zero_stats && k.stats) {
+    k.stats[0] = 0.0;
+    k.stats[1] = 0.0;
+  }
+}
+
+}  // namespace zshmc
+
+extern "C" int zshmc_stepsize_flush(const zshmc_adapt_link* link,
+                                    void* stream) {
+  ZS_REQUIRE(link, "zshmc_stepsize_flush: null link");
+  AdaptLink k;
+  const int rc = make_link(link, &k, "zshmc_stepsize_flush");
+  if (rc != ZSHMC_OK) return rc;
+  if (k.pending == ZSHMC_PEND_NONE) return ZSHMC_OK;
+  hipLaunchKernelGGL(stepsize_flush_kernel, dim3(1), dim3(64), 0,
+                     reinterpret_cast<hipStream_t>(stream), k, 0);
+  ZS_LAUNCH_CHECK("stepsize_flush_kernel launch");
+  return ZSHMC_OK;
+}
+
 extern "C" int zshmc_hmc_diag_normal_step(
     float* q, const float* mean, const float* logstd, const float* mass,
-    const float* step_size_dev, float step_size_host, int64_t n_chains,
-    int64_t n_data, int64_t chain_offset, int n_leapfrogs, uint64_t seed,
-    uint32_t iteration, int commit, float* acceptance_rate,
-    float* orig_hamiltonian, float* hamiltonian, float* orig_log_prob,
-    float* log_prob, double* acc_sum, uint32_t* flags, void* stream) {
-  ZS_REQUIRE(q && mean && logstd, "zshmc_hmc_diag_normal_step: null q/mean/logstd");
+    float step_size_host, int64_t n_chains, int64_t n_data,
+    int64_t chain_offset, int n_leapfrogs, uint64_t seed, uint32_t iteration,
+    int commit, float* acceptance_rate, float* orig_hamiltonian,
+    float* hamiltonian, float* orig_log_prob, float* log_prob, uint32_t* flags,
+    const zshmc_adapt_link* link, void* stream) {
+  ZS_REQUIRE(q && logstd, "zshmc_hmc_diag_normal_step: null q/logstd");
   ZS_REQUIRE(n_chains >= 0 && n_data >= 1,
              "zshmc_hmc_diag_normal_step: bad shape [%lld, %lld]",
              (long long)n_chains, (long long)n_data);
@@ -438,13 +515,23 @@ extern "C" int zshmc_hmc_diag_normal_step(
   ZS_REQUIRE(n_leapfrogs >= 0, "zshmc_hmc_diag_normal_step: n_leapfrogs < 0");
   ZS_REQUIRE(n_chains + chain_offset <= 0xFFFFFFFFll,
              "zshmc_hmc_diag_normal_step: global chain index exceeds 2^32");
-  if (n_chains == 0) return ZSHMC_OK;
   FusedArgs a;
+  {
+    const int rc = make_link(link, &a.link, "zshmc_hmc_diag_normal_step");
+    if (rc != ZSHMC_OK) return rc;
+  }
+  if (n_chains == 0) {
+    if (a.link.stats || a.link.pending != ZSHMC_PEND_NONE) {
+      hipLaunchKernelGGL(stepsize_flush_kernel, dim3(1), dim3(64), 0,
+                         reinterpret_cast<hipStream_t>(stream), a.link, 1);
+      ZS_LAUNCH_CHECK("stepsize_flush_kernel launch");
+    }
+    return ZSHMC_OK;
+  }
   a.q = q;
   a.mean = mean;
   a.logstd = logstd;
   a.mass = mass;
-  a.step_size_dev = step_size_dev;
   a.step_size_host = step_size_host;
   a.n_chains = n_chains;
   a.n_data = n_data;
@@ -459,8 +546,9 @@ extern "C" int zshmc_hmc_diag_normal_step(
   a.hamiltonian = hamiltonian;
   a.orig_log_prob = orig_log_prob;
   a.log_prob = log_prob;
-  a.acc_sum = acc_sum;
   a.flags = flags;
+  a.info_cap = 0;
+  a.commit_direct = 0;
 #ifdef ZS_TIMING
   a.timing = reinterpret_cast<unsigned long long*>(orig_hamiltonian);  // debug
   a.orig_hamiltonian = nullptr;

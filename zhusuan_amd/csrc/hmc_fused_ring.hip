@@ -258,7 +258,9 @@ constexpr int ring_waves_for(int nch, bool has_mass) {
 // out) live in LDS under the chain's ticket (info_cap of them fit); otherwise
 // the uniform is drawn on the scalar unit and the five values are stored from
 // the trip loop (hand-counted, in the ledger).
-template <int NCH, int K, bool HAS_MASS, bool STAGE>
+// ZERO_MEAN: a.mean == NULL (every mean is 0, the usual prior): no mean tile
+// in LDS, no subtraction after the slot read, no re-addition before the store.
+template <int NCH, int K, bool HAS_MASS, bool STAGE, bool ZERO_MEAN>
 __global__ __launch_bounds__(256 * ring_waves_for(NCH, HAS_MASS)) void
 hmc_diag_normal_ring_kernel(FusedArgs a) {
   constexpr int kLedgerInfo = STAGE ? 0 : kInfoStores;
@@ -266,9 +268,10 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
   constexpr int kRowB = kRow * 4;
   constexpr int kWavesPerBlock = 4 * ring_waves_for(NCH, HAS_MASS);  // a CU
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* __restrict__ s_mean = reinterpret_cast<float*>(smem);
-  float* __restrict__ s_sqrtm = s_mean + kRow;  // only if HAS_MASS
-  float* __restrict__ s_ring = s_mean + (HAS_MASS ? 2 : 1) * kRow;
+  constexpr int kTiles = (ZERO_MEAN ? 0 : 1) + (HAS_MASS ? 1 : 0);
+  float* __restrict__ s_mean = reinterpret_cast<float*>(smem);  // !ZERO_MEAN
+  float* __restrict__ s_sqrtm = s_mean + (ZERO_MEAN ? 0 : kRow);  // HAS_MASS
+  float* __restrict__ s_ring = s_mean + kTiles * kRow;
   double* __restrict__ s_acc =
       reinterpret_cast<double*>(s_ring + kWavesPerBlock * K * kRow);
   int* __restrict__ s_bad = reinterpret_cast<int*>(s_acc + kWavesPerBlock);
@@ -312,16 +315,20 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
                              a.iteration, a.k0, a.k1);
 
   // ---- stage mean / sqrt(mass) in LDS (zero padding beyond n_data) --------
-  for (int d = threadIdx.x; d < kRow; d += blockDim.x) {
-    s_mean[d] = d < D ? a.mean[d] : 0.f;
-    if (HAS_MASS) s_sqrtm[d] = d < D ? sqrtf(a.mass[d]) : 0.f;
-  }
+  if (!ZERO_MEAN || HAS_MASS)
+    for (int d = threadIdx.x; d < kRow; d += blockDim.x) {
+      if (!ZERO_MEAN) s_mean[d] = d < D ? a.mean[d] : 0.f;
+      if (HAS_MASS) s_sqrtm[d] = d < D ? sqrtf(a.mass[d]) : 0.f;
+    }
   if (threadIdx.x == 0) {
     *s_bad = 0;
     *s_ticket = 0;
   }
 
-  const float eps = a.step_size_dev ? *a.step_size_dev : a.step_size_host;
+  // the step size of THIS transition: the pending dual-averaging update of
+  // the previous one is applied here (hmc.py:501-505 moved across the launch
+  // boundary), so an adaptive transition is still one launch
+  const float eps = link_step_size(a.link, a.step_size_host);
   const bool moving = eps != 0.f;
   const float se = moving ? eps : 1.f;
   const float inv_se = 1.0f / se;
@@ -348,6 +355,14 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
     }
   }
   const float logz = wave_total_dpp(logz_part);
+  // the drift's scalar factor: from an SGPR (v_pk_fma_f32 with a scalar
+  // operand) or pinned in a VGPR (A/B knob, tools/kbench.py)
+#ifdef ZS_EPS_VGPR
+  float eps_l = eps;
+  asm volatile("" : "+v"(eps_l));
+#else
+  const float eps_l = eps;
+#endif
   const int Lr = moving ? a.n_leapfrogs : 0;
   const float hk = moving ? 0.5f : 0.f;    // first half kick
   const float hk2 = Lr >= 1 ? 0.5f : 0.f;  // taken back from the last
@@ -410,10 +425,9 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
       const float* __restrict__ sl = ring_w + slot * kRow;
 #pragma unroll
       for (int k = 0; k < NCH; ++k) {
-        const f4 qv = *reinterpret_cast<const f4*>(sl + (k * kWave + lane) * 4);
-        const f4 mu =
-            *reinterpret_cast<const f4*>(s_mean + (k * kWave + lane) * 4);
-        r[k] = qv - mu;
+        r[k] = *reinterpret_cast<const f4*>(sl + (k * kWave + lane) * 4);
+        if (!ZERO_MEAN)
+          r[k] -= *reinterpret_cast<const f4*>(s_mean + (k * kWave + lane) * 4);
       }
       // the slot must be in registers before the DMA may overwrite it (the
       // same wait lands the ticket)
@@ -442,7 +456,11 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
     f4 ko = f4{0.f, 0.f, 0.f, 0.f}, uo = ko;
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
-      const uint32_t group = (uint32_t)(k * kWave + lane);
+      uint32_t group = (uint32_t)(k * kWave + lane);
+      // hipcc hoists the first Philox round's M0 * group out of the trip loop
+      // (2 VGPRs per chunk held for the whole kernel); where the budget has
+      // no room for that the counter word is made opaque per trip
+      if (NCH >= 7) asm volatile("" : "+v"(group));
       float z0, z1, z2, z3;
 #ifdef ZS_NO_RNG  // A/B probe only: how much of the trip is the generator
       z0 = __uint_as_float(0x3f000000u | ((group * 2654435761u + gchain) & 0x7fffffu));
@@ -474,15 +492,20 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
 #ifdef ZS_PRIO_LF
     __builtin_amdgcn_s_setprio(ZS_PRIO_LF);
 #endif
-    for (int i = 0; i < Lr; ++i) {
+    // (bottom-tested: a top-tested loop makes hipcc copy r and p into fresh
+    // registers on the zero-trip edge, 12-16 v_mov per chain)
+    if (Lr > 0) {
+      int i = Lr;
+      do {
 #pragma unroll
-      for (int k = 0; k < NCH; ++k) {
-        if (HAS_MASS)
-          r[k] += eim[k] * p[k];
-        else
-          r[k] += eps * p[k];
-        p[k] += nep[k] * r[k];
-      }
+        for (int k = 0; k < NCH; ++k) {
+          if (HAS_MASS)
+            r[k] += eim[k] * p[k];
+          else
+            r[k] += eps_l * p[k];
+          p[k] += nep[k] * r[k];
+        }
+      } while (--i > 0);
     }
 
 #ifdef ZS_PRIO_END
@@ -548,7 +571,9 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
 #endif
     const bool accept = u < acc;  // strict, hmc.py:486
 
-    if (lane == 0) acc_local += (double)acc;
+    // STAGE: the sum is taken from the staged values after the loop, in
+    // ticket order (which wave ran which chain varies from run to run)
+    if (!STAGE && lane == 0) acc_local += (double)acc;
 #ifdef ZS_TIMING
     ++n_done;
 #endif
@@ -559,9 +584,11 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
       const Mask m_acc = mask_if(accept && a.commit != 0);
       // q' = r + mean in place (r is dead after the store): all the LDS reads
       // of the mean tile go out together, ahead of the asm statements
+      if (!ZERO_MEAN) {
 #pragma unroll
-      for (int k = 0; k < NCH; ++k)
-        r[k] += *reinterpret_cast<const f4*>(s_mean + (k * kWave + lane) * 4);
+        for (int k = 0; k < NCH; ++k)
+          r[k] += *reinterpret_cast<const f4*>(s_mean + (k * kWave + lane) * 4);
+      }
       store_row<NCH>(voff, voff_last, r, qrow, m_acc,
                      Mask{m_acc.lo & m_last.lo, m_acc.hi & m_last.hi});
     }
@@ -604,16 +631,23 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
   }
 #endif
 
-  // ---- sum of acceptance rates: wave shuffle -> LDS -> one atomic/block --
+  // ---- sum of acceptance rates of this workgroup, then the order-fixed
+  // total over workgroups (link_retire) --------------------------------------
+  if (bad_old) *s_bad = 1;
+  __syncthreads();  // all waves done: s_info complete, s_bad final
+  if (STAGE) {
+    acc_local = 0.0;
+    for (int t = threadIdx.x; t < count; t += blockDim.x)
+      acc_local += (double)s_info[t];
+  }
   const double w = wave_sum_f64(acc_local);
   if (lane == 0) s_acc[wib] = w;
-  if (bad_old) *s_bad = 1;
   __syncthreads();
   if (threadIdx.x == 0) {
     double tot = 0.0;
     for (int i = 0; i < kWavesPerBlock; ++i) tot += s_acc[i];
-    if (a.acc_sum) atomicAdd(a.acc_sum, tot);
     if (*s_bad && a.flags) atomicOr(a.flags, ZSHMC_FLAG_OLD_LOGPROB_NONFINITE);
+    link_retire(a.link, tot, a.flags);
   }
   // ---- staged HMCInfo scalars -> global, G consecutive chains per line ----
   if (STAGE && a.commit) {
@@ -632,11 +666,12 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
 
 constexpr size_t kLdsLimit = 160 * 1024;
 
-template <int NCH, int K, bool HAS_MASS>
+template <int NCH, int K, bool HAS_MASS, bool ZERO_MEAN>
 static int launch_ring_cfg(const FusedArgs& a_in, hipStream_t stream) {
   constexpr int kWaves = 4 * ring_waves_for(NCH, HAS_MASS);
   constexpr size_t lds_base =
-      (size_t)((HAS_MASS ? 2 : 1) + kWaves * K) * NCH * 1024 +
+      (size_t)((ZERO_MEAN ? 0 : 1) + (HAS_MASS ? 1 : 0) + kWaves * K) * NCH *
+          1024 +
       kWaves * sizeof(double) + 16;
   static_assert(lds_base <= kLdsLimit, "ring does not fit in LDS");
   static bool ready = false;
@@ -644,12 +679,12 @@ static int launch_ring_cfg(const FusedArgs& a_in, hipStream_t stream) {
     // the ring needs more than the default 64 KiB dynamic-LDS cap
     hipError_t e = hipFuncSetAttribute(
         reinterpret_cast<const void*>(
-            hmc_diag_normal_ring_kernel<NCH, K, HAS_MASS, true>),
+            hmc_diag_normal_ring_kernel<NCH, K, HAS_MASS, true, ZERO_MEAN>),
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
     if (e == hipSuccess)
       e = hipFuncSetAttribute(
           reinterpret_cast<const void*>(
-              hmc_diag_normal_ring_kernel<NCH, K, HAS_MASS, false>),
+              hmc_diag_normal_ring_kernel<NCH, K, HAS_MASS, false, ZERO_MEAN>),
           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
     if (e != hipSuccess) return check_hip(e, "ring kernel: LDS size attribute");
     ready = true;
@@ -677,22 +712,28 @@ static int launch_ring_cfg(const FusedArgs& a_in, hipStream_t stream) {
   const size_t lds = lds_base + (stage ? (size_t)share * 24 : 0);
   const dim3 gdim(grid > 0 ? (unsigned)grid : 1u), bdim(64 * kWaves);
   if (stage)
-    hipLaunchKernelGGL((hmc_diag_normal_ring_kernel<NCH, K, HAS_MASS, true>),
-                       gdim, bdim, lds, stream, a);
+    hipLaunchKernelGGL(
+        (hmc_diag_normal_ring_kernel<NCH, K, HAS_MASS, true, ZERO_MEAN>), gdim,
+        bdim, lds, stream, a);
   else
-    hipLaunchKernelGGL((hmc_diag_normal_ring_kernel<NCH, K, HAS_MASS, false>),
-                       gdim, bdim, lds, stream, a);
+    hipLaunchKernelGGL(
+        (hmc_diag_normal_ring_kernel<NCH, K, HAS_MASS, false, ZERO_MEAN>), gdim,
+        bdim, lds, stream, a);
   ZS_LAUNCH_CHECK("hmc_diag_normal_ring_kernel launch");
   return ZSHMC_OK;
 }
 
 template <int NCH, int K>
 static int launch_ring_k(const FusedArgs& a, hipStream_t stream) {
-  return a.mass ? launch_ring_cfg<NCH, K, true>(a, stream)
-                : launch_ring_cfg<NCH, K, false>(a, stream);
+  if (a.mean)
+    return a.mass ? launch_ring_cfg<NCH, K, true, false>(a, stream)
+                  : launch_ring_cfg<NCH, K, false, false>(a, stream);
+  return a.mass ? launch_ring_cfg<NCH, K, true, true>(a, stream)
+                : launch_ring_cfg<NCH, K, false, true>(a, stream);
 }
 
-bool fused_ring_config(int64_t D, bool has_mass, int* nch_out, int* k_out) {
+bool fused_ring_config(int64_t D, bool has_mass, bool zero_mean, int* nch_out,
+                       int* k_out) {
   if (D % 4 != 0 || D <= 128 || D > 2048) return false;
   // NCH = ceil(D / 256) exactly: only the LAST 1 KiB chunk of a row may be
   // ragged (that is what voff_last / m_last handle)
@@ -700,6 +741,8 @@ bool fused_ring_config(int64_t D, bool has_mass, int* nch_out, int* k_out) {
   // 8 chunks + mass does not fit 256 VGPRs without scratch spills (VMEM the
   // ledger cannot count): that shape stays on the register-prefetch kernel
   if (nch == 8 && has_mass) return false;
+  // likewise 7 chunks + mass + a mean tile (one spilled VGPR)
+  if (nch == 7 && has_mass && !zero_mean) return false;
   *nch_out = nch;
   *k_out = nch <= 3 ? 3 : (nch == 4 ? ZS_RING_K4 : 2);
   return true;
@@ -715,7 +758,8 @@ bool fused_ring_enabled() {
 
 int launch_fused_ring(const FusedArgs& a, hipStream_t stream) {
   int nch = 0, k = 0;
-  const bool ok = fused_ring_config(a.n_data, a.mass != nullptr, &nch, &k) &&
+  const bool ok = fused_ring_config(a.n_data, a.mass != nullptr,
+                                    a.mean == nullptr, &nch, &k) &&
                   ((reinterpret_cast<uintptr_t>(a.q) & 15) == 0) &&
                   ((reinterpret_cast<uintptr_t>(a.logstd) & 15) == 0) &&
                   (!a.mass || (reinterpret_cast<uintptr_t>(a.mass) & 15) == 0) &&
@@ -728,8 +772,15 @@ int launch_fused_ring(const FusedArgs& a, hipStream_t stream) {
     case 4: return launch_ring_k<4, ZS_RING_K4>(a, stream);
     case 5: return launch_ring_k<5, 2>(a, stream);
     case 6: return launch_ring_k<6, 2>(a, stream);
-    case 7: return launch_ring_k<7, 2>(a, stream);
-    default: return launch_ring_cfg<8, 2, false>(a, stream);
+    case 7:
+      if (a.mass && a.mean) return ZSHMC_ERR_UNSUPPORTED;  // (not reached)
+      if (a.mean)
+        return launch_ring_cfg<7, 2, false, false>(a, stream);
+      return a.mass ? launch_ring_cfg<7, 2, true, true>(a, stream)
+                    : launch_ring_cfg<7, 2, false, true>(a, stream);
+    default:
+      return a.mean ? launch_ring_cfg<8, 2, false, false>(a, stream)
+                    : launch_ring_cfg<8, 2, false, true>(a, stream);
   }
 }
 

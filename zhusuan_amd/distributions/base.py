@@ -3,6 +3,8 @@ and the sample(n_samples) squeeze rule.  Mirrors reference
 zhusuan/distributions/base.py:17-332 on torch device tensors."""
 import torch
 
+from ..utils import broadcast_shapes
+
 __all__ = ['Distribution']
 
 
@@ -124,7 +126,7 @@ class Distribution(object):
         sample_shape = tuple(self.get_batch_shape()) + tuple(
             self.get_value_shape())
         try:
-            torch.broadcast_shapes(tuple(given.shape), sample_shape)
+            broadcast_shapes(tuple(given.shape), sample_shape)
         except RuntimeError:
             raise ValueError(
                 err_msg + " ({} vs. {} + {})".format(

@@ -5,6 +5,8 @@ multivariate.py:339-449) and MultivariateNormalCholesky (SURVEY 8f-4;
 multivariate.py:41-193)."""
 import torch
 
+from ..utils import broadcast_shapes
+
 from .. import _capi, _ops
 from ..utils import next_op_offset
 from .base import Distribution, as_tensor, common_device, default_device
@@ -107,7 +109,7 @@ class MultivariateNormalCholesky(Distribution):
     def _log_prob(self, given):
         mean = self.path_param(self._mean)
         tril = self.path_param(self._cov_tril)
-        full = torch.broadcast_shapes(given.shape, mean.shape)
+        full = broadcast_shapes(given.shape, mean.shape)
         x = given if tuple(given.shape) == tuple(full) else given.expand(full)
         mb = tuple(mean.shape[:-1])
         if len(mb) and tuple(full[len(full) - 1 - len(mb):-1]) != mb:
@@ -248,7 +250,7 @@ class UnnormalizedMultinomial(Distribution):
                     lazy.theta, lazy.phi, given.reshape(-1, n_cat))
             self._logits = lazy.dense()
         try:
-            full = torch.broadcast_shapes(given.shape, self.logits.shape)
+            full = broadcast_shapes(given.shape, self.logits.shape)
         except RuntimeError:
             raise ValueError(
                 "given and logits cannot broadcast to match. ({} vs. {})"

@@ -5,6 +5,8 @@ zhusuan/distributions/univariate.py:43-184 (Normal), :334-406 (Bernoulli),
 csrc/distributions.hip through zhusuan_amd._ops."""
 import torch
 
+from ..utils import broadcast_shapes
+
 from .. import _capi, _ops
 from ..utils import next_op_offset
 from .base import Distribution, as_tensor, common_device, default_device
@@ -58,32 +60,41 @@ class Normal(Distribution):
         f32 = torch.float32
         self._mean = as_tensor(mean, dtype=None if isinstance(
             mean, torch.Tensor) else f32, device=dev)
+        # The parameter that was not given is derived on first use (a model
+        # function is re-evaluated on every transition: an eager exp / log
+        # would be one more kernel launch per evaluation), unless
+        # check_numerics wants it inspected here.
         if logstd is None:
             self._std = as_tensor(std, dtype=None if isinstance(
                 std, torch.Tensor) else f32, device=dev)
             dtype = _assert_same_float_dtype([(self._mean, 'Normal.mean'),
                                               (self._std, 'Normal.std')])
-            self._logstd = torch.log(self._std)          # :99
+            self._logstd = None                          # log(std), :99
             if check_numerics and not bool(
-                    torch.isfinite(self._logstd).all()):
+                    torch.isfinite(self.logstd).all()):
                 raise FloatingPointError("log(std) : Tensor had Inf or NaN")
+            given = self._std
+            self._given_spread = ('std', given)
         else:
             self._logstd = as_tensor(logstd, dtype=None if isinstance(
                 logstd, torch.Tensor) else f32, device=dev)
             dtype = _assert_same_float_dtype(
                 [(self._mean, 'Normal.mean'),
                  (self._logstd, 'Normal.logstd')])
-            self._std = torch.exp(self._logstd)          # :108
-            if check_numerics and not bool(torch.isfinite(self._std).all()):
+            self._std = None                             # exp(logstd), :108
+            if check_numerics and not bool(torch.isfinite(self.std).all()):
                 raise FloatingPointError("exp(logstd) : Tensor had Inf or NaN")
+            given = self._logstd
+            self._given_spread = ('logstd', given)
         _require_f32(dtype, 'Normal')
         try:
-            torch.broadcast_shapes(self._mean.shape, self._std.shape)
+            self._batch_shape_static = broadcast_shapes(self._mean.shape,
+                                                        given.shape)
         except RuntimeError:
             raise ValueError(
                 "mean and std/logstd should be broadcastable to match each "
                 "other. ({} vs. {})".format(tuple(self._mean.shape),
-                                            tuple(self._std.shape)))
+                                            tuple(given.shape)))
         self._check_numerics = check_numerics
         super(Normal, self).__init__(
             dtype=dtype, param_dtype=dtype, is_continuous=True,
@@ -96,11 +107,21 @@ class Normal(Distribution):
         return self._mean
 
     @property
+    def given_spread(self):
+        """('std' | 'logstd', tensor): the parameter the constructor was
+        given (the other one is derived on first use)."""
+        return self._given_spread
+
+    @property
     def logstd(self):
+        if self._logstd is None:
+            self._logstd = torch.log(self._std)
         return self._logstd
 
     @property
     def std(self):
+        if self._std is None:
+            self._std = torch.exp(self._logstd)
         return self._std
 
     def _device(self):
@@ -110,11 +131,11 @@ class Normal(Distribution):
         return torch.Size([])
 
     def _get_batch_shape(self):
-        return torch.broadcast_shapes(self._mean.shape, self._std.shape)
+        return self._batch_shape_static
 
     def _sample(self, n_samples):
         """univariate.py:161-172 on the Philox STREAM_DIST stream."""
-        mean, std = self._mean, self._std
+        mean, std = self._mean, self.std
         if not self.is_reparameterized:
             mean, std = mean.detach(), std.detach()
         batch = self._get_batch_shape()
@@ -150,8 +171,8 @@ class Normal(Distribution):
 
     def _log_prob_grouped(self, given):
         mean = self.path_param(self._mean)
-        logstd = self.path_param(self._logstd)
-        full = torch.broadcast_shapes(given.shape, mean.shape, logstd.shape)
+        logstd = self.path_param(self.logstd)
+        full = broadcast_shapes(given.shape, mean.shape, logstd.shape)
         if self._group_ndims > len(full):
             raise ValueError("group_ndims {} exceeds log_prob rank {}"
                              .format(self._group_ndims, len(full)))
@@ -164,7 +185,7 @@ class Normal(Distribution):
     def _log_prob(self, given):
         return _ops.NormalLogProb.apply(
             given, self.path_param(self._mean),
-            self.path_param(self._logstd), 0)
+            self.path_param(self.logstd), 0)
 
 
 class LinearLogits(object):
@@ -268,6 +289,9 @@ class Bernoulli(Distribution):
         lazy = self._lazy
         if (lazy is not None and self._group_ndims >= 1 and
                 given.dim() == 1 and given.shape[0] == lazy.X.shape[0] and
+                # the fused kernel differentiates w.r.t. w only: a design
+                # matrix that needs a gradient takes the dense path
+                not lazy.X.requires_grad and not given.requires_grad and
                 lazy.w.shape[-1] <= _ops.LINEAR_BERNOULLI_WIDTHS[-1] and
                 lazy.w.dim() - 1 >= self._group_ndims - 1):
             ll = _ops.LinearBernoulliLogLik.apply(lazy.w, lazy.X, given)
@@ -277,7 +301,7 @@ class Bernoulli(Distribution):
         if self._logits is None:
             self._logits = lazy.dense()
         try:
-            full = torch.broadcast_shapes(given.shape, self._logits.shape)
+            full = broadcast_shapes(given.shape, self._logits.shape)
         except RuntimeError:
             raise ValueError(
                 "given and logits cannot broadcast to match. ({} vs. {})"
@@ -353,7 +377,7 @@ class Categorical(Distribution):
     def _log_prob(self, given):
         # :499-505 explicit broadcast of given vs logits[..., :-1]
         try:
-            batch = torch.broadcast_shapes(given.shape,
+            batch = broadcast_shapes(given.shape,
                                            self._logits.shape[:-1])
         except RuntimeError:
             raise ValueError(

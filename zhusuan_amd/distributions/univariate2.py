@@ -6,6 +6,8 @@ rules; log_prob, its analytic gradients and sampling run in the HIP kernels
 of csrc/distributions2.hip."""
 import torch
 
+from ..utils import broadcast_shapes
+
 from .. import _capi, _ops
 from ..utils import next_op_offset
 from .base import Distribution, as_tensor, common_device, default_device
@@ -33,7 +35,7 @@ class _TwoParam(Distribution):
              (self._b, '%s.%s' % (cls, self._names[1]))])
         _require_f32(dtype, cls)
         try:
-            torch.broadcast_shapes(self._a.shape, self._b.shape)
+            broadcast_shapes(self._a.shape, self._b.shape)
         except RuntimeError:
             raise ValueError(
                 "{} and {} should be broadcastable to match each "
@@ -54,14 +56,14 @@ class _TwoParam(Distribution):
         return torch.Size([])
 
     def _get_batch_shape(self):
-        return torch.broadcast_shapes(self._a.shape, self._b.shape)
+        return broadcast_shapes(self._a.shape, self._b.shape)
 
     def _params_for_log_prob(self):
         return self._a, self._b
 
     def _log_prob_grouped(self, given):
         a, b = self._params_for_log_prob()
-        full = torch.broadcast_shapes(given.shape, a.shape, b.shape)
+        full = broadcast_shapes(given.shape, a.shape, b.shape)
         if self._group_ndims > len(full):
             raise ValueError("group_ndims {} exceeds log_prob rank {}"
                              .format(self._group_ndims, len(full)))

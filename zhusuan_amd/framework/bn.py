@@ -6,6 +6,8 @@ torch device tensors; log-probs come from the HIP kernels via
 zhusuan_amd.distributions."""
 import torch
 
+from ..utils import broadcast_shapes
+
 from .. import distributions
 from ..distributions.base import as_tensor
 from .meta_bn import active_frame
@@ -41,7 +43,7 @@ class StochasticTensor(object):
         dist_shape = tuple(self._dist.get_batch_shape()) + tuple(
             self._dist.get_value_shape())
         try:
-            torch.broadcast_shapes(dist_shape, tuple(observation.shape))
+            broadcast_shapes(dist_shape, tuple(observation.shape))
         except RuntimeError:
             raise ValueError(shape_msg.format(
                 self.__class__.__name__, self._name, dist_shape,
@@ -161,44 +163,36 @@ class _BayesianNet(object):
         self._nodes[name] = input_tensor
         return input_tensor
 
-    def _check_name_exist(self, name, only_stochastic=False):
-        if not isinstance(name, str):
-            raise TypeError(
-                "Expected string in `name_or_names`, got {} of type {}."
-                .format(repr(name), type(name)))
-        if name not in self._nodes:
-            raise ValueError("There isn't a node named '{}' in the {}."
-                             .format(name, BayesianNet.__name__))
-        elif only_stochastic and not isinstance(
-                self._nodes[name], StochasticTensor):
-            raise ValueError("Node '{}' is deterministic (input or output)."
-                             .format(name))
-        return name
-
-    def _check_names_exist(self, name_or_names, only_stochastic=False):
-        if isinstance(name_or_names, str):
-            names = (name_or_names,)
-        else:
-            name_or_names = tuple(name_or_names)
-            names = name_or_names
-        for name in names:
-            self._check_name_exist(name, only_stochastic=only_stochastic)
-        return name_or_names
+    def _resolve(self, name_or_names, stochastic_only, pick):
+        """Shared lookup of `get` / `cond_log_prob` (bn.py:420-452): one name
+        -> one result, any other iterable of names -> a list; the error
+        classes and messages are the reference's (bn.py:386-403)."""
+        single = isinstance(name_or_names, str)
+        picked = []
+        for name in ((name_or_names,) if single else tuple(name_or_names)):
+            if not isinstance(name, str):
+                raise TypeError(
+                    "Expected string in `name_or_names`, got {} of type {}."
+                    .format(repr(name), type(name)))
+            node = self._nodes.get(name, self)     # self: "absent" marker
+            if node is self:
+                raise ValueError("There isn't a node named '{}' in the {}."
+                                 .format(name, BayesianNet.__name__))
+            if stochastic_only and not isinstance(node, StochasticTensor):
+                raise ValueError(
+                    "Node '{}' is deterministic (input or output)."
+                    .format(name))
+            picked.append(pick(node))
+        return picked[0] if single else picked
 
     def get(self, name_or_names):
-        """bn.py:420-435."""
-        name_or_names = self._check_names_exist(name_or_names)
-        if isinstance(name_or_names, tuple):
-            return [self._nodes[name] for name in name_or_names]
-        return self._nodes[name_or_names]
+        """Node(s) by name (bn.py:420-435)."""
+        return self._resolve(name_or_names, False, lambda node: node)
 
     def cond_log_prob(self, name_or_names):
-        """bn.py:437-452."""
-        name_or_names = self._check_names_exist(name_or_names,
-                                                only_stochastic=True)
-        if isinstance(name_or_names, tuple):
-            return [self._nodes[name].cond_log_p for name in name_or_names]
-        return self._nodes[name_or_names].cond_log_p
+        """Conditional log-density of stochastic node(s) (bn.py:437-452)."""
+        return self._resolve(name_or_names, True,
+                             lambda node: node.cond_log_p)
 
     def _log_joint(self):
         """The owner's `log_joint(bn)` if one was assigned, else the sum of
@@ -221,8 +215,7 @@ class _BayesianNet(object):
         return self._log_joint_cache
 
     def __getitem__(self, name):
-        name = self._check_name_exist(name)
-        return self._nodes[name]
+        return self._resolve((name,), False, lambda node: node)[0]
 
     # -- factory methods on the HMC path ------------------------------------
     def normal(self, name, mean=0., _sentinel=None, std=None, logstd=None,

@@ -25,6 +25,8 @@ Two execution plans, chosen in `sample()`:
 Both use the same RNG counters and the same on-device adaptation state.
 """
 
+import ctypes
+
 import torch
 
 from . import _capi
@@ -126,15 +128,26 @@ class HMCInfo(object):
 
     def __init__(self, samples, acceptance_rate, updated_step_size,
                  init_momentum, orig_hamiltonian, hamiltonian, orig_log_prob,
-                 log_prob):
+                 log_prob, _flush=None):
         self.samples = samples
         self.acceptance_rate = acceptance_rate
-        self.updated_step_size = updated_step_size
+        self._updated_step_size = updated_step_size
+        self._flush = _flush
         self.init_momentum = init_momentum
         self.orig_hamiltonian = orig_hamiltonian
         self.hamiltonian = hamiltonian
         self.orig_log_prob = orig_log_prob
         self.log_prob = log_prob
+
+
+    @property
+    def updated_step_size(self):
+        """Step size for the NEXT iteration (hmc.py:514).  The fused plan
+        applies the dual-averaging update of a transition in the prologue of
+        the following launch; reading the value retires a pending update."""
+        if self._flush is not None:
+            self._flush()
+        return self._updated_step_size
 
 
 class _LazyMomentum(dict):
@@ -288,6 +301,7 @@ class HMC(object):
             samples=dict(zip(latent_k, latent_v)),
             acceptance_rate=plan.acceptance_rate.view(chain_shape),
             updated_step_size=st[_capi.ST_STEP_SIZE],
+            _flush=self.flush,
             init_momentum=_LazyMomentum(plan),
             orig_hamiltonian=plan.orig_hamiltonian.view(chain_shape),
             hamiltonian=plan.hamiltonian.view(chain_shape),
@@ -321,14 +335,17 @@ class HMC(object):
             self.adapt_mass, feed_dict, 'adapt_mass')
         stream = _capi.current_stream()
         sh = self.sharding
+        plan.refresh_model()          # parameters fed / updated since last run
 
-        # mass (hmc.py:452-456, :284-305)
+        # mass (hmc.py:452-456, :284-305); with sharded chains its column
+        # sums and the previous transition's acceptance sum travel together
         use_mass = False
         if self.adapt_mass is not None:
             use_ones = t < self.mass_collect_iters        # hmc.py:299-302
             plan.update_mass(adapt_m, use_ones, stream, sh)
             use_mass = not use_ones
         plan.use_mass = use_mass
+        plan.reduce_stats(sh, stream)
 
         # step size for this iteration (hmc.py:463-472)
         init = False
@@ -342,10 +359,9 @@ class HMC(object):
         # With the adapt flag off, hmc.py:108-110 re-assigns
         # step_size <- exp(log_epsilon_bar) every iteration: after two such
         # updates in a row the whole sampler state is at its fixed point, so
-        # neither the mean acceptance (and its all-reduce) nor the update
-        # kernel has anything left to do -- the transition is then exactly one
-        # kernel launch.  (ST_MEAN_ACCEPT, a diagnostic slot, keeps the value of
-        # the last update launch.)
+        # neither the mean acceptance (and its all-reduce) nor the update has
+        # anything left to do.  (ST_MEAN_ACCEPT, a diagnostic slot, keeps the
+        # value of the last update.)
         steady = (self.adapt_step_size is not None and not adapt_ss and
                   not init and self._nonadaptive_streak >= 2 and
                   getattr(plan, 'can_skip_acc', False))
@@ -356,19 +372,17 @@ class HMC(object):
         if self.adapt_step_size is not None and not steady:   # hmc.py:501-505
             self._nonadaptive_streak = 0 if (adapt_ss or init) else \
                 self._nonadaptive_streak + 1
-            if sh is not None:
-                sh.all_reduce_sum(plan.acc_sum)
-            _capi.call('zshmc_stepsize_update', plan.state.data_ptr(),
-                       plan.acc_sum.data_ptr(), plan.n_chains_global,
-                       int(adapt_ss), int(init),
-                       self.target_acceptance_rate, self.gamma, self.t0,
-                       self.kappa, 10.0 * self._init_step_size_value, stream)
-            if eps_host is not None:
-                _capi.call('zshmc_state_set', plan.state.data_ptr(),
-                           _capi.ST_USED_STEP_SIZE, float(eps_host), stream)
+            plan.stepsize_update(adapt_ss, init, eps_host, stream, sh)
         self._pending_check = True
         if sync:
             self.check_numerics()
+
+    def flush(self):
+        """Retire a step-size update still owed to the last transition (the
+        fused plan carries it into the next launch); afterwards the device
+        state block holds `updated_step_size` & co."""
+        if self._plan is not None:
+            self._plan.flush(_capi.current_stream(), self.sharding)
 
     def _search_step_size(self, plan, stream, sh):
         """HMC._init_step_size (hmc.py:308-345): host-driven loop of dry-run
@@ -376,6 +390,7 @@ class HMC(object):
         and t == mass_collect_iters, so the host sync is off the hot loop."""
         factor = 1.5
         f32 = lambda x: float(torch.tensor(x, dtype=torch.float32))
+        plan.flush(stream, sh)
         step_size = float(plan.state[_capi.ST_STEP_SIZE].item())
         delta = f32(self.target_acceptance_rate)
         last = 1.0
@@ -383,12 +398,14 @@ class HMC(object):
         trips = 0
         plan.begin_search(self.t, stream)
         while cond:
-            plan.acc_sum.zero_()
             plan.search_trip(self.t, step_size, stream)
-            if sh is not None:
-                sh.all_reduce_sum(plan.acc_sum)
-            acc = f32(plan.acc_sum.item() / plan.n_chains_global)
-            self.check_numerics(sync=False)
+            plan.reduce_stats(sh, stream)
+            acc_sum, bad = plan.stats[:2].tolist()
+            plan.end_search_trip()
+            acc = f32(acc_sum / plan.n_chains_global)
+            if bad > 0:      # every rank sees the reduced flag: all raise
+                plan.flags.zero_()
+                raise InvalidArgumentError(OLD_LOG_PROB_MSG)
             if acc < delta:
                 new_step = f32(step_size * f32(1.0 / factor))
             else:
@@ -398,21 +415,28 @@ class HMC(object):
             trips += 1
             if trips > 200:
                 raise RuntimeError("step-size search did not terminate")
-        plan.acc_sum.zero_()
         self.n_init_trips = trips
         return step_size
 
     def check_numerics(self, sync=True):
         """Raise InvalidArgumentError if any transition since the last check
-        started from a non-finite log-prob (tf.check_numerics, hmc.py:51-53)."""
+        started from a non-finite log-prob (tf.check_numerics, hmc.py:51-53).
+        With sharded chains the flag is summed over ranks first, so every rank
+        raises (a rank raising alone would leave its peers in a collective)."""
         if self._plan is None:
             return
-        if sync:
+        plan = self._plan
+        self.flush()
+        flags = plan.flags
+        if self.sharding is not None and self.sharding.world_size > 1:
+            flags = self.sharding.all_reduce_sum(
+                (plan.flags != 0).to(torch.float64))
+        elif sync:
             torch.cuda.current_stream().synchronize()
-        flags = int(self._plan.flags.item())
+        bad = int(flags.item()) != 0
         self._pending_check = False
-        if flags & _capi.FLAG_OLD_LOGPROB_NONFINITE:
-            self._plan.flags.zero_()
+        if bad:
+            plan.flags.zero_()
             raise InvalidArgumentError(OLD_LOG_PROB_MSG)
 
     # -- checkpoint / resume of the sampler state (SURVEY.md section 5) -----
@@ -420,6 +444,7 @@ class HMC(object):
         """Sampler state as host values: t, step_size, tuner triple, EWMV
         t/mean/var (the tf.Variables of hmc.py:82-87,118-123,258-264)."""
         plan = self._plan
+        self.flush()
         st = plan.state.cpu()
         out = {'t': self.t, 'state': st.clone(), 'seed': self.seed}
         if self.adapt_mass is not None:
@@ -430,6 +455,7 @@ class HMC(object):
 
     def set_state(self, state):
         plan = self._plan
+        plan.pending = None
         self._nonadaptive_streak = 0
         self.t = int(state['t'])
         self.seed = int(state['seed'])
@@ -471,7 +497,17 @@ class _PlanBase(object):
         f32 = dict(dtype=torch.float32, device=device)
         C = self.n_chains
         self.state = torch.zeros(_capi.STATE_WORDS, **f32)
-        self.acc_sum = torch.zeros(1, dtype=torch.float64, device=device)
+        # Everything that may cross GPUs in one transition sits in ONE buffer
+        # so that it is ONE all-reduce: [0] sum of acceptance
+        # rates, [1] non-finite-start flag, then per latent the 2*D column
+        # sums of the mass estimator (hmc.py:138,143).
+        n_col = 2 * sum(self.n_data) if hmc.adapt_mass is not None else 0
+        self.comm_buf = torch.zeros(_capi.STATS_WORDS + n_col,
+                                    dtype=torch.float64, device=device)
+        self.stats = self.comm_buf[:_capi.STATS_WORDS]
+        self.acc_sum = self.comm_buf[:1]
+        self.stats_local = False      # stats not yet summed over the ranks
+        self.pending = None           # (kind, fresh, used step size) owed
         self.flags = torch.zeros(1, dtype=torch.int32, device=device)
         self.acceptance_rate = torch.zeros(C, **f32)
         self.orig_hamiltonian = torch.zeros(C, **f32)
@@ -483,20 +519,34 @@ class _PlanBase(object):
             self.mass = [torch.ones(d, **f32) for d in self.n_data]
             self.ewmv_mean = [torch.zeros(d, **f32) for d in self.n_data]
             self.ewmv_var = [torch.zeros(d, **f32) for d in self.n_data]
-            self.colsum = [torch.zeros(2 * d, dtype=torch.float64,
-                                       device=device) for d in self.n_data]
+            self.colsum, off = [], _capi.STATS_WORDS
+            for d in self.n_data:
+                self.colsum.append(self.comm_buf[off:off + 2 * d])
+                off += 2 * d
         self.last_t = 0
 
+    def refresh_model(self):
+        """Called at the start of every run: the generic plan re-evaluates the
+        model function on every gradient anyway."""
+
     def update_mass(self, update, use_ones, stream, sharding):
-        """HMC._adapt_mass (hmc.py:284-305) for every latent."""
+        """HMC._adapt_mass (hmc.py:284-305) for every latent: column sums of
+        all latents, ONE all-reduce (carrying the previous transition's
+        acceptance sum along when that is still local), then the updates."""
         hmc = self.hmc
-        for k, q in enumerate(self.q):
-            if update:
+        if update:
+            for k, q in enumerate(self.q):
                 _capi.call('zshmc_mass_colstats', q.data_ptr(),
                            self.ewmv_mean[k].data_ptr(), self.n_chains,
                            self.n_data[k], self.colsum[k].data_ptr(), stream)
-                if sharding is not None:
-                    sharding.all_reduce_sum(self.colsum[k])
+            if sharding is not None and sharding.world_size > 1:
+                if self.stats_local:
+                    sharding.all_reduce_sum(self.comm_buf)
+                    self.stats_local = False
+                else:
+                    sharding.all_reduce_sum(
+                        self.comm_buf[_capi.STATS_WORDS:])
+        for k in range(len(self.q)):
             # EWMV.t is shared by all latents (hmc.py:118,131): bump once,
             # after the last latent
             last = k == len(self.q) - 1
@@ -507,6 +557,19 @@ class _PlanBase(object):
                        self.n_data[k], hmc.mass_decay,
                        (1 if last else 2) if update else 0,
                        int(use_ones), self.mass[k].data_ptr(), stream)
+
+    def reduce_stats(self, sharding, stream):
+        """Sum the acceptance statistic over the ranks if that is still owed."""
+        if self.stats_local:
+            if sharding is not None and sharding.world_size > 1:
+                sharding.all_reduce_sum(self.stats)
+            self.stats_local = False
+
+    def flush(self, stream, sharding):
+        pass
+
+    def end_search_trip(self):
+        pass
 
     def mass_ptr(self, k):
         return self.mass[k].data_ptr() if self.use_mass else None
@@ -520,25 +583,101 @@ class _PlanBase(object):
                    _capi.current_stream())
         return p
 
+    def _tuner_update_eager(self, adapt_ss, init, eps_host, stream, sharding):
+        """hmc.py:501-505 as its own launch (acc_sum filled by atomics)."""
+        hmc = self.hmc
+        if sharding is not None:
+            sharding.all_reduce_sum(self.acc_sum)
+        _capi.call('zshmc_stepsize_update', self.state.data_ptr(),
+                   self.acc_sum.data_ptr(), self.n_chains_global,
+                   int(adapt_ss), int(init), hmc.target_acceptance_rate,
+                   hmc.gamma, hmc.t0, hmc.kappa,
+                   10.0 * hmc._init_step_size_value, stream)
+        if eps_host is not None:
+            _capi.call('zshmc_state_set', self.state.data_ptr(),
+                       _capi.ST_USED_STEP_SIZE, float(eps_host), stream)
+
 
 class _FusedDiagNormalPlan(_PlanBase):
-    """One kernel per transition (csrc/hmc_fused_normal.hip)."""
+    """One kernel per transition (csrc/hmc_fused_ring.hip /
+    hmc_fused_normal.hip), adaptive or not: the dual-averaging update of
+    transition t rides in the prologue of launch t+1 (include/zshmc.h,
+    zshmc_adapt_link)."""
     kind = 'fused_diag_normal'
-    can_skip_acc = True      # the kernel skips its acceptance sum on acc_sum=NULL
+    can_skip_acc = True      # no statistics are collected when stats is NULL
     collect_acc = True
 
-    def __init__(self, hmc, names, values, chain_shape, device, mean, logstd):
+    def __init__(self, hmc, names, values, chain_shape, device, probe):
         super(_FusedDiagNormalPlan, self).__init__(hmc, names, values,
                                                    chain_shape, device)
-        self.mean = mean
-        self.logstd = logstd
+        self._probe = probe
+        self._src = None
+        self.workspace = torch.zeros(_capi.LINK_WORKSPACE_BYTES,
+                                     dtype=torch.uint8, device=device)
+        f32 = dict(dtype=torch.float32, device=device)
+        self.mean = torch.zeros(self.n_data[0], **f32)
+        self.logstd = torch.zeros(self.n_data[0], **f32)
+        self.zero_mean = True
+        self.refresh_model()
+
+    def refresh_model(self):
+        """Re-resolve the Normal's parameters (the generic plan re-runs the
+        model function on every transition; a parameter fed through a
+        placeholder -- lntm_mcem.py:164-169 -- or updated in place between
+        runs must reach the fused kernel too).  The model function is
+        re-evaluated (host only); device copies happen only when a parameter
+        tensor is a different object or version than last time."""
+        mean_src, spread_src, dist = self._probe()
+        src = self._src
+        if (src is not None and src[0] is mean_src and src[1] is spread_src
+                and src[2] == mean_src._version
+                and src[3] == spread_src._version):
+            return
+        data_shape = tuple(self.q[0].shape[len(self.chain_shape):])
+        mean_d = _to_data_shape(dist.mean, data_shape)
+        logstd_d = _to_data_shape(dist.logstd, data_shape)
+        if mean_d is None or logstd_d is None:
+            raise ValueError(
+                "HMC (fused diagonal-Normal plan): the parameters of '{}' "
+                "now vary along the chain axes; build a new HMC for the "
+                "changed model.".format(self.names[0]))
+        self.mean.copy_(mean_d)
+        self.logstd.copy_(logstd_d)
+        self.zero_mean = not bool(mean_d.any().item())
+        self._src = (mean_src, spread_src, mean_src._version,
+                     spread_src._version)
+
+    def _link(self, eps_host, collect):
+        hmc = self.hmc
+        k = _capi.AdaptLink()
+        k.state = None if eps_host is not None else self.state.data_ptr()
+        k.stats = self.stats.data_ptr() if collect else None
+        k.workspace = self.workspace.data_ptr()
+        k.n_chains_global = self.n_chains_global
+        k.pending, k.fresh_start = _capi.PEND_NONE, 0
+        k.used_step_size = float('nan')
+        k.delta, k.gamma = hmc.target_acceptance_rate, hmc.gamma
+        k.t0, k.kappa = hmc.t0, hmc.kappa
+        k.mu = 10.0 * hmc._init_step_size_value            # hmc.py:79 (sic)
+        if self.pending is not None:
+            kind, fresh, used = self.pending
+            k.pending, k.fresh_start = kind, int(fresh)
+            if used is not None:
+                k.used_step_size = float(used)
+        return k
 
     def _launch(self, t, eps_host, commit, n_leapfrogs, stream):
         info = commit
+        if self.pending is not None and eps_host is not None:
+            raise RuntimeError("a pending step-size update must be flushed "
+                               "before a launch with a host step size")
+        # a launch that retires a pending update also publishes its sum
+        collect = self.collect_acc or not commit or self.pending is not None
+        link = self._link(eps_host, collect)
         _capi.call(
             'zshmc_hmc_diag_normal_step', self.q[0].data_ptr(),
-            self.mean.data_ptr(), self.logstd.data_ptr(), self.mass_ptr(0),
-            None if eps_host is not None else self.state.data_ptr(),
+            None if self.zero_mean else self.mean.data_ptr(),
+            self.logstd.data_ptr(), self.mass_ptr(0),
             0.0 if eps_host is None else float(eps_host),
             self.n_chains, self.n_data[0], self.chain_offset, n_leapfrogs,
             self.hmc.seed, t & 0xFFFFFFFF, int(commit),
@@ -547,8 +686,25 @@ class _FusedDiagNormalPlan(_PlanBase):
             self.hamiltonian.data_ptr() if info else None,
             self.orig_log_prob.data_ptr() if info else None,
             self.log_prob.data_ptr() if info else None,
-            self.acc_sum.data_ptr() if (self.collect_acc or not commit)
-            else None, self.flags.data_ptr(), stream)
+            self.flags.data_ptr(), ctypes.byref(link), stream)
+        self.pending = None            # retired by this launch
+        if collect:
+            sh = self.hmc.sharding
+            self.stats_local = sh is not None and sh.world_size > 1
+
+    def stepsize_update(self, adapt_ss, init, eps_host, stream, sharding):
+        """hmc.py:501-505, deferred: recorded here, applied by the next
+        launch (or by flush())."""
+        self.pending = (_capi.PEND_ADAPT if adapt_ss else _capi.PEND_HOLD,
+                        bool(init), eps_host)
+
+    def flush(self, stream, sharding):
+        if self.pending is None:
+            return
+        self.reduce_stats(sharding, stream)
+        link = self._link(None, True)
+        _capi.call('zshmc_stepsize_flush', ctypes.byref(link), stream)
+        self.pending = None
 
     def begin_search(self, t, stream):
         pass
@@ -589,6 +745,7 @@ class _GenericPlan(_PlanBase):
         self.kin_new = torch.zeros(C, **f32)
         self.accept = torch.zeros(C, dtype=torch.uint8, device=device)
         self._search_cache = None
+        self._in_search = False
 
     def value_and_grad(self, qs):
         """log p(q) per chain and d/dq (hmc.py:426-432)."""
@@ -627,7 +784,25 @@ class _GenericPlan(_PlanBase):
         lp0, g0 = self.value_and_grad(self.q)
         self._search_cache = (lp0, g0)
 
+    def stepsize_update(self, adapt_ss, init, eps_host, stream, sharding):
+        self._tuner_update_eager(adapt_ss, init, eps_host, stream, sharding)
+
+    def reduce_stats(self, sharding, stream):
+        """Only the step-size search asks (the transition's own sum is
+        reduced and consumed by stepsize_update): acceptance sum and the
+        non-finite flag of the last dry run, summed over ranks."""
+        if not self._in_search:
+            return
+        self.stats[1] = (self.flags != 0).to(torch.float64)[0]
+        if sharding is not None and sharding.world_size > 1:
+            sharding.all_reduce_sum(self.stats)
+
+    def end_search_trip(self):
+        self.stats.zero_()
+        self._in_search = False
+
     def search_trip(self, t, step_size, stream):
+        self._in_search = True
         lp0, g0 = self._search_cache
         q1 = [q.clone() for q in self.q]
         p1 = [p.clone() for p in self.p]
@@ -709,25 +884,40 @@ def _try_fused_plan(hmc, meta_bn, names, values, chain_shape, device):
     n_chain_dims = len(chain_shape)
     data_shape = tuple(q.shape[n_chain_dims:])
     n_data = _prod(data_shape)
-    if n_data > int(_capi.load().zshmc_fused_max_n_data()):
+    if n_data == 0 or n_data > int(_capi.load().zshmc_fused_max_n_data()):
         return None
-    probe = q.detach().requires_grad_(True)
-    bn = meta_bn.observe(**merge_dicts({name: probe},
-                                      hmc._resolved_observed()))
-    stoch = [n for n in bn.nodes.values() if isinstance(n, StochasticTensor)]
-    if len(stoch) != 1 or stoch[0].name != name:
+
+    def node_dist(value):
+        bn = meta_bn.observe(**merge_dicts({name: value},
+                                           hmc._resolved_observed()))
+        stoch = [n for n in bn.nodes.values()
+                 if isinstance(n, StochasticTensor)]
+        if len(stoch) != 1 or stoch[0].name != name:
+            return None
+        dist = stoch[0].dist
+        if type(dist) is not Normal or dist.group_ndims != len(data_shape):
+            return None
+        if dist.use_path_derivative:
+            return None
+        return dist
+
+    dist = node_dist(q.detach().requires_grad_(True))
+    if dist is None:
         return None
-    dist = stoch[0].dist
-    if type(dist) is not Normal or dist.group_ndims != len(data_shape):
-        return None
-    if dist.use_path_derivative:
-        return None
-    mean, logstd = dist.mean, dist.logstd
-    if mean.requires_grad or logstd.requires_grad:
+    if dist.mean.requires_grad or dist.given_spread[1].requires_grad:
         return None                      # parameters depend on the latent
-    mean_d = _to_data_shape(mean, data_shape)
-    logstd_d = _to_data_shape(logstd, data_shape)
-    if mean_d is None or logstd_d is None or n_data == 0:
+    if _to_data_shape(dist.mean, data_shape) is None or \
+            _to_data_shape(dist.given_spread[1], data_shape) is None:
         return None                      # parameters vary along chain axes
+
+    def probe():
+        d = node_dist(q)
+        if d is None:
+            raise ValueError(
+                "HMC (fused diagonal-Normal plan): the model no longer is a "
+                "single Normal node '{}'; build a new HMC for the changed "
+                "model.".format(name))
+        return d.mean, d.given_spread[1], d
+
     return _FusedDiagNormalPlan(hmc, names, values, chain_shape, device,
-                                mean_d, logstd_d)
+                                probe)

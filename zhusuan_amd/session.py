@@ -37,7 +37,9 @@ def _fetch(f):
     if hasattr(f, 'tensor') and isinstance(f.tensor, torch.Tensor):
         return f.tensor.detach().cpu().numpy()
     if isinstance(f, dict):
-        return type(f)((k, _fetch(v)) for k, v in f.items())
+        # a plain dict: subclasses such as HMCInfo.init_momentum (regenerated
+        # on access) take other constructor arguments
+        return {k: _fetch(f[k]) for k in f.keys()}
     if isinstance(f, tuple) and hasattr(f, '_fields'):        # namedtuple
         return type(f)(*[_fetch(v) for v in f])
     if isinstance(f, (list, tuple)):

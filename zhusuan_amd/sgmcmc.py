@@ -22,7 +22,7 @@ import torch
 
 from . import _capi
 from .framework.meta_bn import MetaBayesianNet
-from .hmc import placeholder
+from .hmc import bind_feed, deferred, placeholder
 from .utils import merge_dicts, next_sampler_seed
 
 __all__ = ['SGMCMC', 'SGLD', 'PSGLD', 'SGHMC', 'SGNHT']
@@ -84,8 +84,13 @@ class SGMCMC(object):
 
         def grad_func(var_list):
             leaves = [q.detach().requires_grad_(True) for q in var_list]
-            joint_obs = merge_dicts(dict(zip(latent_k, leaves)),
-                                    self._observed)
+            # placeholders / deferred expressions in `observed` resolve to the
+            # values bound by this run's feed_dict (the mini-batch idiom
+            # sess.run(sample_op, feed_dict={x: xb, y: yb}))
+            observed_now = {
+                k: (v.value if isinstance(v, (placeholder, deferred)) else v)
+                for k, v in self._observed.items()}
+            joint_obs = merge_dicts(dict(zip(latent_k, leaves)), observed_now)
             lp = self._log_joint(joint_obs)
             grads = torch.autograd.grad(lp.sum(), leaves, allow_unused=True)
             return [torch.zeros_like(q) if g is None else
@@ -110,6 +115,7 @@ class SGMCMC(object):
         return {'q': dict(zip(self._latent_k, self._var_list))}
 
     def _run(self, feed_dict):
+        bind_feed(feed_dict, self._var_list[0].device)
         self._update(self._var_list, self._grad_func, feed_dict,
                      _capi.current_stream())
         self.t += 1                                           # sgmcmc.py:106
@@ -186,16 +192,23 @@ class SGHMC(SGMCMC):
         self.second_order = bool(second_order)
         super(SGHMC, self).__init__(seed)
 
-    def _define_variables(self, qs):
-        dev = qs[0].device
-        lr0 = _value(self.lr, None, 'learning_rate') \
-            if not isinstance(self.lr, placeholder) or \
-            self.lr.default is not None else 0.0
-        self.vs = [torch.empty_like(q) for q in qs]
-        for k, v in enumerate(self.vs):                       # sgmcmc.py:310-314
+    def _init_momentum(self, lr0):
+        for k, v in enumerate(self.vs):
             _capi.call('zshmc_sg_momentum', v.data_ptr(), math.sqrt(lr0),
                        v.numel(), self.seed, _INIT_ITER, k,
                        _capi.current_stream())
+        self._v_ready = True
+
+    def _define_variables(self, qs):
+        dev = qs[0].device
+        self.vs = [torch.empty_like(q) for q in qs]
+        # v0 ~ N(0, lr) (sgmcmc.py:310-314).  A learning-rate placeholder
+        # without a default has no value yet: in the reference the variable
+        # initialiser would have to be fed too; here the draw waits for the
+        # first run's value.
+        self._v_ready = False
+        if not isinstance(self.lr, placeholder) or self.lr.default is not None:
+            self._init_momentum(_value(self.lr, None, 'learning_rate'))
         # {sum v_old^2, sum v'^2} per latent, and the scalar mean_k outputs
         self._sums = [torch.zeros(2, dtype=torch.float64, device=dev)
                       for _ in qs]
@@ -209,6 +222,8 @@ class SGHMC(SGMCMC):
         return d
 
     def _resample(self, lr, feed_dict, stream):
+        if not self._v_ready:
+            self._init_momentum(lr)
         n = int(_value(self.n_iter_resample_v, feed_dict, 'n_iter_resample_v'))
         if n != 0 and self.t % n == 0:                        # sgmcmc.py:319-326
             for k, v in enumerate(self.vs):

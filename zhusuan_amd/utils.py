@@ -1,7 +1,10 @@
 """Small host-side helpers mirroring zhusuan/utils.py."""
 import threading
 
-__all__ = ['merge_dicts', 'set_random_seed', 'get_random_seed']
+import torch
+
+__all__ = ['merge_dicts', 'set_random_seed', 'get_random_seed',
+           'broadcast_shapes']
 
 
 def merge_dicts(*dict_args):
@@ -11,6 +14,32 @@ def merge_dicts(*dict_args):
     for dictionary in dict_args:
         result.update(dictionary)
     return result
+
+
+def broadcast_shapes(*shapes):
+    """NumPy-rule broadcast of static shapes -> torch.Size; RuntimeError when they do
+    not match (as torch.broadcast_shapes, which costs ~25 us of Python per
+    call -- this sits on the per-transition host path of every model
+    evaluation, tf.broadcast_static_shape in distributions/base.py:271-288)."""
+    n = 0
+    for s in shapes:
+        if len(s) > n:
+            n = len(s)
+    out = [1] * n
+    for s in shapes:
+        off = n - len(s)
+        for i, d in enumerate(s):
+            d = int(d)
+            if d != 1:
+                j = off + i
+                if out[j] == 1:
+                    out[j] = d
+                elif out[j] != d:
+                    raise RuntimeError(
+                        "Shape mismatch: objects cannot be broadcast to a "
+                        "single shape: {}".format(
+                            ' vs. '.join(str(tuple(x)) for x in shapes)))
+    return torch.Size(out)
 
 
 class _SeedState(threading.local):
