@@ -113,11 +113,14 @@ const char* zshmc_fused_kernel_name(int64_t n_data, int has_mass,
  *     (bit-identical from run to run; no floating-point atomics);
  *   - the caller may all-reduce stats[0..1] (+ the 2*D mass statistics it
  *     keeps behind them) in ONE message (zshmc_comm_all_reduce_sum);
- *   - the NEXT launch, told `pending` = ZSHMC_PEND_ADAPT / _HOLD (the previous
- *     run's adapt_step_size flag was true / false, hmc.py:92-110), applies
- *     that dual-averaging update to state[] in its prologue -- every
- *     workgroup computes the same scalars from stats[0] -- integrates with
- *     the updated step size, and its last-retiring workgroup writes the
+ *   - all chains on one GPU: `retire_update` = ZSHMC_PEND_ADAPT / _HOLD (this
+ *     run's adapt_step_size flag is true / false, hmc.py:92-110) makes the
+ *     workgroup that retires last apply the dual-averaging update to state[]
+ *     from the total it has just formed;
+ *   - chains sharded over GPUs: the NEXT launch, told `pending` = ..._ADAPT /
+ *     _HOLD, applies the update in its prologue from the all-reduced
+ *     stats[0] -- every workgroup computes the same scalars -- integrates
+ *     with the updated step size, and its last-retiring workgroup writes the
  *     updated state[] back.  zshmc_stepsize_flush applies a pending update
  *     without a transition (before the host reads state[], e.g. for
  *     HMCInfo.updated_step_size).
@@ -136,8 +139,15 @@ typedef struct zshmc_adapt_link {
   double* stats;           /* device, ZSHMC_STATS_WORDS doubles, or NULL */
   void* workspace;         /* device, ZSHMC_LINK_WORKSPACE_BYTES */
   int64_t n_chains_global; /* chains over all ranks (the mean of hmc.py:377) */
-  int32_t pending;         /* ZSHMC_PEND_* : update owed by the previous run */
-  int32_t fresh_start;     /* that run had if_initialize_step_size (:466-467) */
+  int32_t pending;         /* ZSHMC_PEND_* : update owed by the PREVIOUS run,
+                              applied in this launch's prologue from stats[0] */
+  int32_t retire_update;   /* ZSHMC_PEND_* : update of THIS run, applied by the
+                              workgroup that retires last from its own total
+                              (use when all chains live on this GPU: no
+                              all-reduce has to sit in between); exclusive
+                              with `pending` */
+  int32_t fresh_start;     /* the updated-for run had if_initialize_step_size
+                              (hmc.py:466-467) */
   float used_step_size;    /* step size that run used if it came from the
                               search (hmc.py:308-345); NaN otherwise */
   float delta, gamma, t0, kappa; /* StepsizeTuner parameters, hmc.py:67-78 */
@@ -256,6 +266,35 @@ int zshmc_mh_accept(const float* log_prob_old, const float* log_prob_new,
 /* q[c,:] = accept[c] ? q_new[c,:] : q[c,:]   (hmc.py:488-497) */
 int zshmc_select_rows(float* q, const float* q_new, const uint8_t* accept,
                       int64_t n_chains, int64_t n_data, void* stream);
+
+/* ------------------------------------------------------------------------
+ * One trip of HMC._leapfrog (hmc.py:348-372, :38-43) for the NATIVE plans of
+ * the dense-likelihood families (BASELINE configs 3 and 5): a Normal prior on
+ * the latent (univariate.py:174-181, group_ndims = 1) plus a likelihood whose
+ * value and gradient come from zshmc_linear_bernoulli_log_lik (f = identity)
+ * or zshmc_linear_multinomial_log_lik (f = softmax, lntm_mcem.py:39-46).
+ * Everything of the trip that is not the likelihood's GEMMs, in one launch:
+ *   grad  = J_f(q)^T grad_lik - exp(-2 logstd)(q - mean)   (tf.gradients of
+ *           the joint, hmc.py:430-432; softmax: theta*(g - <g,theta>))
+ *   p += kick_scale*eps*grad ;  q += drift_scale*eps*p/mass
+ *   lp_out[c]   = (ll_in ? ll_in[c] : 0) + log N(q_c)   AT the evaluation point
+ *   kinetic[c] += 1/2 sum p'^2/mass                      (if not NULL)
+ *   operand[c, 0:operand_stride] = f(q') zero-padded     (if not NULL): the
+ *           next likelihood evaluation's W / theta operand.  softmax != 0:
+ *           operand is also READ (theta of the current q, for the Jacobian).
+ * grad_lik [n_chains, grad_stride] or NULL (= 0); prior_mean / prior_logstd
+ * are [rows, n_data] used with row period (r % rows) -- 1 row: shared by all
+ * chains; n_docs rows: lntm's per-document eta_mean.  n_data a multiple of 4,
+ * <= 1024; all buffers 16-byte aligned.
+ */
+int zshmc_model_kick_drift(
+    float* q, float* p, const float* grad_lik, int64_t grad_stride,
+    float* operand, int64_t operand_stride, int softmax,
+    const float* prior_mean, int64_t mean_rows, const float* prior_logstd,
+    int64_t logstd_rows, const float* mass, const float* step_size_dev,
+    float step_size_host, float kick_scale, float drift_scale,
+    int64_t n_chains, int64_t n_data, const float* ll_in, float* lp_out,
+    float* kinetic, void* stream);
 
 /* ------------------------------------------------------------------------
  * Stand-alone distribution ops (forward, analytic backward, sampling).

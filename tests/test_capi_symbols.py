@@ -50,7 +50,7 @@ def test_adapt_link_layout_matches_header():
         names.append(parts[0].split()[-1].lstrip('*'))
         names.extend(parts[1:])
     assert names == [f[0] for f in _capi.AdaptLink._fields_], names
-    assert ctypes.sizeof(_capi.AdaptLink) == 3 * 8 + 8 + 2 * 4 + 6 * 4
+    assert ctypes.sizeof(_capi.AdaptLink) == 3 * 8 + 8 + 3 * 4 + 6 * 4 + 4
 
 
 def test_header_declares_functions():
@@ -108,7 +108,7 @@ def test_bad_arguments_are_rejected_before_any_launch(lib):
     rc = lib.zshmc_hmc_diag_normal_step(
         ctypes.c_void_p(16), None, ctypes.c_void_p(16), None, 0.1, 4, 4, 0, 1,
         0, 0, 1, None, None, None, None, None, None, ctypes.byref(link), None)
-    assert rc == 1 and 'pending' in _capi.last_error()
+    assert rc == 1 and 'step-size update needs' in _capi.last_error()
     rc = lib.zshmc_comm_all_reduce_sum(None, None, 0, None)
     assert rc == 1
     rc = lib.zshmc_state_set(ctypes.c_void_p(8), 99, 0.0, None)

@@ -39,7 +39,8 @@ class AdaptLink(Structure):
     hand over the acceptance statistic and the pending step-size update."""
     _fields_ = [('state', c_void_p), ('stats', c_void_p),
                 ('workspace', c_void_p), ('n_chains_global', c_int64),
-                ('pending', c_int32), ('fresh_start', c_int32),
+                ('pending', c_int32), ('retire_update', c_int32),
+                ('fresh_start', c_int32),
                 ('used_step_size', c_float), ('delta', c_float),
                 ('gamma', c_float), ('t0', c_float), ('kappa', c_float),
                 ('mu', c_float)]
@@ -111,6 +112,9 @@ PROTOTYPES = {
         _p, _p, _p, _p, c_int64, c_int64, c_uint64, c_uint32, _p, _p, _p, _p,
         _p, _p, _p, _p]),
     'zshmc_select_rows': (c_int, [_p, _p, _p, c_int64, c_int64, _p]),
+    'zshmc_model_kick_drift': (c_int, [
+        _p, _p, _p, c_int64, _p, c_int64, c_int, _p, c_int64, _p, c_int64, _p,
+        _p, c_float, c_float, c_float, c_int64, c_int64, _p, _p, _p, _p]),
     'zshmc_normal_log_prob': (c_int, [
         _p, _p, _p, _p, c_int64, c_int64, c_int, c_int, c_int, _p]),
     'zshmc_normal_log_prob_grad': (c_int, [

@@ -25,11 +25,10 @@ __global__ void stepsize_update_kernel(float* __restrict__ state,
   k.state = state;
   k.stats = acc_sum;
   k.inv_chains = inv_chains;
-  k.pending = adapt ? ZSHMC_PEND_ADAPT : ZSHMC_PEND_HOLD;
   k.fresh = fresh;
   k.used_step_size = __builtin_nanf("");
   k.tuner = cfg;
-  tuner_persist(k);
+  tuner_persist(k, adapt ? ZSHMC_PEND_ADAPT : ZSHMC_PEND_HOLD, *acc_sum);
   *acc_sum = 0.0;  // consumed; ready for the next transition
 }
 

@@ -54,27 +54,33 @@ __device__ __forceinline__ TunerState tuner_apply(TunerState s, float acc,
 }
 
 // The link between consecutive transitions (include/zshmc.h,
-// zshmc_adapt_link): where the acceptance sum goes and which update of the
-// previous transition is still pending.
+// zshmc_adapt_link): where the acceptance sum goes and which dual-averaging
+// update rides on this launch.
 struct AdaptLink {
   float* state;      // ZSHMC_ST_* block; NULL: no on-device step size / tuner
-  double* stats;     // [0] sum acc (in: previous, all-reduced; out: this
-                     // launch's, order-fixed), [1] non-finite-start flag
+  double* stats;     // [0] sum acc (in: previous, all-reduced, if `pending`;
+                     // out: this launch's, order-fixed), [1] non-finite flag
   double* partials;  // workspace: per-workgroup acceptance sums
   uint32_t* done;    // workspace: retired-workgroup counter (0 between launches)
   double inv_chains; // 1 / n_chains_global
-  int pending;       // ZSHMC_PEND_*
+  int pending;       // ZSHMC_PEND_*: update of the PREVIOUS transition, applied
+                     // in this launch's prologue from stats[0] (sharded chains:
+                     // an all-reduce sat in between)
+  int retire;        // ZSHMC_PEND_*: update of THIS transition, applied by the
+                     // workgroup that retires last from its own total (all
+                     // chains on this GPU)
   float fresh;       // 1: fresh start (hmc.py:466-467, :92-102)
-  float used_step_size;  // epsilon the previous transition used if it came
+  float used_step_size;  // epsilon the updated-for transition used if it came
                          // from the search (NaN: it used state[STEP_SIZE])
   TunerCfg tuner;
 };
 
-// state <- update(state, stats[0]) and the two diagnostic words; one thread.
-__device__ __forceinline__ void tuner_persist(const AdaptLink& k) {
+// state <- update(state, acc_sum) and the two diagnostic words; one thread.
+__device__ __forceinline__ void tuner_persist(const AdaptLink& k, int kind,
+                                              double acc_sum) {
   const TunerState s0 = tuner_load(k.state);
-  const float acc = (float)(k.stats[0] * k.inv_chains);  // hmc.py:377
-  const TunerState s = tuner_apply(s0, acc, k.pending, k.fresh, k.tuner);
+  const float acc = (float)(acc_sum * k.inv_chains);  // hmc.py:377
+  const TunerState s = tuner_apply(s0, acc, kind, k.fresh, k.tuner);
   k.state[ZSHMC_ST_MEAN_ACCEPT] = acc;
   k.state[ZSHMC_ST_USED_STEP_SIZE] =
       k.used_step_size == k.used_step_size ? k.used_step_size : s0.step_size;
@@ -100,23 +106,31 @@ __device__ __forceinline__ float link_step_size(const AdaptLink& k,
 // End of a transition kernel, thread 0 of every workgroup: publish this
 // workgroup's acceptance sum; the workgroup that retires last adds the
 // partials in index order (run-to-run identical, unlike atomics), persists
-// the pending update of the previous transition and publishes the total.
+// the dual-averaging update that rides on this launch and publishes the
+// total.  All hand-over goes through agent-scope atomics (performed at the
+// device-coherent level), so no cache write-back / invalidate is needed: a
+// release fence here would flush the L2 under the workgroups still running
+// (+30 us per launch when it was tried).  The exchange RETURNS, so the
+// partial has landed before the counter moves.
 __device__ __forceinline__ void link_retire(const AdaptLink& k, double wg_sum,
                                             const uint32_t* flags) {
   if (!k.partials) return;
   const unsigned nblk = gridDim.x;
-  __hip_atomic_store(&k.partials[blockIdx.x], wg_sum, __ATOMIC_RELAXED,
-                     __HIP_MEMORY_SCOPE_AGENT);
-  __atomic_thread_fence(__ATOMIC_RELEASE);
+  const double prev = __hip_atomic_exchange(
+      &k.partials[blockIdx.x], wg_sum, __ATOMIC_RELAXED,
+      __HIP_MEMORY_SCOPE_AGENT);
+  // (the counter's operand depends on the returned value: program order)
+  const unsigned one = prev == prev ? 1u : 1u + (unsigned)(prev != prev);
   const unsigned ticket = __hip_atomic_fetch_add(
-      k.done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      k.done, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (ticket != nblk - 1) return;
-  __atomic_thread_fence(__ATOMIC_ACQUIRE);
   double total = 0.0;
   for (unsigned i = 0; i < nblk; ++i)
     total += __hip_atomic_load(&k.partials[i], __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
-  if (k.state && k.pending != ZSHMC_PEND_NONE) tuner_persist(k);
+  if (k.state && k.pending != ZSHMC_PEND_NONE)
+    tuner_persist(k, k.pending, k.stats[0]);
+  if (k.state && k.retire != ZSHMC_PEND_NONE) tuner_persist(k, k.retire, total);
   k.stats[0] = total;
   uint32_t f = 0;
   if (flags)

@@ -446,8 +446,18 @@ static int make_link(const zshmc_adapt_link* link, AdaptLink* out,
                    link->pending == ZSHMC_PEND_HOLD,
                "%s: link->pending %d is not a ZSHMC_PEND_* value", who,
                (int)link->pending);
-    ZS_REQUIRE(link->pending == ZSHMC_PEND_NONE || (link->state && link->stats),
-               "%s: a pending update needs link->state and link->stats", who);
+    ZS_REQUIRE(link->retire_update == ZSHMC_PEND_NONE ||
+                   link->retire_update == ZSHMC_PEND_ADAPT ||
+                   link->retire_update == ZSHMC_PEND_HOLD,
+               "%s: link->retire_update %d is not a ZSHMC_PEND_* value", who,
+               (int)link->retire_update);
+    ZS_REQUIRE(link->pending == ZSHMC_PEND_NONE ||
+                   link->retire_update == ZSHMC_PEND_NONE,
+               "%s: pending and retire_update are exclusive", who);
+    ZS_REQUIRE((link->pending == ZSHMC_PEND_NONE &&
+                link->retire_update == ZSHMC_PEND_NONE) ||
+                   (link->state && link->stats),
+               "%s: a step-size update needs link->state and link->stats", who);
     ZS_REQUIRE(!link->stats || link->workspace,
                "%s: link->stats needs link->workspace", who);
     ZS_REQUIRE(!(link->state || link->stats) || link->n_chains_global > 0,
@@ -462,6 +472,7 @@ static int make_link(const zshmc_adapt_link* link, AdaptLink* out,
     k.inv_chains =
         link->n_chains_global > 0 ? 1.0 / (double)link->n_chains_global : 0.0;
     k.pending = link->pending;
+    k.retire = link->retire_update;
     k.fresh = link->fresh_start ? 1.0f : 0.0f;
     k.used_step_size = link->used_step_size;
     k.tuner = TunerCfg{link->delta, link->gamma, link->t0, link->kappa,
@@ -475,7 +486,11 @@ static int make_link(const zshmc_adapt_link* link, AdaptLink* out,
 // still has to retire the update and publish an empty sum)
 __global__ void stepsize_flush_kernel(AdaptLink k, int zero_stats) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  if (k.state && k.pending != ZSHMC_PEND_NONE) tuner_persist(k);
+  if (k.state && k.pending != ZSHMC_PEND_NONE)
+    tuner_persist(k, k.pending, k.stats[0]);
+  // (a rank without chains: this transition's own sum is 0)
+  if (zero_stats && k.state && k.retire != ZSHMC_PEND_NONE)
+    tuner_persist(k, k.retire, 0.0);
   if (zero_stats && k.stats) {
     k.stats[0] = 0.0;
     k.stats[1] = 0.0;
@@ -521,7 +536,8 @@ extern "C" int zshmc_hmc_diag_normal_step(
     if (rc != ZSHMC_OK) return rc;
   }
   if (n_chains == 0) {
-    if (a.link.stats || a.link.pending != ZSHMC_PEND_NONE) {
+    if (a.link.stats || a.link.pending != ZSHMC_PEND_NONE ||
+        a.link.retire != ZSHMC_PEND_NONE) {
       hipLaunchKernelGGL(stepsize_flush_kernel, dim3(1), dim3(64), 0,
                          reinterpret_cast<hipStream_t>(stream), a.link, 1);
       ZS_LAUNCH_CHECK("stepsize_flush_kernel launch");

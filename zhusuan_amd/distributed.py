@@ -44,7 +44,7 @@ class ChainSharding(object):
         ranks share one GPU (RCCL refuses two ranks on one device)."""
 
     def __init__(self, process_group=None, chain_offset=None,
-                 n_chains_global=None, backend='torch'):
+                 n_chains_global=None, backend='torch', always_reduce=False):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         if backend not in ('torch', 'rccl'):
@@ -55,6 +55,9 @@ class ChainSharding(object):
         self._chain_offset = chain_offset
         self._n_chains_global = n_chains_global
         self.backend = backend
+        # a one-rank communicator normally skips its collectives; tests set
+        # this to run the sharded code path (and RCCL) on a 1-GPU box
+        self.always_reduce = bool(always_reduce)
         self._comm = None
         if backend == 'rccl':
             self._comm = self._create_rccl_comm()
@@ -71,6 +74,11 @@ class ChainSharding(object):
         _capi.call('zshmc_comm_create', ident[0], self.rank, self.world_size,
                    ctypes.byref(comm))
         return comm
+
+    @property
+    def active(self):
+        """Whether the adaptation statistics have to cross ranks."""
+        return self.world_size > 1 or self.always_reduce
 
     @property
     def rccl_ranks(self):

@@ -367,12 +367,18 @@ class HMC(object):
                   getattr(plan, 'can_skip_acc', False))
         plan.collect_acc = not steady
 
-        plan.transition(t, eps_host, stream)              # leapfrog + MH
-
-        if self.adapt_step_size is not None and not steady:   # hmc.py:501-505
+        # the dual-averaging update of this transition (hmc.py:501-505): the
+        # plan decides where it runs -- inside the transition kernel (fused
+        # plan, all chains on this GPU), in the next launch's prologue (fused
+        # plan, sharded chains: the all-reduce sits in between), or as its own
+        # launch (generic plan)
+        update = None
+        if self.adapt_step_size is not None and not steady:
+            update = (_capi.PEND_ADAPT if adapt_ss else _capi.PEND_HOLD,
+                      bool(init), eps_host)
             self._nonadaptive_streak = 0 if (adapt_ss or init) else \
                 self._nonadaptive_streak + 1
-            plan.stepsize_update(adapt_ss, init, eps_host, stream, sh)
+        plan.transition(t, eps_host, stream, update)      # leapfrog + MH
         self._pending_check = True
         if sync:
             self.check_numerics()
@@ -428,7 +434,7 @@ class HMC(object):
         plan = self._plan
         self.flush()
         flags = plan.flags
-        if self.sharding is not None and self.sharding.world_size > 1:
+        if self.sharding is not None and self.sharding.active:
             flags = self.sharding.all_reduce_sum(
                 (plan.flags != 0).to(torch.float64))
         elif sync:
@@ -539,7 +545,7 @@ class _PlanBase(object):
                 _capi.call('zshmc_mass_colstats', q.data_ptr(),
                            self.ewmv_mean[k].data_ptr(), self.n_chains,
                            self.n_data[k], self.colsum[k].data_ptr(), stream)
-            if sharding is not None and sharding.world_size > 1:
+            if sharding is not None and sharding.active:
                 if self.stats_local:
                     sharding.all_reduce_sum(self.comm_buf)
                     self.stats_local = False
@@ -561,7 +567,7 @@ class _PlanBase(object):
     def reduce_stats(self, sharding, stream):
         """Sum the acceptance statistic over the ranks if that is still owed."""
         if self.stats_local:
-            if sharding is not None and sharding.world_size > 1:
+            if sharding is not None and sharding.active:
                 sharding.all_reduce_sum(self.stats)
             self.stats_local = False
 
@@ -647,14 +653,18 @@ class _FusedDiagNormalPlan(_PlanBase):
         self._src = (mean_src, spread_src, mean_src._version,
                      spread_src._version)
 
-    def _link(self, eps_host, collect):
+    def _link(self, eps_host, collect, retire=None):
         hmc = self.hmc
         k = _capi.AdaptLink()
-        k.state = None if eps_host is not None else self.state.data_ptr()
+        # (an in-kernel update needs the state block even when this launch
+        # integrates with the step size the search just returned)
+        k.state = None if (eps_host is not None and retire is None) \
+            else self.state.data_ptr()
         k.stats = self.stats.data_ptr() if collect else None
         k.workspace = self.workspace.data_ptr()
         k.n_chains_global = self.n_chains_global
-        k.pending, k.fresh_start = _capi.PEND_NONE, 0
+        k.pending, k.retire_update, k.fresh_start = _capi.PEND_NONE, \
+            _capi.PEND_NONE, 0
         k.used_step_size = float('nan')
         k.delta, k.gamma = hmc.target_acceptance_rate, hmc.gamma
         k.t0, k.kappa = hmc.t0, hmc.kappa
@@ -664,20 +674,28 @@ class _FusedDiagNormalPlan(_PlanBase):
             k.pending, k.fresh_start = kind, int(fresh)
             if used is not None:
                 k.used_step_size = float(used)
+        if retire is not None:
+            kind, fresh, used = retire
+            k.retire_update, k.fresh_start = kind, int(fresh)
+            if used is not None:
+                k.used_step_size = float(used)
         return k
 
-    def _launch(self, t, eps_host, commit, n_leapfrogs, stream):
+    def _launch(self, t, eps_host, commit, n_leapfrogs, stream, retire=None):
         info = commit
         if self.pending is not None and eps_host is not None:
             raise RuntimeError("a pending step-size update must be flushed "
                                "before a launch with a host step size")
-        # a launch that retires a pending update also publishes its sum
-        collect = self.collect_acc or not commit or self.pending is not None
-        link = self._link(eps_host, collect)
+        # a launch that carries an update also publishes its sum
+        collect = (self.collect_acc or not commit or
+                   self.pending is not None or retire is not None)
+        link = self._link(eps_host, collect, retire)
         _capi.call(
             'zshmc_hmc_diag_normal_step', self.q[0].data_ptr(),
             None if self.zero_mean else self.mean.data_ptr(),
             self.logstd.data_ptr(), self.mass_ptr(0),
+            # (with an in-kernel update the kernel must still integrate with
+            # the searched step size: the state block then carries it)
             0.0 if eps_host is None else float(eps_host),
             self.n_chains, self.n_data[0], self.chain_offset, n_leapfrogs,
             self.hmc.seed, t & 0xFFFFFFFF, int(commit),
@@ -690,13 +708,7 @@ class _FusedDiagNormalPlan(_PlanBase):
         self.pending = None            # retired by this launch
         if collect:
             sh = self.hmc.sharding
-            self.stats_local = sh is not None and sh.world_size > 1
-
-    def stepsize_update(self, adapt_ss, init, eps_host, stream, sharding):
-        """hmc.py:501-505, deferred: recorded here, applied by the next
-        launch (or by flush())."""
-        self.pending = (_capi.PEND_ADAPT if adapt_ss else _capi.PEND_HOLD,
-                        bool(init), eps_host)
+            self.stats_local = sh is not None and sh.active
 
     def flush(self, stream, sharding):
         if self.pending is None:
@@ -713,20 +725,33 @@ class _FusedDiagNormalPlan(_PlanBase):
         # one full leapfrog step (hmc.py:316-321) == the kernel with L = 1
         self._launch(t, step_size, 0, 1, stream)
 
-    def transition(self, t, eps_host, stream):
+    def transition(self, t, eps_host, stream, update=None):
         self.last_t = t
+        sh = self.hmc.sharding
+        sharded = sh is not None and sh.active
+        retire = None if sharded else update
+        if retire is not None and eps_host is not None:
+            # the searched step size travels through the state block so that
+            # the kernel can both use it and update from it
+            _capi.call('zshmc_state_set', self.state.data_ptr(),
+                       _capi.ST_STEP_SIZE, float(eps_host), stream)
+            eps_host = None
         timer = self.hmc.kernel_timer
         self._timer_tick = getattr(self, '_timer_tick', 0) + 1
         if timer is None or self._timer_tick % self.hmc.kernel_timer_stride:
-            self._launch(t, eps_host, 1, self.hmc.n_leapfrogs, stream)
-            return
-        # bench.py: HIP events on the launch stream around the fused kernel
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-        self._launch(t, eps_host, 1, self.hmc.n_leapfrogs, stream)
-        e1.record()
-        timer.append((e0, e1))
+            self._launch(t, eps_host, 1, self.hmc.n_leapfrogs, stream, retire)
+        else:
+            # bench.py: HIP events on the launch stream around the fused kernel
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self._launch(t, eps_host, 1, self.hmc.n_leapfrogs, stream, retire)
+            e1.record()
+            timer.append((e0, e1))
+        if sharded and update is not None:
+            # applied by the next launch's prologue (or flush()) once the
+            # acceptance sums of all ranks have been added
+            self.pending = update
 
 
 class _GenericPlan(_PlanBase):
@@ -784,9 +809,6 @@ class _GenericPlan(_PlanBase):
         lp0, g0 = self.value_and_grad(self.q)
         self._search_cache = (lp0, g0)
 
-    def stepsize_update(self, adapt_ss, init, eps_host, stream, sharding):
-        self._tuner_update_eager(adapt_ss, init, eps_host, stream, sharding)
-
     def reduce_stats(self, sharding, stream):
         """Only the step-size search asks (the transition's own sum is
         reduced and consumed by stepsize_update): acceptance sum and the
@@ -794,7 +816,7 @@ class _GenericPlan(_PlanBase):
         if not self._in_search:
             return
         self.stats[1] = (self.flags != 0).to(torch.float64)[0]
-        if sharding is not None and sharding.world_size > 1:
+        if sharding is not None and sharding.active:
             sharding.all_reduce_sum(self.stats)
 
     def end_search_trip(self):
@@ -816,7 +838,14 @@ class _GenericPlan(_PlanBase):
                    t & 0xFFFFFFFF, None, None, None, None, None,
                    self.acc_sum.data_ptr(), self.flags.data_ptr(), stream)
 
-    def transition(self, t, eps_host, stream):
+    def transition(self, t, eps_host, stream, update=None):
+        self._transition(t, eps_host, stream)
+        if update is not None:
+            kind, init, _ = update
+            self._tuner_update_eager(kind == _capi.PEND_ADAPT, init, eps_host,
+                                     stream, self.hmc.sharding)
+
+    def _transition(self, t, eps_host, stream):
         self.last_t = t
         L = self.hmc.n_leapfrogs
         if self._search_cache is not None:
