@@ -103,31 +103,44 @@ __device__ __forceinline__ float link_step_size(const AdaptLink& k,
   return s.step_size;
 }
 
-// End of a transition kernel, thread 0 of every workgroup: publish this
-// workgroup's acceptance sum; the workgroup that retires last adds the
-// partials in index order (run-to-run identical, unlike atomics), persists
-// the dual-averaging update that rides on this launch and publishes the
+// End of a transition kernel.  link_publish (thread 0 of every workgroup):
+// hand this workgroup's acceptance sum over; true for the workgroup that
+// retires last.  link_finish (ONE FULL WAVE of that workgroup): add the
+// partials in a fixed order -- lane l takes partials l, l+64, ..., then the
+// xor butterfly: run-to-run identical, unlike floating-point atomics --
+// persist the dual-averaging update that rides on this launch and publish the
 // total.  All hand-over goes through agent-scope atomics (performed at the
-// device-coherent level), so no cache write-back / invalidate is needed: a
-// release fence here would flush the L2 under the workgroups still running
-// (+30 us per launch when it was tried).  The exchange RETURNS, so the
-// partial has landed before the counter moves.
-__device__ __forceinline__ void link_retire(const AdaptLink& k, double wg_sum,
-                                            const uint32_t* flags) {
-  if (!k.partials) return;
-  const unsigned nblk = gridDim.x;
+// device-coherent level), so no cache write-back / invalidate is needed (a
+// release fence here flushed the L2 under the workgroups still running).  The
+// exchange RETURNS, so the partial has landed before the counter moves.  The
+// partial loads bypass the L2 (~100 ns each): spread over the lanes they cost
+// ~0.5 us, read one after another by one thread they cost 25 us.
+__device__ __forceinline__ bool link_publish(const AdaptLink& k,
+                                             double wg_sum) {
+  if (!k.partials) return false;
   const double prev = __hip_atomic_exchange(
       &k.partials[blockIdx.x], wg_sum, __ATOMIC_RELAXED,
       __HIP_MEMORY_SCOPE_AGENT);
-  // (the counter's operand depends on the returned value: program order)
-  const unsigned one = prev == prev ? 1u : 1u + (unsigned)(prev != prev);
+  // the counter's operand is made to depend on the returned value (an opaque
+  // asm that consumes it), so hipcc must wait for the exchange to come back
+  unsigned one = 1u;
+  asm volatile("" : "+v"(one) : "v"(prev));
   const unsigned ticket = __hip_atomic_fetch_add(
       k.done, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (ticket != nblk - 1) return;
-  double total = 0.0;
-  for (unsigned i = 0; i < nblk; ++i)
-    total += __hip_atomic_load(&k.partials[i], __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+  return ticket == gridDim.x - 1;
+}
+
+__device__ __forceinline__ void link_finish(const AdaptLink& k,
+                                            const uint32_t* flags, int lane) {
+  const unsigned nblk = gridDim.x;
+  double part = 0.0;
+  for (unsigned i = lane; i < nblk; i += 64)
+    part += __hip_atomic_load(&k.partials[i], __ATOMIC_RELAXED,
+                              __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+  if (lane != 0) return;
+  const double total = part;
   if (k.state && k.pending != ZSHMC_PEND_NONE)
     tuner_persist(k, k.pending, k.stats[0]);
   if (k.state && k.retire != ZSHMC_PEND_NONE) tuner_persist(k, k.retire, total);

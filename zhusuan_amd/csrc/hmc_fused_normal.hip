@@ -328,7 +328,12 @@ __global__ __launch_bounds__(256, ZS_WAVES_PER_EU) void hmc_diag_normal_kernel(
     double tot = 0.0;
     for (int i = 0; i < (int)(blockDim.x / kWave); ++i) tot += s_acc[i];
     if (*s_bad && a.flags) atomicOr(a.flags, ZSHMC_FLAG_OLD_LOGPROB_NONFINITE);
-    link_retire(a.link, tot, a.flags);
+    *s_bad = link_publish(a.link, tot) ? -1 : 0;   // (the flag is spent)
+  }
+  if (a.link.partials) {  // kernel argument: uniform over the grid
+    __syncthreads();
+    if (threadIdx.x < kWave && *s_bad == -1)
+      link_finish(a.link, a.flags, lane);
   }
 }
 

@@ -647,7 +647,11 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
     double tot = 0.0;
     for (int i = 0; i < kWavesPerBlock; ++i) tot += s_acc[i];
     if (*s_bad && a.flags) atomicOr(a.flags, ZSHMC_FLAG_OLD_LOGPROB_NONFINITE);
-    link_retire(a.link, tot, a.flags);
+    *s_ticket = link_publish(a.link, tot) ? -1 : 0;   // (tickets are spent)
+  }
+  if (a.link.partials) {  // kernel argument: uniform over the grid
+    __syncthreads();
+    if (wib == 0 && *s_ticket == -1) link_finish(a.link, a.flags, lane);
   }
   // ---- staged HMCInfo scalars -> global, G consecutive chains per line ----
   if (STAGE && a.commit) {

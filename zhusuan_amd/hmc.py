@@ -210,7 +210,7 @@ class HMC(object):
     def __init__(self, step_size=1., n_leapfrogs=10, adapt_step_size=None,
                  target_acceptance_rate=0.8, gamma=0.05, t0=100, kappa=0.75,
                  adapt_mass=None, mass_collect_iters=10, mass_decay=0.99,
-                 *, seed=None, sharding=None):
+                 *, seed=None, sharding=None, native_plans=True):
         self._init_step_size_value = float(step_size)
         self.n_leapfrogs = int(n_leapfrogs)
         self.target_acceptance_rate = float(target_acceptance_rate)
@@ -231,6 +231,9 @@ class HMC(object):
         self.seed = next_sampler_seed() if seed is None else \
             int(seed) & 0xFFFFFFFFFFFFFFFF
         self.sharding = sharding
+        # False keeps the autograd-driven generic plan for models the native
+        # dense-likelihood plans would otherwise take (A/B and parity tests)
+        self.native_plans = bool(native_plans)
         self._plan = None
         self._pending_check = False
         # list collecting (start, end) HIP-event pairs around the fused
@@ -292,6 +295,9 @@ class HMC(object):
         device = latent_v[0].device
         plan = _try_fused_plan(self, meta_bn, latent_k, latent_v, chain_shape,
                                device)
+        if plan is None and self.native_plans:
+            plan = _try_dense_likelihood_plan(self, meta_bn, latent_k,
+                                              latent_v, chain_shape, device)
         if plan is None:
             plan = _GenericPlan(self, latent_k, latent_v, chain_shape, device)
         self._plan = plan
@@ -883,6 +889,332 @@ class _GenericPlan(_PlanBase):
             _capi.call('zshmc_select_rows', self.q[k].data_ptr(),
                        self.q_new[k].data_ptr(), self.accept.data_ptr(),
                        self.n_chains, self.n_data[k], stream)
+
+
+class _DenseLikelihoodPlan(_PlanBase):
+    """Native plan for the dense-likelihood families (BASELINE configs 3 / 5):
+    one latent with a Normal prior (group_ndims = 1) and one observed node
+    whose log-likelihood and gradient come from the fused fp32-MFMA kernels --
+
+      'linear_bernoulli'    y ~ Bernoulli(linear_logits(w, X), group_ndims=1)
+      'mixture_multinomial' x ~ UnnormalizedMultinomial(
+                                    log_mixture(softmax(eta), phi),
+                                    normalize_logits=False)   (lntm_mcem.py:33-48)
+
+    A transition is momentum + (L+1) x [likelihood kernel, one element-wise
+    launch doing prior gradient / softmax Jacobian / kick / drift / next
+    operand] + MH + select: no autograd graph and no ATen kernel on the path
+    (csrc/hmc_model.hip).  The model function is still re-evaluated on the
+    host at the start of every run, so fed placeholders (mini-batches,
+    eta_mean / eta_logstd of lntm_mcem.py:164-169) and in-place parameter
+    updates are seen."""
+    can_skip_acc = False
+
+    def __init__(self, hmc, names, values, chain_shape, device, probe, kind):
+        super(_DenseLikelihoodPlan, self).__init__(hmc, names, values,
+                                                   chain_shape, device)
+        from . import _ops
+        self._ops = _ops
+        self.kind = kind
+        self._probe = probe
+        f32 = dict(dtype=torch.float32, device=device)
+        C, D = self.n_chains, self.n_data[0]
+        self.width = next(v for v in _ops.LINEAR_BERNOULLI_WIDTHS if v >= D)
+        self.softmax = kind == 'mixture_multinomial'
+        self.p = torch.empty(C, D, **f32)
+        self.q_new = torch.empty(C, D, **f32)
+        self.grad = torch.empty(C, self.width, **f32)
+        # operand of the likelihood kernel: theta = softmax(q) / zero-padded q
+        self.operand = torch.zeros(C, self.width, **f32) \
+            if (self.softmax or self.width != D) else None
+        self.ll = torch.empty(C, **f32)
+        self.lp_old = torch.empty(C, **f32)
+        self.lp_new = torch.empty(C, **f32)
+        self.kin_old = torch.zeros(C, **f32)
+        self.kin_new = torch.zeros(C, **f32)
+        self.accept = torch.zeros(C, dtype=torch.uint8, device=device)
+        self._search_cache = None
+        self._in_search = False
+        self._src = None
+        self._ws = None
+        self.refresh_model()
+
+    # -- model tensors -------------------------------------------------------
+    def refresh_model(self):
+        t = self._probe()
+        if self._src is not None and len(t) == len(self._src) and all(
+                a is b and a._version == v
+                for a, (b, v) in zip(t, self._src)):
+            return
+        self._src = [(a, a._version) for a in t]
+        C, D = self.n_chains, self.n_data[0]
+        mean, logstd = t[0], t[1]
+        self.prior_mean, self.mean_rows = _to_row_period(
+            mean, self.chain_shape, D)
+        self.prior_logstd, self.logstd_rows = _to_row_period(
+            logstd, self.chain_shape, D)
+        ops = self._ops
+        if self.kind == 'linear_bernoulli':
+            X, y = t[2], t[3]
+            self.inner = ops._padded_x(X, self.width)
+            self.obs = y.detach().to(torch.float32).contiguous()
+            n_inner = self.inner.shape[0]
+        else:
+            phi, x = t[2], t[3]
+            self.inner = ops._padded_phi_t(phi, self.width)
+            self.obs = x.detach().to(torch.float32).contiguous().reshape(
+                -1, x.shape[-1])
+            n_inner = self.inner.shape[0]
+            if C % self.obs.shape[0] != 0:
+                raise ValueError("counts rows do not divide the chain rows")
+        self.splits = ops._row_splits(C, n_inner, self.device)
+        need = self.splits * C * (self.width + 1) if self.splits > 1 else 0
+        if need and (self._ws is None or self._ws.numel() < need):
+            self._ws = torch.empty(need, dtype=torch.float32,
+                                   device=self.device)
+
+    # -- building blocks -----------------------------------------------------
+    def _likelihood(self, q, stream):
+        """ll[c] and d ll / d operand at the operand derived from q."""
+        w = self.operand if self.operand is not None else q
+        ws = self._ws if self.splits > 1 else None
+        if self.kind == 'linear_bernoulli':
+            _capi.call('zshmc_linear_bernoulli_log_lik', w.data_ptr(),
+                       self.inner.data_ptr(), self.obs.data_ptr(),
+                       self.n_chains, self.inner.shape[0], self.width,
+                       self.ll.data_ptr(), self.grad.data_ptr(), self.splits,
+                       _capi.ptr(ws), stream)
+        else:
+            _capi.call('zshmc_linear_multinomial_log_lik', w.data_ptr(),
+                       self.inner.data_ptr(), self.obs.data_ptr(),
+                       self.obs.shape[0], self.n_chains, self.inner.shape[0],
+                       self.width, self.ll.data_ptr(), self.grad.data_ptr(),
+                       self.splits, _capi.ptr(ws), stream)
+
+    def _step(self, q, p, use_grad, eps_host, kick, drift, lp_out, kinetic,
+              stream):
+        """csrc/hmc_model.hip: prior + Jacobian + kick + drift + operand."""
+        _capi.call(
+            'zshmc_model_kick_drift', q.data_ptr(), p.data_ptr(),
+            self.grad.data_ptr() if use_grad else None, self.width,
+            _capi.ptr(self.operand), self.width, int(self.softmax),
+            self.prior_mean.data_ptr(), self.mean_rows,
+            self.prior_logstd.data_ptr(), self.logstd_rows, self.mass_ptr(0),
+            None if eps_host is not None else self.state.data_ptr(),
+            0.0 if eps_host is None else float(eps_host), float(kick),
+            float(drift), self.n_chains, self.n_data[0],
+            self.ll.data_ptr() if use_grad else None, _capi.ptr(lp_out),
+            _capi.ptr(kinetic), stream)
+
+    def _momentum(self, t, stream):
+        self.kin_old.zero_()
+        _capi.call('zshmc_momentum', self.p.data_ptr(), self.mass_ptr(0),
+                   self.n_chains, self.n_data[0], self.chain_offset,
+                   self.hmc.seed, t & 0xFFFFFFFF, 0, self.kin_old.data_ptr(),
+                   stream)
+
+    def _first_evaluation(self, q, stream):
+        """operand(q), then likelihood + gradient at q (self.ll, self.grad)."""
+        if self.operand is not None:
+            self._step(q, self.p, False, 0.0, 0.0, 0.0, None, None, stream)
+        self._likelihood(q, stream)
+
+    # -- step-size search (hmc.py:308-345) -----------------------------------
+    def reduce_stats(self, sharding, stream):
+        if not self._in_search:
+            return
+        self.stats[1] = (self.flags != 0).to(torch.float64)[0]
+        if sharding is not None and sharding.active:
+            sharding.all_reduce_sum(self.stats)
+
+    def end_search_trip(self):
+        self.stats.zero_()
+        self._in_search = False
+
+    def begin_search(self, t, stream):
+        self._momentum(t, stream)
+        self.q_new.copy_(self.q[0])
+        self._first_evaluation(self.q_new, stream)
+        self._search_cache = (self.ll.clone(), self.grad.clone(),
+                              None if self.operand is None
+                              else self.operand.clone())
+
+    def search_trip(self, t, step_size, stream):
+        self._in_search = True
+        ll0, g0, op0 = self._search_cache
+        q1, p1 = self.q[0].clone(), self.p.clone()
+        self.ll.copy_(ll0)
+        self.grad.copy_(g0)
+        if op0 is not None:
+            self.operand.copy_(op0)
+        self._step(q1, p1, True, step_size, 0.5, 1.0, self.lp_old, None,
+                   stream)
+        self._likelihood(q1, stream)
+        self.kin_new.zero_()
+        self._step(q1, p1, True, step_size, 0.5, 0.0, self.lp_new,
+                   self.kin_new, stream)
+        _capi.call('zshmc_mh_accept', self.lp_old.data_ptr(),
+                   self.lp_new.data_ptr(), self.kin_old.data_ptr(),
+                   self.kin_new.data_ptr(), self.n_chains, self.chain_offset,
+                   self.hmc.seed, t & 0xFFFFFFFF, None, None, None, None, None,
+                   self.acc_sum.data_ptr(), self.flags.data_ptr(), stream)
+
+    # -- one transition --------------------------------------------------------
+    def transition(self, t, eps_host, stream, update=None):
+        self.last_t = t
+        L = self.hmc.n_leapfrogs
+        q, p = self.q_new, self.p
+        q.copy_(self.q[0])
+        if self._search_cache is not None:    # same q, same p0 (Appendix B 11)
+            ll0, g0, op0 = self._search_cache
+            self._search_cache = None
+            self.ll.copy_(ll0)
+            self.grad.copy_(g0)
+            if op0 is not None:
+                self.operand.copy_(op0)
+        else:
+            self._momentum(t, stream)
+            self._first_evaluation(q, stream)
+        self.kin_new.zero_()
+        # trip 0: zero-length drift, half kick (hmc.py:352-364); the drift of
+        # trip i+1 rides behind the kick of trip i
+        self._step(q, p, True, eps_host, 0.5, 1.0 if L >= 1 else 0.0,
+                   self.lp_old, self.kin_new if L == 0 else None, stream)
+        if L == 0:
+            self.lp_new.copy_(self.lp_old)
+        for i in range(1, L + 1):
+            self._likelihood(q, stream)
+            last = i == L
+            self._step(q, p, True, eps_host, 0.5 if last else 1.0,
+                       0.0 if last else 1.0, self.lp_new if last else None,
+                       self.kin_new if last else None, stream)
+        _capi.call('zshmc_mh_accept', self.lp_old.data_ptr(),
+                   self.lp_new.data_ptr(), self.kin_old.data_ptr(),
+                   self.kin_new.data_ptr(), self.n_chains, self.chain_offset,
+                   self.hmc.seed, t & 0xFFFFFFFF,
+                   self.acceptance_rate.data_ptr(),
+                   self.orig_hamiltonian.data_ptr(),
+                   self.hamiltonian.data_ptr(), self.log_prob.data_ptr(),
+                   self.accept.data_ptr(), self.acc_sum.data_ptr(),
+                   self.flags.data_ptr(), stream)
+        self.orig_log_prob.copy_(self.lp_old)
+        _capi.call('zshmc_select_rows', self.q[0].data_ptr(), q.data_ptr(),
+                   self.accept.data_ptr(), self.n_chains, self.n_data[0],
+                   stream)
+        if update is not None:
+            kind, init, _ = update
+            self._tuner_update_eager(kind == _capi.PEND_ADAPT, init, eps_host,
+                                     stream, self.hmc.sharding)
+
+
+def _to_row_period(param, chain_shape, n_data):
+    """A prior parameter as a contiguous float32 [rows, n_data] matrix used
+    with row period `rows` over the flattened chain axes: the leading chain
+    axes it does not vary along are dropped (1 row: shared by every chain;
+    lntm's eta_mean [n_docs, K] under chain axes [n_chains, n_docs]: n_docs
+    rows)."""
+    t = param.detach().to(torch.float32)
+    full = tuple(chain_shape) + (n_data,)
+    if t.dim() > len(full):
+        t = t.reshape(t.shape[t.dim() - len(full):])
+    shape = (1,) * (len(full) - t.dim()) + tuple(t.shape)
+    t = t.reshape(shape)
+    lead = 0
+    while lead < len(chain_shape) and shape[lead] == 1:
+        lead += 1
+    tail = full[lead:]
+    t = t.reshape(shape[lead:]).expand(tail).contiguous()
+    rows = 1
+    for d in tail[:-1]:
+        rows *= int(d)
+    return t.reshape(rows, n_data), rows
+
+
+def _softmax_of(theta, probe):
+    """True if `theta` is torch.softmax(probe, -1) (recognised on the autograd
+    graph: the model is written with the ordinary torch op)."""
+    fn = getattr(theta, 'grad_fn', None)
+    if fn is None or type(fn).__name__ != 'SoftmaxBackward0':
+        return False
+    dim = getattr(fn, '_saved_dim', None)
+    if dim is None or dim % probe.dim() != probe.dim() - 1:
+        return False
+    nxt = fn.next_functions[0][0]
+    return getattr(nxt, 'variable', None) is probe
+
+
+def _try_dense_likelihood_plan(hmc, meta_bn, names, values, chain_shape,
+                               device):
+    from .distributions import Bernoulli, UnnormalizedMultinomial
+    if not isinstance(meta_bn, MetaBayesianNet) or meta_bn.log_joint is not None:
+        return None
+    if len(names) != 1:
+        return None
+    name, q = names[0], values[0]
+    if q.dim() != len(chain_shape) + 1:
+        return None
+    D = int(q.shape[-1])
+    if D % 4 != 0 or D < 4 or D > 256 or q.data_ptr() % 16 != 0:
+        return None
+
+    def analyse(value):
+        """(kind, [prior mean, prior spread-as-logstd, inner, observation])."""
+        bn = meta_bn.observe(**merge_dicts({name: value},
+                                           hmc._resolved_observed()))
+        stoch = [n for n in bn.nodes.values()
+                 if isinstance(n, StochasticTensor)]
+        if len(stoch) != 2:
+            return None
+        prior = [n for n in stoch if n.name == name]
+        lik = [n for n in stoch if n.name != name]
+        if len(prior) != 1 or len(lik) != 1 or not lik[0].is_observed():
+            return None
+        pd, ld = prior[0].dist, lik[0].dist
+        if type(pd) is not Normal or pd.group_ndims != 1 or \
+                pd.use_path_derivative:
+            return None
+        if pd.mean.requires_grad or pd.given_spread[1].requires_grad:
+            return None
+        obs = lik[0].tensor
+        lazy = getattr(ld, '_lazy', None)
+        if lazy is None:
+            return None
+        if type(ld) is Bernoulli:
+            if ld.group_ndims != 1 or lazy.w is not value or \
+                    lazy.X.requires_grad or obs.dim() != 1 or \
+                    obs.shape[0] != lazy.X.shape[0] or obs.requires_grad:
+                return None
+            return 'linear_bernoulli', [pd.mean, pd.logstd, lazy.X, obs]
+        if type(ld) is UnnormalizedMultinomial:
+            if ld.group_ndims != 0 or ld.normalize_logits or \
+                    lazy.phi.requires_grad or obs.requires_grad:
+                return None
+            if value.requires_grad and not _softmax_of(lazy.theta, value):
+                return None
+            batch = tuple(lazy.shape[:-1])
+            gs = tuple(obs.shape)
+            if not (len(gs) >= 1 and gs[-1] == lazy.phi.shape[1] and
+                    len(gs) - 1 <= len(batch) and
+                    gs[:-1] == batch[len(batch) - (len(gs) - 1):]):
+                return None
+            return 'mixture_multinomial', [pd.mean, pd.logstd, lazy.phi, obs]
+        return None
+
+    found = analyse(q.detach().requires_grad_(True))
+    if found is None:
+        return None
+    kind = found[0]
+
+    def probe():
+        f = analyse(q)
+        if f is None or f[0] != kind:
+            raise ValueError(
+                "HMC (native %s plan): the model changed structure between "
+                "runs; build a new HMC." % kind)
+        return f[1]
+
+    return _DenseLikelihoodPlan(hmc, names, values, chain_shape, device, probe,
+                                kind)
 
 
 def _to_data_shape(param, data_shape):
