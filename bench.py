@@ -48,6 +48,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-ess', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    ap.add_argument('--no-extra-configs', action='store_true')
+    ap.add_argument('--config5-chains', type=int, default=None)
     return ap.parse_args()
 
 
@@ -116,6 +118,157 @@ def cpu_baseline_parallel(n_data, n_leapfrogs, budget_s):
                   '(C + OpenMP restatement, one chain\'s trajectory kept in '
                   'cache, %d threads)' % (C, n_data, n_leapfrogs, iters, el,
                                           threads),
+    }
+
+
+MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 MFMA, MI355X_MICROARCH.md
+
+
+def _time_native_plan(torch, hmc, sample_op, feed, n_warm, n_timed):
+    """Wall time per transition (HIP events on the launch stream) and the
+    likelihood kernel alone (one evaluation = likelihood + gradient)."""
+    for _ in range(n_warm):
+        sample_op.run(feed_dict=feed, sync=False)
+    hmc.check_numerics()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n_timed):
+        sample_op.run(feed_dict=feed, sync=False)
+    e1.record()
+    torch.cuda.synchronize()
+    ms_transition = e0.elapsed_time(e1) / n_timed
+    plan = hmc._plan
+    stream = torch.cuda.current_stream().cuda_stream
+    plan._likelihood(plan.q_new, stream)
+    k0 = torch.cuda.Event(enable_timing=True)
+    k1 = torch.cuda.Event(enable_timing=True)
+    reps = 3
+    k0.record()
+    for _ in range(reps):
+        plan._likelihood(plan.q_new, stream)
+    k1.record()
+    torch.cuda.synchronize()
+    return ms_transition, k0.elapsed_time(k1) / reps
+
+
+def extra_config3(torch, zs, dev, n_rows=1000000, n_chains=32768, n_feat=256,
+                  n_leapfrogs=10):
+    """BASELINE configs[2]: Bayesian logistic regression, synthetic
+    10^6 x 256 design matrix, 32 768 chains, L = 10: native
+    plan = fused fp32-MFMA likelihood + csrc/hmc_model.hip, step-size
+    adaptation on."""
+    g = torch.Generator(device=dev).manual_seed(0)
+    X = torch.randn(n_rows, n_feat, device=dev, generator=g)
+    w_true = torch.randn(n_feat, device=dev, generator=g)
+    y = (torch.rand(n_rows, device=dev, generator=g) <
+         torch.sigmoid(X @ w_true / n_feat ** 0.5)).to(torch.float32)
+    zero, one = torch.zeros(n_feat, device=dev), torch.ones(n_feat, device=dev)
+
+    @zs.meta_bayesian_net()
+    def blr():
+        bn = zs.BayesianNet()
+        w = bn.normal('w', zero, std=one, n_samples=n_chains, group_ndims=1)
+        bn.bernoulli('y', zs.linear_logits(w.tensor, X), group_ndims=1,
+                     dtype=torch.float32)
+        return bn
+
+    w = torch.zeros(n_chains, n_feat, device=dev)
+    hmc = zs.HMC(step_size=1e-3, n_leapfrogs=n_leapfrogs,
+                 adapt_step_size=True, target_acceptance_rate=0.8, seed=2)
+    op, info = hmc.sample(blr(), {'y': y}, {'w': w})
+    ms, kern_ms = _time_native_plan(torch, hmc, op, None, 2, 2)
+    flop_eval = 4.0 * n_rows * n_feat * n_chains
+    return {
+        'workload': 'configs[2]: Bayesian logistic regression, synthetic '
+                    '%d x %d, %d chains, L=%d, adaptation on' % (
+                        n_rows, n_feat, n_chains, n_leapfrogs),
+        'plan': hmc.plan_kind,
+        'ms_per_step': ms,
+        'steps': 2,
+        'value': n_chains * n_leapfrogs / (ms * 1e-3),
+        'unit': 'chain-leapfrog-steps/s',
+        'mean_acceptance': float(info.acceptance_rate.mean().item()),
+        'step_size': float(info.updated_step_size.item()),
+        'roofline': {
+            'bound': 'mfma_f32', 'peak': MFMA_F32_PEAK_TFLOPS,
+            'unit': 'TFLOP/s',
+            'kernel': 'linear_bernoulli_kernel_v2<%d>' % n_feat,
+            'kernel_ms': kern_ms,
+            'achieved': flop_eval / (kern_ms * 1e-3) / 1e12,
+            'frac': flop_eval / (kern_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+            'algorithmic_flop_per_launch': flop_eval,
+            'sustained_over_transition': (n_leapfrogs + 1) * flop_eval /
+            (ms * 1e-3) / 1e12,
+        },
+    }
+
+
+def extra_config5(torch, zs, dev, n_chains=None, n_docs=5000, n_topics=128,
+                  n_vocab=12419, n_leapfrogs=20):
+    """BASELINE configs[4]: the E-step of the logistic-normal topic model at
+    the lntm_mcem.py shape (chain axes [n_chains, n_docs = 5 000], K = 128,
+    V = 12 419 -- the UCI "nips" vocabulary the example loads), step-size and
+    mass adaptation on, L = 20.  "8 192 chains" is read as n_chains = 8 192
+    (4.1e7 (chain, document) rows, 21 GB per [rows, K] buffer) when that fits
+    the free HBM, else the largest power of two that does; the line says which."""
+    free_b, _ = torch.cuda.mem_get_info()
+    if n_chains is None:
+        n_chains = 8192
+        # q, q_new, p, grad, operand + search cache (grad, operand) + headroom
+        while n_chains > 64 and 9.0 * n_chains * n_docs * n_topics * 4 > free_b:
+            n_chains //= 2
+    g = torch.Generator(device=dev).manual_seed(0)
+    phi = torch.softmax(torch.randn(n_topics, n_vocab, device=dev,
+                                    generator=g), -1)
+    x = torch.poisson(torch.full((n_docs, n_vocab), 1000.0 / n_vocab,
+                                 device=dev), generator=g)
+    eta_mean = torch.zeros(n_docs, n_topics, device=dev)
+    eta_logstd = torch.zeros(n_topics, device=dev)
+
+    @zs.meta_bayesian_net()
+    def lntm():
+        bn = zs.BayesianNet()
+        eta = bn.normal('eta', eta_mean, logstd=eta_logstd,
+                        n_samples=n_chains, group_ndims=1)
+        bn.unnormalized_multinomial(
+            'x', zs.log_mixture(torch.softmax(eta.tensor, -1), phi),
+            normalize_logits=False, dtype=torch.float32)
+        return bn
+
+    eta = torch.zeros(n_chains, n_docs, n_topics, device=dev)
+    hmc = zs.HMC(step_size=1e-3, n_leapfrogs=n_leapfrogs,
+                 adapt_step_size=True, adapt_mass=True,
+                 target_acceptance_rate=0.6, seed=3)
+    op, info = hmc.sample(lntm(), {'x': x}, {'eta': eta})
+    big = n_chains >= 2048
+    ms, kern_ms = _time_native_plan(torch, hmc, op, None, 1, 1 if big else 3)
+    rows = n_chains * n_docs
+    flop_eval = 4.0 * rows * n_topics * n_vocab
+    return {
+        'workload': 'configs[4]: logistic-normal topic model E-step, chain '
+                    'axes [n_chains=%d, n_docs=%d] (= %d rows; "8 192 chains" '
+                    'read as n_chains), K=%d, V=%d, L=%d, step-size and mass '
+                    'adaptation on' % (n_chains, n_docs, rows, n_topics,
+                                       n_vocab, n_leapfrogs),
+        'plan': hmc.plan_kind,
+        'ms_per_step': ms,
+        'steps': 1 if big else 3,
+        'value': rows * n_leapfrogs / (ms * 1e-3),
+        'unit': '(chain, document)-leapfrog-steps/s',
+        'mean_acceptance': float(info.acceptance_rate.mean().item()),
+        'roofline': {
+            'bound': 'mfma_f32', 'peak': MFMA_F32_PEAK_TFLOPS,
+            'unit': 'TFLOP/s',
+            'kernel': 'linear_bernoulli_kernel_v2<%d> (multinomial mode)'
+                      % n_topics,
+            'kernel_ms': kern_ms,
+            'achieved': flop_eval / (kern_ms * 1e-3) / 1e12,
+            'frac': flop_eval / (kern_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+            'algorithmic_flop_per_launch': flop_eval,
+            'sustained_over_transition': (n_leapfrogs + 1) * flop_eval /
+            (ms * 1e-3) / 1e12,
+        },
     }
 
 
@@ -391,6 +544,24 @@ def main():
                     D, L, min(args.cpu_seconds, 8.0))
             except Exception as e:           # no gcc / OpenMP on the box
                 out['cpu_baseline_parallel'] = {'error': str(e)[:200]}
+        if world == 1 and not args.no_extra_configs:
+            # the MFMA-bound configurations of BASELINE.json, after the
+            # headline: each frees its buffers before the next starts
+            del x
+            torch.cuda.empty_cache()
+            extras = []
+            for fn, kw in ((extra_config3, {}),
+                           (extra_config5,
+                            {'n_chains': args.config5_chains})):
+                try:
+                    extras.append(fn(torch, zs, dev, **kw))
+                except Exception as e:       # report, never lose the headline
+                    extras.append({'workload': fn.__name__,
+                                   'error': repr(e)[:300]})
+                from zhusuan_amd import _ops
+                _ops.clear_caches()
+                torch.cuda.empty_cache()
+            out['extra_configs'] = extras
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

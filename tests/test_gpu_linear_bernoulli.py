@@ -86,11 +86,15 @@ def test_multi_axis_chains_and_fallback(env):
                                rtol=2e-5, atol=1e-3)
 
 
-def test_bayesian_logistic_regression_hmc(env):
-    """w ~ N(0, 1), y ~ Bernoulli(w X^T): generic plan driving the fused MFMA
-    kernel vs the oracle with materialised logits."""
+@pytest.mark.parametrize('native,D', [(True, 16), (False, 16), (True, 64),
+                                      (True, 20)])
+def test_bayesian_logistic_regression_hmc(env, native, D):
+    """w ~ N(0, 1), y ~ Bernoulli(w X^T) vs the oracle with materialised
+    logits: the native plan (fused MFMA likelihood + csrc/hmc_model.hip, no
+    autograd; D = 64: no operand padding, D = 20: padded) and the generic
+    plan (autograd glue around the same likelihood kernel)."""
     zs, torch, dev = env
-    C, N, D = 96, 600, 16
+    C, N = 96, 600
     X, y, W0 = _data(C, N, D, seed=5)
     W0 *= 0.3
     Xt, yt = torch.tensor(X, device=dev), torch.tensor(y, device=dev)
@@ -105,9 +109,10 @@ def test_bayesian_logistic_regression_hmc(env):
         return bn
 
     wt = torch.tensor(W0, device=dev)
-    hmc = zs.HMC(step_size=0.01, n_leapfrogs=6, adapt_step_size=True, seed=9)
+    hmc = zs.HMC(step_size=0.01, n_leapfrogs=6, adapt_step_size=True, seed=9,
+                 native_plans=native)
     op, info = hmc.sample(blr(), {'y': yt}, {'w': wt})
-    assert hmc.plan_kind == 'generic'
+    assert hmc.plan_kind == ('linear_bernoulli' if native else 'generic')
 
     def lj(q):
         w = q[0]

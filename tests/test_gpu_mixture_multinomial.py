@@ -141,6 +141,85 @@ def test_lntm_estep_fused_equals_dense_model(env):
         eta_b.copy_(eta_a)
 
 
+@pytest.mark.parametrize('user_log_joint', [False, True])
+def test_lntm_native_plan_equals_generic_plan(env, user_log_joint):
+    """The E-step of lntm_mcem.py (eta ~ N(eta_mean[doc], exp(eta_logstd)),
+    x ~ UnnormalizedMultinomial(log(softmax(eta) . phi))) sampled by the
+    native plan -- softmax forward / Jacobian, prior, kick and drift in
+    csrc/hmc_model.hip around the fused MFMA likelihood, no autograd -- and by
+    the generic plan (torch.softmax + autograd around the same likelihood):
+    identical sampler traces, step-size and mass adaptation on, per-document
+    prior means fed through a placeholder and changed mid-run
+    (lntm_mcem.py:164-169).  With the reference's E-step objective
+    (lntm_mcem.py:97-102: cond_log_prob('eta') + cond_log_prob('x') as the
+    user log-joint, a third node `beta` observed) and with the default joint."""
+    zs, torch, dev = env
+    n_chains, n_docs, K, V = 3, 24, 20, 300
+    phi, x, _ = _data(n_chains, n_docs, K, V, seed=11)
+    T = lambda a: torch.tensor(a, device=dev)
+    phi_t, x_t = T(phi), T(x)
+    rng = np.random.RandomState(1)
+    eta0 = (0.1 * rng.normal(size=(n_chains, n_docs, K))).astype(np.float32)
+    means = [np.zeros((n_docs, K), np.float32),
+             (0.3 * rng.normal(size=(n_docs, K))).astype(np.float32)]
+    logstd = T((0.2 * rng.normal(size=K)).astype(np.float32))
+
+    def build(native):
+        mean_ph = zs.placeholder(torch.float32, name='eta_mean')
+        mean_ph.feed(means[0], dev)
+
+        @zs.meta_bayesian_net()
+        def lntm():
+            bn = zs.BayesianNet()
+            eta = bn.normal('eta', mean_ph.value, logstd=logstd,
+                            n_samples=n_chains, group_ndims=1)
+            if user_log_joint:
+                bn.normal('beta', torch.zeros(K, V, device=dev), logstd=1.0,
+                          group_ndims=1)
+            bn.unnormalized_multinomial(
+                'x', zs.log_mixture(torch.softmax(eta.tensor, -1), phi_t),
+                normalize_logits=False, dtype=torch.float32)
+            return bn
+        m = lntm()
+        obs = {'x': x_t}
+        if user_log_joint:
+            m.log_joint = lambda bn: (bn.cond_log_prob('eta') +
+                                      bn.cond_log_prob('x'))
+            obs['beta'] = torch.log(phi_t)
+        eta = T(eta0)
+        flag = zs.placeholder(bool)
+        hmc = zs.HMC(step_size=1e-3, n_leapfrogs=6, adapt_step_size=flag,
+                     adapt_mass=flag, mass_collect_iters=4,
+                     target_acceptance_rate=0.6, seed=4, native_plans=native)
+        op, info = hmc.sample(m, obs, {'eta': eta})
+        return hmc, op, info, eta, mean_ph, flag
+
+    ha, op_a, info_a, eta_a, ph_a, fl_a = build(True)
+    hb, op_b, info_b, eta_b, ph_b, fl_b = build(False)
+    assert ha.plan_kind == 'mixture_multinomial' and hb.plan_kind == 'generic'
+    for it in range(10):
+        m = means[it // 5]
+        op_a.run(feed_dict={ph_a: m, fl_a: it < 8})
+        op_b.run(feed_dict={ph_b: m, fl_b: it < 8})
+        np.testing.assert_allclose(info_a.orig_log_prob.cpu().numpy(),
+                                   info_b.orig_log_prob.cpu().numpy(),
+                                   rtol=2e-5, atol=2e-3)
+        np.testing.assert_allclose(info_a.hamiltonian.cpu().numpy(),
+                                   info_b.hamiltonian.cpu().numpy(),
+                                   rtol=2e-5, atol=4e-3)
+        np.testing.assert_allclose(info_a.acceptance_rate.cpu().numpy(),
+                                   info_b.acceptance_rate.cpu().numpy(),
+                                   atol=5e-3)
+        np.testing.assert_allclose(float(info_a.updated_step_size.item()),
+                                   float(info_b.updated_step_size.item()),
+                                   rtol=5e-3)
+        same = (eta_a - eta_b).abs().amax(-1) < 1e-3
+        assert float(same.float().mean()) > 0.93
+        eta_b.copy_(eta_a)
+    np.testing.assert_allclose(ha._plan.mass[0].cpu().numpy(),
+                               hb._plan.mass[0].cpu().numpy(), rtol=1e-3)
+
+
 def test_recomputed_phi_never_hits_a_stale_pad_cache(env):
     """A model builder recomputes phi = softmax(beta) per evaluation; the
     caching allocator may give the new phi the address of the freed old one.

@@ -14,6 +14,7 @@ write = float(re.search(r'WRITE_SIZE\s+mean ([0-9.e+]+)', txt).group(1))
 rd = fetch * 1024.0 * 2.0
 wr = write * 1024.0
 out = {
+    'round': tag,
     'source': 'profiles/%s_rocprofv3_summary.txt (rocprofv3 --pmc FETCH_SIZE / '
               '--pmc WRITE_SIZE, separate passes, bench.py config 2)' % tag,
     'fetch_size_kb_raw': fetch,

@@ -1,0 +1,57 @@
+#!/usr/bin/env python
+"""Workload for tools/profile_native.sh: a few transitions of the two native
+dense-likelihood plans (BASELINE configs[2] and configs[4], reduced so that a
+traced run takes seconds), bracketed by marker launches (state_set_kernel) so
+that the kernel trace can be cut to the transitions alone.
+  python tools/native_plan_trace.py [n_rows_config3] [n_chains_config5]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import zhusuan_amd as zs  # noqa: E402
+from zhusuan_amd import _capi  # noqa: E402
+import bench  # noqa: E402
+
+n_rows = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+n_chains5 = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+dev = torch.device('cuda', 0)
+marker = torch.zeros(_capi.STATE_WORDS, device=dev)
+
+
+def mark():
+    _capi.call('zshmc_state_set', marker.data_ptr(), 7, 1.0,
+               torch.cuda.current_stream().cuda_stream)
+
+
+orig = bench._time_native_plan
+
+
+def traced(torch_, hmc, op, feed, n_warm, n_timed):
+    for _ in range(n_warm):
+        op.run(feed_dict=feed, sync=False)
+    hmc.check_numerics()
+    torch_.cuda.synchronize()
+    mark()
+    for _ in range(3):
+        op.run(feed_dict=feed, sync=False)
+    mark()
+    torch_.cuda.synchronize()
+    return orig(torch_, hmc, op, feed, 0, 2)
+
+
+bench._time_native_plan = traced
+r3 = bench.extra_config3(torch, zs, dev, n_rows=n_rows)
+print('config3 slice: %.2f ms/transition, kernel %.3f ms = %.1f TFLOP/s (%.1f%%), plan %s' % (
+    r3['ms_per_step'], r3['roofline']['kernel_ms'], r3['roofline']['achieved'],
+    100 * r3['roofline']['frac'], r3['plan']))
+from zhusuan_amd import _ops  # noqa: E402
+_ops.clear_caches()
+torch.cuda.empty_cache()
+r5 = bench.extra_config5(torch, zs, dev, n_chains=n_chains5)
+print('config5 at n_chains=%d: %.2f ms/transition, kernel %.3f ms = %.1f TFLOP/s (%.1f%%), '
+      'sustained %.1f TFLOP/s, plan %s' % (
+          n_chains5, r5['ms_per_step'], r5['roofline']['kernel_ms'],
+          r5['roofline']['achieved'], 100 * r5['roofline']['frac'],
+          r5['roofline']['sustained_over_transition'], r5['plan']))

@@ -8,7 +8,7 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="python $REPO/bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-ess"
+CMD="python $REPO/bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-ess --no-extra-configs"
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -o trace --output-format csv -- $CMD > $OUT/${TAG}_trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $OUT/${TAG}_pmc_fetch -o pmc --output-format csv -- $CMD > $OUT/${TAG}_pmc_fetch.log 2>&1

@@ -1039,14 +1039,23 @@ class _DenseLikelihoodPlan(_PlanBase):
                               None if self.operand is None
                               else self.operand.clone())
 
-    def search_trip(self, t, step_size, stream):
-        self._in_search = True
+    def _restore_start(self, t, stream):
+        """(q, p0, ll, grad, operand) of the start point: q from the latent,
+        p0 regenerated from its Philox counters (cheaper in memory than a
+        copy: config 5 holds 21 GB per [rows, K] buffer), the evaluation from
+        the search cache."""
         ll0, g0, op0 = self._search_cache
-        q1, p1 = self.q[0].clone(), self.p.clone()
+        self.q_new.copy_(self.q[0])
+        self._momentum(t, stream)
         self.ll.copy_(ll0)
         self.grad.copy_(g0)
         if op0 is not None:
             self.operand.copy_(op0)
+
+    def search_trip(self, t, step_size, stream):
+        self._in_search = True
+        self._restore_start(t, stream)
+        q1, p1 = self.q_new, self.p
         self._step(q1, p1, True, step_size, 0.5, 1.0, self.lp_old, None,
                    stream)
         self._likelihood(q1, stream)
@@ -1064,15 +1073,11 @@ class _DenseLikelihoodPlan(_PlanBase):
         self.last_t = t
         L = self.hmc.n_leapfrogs
         q, p = self.q_new, self.p
-        q.copy_(self.q[0])
         if self._search_cache is not None:    # same q, same p0 (Appendix B 11)
-            ll0, g0, op0 = self._search_cache
+            self._restore_start(t, stream)
             self._search_cache = None
-            self.ll.copy_(ll0)
-            self.grad.copy_(g0)
-            if op0 is not None:
-                self.operand.copy_(op0)
         else:
+            q.copy_(self.q[0])
             self._momentum(t, stream)
             self._first_evaluation(q, stream)
         self.kin_new.zero_()
@@ -1143,10 +1148,31 @@ def _softmax_of(theta, probe):
     return getattr(nxt, 'variable', None) is probe
 
 
+def _summands_of(lp, nodes):
+    """The nodes whose `cond_log_p` tensors are exactly the two operands of
+    `lp = a + b` (identity of autograd nodes), else None."""
+    fn = getattr(lp, 'grad_fn', None)
+    if fn is None or type(fn).__name__ != 'AddBackward0' or \
+            getattr(fn, '_saved_alpha', 1) != 1:
+        return None
+    parents = [f for f, _ in fn.next_functions]
+    if len(parents) != 2 or parents[0] is None or parents[1] is None:
+        return None
+    picked = []
+    for node in nodes:
+        clp = node.__dict__.get('_cond_log_p')      # evaluated by lp only
+        if clp is not None and any(clp.grad_fn is f for f in parents):
+            picked.append(node)
+    if len(picked) != 2 or picked[0]._cond_log_p.grad_fn is \
+            picked[1]._cond_log_p.grad_fn:
+        return None
+    return picked
+
+
 def _try_dense_likelihood_plan(hmc, meta_bn, names, values, chain_shape,
                                device):
     from .distributions import Bernoulli, UnnormalizedMultinomial
-    if not isinstance(meta_bn, MetaBayesianNet) or meta_bn.log_joint is not None:
+    if not isinstance(meta_bn, MetaBayesianNet):
         return None
     if len(names) != 1:
         return None
@@ -1163,6 +1189,18 @@ def _try_dense_likelihood_plan(hmc, meta_bn, names, values, chain_shape,
                                            hmc._resolved_observed()))
         stoch = [n for n in bn.nodes.values()
                  if isinstance(n, StochasticTensor)]
+        if meta_bn.log_joint is not None:
+            # a user log-joint is accepted when it is, structurally, the sum
+            # of two nodes' conditional log-densities -- the E-step objective
+            # of lntm_mcem.py:97-102, cond_log_prob('eta') + cond_log_prob('x')
+            # -- checked on the autograd graph (a tempered or re-weighted
+            # joint, e.g. AIS's, has multiplications on top and is refused)
+            stoch = _summands_of(bn.log_joint(), stoch) \
+                if value.requires_grad else [
+                    n for n in stoch if n.name in analyse.accepted]
+            if stoch is None:
+                return None
+            analyse.accepted = [n.name for n in stoch]
         if len(stoch) != 2:
             return None
         prior = [n for n in stoch if n.name == name]
@@ -1200,6 +1238,7 @@ def _try_dense_likelihood_plan(hmc, meta_bn, names, values, chain_shape,
             return 'mixture_multinomial', [pd.mean, pd.logstd, lazy.phi, obs]
         return None
 
+    analyse.accepted = []
     found = analyse(q.detach().requires_grad_(True))
     if found is None:
         return None
