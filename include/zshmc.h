@@ -61,6 +61,9 @@ extern "C" {
 
 const char* zshmc_last_error(void);
 int zshmc_version(void);
+/* Clear n_bytes of device memory on `stream` (the += accumulators below:
+ * kinetic energies, column sums). */
+int zshmc_zero(void* ptr, int64_t n_bytes, void* stream);
 
 /* Largest n_data the fused diag-Normal kernel accepts. */
 int64_t zshmc_fused_max_n_data(void);

@@ -28,20 +28,58 @@ if ROOT not in sys.path:
 from oracle import philox, tf_shim  # noqa: E402
 
 
-def load_reference_hmc():
+def _load(pkg, name):
+    spec = importlib.util.spec_from_file_location(
+        'zhusuan.' + name,
+        os.path.join(REF, 'zhusuan', name.replace('.', '/') + '.py'))
+    m = importlib.util.module_from_spec(spec)
+    sys.modules['zhusuan.' + name] = m
+    spec.loader.exec_module(m)
+    return m
+
+
+def _subpackage(pkg, name, members):
+    """A `zhusuan.<name>` namespace holding the __all__ of the listed member
+    modules (the real __init__ files also import modules this harness does
+    not need: the other distributions, variational objectives ...)."""
+    p = types.ModuleType('zhusuan.' + name)
+    p.__path__ = [os.path.join(REF, 'zhusuan', name)]
+    sys.modules['zhusuan.' + name] = p
+    setattr(pkg, name, p)
+    for member in members:
+        m = _load(pkg, name + '.' + member)
+        for k in getattr(m, '__all__', []):
+            setattr(p, k, getattr(m, k))
+    return p
+
+
+def load_reference():
+    """The reference's own hmc.py, model layer (framework/{utils,meta_bn,bn}.py,
+    distributions/{utils,base,univariate}.py) and evaluation.py, unmodified,
+    over the TensorFlow-API shim.  Returns (tf, zhusuan-like namespace)."""
     tf = tf_shim.install()
     pkg = types.ModuleType('zhusuan')
     pkg.__path__ = [os.path.join(REF, 'zhusuan')]
     sys.modules['zhusuan'] = pkg
-    mods = {}
-    for name in ('utils', 'hmc'):
-        spec = importlib.util.spec_from_file_location(
-            'zhusuan.' + name, os.path.join(REF, 'zhusuan', name + '.py'))
-        m = importlib.util.module_from_spec(spec)
-        sys.modules['zhusuan.' + name] = m
-        spec.loader.exec_module(m)
-        mods[name] = m
-    return tf, mods['hmc']
+    pkg.utils = _load(pkg, 'utils')
+    _subpackage(pkg, 'distributions', ['utils', 'base', 'univariate'])
+    fw = _subpackage(pkg, 'framework', ['utils', 'meta_bn', 'bn'])
+    pkg.hmc = _load(pkg, 'hmc')
+    # evaluation.py imports one symbol of zhusuan.variational that only
+    # is_loglikelihood() uses; AIS does not
+    var = types.ModuleType('zhusuan.variational')
+    var.ImportanceWeightedObjective = None
+    sys.modules['zhusuan.variational'] = var
+    pkg.evaluation = _load(pkg, 'evaluation')
+    pkg.HMC = pkg.hmc.HMC
+    pkg.BayesianNet = fw.BayesianNet
+    pkg.meta_bayesian_net = fw.meta_bayesian_net
+    return tf, pkg
+
+
+def load_reference_hmc():
+    tf, pkg = load_reference()
+    return tf, pkg.hmc
 
 
 class Stream(object):
@@ -68,7 +106,7 @@ class Stream(object):
                                         self.n_chains).reshape(shape)
 
 
-def run_case(tf, ref_hmc, name, make_log_joint, latents, hmc_kwargs, n_iters,
+def run_case(tf, zs, name, make_log_joint, latents, hmc_kwargs, n_iters,
              flags, seed, chain_shape):
     """flags(i) -> (adapt_step_size, adapt_mass) values fed at iteration i
     (None = the sampler was built without that adaptation)."""
@@ -82,8 +120,8 @@ def run_case(tf, ref_hmc, name, make_log_joint, latents, hmc_kwargs, n_iters,
         ph_m = kw['adapt_mass'] = tf.placeholder(tf.bool, name='adapt_mass')
     lat_vars = {k: tf.Variable(np.asarray(v, np.float32), name=k)
                 for k, v in latents.items()}
-    hmc = ref_hmc.HMC(**kw)
-    log_joint = make_log_joint(tf)
+    hmc = zs.hmc.HMC(**kw)
+    log_joint = make_log_joint(tf, zs, int(np.prod(chain_shape)))
     stream = Stream(seed, chain_shape)
     tf_shim.set_random_source(stream.normal, stream.uniform)
     mark = tf_shim.variable_mark()
@@ -125,27 +163,32 @@ def run_case(tf, ref_hmc, name, make_log_joint, latents, hmc_kwargs, n_iters,
 
 
 # ---- the cases (mirrored in tests/helpers_hmc_cases.py) ----------------------
-def gaussian_log_joint(mean, logstd):
-    """Normal._log_prob (univariate.py:174-181) reduced over the data axis
-    (group_ndims = 1, base.py:302-304), written against the tf API."""
-    def make(tf):
-        m = tf.constant(mean)
-        ls = tf.constant(logstd)
-        c = np.float32(-0.5 * np.log(2 * np.pi))
-
-        def log_joint(obs):
-            x = obs['x']
-            prec = tf.exp(-2 * ls)
-            return tf.reduce_sum(c - ls - 0.5 * prec * tf.square(x - m),
-                                 axis=-1)
-        return log_joint
+def gaussian_model(mean, logstd=None, std=None):
+    """The model of examples/toy_examples/gaussian.py:15-20 built with the
+    reference's OWN model layer (meta_bayesian_net -> BayesianNet.normal ->
+    distributions.Normal._log_prob, reduced by group_ndims = 1): what
+    HMC.sample re-enters through meta_bn.observe(**obs).log_joint()
+    (hmc.py:416, meta_bn.py:93-106, bn.py:454-478, base.py:290-304,
+    univariate.py:174-181)."""
+    def make(tf, zs, n_chains):
+        @zs.meta_bayesian_net()
+        def gaussian():
+            bn = zs.BayesianNet()
+            if std is not None:
+                bn.normal('x', tf.constant(mean), std=tf.constant(std),
+                          n_samples=n_chains, group_ndims=1)
+            else:
+                bn.normal('x', tf.constant(mean), logstd=tf.constant(logstd),
+                          n_samples=n_chains, group_ndims=1)
+            return bn
+        return gaussian()
     return make
 
 
 def coupled_log_joint(prec_x):
     """Two latents, chain shape [4, 5]:
     -0.5 sum prec (x^2) - 0.5 sum y^2 - 0.1 (sum x)(sum y)^2 / 10."""
-    def make(tf):
+    def make(tf, zs, n_chains):
         px = tf.constant(prec_x)
 
         def log_joint(obs):
@@ -168,8 +211,8 @@ def cases():
     stdev = (1.0 / (np.arange(D) + 1)).astype(np.float32)
     out.append(dict(
         name='gauss_adapt', chain_shape=(24,),
-        make_log_joint=gaussian_log_joint(np.zeros(D, np.float32),
-                                          np.log(stdev).astype(np.float32)),
+        make_log_joint=gaussian_model(np.zeros(D, np.float32),
+                                     np.log(stdev).astype(np.float32)),
         latents={'x': (0.1 * rng.normal(size=(24, D))).astype(np.float32)},
         hmc_kwargs=dict(step_size=1e-3, n_leapfrogs=5,
                         adapt_step_size='placeholder', adapt_mass='placeholder',
@@ -188,7 +231,7 @@ def cases():
     D = 33
     out.append(dict(
         name='gauss_ss', chain_shape=(17,),
-        make_log_joint=gaussian_log_joint(
+        make_log_joint=gaussian_model(
             np.linspace(-1, 1, D).astype(np.float32),
             np.linspace(-0.7, 0.4, D).astype(np.float32)),
         latents={'x': rng.normal(size=(17, D)).astype(np.float32)},
@@ -200,7 +243,7 @@ def cases():
     D = 260
     out.append(dict(
         name='gauss_ring', chain_shape=(20,),
-        make_log_joint=gaussian_log_joint(
+        make_log_joint=gaussian_model(
             np.linspace(-2, 2, D).astype(np.float32),
             np.linspace(0.0, 1.2, D).astype(np.float32)),
         latents={'x': rng.normal(size=(20, D)).astype(np.float32)},
@@ -208,14 +251,28 @@ def cases():
                         adapt_step_size='placeholder', adapt_mass='placeholder',
                         target_acceptance_rate=0.8, mass_collect_iters=4),
         n_iters=26, flags=lambda i: (i < 22, i < 18), seed=14))
+    # E: examples/toy_examples/gaussian.py literally (:15-20, :27-58 with
+    # n_x = 10): mean tf.zeros, `std=` constructor path (log(std) inside
+    # Normal, univariate.py:96-103), q0 = 0, eps0 = 1e-3, L = 5, delta = 0.9,
+    # both adaptations on for the first half of the run
+    D = 10
+    stdev = (1.0 / (np.arange(D) + 1)).astype(np.float32)
+    out.append(dict(
+        name='gaussian_py', chain_shape=(100,),
+        make_log_joint=gaussian_model(np.zeros(D, np.float32), std=stdev),
+        latents={'x': np.zeros((100, D), np.float32)},
+        hmc_kwargs=dict(step_size=1e-3, n_leapfrogs=5,
+                        adapt_step_size='placeholder', adapt_mass='placeholder',
+                        target_acceptance_rate=0.9),
+        n_iters=30, flags=lambda i: (i < 15, i < 15), seed=1))
     return out
 
 
 def main():
-    tf, ref_hmc = load_reference_hmc()
+    tf, zs = load_reference()
     res = {}
     for c in cases():
-        res.update(run_case(tf, ref_hmc, **c))
+        res.update(run_case(tf, zs, **c))
         for k, v in c['latents'].items():
             res['%s/q0_%s' % (c['name'], k)] = v
     path = os.path.join(ROOT, 'tests', 'golden', 'hmc_reference_traces.npz')

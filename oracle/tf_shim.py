@@ -38,10 +38,13 @@ import types
 import numpy as np
 import torch
 
+float16 = torch.float16
 float32 = torch.float32
 float64 = torch.float64
+int16 = torch.int16
 int32 = torch.int32
 int64 = torch.int64
+Tensor = torch.Tensor
 bool = torch.bool  # noqa: A001  (tf.bool)
 
 _py_bool = __builtins__['bool'] if isinstance(__builtins__, dict) \
@@ -53,14 +56,21 @@ class InvalidArgumentError(ArithmeticError):
 
 
 class TensorShape(object):
+    """Static shapes are always fully known in eager execution; `dims=None`
+    (unknown rank) exists only so that `if not shape` keeps TensorFlow's
+    meaning (hmc.py:437)."""
+
     def __init__(self, dims=()):
-        self.dims = [None if d is None else int(d) for d in dims]
+        if isinstance(dims, TensorShape):
+            dims = dims.dims
+        self.dims = None if dims is None else [
+            None if d is None else int(d) for d in dims]
 
     def __len__(self):
         return len(self.dims)
 
     def __bool__(self):
-        return len(self.dims) > 0
+        return self.dims is not None
 
     __nonzero__ = __bool__
 
@@ -72,14 +82,54 @@ class TensorShape(object):
             return TensorShape(self.dims[i])
         return self.dims[i]
 
+    def __eq__(self, other):
+        try:
+            return list(self.dims) == list(TensorShape(other).dims)
+        except TypeError:
+            return NotImplemented
+
+    def __ne__(self, other):
+        return not self == other
+
+    @property
+    def ndims(self):
+        return None if self.dims is None else len(self.dims)
+
+    def is_fully_defined(self):
+        return self.dims is not None and all(d is not None for d in self.dims)
+
     def concatenate(self, other):
-        return TensorShape(self.dims + list(other))
+        return TensorShape(self.dims + list(TensorShape(other).dims))
 
     def as_list(self):
         return list(self.dims)
 
     def __repr__(self):
         return 'TensorShape(%r)' % (self.dims,)
+
+    __str__ = lambda self: str(tuple(self.dims))
+
+
+def broadcast_static_shape(shape_x, shape_y):
+    a, b = TensorShape(shape_x).as_list(), TensorShape(shape_y).as_list()
+    n = max(len(a), len(b))
+    a, b = [1] * (n - len(a)) + a, [1] * (n - len(b)) + b
+    out = []
+    for x, y in zip(a, b):
+        if x == 1:
+            out.append(y)
+        elif y == 1 or x == y:
+            out.append(x)
+        else:
+            raise ValueError('Incompatible shapes for broadcasting: %s and %s'
+                             % (shape_x, shape_y))
+    return TensorShape(out)
+
+
+def broadcast_dynamic_shape(shape_x, shape_y):
+    return torch.tensor(broadcast_static_shape(
+        _shape_list(shape_x), _shape_list(shape_y)).as_list(),
+        dtype=torch.int32)
 
 
 def _get_shape(t):
@@ -88,6 +138,7 @@ def _get_shape(t):
 
 # tensors are plain torch tensors; give them the one TF method hmc.py calls
 torch.Tensor.get_shape = _get_shape
+torch.Tensor.set_shape = lambda self, shape: None
 
 
 # ---- variables with graph-like persistence --------------------------------
@@ -189,11 +240,22 @@ def placeholder(dtype, shape=None, name=None):
     return Placeholder(dtype, shape, name)
 
 
+_CONVERTERS = []     # tf.register_tensor_conversion_function
+
+
+def register_tensor_conversion_function(base_type, conversion_func,
+                                        priority=100):
+    _CONVERTERS.append((base_type, conversion_func))
+
+
 def _t(x):
     if isinstance(x, Variable):
         return x.value
     if isinstance(x, Placeholder):
         return x.value
+    for base, fn in _CONVERTERS:
+        if isinstance(x, base):
+            return fn(x)
     return x
 
 
@@ -202,6 +264,9 @@ def convert_to_tensor(value, dtype=None, name=None):
         return value                     # resolved where it is consumed
     if isinstance(value, Variable):
         value = value.value
+    for base, fn in _CONVERTERS:
+        if isinstance(value, base):
+            value = fn(value)
     if isinstance(value, TensorShape):
         value = value.as_list()
     if isinstance(value, torch.Tensor):
@@ -423,6 +488,95 @@ def random_uniform(shape, minval=0, maxval=None, dtype=torch.float32,
         _RANDOM['uniform'](tuple(_shape_list(shape))), dtype=np.float32))
 
 
+# ---- the rest of the surface the model layer touches ------------------------
+# (zhusuan/framework/{bn,meta_bn,utils}.py, distributions/{base,utils,
+# univariate}.py, evaluation.py -- loaded unmodified by
+# oracle/make_golden_model.py)
+@contextlib.contextmanager
+def variable_scope(name_or_scope=None, default_name=None, reuse=None, **kw):
+    yield
+
+
+def make_template(name, func, **kw):
+    return func
+
+
+def squeeze(x, axis=None, name=None):
+    x = _t(x)
+    return x.squeeze() if axis is None else x.squeeze(_axes(axis))
+
+
+def reduce_prod(x, axis=None, keepdims=False, name=None, **kw):
+    x = _t(x)
+    ax = _axes(axis)
+    if ax is None:
+        return x.prod()
+    if ax == ():
+        return x
+    for a in sorted([a % x.dim() for a in (ax if isinstance(ax, tuple)
+                                           else (ax,))], reverse=True):
+        x = x.prod(dim=a, keepdim=keepdims)
+    return x
+
+
+def reduce_max(x, axis=None, keepdims=False, name=None, **kw):
+    x = _t(x)
+    ax = _axes(axis)
+    return x.max() if ax is None else x.amax(dim=ax, keepdim=keepdims)
+
+
+def reduce_all(x, axis=None, name=None, **kw):
+    return _t(x).all()
+
+
+def reduce_logsumexp(x, axis=None, keepdims=False, name=None, **kw):
+    x = _t(x)
+    ax = _axes(axis)
+    if ax is None:
+        ax = tuple(__builtins__['range'](x.dim()) if isinstance(
+            __builtins__, dict) else __builtins__.range(x.dim()))
+    return torch.logsumexp(x, dim=ax, keepdim=keepdims)
+
+
+def _noop_assert(*a, **kw):
+    return None
+
+
+assert_rank = assert_rank_at_least = assert_greater = _noop_assert
+assert_greater_equal = assert_positive = assert_non_negative = _noop_assert
+
+
+def concat(values, axis, name=None):
+    return torch.cat([_tt(v).reshape(-1) if _tt(v).dim() == 0 else _tt(v)
+                      for v in values], dim=axis)
+
+
+def stack(values, axis=0, name=None):
+    return torch.stack([_tt(v) for v in values], dim=axis)
+
+
+def reshape(x, s, name=None):
+    return _t(x).reshape(_shape_list(s))
+
+
+def transpose(x, perm=None, name=None):
+    x = _t(x)
+    return x.t() if perm is None else x.permute(*[int(i) for i in perm])
+
+
+def rank(x, name=None):
+    return _t(x).dim()
+
+
+def sigmoid(x, name=None): return torch.sigmoid(_t(x))
+def sign(x, name=None): return torch.sign(_t(x))
+def lgamma(x, name=None): return torch.lgamma(_t(x))
+def less_equal(x, y, name=None): return _tt(x) <= _tt(y)
+def greater(x, y, name=None): return _tt(x) > _tt(y)
+def greater_equal(x, y, name=None): return _tt(x) >= _tt(y)
+def floordiv(x, y, name=None): return torch.floor_divide(_tt(x), _tt(y))
+
+
 def install():
     """Register this module as `tensorflow` (only if the real one is absent)."""
     mod = sys.modules[__name__]
@@ -432,4 +586,20 @@ def install():
     errors = types.ModuleType('tensorflow.errors')
     errors.InvalidArgumentError = InvalidArgumentError
     mod.errors = errors
+    # tensorflow.python.client.session (framework/bn.py:10-11)
+    mod.__path__ = []
+    py = types.ModuleType('tensorflow.python')
+    py.__path__ = []
+    client = types.ModuleType('tensorflow.python.client')
+    client.__path__ = []
+    session = types.ModuleType('tensorflow.python.client.session')
+    session.register_session_run_conversion_functions = \
+        lambda *a, **kw: None
+    client.session, py.client, mod.python = session, client, py
+    sys.modules['tensorflow.python'] = py
+    sys.modules['tensorflow.python.client'] = client
+    sys.modules['tensorflow.python.client.session'] = session
+    nn = types.ModuleType('tensorflow.nn')
+    nn.softplus = lambda x, name=None: torch.nn.functional.softplus(_t(x))
+    mod.nn = nn
     return mod

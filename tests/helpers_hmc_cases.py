@@ -1,4 +1,4 @@
-"""The three HMC cases of tests/golden/hmc_reference_traces.npz (produced by
+"""The HMC cases of tests/golden/hmc_reference_traces.npz (produced by
 running the reference's own zhusuan/hmc.py, see oracle/make_golden_hmc.py),
 restated for the oracle (NumPy log-joint + analytic gradient)."""
 import numpy as np
@@ -76,3 +76,12 @@ def cases():
                                target_acceptance_rate=0.8,
                                mass_collect_iters=4),
                n_iters=26, flags=lambda i: (i < 22, i < 18), seed=14)
+    D = 10
+    stdev = (1.0 / (np.arange(D) + 1)).astype(F32)
+    yield dict(name='gaussian_py', latent_names=['x'],
+               model=gaussian_model(np.zeros(D, F32), np.log(stdev).astype(F32)),
+               params=dict(mean=np.zeros(D, F32), std=stdev),
+               hmc_kwargs=dict(step_size=1e-3, n_leapfrogs=5,
+                               adapt_step_size=True, adapt_mass=True,
+                               target_acceptance_rate=0.9),
+               n_iters=30, flags=lambda i: (i < 15, i < 15), seed=1)

@@ -27,13 +27,17 @@ def _build(zs, torch, dev, case, qs):
     name = case['name']
     if name.startswith('gauss'):
         mean = torch.tensor(case['params']['mean'], device=dev)
-        logstd = torch.tensor(case['params']['logstd'], device=dev)
         C = qs['x'].shape[0]
+        if 'std' in case['params']:      # gaussian.py:15-20, `std=` path
+            spread = dict(std=torch.tensor(case['params']['std'], device=dev))
+        else:
+            spread = dict(logstd=torch.tensor(case['params']['logstd'],
+                                              device=dev))
 
         @zs.meta_bayesian_net()
         def model():
             bn = zs.BayesianNet()
-            bn.normal('x', mean, logstd=logstd, n_samples=C, group_ndims=1)
+            bn.normal('x', mean, n_samples=C, group_ndims=1, **spread)
             return bn
         return model(), 'fused_diag_normal'
     px = torch.tensor(case['params']['prec_x'], device=dev)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Workload for tools/profile_native.sh: a few transitions of the two native
 dense-likelihood plans (BASELINE configs[2] and configs[4], reduced so that a
-traced run takes seconds), bracketed by marker launches (state_set_kernel) so
+traced run takes seconds), bracketed by marker launches (min_positive_rows_kernel) so
 that the kernel trace can be cut to the transitions alone.
   python tools/native_plan_trace.py [n_rows_config3] [n_chains_config5]"""
 import os
@@ -17,12 +17,14 @@ import bench  # noqa: E402
 n_rows = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 n_chains5 = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 dev = torch.device('cuda', 0)
-marker = torch.zeros(_capi.STATE_WORDS, device=dev)
+marker = torch.ones(1, 4, device=dev)
+marker_out = torch.zeros(1, device=dev)
 
 
 def mark():
-    _capi.call('zshmc_state_set', marker.data_ptr(), 7, 1.0,
-               torch.cuda.current_stream().cuda_stream)
+    # a kernel nothing else in this run launches
+    _capi.call('zshmc_min_positive_rows', marker.data_ptr(), 1, 4,
+               marker_out.data_ptr(), torch.cuda.current_stream().cuda_stream)
 
 
 orig = bench._time_native_plan

@@ -22,7 +22,7 @@ for f in glob.glob(os.path.join(out, tag + '_native_trace', '**', '*kernel_trace
     inside, section, sections = False, collections.OrderedDict(), []
     for r in rows:
         name = r['Kernel_Name']
-        if 'state_set_kernel' in name:
+        if 'min_positive_rows_kernel' in name:
             if inside:
                 sections.append(section)
                 section = collections.OrderedDict()

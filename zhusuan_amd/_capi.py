@@ -57,6 +57,7 @@ _p = c_void_p  # every device pointer / stream travels as void*
 PROTOTYPES = {
     'zshmc_last_error': (c_char_p, []),
     'zshmc_version': (c_int, []),
+    'zshmc_zero': (c_int, [_p, c_int64, _p]),
     'zshmc_fused_max_n_data': (c_int64, []),
     'zshmc_fused_kernel_name': (c_char_p, [c_int64, c_int, c_int]),
     'zshmc_linear_multinomial_log_lik': (c_int, [

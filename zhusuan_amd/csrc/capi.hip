@@ -36,3 +36,14 @@ int device_cu_count() {
 
 extern "C" const char* zshmc_last_error(void) { return zshmc::g_err; }
 extern "C" int zshmc_version(void) { return ZSHMC_VERSION; }
+
+// hipMemsetAsync(0) on the caller's stream: the per-chain accumulators of the
+// transition (kinetic energies) are cleared without an ATen fill kernel.
+extern "C" int zshmc_zero(void* ptr, int64_t n_bytes, void* stream) {
+  ZS_REQUIRE(ptr && n_bytes >= 0, "zshmc_zero: bad argument");
+  if (n_bytes == 0) return ZSHMC_OK;
+  return zshmc::check_hip(
+      hipMemsetAsync(ptr, 0, (size_t)n_bytes,
+                     reinterpret_cast<hipStream_t>(stream)),
+      "hipMemsetAsync");
+}

@@ -928,7 +928,7 @@ class _DenseLikelihoodPlan(_PlanBase):
         self.operand = torch.zeros(C, self.width, **f32) \
             if (self.softmax or self.width != D) else None
         self.ll = torch.empty(C, **f32)
-        self.lp_old = torch.empty(C, **f32)
+        self.lp_old = self.orig_log_prob      # HMCInfo.orig_log_prob itself
         self.lp_new = torch.empty(C, **f32)
         self.kin_old = torch.zeros(C, **f32)
         self.kin_new = torch.zeros(C, **f32)
@@ -941,14 +941,17 @@ class _DenseLikelihoodPlan(_PlanBase):
 
     # -- model tensors -------------------------------------------------------
     def refresh_model(self):
-        t = self._probe()
+        t = list(self._probe())
+        how, spread = t[1]           # ('std' | 'logstd', tensor as given)
+        t[1] = spread
         if self._src is not None and len(t) == len(self._src) and all(
                 a is b and a._version == v
                 for a, (b, v) in zip(t, self._src)):
             return
         self._src = [(a, a._version) for a in t]
         C, D = self.n_chains, self.n_data[0]
-        mean, logstd = t[0], t[1]
+        mean = t[0]
+        logstd = torch.log(spread) if how == 'std' else spread  # :96-103
         self.prior_mean, self.mean_rows = _to_row_period(
             mean, self.chain_shape, D)
         self.prior_logstd, self.logstd_rows = _to_row_period(
@@ -1007,7 +1010,8 @@ class _DenseLikelihoodPlan(_PlanBase):
             _capi.ptr(kinetic), stream)
 
     def _momentum(self, t, stream):
-        self.kin_old.zero_()
+        _capi.call('zshmc_zero', self.kin_old.data_ptr(),
+                   4 * self.n_chains, stream)
         _capi.call('zshmc_momentum', self.p.data_ptr(), self.mass_ptr(0),
                    self.n_chains, self.n_data[0], self.chain_offset,
                    self.hmc.seed, t & 0xFFFFFFFF, 0, self.kin_old.data_ptr(),
@@ -1059,7 +1063,8 @@ class _DenseLikelihoodPlan(_PlanBase):
         self._step(q1, p1, True, step_size, 0.5, 1.0, self.lp_old, None,
                    stream)
         self._likelihood(q1, stream)
-        self.kin_new.zero_()
+        _capi.call('zshmc_zero', self.kin_new.data_ptr(), 4 * self.n_chains,
+                   stream)
         self._step(q1, p1, True, step_size, 0.5, 0.0, self.lp_new,
                    self.kin_new, stream)
         _capi.call('zshmc_mh_accept', self.lp_old.data_ptr(),
@@ -1080,7 +1085,8 @@ class _DenseLikelihoodPlan(_PlanBase):
             q.copy_(self.q[0])
             self._momentum(t, stream)
             self._first_evaluation(q, stream)
-        self.kin_new.zero_()
+        _capi.call('zshmc_zero', self.kin_new.data_ptr(), 4 * self.n_chains,
+                   stream)
         # trip 0: zero-length drift, half kick (hmc.py:352-364); the drift of
         # trip i+1 rides behind the kick of trip i
         self._step(q, p, True, eps_host, 0.5, 1.0 if L >= 1 else 0.0,
@@ -1102,7 +1108,6 @@ class _DenseLikelihoodPlan(_PlanBase):
                    self.hamiltonian.data_ptr(), self.log_prob.data_ptr(),
                    self.accept.data_ptr(), self.acc_sum.data_ptr(),
                    self.flags.data_ptr(), stream)
-        self.orig_log_prob.copy_(self.lp_old)
         _capi.call('zshmc_select_rows', self.q[0].data_ptr(), q.data_ptr(),
                    self.accept.data_ptr(), self.n_chains, self.n_data[0],
                    stream)
@@ -1142,7 +1147,11 @@ def _softmax_of(theta, probe):
     if fn is None or type(fn).__name__ != 'SoftmaxBackward0':
         return False
     dim = getattr(fn, '_saved_dim', None)
-    if dim is None or dim % probe.dim() != probe.dim() - 1:
+    if dim is None:
+        return False
+    if dim >= 1 << 63:              # a negative axis, saved as uint64
+        dim -= 1 << 64
+    if dim % probe.dim() != probe.dim() - 1:
         return False
     nxt = fn.next_functions[0][0]
     return getattr(nxt, 'variable', None) is probe
@@ -1222,7 +1231,7 @@ def _try_dense_likelihood_plan(hmc, meta_bn, names, values, chain_shape,
                     lazy.X.requires_grad or obs.dim() != 1 or \
                     obs.shape[0] != lazy.X.shape[0] or obs.requires_grad:
                 return None
-            return 'linear_bernoulli', [pd.mean, pd.logstd, lazy.X, obs]
+            return 'linear_bernoulli', [pd.mean, pd.given_spread, lazy.X, obs]
         if type(ld) is UnnormalizedMultinomial:
             if ld.group_ndims != 0 or ld.normalize_logits or \
                     lazy.phi.requires_grad or obs.requires_grad:
@@ -1235,7 +1244,7 @@ def _try_dense_likelihood_plan(hmc, meta_bn, names, values, chain_shape,
                     len(gs) - 1 <= len(batch) and
                     gs[:-1] == batch[len(batch) - (len(gs) - 1):]):
                 return None
-            return 'mixture_multinomial', [pd.mean, pd.logstd, lazy.phi, obs]
+            return 'mixture_multinomial', [pd.mean, pd.given_spread, lazy.phi, obs]
         return None
 
     analyse.accepted = []
