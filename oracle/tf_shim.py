@@ -227,13 +227,28 @@ class Placeholder(object):
     def __init__(self, dtype, shape=None, name=None):
         self.dtype, self.name, self._v = dtype, name, None
 
+    # value used while a harness executes graph CONSTRUCTION eagerly (an
+    # unfed placeholder is legal there in TensorFlow); None = must be fed
+    unfed_default = None
+
     def feed(self, v):
         self._v = v
 
     @property
     def value(self):
-        assert self._v is not None, 'placeholder %s was not fed' % self.name
-        return torch.as_tensor(self._v, dtype=self.dtype)
+        v = self._v if self._v is not None else Placeholder.unfed_default
+        assert v is not None, 'placeholder %s was not fed' % self.name
+        return torch.as_tensor(v, dtype=self.dtype)
+
+    # arithmetic on the fed value (evaluation.py:101-103 multiplies by the
+    # temperature placeholder)
+    def __add__(self, o): return self.value + _t(o)
+    def __radd__(self, o): return _t(o) + self.value
+    def __sub__(self, o): return self.value - _t(o)
+    def __rsub__(self, o): return _t(o) - self.value
+    def __mul__(self, o): return self.value * _t(o)
+    def __rmul__(self, o): return _t(o) * self.value
+    def __hash__(self): return id(self)
 
 
 def placeholder(dtype, shape=None, name=None):

@@ -143,3 +143,51 @@ def test_ais_conjugate_gaussian(env):
     # schedule end points (evaluation.py:112-117)
     assert ais._get_schedule_t(0) == 0.0
     assert abs(ais._get_schedule_t(120) - 1.0) < 1e-12
+
+
+def test_ais_reproduces_the_reference_run(env):
+    """zhusuan_amd.AIS on the device against a run of the reference's OWN
+    zhusuan/evaluation.py:AIS (its hmc.py and model layer under it, over the
+    TensorFlow-API shim; oracle/make_golden_ais.py ->
+    tests/golden/ais_reference.npz): same proposal draws (stand-alone sampling
+    stream, offsets 0 and 1), same momenta and MH uniforms, 8 adaptation + 40
+    annealing transitions free-running, per-chain log importance weights."""
+    import os
+    import helpers_ais_case as case
+    zs, torch, dev = env
+    gold = np.load(os.path.join(os.path.dirname(__file__), 'golden',
+                                'ais_reference.npz'))
+    w_t = torch.tensor(case.W, device=dev)
+    x_t = torch.tensor(case.X_OBS, device=dev)
+    C, D = case.N_CHAINS, case.D
+
+    @zs.meta_bayesian_net()
+    def model():
+        bn = zs.BayesianNet()
+        z = bn.normal('z', torch.zeros(D, device=dev), std=1., n_samples=C,
+                      group_ndims=1)
+        bn.normal('x', z * w_t, std=float(case.X_STD), group_ndims=1)
+        return bn
+
+    @zs.meta_bayesian_net()
+    def proposal():
+        bn = zs.BayesianNet()
+        bn.normal('z', torch.zeros(D, device=dev), std=1., n_samples=C,
+                  group_ndims=1)
+        return bn
+
+    zs.set_random_seed(case.GLOBAL_SEED)
+    z = torch.zeros(C, D, device=dev)
+    hmc = zs.HMC(seed=case.HMC_SEED, **case.HMC_KW)
+    ais = zs.AIS(model(), proposal(), hmc, {'x': x_t}, {'z': z},
+                 n_temperatures=case.N_TEMPERATURES, n_adapt=case.N_ADAPT)
+    est = ais.run()
+    lw = ais.log_weights.cpu().numpy()
+    close = np.isclose(lw, gold['log_weights'], atol=5e-3)
+    assert close.mean() >= 0.9, (close.mean(),
+                                 np.abs(lw - gold['log_weights']).max())
+    np.testing.assert_allclose(est, float(gold['estimate']), atol=0.08)
+    np.testing.assert_allclose(float(hmc.hmc_info.updated_step_size.item()),
+                               float(gold['final_step_size']), rtol=3e-2)
+    same = np.isclose(z.cpu().numpy(), gold['z_final'], atol=2e-3).all(axis=1)
+    assert same.mean() >= 0.9

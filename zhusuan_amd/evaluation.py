@@ -98,6 +98,8 @@ class AIS(object):
             if k < n:
                 log_w -= info.log_prob
         self._hmc.check_numerics()
+        self.log_weights = log_w      # per chain, device (the reference keeps
+        #                               them local to run())
         return float(self.lower_bound(log_w).mean())
 
     @staticmethod
