@@ -52,8 +52,11 @@ class AIS(object):
         target, prior = _as_log_joint(meta_bn), _as_log_joint(proposal_meta_bn)
 
         def tempered(values):
-            t = float(self.temperature)
-            return prior(values) * (1 - t) + target(values) * t   # :98-100
+            # the reference's temperature is a float32 placeholder: 1 - T is
+            # formed in float32 (:101-103)
+            t = np.float32(self.temperature)
+            return prior(values) * float(np.float32(1) - t) + \
+                target(values) * float(t)
 
         self.log_fn = tempered
         self.sample_op, self.hmc_info = hmc.sample(tempered, observed, latent)
