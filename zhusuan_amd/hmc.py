@@ -921,6 +921,7 @@ class _DenseLikelihoodPlan(_PlanBase):
         C, D = self.n_chains, self.n_data[0]
         self.width = next(v for v in _ops.LINEAR_BERNOULLI_WIDTHS if v >= D)
         self.softmax = kind == 'mixture_multinomial'
+        self.q_flat = self.q[0].view(C, D)      # chain axes flattened
         self.p = torch.empty(C, D, **f32)
         self.q_new = torch.empty(C, D, **f32)
         self.grad = torch.empty(C, self.width, **f32)
@@ -1037,7 +1038,7 @@ class _DenseLikelihoodPlan(_PlanBase):
 
     def begin_search(self, t, stream):
         self._momentum(t, stream)
-        self.q_new.copy_(self.q[0])
+        self.q_new.copy_(self.q_flat)
         self._first_evaluation(self.q_new, stream)
         self._search_cache = (self.ll.clone(), self.grad.clone(),
                               None if self.operand is None
@@ -1049,7 +1050,7 @@ class _DenseLikelihoodPlan(_PlanBase):
         copy: config 5 holds 21 GB per [rows, K] buffer), the evaluation from
         the search cache."""
         ll0, g0, op0 = self._search_cache
-        self.q_new.copy_(self.q[0])
+        self.q_new.copy_(self.q_flat)
         self._momentum(t, stream)
         self.ll.copy_(ll0)
         self.grad.copy_(g0)
@@ -1082,7 +1083,7 @@ class _DenseLikelihoodPlan(_PlanBase):
             self._restore_start(t, stream)
             self._search_cache = None
         else:
-            q.copy_(self.q[0])
+            q.copy_(self.q_flat)
             self._momentum(t, stream)
             self._first_evaluation(q, stream)
         _capi.call('zshmc_zero', self.kin_new.data_ptr(), 4 * self.n_chains,
