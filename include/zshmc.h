@@ -445,8 +445,11 @@ int zshmc_mvn_tril_sample(float* out, const float* mean, const float* tril,
  *             .log_prob(counts)                     multivariate.py:435-443
  *   grad_theta[r,k] = sum_v counts[.,v] * phi_t[v,k] / (theta.phi)[r,v]
  * theta [n_rows, n_topics], phi_t = phi^T [n_vocab, n_topics] (n_topics 64,
- * 128 or 256: zero-pad), counts [count_rows, n_vocab] shared by the rows with
- * period count_rows.  The [n_rows, n_vocab] product never reaches memory.
+ * 128 or 256: zero-pad), counts [count_rows, n_vocab] with `count_stride`
+ * floats between rows, shared by the rows with period count_rows.  A
+ * count_stride that is a multiple of 4 (>= n_vocab rounded up to 4, the pad
+ * zero-filled) on a 16-byte aligned base lets every lane fetch its counts --
+ * a gather, one matrix row per chain -- 16 bytes at a time.  The [n_rows, n_vocab] product never reaches memory.
  * grad_theta may be NULL.  n_splits > 1 splits the vocabulary into that many
  * row ranges handled by separate workgroups (for n_rows / 64 < #CUs) whose
  * partial sums land in `workspace` (n_splits * n_rows * (n_topics + 1) floats,
@@ -454,6 +457,7 @@ int zshmc_mvn_tril_sample(float* out, const float* mean, const float* tril,
  */
 int zshmc_linear_multinomial_log_lik(const float* theta, const float* phi_t,
                                      const float* counts, int64_t count_rows,
+                                     int64_t count_stride,
                                      int64_t n_rows, int64_t n_vocab,
                                      int64_t n_topics, float* log_lik,
                                      float* grad_theta, int n_splits,

@@ -61,7 +61,8 @@ PROTOTYPES = {
     'zshmc_fused_max_n_data': (c_int64, []),
     'zshmc_fused_kernel_name': (c_char_p, [c_int64, c_int, c_int]),
     'zshmc_linear_multinomial_log_lik': (c_int, [
-        _p, _p, _p, c_int64, c_int64, c_int64, c_int64, _p, _p, c_int, _p, _p]),
+        _p, _p, _p, c_int64, c_int64, c_int64, c_int64, c_int64, _p, _p, c_int,
+        _p, _p]),
     'zshmc_ess_series': (c_int, [_p, c_int64, c_int64, _p, _p]),
     'zshmc_min_positive_rows': (c_int, [_p, c_int64, c_int64, _p, _p]),
     'zshmc_uni2_log_prob': (c_int, [

@@ -272,6 +272,7 @@ def clear_caches():
     done."""
     _x_cache.clear()
     _phi_cache.clear()
+    _counts_cache.clear()
     _csr_cache.clear()
 
 
@@ -532,6 +533,27 @@ def _padded_phi_t(phi, width):
     return pt
 
 
+_counts_cache = {}
+
+
+def _padded_counts(x):
+    """counts [R0, V] -> contiguous float32 [R0, V rounded up to 4] with a zero
+    pad, cached while the SAME tensor (storage, version) is passed again: the
+    likelihood kernel gathers one row per chain and wants 16-B groups."""
+    v = x.shape[-1]
+    vp = (v + 3) // 4 * 4
+    if vp == v and x.is_contiguous() and x.dtype == _F32:
+        return x.reshape(-1, v), v
+    key = (x.data_ptr(), tuple(x.shape), tuple(x.stride()), x._version)
+    hit = _counts_cache.get('x')
+    if hit is not None and hit[0] == key:
+        return hit[1], vp
+    xp = torch.zeros(x.numel() // v, vp, dtype=_F32, device=x.device)
+    xp[:, :v] = x.detach().reshape(-1, v)
+    _counts_cache['x'] = (key, xp, x)
+    return xp, vp
+
+
 class MixtureMultinomialLogLik(torch.autograd.Function):
     """ll[r] = sum_v x[r % R0, v] log((theta . phi)[r, v]) and d/dtheta in one
     pass over phi (the [rows, V] product is never materialised): the fused
@@ -546,7 +568,7 @@ class MixtureMultinomialLogLik(torch.autograd.Function):
         width = next(v for v in LINEAR_BERNOULLI_WIDTHS if v >= k)
         t2 = _pad_features(theta.detach().reshape(-1, k).to(_F32), width)
         pt = _padded_phi_t(phi, width)
-        xf = x.detach().to(_F32).contiguous().reshape(-1, x.shape[-1])
+        xf, x_stride = _padded_counts(x)
         rows, vocab = t2.shape[0], pt.shape[0]
         ll = torch.empty(rows, dtype=_F32, device=theta.device)
         need_grad = ctx.needs_input_grad[0]
@@ -556,8 +578,9 @@ class MixtureMultinomialLogLik(torch.autograd.Function):
         ws = torch.empty(splits * rows * (width + 1), dtype=_F32,
                          device=theta.device) if splits > 1 else None
         _capi.call('zshmc_linear_multinomial_log_lik', t2.data_ptr(),
-                   pt.data_ptr(), xf.data_ptr(), xf.shape[0], rows, vocab,
-                   width, ll.data_ptr(), _capi.ptr(gt), splits, _capi.ptr(ws),
+                   pt.data_ptr(), xf.data_ptr(), xf.shape[0], x_stride, rows,
+                   vocab, width, ll.data_ptr(), _capi.ptr(gt), splits,
+                   _capi.ptr(ws),
                    _capi.current_stream())
         ctx.t_shape = tuple(theta.shape)
         if need_grad:

@@ -285,8 +285,8 @@ template <int D, bool GRAD, int OP>
 __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2(
     const float* __restrict__ W, const float* __restrict__ X,
     const float* __restrict__ y, const float* __restrict__ yc,
-    int64_t yc_rows, int64_t C, int64_t N, int64_t ldw, int64_t ldx,
-    float* __restrict__ ll, float* __restrict__ gW) {
+    int64_t yc_rows, int64_t ldy, int64_t C, int64_t N, int64_t ldw,
+    int64_t ldx, float* __restrict__ ll, float* __restrict__ gW) {
   constexpr int LD = D + 4;          // padded LDS row: conflict-free b128 reads
   constexpr int kRows = 64;          // data rows per tile
   constexpr int KK = D / 8;          // phase-1 steps of 4 MFMAs (8 features)
@@ -308,6 +308,9 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2
   const int a = wave >> 1, b = wave & 1;
   const int lo = lane & 31, hi = lane >> 5;
   const int64_t c0 = (int64_t)blockIdx.x * kMC;
+  // OP 1: counts rows are 16-B aligned and zero-padded to 4-float groups
+  const bool yc_vec = OP == 1 && (ldy & 3) == 0 && ldy >= ((N + 3) & ~3ll) &&
+                      (reinterpret_cast<uintptr_t>(yc) & 15) == 0;
 
   // ---- this wave's W block -> registers (B operand: k-slot = lane half) ----
   float wreg[KK * 4];
@@ -432,13 +435,28 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2
       cr = cr < C ? cr : C - 1;
       // counts rows repeat with period yc_rows (x[n_docs, V] shared by chains)
       const float* __restrict__ xrow0 =
-          yc + (cr % yc_rows) * N + tile * kRows + b * 32 + 4 * hi;
+          yc + (cr % yc_rows) * ldy + tile * kRows + b * 32 + 4 * hi;
       const int64_t left = N - (tile * kRows + b * 32 + 4 * hi);  // may be <= 0
+      // Every lane reads its own row of the counts matrix (a gather: 32
+      // chains = 32 rows per instruction), so the instruction count is what
+      // costs.  Rows padded with zeros to a multiple of 4 floats and 16-B
+      // aligned (the caller's count_stride): 4 x 16 B per lane instead of
+      // 16 x 4 B.
+      if (yc_vec) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j) {
+          f4 v = f4{0.f, 0.f, 0.f, 0.f};
+          if (8 * j < left) v = *reinterpret_cast<const f4*>(xrow0 + 8 * j);
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
-          xcnt[j * 4 + m] = (8 * j + m < left) ? xrow0[8 * j + m] : 0.f;
+          for (int m = 0; m < 4; ++m) xcnt[j * 4 + m] = v[m];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+            xcnt[j * 4 + m] = (8 * j + m < left) ? xrow0[8 * j + m] : 0.f;
+      }
     }
 
     // ---- phase 1 (own 32 rows, full K) --------------------------------------
@@ -635,8 +653,8 @@ __global__ __launch_bounds__(256) void lb_reduce_splits_kernel(
 
 template <int D, int OP>
 static int launch_v2(const float* W, const float* X, const float* y,
-                     const float* yc, int64_t yc_rows, int64_t C, int64_t N,
-                     int64_t ldw, int64_t ldx, float* ll, float* gW,
+                     const float* yc, int64_t yc_rows, int64_t ldy, int64_t C,
+                     int64_t N, int64_t ldw, int64_t ldx, float* ll, float* gW,
                      hipStream_t s, int n_splits = 1,
                      float* workspace = nullptr) {
   constexpr int LD = D + 4;
@@ -661,11 +679,11 @@ static int launch_v2(const float* W, const float* X, const float* y,
   const dim3 grid(gx, S);
   if (gW)
     hipLaunchKernelGGL((linear_bernoulli_kernel_v2<D, true, OP>), grid,
-                       dim3(256), lds, s, W, X, y, yc, yc_rows, C, N, ldw, ldx,
+                       dim3(256), lds, s, W, X, y, yc, yc_rows, ldy, C, N, ldw, ldx,
                        ll_out, g_out);
   else
     hipLaunchKernelGGL((linear_bernoulli_kernel_v2<D, false, OP>), grid,
-                       dim3(256), lds, s, W, X, y, yc, yc_rows, C, N, ldw, ldx,
+                       dim3(256), lds, s, W, X, y, yc, yc_rows, ldy, C, N, ldw, ldx,
                        ll_out, g_out);
   ZS_LAUNCH_CHECK("linear_bernoulli_kernel_v2 launch");
   if (S > 1) {
@@ -688,7 +706,7 @@ static int launch_lb(const float* W, const float* X, const float* y, int64_t C,
     return e && e[0] == '1';
   }();
   if (!use_v1)
-    return launch_v2<D, 0>(W, X, y, nullptr, 1, C, N, ldw, ldx, ll, gW, s,
+    return launch_v2<D, 0>(W, X, y, nullptr, 1, N, C, N, ldw, ldx, ll, gW, s,
                            n_splits, workspace);
   constexpr int LD = D + 4;
   const size_t lds = (size_t)(kMC * LD + 2 * kNT * LD + 2 * kNT + 4 * 16 * 64) *
@@ -750,6 +768,7 @@ extern "C" int zshmc_linear_multinomial_log_lik(const float* theta,
                                                 const float* phi_t,
                                                 const float* counts,
                                                 int64_t count_rows,
+                                                int64_t count_stride,
                                                 int64_t n_rows, int64_t n_vocab,
                                                 int64_t n_topics, float* log_lik,
                                                 float* grad_theta, int n_splits,
@@ -758,7 +777,7 @@ extern "C" int zshmc_linear_multinomial_log_lik(const float* theta,
   ZS_REQUIRE(theta && phi_t && counts && log_lik,
              "zshmc_linear_multinomial_log_lik: null pointer");
   ZS_REQUIRE(n_rows > 0 && n_vocab > 0 && count_rows > 0 &&
-                 n_rows % count_rows == 0,
+                 n_rows % count_rows == 0 && count_stride >= n_vocab,
              "zshmc_linear_multinomial_log_lik: bad shape");
   ZS_REQUIRE(n_topics == 64 || n_topics == 128 || n_topics == 256,
              "zshmc_linear_multinomial_log_lik: n_topics must be 64, 128 or 256 "
@@ -772,16 +791,19 @@ extern "C" int zshmc_linear_multinomial_log_lik(const float* theta,
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   switch (n_topics) {
     case 64:
-      return launch_v2<64, 1>(theta, phi_t, nullptr, counts, count_rows, n_rows,
+      return launch_v2<64, 1>(theta, phi_t, nullptr, counts, count_rows,
+                              count_stride, n_rows,
                               n_vocab, 64,
                               64, log_lik, grad_theta, s, n_splits, workspace);
     case 128:
-      return launch_v2<128, 1>(theta, phi_t, nullptr, counts, count_rows, n_rows,
+      return launch_v2<128, 1>(theta, phi_t, nullptr, counts, count_rows,
+                              count_stride, n_rows,
                               n_vocab,
                                128, 128, log_lik, grad_theta, s, n_splits,
                                workspace);
     default:
-      return launch_v2<256, 1>(theta, phi_t, nullptr, counts, count_rows, n_rows,
+      return launch_v2<256, 1>(theta, phi_t, nullptr, counts, count_rows,
+                              count_stride, n_rows,
                               n_vocab,
                                256, 256, log_lik, grad_theta, s, n_splits,
                                workspace);

@@ -966,8 +966,7 @@ class _DenseLikelihoodPlan(_PlanBase):
         else:
             phi, x = t[2], t[3]
             self.inner = ops._padded_phi_t(phi, self.width)
-            self.obs = x.detach().to(torch.float32).contiguous().reshape(
-                -1, x.shape[-1])
+            self.obs, self.obs_stride = ops._padded_counts(x)
             n_inner = self.inner.shape[0]
             if C % self.obs.shape[0] != 0:
                 raise ValueError("counts rows do not divide the chain rows")
@@ -991,9 +990,10 @@ class _DenseLikelihoodPlan(_PlanBase):
         else:
             _capi.call('zshmc_linear_multinomial_log_lik', w.data_ptr(),
                        self.inner.data_ptr(), self.obs.data_ptr(),
-                       self.obs.shape[0], self.n_chains, self.inner.shape[0],
-                       self.width, self.ll.data_ptr(), self.grad.data_ptr(),
-                       self.splits, _capi.ptr(ws), stream)
+                       self.obs.shape[0], self.obs_stride, self.n_chains,
+                       self.inner.shape[0], self.width, self.ll.data_ptr(),
+                       self.grad.data_ptr(), self.splits, _capi.ptr(ws),
+                       stream)
 
     def _step(self, q, p, use_grad, eps_host, kick, drift, lp_out, kinetic,
               stream):
