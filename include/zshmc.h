@@ -111,9 +111,10 @@ const char* zshmc_fused_kernel_name(int64_t n_data, int has_mass,
  * GPUs, ONE collective:
  *   - the launch publishes  stats[0] = sum_c acceptance_rate_c  of its own
  *     chains and stats[1] = 1 if some chain started from a non-finite
- *     log-prob (else 0).  The sum is order-fixed: per-workgroup partials in
- *     `workspace`, added in index order by the workgroup that retires last
- *     (bit-identical from run to run; no floating-point atomics);
+ *     log-prob (else 0).  The sum is order-independent: every workgroup adds
+ *     its partial as a fixed-point integer, together with its retirement
+ *     count, in ONE 64-bit atomic on `workspace` (integer addition is
+ *     associative: bit-identical from run to run; no floating-point atomics);
  *   - the caller may all-reduce stats[0..1] (+ the 2*D mass statistics it
  *     keeps behind them) in ONE message (zshmc_comm_all_reduce_sum);
  *   - all chains on one GPU: `retire_update` = ZSHMC_PEND_ADAPT / _HOLD (this
@@ -136,7 +137,7 @@ const char* zshmc_fused_kernel_name(int64_t n_data, int has_mass,
 #define ZSHMC_PEND_ADAPT 1 /* hmc.py:92-106 */
 #define ZSHMC_PEND_HOLD 2  /* hmc.py:108-110: step_size <- exp(log_epsilon_bar) */
 #define ZSHMC_STATS_WORDS 2 /* doubles: sum of acceptance, non-finite flag */
-#define ZSHMC_LINK_WORKSPACE_BYTES (64 + 8 * 4096)
+#define ZSHMC_LINK_WORKSPACE_BYTES 64
 typedef struct zshmc_adapt_link {
   float* state;            /* device, ZSHMC_STATE_WORDS floats, or NULL */
   double* stats;           /* device, ZSHMC_STATS_WORDS doubles, or NULL */

@@ -29,7 +29,7 @@ PEND_NONE = 0
 PEND_ADAPT = 1
 PEND_HOLD = 2
 STATS_WORDS = 2
-LINK_WORKSPACE_BYTES = 64 + 8 * 4096
+LINK_WORKSPACE_BYTES = 64
 COMM_ID_BYTES = 128
 ERR_COMM = 4
 

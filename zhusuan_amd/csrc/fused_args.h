@@ -60,8 +60,9 @@ struct AdaptLink {
   float* state;      // ZSHMC_ST_* block; NULL: no on-device step size / tuner
   double* stats;     // [0] sum acc (in: previous, all-reduced, if `pending`;
                      // out: this launch's, order-fixed), [1] non-finite flag
-  double* partials;  // workspace: per-workgroup acceptance sums
-  uint32_t* done;    // workspace: retired-workgroup counter (0 between launches)
+  unsigned long long* accum;  // workspace: {retired count | fixed-point sum},
+                              // 0 between launches
+  double fx_scale, fx_inv_scale;  // 2^shift, 2^-shift of the fixed point
   double inv_chains; // 1 / n_chains_global
   int pending;       // ZSHMC_PEND_*: update of the PREVIOUS transition, applied
                      // in this launch's prologue from stats[0] (sharded chains:
@@ -103,44 +104,33 @@ __device__ __forceinline__ float link_step_size(const AdaptLink& k,
   return s.step_size;
 }
 
-// End of a transition kernel.  link_publish (thread 0 of every workgroup):
-// hand this workgroup's acceptance sum over; true for the workgroup that
-// retires last.  link_finish (ONE FULL WAVE of that workgroup): add the
-// partials in a fixed order -- lane l takes partials l, l+64, ..., then the
-// xor butterfly: run-to-run identical, unlike floating-point atomics --
-// persist the dual-averaging update that rides on this launch and publish the
-// total.  All hand-over goes through agent-scope atomics (performed at the
-// device-coherent level), so no cache write-back / invalidate is needed (a
-// release fence here flushed the L2 under the workgroups still running).  The
-// exchange RETURNS, so the partial has landed before the counter moves.  The
-// partial loads bypass the L2 (~100 ns each): spread over the lanes they cost
-// ~0.5 us, read one after another by one thread they cost 25 us.
-__device__ __forceinline__ bool link_publish(const AdaptLink& k,
-                                             double wg_sum) {
-  if (!k.partials) return false;
-  const double prev = __hip_atomic_exchange(
-      &k.partials[blockIdx.x], wg_sum, __ATOMIC_RELAXED,
-      __HIP_MEMORY_SCOPE_AGENT);
-  // the counter's operand is made to depend on the returned value (an opaque
-  // asm that consumes it), so hipcc must wait for the exchange to come back
-  unsigned one = 1u;
-  asm volatile("" : "+v"(one) : "v"(prev));
-  const unsigned ticket = __hip_atomic_fetch_add(
-      k.done, one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return ticket == gridDim.x - 1;
-}
+// End of a transition kernel, thread 0 of every workgroup: ONE 64-bit atomic
+// add carries both this workgroup's acceptance sum (fixed point in the low
+// kSumBits bits) and its retirement (count in the bits above).  Integer
+// addition is associative, so the total is identical from run to run whatever
+// the order (unlike floating-point atomics), and the workgroup whose add
+// returns count == gridDim.x - 1 holds the complete total in the returned
+// value: no second atomic, no partial array to read back, no fence (a
+// release fence here flushed the L2 under the workgroups still running).
+// That workgroup persists the dual-averaging update riding on this launch,
+// publishes the total and clears the accumulator.
+// Fixed point: 2^-shift resolution per workgroup, shift chosen by the
+// launcher so that n_chains * 2^shift < 2^kSumBits (65 536 chains: 2^-34);
+// the quantisation is far below the float32 mean the tuner consumes.
+constexpr int kSumBits = 50;  // count: 64 - 50 = 14 bits >= log2(kFusedMaxGrid)+1
 
-__device__ __forceinline__ void link_finish(const AdaptLink& k,
-                                            const uint32_t* flags, int lane) {
-  const unsigned nblk = gridDim.x;
-  double part = 0.0;
-  for (unsigned i = lane; i < nblk; i += 64)
-    part += __hip_atomic_load(&k.partials[i], __ATOMIC_RELAXED,
-                              __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
-  if (lane != 0) return;
-  const double total = part;
+__device__ __forceinline__ void link_retire(const AdaptLink& k, double wg_sum,
+                                            const uint32_t* flags) {
+  if (!k.accum) return;
+  const unsigned long long sum_fx =
+      (unsigned long long)(wg_sum * k.fx_scale + 0.5);
+  const unsigned long long mine = (1ull << kSumBits) + sum_fx;
+  const unsigned long long before = __hip_atomic_fetch_add(
+      k.accum, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if ((before >> kSumBits) != gridDim.x - 1) return;
+  const unsigned long long all = before + mine;
+  const double total =
+      (double)(all & ((1ull << kSumBits) - 1)) * k.fx_inv_scale;
   if (k.state && k.pending != ZSHMC_PEND_NONE)
     tuner_persist(k, k.pending, k.stats[0]);
   if (k.state && k.retire != ZSHMC_PEND_NONE) tuner_persist(k, k.retire, total);
@@ -149,7 +139,7 @@ __device__ __forceinline__ void link_finish(const AdaptLink& k,
   if (flags)
     f = __hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   k.stats[1] = (f & ZSHMC_FLAG_OLD_LOGPROB_NONFINITE) ? 1.0 : 0.0;
-  __hip_atomic_store(k.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(k.accum, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 struct FusedArgs {

@@ -328,12 +328,7 @@ __global__ __launch_bounds__(256, ZS_WAVES_PER_EU) void hmc_diag_normal_kernel(
     double tot = 0.0;
     for (int i = 0; i < (int)(blockDim.x / kWave); ++i) tot += s_acc[i];
     if (*s_bad && a.flags) atomicOr(a.flags, ZSHMC_FLAG_OLD_LOGPROB_NONFINITE);
-    *s_bad = link_publish(a.link, tot) ? -1 : 0;   // (the flag is spent)
-  }
-  if (a.link.partials) {  // kernel argument: uniform over the grid
-    __syncthreads();
-    if (threadIdx.x < kWave && *s_bad == -1)
-      link_finish(a.link, a.flags, lane);
+    link_retire(a.link, tot, a.flags);
   }
 }
 
@@ -469,11 +464,8 @@ static int make_link(const zshmc_adapt_link* link, AdaptLink* out,
                "%s: link->n_chains_global <= 0", who);
     k.state = link->state;
     k.stats = link->stats;
-    if (link->stats) {
-      char* ws = reinterpret_cast<char*>(link->workspace);
-      k.done = reinterpret_cast<uint32_t*>(ws);
-      k.partials = reinterpret_cast<double*>(ws + 64);
-    }
+    if (link->stats)
+      k.accum = reinterpret_cast<unsigned long long*>(link->workspace);
     k.inv_chains =
         link->n_chains_global > 0 ? 1.0 / (double)link->n_chains_global : 0.0;
     k.pending = link->pending;
@@ -570,6 +562,15 @@ extern "C" int zshmc_hmc_diag_normal_step(
   a.flags = flags;
   a.info_cap = 0;
   a.commit_direct = 0;
+  {
+    // fixed-point scale of the acceptance sum: n_chains * 2^shift < 2^kSumBits
+    int shift = 40;
+    while (shift > 0 && (double)(n_chains + 1) * (double)(1ull << shift) >=
+                            (double)(1ull << kSumBits))
+      --shift;
+    a.link.fx_scale = (double)(1ull << shift);
+    a.link.fx_inv_scale = 1.0 / a.link.fx_scale;
+  }
 #ifdef ZS_TIMING
   a.timing = reinterpret_cast<unsigned long long*>(orig_hamiltonian);  // debug
   a.orig_hamiltonian = nullptr;

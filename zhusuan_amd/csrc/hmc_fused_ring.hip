@@ -66,6 +66,9 @@ namespace zshmc {
 #ifndef ZS_RING_K4
 #define ZS_RING_K4 2  // ring depth at NCH = 4 (n_data 772..1024)
 #endif
+#ifndef ZS_RNG_PAIR
+#define ZS_RNG_PAIR 1  // generator runs two chunks interleaved (A/B knob)
+#endif
 #ifndef ZS_RING_WAVES
 #define ZS_RING_WAVES 4  // waves per SIMD at NCH = 4 without mass
 #endif
@@ -204,9 +207,18 @@ __device__ __forceinline__ float keep_if(float v, uint64_t mask) {
   return r;
 }
 
+// A/B probes only: VMEM issued with EXEC = 0 (ZS_NO_MEM: compute-only time;
+// ZS_NO_LD / ZS_NO_ST: one direction of the row traffic)
+template <bool LOAD>
 __device__ __forceinline__ Mask mask_if(bool c) {
-#ifdef ZS_NO_MEM  // A/B probe only: VMEM issued with EXEC = 0 (compute-only time)
+#if defined(ZS_NO_MEM)
   c = false;
+#endif
+#if defined(ZS_NO_LD)
+  if (LOAD) c = false;
+#endif
+#if defined(ZS_NO_ST)
+  if (!LOAD) c = false;
 #endif
   const uint32_t f = uni32(c ? 0xFFFFFFFFu : 0u);
   return Mask{f, f};
@@ -396,7 +408,7 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
     int64_t row = ZS_CHAIN_OF(tk[j]);
     row = row < last_row ? row : last_row;
     issue_row<NCH>(voff, voff_last, a.q + uni64(row * D),
-                   ring_addr + j * kRowB, mask_if(tk[j] < count));
+                   ring_addr + j * kRowB, mask_if<true>(tk[j] < count));
   }
 
   double acc_local = 0.0;
@@ -437,7 +449,7 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
       nrow = nrow < last_row ? nrow : last_row;
       issue_row<NCH>(voff, voff_last, a.q + uni64(nrow * D),
                      uni32(ring_addr + (uint32_t)slot * kRowB),
-                     mask_if(nt < count));
+                     mask_if<true>(nt < count));
       slot = slot + 1 == K ? 0 : slot + 1;
 #pragma unroll
       for (int j = 0; j + 1 < K; ++j) tk[j] = tk[j + 1];
@@ -454,21 +466,8 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
     __builtin_amdgcn_s_setprio(ZS_PRIO_RNG);
 #endif
     f4 ko = f4{0.f, 0.f, 0.f, 0.f}, uo = ko;
-#pragma unroll
-    for (int k = 0; k < NCH; ++k) {
-      uint32_t group = (uint32_t)(k * kWave + lane);
-      // hipcc hoists the first Philox round's M0 * group out of the trip loop
-      // (2 VGPRs per chunk held for the whole kernel); where the budget has
-      // no room for that the counter word is made opaque per trip
-      if (NCH >= 7) asm volatile("" : "+v"(group));
-      float z0, z1, z2, z3;
-#ifdef ZS_NO_RNG  // A/B probe only: how much of the trip is the generator
-      z0 = __uint_as_float(0x3f000000u | ((group * 2654435761u + gchain) & 0x7fffffu));
-      z1 = z0 - 0.75f; z2 = 0.6f - z0; z3 = z0 * z1;
-#else
-      normal4(group, gchain, a.iteration, kStreamMomentum, key0, key1, z0, z1,
-              z2, z3);
-#endif
+    // one chunk's share of: p0 = z * sqrt(mass), K0, U0, first half kick
+    auto start_chunk = [&](int k, float z0, float z1, float z2, float z3) {
       p[k] = f4{z0, z1, z2, z3};
       if (HAS_MASS) {
         p[k] = p[k] *
@@ -481,11 +480,44 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
       const f4 t = nep[k] * r[k];
       uo += t * r[k];
       p[k] += hk * t;
+    };
+#ifdef ZS_NO_RNG  // A/B probe only: how much of the trip is the generator
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const uint32_t group = (uint32_t)(k * kWave + lane);
+      const float z0 = __uint_as_float(
+          0x3f000000u | ((group * 2654435761u + gchain) & 0x7fffffu));
+      start_chunk(k, z0, z0 - 0.75f, 0.6f - z0, z0 * (z0 - 0.75f));
+    }
+#else
+    // the generator runs two chunks at a time where the register budget has
+    // room (philox.h: normal4x2), one otherwise
+    constexpr int kPair = (ZS_RNG_PAIR && NCH <= 4) ? 2 : 1;
+#pragma unroll
+    for (int k = 0; k < NCH; k += kPair) {
+      uint32_t group = (uint32_t)(k * kWave + lane);
+      // hipcc hoists the first Philox round's M0 * group out of the trip loop
+      // (2 VGPRs per chunk held for the whole kernel); where the budget has
+      // no room for that the counter word is made opaque per trip
+      if (NCH >= 7) asm volatile("" : "+v"(group));
+      if (kPair == 2 && k + 1 < NCH) {
+        float za[4], zb[4];
+        normal4x2(group, group + kWave, gchain, a.iteration, kStreamMomentum,
+                  key0, key1, za, zb);
+        start_chunk(k, za[0], za[1], za[2], za[3]);
+        start_chunk(k + 1, zb[0], zb[1], zb[2], zb[3]);
+      } else {
+        float z0, z1, z2, z3;
+        normal4(group, gchain, a.iteration, kStreamMomentum, key0, key1, z0,
+                z1, z2, z3);
+        start_chunk(k, z0, z1, z2, z3);
+      }
 #ifdef ZS_RING_SERIAL_RNG
       // one generator state live at a time (register budget for 4 waves/SIMD)
       __builtin_amdgcn_sched_barrier(0);
 #endif
     }
+#endif
 
     // ---- leapfrog (hmc.py:348-372): L full drifts + full kicks; half of the
     // last kick is taken back below ----------------------------------------
@@ -581,7 +613,7 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
     // ---- MH select: the accepted row goes back in place (hmc.py:487-497);
     // EXEC-predicated, so a rejected chain issues the same NCH (empty) stores
     {
-      const Mask m_acc = mask_if(accept && a.commit != 0);
+      const Mask m_acc = mask_if<false>(accept && a.commit != 0);
       // q' = r + mean in place (r is dead after the store): all the LDS reads
       // of the mean tile go out together, ahead of the asm statements
       if (!ZERO_MEAN) {
@@ -647,11 +679,7 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
     double tot = 0.0;
     for (int i = 0; i < kWavesPerBlock; ++i) tot += s_acc[i];
     if (*s_bad && a.flags) atomicOr(a.flags, ZSHMC_FLAG_OLD_LOGPROB_NONFINITE);
-    *s_ticket = link_publish(a.link, tot) ? -1 : 0;   // (tickets are spent)
-  }
-  if (a.link.partials) {  // kernel argument: uniform over the grid
-    __syncthreads();
-    if (wib == 0 && *s_ticket == -1) link_finish(a.link, a.flags, lane);
+    link_retire(a.link, tot, a.flags);
   }
   // ---- staged HMCInfo scalars -> global, G consecutive chains per line ----
   if (STAGE && a.commit) {
