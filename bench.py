@@ -10,8 +10,13 @@ HBM before the timed region.  Prints ONE JSON line (see the task contract):
   value     = chain-leapfrog-steps/s = n_chains_total * L * steps / t
   roofline  = algorithmic bytes (8 B per chain-latent per transition:
               read q + write q) / fused-kernel duration, vs 8 TB/s HBM
-  cpu_baseline = the NumPy oracle (port of zhusuan/hmc.py) on a bounded
-              sample of the same workload on the host cores (rank 0, N = 1)
+  cpu_baseline = the C + OpenMP port of the transition on ALL host threads
+              (bounded sample, rank 0, N = 1); beside it the op-for-op ports
+              (torch-CPU all threads, NumPy one core) and the recorded timing
+              of the reference's own hmc.py over the TensorFlow-API shim
+  extra_configs = BASELINE configs[2] (logistic regression, 10^6 x 256, 32 768
+              chains) and configs[4] (topic model, 5 000 docs x 128 topics),
+              MFMA-bound, through the native plans
 
     python bench.py --gpus 1 --steps 200 --warmup 20
     python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8
@@ -53,7 +58,7 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(n_data, n_leapfrogs, budget_s):
+def cpu_baseline_numpy(n_data, n_leapfrogs, budget_s):
     """Time the NumPy restatement of zhusuan/hmc.py (oracle/hmc_ref.py) on
     C = 4096 chains of the same target; throughput is size-independent once
     DRAM-bound."""
@@ -85,6 +90,59 @@ def cpu_baseline(n_data, n_leapfrogs, budget_s):
                   'in this image)' % (C, n_data, n_leapfrogs, iters, el),
         'elem_leapfrog_steps_per_sec': C * n_data * n_leapfrogs * iters / el,
     }
+
+
+def cpu_baseline_torch(n_data, n_leapfrogs, budget_s):
+    """The same transition op for op on torch-CPU with every host thread
+    (oracle/hmc_torch_port.py): each TensorFlow op of the reference's graph is
+    one multi-threaded full-array pass -- the nearest runnable stand-in for
+    "TF-CPU with intra-op parallelism" on a box without TensorFlow."""
+    import torch
+    from oracle import hmc_torch_port
+    threads = os.cpu_count() or 1
+    old = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        C = 16384
+        logstd = torch.linspace(-1.0, 1.0, n_data)
+        mean = torch.zeros(n_data)
+        q = torch.randn(C, n_data) * torch.exp(logstd)
+        hmc_torch_port.transition(q, mean, logstd, 0.14, n_leapfrogs,
+                                  torch.randn(C, n_data), torch.rand(C))
+        iters = 0
+        t0 = time.perf_counter()
+        while True:
+            hmc_torch_port.transition(q, mean, logstd, 0.14, n_leapfrogs,
+                                      torch.randn(C, n_data), torch.rand(C))
+            iters += 1
+            el = time.perf_counter() - t0
+            if el >= budget_s or iters >= 2000:
+                break
+    finally:
+        torch.set_num_threads(old)
+    return {
+        'value': C * n_leapfrogs * iters / el,
+        'unit': 'chain-leapfrog-steps/s',
+        'cores': threads,
+        'kind': 'port',
+        'sample': '%d chains x %d latents, L=%d, %d transitions in %.1f s '
+                  '(torch-CPU, one multi-threaded pass per TensorFlow op of '
+                  'the reference graph, %d threads)' % (
+                      C, n_data, n_leapfrogs, iters, el, threads),
+    }
+
+
+def cpu_reference_recorded():
+    """The reference's OWN hmc.py timed over the TensorFlow-API shim
+    (tools/time_reference_over_shim.py).  It needs /root/reference, which does
+    not exist on the GPU box, so the number is a RECORDED one and says where
+    it was measured."""
+    path = os.path.join(ROOT, 'profiles', 'r02_cpu_reference_over_shim.json')
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except Exception:
+        return None
 
 
 def cpu_baseline_parallel(n_data, n_leapfrogs, budget_s):
@@ -538,12 +596,27 @@ def main():
         if ess is not None:
             out['ess'] = ess
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(D, L, args.cpu_seconds)
+            # Measured live on this box's host cores, strongest first: the
+            # chain-fused C + OpenMP port on all threads is THE cpu_baseline
+            # (a GPU/CPU ratio against a 1-core NumPy loop says nothing);
+            # the op-for-op ports (torch-CPU all threads, NumPy one core)
+            # model the TF-CPU executor's pass structure; the reference's own
+            # hmc.py over the TensorFlow-API shim cannot run here (its sources
+            # do not travel) and is carried as a recorded number.
+            budget = min(args.cpu_seconds, 8.0)
             try:
-                out['cpu_baseline_parallel'] = cpu_baseline_parallel(
-                    D, L, min(args.cpu_seconds, 8.0))
+                out['cpu_baseline'] = cpu_baseline_parallel(D, L, budget)
             except Exception as e:           # no gcc / OpenMP on the box
-                out['cpu_baseline_parallel'] = {'error': str(e)[:200]}
+                out['cpu_baseline'] = {'error': str(e)[:200]}
+            try:
+                out['cpu_baseline_torch_all_threads'] = cpu_baseline_torch(
+                    D, L, budget)
+            except Exception as e:
+                out['cpu_baseline_torch_all_threads'] = {'error': str(e)[:200]}
+            out['cpu_baseline_numpy_1core'] = cpu_baseline_numpy(D, L, budget)
+            if 'error' in out['cpu_baseline']:
+                out['cpu_baseline'] = out['cpu_baseline_numpy_1core']
+            out['cpu_reference_over_shim'] = cpu_reference_recorded()
         if world == 1 and not args.no_extra_configs:
             # the MFMA-bound configurations of BASELINE.json, after the
             # headline: each frees its buffers before the next starts
