@@ -23,9 +23,14 @@ def test_product_never_touches_oracle():
 def test_bench_uses_oracle_only_in_cpu_baseline():
     src = open(os.path.join(ROOT, 'bench.py')).read()
     uses = [m.start() for m in re.finditer(r'from oracle', src)]
-    # the NumPy port (cpu_baseline) and the C + OpenMP port
-    # (cpu_baseline_parallel): both inside the CPU-baseline functions only
-    assert len(uses) == 2
+    # the NumPy, torch-CPU and C + OpenMP ports: all inside the CPU-baseline
+    # functions only, which sit in front of everything that runs the product
+    assert len(uses) == 3
     start = src.index('def cpu_baseline')
-    end = src.index('def main')
+    end = src.index('def _time_native_plan')
     assert all(start < u < end for u in uses)
+    for fn in ('cpu_baseline_numpy', 'cpu_baseline_torch',
+               'cpu_baseline_parallel'):
+        body = src[src.index('def ' + fn):]
+        body = body[:body.index('\ndef ', 1)]
+        assert 'from oracle' in body, fn
