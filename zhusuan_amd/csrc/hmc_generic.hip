@@ -36,7 +36,39 @@ __global__ __launch_bounds__(256) void momentum_kernel(
     const uint32_t gchain = (uint32_t)(c + chain_offset);
     float* __restrict__ row = p + c * n_data;
     float kin = 0.f;
-    for (int64_t g = lane; g < n_groups; g += 64) {
+    if (VEC) {
+      // two 4-latent groups per trip, their Philox calls advanced together
+      // (philox.h: normal4x2): twice the independent work between dependent
+      // instructions of the generator
+      for (int64_t base = 0; base + 128 <= n_groups; base += 128) {
+        const int64_t g = base + lane;
+        float za[4], zb[4];
+        normal4x2((uint32_t)g, (uint32_t)(g + 64), gchain, iteration,
+                  stream_word, k0, k1, za, zb);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const float* z = h ? zb : za;
+          const int64_t gg = g + 64 * h;
+          g4 v = g4{z[0], z[1], z[2], z[3]};
+          if (mass) {
+            const g4 m = *reinterpret_cast<const g4*>(mass + gg * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              v[j] *= sqrtf(m[j]);
+              kin += v[j] * v[j] / m[j];
+            }
+          } else {
+            const g4 sq = v * v;
+            kin += (sq[0] + sq[1]) + (sq[2] + sq[3]);
+          }
+          *reinterpret_cast<g4*>(row + gg * 4) = v;
+        }
+      }
+    }
+    // (the paired loop covers whole 128-group spans; what is left -- and the
+    // ragged path -- one group per trip)
+    const int64_t g_start = VEC ? (n_groups / 128) * 128 + lane : lane;
+    for (int64_t g = g_start; g < n_groups; g += 64) {
       float z[4];
       normal4((uint32_t)g, gchain, iteration, stream_word, k0, k1, z[0], z[1],
               z[2], z[3]);
@@ -162,6 +194,11 @@ __global__ __launch_bounds__(256) void mh_accept_kernel(
   }
 }
 
+// Accepted rows only are copied (a rejected row costs one byte of `accept`):
+// the row copy is EXEC-uniform per wave.  VEC: 16 B per lane, up to four
+// 1-KiB chunks of the row loaded before the first store so that a wave has
+// 4 KiB in flight (the scalar form had 256 B).
+template <bool VEC>
 __global__ __launch_bounds__(256) void select_rows_kernel(
     float* __restrict__ q, const float* __restrict__ q_new,
     const uint8_t* __restrict__ accept, int64_t n_chains, int64_t n_data) {
@@ -171,7 +208,21 @@ __global__ __launch_bounds__(256) void select_rows_kernel(
   for (int64_t c = wave; c < n_chains; c += n_waves) {
     if (!accept[c]) continue;  // wave-uniform
     const int64_t off = c * n_data;
-    for (int64_t d = lane; d < n_data; d += 64) q[off + d] = q_new[off + d];
+    if (VEC) {
+      for (int64_t d0 = (int64_t)lane * 4; d0 < n_data; d0 += 4 * 256) {
+        g4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (d0 + k * 256 < n_data)
+            v[k] = *reinterpret_cast<const g4*>(q_new + off + d0 + k * 256);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (d0 + k * 256 < n_data)
+            *reinterpret_cast<g4*>(q + off + d0 + k * 256) = v[k];
+      }
+    } else {
+      for (int64_t d = lane; d < n_data; d += 64) q[off + d] = q_new[off + d];
+    }
   }
 }
 
@@ -277,9 +328,14 @@ extern "C" int zshmc_select_rows(float* q, const float* q_new,
   ZS_REQUIRE(q && q_new && accept, "zshmc_select_rows: null pointer");
   ZS_REQUIRE(n_chains >= 0 && n_data >= 1, "zshmc_select_rows: bad shape");
   if (n_chains == 0) return ZSHMC_OK;
-  hipLaunchKernelGGL(select_rows_kernel, dim3(row_grid(n_chains)), dim3(256),
-                     0, reinterpret_cast<hipStream_t>(stream), q, q_new,
-                     accept, n_chains, n_data);
+  if (n_data % 4 == 0 && aligned16(q) && aligned16(q_new))
+    hipLaunchKernelGGL(select_rows_kernel<true>, dim3(row_grid(n_chains)),
+                       dim3(256), 0, reinterpret_cast<hipStream_t>(stream), q,
+                       q_new, accept, n_chains, n_data);
+  else
+    hipLaunchKernelGGL(select_rows_kernel<false>, dim3(row_grid(n_chains)),
+                       dim3(256), 0, reinterpret_cast<hipStream_t>(stream), q,
+                       q_new, accept, n_chains, n_data);
   ZS_LAUNCH_CHECK("select_rows_kernel launch");
   return ZSHMC_OK;
 }
