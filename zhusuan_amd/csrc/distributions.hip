@@ -275,17 +275,25 @@ __global__ __launch_bounds__(256) void softmax_family_reg_kernel(
         x[k] = d4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
       }
     }
-    float lse = 0.f;
+    float lse = 0.f, inv_se = 0.f;
     if (MODE < 2 || normalize) {
       mx = wave_max(mx);
       const float shift = isfinite(mx) ? mx : 0.f;
       float se = 0.f;
+      // the gradients need softmax = exp(x - shift) / sum: keep the
+      // exponentials in place of x (one expf per element instead of two)
+      constexpr bool kKeepExp = MODE == 1 || MODE == 3;
 #pragma unroll
       for (int k = 0; k < NPL; ++k)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) se += expf(x[k][j] - shift);
+        for (int j = 0; j < 4; ++j) {
+          const float e = expf(x[k][j] - shift);
+          se += e;
+          if (kKeepExp) x[k][j] = e;
+        }
       se = group_sum<64>(se);
       lse = shift + logf(se);
+      inv_se = 1.0f / se;
     }
     if (MODE == 0) {
       if (lane == 0) {
@@ -302,7 +310,7 @@ __global__ __launch_bounds__(256) void softmax_family_reg_kernel(
           d4 o;
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            o[j] = g * ((j0 + j == kk ? 1.0f : 0.0f) - expf(x[k][j] - lse));
+            o[j] = g * ((j0 + j == kk ? 1.0f : 0.0f) - x[k][j] * inv_se);
           *reinterpret_cast<d4*>(out + r * n_cat + j0) = o;
         }
       }
@@ -318,7 +326,7 @@ __global__ __launch_bounds__(256) void softmax_family_reg_kernel(
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             tot += gv[k][j];
-            sdot += gv[k][j] * (x[k][j] - lse);
+            if (MODE == 2) sdot += gv[k][j] * (x[k][j] - lse);
           }
         }
       }
@@ -336,7 +344,7 @@ __global__ __launch_bounds__(256) void softmax_family_reg_kernel(
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               float v = gv[k][j];
-              if (normalize) v -= tot * expf(x[k][j] - lse);
+              if (normalize) v -= tot * (x[k][j] * inv_se);
               o[j] = g * v;
             }
             *reinterpret_cast<d4*>(out + r * n_cat + j0) = o;
