@@ -330,6 +330,43 @@ def extra_config5(torch, zs, dev, n_chains=None, n_docs=5000, n_topics=128,
     }
 
 
+def make_sharding(dist, torch, ChainSharding, backend, dev, **layout):
+    """The direct RCCL communicator, proven with one all-reduce before it is
+    trusted; if its bootstrap fails or does not come back within two minutes
+    on ANY rank, every rank falls back to torch.distributed over the gloo
+    bootstrap group (device tensors staged through the host) so that the run
+    still produces its line -- which then says so (`rccl_ranks` 0)."""
+    import threading
+    if backend != 'rccl':
+        return ChainSharding(backend='torch', **layout), \
+            'torch.distributed/%s by request' % backend
+    box = {}
+
+    def attempt():
+        try:
+            torch.cuda.set_device(dev)
+            sh = ChainSharding(backend='rccl', **layout)
+            probe = torch.ones(2, dtype=torch.float64, device=dev)
+            sh.all_reduce_sum(probe)
+            torch.cuda.synchronize()
+            if probe.tolist() == [float(sh.world_size)] * 2:
+                box['sh'] = sh
+            else:
+                box['err'] = 'probe all-reduce returned %r' % (probe.tolist(),)
+        except Exception as e:                       # noqa: BLE001
+            box['err'] = repr(e)[:300]
+    th = threading.Thread(target=attempt, daemon=True)
+    th.start()
+    th.join(120.0)
+    ok = torch.tensor([1.0 if 'sh' in box else 0.0], dtype=torch.float64)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if float(ok.item()) == 1.0:
+        return box['sh'], 'RCCL (ncclAllReduce through zshmc_comm_*)'
+    return ChainSharding(backend='torch', **layout), (
+        'FALLBACK torch.distributed/gloo: RCCL communicator unavailable (%s)'
+        % box.get('err', 'bootstrap did not return within 120 s'))
+
+
 def main():
     args = parse()
     import torch
@@ -357,14 +394,14 @@ def main():
     local_dev = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_dev)
     dev = torch.device('cuda', local_dev)
-    sharding = None
+    sharding, collective_note = None, 'no collective'
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group(backend='gloo', rank=rank, world_size=world)
-        sharding = ChainSharding(
+        sharding, collective_note = make_sharding(
+            dist, torch, ChainSharding, backend, dev,
             chain_offset=rank * args.chains_per_gpu,
-            n_chains_global=world * args.chains_per_gpu,
-            backend='rccl' if backend == 'rccl' else 'torch')
+            n_chains_global=world * args.chains_per_gpu)
 
     C, D, L = args.chains_per_gpu, args.n_data, args.leapfrogs
     logstd = torch.linspace(-1.0, 1.0, D, device=dev)     # std = e^[-1, 1]
@@ -567,6 +604,7 @@ def main():
                     'the compute stream' if world > 1 else 'no collective'),
             },
             'rccl_ranks': 0 if sharding is None else sharding.rccl_ranks,
+            'collective': collective_note,
             'launches_per_transition': 1,
             'elem_leapfrog_steps_per_sec': value * D,
             'mean_acceptance': acc_mean,
