@@ -21,6 +21,21 @@ for f in find('%s_trace/**/*kernel_stats.csv' % tag):
             if i < 12:
                 lines.append('  ' + ', '.join(row))
 
+for f in find('%s_trace/**/*kernel_trace.csv' % tag):
+    rows = [r for r in csv.DictReader(open(f))
+            if 'hmc_diag_normal' in r.get('Kernel_Name', '')]
+    rows.sort(key=lambda r: int(r['Start_Timestamp']))
+    d = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) * 1e-3
+         for r in rows]
+    if d:
+        half = sorted(d[len(d) // 2:])
+        lines.append('== fused kernel, per-launch durations from the trace (us): '
+                     'all %d launches mean %.2f (burn-in, step-size-search dry '
+                     'runs and clock ramp included); second half (steady '
+                     'state) mean %.2f median %.2f min %.2f max %.2f' % (
+                         len(d), sum(d) / len(d), sum(half) / len(half),
+                         half[len(half) // 2], half[0], half[-1]))
+
 for sub in ('pmc_fetch', 'pmc_write', 'pmc_sq', 'pmc_sq2', 'pmc_sq3'):
     for f in find('%s_%s/**/*counter_collection.csv' % (tag, sub)):
         agg = {}
