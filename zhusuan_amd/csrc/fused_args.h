@@ -32,25 +32,55 @@ __device__ __forceinline__ TunerState tuner_load(const float* state) {
 // NEXT transition kernel, the workgroup that retires that kernel last, and the
 // stand-alone flush kernel -- which must agree to the bit: contraction is off
 // so that hipcc cannot fuse differently in different inlining contexts.
-__device__ __forceinline__ TunerState tuner_apply(TunerState s, float acc,
-                                                  int kind, float fresh,
-                                                  const TunerCfg& c) {
+// Split in two so that everything that does not depend on the acceptance --
+// the reciprocal, the square root and the power of the step counter, or the
+// whole HOLD update -- can be evaluated while the transition runs and only
+// tuner_finish (a handful of flops and one expf) sits behind the last
+// workgroup's retirement.
+struct TunerPrep {
+  float keep, step, rate1, sqrt_over_gamma, rate, hold_step_size;
+};
+
+__device__ __forceinline__ TunerPrep tuner_prepare(const TunerState& s,
+                                                   int kind, float fresh,
+                                                   const TunerCfg& c) {
+#pragma clang fp contract(off)
+  TunerPrep p{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (kind == ZSHMC_PEND_ADAPT) {
+    p.keep = 1.0f - fresh;
+    p.step = p.keep * s.step + 1.0f;
+    p.rate1 = 1.0f / (p.step + c.t0);
+    p.sqrt_over_gamma = sqrtf(p.step) / c.gamma;
+    p.rate = powf(p.step, -c.kappa);
+  } else {
+    p.hold_step_size = expf(s.log_eps_bar);
+  }
+  return p;
+}
+
+__device__ __forceinline__ TunerState tuner_finish(TunerState s,
+                                                   const TunerPrep& p,
+                                                   float acc, int kind,
+                                                   const TunerCfg& c) {
 #pragma clang fp contract(off)
   if (kind == ZSHMC_PEND_ADAPT) {
-    const float keep = 1.0f - fresh;
-    const float step = keep * s.step + 1.0f;
-    const float rate1 = 1.0f / (step + c.t0);
-    const float h_bar = keep * (1.0f - rate1) * s.h_bar + rate1 * (c.delta - acc);
-    const float log_eps = c.mu - sqrtf(step) / c.gamma * h_bar;
-    const float rate = powf(step, -c.kappa);
-    s.log_eps_bar = rate * log_eps + keep * (1.0f - rate) * s.log_eps_bar;
-    s.step = step;
+    const float h_bar =
+        p.keep * (1.0f - p.rate1) * s.h_bar + p.rate1 * (c.delta - acc);
+    const float log_eps = c.mu - p.sqrt_over_gamma * h_bar;
+    s.log_eps_bar = p.rate * log_eps + p.keep * (1.0f - p.rate) * s.log_eps_bar;
+    s.step = p.step;
     s.h_bar = h_bar;
     s.step_size = expf(log_eps);
   } else {
-    s.step_size = expf(s.log_eps_bar);
+    s.step_size = p.hold_step_size;
   }
   return s;
+}
+
+__device__ __forceinline__ TunerState tuner_apply(TunerState s, float acc,
+                                                  int kind, float fresh,
+                                                  const TunerCfg& c) {
+  return tuner_finish(s, tuner_prepare(s, kind, fresh, c), acc, kind, c);
 }
 
 // The link between consecutive transitions (include/zshmc.h,
@@ -78,10 +108,13 @@ struct AdaptLink {
 
 // state <- update(state, acc_sum) and the two diagnostic words; one thread.
 __device__ __forceinline__ void tuner_persist(const AdaptLink& k, int kind,
-                                              double acc_sum) {
+                                              double acc_sum,
+                                              const TunerPrep* prep = nullptr) {
   const TunerState s0 = tuner_load(k.state);
   const float acc = (float)(acc_sum * k.inv_chains);  // hmc.py:377
-  const TunerState s = tuner_apply(s0, acc, kind, k.fresh, k.tuner);
+  const TunerState s =
+      prep ? tuner_finish(s0, *prep, acc, kind, k.tuner)
+           : tuner_apply(s0, acc, kind, k.fresh, k.tuner);
   k.state[ZSHMC_ST_MEAN_ACCEPT] = acc;
   k.state[ZSHMC_ST_USED_STEP_SIZE] =
       k.used_step_size == k.used_step_size ? k.used_step_size : s0.step_size;
@@ -94,6 +127,15 @@ __device__ __forceinline__ void tuner_persist(const AdaptLink& k, int kind,
 // The step size this launch integrates with: the host value, or the device
 // state with the pending update applied (every workgroup computes the same
 // scalars from the same inputs; nobody writes them until all have read).
+// link_prepare: thread 0's head start on the update this launch will retire
+// with (the state block is not written before the last workgroup retires).
+__device__ __forceinline__ bool link_prepare(const AdaptLink& k,
+                                             TunerPrep* out) {
+  if (!k.state || k.retire == ZSHMC_PEND_NONE) return false;
+  *out = tuner_prepare(tuner_load(k.state), k.retire, k.fresh, k.tuner);
+  return true;
+}
+
 __device__ __forceinline__ float link_step_size(const AdaptLink& k,
                                                 float step_size_host) {
   if (!k.state) return step_size_host;
@@ -119,8 +161,11 @@ __device__ __forceinline__ float link_step_size(const AdaptLink& k,
 // the quantisation is far below the float32 mean the tuner consumes.
 constexpr int kSumBits = 50;  // count: 64 - 50 = 14 bits >= log2(kFusedMaxGrid)+1
 
+// `prep`: the acceptance-independent half of THIS transition's update
+// (retire), evaluated by the caller while the transition ran (or NULL).
 __device__ __forceinline__ void link_retire(const AdaptLink& k, double wg_sum,
-                                            const uint32_t* flags) {
+                                            const uint32_t* flags,
+                                            const TunerPrep* prep = nullptr) {
   if (!k.accum) return;
   const unsigned long long sum_fx =
       (unsigned long long)(wg_sum * k.fx_scale + 0.5);
@@ -133,7 +178,8 @@ __device__ __forceinline__ void link_retire(const AdaptLink& k, double wg_sum,
       (double)(all & ((1ull << kSumBits) - 1)) * k.fx_inv_scale;
   if (k.state && k.pending != ZSHMC_PEND_NONE)
     tuner_persist(k, k.pending, k.stats[0]);
-  if (k.state && k.retire != ZSHMC_PEND_NONE) tuner_persist(k, k.retire, total);
+  if (k.state && k.retire != ZSHMC_PEND_NONE)
+    tuner_persist(k, k.retire, total, prep);
   k.stats[0] = total;
   uint32_t f = 0;
   if (flags)

@@ -288,7 +288,9 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
       reinterpret_cast<double*>(s_ring + kWavesPerBlock * K * kRow);
   int* __restrict__ s_bad = reinterpret_cast<int*>(s_acc + kWavesPerBlock);
   int* __restrict__ s_ticket = s_bad + 1;
-  float* __restrict__ s_info = reinterpret_cast<float*>(s_bad + 4);  // [5][cap]
+  // [2] = "the update's acceptance-independent half is in s_prep"
+  TunerPrep* __restrict__ s_prep = reinterpret_cast<TunerPrep*>(s_bad + 4);
+  float* __restrict__ s_info = reinterpret_cast<float*>(s_bad + 12);  // [5][cap]
 
 #ifdef ZS_TIMING
   const unsigned long long t_start = wall_clock64();
@@ -381,6 +383,12 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
   // every compiler-issued load above has been consumed: from here on the
   // loop's VMEM traffic is the hand-counted asm only
   __syncthreads();  // LDS tile ready
+  // the acceptance-independent half of the step-size update this launch
+  // retires with: one lane of the last wave, off everybody else's path (its
+  // wave joins the ticket queue a microsecond late); read after the
+  // barriers at the end of the kernel
+  if (wib == kWavesPerBlock - 1 && lane == 0)
+    s_bad[2] = link_prepare(a.link, s_prep) ? 1 : 0;
 
   auto draw = [&]() -> int {  // next ticket of this workgroup (wave-uniform)
     int t = 0;
@@ -679,7 +687,7 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
     double tot = 0.0;
     for (int i = 0; i < kWavesPerBlock; ++i) tot += s_acc[i];
     if (*s_bad && a.flags) atomicOr(a.flags, ZSHMC_FLAG_OLD_LOGPROB_NONFINITE);
-    link_retire(a.link, tot, a.flags);
+    link_retire(a.link, tot, a.flags, s_bad[2] ? s_prep : nullptr);
   }
   // ---- staged HMCInfo scalars -> global, G consecutive chains per line ----
   if (STAGE && a.commit) {
@@ -704,7 +712,7 @@ static int launch_ring_cfg(const FusedArgs& a_in, hipStream_t stream) {
   constexpr size_t lds_base =
       (size_t)((ZERO_MEAN ? 0 : 1) + (HAS_MASS ? 1 : 0) + kWaves * K) * NCH *
           1024 +
-      kWaves * sizeof(double) + 16;
+      kWaves * sizeof(double) + 48;
   static_assert(lds_base <= kLdsLimit, "ring does not fit in LDS");
   static bool ready = false;
   if (!ready) {
