@@ -186,7 +186,14 @@ __global__ __launch_bounds__(256) void mh_accept_kernel(
     if (accept) accept[c] = ok ? 1 : 0;
     acc_local += (double)acc;
   }
-  const double w = wave_sum_f64(acc_local);
+  // Each wave's partial is rounded to a multiple of 2^-20 before it is added:
+  // doubles that are exact multiples of 2^-20 add without rounding up to
+  // 2^33, so the total does not depend on the order of the atomics -- the
+  // mean acceptance, hence the adapted step size, is bit-identical from run
+  // to run (the quantisation, < 5e-7 per 64 chains, is far below the float32
+  // mean the tuner consumes).
+  const double w =
+      __builtin_rint(wave_sum_f64(acc_local) * 1048576.0) * (1.0 / 1048576.0);
   const unsigned long long any_bad = __ballot(bad);
   if ((threadIdx.x & 63) == 0) {
     if (acc_sum && w != 0.0) atomicAdd(acc_sum, w);
