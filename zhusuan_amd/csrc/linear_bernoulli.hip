@@ -415,6 +415,36 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2
 #else
 #define ZS_LB_MARK(i)
 #endif
+  // OP 1: the counts x[c, n] of one tile for this lane (a gather: every lane
+  // reads its own chain's row of the counts matrix, 32 rows per instruction,
+  // so the instruction count is what costs).  Rows padded with zeros to a
+  // multiple of 4 floats and 16-B aligned (the caller's count_stride): 4 x
+  // 16 B per lane instead of 16 x 4 B.
+  float xcnt[16], xnext[16];
+  auto load_counts = [&](int64_t t, float* dst) {
+    int64_t cr = c0 + a * 32 + lo;
+    cr = cr < C ? cr : C - 1;
+    // counts rows repeat with period yc_rows (x[n_docs, V] shared by chains)
+    const float* __restrict__ xrow0 =
+        yc + (cr % yc_rows) * ldy + t * kRows + b * 32 + 4 * hi;
+    const int64_t left = N - (t * kRows + b * 32 + 4 * hi);  // may be <= 0
+    if (yc_vec) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f4 v = f4{0.f, 0.f, 0.f, 0.f};
+        if (8 * j < left) v = *reinterpret_cast<const f4*>(xrow0 + 8 * j);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) dst[j * 4 + m] = v[m];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          dst[j * 4 + m] = (8 * j + m < left) ? xrow0[8 * j + m] : 0.f;
+    }
+  };
+  if (OP == 1) load_counts(tile_begin, xcnt);
   for (int64_t tile = tile_begin; tile < n_tiles; ++tile) {
     const int buf = (int)((tile - tile_begin) & 1);       // sY slot
     const int xbuf = kBuf == 2 ? buf : 0;                 // sX slot
@@ -427,37 +457,13 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2
       const int64_t nr = n_next + tid;
       yr = nr < N ? y[nr] : 0.f;
     }
-    // OP 1: this lane's 16 counts of the CURRENT tile (chain a*32+lo, rows
-    // b*32 + 8j + 4hi .. +3): four 16-B groups of its own row of yc
-    float xcnt[16];
-    if (OP == 1) {
-      int64_t cr = c0 + a * 32 + lo;
-      cr = cr < C ? cr : C - 1;
-      // counts rows repeat with period yc_rows (x[n_docs, V] shared by chains)
-      const float* __restrict__ xrow0 =
-          yc + (cr % yc_rows) * ldy + tile * kRows + b * 32 + 4 * hi;
-      const int64_t left = N - (tile * kRows + b * 32 + 4 * hi);  // may be <= 0
-      // Every lane reads its own row of the counts matrix (a gather: 32
-      // chains = 32 rows per instruction), so the instruction count is what
-      // costs.  Rows padded with zeros to a multiple of 4 floats and 16-B
-      // aligned (the caller's count_stride): 4 x 16 B per lane instead of
-      // 16 x 4 B.
-      if (yc_vec) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          f4 v = f4{0.f, 0.f, 0.f, 0.f};
-          if (8 * j < left) v = *reinterpret_cast<const f4*>(xrow0 + 8 * j);
-#pragma unroll
-          for (int m = 0; m < 4; ++m) xcnt[j * 4 + m] = v[m];
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int m = 0; m < 4; ++m)
-            xcnt[j * 4 + m] = (8 * j + m < left) ? xrow0[8 * j + m] : 0.f;
-      }
-    }
+    // OP 1: this lane's 16 counts (chain a*32+lo, rows b*32 + 8j + 4hi .. +3)
+    // of the NEXT tile go out now and are consumed one tile later: hipcc waits
+    // for its own loads with `s_waitcnt vmcnt(n)` counted WITHOUT the
+    // hand-issued DMA rows behind them in the same in-order queue, so a load
+    // used in this tile's residual would drag the whole next X tile's DMA
+    // into the wait; the end-of-tile vmcnt(0) lands these for free.
+    if (OP == 1) load_counts(more ? tile + 1 : tile, xnext);
 
     // ---- phase 1 (own 32 rows, full K) --------------------------------------
     // Hand-pipelined: the LDS read of step kk+1 and one DMA row of tile+1 go
@@ -595,6 +601,10 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA rows landed
+    if (OP == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xcnt[r] = xnext[r];
+    }
     __syncthreads();  // tile+1 published; this buffer free for tile+2
     ZS_LB_MARK(5)  // DMA wait + barrier 2
   }

@@ -655,7 +655,14 @@ class _FusedDiagNormalPlan(_PlanBase):
                 "changed model.".format(self.names[0]))
         self.mean.copy_(mean_d)
         self.logstd.copy_(logstd_d)
-        self.zero_mean = not bool(mean_d.any().item())
+        # The zero-mean instantiation (no mean tile) is chosen when the mean
+        # is verified to be all zeros -- a host read, so only at plan build.
+        # A model function that hands over a NEW parameter tensor on a later
+        # run (torch.zeros(...) built inside the function, a fed mean) gets
+        # the general instantiation from then on: no synchronisation on the
+        # per-run path.
+        self.zero_mean = not bool(mean_d.any().item()) if src is None \
+            else False
         self._src = (mean_src, spread_src, mean_src._version,
                      spread_src._version)
 
