@@ -64,7 +64,13 @@ namespace zshmc {
 #define ZS_RING_GRANULE 16  // consecutive chains per workgroup turn (16 = one
 #endif                      // 64-B line of each HMCInfo array)
 #ifndef ZS_RING_K4
-#define ZS_RING_K4 2  // ring depth at NCH = 4 (n_data 772..1024)
+#define ZS_RING_K4 1  // ring depth at NCH = 4 (n_data 772..1024): one row ahead is
+                      // enough to hide HBM latency behind a ~6 us trip, and a
+                      // shallower ring shortens the read -> write-back distance
+                      // of a row (0.0951 -> 0.0925 ms)
+#endif
+#ifndef ZS_RING_DMA_POS
+#define ZS_RING_DMA_POS 0
 #endif
 #ifndef ZS_RNG_PAIR
 #define ZS_RNG_PAIR 1  // generator runs two chunks interleaved (A/B knob)
@@ -441,6 +447,14 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
     else
       wait_vmcnt<(K - 1) * NCH + K * (NCH + kLedgerInfo)>();
     f4 r[NCH], p[NCH];
+    // refill of the slot this trip frees: where in the trip it is issued is
+    // an A/B knob (ZS_RING_DMA_POS: 0 right after the slot is in registers,
+    // 1 after the generator, 2 after the leapfrog -- later = a shorter
+    // distance between a row's read and its write-back); always before this
+    // trip's stores, so the vmcnt ledger does not change
+    const float* late_src;
+    uint32_t late_dst;
+    bool late_on;
     {
       const float* __restrict__ sl = ring_w + slot * kRow;
 #pragma unroll
@@ -455,9 +469,13 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
       const int nt = (int)uni32(nt_raw);
       int64_t nrow = ZS_CHAIN_OF(nt);
       nrow = nrow < last_row ? nrow : last_row;
-      issue_row<NCH>(voff, voff_last, a.q + uni64(nrow * D),
-                     uni32(ring_addr + (uint32_t)slot * kRowB),
-                     mask_if<true>(nt < count));
+      late_src = a.q + uni64(nrow * D);
+      late_dst = uni32(ring_addr + (uint32_t)slot * kRowB);
+      late_on = nt < count;
+#if ZS_RING_DMA_POS == 0
+      issue_row<NCH>(voff, voff_last, late_src, late_dst,
+                     mask_if<true>(late_on));
+#endif
       slot = slot + 1 == K ? 0 : slot + 1;
 #pragma unroll
       for (int j = 0; j + 1 < K; ++j) tk[j] = tk[j + 1];
@@ -527,6 +545,9 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
     }
 #endif
 
+#if ZS_RING_DMA_POS == 1
+    issue_row<NCH>(voff, voff_last, late_src, late_dst, mask_if<true>(late_on));
+#endif
     // ---- leapfrog (hmc.py:348-372): L full drifts + full kicks; half of the
     // last kick is taken back below ----------------------------------------
 #ifdef ZS_PRIO_LF
@@ -550,6 +571,9 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
 
 #ifdef ZS_PRIO_END
     __builtin_amdgcn_s_setprio(ZS_PRIO_END);
+#endif
+#if ZS_RING_DMA_POS == 2
+    issue_row<NCH>(voff, voff_last, late_src, late_dst, mask_if<true>(late_on));
 #endif
     // ---- Hamiltonians (hmc.py:30-35) and acceptance (hmc.py:46-61) -------
     f4 kn = f4{0.f, 0.f, 0.f, 0.f}, un = kn;
