@@ -642,16 +642,18 @@ def main():
             # hmc.py over the TensorFlow-API shim cannot run here (its sources
             # do not travel) and is carried as a recorded number.
             budget = min(args.cpu_seconds, 8.0)
-            try:
-                out['cpu_baseline'] = cpu_baseline_parallel(D, L, budget)
-            except Exception as e:           # no gcc / OpenMP on the box
-                out['cpu_baseline'] = {'error': str(e)[:200]}
+            # (torch first: the OpenMP pool of the C port keeps spinning for a
+            # while after its last parallel region and would fight torch's)
             try:
                 out['cpu_baseline_torch_all_threads'] = cpu_baseline_torch(
                     D, L, budget)
             except Exception as e:
                 out['cpu_baseline_torch_all_threads'] = {'error': str(e)[:200]}
             out['cpu_baseline_numpy_1core'] = cpu_baseline_numpy(D, L, budget)
+            try:
+                out['cpu_baseline'] = cpu_baseline_parallel(D, L, budget)
+            except Exception as e:           # no gcc / OpenMP on the box
+                out['cpu_baseline'] = {'error': str(e)[:200]}
             if 'error' in out['cpu_baseline']:
                 out['cpu_baseline'] = out['cpu_baseline_numpy_1core']
             out['cpu_reference_over_shim'] = cpu_reference_recorded()
