@@ -114,6 +114,48 @@ def test_learning_rate_placeholder_and_errors(env):
         s.sample(lambda o: 0, {}, {'x': x})
 
 
+def test_minibatch_fed_per_run_reaches_the_model(env):
+    """The reference's main SGMCMC idiom, sess.run(sample_op,
+    feed_dict={x: xb, y: yb}) per mini-batch: data placeholders in `observed`
+    (and read as `.value` inside the log-joint) must be bound by the run's
+    feed_dict.  lr -> deterministic part of SGLD: q += lr/2 * grad, so with the
+    noise subtracted two runs with different batches must move q by the
+    gradient of THAT batch; a learning-rate placeholder without a default
+    makes SGHMC draw its initial momentum at the first run's lr."""
+    zs, torch, dev = env
+    xb = zs.placeholder(torch.float32, name='xb')
+    scale = zs.placeholder(torch.float32, name='scale')
+    w = torch.zeros(7, 3, device=dev)
+
+    def log_joint(obs):
+        # quadratic pull of w towards the fed batch mean, scaled by a tensor
+        # that is read through .value inside the model
+        return -0.5 * scale.value * ((obs['w'] - obs['xb'].mean(0)) ** 2).sum(-1)
+
+    s = zs.SGLD(learning_rate=0.2, seed=3)
+    op, _ = s.sample(log_joint, {'xb': xb}, {'w': w})
+    batches = [np.full((5, 3), 2.0, np.float32), np.full((4, 3), -1.0, np.float32)]
+    moved = []
+    for b, sc in zip(batches, (1.0, 3.0)):
+        before = w.clone()
+        op.run(feed_dict={xb: b, scale: np.float32(sc)})
+        # expected drift lr/2 * grad = 0.1 * sc * (mean(b) - w_before)
+        drift = 0.1 * sc * (torch.tensor(b, device=dev).mean(0) - before)
+        moved.append((w - before - drift))
+    # what is left is the N(0, lr) noise: zero-mean, std sqrt(0.2), and NOT
+    # the several-sigma offset a stale / unbound batch would leave
+    for r in moved:
+        assert abs(float(r.mean())) < 0.45 and 0.2 < float(r.std()) < 0.8
+    # SGHMC with an lr placeholder and no default: v0 ~ N(0, lr) at the first run
+    lr = zs.placeholder(float)
+    x = torch.zeros(4000, device=dev)
+    h = zs.SGHMC(learning_rate=lr, friction=0.3, seed=5)
+    oph, _ = h.sample(lambda o: -0.5 * o['x'] ** 2, {}, {'x': x})
+    oph.run(feed_dict={lr: 0.04})
+    v = h.vs[0]
+    assert 0.1 < float(v.std()) < 0.4          # ~ sqrt(0.04) = 0.2, not 0
+
+
 def _sample_error_with(zs, torch, dev, sampler, n_chains, n_iters, thinning=50):
     """tests/test_mcmc.py:14-50 (Fig. 1 of Chen et al.): double well
     2x^2 - x^4 with a noisy log-likelihood, KDE error of the pooled samples."""

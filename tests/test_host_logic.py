@@ -249,3 +249,21 @@ def test_placeholder_deferred_and_session_fetch_structure():
     assert fetched[0].alpha[1] == 4 and isinstance(fetched[0].alpha[0], np.ndarray)
     single = zs.Session().run(Info(q=torch.ones(1), alpha=None))
     assert isinstance(single, Info) and single.alpha is None
+
+    # a dict subclass whose constructor takes something else than (key, value)
+    # pairs -- HMCInfo.init_momentum regenerates p0 on access -- is fetched
+    # as a plain dict of arrays
+    class Lazy(dict):
+        def __init__(self, plan):
+            super(Lazy, self).__init__()
+            self._plan = plan
+
+        def __getitem__(self, k):
+            return torch.full((2,), float(self._plan[k]))
+
+        def keys(self):
+            return list(self._plan)
+
+    got = zs.Session().run([Lazy({'x': 3, 'y': 4})])[0]
+    assert type(got) is dict and sorted(got) == ['x', 'y']
+    np.testing.assert_array_equal(got['y'], np.full(2, 4.0, np.float32))
