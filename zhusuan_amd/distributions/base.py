@@ -39,63 +39,38 @@ def common_device(*tensors):
 class Distribution(object):
     """base.py:17-120."""
 
+    # read-only attributes of the reference's Distribution (base.py:123-181),
+    # filled by the constructor and exposed as properties below the class
+    _FIELDS = ('dtype', 'param_dtype', 'is_continuous', 'is_reparameterized',
+               'use_path_derivative', 'group_ndims')
+
     def __init__(self, dtype, param_dtype, is_continuous, is_reparameterized,
                  use_path_derivative=False, group_ndims=0, **kwargs):
-        self._dtype = dtype
-        self._param_dtype = param_dtype
-        self._is_continuous = is_continuous
-        self._is_reparameterized = is_reparameterized
-        self._use_path_derivative = use_path_derivative
         if isinstance(group_ndims, bool) or not isinstance(group_ndims, int):
             raise TypeError("group_ndims should be a Python int, got {!r}"
                             .format(group_ndims))
         if group_ndims < 0:
             raise ValueError("group_ndims must be non-negative.")
-        self._group_ndims = group_ndims
-
-    @property
-    def dtype(self):
-        return self._dtype
-
-    @property
-    def param_dtype(self):
-        return self._param_dtype
-
-    @property
-    def is_continuous(self):
-        return self._is_continuous
-
-    @property
-    def is_reparameterized(self):
-        return self._is_reparameterized
-
-    @property
-    def use_path_derivative(self):
-        return self._use_path_derivative
-
-    @property
-    def group_ndims(self):
-        return self._group_ndims
+        for field, value in zip(self._FIELDS, (
+                dtype, param_dtype, is_continuous, is_reparameterized,
+                use_path_derivative, group_ndims)):
+            setattr(self, '_' + field, value)
 
     def path_param(self, param):
         """base.py:183-190: stop gradients through parameters when the path
         derivative estimator is requested."""
         return param.detach() if self._use_path_derivative else param
 
-    # -- shapes (static == dynamic: torch shapes are always concrete) -----
-    @property
-    def value_shape(self):
-        return self._get_value_shape()
-
+    # -- shapes: torch shapes are always concrete, so the reference's static
+    # (`get_*_shape()`) and dynamic (`*_shape`) views are one and the same ----
     def get_value_shape(self):
         return self._get_value_shape()
 
-    @property
-    def batch_shape(self):
-        return self._get_batch_shape()
-
     def get_batch_shape(self):
         return self._get_batch_shape()
+
+    value_shape = property(lambda self: self._get_value_shape())
+    batch_shape = property(lambda self: self._get_batch_shape())
 
     def _get_value_shape(self):
         raise NotImplementedError()
@@ -160,3 +135,9 @@ class Distribution(object):
 
     def _log_prob(self, given):
         raise NotImplementedError()
+
+
+for _f in Distribution._FIELDS:
+    setattr(Distribution, _f, property(
+        lambda self, _k='_' + _f: getattr(self, _k),
+        doc="The reference's Distribution.%s (read-only)." % _f))

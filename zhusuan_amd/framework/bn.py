@@ -217,81 +217,87 @@ class _BayesianNet(object):
     def __getitem__(self, name):
         return self._resolve((name,), False, lambda node: node)[0]
 
-    # -- factory methods on the HMC path ------------------------------------
-    def normal(self, name, mean=0., _sentinel=None, std=None, logstd=None,
-               group_ndims=0, n_samples=None, is_reparameterized=True,
-               check_numerics=False, **kwargs):
-        """bn.py:556-590."""
-        dist = distributions.Normal(
-            mean, _sentinel=_sentinel, std=std, logstd=logstd,
-            group_ndims=group_ndims, is_reparameterized=is_reparameterized,
-            check_numerics=check_numerics, **kwargs)
-        return self.stochastic(name, dist, n_samples=n_samples, **kwargs)
 
-    def laplace(self, name, loc, scale, n_samples=None, group_ndims=0,
-                is_reparameterized=True, check_numerics=False, **kwargs):
-        """bn.py (reference): add a Laplace node."""
-        dist = distributions.Laplace(
-            loc, scale, group_ndims=group_ndims,
-            is_reparameterized=is_reparameterized,
-            check_numerics=check_numerics, **kwargs)
-        return self.stochastic(name, dist, n_samples=n_samples, **kwargs)
 
-    def gamma(self, name, alpha, beta, n_samples=None, group_ndims=0,
-              check_numerics=False, **kwargs):
-        dist = distributions.Gamma(alpha, beta, group_ndims=group_ndims,
-                                   check_numerics=check_numerics, **kwargs)
-        return self.stochastic(name, dist, n_samples=n_samples, **kwargs)
+# -- node factories ----------------------------------------------------------
+# `bn.normal(name, ...)`, `bn.bernoulli(name, ...)` ... (reference bn.py:556-965)
+# are generated from this table: distribution class, then the parameters in
+# the reference's positional order with their defaults (_REQUIRED = no
+# default).  `n_samples` goes to the node (how many samples an unobserved node
+# draws), everything else to the distribution's constructor; unknown keyword
+# options are passed to both, as the reference does.
+_REQUIRED = object()
+_COMMON = (('n_samples', None), ('group_ndims', 0))
+_NODE_FACTORIES = {
+    'normal': ('Normal', (
+        ('mean', 0.), ('_sentinel', None), ('std', None), ('logstd', None),
+        ('group_ndims', 0), ('n_samples', None), ('is_reparameterized', True),
+        ('check_numerics', False)), 'bn.py:556-590'),
+    'laplace': ('Laplace', (
+        ('loc', _REQUIRED), ('scale', _REQUIRED)) + _COMMON + (
+        ('is_reparameterized', True), ('check_numerics', False)),
+        'bn.py:1041-1068'),
+    'gamma': ('Gamma', (
+        ('alpha', _REQUIRED), ('beta', _REQUIRED)) + _COMMON + (
+        ('check_numerics', False),), 'bn.py:713-738'),
+    'inverse_gamma': ('InverseGamma', (
+        ('alpha', _REQUIRED), ('beta', _REQUIRED)) + _COMMON + (
+        ('check_numerics', False),), 'bn.py:1012-1039'),
+    'beta': ('Beta', (
+        ('alpha', _REQUIRED), ('beta', _REQUIRED)) + _COMMON + (
+        ('check_numerics', False),), 'bn.py:740-765'),
+    'bernoulli': ('Bernoulli', (
+        ('logits', _REQUIRED),) + _COMMON + (('dtype', torch.int32),),
+        'bn.py:628-654'),
+    'categorical': ('Categorical', (
+        ('logits', _REQUIRED),) + _COMMON + (('dtype', torch.int32),),
+        'bn.py:656-682'),
+    'unnormalized_multinomial': ('UnnormalizedMultinomial', (
+        ('logits', _REQUIRED), ('normalize_logits', True), ('group_ndims', 0),
+        ('dtype', torch.int32)), 'bn.py:938-965'),
+    'multivariate_normal_cholesky': ('MultivariateNormalCholesky', (
+        ('mean', _REQUIRED), ('cov_tril', _REQUIRED)) + _COMMON + (
+        ('is_reparameterized', True), ('check_numerics', False)),
+        'bn.py:840-870'),
+}
+_ALIASES = {'discrete': 'categorical',
+            'bag_of_categoricals': 'unnormalized_multinomial'}
 
-    def inverse_gamma(self, name, alpha, beta, n_samples=None, group_ndims=0,
-                      check_numerics=False, **kwargs):
-        dist = distributions.InverseGamma(
-            alpha, beta, group_ndims=group_ndims,
-            check_numerics=check_numerics, **kwargs)
-        return self.stochastic(name, dist, n_samples=n_samples, **kwargs)
 
-    def beta(self, name, alpha, beta, n_samples=None, group_ndims=0,
-             check_numerics=False, **kwargs):
-        dist = distributions.Beta(alpha, beta, group_ndims=group_ndims,
-                                  check_numerics=check_numerics, **kwargs)
-        return self.stochastic(name, dist, n_samples=n_samples, **kwargs)
+def _make_factory(method, dist_name, params, cite):
+    order = [k for k, _ in params]
 
-    def bernoulli(self, name, logits, n_samples=None, group_ndims=0,
-                  dtype=torch.int32, **kwargs):
-        """bn.py:628-654."""
-        dist = distributions.Bernoulli(
-            logits, group_ndims=group_ndims, dtype=dtype, **kwargs)
-        return self.stochastic(name, dist, n_samples=n_samples, **kwargs)
+    def add_node(self, name, *args, **options):
+        if len(args) > len(order):
+            raise TypeError("%s() takes at most %d positional arguments (%d "
+                            "given)" % (method, len(order) + 1, len(args) + 1))
+        given = dict(zip(order, args))
+        for k in list(options):
+            if k in given:
+                raise TypeError("%s() got multiple values for argument '%s'"
+                                % (method, k))
+        extras = {k: v for k, v in options.items() if k not in order}
+        given.update({k: v for k, v in options.items() if k in order})
+        for k, default in params:
+            if k not in given:
+                if default is _REQUIRED:
+                    raise TypeError("%s() missing required argument: '%s'"
+                                    % (method, k))
+                given[k] = default
+        node_opts = dict(extras)
+        if 'n_samples' in given:
+            node_opts['n_samples'] = given.pop('n_samples')
+        dist = getattr(distributions, dist_name)(**dict(given, **extras))
+        return self.stochastic(name, dist, **node_opts)
+    add_node.__name__ = method
+    add_node.__doc__ = "Add a %s node (reference %s)." % (dist_name, cite)
+    return add_node
 
-    def categorical(self, name, logits, n_samples=None, group_ndims=0,
-                    dtype=torch.int32, **kwargs):
-        """bn.py:656-682."""
-        dist = distributions.Categorical(
-            logits, group_ndims=group_ndims, dtype=dtype, **kwargs)
-        return self.stochastic(name, dist, n_samples=n_samples, **kwargs)
 
-    discrete = categorical
-
-    def unnormalized_multinomial(self, name, logits, normalize_logits=True,
-                                 group_ndims=0, dtype=torch.int32, **kwargs):
-        """bn.py:938-965."""
-        dist = distributions.UnnormalizedMultinomial(
-            logits, normalize_logits=normalize_logits,
-            group_ndims=group_ndims, dtype=dtype, **kwargs)
-        return self.stochastic(name, dist, **kwargs)
-
-    bag_of_categoricals = unnormalized_multinomial
-
-    def multivariate_normal_cholesky(self, name, mean, cov_tril,
-                                     n_samples=None, group_ndims=0,
-                                     is_reparameterized=True,
-                                     check_numerics=False, **kwargs):
-        """bn.py:840-870."""
-        dist = distributions.MultivariateNormalCholesky(
-            mean, cov_tril, group_ndims=group_ndims,
-            is_reparameterized=is_reparameterized,
-            check_numerics=check_numerics, **kwargs)
-        return self.stochastic(name, dist, n_samples=n_samples, **kwargs)
+for _m, (_d, _p, _c) in _NODE_FACTORIES.items():
+    setattr(_BayesianNet, _m, _make_factory(_m, _d, _p, _c))
+for _alias, _m in _ALIASES.items():
+    setattr(_BayesianNet, _alias, getattr(_BayesianNet, _m))
 
 
 class BayesianNet(_BayesianNet):
