@@ -180,14 +180,26 @@ def cpu_baseline_parallel(n_data, n_leapfrogs, budget_s):
 
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 MFMA, MI355X_MICROARCH.md
+ADAPT_TRANSIENT_NOTE = (
+    "timed transitions 3-4 sit in the reference's dual-averaging start-up "
+    "transient: mu = 10*eps0 is used as a LOG step size (hmc.py:79, sic), so "
+    "eps jumps to ~1 after the first adapted iteration and acceptance is ~0 "
+    "until ~iteration 9; transition 1 uses the searched step size "
+    "(mean_acceptance_first_transition).  The work per transition -- L + 1 "
+    "likelihood + gradient evaluations -- does not depend on it.")
 
 
 def _time_native_plan(torch, hmc, sample_op, feed, n_warm, n_timed):
     """Wall time per transition (HIP events on the launch stream) and the
     likelihood kernel alone (one evaluation = likelihood + gradient)."""
-    for _ in range(n_warm):
+    first_acc = None
+    for i in range(n_warm):
         sample_op.run(feed_dict=feed, sync=False)
+        if i == 0:
+            # transition 1 integrates with the step size the search returned
+            first_acc = float(hmc.hmc_info.acceptance_rate.mean().item())
     hmc.check_numerics()
+    hmc._first_transition_acceptance = first_acc
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -247,6 +259,9 @@ def extra_config3(torch, zs, dev, n_rows=1000000, n_chains=32768, n_feat=256,
         'value': n_chains * n_leapfrogs / (ms * 1e-3),
         'unit': 'chain-leapfrog-steps/s',
         'mean_acceptance': float(info.acceptance_rate.mean().item()),
+        'mean_acceptance_first_transition': getattr(
+            hmc, '_first_transition_acceptance', None),
+        'acceptance_note': ADAPT_TRANSIENT_NOTE,
         'step_size': float(info.updated_step_size.item()),
         'roofline': {
             'bound': 'mfma_f32', 'peak': MFMA_F32_PEAK_TFLOPS,
@@ -315,6 +330,9 @@ def extra_config5(torch, zs, dev, n_chains=None, n_docs=5000, n_topics=128,
         'value': rows * n_leapfrogs / (ms * 1e-3),
         'unit': '(chain, document)-leapfrog-steps/s',
         'mean_acceptance': float(info.acceptance_rate.mean().item()),
+        'mean_acceptance_first_transition': getattr(
+            hmc, '_first_transition_acceptance', None),
+        'acceptance_note': ADAPT_TRANSIENT_NOTE,
         'roofline': {
             'bound': 'mfma_f32', 'peak': MFMA_F32_PEAK_TFLOPS,
             'unit': 'TFLOP/s',
