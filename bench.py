@@ -181,8 +181,8 @@ def cpu_baseline_parallel(n_data, n_leapfrogs, budget_s):
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 MFMA, MI355X_MICROARCH.md
 ADAPT_TRANSIENT_NOTE = (
-    "timed transitions 3-4 sit in the reference's dual-averaging start-up "
-    "transient: mu = 10*eps0 is used as a LOG step size (hmc.py:79, sic), so "
+    "the timed transitions (numbers 2-4) sit in the reference's "
+    "dual-averaging start-up transient: mu = 10*eps0 is used as a LOG step size (hmc.py:79, sic), so "
     "eps jumps to ~1 after the first adapted iteration and acceptance is ~0 "
     "until ~iteration 9; transition 1 uses the searched step size "
     "(mean_acceptance_first_transition).  The work per transition -- L + 1 "
