@@ -267,3 +267,81 @@ def test_placeholder_deferred_and_session_fetch_structure():
     got = zs.Session().run([Lazy({'x': 3, 'y': 4})])[0]
     assert type(got) is dict and sorted(got) == ['x', 'y']
     np.testing.assert_array_equal(got['y'], np.full(2, 4.0, np.float32))
+
+
+def test_native_plan_reprobes_the_model_on_a_meta_latent(monkeypatch):
+    """The per-run re-evaluation of the model function (fed / updated
+    parameters must be seen, SURVEY section 7 "no stale caching") gets a META
+    tensor for the latent: `torch.softmax(eta, -1)` in the model function then
+    is shape arithmetic -- no ATen launch and no [rows, K] temporary per
+    transition -- while the parameter tensors are found again by identity."""
+    import torch
+    import zhusuan_amd as zs
+    from zhusuan_amd import hmc as H
+    n_chains, n_docs, K, V = 4, 6, 8, 20
+    phi = torch.softmax(torch.randn(K, V), -1)
+    x = torch.poisson(torch.full((n_docs, V), 2.0))
+    eta_mean = zs.placeholder(torch.float32, name='eta_mean',
+                              default=torch.zeros(n_docs, K))
+    eta_logstd = torch.zeros(K)
+    seen = []
+
+    @zs.meta_bayesian_net()
+    def lntm():
+        bn = zs.BayesianNet()
+        eta = bn.normal('eta', eta_mean.value, logstd=eta_logstd,
+                        n_samples=n_chains, group_ndims=1)
+        seen.append(eta.tensor.device.type)
+        bn.unnormalized_multinomial(
+            'x', zs.log_mixture(torch.softmax(eta.tensor, -1), phi),
+            normalize_logits=False, dtype=torch.float32)
+        return bn
+
+    class Stub(object):
+        def __init__(self, hmc, names, values, cs, dev, probe, kind):
+            self.probe, self.kind = probe, kind
+
+    monkeypatch.setattr(H, '_DenseLikelihoodPlan', Stub)
+    hmc = zs.HMC(step_size=1e-3)
+    hmc._observed = {'x': x}
+    q = torch.zeros(n_chains, n_docs, K)
+    plan = H._try_dense_likelihood_plan(hmc, lntm(), ['eta'], [q],
+                                        (n_chains, n_docs), q.device)
+    assert plan is not None and plan.kind == 'mixture_multinomial'
+    assert seen == ['cpu']          # the build-time analysis: real latent
+    del seen[:]
+    mean, (how, spread), phi_seen, x_seen = plan.probe()
+    assert seen == ['meta']
+    assert mean is eta_mean.value and spread is eta_logstd and how == 'logstd'
+    assert phi_seen is phi and x_seen is x
+    # a newly fed prior mean is what the next probe returns
+    new_mean = torch.ones(n_docs, K)
+    eta_mean._value = new_mean
+    assert plan.probe()[0] is new_mean and seen == ['meta', 'meta']
+
+    # a model function that mixes the latent with device tensors cannot run
+    # on a meta latent: it is evaluated on the latent itself from then on
+    bias = torch.zeros(K)
+    del seen[:]
+
+    @zs.meta_bayesian_net()
+    def shifted():
+        bn = zs.BayesianNet()
+        eta = bn.normal('eta', torch.zeros(n_docs, K), logstd=eta_logstd,
+                        n_samples=n_chains, group_ndims=1)
+        seen.append(eta.tensor.device.type)
+        _ = eta.tensor + bias       # meta + cpu: refused by torch
+        bn.unnormalized_multinomial(
+            'x', zs.log_mixture(torch.softmax(eta.tensor, -1), phi),
+            normalize_logits=False, dtype=torch.float32)
+        return bn
+
+    hmc2 = zs.HMC(step_size=1e-3)
+    hmc2._observed = {'x': x}
+    plan2 = H._try_dense_likelihood_plan(hmc2, shifted(), ['eta'], [q],
+                                         (n_chains, n_docs), q.device)
+    del seen[:]
+    plan2.probe()
+    assert seen == ['meta', 'cpu']
+    plan2.probe()
+    assert seen == ['meta', 'cpu', 'cpu']

@@ -29,7 +29,10 @@ for f in glob.glob(os.path.join(out, tag + '_native_trace', '**', '*kernel_trace
             inside = not inside
             continue
         if inside:
-            key = name.split('(')[0][:110]
+            # 'void (anonymous namespace)::softmax_warp_forward<...>(...)':
+            # cut at the argument list, not at the first parenthesis
+            key = re.sub(r'\(anonymous namespace\)', '{anon}', name)
+            key = key.split('(')[0][:110]
             d = section.setdefault(key, [0, 0.0])
             d[0] += 1
             d[1] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) * 1e-3
@@ -38,8 +41,13 @@ for f in glob.glob(os.path.join(out, tag + '_native_trace', '**', '*kernel_trace
                      '(config %s): name, launches, total us' % (i, '3' if i == 0 else '5'))
         for k, (n, us) in sorted(sec.items(), key=lambda kv: -kv[1][1]):
             lines.append('  %-112s %5d %12.1f' % (k, n, us))
-        aten = [k for k in sec if 'at::' in k or 'aten' in k.lower()]
-        lines.append('  at::native kernels inside the transitions: %d' % len(aten))
+        # anything that is neither this library's nor the runtime's copy /
+        # fill blit is somebody else's kernel (ATen, ...)
+        foreign = [k for k in sec if 'zshmc::' not in k and
+                   '__amd_rocclr' not in k]
+        lines.append('  kernels that are neither zshmc:: nor runtime blits '
+                     '(ATen etc.) inside the transitions: %d%s' % (
+                         len(foreign), ''.join('\n    ' + k for k in foreign)))
 for f in glob.glob(os.path.join(out, tag + '_native_pmc', '**', '*counter_collection.csv'), recursive=True):
     agg = {}
     for row in csv.DictReader(open(f)):

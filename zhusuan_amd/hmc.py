@@ -1261,8 +1261,28 @@ def _try_dense_likelihood_plan(hmc, meta_bn, names, values, chain_shape,
         return None
     kind = found[0]
 
+    # The per-run re-evaluation of the model function only has to find the
+    # parameter tensors again, so it is given a META tensor for the latent:
+    # whatever the function computes from it before the lazy contraction
+    # (torch.softmax(eta, -1), lntm_mcem.py:39) is shape arithmetic, not a
+    # launch and not a [rows, K] temporary on the device.  A function that
+    # does more with the latent than that (mixes it with device tensors)
+    # fails on the meta tensor and is evaluated on the latent itself from
+    # then on.
+    q_meta = torch.empty_like(q, device='meta')
+    on_meta = [True]
+
     def probe():
-        f = analyse(q)
+        f = None
+        if on_meta[0]:
+            try:
+                f = analyse(q_meta)
+            except Exception:                            # noqa: BLE001
+                f = None
+            if f is None or f[0] != kind:
+                on_meta[0], f = False, None
+        if f is None:
+            f = analyse(q)
         if f is None or f[0] != kind:
             raise ValueError(
                 "HMC (native %s plan): the model changed structure between "
