@@ -396,6 +396,25 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
   if (wib == kWavesPerBlock - 1 && lane == 0)
     s_bad[2] = link_prepare(a.link, s_prep) ? 1 : 0;
 
+#ifdef ZS_PRIO_STAGGER
+  // A/B knob: static issue priorities by the wave's slot on its SIMD (waves
+  // of a workgroup are dealt round-robin to the 4 SIMDs: slot = wib >> 2).
+  // A high-priority wave runs its trip at nearly the full issue rate, so its
+  // row is written back sooner after it was read; the others fill its gaps.
+  // (tickets are drawn dynamically: the fast slots simply take more rows)
+  {
+    const int slot = __builtin_amdgcn_readfirstlane(wib >> 2);
+#if ZS_PRIO_STAGGER == 1
+    if (slot == 1) __builtin_amdgcn_s_setprio(1);
+    if (slot == 2) __builtin_amdgcn_s_setprio(2);
+    if (slot >= 3) __builtin_amdgcn_s_setprio(3);
+#elif ZS_PRIO_STAGGER == 2
+    if (slot == 0) __builtin_amdgcn_s_setprio(3);
+#else
+    if (slot < 2) __builtin_amdgcn_s_setprio(2);
+#endif
+  }
+#endif
   auto draw = [&]() -> int {  // next ticket of this workgroup (wave-uniform)
     int t = 0;
     if (lane == 0) t = atomicAdd(s_ticket, 1);
