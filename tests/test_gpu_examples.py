@@ -52,3 +52,13 @@ def test_pmf_example():
     tr = [float(l.split('rmse = ')[1]) for l in out.splitlines()
           if 'Train: rmse' in l]
     assert len(tr) == 5 and tr[-1] < 0.8 * tr[0]
+
+
+@pytest.mark.parametrize('sampler,bound', [('sghmc', 0.40), ('sgld', 0.46)])
+def test_bnn_sgmcmc_example(sampler, bound):
+    out = _run('examples/bayesian_nn_sgmcmc.py', '--small', '--sampler',
+               sampler)
+    rmse = [float(l.split('Test rmse = ')[1].split(',')[0])
+            for l in out.splitlines() if 'Test rmse' in l]
+    # teacher noise 0.3 (SGHMC reaches 0.36 in 8 short epochs, SGLD 0.41)
+    assert len(rmse) == 8 and rmse[-1] < rmse[0] and rmse[-1] < bound
