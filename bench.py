@@ -22,6 +22,7 @@ HBM before the timed region.  Prints ONE JSON line (see the task contract):
     python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -466,6 +467,16 @@ def main():
         sample_op.run(feed_dict=feed, sync=False)
     for _ in range(args.warmup):
         sample_op.run(feed_dict=feed, sync=False)
+    # The host is ~4x ahead of the device (0.025 ms per enqueue against a
+    # 0.095 ms kernel), but a full collection of CPython's cyclic GC over a
+    # process that has torch loaded stops it for ~40 ms -- 400 transitions'
+    # worth; tools/first_run_probe.py shows exactly one in the first few
+    # hundred runs of a process (the per-run model re-evaluation allocates
+    # containers).  Timed regions run with the collector parked, as timeit
+    # does.
+    gc.collect()
+    gc.freeze()
+    gc.disable()
     barrier()
     # HIP events on the launch stream around every 4th fused launch of the
     # timed region (two event records per launch cost ~3 us of stream time);
@@ -554,6 +565,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         other_elapsed = float(tt.item())
     hmc.set_state(saved)
+    gc.enable()
     other_mode = {
         'adaptation': 'off' if adapt_timed else 'on',
         'ms_per_step': other_elapsed / n_other * 1e3,
