@@ -229,11 +229,17 @@ def extra_config3(torch, zs, dev, n_rows=1000000, n_chains=32768, n_feat=256,
     10^6 x 256 design matrix, 32 768 chains, L = 10: native
     plan = fused fp32-MFMA likelihood + csrc/hmc_model.hip, step-size
     adaptation on."""
-    g = torch.Generator(device=dev).manual_seed(0)
-    X = torch.randn(n_rows, n_feat, device=dev, generator=g)
-    w_true = torch.randn(n_feat, device=dev, generator=g)
-    y = (torch.rand(n_rows, device=dev, generator=g) <
-         torch.sigmoid(X @ w_true / n_feat ** 0.5)).to(torch.float32)
+    # the data of SURVEY 8d c3: X ~ N(0,1), w* ~ N(0,1), y ~ Bernoulli(
+    # sigmoid(X w* / sqrt(D))) from numpy.random.default_rng(0)
+    rng = np.random.default_rng(0)
+    X_h = rng.standard_normal((n_rows, n_feat), dtype=np.float32)
+    w_h = rng.standard_normal(n_feat).astype(np.float32)
+    y_h = rng.random(n_rows) < 1.0 / (1.0 + np.exp(
+        -(X_h @ w_h) / np.float32(n_feat ** 0.5)))
+    X = torch.from_numpy(X_h).to(dev)
+    w_true = torch.from_numpy(w_h).to(dev)
+    y = torch.from_numpy(y_h.astype(np.float32)).to(dev)
+    del X_h, y_h
     zero, one = torch.zeros(n_feat, device=dev), torch.ones(n_feat, device=dev)
 
     @zs.meta_bayesian_net()
@@ -256,7 +262,8 @@ def extra_config3(torch, zs, dev, n_rows=1000000, n_chains=32768, n_feat=256,
     return {
         'workload': 'configs[2]: Bayesian logistic regression, synthetic '
                     '%d x %d, %d chains started at the data-generating '
-                    'weights, L=%d, adaptation on' % (
+                    'weights (SURVEY c3: "q0 = 0 or MAP + noise"), L=%d, '
+                    'adaptation on' % (
                         n_rows, n_feat, n_chains, n_leapfrogs),
         'plan': hmc.plan_kind,
         'ms_per_step': ms,
@@ -299,8 +306,15 @@ def extra_config5(torch, zs, dev, n_chains=None, n_docs=5000, n_topics=128,
     g = torch.Generator(device=dev).manual_seed(0)
     phi = torch.softmax(torch.randn(n_topics, n_vocab, device=dev,
                                     generator=g), -1)
-    x = torch.poisson(torch.full((n_docs, n_vocab), 1000.0 / n_vocab,
-                                 device=dev), generator=g)
+    # documents of ~1 000 tokens drawn from the mixture of a
+    # random phi (the "nips" file is not reachable offline)
+    doc_mix = torch.softmax(torch.randn(n_docs, n_topics, device=dev,
+                                        generator=g), -1)
+    words = torch.multinomial(doc_mix @ phi, 1000, replacement=True,
+                              generator=g)
+    x = torch.zeros(n_docs, n_vocab, device=dev).scatter_add_(
+        1, words, torch.ones(words.shape, device=dev))
+    del doc_mix, words
     eta_mean = torch.zeros(n_docs, n_topics, device=dev)
     eta_logstd = torch.zeros(n_topics, device=dev)
 
