@@ -85,7 +85,8 @@ class Normal(object):
 
 
 def _sigmoid(l):
-    return F32(1) / (F32(1) + np.exp(-l))
+    with np.errstate(over='ignore'):      # exp(-l) -> inf gives the limit 0
+        return F32(1) / (F32(1) + np.exp(-l))
 
 
 class Bernoulli(object):

@@ -1,0 +1,30 @@
+"""Inputs of the two model-family cases of tests/golden/hmc_reference_traces.npz
+(`blr`, `lntm`), shared by the generator that runs the reference's own code
+(oracle/make_golden_hmc.py) and the test-side restatements
+(tests/helpers_hmc_cases.py).  TEST INFRASTRUCTURE (oracle/__init__.py)."""
+import numpy as np
+
+
+def blr_data():
+    """Bayesian logistic regression (BASELINE configs[2] family), small."""
+    rng = np.random.RandomState(77)
+    n_rows, n_feat, n_chains = 40, 8, 12
+    X = rng.normal(size=(n_rows, n_feat)).astype(np.float32)
+    w_true = rng.normal(size=n_feat).astype(np.float32)
+    y = (rng.uniform(size=n_rows) < 1 / (1 + np.exp(-X @ w_true))).astype(
+        np.int32)
+    w0 = (0.1 * rng.normal(size=(n_chains, n_feat))).astype(np.float32)
+    return X, y, w0
+
+
+def lntm_data():
+    """Logistic-normal topic model (BASELINE configs[4] family), small."""
+    rng = np.random.RandomState(78)
+    n_chains, n_docs, n_topics, n_vocab = 3, 4, 8, 20
+    beta = rng.normal(size=(n_topics, n_vocab)).astype(np.float32)
+    x = rng.poisson(1.5, size=(n_docs, n_vocab)).astype(np.float32)
+    eta_mean = (0.3 * rng.normal(size=n_topics)).astype(np.float32)
+    eta_logstd = (0.2 * rng.normal(size=n_topics)).astype(np.float32)
+    eta0 = (0.5 * rng.normal(size=(n_chains, n_docs, n_topics))).astype(
+        np.float32)
+    return beta, x, eta_mean, eta_logstd, eta0

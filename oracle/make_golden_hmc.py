@@ -26,6 +26,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from oracle import philox, tf_shim  # noqa: E402
+from oracle.hmc_case_data import blr_data, lntm_data  # noqa: E402
 
 
 def _load(pkg, name):
@@ -55,14 +56,15 @@ def _subpackage(pkg, name, members):
 
 def load_reference():
     """The reference's own hmc.py, model layer (framework/{utils,meta_bn,bn}.py,
-    distributions/{utils,base,univariate}.py) and evaluation.py, unmodified,
+    distributions/{utils,base,univariate,multivariate}.py) and evaluation.py, unmodified,
     over the TensorFlow-API shim.  Returns (tf, zhusuan-like namespace)."""
     tf = tf_shim.install()
     pkg = types.ModuleType('zhusuan')
     pkg.__path__ = [os.path.join(REF, 'zhusuan')]
     sys.modules['zhusuan'] = pkg
     pkg.utils = _load(pkg, 'utils')
-    _subpackage(pkg, 'distributions', ['utils', 'base', 'univariate'])
+    _subpackage(pkg, 'distributions', ['utils', 'base', 'univariate',
+                                       'multivariate'])
     fw = _subpackage(pkg, 'framework', ['utils', 'meta_bn', 'bn'])
     pkg.hmc = _load(pkg, 'hmc')
     # evaluation.py imports one symbol of zhusuan.variational that only
@@ -107,7 +109,7 @@ class Stream(object):
 
 
 def run_case(tf, zs, name, make_log_joint, latents, hmc_kwargs, n_iters,
-             flags, seed, chain_shape):
+             flags, seed, chain_shape, make_observed=None):
     """flags(i) -> (adapt_step_size, adapt_mass) values fed at iteration i
     (None = the sampler was built without that adaptation)."""
     tf_shim._VARS[:] = []
@@ -122,6 +124,7 @@ def run_case(tf, zs, name, make_log_joint, latents, hmc_kwargs, n_iters,
                 for k, v in latents.items()}
     hmc = zs.hmc.HMC(**kw)
     log_joint = make_log_joint(tf, zs, int(np.prod(chain_shape)))
+    observed = {} if make_observed is None else make_observed(tf)
     stream = Stream(seed, chain_shape)
     tf_shim.set_random_source(stream.normal, stream.uniform)
     mark = tf_shim.variable_mark()
@@ -140,7 +143,7 @@ def run_case(tf, zs, name, make_log_joint, latents, hmc_kwargs, n_iters,
         stream.begin(i + 1)
         if i > 0:
             tf_shim.begin_run(mark)
-        _, info = hmc.sample(log_joint, {}, lat_vars)   # = one sess.run
+        _, info = hmc.sample(log_joint, observed, lat_vars)   # = one sess.run
         tf_shim.end_replay()
         acc = info.acceptance_rate.detach().numpy()
         out['acceptance_rate'].append(acc.copy())
@@ -199,6 +202,58 @@ def coupled_log_joint(prec_x):
                     - 0.5 * tf.reduce_sum(tf.square(y), axis=-1)
                     - 0.01 * tf.square(sx) * tf.square(sy))
         return log_joint
+    return make
+
+
+def blr_model(X):
+    """w ~ Normal(0, std=1) per chain, y ~ Bernoulli(logits = w X^T) with
+    group_ndims = 1, built with the reference's own bn.normal / bn.bernoulli
+    (bn.py:556-590,628-654 -> univariate.py:43-184,334-406) and tf.matmul."""
+    def make(tf, zs, n_chains):
+        @zs.meta_bayesian_net()
+        def blr():
+            bn = zs.BayesianNet()
+            w = bn.normal('w', tf.zeros([X.shape[1]]), std=1.,
+                          n_samples=n_chains, group_ndims=1)
+            logits = tf.matmul(w, tf.constant(X), transpose_b=True)
+            bn.bernoulli('y', logits, group_ndims=1)
+            return bn
+        return blr()
+    return make
+
+
+def lntm_model(eta_mean, eta_logstd, n_docs, n_topics, n_vocab):
+    """The model function of examples/topic_models/lntm_mcem.py:31-48,
+    statement for statement, with its E-step objective (:97-102) as the
+    log-joint -- through the reference's own bn.normal /
+    bn.unnormalized_multinomial (multivariate.py:339-446)."""
+    log_delta = 10.0
+
+    def make(tf, zs, n_chains_total):
+        n_chains = n_chains_total // n_docs
+
+        @zs.meta_bayesian_net(scope='lntm')
+        def lntm(n_chains, n_docs, n_topics, n_vocab, eta_mean, eta_logstd):
+            bn = zs.BayesianNet()
+            eta_mean = tf.tile(tf.expand_dims(eta_mean, 0), [n_docs, 1])
+            eta = bn.normal('eta', eta_mean, logstd=eta_logstd,
+                            n_samples=n_chains, group_ndims=1)
+            theta = tf.nn.softmax(eta)
+            beta = bn.normal('beta', tf.zeros([n_topics, n_vocab]),
+                             logstd=log_delta, group_ndims=1)
+            phi = tf.nn.softmax(beta)
+            doc_word = tf.matmul(tf.reshape(theta, [-1, n_topics]), phi)
+            doc_word = tf.reshape(doc_word, [n_chains, n_docs, n_vocab])
+            bn.unnormalized_multinomial('x', tf.log(doc_word),
+                                        normalize_logits=False,
+                                        dtype=tf.float32)
+            return bn
+
+        model = lntm(n_chains, n_docs, n_topics, n_vocab,
+                     tf.constant(eta_mean), tf.constant(eta_logstd))
+        model.log_joint = lambda bn: (bn.cond_log_prob('eta') +
+                                      bn.cond_log_prob('x'))
+        return model
     return make
 
 
@@ -265,6 +320,37 @@ def cases():
                         adapt_step_size='placeholder', adapt_mass='placeholder',
                         target_acceptance_rate=0.9),
         n_iters=30, flags=lambda i: (i < 15, i < 15), seed=1))
+    # F: Bayesian logistic regression through the reference's own model layer
+    # (configs[2] family): step-size adaptation on.  The observation is given
+    # with the full batch shape: distributions/utils.py:43-44 broadcasts with
+    # `x *= ones_like(y)`, which rebinds in TensorFlow but is an in-place
+    # (non-broadcasting) multiply on the shim's torch tensors.
+    X, y, w0 = blr_data()
+    out.append(dict(
+        name='blr', chain_shape=(w0.shape[0],),
+        make_log_joint=blr_model(X),
+        make_observed=lambda tf: {'y': tf.constant(
+            np.tile(y[None, :], (w0.shape[0], 1)))},
+        latents={'w': w0},
+        hmc_kwargs=dict(step_size=0.02, n_leapfrogs=6, adapt_step_size=True,
+                        target_acceptance_rate=0.8),
+        n_iters=10, flags=lambda i: (True, None), seed=15))
+    # G: the topic model of lntm_mcem.py with its E-step objective, chain axes
+    # [n_chains, n_docs], step-size and mass adaptation on (configs[4] family)
+    beta, x, eta_mean, eta_logstd, eta0 = lntm_data()
+    n_c, n_d, n_k = eta0.shape
+    out.append(dict(
+        name='lntm', chain_shape=(n_c, n_d),
+        make_log_joint=lntm_model(eta_mean, eta_logstd, n_d, n_k,
+                                  x.shape[1]),
+        make_observed=lambda tf: {
+            'x': tf.constant(np.tile(x[None], (n_c, 1, 1))),
+            'beta': tf.constant(beta)},
+        latents={'eta': eta0},
+        hmc_kwargs=dict(step_size=5e-3, n_leapfrogs=5,
+                        adapt_step_size='placeholder', adapt_mass='placeholder',
+                        target_acceptance_rate=0.6, mass_collect_iters=3),
+        n_iters=14, flags=lambda i: (i < 11, i < 9), seed=16))
     return out
 
 

@@ -592,6 +592,30 @@ def greater_equal(x, y, name=None): return _tt(x) >= _tt(y)
 def floordiv(x, y, name=None): return torch.floor_divide(_tt(x), _tt(y))
 
 
+def matmul(a, b, transpose_a=False, transpose_b=False, name=None):
+    a, b = _t(a), _t(b)
+    if transpose_a:
+        a = a.transpose(-1, -2)
+    if transpose_b:
+        b = b.transpose(-1, -2)
+    return a @ b
+
+
+def tile(x, multiples, name=None):
+    return _t(x).repeat(*[int(m) for m in _shape_list(multiples)])
+
+
+def _softmax(logits, axis=-1, name=None):
+    return torch.softmax(_t(logits), dim=axis)
+
+
+def _sigmoid_cross_entropy_with_logits(labels=None, logits=None, name=None):
+    # tf.nn.sigmoid_cross_entropy_with_logits:
+    # max(x, 0) - x * z + log(1 + exp(-abs(x)))
+    x, z = _t(logits), _t(labels)
+    return torch.clamp(x, min=0) - x * z + torch.log1p(torch.exp(-torch.abs(x)))
+
+
 def install():
     """Register this module as `tensorflow` (only if the real one is absent)."""
     mod = sys.modules[__name__]
@@ -616,5 +640,7 @@ def install():
     sys.modules['tensorflow.python.client.session'] = session
     nn = types.ModuleType('tensorflow.nn')
     nn.softplus = lambda x, name=None: torch.nn.functional.softplus(_t(x))
+    nn.softmax = _softmax
+    nn.sigmoid_cross_entropy_with_logits = _sigmoid_cross_entropy_with_logits
     mod.nn = nn
     return mod

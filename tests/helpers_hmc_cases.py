@@ -3,6 +3,9 @@ running the reference's own zhusuan/hmc.py, see oracle/make_golden_hmc.py),
 restated for the oracle (NumPy log-joint + analytic gradient)."""
 import numpy as np
 
+from oracle import distributions_ref as dref
+from oracle.hmc_case_data import blr_data, lntm_data
+
 F32 = np.float32
 
 
@@ -37,6 +40,58 @@ def coupled_model(prec_x):
         gx = -px * x - (F32(0.02) * sx * np.square(sy))[..., None]
         gy = -y - (F32(0.02) * np.square(sx) * sy)[..., None]
         return [gx.astype(F32), gy.astype(F32)]
+    return log_joint, grad
+
+
+def blr_model(X, y):
+    """w ~ Normal(0, std = 1) (group_ndims 1), y ~ Bernoulli(w X^T)
+    (group_ndims 1): log-joint and its gradient through the matmul."""
+    X = X.astype(F32)
+
+    def parts(w):
+        prior = dref.Normal(F32(0), std=F32(1), group_ndims=1)
+        lik = dref.Bernoulli((w @ X.T).astype(F32), group_ndims=1)
+        return prior, lik
+
+    def log_joint(qs):
+        prior, lik = parts(qs[0])
+        return (prior.log_prob(qs[0]) + lik.log_prob(y)).astype(F32)
+
+    def grad(qs):
+        prior, lik = parts(qs[0])
+        return [(prior.grad_given(qs[0]) +
+                 lik.grad_logits(y) @ X).astype(F32)]
+    return log_joint, grad
+
+
+def lntm_model(beta, x, eta_mean, eta_logstd):
+    """The E-step objective of lntm_mcem.py:97-102: log N(eta) +
+    sum_v x_v log(softmax(eta) . softmax(beta))_v, chain axes [chains, docs]."""
+    e = np.exp(beta - beta.max(-1, keepdims=True)).astype(F32)
+    phi = (e / e.sum(-1, keepdims=True)).astype(F32)
+
+    def softmax(eta):
+        t = np.exp(eta - eta.max(-1, keepdims=True)).astype(F32)
+        return (t / t.sum(-1, keepdims=True)).astype(F32)
+
+    def parts(eta):
+        theta = softmax(eta)
+        prior = dref.Normal(eta_mean, logstd=eta_logstd, group_ndims=1)
+        lik = dref.UnnormalizedMultinomial(
+            np.log(theta @ phi).astype(F32), normalize_logits=False,
+            dtype=np.float32)
+        return theta, prior, lik
+
+    def log_joint(qs):
+        _, prior, lik = parts(qs[0])
+        return (prior.log_prob(qs[0]) + lik.log_prob(x)).astype(F32)
+
+    def grad(qs):
+        theta, prior, lik = parts(qs[0])
+        # d/d logits = x; through log, the mixture and the softmax
+        g_theta = ((lik.grad_logits(x) / (theta @ phi)) @ phi.T).astype(F32)
+        g_eta = theta * (g_theta - (g_theta * theta).sum(-1, keepdims=True))
+        return [(prior.grad_given(qs[0]) + g_eta).astype(F32)]
     return log_joint, grad
 
 
@@ -85,3 +140,20 @@ def cases():
                                adapt_step_size=True, adapt_mass=True,
                                target_acceptance_rate=0.9),
                n_iters=30, flags=lambda i: (i < 15, i < 15), seed=1)
+    X, y, _ = blr_data()
+    yield dict(name='blr', latent_names=['w'], model=blr_model(X, y),
+               params=dict(X=X, y=y),
+               hmc_kwargs=dict(step_size=0.02, n_leapfrogs=6,
+                               adapt_step_size=True,
+                               target_acceptance_rate=0.8),
+               n_iters=10, flags=lambda i: (True, None), seed=15)
+    beta, x, eta_mean, eta_logstd, _ = lntm_data()
+    yield dict(name='lntm', latent_names=['eta'],
+               model=lntm_model(beta, x, eta_mean, eta_logstd),
+               params=dict(beta=beta, x=x, eta_mean=eta_mean,
+                           eta_logstd=eta_logstd),
+               hmc_kwargs=dict(step_size=5e-3, n_leapfrogs=5,
+                               adapt_step_size=True, adapt_mass=True,
+                               target_acceptance_rate=0.6,
+                               mass_collect_iters=3),
+               n_iters=14, flags=lambda i: (i < 11, i < 9), seed=16)

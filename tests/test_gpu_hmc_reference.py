@@ -22,8 +22,75 @@ def env():
     return zs, torch, torch.device('cuda', 0), traces
 
 
-def _build(zs, torch, dev, case, qs):
-    """The same model through the product's own front-end."""
+# how the two model-family cases are written on the device side: the fused
+# spelling on the native plan, the same spelling on the autograd-driven
+# generic plan, and the reference's literal dense expression
+VARIANTS = {'blr': ('native', 'generic', 'dense'),
+            'lntm': ('native', 'generic', 'dense')}
+
+
+def _build_blr(zs, torch, dev, case, qs, variant):
+    X = torch.tensor(case['params']['X'], device=dev)
+    y = torch.tensor(case['params']['y'], device=dev)        # int32
+    C, D = qs['w'].shape
+
+    @zs.meta_bayesian_net()
+    def model():
+        bn = zs.BayesianNet()
+        w = bn.normal('w', torch.zeros(D, device=dev), std=1., n_samples=C,
+                      group_ndims=1)
+        logits = w.tensor @ X.t() if variant == 'dense' else \
+            zs.linear_logits(w.tensor, X)
+        bn.bernoulli('y', logits, group_ndims=1)
+        return bn
+    plan = 'linear_bernoulli' if variant == 'native' else 'generic'
+    return model(), plan, {'y': y}
+
+
+def _build_lntm(zs, torch, dev, case, qs, variant):
+    """examples/topic_models/lntm_mcem.py:31-48 and its E-step objective
+    (:97-102), beta observed as there (:104-106)."""
+    p = {k: torch.tensor(v, device=dev) for k, v in case['params'].items()}
+    n_chains, n_docs, K = qs['eta'].shape
+    V = p['x'].shape[1]
+
+    @zs.meta_bayesian_net(scope='lntm')
+    def lntm():
+        bn = zs.BayesianNet()
+        eta = bn.normal('eta', p['eta_mean'].unsqueeze(0).repeat(n_docs, 1),
+                        logstd=p['eta_logstd'], n_samples=n_chains,
+                        group_ndims=1)
+        theta = torch.softmax(eta.tensor, -1)
+        beta = bn.normal('beta', torch.zeros(K, V, device=dev), logstd=10.0,
+                         group_ndims=1)
+        phi = torch.softmax(beta.tensor, -1)
+        if variant == 'dense':
+            logits = torch.log((theta.reshape(-1, K) @ phi).reshape(
+                n_chains, n_docs, V))
+        else:
+            logits = zs.log_mixture(theta, phi)
+        bn.unnormalized_multinomial('x', logits, normalize_logits=False,
+                                    dtype=torch.float32)
+        return bn
+    model = lntm()
+    model.log_joint = lambda bn: (bn.cond_log_prob('eta') +
+                                  bn.cond_log_prob('x'))
+    plan = 'mixture_multinomial' if variant == 'native' else 'generic'
+    return model, plan, {'x': p['x'], 'beta': p['beta']}
+
+
+def _build(zs, torch, dev, case, qs, variant=None):
+    """The same model through the product's own front-end:
+    (model, expected plan, observed)."""
+    name = case['name']
+    if name == 'blr':
+        return _build_blr(zs, torch, dev, case, qs, variant)
+    if name == 'lntm':
+        return _build_lntm(zs, torch, dev, case, qs, variant)
+    return _build_plain(zs, torch, dev, case, qs) + ({},)
+
+
+def _build_plain(zs, torch, dev, case, qs):
     name = case['name']
     if name.startswith('gauss'):
         mean = torch.tensor(case['params']['mean'], device=dev)
@@ -50,8 +117,15 @@ def _build(zs, torch, dev, case, qs):
     return log_joint, 'generic'
 
 
-@pytest.mark.parametrize('case', list(cases()), ids=lambda c: c['name'])
-def test_device_reproduces_reference_hmc_traces(env, case):
+def _case_variants():
+    for c in cases():
+        for v in VARIANTS.get(c['name'], (None,)):
+            yield pytest.param(c, v, id=c['name'] + ('' if v is None
+                                                     else '-' + v))
+
+
+@pytest.mark.parametrize('case,variant', list(_case_variants()))
+def test_device_reproduces_reference_hmc_traces(env, case, variant):
     zs, torch, dev, traces = env
     name = case['name']
     qs = {k: torch.tensor(traces['%s/q0_%s' % (name, k)], device=dev)
@@ -63,9 +137,11 @@ def test_device_reproduces_reference_hmc_traces(env, case):
         ph_ss = kw['adapt_step_size'] = zs.placeholder(bool)
     if kw.get('adapt_mass') is True:
         ph_m = kw['adapt_mass'] = zs.placeholder(bool)
+    if variant == 'generic':
+        kw['native_plans'] = False
     hmc = zs.HMC(seed=case['seed'], **kw)
-    model, plan = _build(zs, torch, dev, case, qs)
-    op, info = hmc.sample(model, {}, qs)
+    model, plan, observed = _build(zs, torch, dev, case, qs, variant)
+    op, info = hmc.sample(model, observed, qs)
     assert hmc.plan_kind == plan
     n_flip = n_total = 0
     for i in range(case['n_iters']):
