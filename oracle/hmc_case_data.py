@@ -28,3 +28,15 @@ def lntm_data():
     eta0 = (0.5 * rng.normal(size=(n_chains, n_docs, n_topics))).astype(
         np.float32)
     return beta, x, eta_mean, eta_logstd, eta0
+
+
+def softmax_regression_data():
+    """Multi-class logistic regression with a Categorical likelihood."""
+    rng = np.random.RandomState(79)
+    n_rows, n_feat, n_cat, n_chains = 30, 5, 4, 10
+    X = rng.normal(size=(n_rows, n_feat)).astype(np.float32)
+    w_true = rng.normal(size=(n_cat, n_feat)).astype(np.float32)
+    y = np.argmax(X @ w_true.T + rng.gumbel(size=(n_rows, n_cat)),
+                  axis=-1).astype(np.int32)
+    w0 = (0.1 * rng.normal(size=(n_chains, n_cat, n_feat))).astype(np.float32)
+    return X, y, w0

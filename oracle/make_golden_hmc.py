@@ -26,7 +26,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from oracle import philox, tf_shim  # noqa: E402
-from oracle.hmc_case_data import blr_data, lntm_data  # noqa: E402
+from oracle.hmc_case_data import (  # noqa: E402
+    blr_data, lntm_data, softmax_regression_data)
 
 
 def _load(pkg, name):
@@ -257,6 +258,24 @@ def lntm_model(eta_mean, eta_logstd, n_docs, n_topics, n_vocab):
     return make
 
 
+def softmax_regression_model(X, n_cat):
+    """w[n_cat, n_feat] ~ Normal(0, 1) (group_ndims = 2) per chain,
+    y ~ Categorical(logits[n, k] = <X[n], w[k]>), group_ndims = 1, through
+    the reference's bn.categorical (bn.py:656-682, univariate.py:409-551)."""
+    def make(tf, zs, n_chains):
+        @zs.meta_bayesian_net()
+        def softmax_regression():
+            bn = zs.BayesianNet()
+            w = bn.normal('w', tf.zeros([n_cat, X.shape[1]]), std=1.,
+                          n_samples=n_chains, group_ndims=2)
+            Xc = tf.tile(tf.expand_dims(tf.constant(X), 0), [n_chains, 1, 1])
+            logits = tf.matmul(Xc, w, transpose_b=True)     # [C, N, n_cat]
+            bn.categorical('y', logits, group_ndims=1)
+            return bn
+        return softmax_regression()
+    return make
+
+
 def cases():
     rng = np.random.RandomState(2024)
     out = []
@@ -351,6 +370,19 @@ def cases():
                         adapt_step_size='placeholder', adapt_mass='placeholder',
                         target_acceptance_rate=0.6, mass_collect_iters=3),
         n_iters=14, flags=lambda i: (i < 11, i < 9), seed=16))
+    # H: a Categorical likelihood (multi-class logistic regression), the third
+    # family north_star names; labels given with the full batch shape for the
+    # same reason as in F (univariate.py:505-506 `given *= ones_`)
+    Xs, ys, ws0 = softmax_regression_data()
+    out.append(dict(
+        name='softmax_reg', chain_shape=(ws0.shape[0],),
+        make_log_joint=softmax_regression_model(Xs, ws0.shape[1]),
+        make_observed=lambda tf: {'y': tf.constant(
+            np.tile(ys[None, :], (ws0.shape[0], 1)))},
+        latents={'w': ws0},
+        hmc_kwargs=dict(step_size=0.03, n_leapfrogs=5, adapt_step_size=True,
+                        target_acceptance_rate=0.8),
+        n_iters=8, flags=lambda i: (True, None), seed=17))
     return out
 
 

@@ -616,6 +616,13 @@ def _sigmoid_cross_entropy_with_logits(labels=None, logits=None, name=None):
     return torch.clamp(x, min=0) - x * z + torch.log1p(torch.exp(-torch.abs(x)))
 
 
+def _sparse_softmax_cross_entropy_with_logits(labels=None, logits=None,
+                                             name=None):
+    # logsumexp(logits) - logits[label]
+    x, k = _t(logits), _t(labels).to(torch.int64)
+    return torch.logsumexp(x, dim=-1) - x.gather(-1, k.unsqueeze(-1)).squeeze(-1)
+
+
 def install():
     """Register this module as `tensorflow` (only if the real one is absent)."""
     mod = sys.modules[__name__]
@@ -642,5 +649,7 @@ def install():
     nn.softplus = lambda x, name=None: torch.nn.functional.softplus(_t(x))
     nn.softmax = _softmax
     nn.sigmoid_cross_entropy_with_logits = _sigmoid_cross_entropy_with_logits
+    nn.sparse_softmax_cross_entropy_with_logits = \
+        _sparse_softmax_cross_entropy_with_logits
     mod.nn = nn
     return mod

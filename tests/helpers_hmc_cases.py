@@ -4,7 +4,8 @@ restated for the oracle (NumPy log-joint + analytic gradient)."""
 import numpy as np
 
 from oracle import distributions_ref as dref
-from oracle.hmc_case_data import blr_data, lntm_data
+from oracle.hmc_case_data import (blr_data, lntm_data,
+                                  softmax_regression_data)
 
 F32 = np.float32
 
@@ -95,6 +96,28 @@ def lntm_model(beta, x, eta_mean, eta_logstd):
     return log_joint, grad
 
 
+def softmax_regression_model(X, y):
+    """w[k, f] ~ Normal(0, 1) (group_ndims 2), y ~ Categorical(logits[n, k] =
+    <X[n], w[k]>) (group_ndims 1)."""
+    X = X.astype(F32)
+
+    def parts(w):
+        prior = dref.Normal(F32(0), std=F32(1), group_ndims=2)
+        logits = np.einsum('nf,ckf->cnk', X, w).astype(F32)
+        return prior, dref.Categorical(logits, group_ndims=1)
+
+    def log_joint(qs):
+        prior, lik = parts(qs[0])
+        return (prior.log_prob(qs[0]) + lik.log_prob(y)).astype(F32)
+
+    def grad(qs):
+        prior, lik = parts(qs[0])
+        g_logits = lik.grad_logits(y)                       # [C, N, K]
+        return [(prior.grad_given(qs[0]) +
+                 np.einsum('cnk,nf->ckf', g_logits, X)).astype(F32)]
+    return log_joint, grad
+
+
 def cases():
     D = 10
     stdev = (1.0 / (np.arange(D) + 1)).astype(F32)
@@ -157,3 +180,11 @@ def cases():
                                target_acceptance_rate=0.6,
                                mass_collect_iters=3),
                n_iters=14, flags=lambda i: (i < 11, i < 9), seed=16)
+    Xs, ys, _ = softmax_regression_data()
+    yield dict(name='softmax_reg', latent_names=['w'],
+               model=softmax_regression_model(Xs, ys),
+               params=dict(X=Xs, y=ys),
+               hmc_kwargs=dict(step_size=0.03, n_leapfrogs=5,
+                               adapt_step_size=True,
+                               target_acceptance_rate=0.8),
+               n_iters=8, flags=lambda i: (True, None), seed=17)

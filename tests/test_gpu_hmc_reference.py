@@ -79,6 +79,22 @@ def _build_lntm(zs, torch, dev, case, qs, variant):
     return model, plan, {'x': p['x'], 'beta': p['beta']}
 
 
+def _build_softmax_regression(zs, torch, dev, case, qs):
+    X = torch.tensor(case['params']['X'], device=dev)
+    y = torch.tensor(case['params']['y'], device=dev)        # int32 labels
+    C, K, F = qs['w'].shape
+
+    @zs.meta_bayesian_net()
+    def model():
+        bn = zs.BayesianNet()
+        w = bn.normal('w', torch.zeros(K, F, device=dev), std=1., n_samples=C,
+                      group_ndims=2)
+        logits = X.unsqueeze(0) @ w.tensor.transpose(-1, -2)  # [C, N, K]
+        bn.categorical('y', logits, group_ndims=1)
+        return bn
+    return model(), 'generic', {'y': y}
+
+
 def _build(zs, torch, dev, case, qs, variant=None):
     """The same model through the product's own front-end:
     (model, expected plan, observed)."""
@@ -87,6 +103,8 @@ def _build(zs, torch, dev, case, qs, variant=None):
         return _build_blr(zs, torch, dev, case, qs, variant)
     if name == 'lntm':
         return _build_lntm(zs, torch, dev, case, qs, variant)
+    if name == 'softmax_reg':
+        return _build_softmax_regression(zs, torch, dev, case, qs)
     return _build_plain(zs, torch, dev, case, qs) + ({},)
 
 
