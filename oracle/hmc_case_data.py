@@ -40,3 +40,19 @@ def softmax_regression_data():
                   axis=-1).astype(np.int32)
     w0 = (0.1 * rng.normal(size=(n_chains, n_cat, n_feat))).astype(np.float32)
     return X, y, w0
+
+
+def pmf_data():
+    """The rating model of pmf_hmc.py, small: 6 particles, 7 users x 5 items,
+    4 factors, 20 observed (user, item) pairs with ratings in [0, 1]."""
+    rng = np.random.RandomState(80)
+    n_particles, n_users, n_items, n_factors, n_pairs = 6, 7, 5, 4, 20
+    su = rng.randint(0, n_users, size=n_pairs).astype(np.int32)
+    sv = rng.randint(0, n_items, size=n_pairs).astype(np.int32)
+    r = rng.uniform(size=n_pairs).astype(np.float32)
+    v_obs = (0.5 * rng.normal(size=(n_particles, n_items, n_factors))).astype(
+        np.float32)
+    u0 = (0.1 * rng.normal(size=(n_particles, n_users, n_factors))).astype(
+        np.float32)
+    alphas = (1.0, 1.0, 0.2)        # alpha_u, alpha_v, alpha_pred (std)
+    return su, sv, r, v_obs, u0, alphas

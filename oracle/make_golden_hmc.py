@@ -27,7 +27,7 @@ if ROOT not in sys.path:
 
 from oracle import philox, tf_shim  # noqa: E402
 from oracle.hmc_case_data import (  # noqa: E402
-    blr_data, lntm_data, softmax_regression_data)
+    blr_data, lntm_data, pmf_data, softmax_regression_data)
 
 
 def _load(pkg, name):
@@ -78,6 +78,36 @@ def load_reference():
     pkg.BayesianNet = fw.BayesianNet
     pkg.meta_bayesian_net = fw.meta_bayesian_net
     return tf, pkg
+
+
+def load_reference_example(rel_path):
+    """A module of the reference's examples/ (e.g.
+    'topic_models/lntm_mcem.py'), unmodified, for its MODEL FUNCTION: the
+    scripts keep their training loops under `if __name__ == '__main__'` / in
+    main().  `examples.utils` (tensorflow.contrib, progressbar, data-set
+    downloaders -- none of it on the sampling path, none of it importable
+    here) is replaced by an empty namespace; `examples.conf` is the
+    reference's.  Call load_reference() first."""
+    if 'examples' not in sys.modules:
+        ex = types.ModuleType('examples')
+        ex.__path__ = [os.path.join(REF, 'examples')]
+        sys.modules['examples'] = ex
+        spec = importlib.util.spec_from_file_location(
+            'examples.conf', os.path.join(REF, 'examples', 'conf.py'))
+        conf = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(conf)
+        sys.modules['examples.conf'] = ex.conf = conf
+        utils = types.ModuleType('examples.utils')
+        utils.dataset = types.ModuleType('examples.utils.dataset')
+        utils.average_rmse_over_batches = None
+        sys.modules['examples.utils'] = ex.utils = utils
+        sys.modules['examples.utils.dataset'] = utils.dataset
+    name = 'examples.' + rel_path[:-3].replace('/', '.')
+    spec = importlib.util.spec_from_file_location(
+        name, os.path.join(REF, 'examples', rel_path))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
 
 
 def load_reference_hmc():
@@ -224,36 +254,43 @@ def blr_model(X):
 
 
 def lntm_model(eta_mean, eta_logstd, n_docs, n_topics, n_vocab):
-    """The model function of examples/topic_models/lntm_mcem.py:31-48,
-    statement for statement, with its E-step objective (:97-102) as the
-    log-joint -- through the reference's own bn.normal /
-    bn.unnormalized_multinomial (multivariate.py:339-446)."""
-    log_delta = 10.0
-
+    """The reference's OWN model function -- `lntm` of
+    examples/topic_models/lntm_mcem.py:31-48, imported from the unmodified
+    file -- with the E-step objective of :97-102 (two lines inside the
+    script's __main__ block, restated) as the log-joint: bn.normal /
+    bn.unnormalized_multinomial (multivariate.py:339-446), tf.nn.softmax,
+    tf.matmul, tf.log."""
     def make(tf, zs, n_chains_total):
-        n_chains = n_chains_total // n_docs
-
-        @zs.meta_bayesian_net(scope='lntm')
-        def lntm(n_chains, n_docs, n_topics, n_vocab, eta_mean, eta_logstd):
-            bn = zs.BayesianNet()
-            eta_mean = tf.tile(tf.expand_dims(eta_mean, 0), [n_docs, 1])
-            eta = bn.normal('eta', eta_mean, logstd=eta_logstd,
-                            n_samples=n_chains, group_ndims=1)
-            theta = tf.nn.softmax(eta)
-            beta = bn.normal('beta', tf.zeros([n_topics, n_vocab]),
-                             logstd=log_delta, group_ndims=1)
-            phi = tf.nn.softmax(beta)
-            doc_word = tf.matmul(tf.reshape(theta, [-1, n_topics]), phi)
-            doc_word = tf.reshape(doc_word, [n_chains, n_docs, n_vocab])
-            bn.unnormalized_multinomial('x', tf.log(doc_word),
-                                        normalize_logits=False,
-                                        dtype=tf.float32)
-            return bn
-
-        model = lntm(n_chains, n_docs, n_topics, n_vocab,
-                     tf.constant(eta_mean), tf.constant(eta_logstd))
+        example = load_reference_example('topic_models/lntm_mcem.py')
+        model = example.lntm(n_chains_total // n_docs, n_docs, n_topics,
+                             n_vocab, tf.constant(eta_mean),
+                             tf.constant(eta_logstd))
         model.log_joint = lambda bn: (bn.cond_log_prob('eta') +
                                       bn.cond_log_prob('x'))
+        return model
+    return make
+
+
+def pmf_model(n_users, n_items, n_factors, select_u, select_v, alphas):
+    """The reference's OWN `pmf` model function
+    (examples/probabilistic_matrix_factorization/pmf_hmc.py:19-31, imported
+    from the unmodified file: two tf.gather, multiply, reduce_sum, sigmoid,
+    Normal rating likelihood) with the log-joint of :135-141 (inside the
+    script's main(), restated)."""
+    def make(tf, zs, n_particles):
+        example = load_reference_example(
+            'probabilistic_matrix_factorization/pmf_hmc.py')
+        model = example.pmf(n_users, n_items, n_factors, n_particles,
+                            tf.constant(select_u), tf.constant(select_v),
+                            *alphas)
+
+        def log_joint(bn):
+            log_pu, log_pv = bn.cond_log_prob(['u', 'v'])
+            log_pr = bn.cond_log_prob('r')
+            return (tf.reduce_sum(log_pu, axis=-1) +
+                    tf.reduce_sum(log_pv, axis=-1) +
+                    tf.reduce_sum(log_pr, axis=-1))
+        model.log_joint = log_joint
         return model
     return make
 
@@ -383,6 +420,19 @@ def cases():
         hmc_kwargs=dict(step_size=0.03, n_leapfrogs=5, adapt_step_size=True,
                         target_acceptance_rate=0.8),
         n_iters=8, flags=lambda i: (True, None), seed=17))
+    # I: the rating model of pmf_hmc.py -- HMC over the user factors with the
+    # item factors and ratings observed (one chunk update of pmf_hmc.py:145-148),
+    # no adaptation, as there (:119-122)
+    su, sv, r, v_obs, u0, alphas = pmf_data()
+    out.append(dict(
+        name='pmf', chain_shape=(u0.shape[0],),
+        make_log_joint=pmf_model(u0.shape[1], v_obs.shape[1], u0.shape[2],
+                                 su, sv, alphas),
+        make_observed=lambda tf: {'r': tf.constant(r),
+                                  'v': tf.constant(v_obs)},
+        latents={'u': u0},
+        hmc_kwargs=dict(step_size=0.4, n_leapfrogs=6),
+        n_iters=6, flags=lambda i: (None, None), seed=18))
     return out
 
 

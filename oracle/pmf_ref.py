@@ -12,9 +12,14 @@ Follows, in /root/reference:
 tf.gather / tf.gradients (unsorted segment sum) are TensorFlow's; restated as
 NumPy fancy indexing and np.add.at.
 
-Pinning: the example ships no test and no golden output, and its data set
-(MovieLens-1M) is not available offline; the closed form above is checked in
-float64 against torch autograd in tests/test_gpu_gather_dot.py."""
+Pinning (round 2): the example ships no test, no golden output and its data
+set (MovieLens-1M) is not available offline, but its MODEL FUNCTION runs: the
+`pmf` of the unmodified pmf_hmc.py, imported by oracle/make_golden_hmc.py and
+sampled by the reference's own hmc.py over oracle/tf_shim.py, produced case
+`pmf` of tests/golden/hmc_reference_traces.npz, which this restatement
+reproduces under oracle/hmc_ref.py (tests/test_oracle_hmc_reference.py[pmf]).
+The closed form is also checked in float64 against torch autograd in
+tests/test_gpu_gather_dot.py."""
 import numpy as np
 
 F32 = np.float32

@@ -439,12 +439,12 @@ def _shape_list(s):
     return [int(v) for v in s]
 
 
-def zeros(s, dtype=torch.float32, name=None):
-    return torch.zeros(_shape_list(s), dtype=dtype)
+def zeros(shape=None, dtype=torch.float32, name=None):
+    return torch.zeros(_shape_list(shape), dtype=dtype)
 
 
-def ones(s, dtype=torch.float32, name=None):
-    return torch.ones(_shape_list(s), dtype=dtype)
+def ones(shape=None, dtype=torch.float32, name=None):
+    return torch.ones(_shape_list(shape), dtype=dtype)
 
 
 def zeros_like(x, dtype=None, name=None):
@@ -614,6 +614,13 @@ def _sigmoid_cross_entropy_with_logits(labels=None, logits=None, name=None):
     # max(x, 0) - x * z + log(1 + exp(-abs(x)))
     x, z = _t(logits), _t(labels)
     return torch.clamp(x, min=0) - x * z + torch.log1p(torch.exp(-torch.abs(x)))
+
+
+def gather(params, indices, axis=0, name=None, **kw):
+    idx = _t(indices).to(torch.int64)
+    return torch.index_select(_t(params), int(axis), idx.reshape(-1)).reshape(
+        tuple(_t(params).shape[:int(axis)]) + tuple(idx.shape) +
+        tuple(_t(params).shape[int(axis) + 1:]))
 
 
 def _sparse_softmax_cross_entropy_with_logits(labels=None, logits=None,

@@ -4,7 +4,8 @@ restated for the oracle (NumPy log-joint + analytic gradient)."""
 import numpy as np
 
 from oracle import distributions_ref as dref
-from oracle.hmc_case_data import (blr_data, lntm_data,
+from oracle import pmf_ref
+from oracle.hmc_case_data import (blr_data, lntm_data, pmf_data,
                                   softmax_regression_data)
 
 F32 = np.float32
@@ -118,6 +119,17 @@ def softmax_regression_model(X, y):
     return log_joint, grad
 
 
+def pmf_model(su, sv, r, v_obs, alphas):
+    """pmf_hmc.py:19-31,135-141 with the item factors observed: HMC over the
+    user factors u[particles, users, factors]."""
+    def log_joint(qs):
+        return pmf_ref.log_joint(qs[0], v_obs, su, sv, r, *alphas)
+
+    def grad(qs):
+        return [pmf_ref.grad_log_joint(qs[0], v_obs, su, sv, r, *alphas)[0]]
+    return log_joint, grad
+
+
 def cases():
     D = 10
     stdev = (1.0 / (np.arange(D) + 1)).astype(F32)
@@ -188,3 +200,9 @@ def cases():
                                adapt_step_size=True,
                                target_acceptance_rate=0.8),
                n_iters=8, flags=lambda i: (True, None), seed=17)
+    su, sv, r, v_obs, _, alphas = pmf_data()
+    yield dict(name='pmf', latent_names=['u'],
+               model=pmf_model(su, sv, r, v_obs, alphas),
+               params=dict(su=su, sv=sv, r=r, v=v_obs),
+               hmc_kwargs=dict(step_size=0.4, n_leapfrogs=6),
+               n_iters=6, flags=lambda i: (None, None), seed=18)

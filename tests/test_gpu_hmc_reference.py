@@ -26,7 +26,8 @@ def env():
 # spelling on the native plan, the same spelling on the autograd-driven
 # generic plan, and the reference's literal dense expression
 VARIANTS = {'blr': ('native', 'generic', 'dense'),
-            'lntm': ('native', 'generic', 'dense')}
+            'lntm': ('native', 'generic', 'dense'),
+            'pmf': ('fused', 'dense')}
 
 
 def _build_blr(zs, torch, dev, case, qs, variant):
@@ -95,6 +96,39 @@ def _build_softmax_regression(zs, torch, dev, case, qs):
     return model(), 'generic', {'y': y}
 
 
+def _build_pmf(zs, torch, dev, case, qs, variant):
+    """pmf_hmc.py:19-31 and its log-joint (:135-141); `fused` spells the
+    logits zs.gathered_dot, `dense` the reference's two gathers."""
+    from oracle.hmc_case_data import pmf_data
+    alpha_u, alpha_v, alpha_pred = pmf_data()[5]
+    p = {k: torch.tensor(v, device=dev) for k, v in case['params'].items()}
+    K, n, D = qs['u'].shape
+    m = p['v'].shape[1]
+    su, sv = p['su'].long(), p['sv'].long()
+
+    @zs.meta_bayesian_net(scope='pmf', reuse_variables=True)
+    def pmf():
+        bn = zs.BayesianNet()
+        u = bn.normal('u', torch.zeros(n, D, device=dev), std=alpha_u,
+                      n_samples=K, group_ndims=1)
+        v = bn.normal('v', torch.zeros(m, D, device=dev), std=alpha_v,
+                      n_samples=K, group_ndims=1)
+        if variant == 'dense':
+            r_logits = (u.tensor[:, su] * v.tensor[:, sv]).sum(2)
+        else:
+            r_logits = zs.gathered_dot(u, p['su'], v, p['sv'])
+        bn.deterministic('r_pred', torch.sigmoid(r_logits))
+        bn.normal('r', torch.sigmoid(r_logits), std=alpha_pred)
+        return bn
+    model = pmf()
+
+    def log_joint(bn):
+        log_pu, log_pv = bn.cond_log_prob(['u', 'v'])
+        return log_pu.sum(-1) + log_pv.sum(-1) + bn.cond_log_prob('r').sum(-1)
+    model.log_joint = log_joint
+    return model, 'generic', {'r': p['r'], 'v': p['v']}
+
+
 def _build(zs, torch, dev, case, qs, variant=None):
     """The same model through the product's own front-end:
     (model, expected plan, observed)."""
@@ -103,6 +137,8 @@ def _build(zs, torch, dev, case, qs, variant=None):
         return _build_blr(zs, torch, dev, case, qs, variant)
     if name == 'lntm':
         return _build_lntm(zs, torch, dev, case, qs, variant)
+    if name == 'pmf':
+        return _build_pmf(zs, torch, dev, case, qs, variant)
     if name == 'softmax_reg':
         return _build_softmax_regression(zs, torch, dev, case, qs)
     return _build_plain(zs, torch, dev, case, qs) + ({},)
