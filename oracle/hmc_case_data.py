@@ -56,3 +56,19 @@ def pmf_data():
         np.float32)
     alphas = (1.0, 1.0, 0.2)        # alpha_u, alpha_v, alpha_pred (std)
     return su, sv, r, v_obs, u0, alphas
+
+
+def bnn_data():
+    """Bayesian-neural-network regression (bnn_sgmcmc.py), small: 6 particles,
+    a [5, 10, 1] network, one mini-batch of 16 rows of a 100-row train set."""
+    rng = np.random.RandomState(81)
+    n_particles, layer_sizes, batch, n_train = 6, [5, 10, 1], 16, 100
+    x = rng.normal(size=(batch, layer_sizes[0])).astype(np.float32)
+    y = rng.normal(size=batch).astype(np.float32)
+    ws0, logstds = [], []
+    for n_in, n_out in zip(layer_sizes[:-1], layer_sizes[1:]):
+        ws0.append(rng.uniform(-2, 2, size=(n_particles, n_out, n_in + 1))
+                   .astype(np.float32))
+        logstds.append((0.1 * rng.normal(size=(n_out, n_in + 1))).astype(
+            np.float32))
+    return x, y, ws0, logstds, layer_sizes, n_train

@@ -154,5 +154,73 @@ def main():
     print('wrote', path, '(%d arrays)' % len(res))
 
 
+BNN_CASES = [
+    ('bnn_sghmc2', 'SGHMC', dict(learning_rate=2e-4, friction=0.2,
+                                 n_iter_resample_v=4, second_order=True)),
+    ('bnn_sgld', 'SGLD', dict(learning_rate=1e-4)),
+    ('bnn_sgnht', 'SGNHT', dict(learning_rate=2e-4, variance_extra=0.,
+                                tune_rate=50., second_order=True)),
+]
+BNN_SEED, BNN_ITERS = 43, 6
+
+
+def main_bnn():
+    """The reference's own sgmcmc.py sampling the reference's own model
+    function -- build_bnn of examples/bayesian_neural_nets/bnn_sgmcmc.py:19-35,
+    imported from the unmodified file -- with the log-joint of :71-76 (inside
+    the script's main(), restated).  Several latents of different shapes,
+    group_ndims = 2 priors, a deterministic node, mini-batch rescaling."""
+    from oracle.hmc_case_data import bnn_data
+    from oracle.make_golden_hmc import load_reference, load_reference_example, _load
+    tf, pkg = load_reference()
+    ref = _load(pkg, 'sgmcmc')
+    example = load_reference_example('bayesian_neural_nets/bnn_sgmcmc.py')
+    x, y, ws0, logstds, layer_sizes, n_train = bnn_data()
+    names = ['w%d' % i for i in range(len(ws0))]
+    res = {}
+    for name, cls, kw in BNN_CASES:
+        tf_shim._VARS[:] = []
+        tf_shim.end_replay()
+        lat = {n: tf.Variable(w.copy(), name=n) for n, w in zip(names, ws0)}
+        model = example.build_bnn(tf.constant(x), layer_sizes,
+                                  [tf.constant(l) for l in logstds],
+                                  ws0[0].shape[0])
+
+        def log_joint(bn):
+            log_pws = bn.cond_log_prob(names)
+            log_py_xw = bn.cond_log_prob('y')
+            return tf.add_n(log_pws) + tf.reduce_mean(log_py_xw, 1) * n_train
+        model.log_joint = log_joint
+        sampler = getattr(ref, cls)(**kw)
+        has_mom = cls in ('SGHMC', 'SGNHT')
+        stream = Stream(BNN_SEED, len(names), has_mom,
+                        int(kw.get('n_iter_resample_v') or 0))
+        tf_shim.set_random_source(stream.normal, stream.uniform)
+        mark = tf_shim.variable_mark()
+        tr = {}
+        for i in range(BNN_ITERS):
+            stream.begin(i)
+            if i > 0:
+                tf_shim.begin_run(mark)
+            _, info = sampler.sample(model, {'y': tf.constant(y)}, lat)
+            tf_shim.end_replay()
+            for n in names:
+                tr.setdefault(n, []).append(lat[n].numpy())
+                for f in ('mean_k', 'alpha'):
+                    if hasattr(info, f):
+                        tr.setdefault('%s_%s' % (f, n), []).append(np.asarray(
+                            tf_shim._t(getattr(info, f)[n]).detach().numpy(),
+                            np.float32).copy())
+        for k, v in tr.items():
+            res['%s/%s' % (name, k)] = np.stack(v)
+        print('%-10s %s ok, |w0| %.3f' % (
+            name, cls, float(np.abs(tr['w0'][-1]).mean())))
+    path = os.path.join(ROOT, 'tests', 'golden',
+                        'sgmcmc_bnn_reference_traces.npz')
+    np.savez_compressed(path, **res)
+    print('wrote', path, '(%d arrays)' % len(res))
+
+
 if __name__ == '__main__':
     main()
+    main_bnn()

@@ -301,7 +301,10 @@ def constant(value, dtype=None, name=None, shape=None):
 
 
 def cast(x, dtype, name=None):
-    return _t(x).to(dtype)
+    x = _t(x)
+    if not isinstance(x, torch.Tensor):      # a Python number (tf.shape(h)[2])
+        return torch.tensor(x, dtype=dtype)
+    return x.to(dtype)
 
 
 def identity(x, name=None):
@@ -616,6 +619,10 @@ def _sigmoid_cross_entropy_with_logits(labels=None, logits=None, name=None):
     return torch.clamp(x, min=0) - x * z + torch.log1p(torch.exp(-torch.abs(x)))
 
 
+def einsum(equation, *inputs, **kw):
+    return torch.einsum(equation, *[_t(x) for x in inputs])
+
+
 def gather(params, indices, axis=0, name=None, **kw):
     idx = _t(indices).to(torch.int64)
     return torch.index_select(_t(params), int(axis), idx.reshape(-1)).reshape(
@@ -655,6 +662,7 @@ def install():
     nn = types.ModuleType('tensorflow.nn')
     nn.softplus = lambda x, name=None: torch.nn.functional.softplus(_t(x))
     nn.softmax = _softmax
+    nn.relu = lambda x, name=None: torch.relu(_t(x))
     nn.sigmoid_cross_entropy_with_logits = _sigmoid_cross_entropy_with_logits
     nn.sparse_softmax_cross_entropy_with_logits = \
         _sparse_softmax_cross_entropy_with_logits

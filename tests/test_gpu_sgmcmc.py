@@ -230,3 +230,51 @@ def test_reference_traces(env):
                             getattr(info, f)[nm].cpu().numpy(),
                             tr['%s/%s_%s' % (name, f, nm)][i], rtol=2e-4,
                             atol=1e-6, err_msg='%s %s it %d' % (name, f, i))
+
+
+def test_reference_bnn_traces(env):
+    """The device path -- the model function of examples/bayesian_nn_sgmcmc.py
+    (several latents of different shapes, group_ndims = 2 priors, deterministic
+    node, user log-joint with mini-batch rescaling) under SGHMC / SGLD / SGNHT
+    -- against traces of the reference's OWN sgmcmc.py sampling the
+    reference's OWN build_bnn (oracle/make_golden_sgmcmc.py::main_bnn)."""
+    import importlib.util
+    import os
+    from oracle.hmc_case_data import bnn_data
+    from test_oracle_sgmcmc_reference import BNN_CASES, BNN_SEED
+    zs, torch, dev = env
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location(
+        'bayesian_nn_sgmcmc', os.path.join(root, 'examples',
+                                           'bayesian_nn_sgmcmc.py'))
+    example = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(example)
+    tr = np.load(os.path.join(root, 'tests', 'golden',
+                              'sgmcmc_bnn_reference_traces.npz'))
+    x, y, ws0, logstds, layer_sizes, n_train = bnn_data()
+    names = ['w%d' % i for i in range(len(ws0))]
+    x_in = zs.placeholder(torch.float32, name='x')
+    x_in.feed(x, dev)
+    y_d = torch.tensor(y, device=dev)
+    for name, cls, kw in BNN_CASES:
+        ws = [torch.tensor(w, device=dev) for w in ws0]
+        model = example.make_model(
+            x_in, layer_sizes, [torch.tensor(l, device=dev) for l in logstds],
+            ws0[0].shape[0])
+        model.log_joint = lambda bn: (sum(bn.cond_log_prob(names)) +
+                                      bn.cond_log_prob('y').mean(1) * n_train)
+        sampler = getattr(zs, cls)(seed=BNN_SEED, **kw)
+        op, info = sampler.sample(model, {'y': y_d}, dict(zip(names, ws)))
+        for i in range(tr[name + '/w0'].shape[0]):
+            op.run()
+            for k, nm in enumerate(names):
+                np.testing.assert_allclose(
+                    ws[k].cpu().numpy(), tr['%s/%s' % (name, nm)][i],
+                    rtol=1e-4, atol=1e-4, err_msg='%s %s it %d' % (name, nm, i))
+                for f in ('mean_k', 'alpha'):
+                    key = '%s/%s_%s' % (name, f, nm)
+                    if key in tr.files:
+                        np.testing.assert_allclose(
+                            getattr(info, f)[nm].cpu().numpy(), tr[key][i],
+                            rtol=1e-3, atol=1e-6,
+                            err_msg='%s %s %s it %d' % (name, f, nm, i))
