@@ -102,6 +102,13 @@ def load_reference_example(rel_path):
         utils.average_rmse_over_batches = None
         sys.modules['examples.utils'] = ex.utils = utils
         sys.modules['examples.utils.dataset'] = utils.dataset
+    try:
+        import matplotlib.pyplot  # noqa: F401  (gaussian.py plots in __main__)
+    except ImportError:
+        mpl = types.ModuleType('matplotlib')
+        mpl.pyplot = types.ModuleType('matplotlib.pyplot')
+        sys.modules.setdefault('matplotlib', mpl)
+        sys.modules.setdefault('matplotlib.pyplot', mpl.pyplot)
     name = 'examples.' + rel_path[:-3].replace('/', '.')
     spec = importlib.util.spec_from_file_location(
         name, os.path.join(REF, 'examples', rel_path))
@@ -362,15 +369,17 @@ def cases():
                         adapt_step_size='placeholder', adapt_mass='placeholder',
                         target_acceptance_rate=0.8, mass_collect_iters=4),
         n_iters=26, flags=lambda i: (i < 22, i < 18), seed=14))
-    # E: examples/toy_examples/gaussian.py literally (:15-20, :27-58 with
-    # n_x = 10): mean tf.zeros, `std=` constructor path (log(std) inside
+    # E: examples/toy_examples/gaussian.py: ITS OWN model function `gaussian`
+    # (:15-20, imported from the unmodified file) driven as :27-58 does with
+    # n_x = 10: mean tf.zeros, `std=` constructor path (log(std) inside
     # Normal, univariate.py:96-103), q0 = 0, eps0 = 1e-3, L = 5, delta = 0.9,
     # both adaptations on for the first half of the run
     D = 10
     stdev = (1.0 / (np.arange(D) + 1)).astype(np.float32)
     out.append(dict(
         name='gaussian_py', chain_shape=(100,),
-        make_log_joint=gaussian_model(np.zeros(D, np.float32), std=stdev),
+        make_log_joint=lambda tf, zs, n_chains: load_reference_example(
+            'toy_examples/gaussian.py').gaussian(D, stdev, n_chains),
         latents={'x': np.zeros((100, D), np.float32)},
         hmc_kwargs=dict(step_size=1e-3, n_leapfrogs=5,
                         adapt_step_size='placeholder', adapt_mass='placeholder',
