@@ -49,7 +49,8 @@ HMC_KW = dict(step_size=0.05, n_leapfrogs=5, adapt_step_size=True,
 
 class HarnessSession(object):
     def __init__(self, tf, ais, hmc, observed, latent, proposal, stream,
-                 prior_offset):
+                 prior_offset, global_seed=GLOBAL_SEED):
+        self.global_seed = global_seed
         self.tf, self.ais, self.hmc = tf, ais, hmc
         self.observed, self.latent, self.proposal = observed, latent, proposal
         self.stream = stream
@@ -62,7 +63,7 @@ class HarnessSession(object):
 
     def _prior_normal(self, shape):
         n = int(np.prod(shape))
-        z = philox.normal_flat(GLOBAL_SEED, self.prior_offset[0], n)
+        z = philox.normal_flat(self.global_seed, self.prior_offset[0], n)
         self.prior_offset[0] += 1
         return z.reshape(shape)
 
@@ -116,16 +117,16 @@ def true_log_marginal():
                         - 0.5 * X_OBS.astype(np.float64) ** 2 / var))
 
 
-def main():
-    tf, zs = load_reference()
+def run_case(tf, zs, build, latent0, make_observed, chain_shape, hmc_kw,
+             n_temperatures, n_adapt, hmc_seed, global_seed):
+    """One run of the reference's AIS; returns (estimate, arrays)."""
     tf_shim._VARS[:] = []
     tf_shim.end_replay()
     model, proposal = build(tf, zs)
-    z = tf.Variable(np.zeros((N_CHAINS, D), np.float32), name='z')
-    observed = {'x': tf.constant(X_OBS)}
-    latent = {'z': z}
-    hmc = zs.hmc.HMC(**HMC_KW)
-    stream = Stream(HMC_SEED, (N_CHAINS,))
+    latent = {k: tf.Variable(v.copy(), name=k) for k, v in latent0.items()}
+    observed = make_observed(tf)
+    hmc = zs.hmc.HMC(**hmc_kw)
+    stream = Stream(hmc_seed, chain_shape)
     stream.begin(0)
     offset = [0]
     # AIS.__init__ builds the graph: its proposal draw and its one
@@ -136,23 +137,21 @@ def main():
         lambda shape: throwaway.normal(size=shape).astype(np.float32),
         lambda shape: throwaway.uniform(size=shape).astype(np.float32))
     mark = tf_shim.variable_mark()
-    z0 = z.numpy()
     state_before = [v.numpy() for v in tf_shim._VARS]
     tf_shim.Placeholder.unfed_default = 0.0
     ais = zs.evaluation.AIS(model, proposal, hmc, observed, latent,
-                            n_temperatures=N_TEMPERATURES, n_adapt=N_ADAPT)
+                            n_temperatures=n_temperatures, n_adapt=n_adapt)
     tf_shim.Placeholder.unfed_default = None
     tf_shim.end_replay()
-    # undo what the eager "graph construction" executed: latent, sampler
+    # undo what the eager "graph construction" executed: latents, sampler
     # variables (t, step size, tuner) back to their initial values
     for v, init in zip(tf_shim._VARS, state_before):
         v.assign(init)
-    for v in tf_shim._VARS[len(state_before):]:
-        pass                      # variables created by sample(): see below
-    z.assign(z0)
-    _reset_sampler_variables(hmc, HMC_KW)
+    for k, v in latent0.items():
+        latent[k].assign(v)
+    _reset_sampler_variables(hmc, hmc_kw)
     sess = HarnessSession(tf, ais, hmc, observed, latent, proposal, stream,
-                          offset)
+                          offset, global_seed)
     sess.mark = mark
     # capture the per-chain weights: AIS.run only returns their bound
     captured = {}
@@ -163,21 +162,77 @@ def main():
         return orig_bound(log_weights)
     ais._get_lower_bound = capture
     estimate = ais.run(sess, feed_dict={})
-    acc = np.stack(sess.acc_trace)
     out = {
         'estimate': np.float64(estimate),
         'log_weights': captured['log_weights'],
-        'acceptance_rate': acc,
-        'final_step_size': np.float32(tf_shim._t(hmc.step_size).detach().numpy()),
-        'z_final': z.numpy(),
-        'true_log_marginal': np.float64(true_log_marginal()),
-        'x_obs': X_OBS, 'w': W,
+        'acceptance_rate': np.stack(sess.acc_trace),
+        'final_step_size': np.float32(
+            tf_shim._t(hmc.step_size).detach().numpy()),
     }
+    for k in latent0:
+        out[k + '_final'] = latent[k].numpy()
+    return estimate, out
+
+
+# ---- second case: the evaluation block of lntm_mcem.py (:116-141) -----------
+LNTM_N_TEMPERATURES, LNTM_N_ADAPT = 10, 4
+LNTM_HMC_SEED, LNTM_GLOBAL_SEED = 33, 7
+LNTM_HMC_KW = dict(step_size=0.01, n_leapfrogs=5, adapt_step_size=True,
+                   target_acceptance_rate=0.6)
+
+
+def build_lntm(tf, zs):
+    """The reference's OWN `lntm` model function (imported from the
+    unmodified examples/topic_models/lntm_mcem.py) with the script's E-step
+    objective (:97-102) as the target and its copy with the prior of eta as
+    the proposal (:128-134)."""
+    from copy import copy
+    from oracle.hmc_case_data import lntm_data
+    from oracle.make_golden_hmc import load_reference_example
+    beta, x, eta_mean, eta_logstd, eta0 = lntm_data()
+    n_chains, n_docs, n_topics = eta0.shape
+    example = load_reference_example('topic_models/lntm_mcem.py')
+    model = example.lntm(n_chains, n_docs, n_topics, x.shape[1],
+                         tf.constant(eta_mean), tf.constant(eta_logstd))
+    model.log_joint = lambda bn: (bn.cond_log_prob('eta') +
+                                  bn.cond_log_prob('x'))
+    proposal = copy(model)
+    proposal.log_joint = lambda bn: bn.cond_log_prob('eta')
+    return model, proposal
+
+
+def main():
+    tf, zs = load_reference()
+    estimate, out = run_case(
+        tf, zs, build, {'z': np.zeros((N_CHAINS, D), np.float32)},
+        lambda tf: {'x': tf.constant(X_OBS)}, (N_CHAINS,), HMC_KW,
+        N_TEMPERATURES, N_ADAPT, HMC_SEED, GLOBAL_SEED)
+    out.update({'true_log_marginal': np.float64(true_log_marginal()),
+                'x_obs': X_OBS, 'w': W})
     path = os.path.join(ROOT, 'tests', 'golden', 'ais_reference.npz')
     np.savez_compressed(path, **out)
     print('AIS estimate %.5f  (exact log marginal %.5f), mean acc %.3f, '
           'final eps %.4f' % (estimate, out['true_log_marginal'],
-                              acc[N_ADAPT:].mean(), out['final_step_size']))
+                              out['acceptance_rate'][N_ADAPT:].mean(),
+                              out['final_step_size']))
+    print('wrote', path)
+
+    from oracle.hmc_case_data import lntm_data
+    beta, x, _, _, eta0 = lntm_data()
+    # (the counts are given with the full batch shape: distributions/
+    # utils.py:43-44 broadcasts with an in-place multiply, see
+    # make_golden_hmc.py case F)
+    estimate, out = run_case(
+        tf, zs, build_lntm, {'eta': np.zeros_like(eta0)},
+        lambda tf: {'x': tf.constant(np.tile(x[None], (eta0.shape[0], 1, 1))),
+                    'beta': tf.constant(beta)},
+        eta0.shape[:2], LNTM_HMC_KW, LNTM_N_TEMPERATURES, LNTM_N_ADAPT,
+        LNTM_HMC_SEED, LNTM_GLOBAL_SEED)
+    path = os.path.join(ROOT, 'tests', 'golden', 'ais_lntm_reference.npz')
+    np.savez_compressed(path, **out)
+    print('lntm AIS estimate %.5f per document, mean acc %.3f, final eps %.4f'
+          % (estimate, out['acceptance_rate'][LNTM_N_ADAPT:].mean(),
+             out['final_step_size']))
     print('wrote', path)
 
 

@@ -191,3 +191,59 @@ def test_ais_reproduces_the_reference_run(env):
                                float(gold['final_step_size']), rtol=3e-2)
     same = np.isclose(z.cpu().numpy(), gold['z_final'], atol=2e-3).all(axis=1)
     assert same.mean() >= 0.9
+
+
+@pytest.mark.parametrize('variant', ['fused', 'dense'])
+def test_ais_reproduces_the_reference_lntm_run(env, variant):
+    """zhusuan_amd.AIS on the topic model against the evaluation block of
+    lntm_mcem.py (:116-141) executed by the reference's OWN evaluation.py,
+    hmc.py and `lntm` model function (oracle/make_golden_ais.py ->
+    tests/golden/ais_lntm_reference.npz): target = E-step objective, proposal
+    = the same model with the prior of eta as its log-joint, 4 adaptation +
+    10 annealing transitions free-running on 3 chains x 4 documents."""
+    import copy
+    import os
+    from oracle.hmc_case_data import lntm_data
+    from oracle.make_golden_ais import (
+        LNTM_GLOBAL_SEED, LNTM_HMC_KW, LNTM_HMC_SEED, LNTM_N_ADAPT,
+        LNTM_N_TEMPERATURES)
+    zs, torch, dev = env
+    gold = np.load(os.path.join(os.path.dirname(__file__), 'golden',
+                                'ais_lntm_reference.npz'))
+    beta, x, eta_mean, eta_logstd, eta0 = [
+        torch.tensor(a, device=dev) for a in lntm_data()]
+    n_chains, n_docs, K = eta0.shape
+    V = x.shape[1]
+
+    @zs.meta_bayesian_net(scope='lntm')
+    def lntm():
+        bn = zs.BayesianNet()
+        eta = bn.normal('eta', eta_mean.unsqueeze(0).repeat(n_docs, 1),
+                        logstd=eta_logstd, n_samples=n_chains, group_ndims=1)
+        theta = torch.softmax(eta.tensor, -1)
+        b = bn.normal('beta', torch.zeros(K, V, device=dev), logstd=10.0,
+                      group_ndims=1)
+        phi = torch.softmax(b.tensor, -1)
+        logits = zs.log_mixture(theta, phi) if variant == 'fused' else \
+            torch.log((theta.reshape(-1, K) @ phi).reshape(n_chains, n_docs, V))
+        bn.unnormalized_multinomial('x', logits, normalize_logits=False,
+                                    dtype=torch.float32)
+        return bn
+    model = lntm()
+    model.log_joint = lambda bn: (bn.cond_log_prob('eta') +
+                                  bn.cond_log_prob('x'))
+    proposal = copy.copy(model)
+    proposal.log_joint = lambda bn: bn.cond_log_prob('eta')
+
+    zs.set_random_seed(LNTM_GLOBAL_SEED)
+    eta = torch.zeros(n_chains, n_docs, K, device=dev)
+    hmc = zs.HMC(seed=LNTM_HMC_SEED, **LNTM_HMC_KW)
+    ais = zs.AIS(model, proposal, hmc, {'x': x, 'beta': beta}, {'eta': eta},
+                 n_temperatures=LNTM_N_TEMPERATURES, n_adapt=LNTM_N_ADAPT)
+    est = ais.run()
+    lw = ais.log_weights.cpu().numpy()
+    close = np.isclose(lw, gold['log_weights'], atol=2e-2)
+    assert close.mean() >= 0.75, (close.mean(), lw, gold['log_weights'])
+    np.testing.assert_allclose(est, float(gold['estimate']), atol=0.1)
+    np.testing.assert_allclose(float(hmc.hmc_info.updated_step_size.item()),
+                               float(gold['final_step_size']), rtol=3e-2)
