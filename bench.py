@@ -725,6 +725,12 @@ def main():
             out['extra_configs'] = extras
         print(json.dumps(out))
     if world > 1:
+        # every rank has passed the last barrier with an idle stream: the
+        # communicator can go (a failure here must not cost the line above)
+        try:
+            sharding.close()
+        except Exception as e:                       # noqa: BLE001
+            sys.stderr.write('communicator teardown: %r\n' % (e,))
         dist.destroy_process_group()
 
 
