@@ -36,6 +36,26 @@ for f in find('%s_trace/**/*kernel_trace.csv' % tag):
                          len(d), sum(d) / len(d), sum(half) / len(half),
                          half[len(half) // 2], half[0], half[-1]))
 
+# what bench.py itself measured inside the traced run (HIP events around the
+# launches of its timed region): must agree with the trace
+log = os.path.join(out, '%s_trace.log' % tag)
+if os.path.exists(log):
+    import json
+    for line in open(log):
+        if line.startswith('{') and '"roofline"' in line:
+            try:
+                b = json.loads(line)
+            except ValueError:
+                continue
+            r = b['roofline']
+            lines.append(
+                '== bench.py line of the SAME traced run: roofline.kernel_ms '
+                '%.4f (HIP events, %d launches of the timed region), frac '
+                '%.3f, ms_per_step %.4f' % (
+                    r.get('kernel_ms', float('nan')),
+                    r.get('kernel_launches_timed', -1), r['frac'],
+                    b['ms_per_step']))
+
 for sub in ('pmc_fetch', 'pmc_write', 'pmc_sq', 'pmc_sq2', 'pmc_sq3'):
     for f in find('%s_%s/**/*counter_collection.csv' % (tag, sub)):
         agg = {}
