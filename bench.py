@@ -492,17 +492,21 @@ def main():
     gc.freeze()
     gc.disable()
     barrier()
-    # HIP events on the launch stream around every 4th fused launch of the
-    # timed region (two event records per launch cost ~3 us of stream time);
-    # around every launch when that would leave fewer than ~25 samples
-    stride = 4 if args.steps >= 100 else 1
-    hmc.kernel_timer, hmc.kernel_timer_stride = [], stride
+    # ONE HIP-event pair on the launch stream brackets the K launches of the
+    # timed region: nothing is recorded between the launches (event records
+    # around every launch stretch a 20-step region by 28 %: 0.125 against
+    # 0.098 ms per step, gpurun_out/r02w).  At N = 1 the region holds exactly
+    # K fused launches and nothing else, so elapsed / K is the kernel's
+    # average duration with the inter-launch gaps included -- an upper bound.
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()
     for _ in range(args.steps):
         sample_op.run(feed_dict=feed, sync=False)
+    ev1.record()
     barrier()
     elapsed = time.perf_counter() - t0
-    kernel_events, hmc.kernel_timer = hmc.kernel_timer, None
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -510,11 +514,11 @@ def main():
     hmc.check_numerics()
     acc_mean = float(info.acceptance_rate.mean().item())
     eps = float(info.updated_step_size.item())
-    # the dominant kernel's mean duration over the timed region
-    kern_ms_region = sum(a.elapsed_time(b) for a, b in kernel_events) / max(
-        1, len(kernel_events))
+    kern_ms_region = ev0.elapsed_time(ev1) / args.steps
 
-    # the same kernel alone, back to back
+    # the same kernel after the timed region: (a) back to back under one event
+    # pair, (b) launch by launch, each one under its own event pair (the pure
+    # kernel duration; the events' cost falls between the pairs)
     plan = hmc._plan
     plan.collect_acc = False
     stream = torch.cuda.current_stream().cuda_stream
@@ -531,11 +535,34 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     kern_ms_alone = e0.elapsed_time(e1) / reps
-    # a roofline is quoted from >= 20 timed launches: the in-region events, or
-    # (with --steps < 20) the back-to-back loop, and the line says which
-    enough = len(kernel_events) >= 20
-    kern_ms = kern_ms_region if enough else kern_ms_alone
-    hmc.t = t_iter + 6 + reps
+    pairs = []
+    for i in range(24):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(
+            enable_timing=True)
+        a.record()
+        plan._launch(t_iter + 6 + reps + i, None, 1, L, stream)
+        b.record()
+        pairs.append((a, b))
+    torch.cuda.synchronize()
+    kern_ms_single = sum(a.elapsed_time(b) for a, b in pairs) / len(pairs)
+    # The roofline is quoted from >= 20 timed launches.  N = 1: the timed
+    # region itself (or, with --steps < 20, the per-launch event pairs, and
+    # the line says so).  N > 1: the region also holds the collectives, so
+    # the kernel's own duration comes from the per-launch event pairs.
+    if world == 1 and args.steps >= 20:
+        kern_ms, n_timed = kern_ms_region, args.steps
+        kernel_timing = (
+            'one HIP-event pair on the launch stream around the %d fused '
+            'launches of the timed region (nothing else is in the stream): '
+            'average per launch, inter-launch gaps included' % args.steps)
+    else:
+        kern_ms, n_timed = kern_ms_single, len(pairs)
+        kernel_timing = (
+            '%d launches after the timed region, each under its own '
+            'HIP-event pair (%s)' % (len(pairs), (
+                'the timed region also holds the collectives' if world > 1
+                else 'fewer than 20 launches were timed inside the region')))
+    hmc.t = t_iter + 6 + reps + len(pairs)
     algo_bytes = ALGO_BYTES_PER_ELEM * C * D
     from zhusuan_amd import _capi
     kernel_name = _capi.load().zshmc_fused_kernel_name(D, 0, 1).decode()
@@ -668,14 +695,11 @@ def main():
                 'traffic': traffic,
                 'traffic_source': traffic_source,
                 'kernel_ms': kern_ms,
+                'kernel_ms_timed_region': kern_ms_region,
+                'kernel_ms_single_launch_events': kern_ms_single,
                 'kernel_ms_back_to_back': kern_ms_alone,
-                'kernel_launches_timed': len(kernel_events),
-                'kernel_timing': (
-                    'HIP events on the launch stream around every %s fused '
-                    'launch inside the timed region' % (
-                        '4th' if stride == 4 else 'single')) if enough else (
-                    'back-to-back loop of %d launches after the timed region '
-                    '(fewer than 20 launches were timed inside it)' % reps),
+                'kernel_launches_timed': n_timed,
+                'kernel_timing': kernel_timing,
                 'algorithmic_bytes_per_launch': algo_bytes,
             },
         }
