@@ -527,12 +527,15 @@ def main():
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(
         enable_timing=True)
     t_iter = hmc.t
-    for i in range(5):
+    # (the host reads above left the GPU idle for milliseconds: 100 launches
+    # bring the clocks back before the first event, which is recorded in
+    # stream order -- no synchronisation between warm-up and measurement)
+    n_pre = 100
+    for i in range(n_pre):
         plan._launch(t_iter + 1 + i, None, 1, L, stream)
-    torch.cuda.synchronize()
     e0.record()
     for i in range(reps):
-        plan._launch(t_iter + 6 + i, None, 1, L, stream)
+        plan._launch(t_iter + 1 + n_pre + i, None, 1, L, stream)
     e1.record()
     torch.cuda.synchronize()
     kern_ms_alone = e0.elapsed_time(e1) / reps
@@ -553,7 +556,7 @@ def main():
             'the timed region (%s)' % (reps, (
                 'the timed region also holds the collectives' if world > 1
                 else 'fewer than 20 launches were timed inside the region')))
-    hmc.t = t_iter + 6 + reps
+    hmc.t = t_iter + 1 + n_pre + reps
     algo_bytes = ALGO_BYTES_PER_ELEM * C * D
     from zhusuan_amd import _capi
     kernel_name = _capi.load().zshmc_fused_kernel_name(D, 0, 1).decode()
