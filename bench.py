@@ -37,7 +37,7 @@ if ROOT not in sys.path:
 N_CHAINS_PER_GPU = 65536
 N_DATA = 1024
 N_LEAPFROGS = 10
-SETTLE = 400         # untimed transitions after the burn-in (clock ramp, ~40 ms)
+SETTLE = 300            # untimed launches that bring the clocks up after host-side pauses
 BURN_IN_ADAPT = 50
 HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md
 ALGO_BYTES_PER_ELEM = 8.0   # read q + write q per transition
@@ -473,6 +473,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The host is ~4x ahead of the device (0.025 ms per enqueue against a
+    # 0.095 ms kernel), but a full collection of CPython's cyclic GC over a
+    # process that has torch loaded stops it for ~40 ms -- 400 transitions'
+    # worth; tools/first_run_probe.py shows exactly one in the first few
+    # hundred runs of a process (the per-run model re-evaluation allocates
+    # containers).  Timed regions run with the collector parked, as timeit
+    # does.
+    # Parked BEFORE the settle launches: the collection itself takes tens of
+    # milliseconds, and a GPU left idle that long starts the timed region
+    # with its clocks down (tools/startup_probe.py: 106 us per launch over
+    # the 40 launches that follow a 20 ms pause, 93 after none).
+    gc.collect()
+    gc.freeze()
+    gc.disable()
     # settle: the chip's clocks move for the first ~70 launches of a process
     # (per-launch durations 77 -> 130 -> 108 us in profiles/r01i_rocprofv3_
     # summary.txt); keep that transient out of the timed region whatever
@@ -481,16 +495,6 @@ def main():
         sample_op.run(feed_dict=feed, sync=False)
     for _ in range(args.warmup):
         sample_op.run(feed_dict=feed, sync=False)
-    # The host is ~4x ahead of the device (0.025 ms per enqueue against a
-    # 0.095 ms kernel), but a full collection of CPython's cyclic GC over a
-    # process that has torch loaded stops it for ~40 ms -- 400 transitions'
-    # worth; tools/first_run_probe.py shows exactly one in the first few
-    # hundred runs of a process (the per-run model re-evaluation allocates
-    # containers).  Timed regions run with the collector parked, as timeit
-    # does.
-    gc.collect()
-    gc.freeze()
-    gc.disable()
     barrier()
     # ONE HIP-event pair on the launch stream brackets the K launches of the
     # timed region: nothing is recorded between the launches (event records

@@ -1,7 +1,7 @@
 #!/bin/bash
 mkdir -p gpurun_out/r02w
 O=gpurun_out/r02w
-for K in 2000 20000 200; do
+for K in 20 20 200 10; do
 timeout 600 python bench.py --gpus 1 --steps $K --warmup 5 --no-extra-configs --no-cpu-baseline --no-ess > $O/bench$K.json 2> $O/bench$K.err
 python - <<PY
 import json
