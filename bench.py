@@ -37,7 +37,7 @@ if ROOT not in sys.path:
 N_CHAINS_PER_GPU = 65536
 N_DATA = 1024
 N_LEAPFROGS = 10
-SETTLE = 300            # untimed launches that bring the clocks up after host-side pauses
+SETTLE = 400         # untimed transitions after the burn-in and the host-side pauses (clock ramp, ~40 ms)
 BURN_IN_ADAPT = 50
 HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md
 ALGO_BYTES_PER_ELEM = 8.0   # read q + write q per transition
