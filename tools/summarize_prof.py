@@ -48,6 +48,28 @@ if os.path.exists(log):
             except ValueError:
                 continue
             r = b['roofline']
+            # the same launches in the trace, by position: bench.py issues
+            # [burn-in incl. the step-size search's single-leapfrog dry runs]
+            # [settle] [warmup] [TIMED: steps] [back-to-back loop] [other mode]
+            try:
+                sys.path.insert(0, os.path.dirname(os.path.dirname(
+                    os.path.abspath(__file__))))
+                import bench as _bench
+                med = sorted(d)[len(d) // 2]
+                n_search = sum(1 for v in d[:60] if v < 0.8 * med)
+                lo = (n_search + _bench.BURN_IN_ADAPT + _bench.SETTLE +
+                      b['warmup'])
+                win = d[lo:lo + b['steps']]
+                if len(win) == b['steps']:
+                    w = sorted(win)
+                    lines.append(
+                        '== the %d launches of bench.py\'s timed region in the '
+                        'trace (launches %d..%d by start time; %d search dry '
+                        'runs before them): mean %.2f median %.2f us' % (
+                            len(win), lo, lo + len(win) - 1, n_search,
+                            sum(win) / len(win), w[len(w) // 2]))
+            except Exception as e:                      # noqa: BLE001
+                lines.append('(timed-region window not located: %r)' % (e,))
             lines.append(
                 '== bench.py line of the SAME traced run: roofline.kernel_ms '
                 '%.4f (HIP events, %d launches of the timed region), frac '
