@@ -37,7 +37,9 @@ if ROOT not in sys.path:
 N_CHAINS_PER_GPU = 65536
 N_DATA = 1024
 N_LEAPFROGS = 10
-SETTLE = 400         # untimed transitions after the burn-in and the host-side pauses (clock ramp, ~40 ms)
+# untimed transitions after the burn-in and the host-side pauses that follow
+# it (clock ramp, ~40 ms)
+SETTLE = 400
 BURN_IN_ADAPT = 50
 HBM_PEAK_GBPS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md
 ALGO_BYTES_PER_ELEM = 8.0   # read q + write q per transition
@@ -183,8 +185,9 @@ def cpu_baseline_parallel(n_data, n_leapfrogs, budget_s):
 MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 MFMA, MI355X_MICROARCH.md
 ADAPT_TRANSIENT_NOTE = (
     "the timed transitions (numbers 2-4) sit in the reference's "
-    "dual-averaging start-up transient: mu = 10*eps0 is used as a LOG step size (hmc.py:79, sic), so "
-    "eps jumps to ~1 after the first adapted iteration and acceptance is ~0 "
+    "dual-averaging start-up transient: mu = 10*eps0 is used as a LOG step "
+    "size (hmc.py:79, sic), so eps jumps to ~1 after the first adapted "
+    "iteration and acceptance is ~0 "
     "until ~iteration 9; transition 1 uses the searched step size "
     "(mean_acceptance_first_transition).  The work per transition -- L + 1 "
     "likelihood + gradient evaluations -- does not depend on it.")
