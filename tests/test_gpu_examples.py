@@ -62,3 +62,27 @@ def test_bnn_sgmcmc_example(sampler, bound):
             for l in out.splitlines() if 'Test rmse' in l]
     # teacher noise 0.3 (SGHMC reaches 0.36 in 8 short epochs, SGLD 0.41)
     assert len(rmse) == 8 and rmse[-1] < rmse[0] and rmse[-1] < bound
+
+
+def test_plain_c_host_drives_the_fused_transition(tmp_path):
+    """examples/c_host/diag_gaussian_hmc.c: a C99 program (gcc, no Python, no
+    torch) includes include/zshmc.h, links libzshmc.so and samples the
+    gaussian.py target with in-kernel dual averaging -- the C-ABI is the
+    boundary, whoever owns the device pointers."""
+    exe = str(tmp_path / 'hmc_c')
+    lib = os.path.join(ROOT, 'zhusuan_amd', 'lib')
+    cmd = ['gcc', '-std=c99', '-O2', '-D__HIP_PLATFORM_AMD__',
+           '-I/opt/rocm/include', '-I' + os.path.join(ROOT, 'include'),
+           os.path.join(ROOT, 'examples', 'c_host', 'diag_gaussian_hmc.c'),
+           '-L' + lib, '-lzshmc', '-L/opt/rocm/lib', '-lamdhip64', '-lm',
+           '-Wl,-rpath,' + lib, '-Wl,-rpath,/opt/rocm/lib', '-o', exe]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe, '2000', '12', '400'], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-1000:]
+    out = r.stdout
+    acc = float(out.split('mean acceptance ')[1].split(',')[0])
+    err = float(out.split('worst relative error of stdev ')[1].split()[0])
+    eps = float(out.split('final step size ')[1].split(',')[0])
+    assert 0.8 < acc < 0.97 and err < 0.06 and 0.01 < eps < 1.0, out
