@@ -121,3 +121,24 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_capi, 'LIB_PATH', str(tmp_path / 'nope.so'))
     with pytest.raises(_capi.LibraryMissing, match='no CPU fallback'):
         _capi.load()
+
+
+def test_header_is_plain_c_and_cpp(tmp_path):
+    """include/zshmc.h is the boundary: it must compile as C99 and as C++
+    on its own (no HIP, no torch types in the signatures)."""
+    import shutil
+    import subprocess
+    src = tmp_path / 'use_header.c'
+    src.write_text('#include "zshmc.h"\n'
+                   'int use(void) { zshmc_adapt_link l; l.pending = '
+                   'ZSHMC_PEND_NONE; return (int)sizeof(l) + '
+                   'ZSHMC_STATE_WORDS; }\n')
+    inc = os.path.join(ROOT, 'include')
+    for cc, std in (('gcc', '-std=c99'), ('g++', '-std=c++11')):
+        if shutil.which(cc) is None:
+            pytest.skip(cc + ' not available')
+        args = [cc, std, '-Wall', '-Werror', '-pedantic', '-fsyntax-only',
+                '-I' + inc]
+        args += ['-x', 'c++' if cc == 'g++' else 'c', str(src)]
+        r = subprocess.run(args, capture_output=True, text=True)
+        assert r.returncode == 0, (cc, r.stderr[-1500:])
