@@ -86,3 +86,32 @@ def test_plain_c_host_drives_the_fused_transition(tmp_path):
     err = float(out.split('worst relative error of stdev ')[1].split()[0])
     eps = float(out.split('final step size ')[1].split(',')[0])
     assert 0.8 < acc < 0.97 and err < 0.06 and 0.01 < eps < 1.0, out
+
+    # the Python front-end on the same problem, seed and schedule: the same
+    # launches with the same arguments, hence the same bits
+    import numpy as np
+    import torch
+    import zhusuan_amd as zs
+    dev = torch.device('cuda', 0)
+    C, D, n_iters = 2000, 12, 400
+    logstd = torch.tensor(-0.125 * np.arange(D, dtype=np.float32), device=dev)
+
+    @zs.meta_bayesian_net()
+    def gaussian():
+        bn = zs.BayesianNet()
+        bn.normal('x', torch.zeros(D, device=dev), logstd=logstd, n_samples=C,
+                  group_ndims=1)
+        return bn
+    flag = zs.placeholder(bool)
+    hmc = zs.HMC(step_size=0.05, n_leapfrogs=5, adapt_step_size=flag,
+                 target_acceptance_rate=0.9, seed=1234)
+    x = torch.zeros(C, D, device=dev)
+    op, info = hmc.sample(gaussian(), {}, {'x': x})
+    for t in range(1, n_iters + 1):
+        op.run(feed_dict={flag: t <= n_iters // 2}, sync=False)
+    hmc.check_numerics()
+    want = [float.fromhex(v) for v in
+            out.split('bits: ')[1].split()[1::2]]
+    got = [float(info.updated_step_size.item()), float(x[0, 0]),
+           float(x[0, 1]), float(x[-1, -1])]
+    assert got == want, (got, want)
