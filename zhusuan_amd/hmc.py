@@ -236,10 +236,6 @@ class HMC(object):
         self.native_plans = bool(native_plans)
         self._plan = None
         self._pending_check = False
-        # list collecting (start, end) HIP-event pairs around the fused
-        # transition kernel of every run while it is set (bench.py)
-        self.kernel_timer = None         # bench.py: list collecting (start, end) events
-        self.kernel_timer_stride = 1      # time every n-th fused launch
 
     # -- sample(): builds the execution plan (hmc.py:382-522) -------------
     def sample(self, meta_bn, observed, latent):
@@ -749,18 +745,7 @@ class _FusedDiagNormalPlan(_PlanBase):
             _capi.call('zshmc_state_set', self.state.data_ptr(),
                        _capi.ST_STEP_SIZE, float(eps_host), stream)
             eps_host = None
-        timer = self.hmc.kernel_timer
-        self._timer_tick = getattr(self, '_timer_tick', 0) + 1
-        if timer is None or self._timer_tick % self.hmc.kernel_timer_stride:
-            self._launch(t, eps_host, 1, self.hmc.n_leapfrogs, stream, retire)
-        else:
-            # bench.py: HIP events on the launch stream around the fused kernel
-            e0 = torch.cuda.Event(enable_timing=True)
-            e1 = torch.cuda.Event(enable_timing=True)
-            e0.record()
-            self._launch(t, eps_host, 1, self.hmc.n_leapfrogs, stream, retire)
-            e1.record()
-            timer.append((e0, e1))
+        self._launch(t, eps_host, 1, self.hmc.n_leapfrogs, stream, retire)
         if sharded and update is not None:
             # applied by the next launch's prologue (or flush()) once the
             # acceptance sums of all ranks have been added
