@@ -1,0 +1,140 @@
+"""A NumPy stand-in for the C entry points the fused diagonal-Normal plan
+calls, so that the HOST ORCHESTRATION of zhusuan_amd/hmc.py (`HMC._run`: flag
+handling, the step-size search loop, pending / retired dual-averaging
+updates, flush, chain sharding and its all-reduces) can be exercised on a box
+without a GPU -- where the driver runs `-m "not gpu"`.  Test infrastructure:
+the transition itself is the oracle's (oracle/hmc_ref.py pieces); what is
+restated here is the host-visible CONTRACT of include/zshmc.h for
+zshmc_hmc_diag_normal_step / zshmc_adapt_link / zshmc_stepsize_flush /
+zshmc_state_set (csrc/fused_args.h: link_step_size, link_retire,
+tuner_persist).  Tensors are torch CPU tensors addressed through data_ptr()."""
+import ctypes
+
+import numpy as np
+
+from oracle import hmc_ref, philox
+from zhusuan_amd import _capi
+
+F32 = np.float32
+
+
+def _view(ptr, n, ctype, dtype):
+    if not ptr:
+        return None
+    return np.frombuffer((ctype * n).from_address(int(ptr)), dtype=dtype)
+
+
+def _f32(ptr, n):
+    return _view(ptr, n, ctypes.c_float, np.float32)
+
+
+def _tuner_apply(state, acc, kind, fresh, link):
+    """csrc/fused_args.h::tuner_apply on the state block: returns the new
+    (step_size, step, log_eps_bar, h_bar)."""
+    t = hmc_ref.StepsizeTuner(F32(link.mu) / F32(10), link.gamma, link.t0,
+                              link.kappa, link.delta)
+    t.mu = F32(link.mu)
+    t.step = F32(state[_capi.ST_TUNER_STEP])
+    t.log_epsilon_bar = F32(state[_capi.ST_LOG_EPS_BAR])
+    t.h_bar = F32(state[_capi.ST_H_BAR])
+    eps = t.tune(F32(acc), F32(fresh), kind == _capi.PEND_ADAPT)
+    return F32(eps), t.step, t.log_epsilon_bar, t.h_bar
+
+
+def _tuner_persist(state, link, kind, acc_sum):
+    acc = F32(acc_sum / float(link.n_chains_global))
+    old_eps = F32(state[_capi.ST_STEP_SIZE])
+    eps, step, leb, hb = _tuner_apply(state, acc, kind, link.fresh_start, link)
+    used = F32(link.used_step_size)
+    state[_capi.ST_MEAN_ACCEPT] = acc
+    state[_capi.ST_USED_STEP_SIZE] = used if used == used else old_eps
+    state[_capi.ST_STEP_SIZE] = eps
+    state[_capi.ST_TUNER_STEP] = step
+    state[_capi.ST_LOG_EPS_BAR] = leb
+    state[_capi.ST_H_BAR] = hb
+
+
+class FakeLibrary(object):
+    """`call(name, *args)` with the argument order of _capi.PROTOTYPES."""
+
+    def __init__(self):
+        self.calls = []
+
+    def call(self, name, *args):
+        self.calls.append(name)
+        return getattr(self, name)(*args)
+
+    # -- zshmc_state_set(state, index, value, stream) -------------------------
+    def zshmc_state_set(self, state, index, value, stream):
+        _f32(state, _capi.STATE_WORDS)[index] = F32(value)
+
+    # -- zshmc_stepsize_flush(link, stream) ------------------------------------
+    def zshmc_stepsize_flush(self, link_ref, stream):
+        link = link_ref._obj
+        if link.pending != _capi.PEND_NONE:
+            state = _f32(link.state, _capi.STATE_WORDS)
+            stats = _view(link.stats, _capi.STATS_WORDS, ctypes.c_double,
+                          np.float64)
+            _tuner_persist(state, link, link.pending, stats[0])
+
+    # -- zshmc_hmc_diag_normal_step -------------------------------------------
+    def zshmc_hmc_diag_normal_step(
+            self, q, mean, logstd, mass, step_size_host, n_chains, n_data,
+            chain_offset, n_leapfrogs, seed, iteration, commit, acc_out, h0,
+            h1, lp0, lp1, flags, link_ref, stream):
+        link = link_ref._obj
+        C, D = int(n_chains), int(n_data)
+        qv = _f32(q, C * D).reshape(C, D)
+        mean_v = _f32(mean, D) if mean else np.zeros(D, F32)
+        model = hmc_ref.DiagNormalModel(mean_v.copy(),
+                                        logstd=_f32(logstd, D).copy())
+        m = [(_f32(mass, D) if mass else np.ones(D, F32)).reshape(1, D)]
+        state = _f32(link.state, _capi.STATE_WORDS)
+        stats = _view(link.stats, _capi.STATS_WORDS, ctypes.c_double,
+                      np.float64)
+        # prologue: the step size of THIS transition (link_step_size)
+        if state is None:
+            eps = F32(step_size_host)
+        elif link.pending != _capi.PEND_NONE:
+            eps = _tuner_apply(state, F32(stats[0] /
+                                          float(link.n_chains_global)),
+                               link.pending, link.fresh_start, link)[0]
+        else:
+            eps = F32(state[_capi.ST_STEP_SIZE])
+        # the transition (hmc.py:458-498), oracle pieces
+        p0 = hmc_ref.random_momentum(seed, int(iteration), [(C, D)], m, 1,
+                                     int(chain_offset))
+        cq, cp = [qv.copy()], list(p0)
+        for i in range(int(n_leapfrogs) + 1):
+            s1 = eps if i > 0 else F32(0)
+            s2 = eps if 0 < i < n_leapfrogs else eps / F32(2)
+            cq, cp = hmc_ref.leapfrog_integrator(cq, cp, s1, s2, model.grad, m)
+        bad = False
+        try:
+            oh, nh, olp, nlp, acc = hmc_ref.get_acceptance_rate(
+                [qv], p0, cq, cp, model.log_joint, m, [[1]])
+        except hmc_ref.NumericError:
+            bad = True
+            acc = np.zeros(C, F32)
+            oh = nh = olp = nlp = np.full(C, np.nan, F32)
+        u = philox.uniform_per_chain(seed, int(iteration), C,
+                                     int(chain_offset))
+        accept = u < acc
+        if commit:
+            qv[...] = np.where(accept[:, None], cq[0], qv)
+            for ptr, val in ((acc_out, acc), (h0, oh), (h1, nh), (lp0, olp),
+                             (lp1, np.where(accept, nlp, olp))):
+                if ptr:
+                    _f32(ptr, C)[...] = val
+        if bad and flags:
+            _view(flags, 1, ctypes.c_uint32, np.uint32)[0] |= 1
+        # epilogue (link_retire): persist the pending update from the OLD
+        # sum, then this transition's own update, then publish the new sum
+        total = float(np.sum(acc.astype(np.float64)))
+        if state is not None and link.pending != _capi.PEND_NONE:
+            _tuner_persist(state, link, link.pending, stats[0])
+        if state is not None and link.retire_update != _capi.PEND_NONE:
+            _tuner_persist(state, link, link.retire_update, total)
+        if stats is not None:
+            stats[0] = total
+            stats[1] = 1.0 if bad else 0.0
