@@ -6,6 +6,7 @@ without a GPU -- where the driver runs `-m "not gpu"`.  Test infrastructure:
 the transition itself is the oracle's (oracle/hmc_ref.py pieces); what is
 restated here is the host-visible CONTRACT of include/zshmc.h for
 zshmc_hmc_diag_normal_step / zshmc_adapt_link / zshmc_stepsize_flush /
+zshmc_mass_colstats / zshmc_mass_update (csrc/adapt.hip) /
 zshmc_state_set (csrc/fused_args.h: link_step_size, link_retire,
 tuner_persist).  Tensors are torch CPU tensors addressed through data_ptr()."""
 import ctypes
@@ -138,3 +139,36 @@ class FakeLibrary(object):
         if stats is not None:
             stats[0] = total
             stats[1] = 1.0 if bad else 0.0
+
+    # -- zshmc_mass_colstats / zshmc_mass_update (csrc/adapt.hip) -------------
+    def zshmc_mass_colstats(self, q, ewmv_mean, n_chains, n_data, colsum,
+                            stream):
+        C, D = int(n_chains), int(n_data)
+        qv = _f32(q, C * D).reshape(C, D)
+        d = (qv - _f32(ewmv_mean, D)).astype(np.float64)
+        cs = _view(colsum, 2 * D, ctypes.c_double, np.float64)
+        cs[:D] += d.sum(0)
+        cs[D:] += (d * d).sum(0)
+
+    def zshmc_mass_update(self, state, ewmv_mean, ewmv_var, colsum,
+                          n_chains_global, n_data, decay, update, use_ones,
+                          mass_out, stream):
+        D = int(n_data)
+        st = _f32(state, _capi.STATE_WORDS)
+        mean, var = _f32(ewmv_mean, D), _f32(ewmv_var, D)
+        tau_new = F32(st[_capi.ST_EWMV_T]) + F32(1)
+        if update:
+            cs = _view(colsum, 2 * D, ctypes.c_double, np.float64)
+            w = (F32(1) - F32(decay)) / (F32(1) - np.power(F32(decay), tau_new,
+                                                           dtype=F32))
+            s1 = cs[:D] / float(n_chains_global)
+            s2 = cs[D:] / float(n_chains_global)
+            delta = float(w) * s1
+            mean[...] = (mean.astype(np.float64) + delta).astype(F32)
+            var[...] = ((1.0 - float(w)) * var.astype(np.float64) +
+                        float(w) * s2 - delta * delta).astype(F32)
+            cs[...] = 0.0
+        with np.errstate(divide='ignore'):
+            _f32(mass_out, D)[...] = F32(1) if use_ones else F32(1) / var
+        if update == 1:
+            st[_capi.ST_EWMV_T] = tau_new
