@@ -9,7 +9,6 @@ The caller supplies log-prior / log-joint callables with analytic gradients
 k-th proposal draw (proposal_meta_bn.observe().get(latent_k), :96)."""
 import numpy as np
 
-from . import hmc_ref
 
 F32 = np.float32
 
