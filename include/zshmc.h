@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ZSHMC_VERSION 200 /* 0.2.0 */
+#define ZSHMC_VERSION 201 /* 0.2.1 */
 
 /* status codes */
 #define ZSHMC_OK 0
@@ -281,11 +281,16 @@ int zshmc_select_rows(float* q, const float* q_new, const uint8_t* accept,
  *   grad  = J_f(q)^T grad_lik - exp(-2 logstd)(q - mean)   (tf.gradients of
  *           the joint, hmc.py:430-432; softmax: theta*(g - <g,theta>))
  *   p += kick_scale*eps*grad ;  q += drift_scale*eps*p/mass
- *   lp_out[c]   = (ll_in ? ll_in[c] : 0) + log N(q_c)   AT the evaluation point
+ *   lp_out[c]   = lik_scale * (ll_in ? ll_in[c] : 0) + log N(q_c)
+ *                                                     AT the evaluation point
  *   kinetic[c] += 1/2 sum p'^2/mass                      (if not NULL)
  *   operand[c, 0:operand_stride] = f(q') zero-padded     (if not NULL): the
  *           next likelihood evaluation's W / theta operand.  softmax != 0:
  *           operand is also READ (theta of the current q, for the Jacobian).
+ * lik_scale multiplies the likelihood's log-density and gradient: 1 for the
+ * joint; the temperature T of annealed importance sampling, whose target is
+ * (1 - T) log prior + T (log prior + log lik) = log prior + T log lik
+ * (evaluation.py:101-103).
  * grad_lik [n_chains, grad_stride] or NULL (= 0); prior_mean / prior_logstd
  * are [rows, n_data] used with row period (r % rows) -- 1 row: shared by all
  * chains; n_docs rows: lntm's per-document eta_mean.  n_data a multiple of 4,
@@ -297,8 +302,8 @@ int zshmc_model_kick_drift(
     const float* prior_mean, int64_t mean_rows, const float* prior_logstd,
     int64_t logstd_rows, const float* mass, const float* step_size_dev,
     float step_size_host, float kick_scale, float drift_scale,
-    int64_t n_chains, int64_t n_data, const float* ll_in, float* lp_out,
-    float* kinetic, void* stream);
+    float lik_scale, int64_t n_chains, int64_t n_data, const float* ll_in,
+    float* lp_out, float* kinetic, void* stream);
 
 /* ------------------------------------------------------------------------
  * Stand-alone distribution ops (forward, analytic backward, sampling).

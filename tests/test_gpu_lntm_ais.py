@@ -240,6 +240,11 @@ def test_ais_reproduces_the_reference_lntm_run(env, variant):
     hmc = zs.HMC(seed=LNTM_HMC_SEED, **LNTM_HMC_KW)
     ais = zs.AIS(model, proposal, hmc, {'x': x, 'beta': beta}, {'eta': eta},
                  n_temperatures=LNTM_N_TEMPERATURES, n_adapt=LNTM_N_ADAPT)
+    # the fused spelling anneals on the target's own native plan (likelihood
+    # term scaled by the temperature: the MFMA kernel, no autograd graph);
+    # the dense spelling on the generic plan over the tempered callable
+    assert hmc.plan_kind == ('mixture_multinomial' if variant == 'fused'
+                             else 'generic')
     est = ais.run()
     lw = ais.log_weights.cpu().numpy()
     close = np.isclose(lw, gold['log_weights'], atol=2e-2)

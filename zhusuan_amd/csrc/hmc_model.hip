@@ -20,7 +20,7 @@
 //                                               what tf.gradients gives, hmc.py:430-432)
 //   p <- p + kick_scale * eps * grad           (hmc.py:42)
 //   q <- q + drift_scale * eps * p / mass      (hmc.py:39, :26-27)
-//   lp_out     = ll_in + prior_lp              (log-joint AT the evaluation
+//   lp_out     = lik_scale * ll_in + prior_lp  (log-joint AT the evaluation
 //                                               point: old / new log-prob)
 //   kinetic   += 1/2 sum p^2 / mass            (hmc.py:32-34, on request)
 //   operand    = f(q_new), zero-padded to the MFMA kernel's feature width --
@@ -51,6 +51,7 @@ struct ModelStepArgs {
   const float* step_size_dev;
   float step_size_host;
   float kick_scale, drift_scale;
+  float lik_scale;  // multiplies log_lik and its gradient (AIS temperature)
   int64_t n_chains, n_data;
   const float* ll_in;  // [C] or NULL
   float* lp_out;       // [C] or NULL
@@ -100,7 +101,8 @@ __global__ __launch_bounds__(256) void model_kick_drift_kernel(ModelStepArgs a) 
       }
       m4 gl = zero;
       if (a.grad_lik)
-        gl = *reinterpret_cast<const m4*>(a.grad_lik + c * a.grad_stride + d);
+        gl = a.lik_scale *
+             *reinterpret_cast<const m4*>(a.grad_lik + c * a.grad_stride + d);
       m4 th = zero;
       if (SOFTMAX && a.grad_lik)
         th = *reinterpret_cast<const m4*>(a.operand + c * a.operand_stride + d);
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(256) void model_kick_drift_kernel(ModelStepArgs a) 
       if (lane == 0) a.kinetic[c] += 0.5f * kin;
     }
     if (a.lp_out && lane == 0)
-      a.lp_out[c] = (a.ll_in ? a.ll_in[c] : 0.f) + prior;
+      a.lp_out[c] = (a.ll_in ? a.lik_scale * a.ll_in[c] : 0.f) + prior;
     // operand of the next likelihood evaluation: f(q_new), zero padding
     if (a.operand) {
       float inv_sum = 1.f;
@@ -211,8 +213,8 @@ extern "C" int zshmc_model_kick_drift(
     const float* prior_mean, int64_t mean_rows, const float* prior_logstd,
     int64_t logstd_rows, const float* mass, const float* step_size_dev,
     float step_size_host, float kick_scale, float drift_scale,
-    int64_t n_chains, int64_t n_data, const float* ll_in, float* lp_out,
-    float* kinetic, void* stream) {
+    float lik_scale, int64_t n_chains, int64_t n_data, const float* ll_in,
+    float* lp_out, float* kinetic, void* stream) {
   ZS_REQUIRE(q && p && prior_mean && prior_logstd,
              "zshmc_model_kick_drift: null q/p/prior");
   ZS_REQUIRE(n_chains >= 0 && n_data >= 4 && n_data <= 1024 && n_data % 4 == 0,
@@ -236,7 +238,7 @@ extern "C" int zshmc_model_kick_drift(
   ModelStepArgs a{q, p, grad_lik, grad_stride, operand, operand_stride,
                   prior_mean, mean_rows, prior_logstd, logstd_rows, mass,
                   step_size_dev, step_size_host, kick_scale, drift_scale,
-                  n_chains, n_data, ll_in, lp_out, kinetic};
+                  lik_scale, n_chains, n_data, ll_in, lp_out, kinetic};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int64_t width = operand && operand_stride > n_data ? operand_stride : n_data;
   const int nv = (int)((width + 255) / 256);

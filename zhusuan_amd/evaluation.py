@@ -6,6 +6,12 @@ one HMC transition per temperature, and the importance weights are the
 telescoping sums of HMCInfo.orig_log_prob / log_prob; the estimate is the
 log-mean-exp over the chain axis.
 
+When the proposal is the target's own model with the latent's prior as its
+log-joint (lntm_mcem.py:128-134) and the target lowers to a native
+dense-likelihood plan, the tempered target is `log prior + T * log lik` and
+the sampler runs on that plan with the likelihood term scaled by T
+(zshmc_model_kick_drift's lik_scale) -- no autograd graph per leapfrog trip.
+
 MI355X-first differences: there is no session (`sess` is accepted and
 ignored), the temperature is a host scalar that the tempered log-joint reads
 every time the sampler evaluates it (exactly like a fed placeholder), and the
@@ -27,6 +33,55 @@ def _as_log_joint(model):
     if callable(model) and not hasattr(model, 'observe'):
         return model
     return lambda values: model.observe(**values).log_joint()
+
+
+def _proposal_is_prior_of(target, proposal, observed, latent):
+    """True if `proposal` is the target's own model with the conditional
+    log-density of the single latent as its log-joint (what lntm_mcem.py:128-134
+    builds: `proposal = copy(model); proposal.log_joint = lambda bn:
+    bn.cond_log_prob('eta')`) AND the target's log-joint is that prior plus
+    one observed node's likelihood, in a form the native dense-likelihood
+    plans take.  Checked structurally, on one evaluation of each."""
+    from .framework.bn import StochasticTensor
+    from .framework.meta_bn import MetaBayesianNet
+    from .hmc import _summands_of, deferred, placeholder
+    if not (isinstance(target, MetaBayesianNet) and
+            isinstance(proposal, MetaBayesianNet)) or len(latent) != 1:
+        return False
+    def same(a, b):
+        return len(a) == len(b) and all(x is y for x, y in zip(a, b))
+    if getattr(proposal, '_builder', None) is not getattr(
+            target, '_builder', 0) or \
+            not same(proposal._call_args, target._call_args) or \
+            sorted(proposal._call_kwargs) != sorted(target._call_kwargs) or \
+            not same([proposal._call_kwargs[k]
+                      for k in sorted(proposal._call_kwargs)],
+                     [target._call_kwargs[k]
+                      for k in sorted(target._call_kwargs)]):
+        return False
+    name, value = next(iter(latent.items()))
+    obs = {k: (v.value if isinstance(v, (placeholder, deferred)) else v)
+           for k, v in observed.items()}
+    probe = value.detach().requires_grad_(True)
+    try:
+        bn_p = proposal.observe(**merge_dicts(obs, {name: probe}))
+        lp = bn_p.log_joint()
+        prior_node = bn_p.get(name)
+        if not isinstance(prior_node, StochasticTensor) or \
+                lp is not prior_node.__dict__.get('_cond_log_p'):
+            return False
+        bn_t = target.observe(**merge_dicts(obs, {name: probe}))
+        nodes = [n for n in bn_t.nodes.values()
+                 if isinstance(n, StochasticTensor)]
+        if target.log_joint is not None:
+            nodes = _summands_of(bn_t.log_joint(), nodes)
+        if nodes is None or len(nodes) != 2:
+            return False
+        return any(n.name == name for n in nodes) and any(
+            n.name != name and n.is_observed() and
+            getattr(n.dist, '_lazy', None) is not None for n in nodes)
+    except Exception:                                    # noqa: BLE001
+        return False
 
 
 def sigmoid_schedule(n_temperatures):
@@ -59,7 +114,26 @@ class AIS(object):
                 target(values) * float(t)
 
         self.log_fn = tempered
-        self.sample_op, self.hmc_info = hmc.sample(tempered, observed, latent)
+        self.sample_op = self.hmc_info = None
+        if _proposal_is_prior_of(meta_bn, proposal_meta_bn, observed, latent):
+            # (1 - T) log prior + T (log prior + log lik) = log prior +
+            # T log lik: the target's own native plan with the likelihood term
+            # scaled by the temperature -- the fused MFMA likelihood instead
+            # of an autograd graph per leapfrog trip (lntm_mcem.py:116-141)
+            self.sample_op, self.hmc_info = hmc.sample(meta_bn, observed,
+                                                       latent)
+            plan = hmc._plan
+            if hasattr(plan, 'lik_scale'):
+                plan.lik_scale = lambda: float(np.float32(self.temperature))
+            else:
+                # the target did not lower to a dense-likelihood plan (shape,
+                # alignment, native_plans=False): that plan could not anneal;
+                # build the sampler again on the tempered callable
+                hmc._plan = None
+                self.sample_op = None
+        if self.sample_op is None:
+            self.sample_op, self.hmc_info = hmc.sample(tempered, observed,
+                                                       latent)
         self._hmc = hmc
 
     # kept for callers of the reference's private helper

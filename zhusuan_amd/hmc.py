@@ -930,6 +930,9 @@ class _DenseLikelihoodPlan(_PlanBase):
         self._in_search = False
         self._src = None
         self._ws = None
+        # multiplies the likelihood term (log-density and gradient): 1 for the
+        # joint; AIS installs its temperature (evaluation.py:101-103)
+        self.lik_scale = lambda: 1.0
         self.refresh_model()
 
     # -- model tensors -------------------------------------------------------
@@ -998,7 +1001,8 @@ class _DenseLikelihoodPlan(_PlanBase):
             self.prior_logstd.data_ptr(), self.logstd_rows, self.mass_ptr(0),
             None if eps_host is not None else self.state.data_ptr(),
             0.0 if eps_host is None else float(eps_host), float(kick),
-            float(drift), self.n_chains, self.n_data[0],
+            float(drift), float(self.lik_scale()), self.n_chains,
+            self.n_data[0],
             self.ll.data_ptr() if use_grad else None, _capi.ptr(lp_out),
             _capi.ptr(kinetic), stream)
 
