@@ -1,4 +1,5 @@
 #!/bin/bash
 mkdir -p gpurun_out/r02u
-timeout 1200 python -m pytest tests/test_gpu_lntm_ais.py tests/test_gpu_mixture_multinomial.py tests/test_gpu_linear_bernoulli.py tests/test_gpu_hmc_reference.py tests/test_gpu_examples.py -q -x 2>&1 | grep -v amdgpu.ids | tail -30 | tee gpurun_out/r02u/pytest.txt
-timeout 600 python examples/topic_model_mcem.py --epochs 2 2>&1 | grep -v amdgpu.ids | tail -4
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | grep -v amdgpu.ids | tail -3 | tee gpurun_out/r02u/pytest.txt
+timeout 300 python tools/generic_bench.py 2>&1 | grep -v amdgpu.ids | tail -3
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
