@@ -25,8 +25,10 @@
 //   kinetic   += 1/2 sum p^2 / mass            (hmc.py:32-34, on request)
 //   operand    = f(q_new), zero-padded to the MFMA kernel's feature width --
 //                the next likelihood evaluation reads it directly.
-// One wave per row, the row in registers (n_data <= 1024, multiple of 4,
-// 16-B aligned), 16 B per lane and access, row sums by wave shuffles.
+// One wave per row -- two / four rows per wave when a row is at most 128 / 64
+// floats wide, so that no lane idles (config 5: K = 128 topics) -- the row in
+// registers (n_data <= 1024, multiple of 4, 16-B aligned), 16 B per lane and
+// access, row sums by shuffles inside the row's lane group.
 // HBM-bound: 4-6 row passes of 4*n_data bytes per call, noise next to the
 // 2*N*D*C flop likelihood it sits between.
 #include "common.h"
@@ -58,15 +60,21 @@ struct ModelStepArgs {
   float* kinetic;      // [C] or NULL
 };
 
-__device__ __forceinline__ float wave_max(float v) {
+template <int WIDTH>
+__device__ __forceinline__ float group_max(float v) {
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  for (int off = WIDTH / 2; off > 0; off >>= 1)
+    v = fmaxf(v, __shfl_xor(v, off, 64));
   return v;
 }
 
-template <int NV, bool SOFTMAX>
+// LANES lanes per row (64, 32 or 16): a wave holds 64 / LANES rows at once.
+template <int NV, bool SOFTMAX, int LANES>
 __global__ __launch_bounds__(256) void model_kick_drift_kernel(ModelStepArgs a) {
-  const int lane = threadIdx.x & 63;
+  constexpr int kRows = 64 / LANES;  // rows per wave
+  static_assert(NV == 1 || LANES == 64, "narrow rows are one chunk per lane");
+  const int lane = threadIdx.x & (LANES - 1);     // lane inside the row group
+  const int sub = (threadIdx.x & 63) / LANES;     // which row of the wave
   const int64_t wave = (int64_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
   const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x / 64);
   const int64_t D = a.n_data;
@@ -75,7 +83,13 @@ __global__ __launch_bounds__(256) void model_kick_drift_kernel(ModelStepArgs a) 
   const float s1 = a.drift_scale * eps;
   const m4 zero = m4{0.f, 0.f, 0.f, 0.f};
 
-  for (int64_t c = wave; c < a.n_chains; c += n_waves) {
+  // (wave-uniform trip count: the rows past the end are clamped to the last
+  // row for the loads and masked for the stores, so every lane takes part in
+  // the shuffles)
+  for (int64_t base = wave * kRows; base < a.n_chains;
+       base += n_waves * kRows) {
+    const bool row_on = base + sub < a.n_chains;
+    const int64_t c = row_on ? base + sub : a.n_chains - 1;
     float* __restrict__ qrow = a.q + c * D;
     float* __restrict__ prow = a.p + c * D;
     const float* __restrict__ mrow = a.prior_mean + (c % a.mean_rows) * D;
@@ -85,7 +99,7 @@ __global__ __launch_bounds__(256) void model_kick_drift_kernel(ModelStepArgs a) 
     float prior = 0.f, dot = 0.f;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
-      const int64_t d = (int64_t)(k * 64 + lane) * 4;
+      const int64_t d = (int64_t)(k * LANES + lane) * 4;
       in[k] = d < D;
       q[k] = p[k] = g[k] = zero;
       im[k] = m4{1.f, 1.f, 1.f, 1.f};
@@ -124,13 +138,13 @@ __global__ __launch_bounds__(256) void model_kick_drift_kernel(ModelStepArgs a) 
       else
         g[k] += gl;
     }
-    prior = group_sum<64>(prior);
+    prior = group_sum<LANES>(prior);
     if (SOFTMAX && a.grad_lik) {
-      dot = group_sum<64>(dot);
+      dot = group_sum<LANES>(dot);
 #pragma unroll
       for (int k = 0; k < NV; ++k) {
         if (!in[k]) continue;
-        const int64_t d = (int64_t)(k * 64 + lane) * 4;
+        const int64_t d = (int64_t)(k * LANES + lane) * 4;
         const m4 th =
             *reinterpret_cast<const m4*>(a.operand + c * a.operand_stride + d);
         g[k] -= dot * th;
@@ -141,13 +155,14 @@ __global__ __launch_bounds__(256) void model_kick_drift_kernel(ModelStepArgs a) 
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
       if (!in[k]) continue;
-      const int64_t d = (int64_t)(k * 64 + lane) * 4;
+      const int64_t d = (int64_t)(k * LANES + lane) * 4;
       p[k] = p[k] + s2 * g[k];
       const m4 vel = p[k] * im[k];
-      if (a.kick_scale != 0.f) *reinterpret_cast<m4*>(prow + d) = p[k];
+      if (a.kick_scale != 0.f && row_on)
+        *reinterpret_cast<m4*>(prow + d) = p[k];
       if (a.drift_scale != 0.f) {
         q[k] = q[k] + s1 * vel;
-        *reinterpret_cast<m4*>(qrow + d) = q[k];
+        if (row_on) *reinterpret_cast<m4*>(qrow + d) = q[k];
       }
       const m4 e = p[k] * vel;
       kin += (e[0] + e[1]) + (e[2] + e[3]);
@@ -156,16 +171,16 @@ __global__ __launch_bounds__(256) void model_kick_drift_kernel(ModelStepArgs a) 
                      qmax);
     }
     if (a.kinetic) {
-      kin = group_sum<64>(kin);
-      if (lane == 0) a.kinetic[c] += 0.5f * kin;
+      kin = group_sum<LANES>(kin);
+      if (lane == 0 && row_on) a.kinetic[c] += 0.5f * kin;
     }
-    if (a.lp_out && lane == 0)
+    if (a.lp_out && lane == 0 && row_on)
       a.lp_out[c] = (a.ll_in ? a.lik_scale * a.ll_in[c] : 0.f) + prior;
     // operand of the next likelihood evaluation: f(q_new), zero padding
     if (a.operand) {
       float inv_sum = 1.f;
       if (SOFTMAX) {
-        qmax = wave_max(qmax);
+        qmax = group_max<LANES>(qmax);
         float sum = 0.f;
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
@@ -176,29 +191,32 @@ __global__ __launch_bounds__(256) void model_kick_drift_kernel(ModelStepArgs a) 
             sum += q[k][j];
           }
         }
-        inv_sum = 1.0f / group_sum<64>(sum);
+        inv_sum = 1.0f / group_sum<LANES>(sum);
       }
       float* __restrict__ orow = a.operand + c * a.operand_stride;
 #pragma unroll
       for (int k = 0; k < NV; ++k) {
-        const int64_t d = (int64_t)(k * 64 + lane) * 4;
-        if (d >= a.operand_stride) continue;
+        const int64_t d = (int64_t)(k * LANES + lane) * 4;
+        if (d >= a.operand_stride || !row_on) continue;
         *reinterpret_cast<m4*>(orow + d) = in[k] ? q[k] * inv_sum : zero;
       }
     }
   }
 }
 
-template <int NV>
+template <int NV, int LANES>
 static int launch_model_step(const ModelStepArgs& a, bool softmax,
                              hipStream_t s) {
-  const int64_t need = (a.n_chains + 3) / 4;
+  constexpr int kRows = 64 / LANES;
+  const int64_t need = (a.n_chains + 4 * kRows - 1) / (4 * kRows);
   const int64_t cap = (int64_t)device_cu_count() * 8;
   const dim3 grid((unsigned)(need < cap ? need : cap)), block(256);
   if (softmax)
-    hipLaunchKernelGGL((model_kick_drift_kernel<NV, true>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((model_kick_drift_kernel<NV, true, LANES>), grid, block,
+                       0, s, a);
   else
-    hipLaunchKernelGGL((model_kick_drift_kernel<NV, false>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((model_kick_drift_kernel<NV, false, LANES>), grid, block,
+                       0, s, a);
   ZS_LAUNCH_CHECK("model_kick_drift_kernel launch");
   return ZSHMC_OK;
 }
@@ -242,10 +260,14 @@ extern "C" int zshmc_model_kick_drift(
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int64_t width = operand && operand_stride > n_data ? operand_stride : n_data;
   const int nv = (int)((width + 255) / 256);
+  // a row of at most 64 / 128 floats leaves lanes of a 64-lane group idle:
+  // pack four / two rows into a wave
+  if (width <= 64) return launch_model_step<1, 16>(a, softmax != 0, s);
+  if (width <= 128) return launch_model_step<1, 32>(a, softmax != 0, s);
   switch (nv) {
-    case 1: return launch_model_step<1>(a, softmax != 0, s);
-    case 2: return launch_model_step<2>(a, softmax != 0, s);
-    case 3: return launch_model_step<3>(a, softmax != 0, s);
-    default: return launch_model_step<4>(a, softmax != 0, s);
+    case 1: return launch_model_step<1, 64>(a, softmax != 0, s);
+    case 2: return launch_model_step<2, 64>(a, softmax != 0, s);
+    case 3: return launch_model_step<3, 64>(a, softmax != 0, s);
+    default: return launch_model_step<4, 64>(a, softmax != 0, s);
   }
 }
