@@ -1,12 +1,13 @@
 #!/bin/bash
-mkdir -p gpurun_out/r02u
+mkdir -p gpurun_out/r02final
+O=gpurun_out/r02final
 SECONDS=0
-timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 20 --warmup 5 --no-ess > gpurun_out/r02u/bench2.json 2> gpurun_out/r02u/bench2.err
-echo "rc=$? wall ${SECONDS}s"
-tail -3 gpurun_out/r02u/bench2.err | cut -c1-300
+timeout 1500 python bench.py > $O/bench2.json 2> $O/bench2.err
+echo "bench (no flags) wall ${SECONDS}s rc=$?"
 python - <<PY
 import json
-d=json.loads(open('gpurun_out/r02u/bench2.json').read().strip().split('\n')[-1])
-print({k: d[k] for k in ('value','n_gpus','ms_per_step','rccl_ranks','collective','scaling')})
-print(d['roofline']['kernel_timing'], d['roofline']['frac'])
+d=json.load(open('$O/bench2.json'))
+r=d['roofline']
+print('value %.4g ms/step %.4f steps %d | kernel_ms %.4f frac %.3f | other %s' % (d['value'], d['ms_per_step'], d['steps'], r['kernel_ms'], r['frac'], d['other_adaptation_mode']))
+for e in d.get('extra_configs', []): print(e.get('workload','')[:40], e.get('ms_per_step'), e.get('mean_acceptance_first_transition'), e.get('roofline',{}).get('frac'), e.get('roofline',{}).get('sustained_over_transition'), e.get('error'))
 PY
