@@ -58,6 +58,13 @@ def parse():
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--no-extra-configs', action='store_true')
     ap.add_argument('--config5-chains', type=int, default=None)
+    ap.add_argument('--workload', choices=('gaussian', 'lntm'),
+                    default='gaussian',
+                    help="gaussian: configs[1]/[3] (the headline); lntm: "
+                         "configs[4], chains sharded over --gpus ranks")
+    ap.add_argument('--lntm-chains-per-gpu', type=int, default=1024)
+    ap.add_argument('--lntm-docs', type=int, default=5000)
+    ap.add_argument('--lntm-vocab', type=int, default=12419)
     return ap.parse_args()
 
 
@@ -183,35 +190,60 @@ def cpu_baseline_parallel(n_data, n_leapfrogs, budget_s):
 
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 MFMA, MI355X_MICROARCH.md
-ADAPT_TRANSIENT_NOTE = (
-    "the timed transitions (numbers 2-4) sit in the reference's "
-    "dual-averaging start-up transient: mu = 10*eps0 is used as a LOG step "
-    "size (hmc.py:79, sic), so eps jumps to ~1 after the first adapted "
-    "iteration and acceptance is ~0 "
-    "until ~iteration 9; transition 1 uses the searched step size "
-    "(mean_acceptance_first_transition).  The work per transition -- L + 1 "
-    "likelihood + gradient evaluations -- does not depend on it.")
+EXTRA_TIMEOUT_S = 420          # N > 1: budget of the sharded configs[4] extra
+TUNED_START_NOTE = (
+    "timed AFTER the reference's dual-averaging start-up transient (mu = "
+    "10*eps0 used as a LOG step size, hmc.py:79 sic: eps jumps to ~1 after the "
+    "first adapted iteration and acceptance is ~0 until ~iteration 9): a "
+    "subset of the chains is burnt in with adaptation on, its sampler state "
+    "(t, step size, tuner triple, EWMV mean/var, mass) is restored into the "
+    "full-size sampler with set_state and its end state tiled over the full "
+    "chain axis; the timed transitions then run with adaptation ON (tuner and "
+    "mass estimator continue from the restored state; the all-reduce of "
+    "[sum acc, flag, colsum] is in the loop when sharded).")
 
 
-def _time_native_plan(torch, hmc, sample_op, feed, n_warm, n_timed):
-    """Wall time per transition (HIP events on the launch stream) and the
-    likelihood kernel alone (one evaluation = likelihood + gradient)."""
-    first_acc = None
-    for i in range(n_warm):
-        sample_op.run(feed_dict=feed, sync=False)
-        if i == 0:
-            # transition 1 integrates with the step size the search returned
-            first_acc = float(hmc.hmc_info.acceptance_rate.mean().item())
+def _tuned_start(torch, zs, build, n_sub, n_burn, n_draws, flags_on):
+    """Burn a subset of `n_sub` chains in (adaptation on), then record
+    `n_draws` more transitions (adaptation held) for the reference's ESS
+    estimator.  Returns (sampler state, end state of the subset, ESS per
+    (chain row) per transition, mean acceptance of the recorded phase)."""
+    hmc, op, info, q, flags = build(n_sub, None)
+    feed_on = dict(zip(flags, flags_on))
+    for _ in range(n_burn):
+        op.run(feed_dict=feed_on, sync=False)
     hmc.check_numerics()
-    hmc._first_transition_acceptance = first_acc
-    e0 = torch.cuda.Event(enable_timing=True)
-    e1 = torch.cuda.Event(enable_timing=True)
-    e0.record()
+    state = hmc.get_state()
+    q_end = q.clone()
+    feed_off = {f: False for f in flags}
+    rec = torch.empty((n_draws,) + tuple(q.shape), device=q.device)
+    acc = 0.0
+    for i in range(n_draws):
+        op.run(feed_dict=feed_off, sync=False)
+        rec[i].copy_(q)
+        acc += float(info.acceptance_rate.mean().item()) / n_draws
+    burn = n_draws // 3
+    ess = zs.diagnostics.effective_sample_size_device(rec, burn_in=burn)
+    ok = torch.isfinite(ess)
+    ess_per_transition = float(ess[ok].mean().item()) / (n_draws - burn)
+    del rec
+    return state, q_end, ess_per_transition, acc
+
+
+def _time_transitions(torch, hmc, op, info, feed, n_warm, n_timed, barrier):
+    """Wall time per transition (host clock around a barrier-bracketed
+    region; the contract's max over ranks is taken by the caller) and the
+    likelihood kernel alone (one evaluation = likelihood + gradient)."""
+    for _ in range(n_warm):
+        op.run(feed_dict=feed, sync=False)
+    hmc.check_numerics()
+    barrier()
+    t0 = time.perf_counter()
     for _ in range(n_timed):
-        sample_op.run(feed_dict=feed, sync=False)
-    e1.record()
-    torch.cuda.synchronize()
-    ms_transition = e0.elapsed_time(e1) / n_timed
+        op.run(feed_dict=feed, sync=False)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    acc = float(info.acceptance_rate.mean().item())
     plan = hmc._plan
     stream = torch.cuda.current_stream().cuda_stream
     plan._likelihood(plan.q_new, stream)
@@ -223,15 +255,28 @@ def _time_native_plan(torch, hmc, sample_op, feed, n_warm, n_timed):
         plan._likelihood(plan.q_new, stream)
     k1.record()
     torch.cuda.synchronize()
-    return ms_transition, k0.elapsed_time(k1) / reps
+    return elapsed, k0.elapsed_time(k1) / reps, acc
+
+
+def _mfma_roofline(kernel, kern_ms, flop_eval, n_evals, ms_transition):
+    ach = flop_eval / (kern_ms * 1e-3) / 1e12
+    return {
+        'bound': 'mfma', 'dtype': 'f32', 'peak': MFMA_F32_PEAK_TFLOPS,
+        'unit': 'TFLOP/s', 'kernel': kernel, 'kernel_ms': kern_ms,
+        'achieved': ach, 'frac': ach / MFMA_F32_PEAK_TFLOPS,
+        'traffic': None,
+        'algorithmic_flop_per_launch': flop_eval,
+        'sustained_over_transition': n_evals * flop_eval /
+        (ms_transition * 1e-3) / 1e12,
+    }
 
 
 def extra_config3(torch, zs, dev, n_rows=1000000, n_chains=32768, n_feat=256,
-                  n_leapfrogs=10):
+                  n_leapfrogs=10, n_sub=256, n_timed=2):
     """BASELINE configs[2]: Bayesian logistic regression, synthetic
     10^6 x 256 design matrix, 32 768 chains, L = 10: native
     plan = fused fp32-MFMA likelihood + csrc/hmc_model.hip, step-size
-    adaptation on."""
+    adaptation on, timed after the start-up transient."""
     # the data of SURVEY 8d c3: X ~ N(0,1), w* ~ N(0,1), y ~ Bernoulli(
     # sigmoid(X w* / sqrt(D))) from numpy.random.default_rng(0)
     rng = np.random.default_rng(0)
@@ -245,129 +290,206 @@ def extra_config3(torch, zs, dev, n_rows=1000000, n_chains=32768, n_feat=256,
     del X_h, y_h
     zero, one = torch.zeros(n_feat, device=dev), torch.ones(n_feat, device=dev)
 
-    @zs.meta_bayesian_net()
-    def blr():
-        bn = zs.BayesianNet()
-        w = bn.normal('w', zero, std=one, n_samples=n_chains, group_ndims=1)
-        bn.bernoulli('y', zs.linear_logits(w.tensor, X), group_ndims=1,
-                     dtype=torch.float32)
-        return bn
+    def build(n, sharding):
+        @zs.meta_bayesian_net()
+        def blr():
+            bn = zs.BayesianNet()
+            w = bn.normal('w', zero, std=one, n_samples=n, group_ndims=1)
+            bn.bernoulli('y', w.tensor @ X.t(), group_ndims=1,
+                         dtype=torch.float32)
+            return bn
+        # chains start at the data-generating weights (inside the posterior's
+        # bulk: at N = 10^6 its width is ~2e-3, and from w = 0 the
+        # reference's step-size search accepts any step that runs uphill)
+        w = (w_true / n_feat ** 0.5).repeat(n, 1).contiguous()
+        flag = zs.placeholder(bool)
+        hmc = zs.HMC(step_size=1e-3, n_leapfrogs=n_leapfrogs,
+                     adapt_step_size=flag, target_acceptance_rate=0.8, seed=2,
+                     sharding=sharding)
+        op, info = hmc.sample(blr(), {'y': y}, {'w': w})
+        return hmc, op, info, w, (flag,)
 
-    # chains start at the data-generating weights (inside the posterior's
-    # bulk: at N = 10^6 its width is ~2e-3, and from w = 0 the reference's
-    # step-size search accepts any step that runs uphill)
-    w = (w_true / n_feat ** 0.5).repeat(n_chains, 1).contiguous()
-    hmc = zs.HMC(step_size=1e-3, n_leapfrogs=n_leapfrogs,
-                 adapt_step_size=True, target_acceptance_rate=0.8, seed=2)
-    op, info = hmc.sample(blr(), {'y': y}, {'w': w})
-    ms, kern_ms = _time_native_plan(torch, hmc, op, None, 2, 2)
+    state, w_sub, ess_pt, acc_sub = _tuned_start(
+        torch, zs, build, n_sub, 40, 240, (True,))
+    hmc, op, info, w, flags = build(n_chains, None)
+    w.copy_(w_sub.repeat(n_chains // n_sub, 1))
+    hmc.set_state(state)
+
+    def barrier():
+        torch.cuda.synchronize()
+    elapsed, kern_ms, acc = _time_transitions(
+        torch, hmc, op, info, {flags[0]: True}, 1, n_timed, barrier)
+    ms = elapsed / n_timed * 1e3
     flop_eval = 4.0 * n_rows * n_feat * n_chains
     return {
         'workload': 'configs[2]: Bayesian logistic regression, synthetic '
-                    '%d x %d, %d chains started at the data-generating '
-                    'weights (SURVEY c3: "q0 = 0 or MAP + noise"), L=%d, '
-                    'adaptation on' % (
+                    '%d x %d, %d chains, L=%d, step-size adaptation on, the '
+                    'model written with the reference\'s literal '
+                    '`w @ X.T` logits' % (
                         n_rows, n_feat, n_chains, n_leapfrogs),
         'plan': hmc.plan_kind,
         'ms_per_step': ms,
-        'steps': 2,
+        'steps': n_timed,
         'value': n_chains * n_leapfrogs / (ms * 1e-3),
         'unit': 'chain-leapfrog-steps/s',
-        'mean_acceptance': float(info.acceptance_rate.mean().item()),
-        'mean_acceptance_first_transition': getattr(
-            hmc, '_first_transition_acceptance', None),
-        'acceptance_note': ADAPT_TRANSIENT_NOTE,
+        'mean_acceptance': acc,
+        'target_acceptance': 0.8,
         'step_size': float(info.updated_step_size.item()),
-        'roofline': {
-            'bound': 'mfma_f32', 'peak': MFMA_F32_PEAK_TFLOPS,
-            'unit': 'TFLOP/s',
-            'kernel': 'linear_bernoulli_kernel_v2<%d>' % n_feat,
-            'kernel_ms': kern_ms,
-            'achieved': flop_eval / (kern_ms * 1e-3) / 1e12,
-            'frac': flop_eval / (kern_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
-            'algorithmic_flop_per_launch': flop_eval,
-            'sustained_over_transition': (n_leapfrogs + 1) * flop_eval /
-            (ms * 1e-3) / 1e12,
+        'start': TUNED_START_NOTE + ' Subset: %d chains, 40 adaptive + 240 '
+                 'recorded transitions (mean acceptance %.3f).' % (
+                     n_sub, acc_sub),
+        'ess': {
+            'ess_per_chain_per_transition': ess_pt,
+            'ess_per_sec': ess_pt * n_chains * 1e3 / ms,
+            'method': 'zhusuan.diagnostics estimator (min over dims per '
+                      'chain, mean over chains) on the %d-chain subset run '
+                      'with the same step size, scaled to %d chains at the '
+                      'timed rate' % (n_sub, n_chains),
         },
+        'roofline': _mfma_roofline(
+            'linear_bernoulli_kernel_v2<%d>' % n_feat, kern_ms, flop_eval,
+            n_leapfrogs + 1, ms),
     }
 
 
-def extra_config5(torch, zs, dev, n_chains=None, n_docs=5000, n_topics=128,
-                  n_vocab=12419, n_leapfrogs=20):
-    """BASELINE configs[4]: the E-step of the logistic-normal topic model at
-    the lntm_mcem.py shape (chain axes [n_chains, n_docs = 5 000], K = 128,
-    V = 12 419 -- the UCI "nips" vocabulary the example loads), step-size and
-    mass adaptation on, L = 20.  "8 192 chains" is read as n_chains = 8 192
-    (4.1e7 (chain, document) rows, 21 GB per [rows, K] buffer) when that fits
-    the free HBM, else the largest power of two that does; the line says which."""
-    free_b, _ = torch.cuda.mem_get_info()
-    if n_chains is None:
-        n_chains = 8192
-        # q, q_new, p, grad, operand + search cache (grad, operand) + headroom
-        while n_chains > 64 and 9.0 * n_chains * n_docs * n_topics * 4 > free_b:
-            n_chains //= 2
+def lntm_problem(torch, dev, n_docs, n_topics, n_vocab):
+    """documents of ~1 000 tokens drawn from the mixture of a
+    random phi (the "nips" file is not reachable offline); seed 0, so every
+    rank builds the same data."""
     g = torch.Generator(device=dev).manual_seed(0)
     phi = torch.softmax(torch.randn(n_topics, n_vocab, device=dev,
                                     generator=g), -1)
-    # SURVEY 8d c5: documents of ~1 000 tokens drawn from the mixture of a
-    # random phi (the "nips" file is not reachable offline)
     doc_mix = torch.softmax(torch.randn(n_docs, n_topics, device=dev,
                                         generator=g), -1)
     words = torch.multinomial(doc_mix @ phi, 1000, replacement=True,
                               generator=g)
     x = torch.zeros(n_docs, n_vocab, device=dev).scatter_add_(
         1, words, torch.ones(words.shape, device=dev))
-    del doc_mix, words
+    return phi, x
+
+
+def lntm_workload(torch, zs, dev, n_chains, sharding=None, dist=None,
+                  n_docs=5000, n_topics=128, n_vocab=12419, n_leapfrogs=20,
+                  n_sub=4, n_timed=1, n_warm=1):
+    """BASELINE configs[4]: the E-step of the logistic-normal topic model at
+    the lntm_mcem.py shape (chain axes [n_chains, n_docs = 5 000], K = 128,
+    V = 12 419 -- the UCI "nips" vocabulary the example loads), step-size and
+    mass adaptation ON in the timed region, L = 20, the model written with
+    the reference's literal log(softmax(eta) @ phi).  `n_chains` is THIS
+    rank's share of the leading chain axis (weak scaling: 1 024 per GPU, 8 192
+    on 8 GPUs)."""
+    world = 1 if sharding is None else sharding.world_size
+    rank = 0 if sharding is None else sharding.rank
+    phi, x = lntm_problem(torch, dev, n_docs, n_topics, n_vocab)
     eta_mean = torch.zeros(n_docs, n_topics, device=dev)
     eta_logstd = torch.zeros(n_topics, device=dev)
 
-    @zs.meta_bayesian_net()
-    def lntm():
-        bn = zs.BayesianNet()
-        eta = bn.normal('eta', eta_mean, logstd=eta_logstd,
-                        n_samples=n_chains, group_ndims=1)
-        bn.unnormalized_multinomial(
-            'x', zs.log_mixture(torch.softmax(eta.tensor, -1), phi),
-            normalize_logits=False, dtype=torch.float32)
-        return bn
+    def build(n, sh):
+        @zs.meta_bayesian_net()
+        def lntm():
+            bn = zs.BayesianNet()
+            eta = bn.normal('eta', eta_mean, logstd=eta_logstd, n_samples=n,
+                            group_ndims=1)
+            theta = torch.softmax(eta.tensor, -1)
+            pred = (theta.reshape(-1, n_topics) @ phi).reshape(
+                n, n_docs, n_vocab)                 # lntm_mcem.py:40-45
+            bn.unnormalized_multinomial('x', torch.log(pred),
+                                        normalize_logits=False,
+                                        dtype=torch.float32)
+            return bn
+        eta = torch.zeros(n, n_docs, n_topics, device=dev)
+        f_ss, f_m = zs.placeholder(bool), zs.placeholder(bool)
+        hmc = zs.HMC(step_size=1e-3, n_leapfrogs=n_leapfrogs,
+                     adapt_step_size=f_ss, adapt_mass=f_m,
+                     target_acceptance_rate=0.6, seed=3, sharding=sh)
+        op, info = hmc.sample(lntm(), {'x': x}, {'eta': eta})
+        return hmc, op, info, eta, (f_ss, f_m)
 
-    eta = torch.zeros(n_chains, n_docs, n_topics, device=dev)
-    hmc = zs.HMC(step_size=1e-3, n_leapfrogs=n_leapfrogs,
-                 adapt_step_size=True, adapt_mass=True,
-                 target_acceptance_rate=0.6, seed=3)
-    op, info = hmc.sample(lntm(), {'x': x}, {'eta': eta})
-    big = n_chains >= 2048
-    ms, kern_ms = _time_native_plan(torch, hmc, op, None, 1, 1 if big else 3)
-    rows = n_chains * n_docs
-    flop_eval = 4.0 * rows * n_topics * n_vocab
+    # rank 0 burns the subset in; every rank starts from ITS result (one
+    # replicated sampler state, bit for bit)
+    box = [None]
+    if rank == 0:
+        state, eta_sub, ess_pt, acc_sub = _tuned_start(
+            torch, zs, build, n_sub, 40, 150, (True, True))
+        box = [(state, eta_sub.cpu(), ess_pt, acc_sub)]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0)
+    state, eta_sub, ess_pt, acc_sub = box[0]
+    eta_sub = eta_sub.to(dev)
+    hmc, op, info, eta, flags = build(n_chains, sharding)
+    assert n_chains % n_sub == 0
+    eta.copy_(eta_sub.repeat(n_chains // n_sub, 1, 1))
+    hmc.set_state(state)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    elapsed, kern_ms, acc = _time_transitions(
+        torch, hmc, op, info, {flags[0]: True, flags[1]: True}, n_warm,
+        n_timed, barrier)
+    if world > 1:
+        tt = torch.tensor([elapsed, acc], dtype=torch.float64)
+        dist.all_reduce(tt[:1], op=dist.ReduceOp.MAX)
+        dist.all_reduce(tt[1:], op=dist.ReduceOp.SUM)
+        elapsed, acc = float(tt[0].item()), float(tt[1].item()) / world
+    ms = elapsed / n_timed * 1e3
+    rows_rank = n_chains * n_docs
+    rows = rows_rank * world
+    flop_eval = 4.0 * rows_rank * n_topics * n_vocab      # per GPU per launch
+    roof = _mfma_roofline(
+        'linear_bernoulli_kernel_v2<%d> (multinomial mode)' % n_topics,
+        kern_ms, flop_eval, n_leapfrogs + 1, ms)
+    roof['note'] = 'per GPU (rank 0): one launch covers this rank\'s rows'
     return {
         'workload': 'configs[4]: logistic-normal topic model E-step, chain '
                     'axes [n_chains=%d, n_docs=%d] (= %d rows; "8 192 chains" '
-                    'read as n_chains), K=%d, V=%d, L=%d, step-size and mass '
-                    'adaptation on' % (n_chains, n_docs, rows, n_topics,
-                                       n_vocab, n_leapfrogs),
+                    'read as n_chains at 8 GPUs: %d per GPU), K=%d, V=%d, '
+                    'L=%d, step-size and mass adaptation on in the timed '
+                    'region, literal log(softmax(eta) @ phi) spelling' % (
+                        n_chains * world, n_docs, rows, n_chains, n_topics,
+                        n_vocab, n_leapfrogs),
         'plan': hmc.plan_kind,
+        'n_gpus': world,
         'ms_per_step': ms,
-        'steps': 1 if big else 3,
+        'steps': n_timed,
         'value': rows * n_leapfrogs / (ms * 1e-3),
         'unit': '(chain, document)-leapfrog-steps/s',
-        'mean_acceptance': float(info.acceptance_rate.mean().item()),
-        'mean_acceptance_first_transition': getattr(
-            hmc, '_first_transition_acceptance', None),
-        'acceptance_note': ADAPT_TRANSIENT_NOTE,
-        'roofline': {
-            'bound': 'mfma_f32', 'peak': MFMA_F32_PEAK_TFLOPS,
-            'unit': 'TFLOP/s',
-            'kernel': 'linear_bernoulli_kernel_v2<%d> (multinomial mode)'
-                      % n_topics,
-            'kernel_ms': kern_ms,
-            'achieved': flop_eval / (kern_ms * 1e-3) / 1e12,
-            'frac': flop_eval / (kern_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
-            'algorithmic_flop_per_launch': flop_eval,
-            'sustained_over_transition': (n_leapfrogs + 1) * flop_eval /
-            (ms * 1e-3) / 1e12,
+        'mean_acceptance': acc,
+        'target_acceptance': 0.6,
+        'step_size': float(info.updated_step_size.item()),
+        'collective': 'none' if world == 1 else
+                      'ONE all-reduce of %d doubles per transition '
+                      '[sum acc, flag, colsum[2 x %d]]' % (
+                          2 + 2 * n_topics, n_topics),
+        'rccl_ranks': 0 if sharding is None else sharding.rccl_ranks,
+        'start': TUNED_START_NOTE + ' Subset: %d chains x %d docs, 40 '
+                 'adaptive + 150 recorded transitions (mean acceptance '
+                 '%.3f).' % (n_sub, n_docs, acc_sub),
+        'ess': {
+            'ess_per_row_per_transition': ess_pt,
+            'ess_per_sec': ess_pt * rows * 1e3 / ms,
+            'method': 'zhusuan.diagnostics estimator (min over the K dims '
+                      'per (chain, document) row, mean over rows) on the '
+                      'subset run with the same step size and mass, scaled '
+                      'to %d rows at the timed rate' % rows,
         },
+        'roofline': roof,
     }
+
+
+def extra_config5(torch, zs, dev, n_chains=None, **kw):
+    """configs[4] on ONE GPU at the full named shape (n_chains = 8 192, 4.1e7
+    rows, 21 GB per [rows, K] buffer) when that fits the free HBM, else the
+    largest power of two that does; the line says which."""
+    free_b, _ = torch.cuda.mem_get_info()
+    if n_chains is None:
+        n_chains = 8192
+        # q, q_new, p, grad, operand + search cache (grad, operand) + headroom
+        while n_chains > 64 and 9.0 * n_chains * 5000 * 128 * 4 > free_b:
+            n_chains //= 2
+    return lntm_workload(torch, zs, dev, n_chains, **kw)
 
 
 def make_sharding(dist, torch, ChainSharding, backend, dev, **layout):
@@ -407,6 +529,44 @@ def make_sharding(dist, torch, ChainSharding, backend, dev, **layout):
         % box.get('err', 'bootstrap did not return within 120 s'))
 
 
+def run_lntm_line(args, torch, zs, dist, ChainSharding, dev, world, rank,
+                  backend):
+    """`--workload lntm`: BASELINE configs[4] as the line's own workload.
+    A step = one HMC transition (L = 20, 21 likelihood + gradient
+    evaluations) over every rank's [n_chains/N, n_docs] rows."""
+    sharding, note = None, 'no collective'
+    n = args.lntm_chains_per_gpu
+    if world > 1:
+        # (the layout is derived by the sampler: flat (chain, document) rows)
+        sharding, note = make_sharding(dist, torch, ChainSharding, backend,
+                                       dev)
+    r = lntm_workload(torch, zs, dev, n, sharding=sharding, dist=dist,
+                      n_docs=args.lntm_docs, n_vocab=args.lntm_vocab,
+                      n_timed=args.steps, n_warm=args.warmup)
+    if rank == 0:
+        out = {
+            'metric': 'leapfrog-steps/sec', 'value': r['value'],
+            'unit': r['unit'], 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': r['ms_per_step'],
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': r['workload'],
+                       'parallelism': 'leading chain axis sharded over %d '
+                                      'GPU(s); %s' % (world, r['collective'])},
+            'collective_backend': note,
+        }
+        for k in ('plan', 'mean_acceptance', 'target_acceptance', 'step_size',
+                  'rccl_ranks', 'start', 'ess', 'roofline'):
+            out[k] = r[k]
+        print(json.dumps(out))
+    if world > 1:
+        try:
+            sharding.close()
+        except Exception as e:                       # noqa: BLE001
+            sys.stderr.write('communicator teardown: %r\n' % (e,))
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     import torch
@@ -438,6 +598,11 @@ def main():
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group(backend='gloo', rank=rank, world_size=world)
+    if args.workload == 'lntm':
+        run_lntm_line(args, torch, zs, dist, ChainSharding, dev, world, rank,
+                      backend)
+        return
+    if world > 1:
         sharding, collective_note = make_sharding(
             dist, torch, ChainSharding, backend, dev,
             chain_offset=rank * args.chains_per_gpu,
@@ -729,23 +894,65 @@ def main():
             if 'error' in out['cpu_baseline']:
                 out['cpu_baseline'] = out['cpu_baseline_numpy_1core']
             out['cpu_reference_over_shim'] = cpu_reference_recorded()
-        if world == 1 and not args.no_extra_configs:
-            # the MFMA-bound configurations of BASELINE.json, after the
-            # headline: each frees its buffers before the next starts
-            del x
+    else:
+        out = {}
+    # the MFMA-bound configurations of BASELINE.json, after the headline
+    # (each frees its buffers before the next starts).  N = 1: configs[2] and
+    # configs[4] at its full one-GPU shape.  N > 1: configs[4] with its
+    # leading chain axis sharded over the ranks (1 024 chains per GPU = 8 192
+    # at N = 8), step-size and mass adaptation on, ONE all-reduce of
+    # 2 + 2 K doubles per transition on the same communicator.
+    extras = None
+    if not args.no_extra_configs:
+        # N > 1: the sharded extra has collectives in it; should a rank fail
+        # or RCCL stall there, the headline measured above must still be
+        # printed -- a watchdog emits it and ends the process
+        watchdog = None
+        if world > 1:
+            import threading
+
+            def give_up():
+                if rank == 0:
+                    out['extra_configs'] = [{
+                        'workload': 'configs[4] sharded', 'error':
+                        'did not finish within %d s' % EXTRA_TIMEOUT_S}]
+                    print(json.dumps(out))
+                    sys.stdout.flush()
+                os._exit(0)
+            watchdog = threading.Timer(EXTRA_TIMEOUT_S + (0 if rank == 0
+                                                          else 5), give_up)
+            watchdog.daemon = True
+            watchdog.start()
+        del x
+        torch.cuda.empty_cache()
+        from zhusuan_amd import _ops
+        extras = []
+        if world == 1:
+            todo = ((extra_config3, {}),
+                    (extra_config5, {'n_chains': args.config5_chains}))
+        else:
+            todo = ((lntm_workload, dict(
+                n_chains=args.lntm_chains_per_gpu,
+                sharding=sharding.relayout(), dist=dist,
+                n_docs=args.lntm_docs, n_vocab=args.lntm_vocab)),)
+        for fn, kw in todo:
+            try:
+                extras.append(fn(torch, zs, dev, **kw))
+            except Exception as e:           # report, never lose the headline
+                if world > 1:
+                    # (the peers are in a collective: let the watchdog print)
+                    sys.stderr.write('rank %d: %r\n' % (rank, e))
+                    time.sleep(EXTRA_TIMEOUT_S + 10)
+                extras.append({'workload': fn.__name__,
+                               'error': repr(e)[:300]})
+            _ops.clear_caches()
             torch.cuda.empty_cache()
-            extras = []
-            for fn, kw in ((extra_config3, {}),
-                           (extra_config5,
-                            {'n_chains': args.config5_chains})):
-                try:
-                    extras.append(fn(torch, zs, dev, **kw))
-                except Exception as e:       # report, never lose the headline
-                    extras.append({'workload': fn.__name__,
-                                   'error': repr(e)[:300]})
-                from zhusuan_amd import _ops
-                _ops.clear_caches()
-                torch.cuda.empty_cache()
+        if world > 1:
+            barrier()
+            watchdog.cancel()
+
+    if rank == 0:
+        if extras is not None:
             out['extra_configs'] = extras
         print(json.dumps(out))
     if world > 1:

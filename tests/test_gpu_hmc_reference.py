@@ -24,9 +24,12 @@ def env():
 
 # how the two model-family cases are written on the device side: the fused
 # spelling on the native plan, the same spelling on the autograd-driven
-# generic plan, and the reference's literal dense expression
-VARIANTS = {'blr': ('native', 'generic', 'dense'),
-            'lntm': ('native', 'generic', 'dense'),
+# generic plan, the reference's literal dense expression (recognised
+# symbolically, zhusuan_amd/_symbolic.py: native plan too), and a near miss
+# of it (`latent * 1.0` first) that must fall back to the generic plan and
+# still reproduce the traces
+VARIANTS = {'blr': ('native', 'generic', 'dense', 'nearmiss'),
+            'lntm': ('native', 'generic', 'dense', 'nearmiss'),
             'pmf': ('fused', 'dense')}
 
 
@@ -40,11 +43,15 @@ def _build_blr(zs, torch, dev, case, qs, variant):
         bn = zs.BayesianNet()
         w = bn.normal('w', torch.zeros(D, device=dev), std=1., n_samples=C,
                       group_ndims=1)
-        logits = w.tensor @ X.t() if variant == 'dense' else \
-            zs.linear_logits(w.tensor, X)
+        if variant == 'dense':
+            logits = w.tensor @ X.t()            # the reference's spelling
+        elif variant == 'nearmiss':
+            logits = (w.tensor * 1.0) @ X.t()
+        else:
+            logits = zs.linear_logits(w.tensor, X)
         bn.bernoulli('y', logits, group_ndims=1)
         return bn
-    plan = 'linear_bernoulli' if variant == 'native' else 'generic'
+    plan = 'linear_bernoulli' if variant in ('native', 'dense') else 'generic'
     return model(), plan, {'y': y}
 
 
@@ -61,11 +68,12 @@ def _build_lntm(zs, torch, dev, case, qs, variant):
         eta = bn.normal('eta', p['eta_mean'].unsqueeze(0).repeat(n_docs, 1),
                         logstd=p['eta_logstd'], n_samples=n_chains,
                         group_ndims=1)
-        theta = torch.softmax(eta.tensor, -1)
+        theta = torch.softmax(eta.tensor * 1.0 if variant == 'nearmiss'
+                              else eta.tensor, -1)
         beta = bn.normal('beta', torch.zeros(K, V, device=dev), logstd=10.0,
                          group_ndims=1)
         phi = torch.softmax(beta.tensor, -1)
-        if variant == 'dense':
+        if variant in ('dense', 'nearmiss'):     # lntm_mcem.py:39-46
             logits = torch.log((theta.reshape(-1, K) @ phi).reshape(
                 n_chains, n_docs, V))
         else:
@@ -76,7 +84,8 @@ def _build_lntm(zs, torch, dev, case, qs, variant):
     model = lntm()
     model.log_joint = lambda bn: (bn.cond_log_prob('eta') +
                                   bn.cond_log_prob('x'))
-    plan = 'mixture_multinomial' if variant == 'native' else 'generic'
+    plan = 'mixture_multinomial' if variant in ('native', 'dense') \
+        else 'generic'
     return model, plan, {'x': p['x'], 'beta': p['beta']}
 
 

@@ -128,12 +128,20 @@ def test_two_rank_sharded_gpu_run_matches_single_process(tmp_path):
 
 def test_bench_two_ranks_prints_contract_json():
     r = _launch(['bench.py', '--gpus', '2', '--steps', '10', '--warmup', '2',
-                 '--chains-per-gpu', '4096', '--no-ess'], 2,
+                 '--chains-per-gpu', '4096', '--no-ess',
+                 '--lntm-chains-per-gpu', '8', '--lntm-docs', '48',
+                 '--lntm-vocab', '700'], 2,
                 {'ZSHMC_DIST_BACKEND': 'gloo'})
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
     out = json.loads(line)
     assert out['n_gpus'] == 2 and out['steps'] == 10 and out['warmup'] == 2
+    # configs[4] rides along at N > 1: leading chain axis sharded, literal
+    # spelling on the native plan, adaptation on in the timed region
+    (extra,) = out['extra_configs']
+    assert extra['plan'] == 'mixture_multinomial' and extra['n_gpus'] == 2
+    assert 'ONE all-reduce of 258 doubles' in extra['collective']
+    assert 0.2 < extra['mean_acceptance'] <= 1.0 and extra['value'] > 0
     assert out['scaling'] == 'weak' and out['higher_is_better'] is True
     assert out['config']['n_chains_total'] == 8192
     assert out['value'] > 0 and 0.3 < out['mean_acceptance'] <= 1.0
@@ -255,3 +263,22 @@ def test_direct_rccl_communicator(tmp_path, world):
         np.testing.assert_allclose(ranks[0]['mass'], mass1, rtol=1e-5)
         close = np.isclose(x, x1, atol=1e-4).all(axis=1)
         assert close.mean() > 0.98
+
+
+def test_bench_lntm_workload_two_ranks():
+    """`bench.py --workload lntm --gpus 2`: BASELINE configs[4] as the line's
+    own workload (reduced sizes here), the way the driver would launch it."""
+    r = _launch(['bench.py', '--gpus', '2', '--steps', '3', '--warmup', '1',
+                 '--workload', 'lntm', '--lntm-chains-per-gpu', '8',
+                 '--lntm-docs', '48', '--lntm-vocab', '700'], 2,
+                {'ZSHMC_DIST_BACKEND': 'gloo'})
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
+    out = json.loads(line)
+    assert out['n_gpus'] == 2 and out['steps'] == 3 and out['scaling'] == 'weak'
+    assert out['plan'] == 'mixture_multinomial'
+    assert out['roofline']['bound'] == 'mfma' and out['roofline']['frac'] > 0
+    assert out['value'] == pytest.approx(
+        2 * 8 * 48 * 20 / (out['ms_per_step'] * 1e-3), rel=1e-6)
+    assert 0.2 < out['mean_acceptance'] <= 1.0
+    assert out['ess']['ess_per_sec'] > 0

@@ -1,0 +1,81 @@
+"""The N > 1 path of the NON-fused plans on real kernels: two processes
+(gloo rendezvous, both on cuda:0) shard the leading chain axis of the
+topic-model E step (BASELINE configs[4] family, `_DenseLikelihoodPlan`, mass
+adaptation on: ONE all-reduce of [sum acc, flag, colsum[2 K]] per
+transition) and of Bayesian logistic regression, on the native plans and on
+the autograd-driven generic plan.  Adaptation off: the rank-concatenated
+states equal the single-process run bit for bit (RNG keyed by the GLOBAL
+chain index; per-document prior rows addressed with a row period under the
+chain offset).  Adaptation on: step size, tuner state and mass agree across
+ranks and with the single-process run.  Rank 0 alone reads
+`updated_step_size` and `get_state()` every iteration: neither communicates.
+"""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import helpers_sharded_cases as cases
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.fixture(scope='module')
+def ranks(tmp_path_factory):
+    out = tmp_path_factory.mktemp('sharded_plans')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()),
+           os.path.join(HERE, 'sharded_plan_worker.py'), str(out)]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    return [np.load(str(out / ('rank%d.npz' % i))) for i in range(2)]
+
+
+@pytest.mark.parametrize('family', ['lntm', 'blr'])
+@pytest.mark.parametrize('native', [True, False])
+def test_sharded_plan_matches_single_process(ranks, family, native):
+    import torch
+    import zhusuan_amd as zs
+    dev = torch.device('cuda', 0)
+    n = getattr(cases, family + '_problem')()['q0'].shape[0]
+    key = lambda adapt, k: '%s/%d/%d/%s' % (family, native, adapt, k)
+
+    # adaptation off: bit-exact whatever the sharding
+    one = cases.run(zs, torch, dev, family, 0, n, False, None, native)
+    q = np.concatenate([r[key(0, 'q')] for r in ranks])
+    acc = np.concatenate([r[key(0, 'acc')].reshape(-1) for r in ranks])
+    np.testing.assert_array_equal(q, one['q'])
+    np.testing.assert_array_equal(acc, one['acc'].reshape(-1))
+
+    # adaptation on (step size + mass): replicated state identical on both
+    # ranks and equal to the single-process run up to summation order
+    one = cases.run(zs, torch, dev, family, 0, n, True, None, native)
+    for k in ('step_size', 'state', 'mass'):
+        np.testing.assert_array_equal(ranks[0][key(1, k)], ranks[1][key(1, k)])
+    np.testing.assert_allclose(ranks[0][key(1, 'state')], one['state'],
+                               rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(ranks[0][key(1, 'mass')], one['mass'],
+                               rtol=2e-5)
+    q = np.concatenate([r[key(1, 'q')] for r in ranks])
+    close = np.isclose(q, one['q'], atol=2e-4).reshape(q.shape[0], -1).all(1)
+    assert close.mean() >= 0.9, close
+    # rank 0 read the step size after every run without its peer
+    eps = ranks[0][key(1, 'eps')]
+    assert eps.shape == (cases.N_ITERS,) and np.isfinite(eps).all()
+    assert float(eps[-1]) == float(ranks[1][key(1, 'step_size')])

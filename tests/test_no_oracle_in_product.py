@@ -27,7 +27,7 @@ def test_bench_uses_oracle_only_in_cpu_baseline():
     # functions only, which sit in front of everything that runs the product
     assert len(uses) == 3
     start = src.index('def cpu_baseline')
-    end = src.index('def _time_native_plan')
+    end = src.index('def _tuned_start')
     assert all(start < u < end for u in uses)
     for fn in ('cpu_baseline_numpy', 'cpu_baseline_torch',
                'cpu_baseline_parallel'):

@@ -1,0 +1,125 @@
+"""zhusuan_amd/_symbolic.py on CPU tensors: the reference's literal dense
+spellings (univariate.py:398-403 with logits = matmul(w, X^T);
+lntm_mcem.py:39-46) stay symbolic until a distribution lowers them to the
+fused likelihood's lazy operands; every other op computes on the plain
+tensors exactly what it would without the wrapper."""
+import numpy as np
+import pytest
+import torch
+
+import zhusuan_amd as zs
+from zhusuan_amd import _symbolic as sym
+
+
+def _latent(*shape, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g)
+
+
+def test_literal_linear_logits_lower_to_the_fused_operand():
+    w, X = _latent(6, 8), _latent(40, 8, seed=1)
+    s = sym.wrap_latent(w)
+    for logits in (s @ X.t(), torch.matmul(s, X.t()), s.matmul(X.t()),
+                   torch.mm(s, X.t()), torch.nn.functional.linear(s, X)):
+        assert isinstance(logits, sym.Sym) and logits.shape == (6, 40)
+        lazy = sym.lower_bernoulli_logits(logits)
+        assert isinstance(lazy, zs.distributions.LinearLogits)
+        assert lazy.w is w
+        assert lazy.X.data_ptr() == X.data_ptr() and lazy.X.shape == X.shape
+        assert lazy.X.is_contiguous()
+        torch.testing.assert_close(logits.force(), w @ X.t())
+    d = zs.distributions.Bernoulli(s @ X.t(), group_ndims=1)
+    assert d._lazy is not None and d._lazy.w is w
+    assert tuple(d.get_batch_shape()) == (6, 40)
+
+
+def test_literal_topic_model_logits_lower_to_the_fused_operand():
+    n, n_docs, K, V = 3, 4, 8, 20
+    eta, phi = _latent(n, n_docs, K), torch.softmax(_latent(K, V, seed=2), -1)
+    s = sym.wrap_latent(eta)
+    theta = torch.softmax(s, -1)                        # lntm_mcem.py:39
+    pred = (theta.reshape(-1, K) @ phi).reshape(n, n_docs, V)   # :40-45
+    logits = torch.log(pred)                                     # :46
+    assert isinstance(logits, sym.Sym) and logits.shape == (n, n_docs, V)
+    lazy = sym.lower_multinomial_logits(logits)
+    assert isinstance(lazy, zs.distributions.LogMixture)
+    assert lazy.softmax_source is eta and lazy.phi is phi
+    assert tuple(lazy.shape) == (n, n_docs, V) and lazy._theta is None
+    torch.testing.assert_close(lazy.theta, torch.softmax(eta, -1))
+    torch.testing.assert_close(
+        logits.force(), torch.log(torch.softmax(eta, -1) @ phi))
+    # without the reshapes, and through zs.log_mixture on a symbolic theta
+    lazy2 = sym.lower_multinomial_logits(torch.log(torch.softmax(s, -1) @ phi))
+    assert lazy2.softmax_source is eta
+    lazy3 = zs.log_mixture(torch.softmax(s, -1), phi)
+    assert lazy3.softmax_source is eta and tuple(lazy3.shape) == (n, n_docs, V)
+    d = zs.distributions.UnnormalizedMultinomial(
+        logits, normalize_logits=False, dtype=torch.float32)
+    assert d._lazy is not None and d._lazy.softmax_source is eta
+    # re-normalised logits need the dense tensor (multivariate.py:440-441)
+    d = zs.distributions.UnnormalizedMultinomial(logits, dtype=torch.float32)
+    assert d._lazy is None and not isinstance(d.logits, sym.Sym)
+
+
+@pytest.mark.parametrize('near_miss', [
+    lambda s, X, phi: torch.softmax(s * 1.0, -1) @ phi,        # scaled latent
+    lambda s, X, phi: torch.softmax(s, 0) @ phi,               # other axis
+    lambda s, X, phi: torch.log(torch.softmax(s, -1) @ phi + 1e-6),
+    lambda s, X, phi: (s @ X.t()) * 2.0,
+    lambda s, X, phi: s.t() @ _latent(6, 5, seed=9),
+    lambda s, X, phi: (s ** 2).sum(-1) + torch.sin(s).mean(),
+    lambda s, X, phi: torch.cat([s, s], 0)[1:4] @ X.t(),
+    lambda s, X, phi: s[:, :4] @ X.t()[:4],
+])
+def test_everything_else_computes_on_the_plain_tensor(near_miss):
+    w = _latent(6, 8).requires_grad_(True)
+    X, phi = _latent(40, 8, seed=1), torch.softmax(_latent(8, 20, seed=2), -1)
+    want = near_miss(w, X, phi)
+    got = sym.force(near_miss(sym.wrap_latent(w), X, phi))
+    assert not isinstance(got, sym.Sym)
+    torch.testing.assert_close(got, want, rtol=0, atol=0)
+    g_want, = torch.autograd.grad(want.sum(), w)
+    g_got, = torch.autograd.grad(got.sum(), w)
+    torch.testing.assert_close(g_got, g_want, rtol=0, atol=0)
+    # a distribution handed a symbol it cannot lower sees the value
+    assert not isinstance(sym.lower_bernoulli_logits(
+        near_miss(sym.wrap_latent(w), X, phi)), sym.Sym)
+
+
+def test_metadata_and_meta_latents():
+    w = _latent(6, 8)
+    s = sym.wrap_latent(w)
+    assert s.shape == (6, 8) and s.dim() == 2 and s.dtype == torch.float32
+    assert s.device == w.device and s.size(0) == 6 and not s.requires_grad
+    assert sym.wrap_latent(s) is s and sym.force(s) is w
+    # a META latent against real constants: nothing executes, shapes follow
+    m = sym.wrap_latent(torch.empty(6, 8, device='meta'))
+    X = _latent(40, 8, seed=1)
+    lazy = sym.lower_bernoulli_logits(m @ X.t())
+    assert lazy.w.is_meta and tuple(lazy.shape) == (6, 40)
+
+
+def test_model_function_with_literal_spelling_builds_fused_nodes():
+    n, N, D = 5, 30, 8
+    X = _latent(N, D, seed=1)
+    y = (torch.rand(N) < 0.5).float()
+
+    @zs.meta_bayesian_net()
+    def blr():
+        bn = zs.BayesianNet()
+        w = bn.normal('w', torch.zeros(D), std=1., n_samples=n, group_ndims=1)
+        bn.bernoulli('y', w.tensor @ X.t(), group_ndims=1,
+                     dtype=torch.float32)
+        return bn
+    w = _latent(n, D, seed=3)
+    bn = blr().observe(w=sym.wrap_latent(w), y=y)
+    assert bn.get('y').dist._lazy.w is w
+    # the StochasticTensor itself in the expression (bn.py:178-193 mixin)
+    @zs.meta_bayesian_net()
+    def blr2():
+        bn = zs.BayesianNet()
+        w = bn.normal('w', torch.zeros(D), std=1., n_samples=n, group_ndims=1)
+        bn.bernoulli('y', w @ X.t(), group_ndims=1, dtype=torch.float32)
+        return bn
+    bn = blr2().observe(w=sym.wrap_latent(w), y=y)
+    assert bn.get('y').dist._lazy.w is w

@@ -1,0 +1,283 @@
+"""Recognition of the reference's LITERAL dense spellings.
+
+The reference writes its dense-likelihood models with ordinary graph ops:
+
+    y ~ Bernoulli(logits = tf.matmul(w, X, transpose_b=True))
+                                        (univariate.py:398-403 + hmc.py:430-432)
+    x ~ UnnormalizedMultinomial(tf.log(tf.matmul(tf.nn.softmax(eta), phi)))
+                                        (examples/topic_models/lntm_mcem.py:39-46)
+
+TensorFlow builds a graph first, so nothing is materialised before the
+executor runs.  torch is eager: `w @ X.T` at BASELINE configs[2] is a
+[32 768, 10^6] tensor (131 GB) before any distribution sees it.  So the
+latents handed to a model function travel as `Sym` tensors -- wrapper
+subclasses WITHOUT storage whose `__torch_function__` keeps the few ops of
+those two spellings symbolic
+
+    latent -> softmax(., -1) -> reshape(leading axes) -> matmul(., constant)
+           -> reshape(leading axes) -> log
+
+and executes everything else on the real tensors (the wrapper is forced --
+replaced by the value of its expression -- the moment an op outside the
+table touches it, so an arbitrary model function computes exactly what it
+would on plain tensors).  `Bernoulli` / `UnnormalizedMultinomial` lower a
+symbolic `logits` argument to the lazy operands of the fused fp32-MFMA
+likelihood (`LinearLogits`, `LogMixture`): the literal spelling then runs on
+the same native plans as `zs.linear_logits` / `zs.log_mixture`.
+"""
+import torch
+from torch.utils._pytree import tree_map
+
+__all__ = ['Sym', 'wrap_latent', 'force', 'lower_bernoulli_logits',
+           'lower_multinomial_logits']
+
+_T = torch.Tensor
+
+
+def _getter(name):
+    return getattr(_T, name).__get__
+
+
+# ops that only look at the wrapper's metadata: answered by the wrapper
+_METADATA = {
+    _getter('shape'), _getter('dtype'), _getter('device'), _getter('ndim'),
+    _getter('is_cuda'), _getter('is_meta'), _getter('layout'),
+    _getter('requires_grad'), _getter('grad_fn'), _getter('is_leaf'),
+    _getter('is_sparse'), _getter('is_quantized'), _getter('names'),
+    _T.dim, _T.size, _T.numel, _T.nelement, _T.ndimension,
+    _T.is_floating_point, _T.is_complex, _T.element_size, _T.__len__,
+    _T.get_device, _T.__repr__, _T.__hash__, _T.__format__,
+}
+
+_SOFTMAX = {torch.softmax, torch.nn.functional.softmax, _T.softmax}
+_MATMUL = {torch.matmul, _T.matmul, _T.__matmul__, torch.mm, _T.mm}
+_RESHAPE = {torch.reshape, _T.reshape, _T.view}
+_LOG = {torch.log, _T.log}
+
+
+class Sym(torch.Tensor):
+    """A tensor-shaped symbol: `expr` is one of
+         ('latent', tensor)
+         ('softmax', Sym)                 over the last axis
+         ('reshape', Sym)                 leading axes only (last axis kept)
+         ('matmul', Sym, tensor[K, N])
+         ('log', Sym)
+    """
+
+    @staticmethod
+    def __new__(cls, expr, shape, dtype, device):
+        r = _T._make_wrapper_subclass(cls, tuple(shape), dtype=dtype,
+                                      device=device, requires_grad=False)
+        r._expr = expr
+        r._value = None
+        r._meta = (tuple(int(d) for d in shape), dtype, torch.device(device))
+        return r
+
+    def __init__(self, *a, **k):
+        pass
+
+    # -- the value of the expression (computed once) -------------------------
+    def force(self):
+        if self._value is None:
+            e = self._expr
+            kind = e[0]
+            if kind == 'latent':
+                v = e[1]
+            elif kind == 'softmax':
+                v = torch.softmax(e[1].force(), -1)
+            elif kind == 'reshape':
+                v = e[1].force().reshape(tuple(_shape_of(self)))
+            elif kind == 'matmul':
+                v = e[1].force() @ e[2]
+            else:
+                v = torch.log(e[1].force())
+            self._value = v
+        return self._value
+
+    def __repr__(self):
+        return 'Sym(%s, shape=%s)' % (_describe(self._expr), self._meta[0])
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func in _METADATA:
+            with torch._C.DisableTorchFunctionSubclass():
+                return func(*args, **kwargs)
+        out = _symbolic_rule(func, args, kwargs)
+        if out is not None:
+            return out
+        # anything else: on the real tensors
+        args, kwargs = tree_map(_forced, (args, kwargs))
+        return func(*args, **kwargs)
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        # reached only by callers that skip __torch_function__ (C++ entry
+        # points): same rule, the op runs on the values
+        args, kwargs = tree_map(_forced, (args, kwargs or {}))
+        return func(*args, **kwargs)
+
+
+def _shape_of(t):
+    return t._meta[0]
+
+
+def _describe(e):
+    if e[0] == 'latent':
+        return 'latent'
+    if e[0] == 'matmul':
+        return 'matmul(%s, const%s)' % (_describe(e[1]._expr),
+                                        list(e[2].shape))
+    return '%s(%s)' % (e[0], _describe(e[1]._expr))
+
+
+def _forced(x):
+    return x.force() if isinstance(x, Sym) else x
+
+
+def force(x):
+    """The plain tensor a (possibly symbolic) value stands for."""
+    return _forced(x)
+
+
+def wrap_latent(t):
+    """The latent `t` as the root symbol (idempotent)."""
+    if isinstance(t, Sym) or not isinstance(t, torch.Tensor):
+        return t
+    return Sym(('latent', t), t.shape, t.dtype, t.device)
+
+
+def _kind(s):
+    return s._expr[0]
+
+
+def _chain_kind(s):
+    """Kind of the expression with leading-axes reshapes looked through."""
+    while _kind(s) == 'reshape':
+        s = s._expr[1]
+    return _kind(s)
+
+
+def _norm_dim(dim, rank):
+    return dim + rank if dim < 0 else dim
+
+
+def _resolve_shape(shape_args, numel):
+    if len(shape_args) == 1 and isinstance(shape_args[0], (tuple, list,
+                                                           torch.Size)):
+        shape_args = tuple(shape_args[0])
+    shape = [int(s) for s in shape_args]
+    if shape.count(-1) > 1:
+        return None
+    if -1 in shape:
+        known = 1
+        for s in shape:
+            if s != -1:
+                known *= s
+        if known == 0 or numel % known:
+            return None
+        shape[shape.index(-1)] = numel // known
+    n = 1
+    for s in shape:
+        n *= s
+    return tuple(shape) if n == numel else None
+
+
+def _symbolic_rule(func, args, kwargs):
+    """The new symbol if `func(*args)` continues one of the two spellings,
+    else None."""
+    if not args or not isinstance(args[0], Sym):
+        return None
+    x = args[0]
+    xs, x_dtype, x_device = x._meta
+    if func in _SOFTMAX:
+        dim = kwargs.get('dim', args[1] if len(args) > 1 else None)
+        extra = {k for k in kwargs if k not in ('dim', '_stacklevel')}
+        if dim is None or extra or len(args) > 2 or not xs or \
+                kwargs.get('dtype') is not None:
+            return None
+        if _kind(x) == 'latent' and _norm_dim(int(dim), len(xs)) == len(xs) - 1:
+            return Sym(('softmax', x), xs, x_dtype, x_device)
+        return None
+    if func in _RESHAPE:
+        if kwargs or _chain_kind(x) not in ('latent', 'softmax', 'matmul'):
+            return None
+        numel = 1
+        for s in xs:
+            numel *= s
+        shape = _resolve_shape(args[1:], numel)
+        if shape is None or not shape or not xs or shape[-1] != xs[-1]:
+            return None
+        return Sym(('reshape', x), shape, x_dtype, x_device)
+    if func in _MATMUL:
+        if kwargs or len(args) != 2:
+            return None
+        rhs = args[1]
+        if isinstance(rhs, Sym) or not isinstance(rhs, torch.Tensor) or \
+                rhs.dim() != 2 or rhs.requires_grad or not xs or \
+                rhs.shape[0] != xs[-1] or rhs.dtype != x_dtype or \
+                (rhs.device != x_device and x_device.type != 'meta'):
+            return None
+        if _chain_kind(x) not in ('latent', 'softmax'):
+            return None
+        if func in (torch.mm, _T.mm) and len(xs) != 2:
+            return None
+        return Sym(('matmul', x, rhs), xs[:-1] + (int(rhs.shape[1]),),
+                   x_dtype, x_device)
+    if func in _LOG:
+        if kwargs or len(args) != 1 or _chain_kind(x) != 'matmul':
+            return None
+        return Sym(('log', x), xs, x_dtype, x_device)
+    if func is torch.nn.functional.linear:
+        # F.linear(w, X) = w @ X^T
+        if len(args) == 2 and not kwargs and isinstance(args[1], _T) and \
+                not isinstance(args[1], Sym) and args[1].dim() == 2:
+            return _symbolic_rule(torch.matmul, (x, args[1].t()), {})
+    return None
+
+
+def _strip_reshapes(s):
+    while _kind(s) == 'reshape':
+        s = s._expr[1]
+    return s
+
+
+def softmax_source(theta):
+    """The latent tensor if `theta` is the symbol softmax(latent, -1)
+    (leading-axes reshapes looked through), else None."""
+    if not isinstance(theta, Sym):
+        return None
+    t = _strip_reshapes(theta)
+    return t._expr[1]._expr[1] if _kind(t) == 'softmax' else None
+
+
+def lower_bernoulli_logits(logits):
+    """`latent @ const[D, N]` -> LinearLogits(latent, const^T); any other
+    symbol -> its value."""
+    if not isinstance(logits, Sym):
+        return logits
+    from .distributions.univariate import LinearLogits
+    s = logits
+    if _kind(s) == 'matmul' and _kind(s._expr[1]) == 'latent' and \
+            s._meta[1] == torch.float32:
+        w = s._expr[1]._expr[1]
+        return LinearLogits(w, s._expr[2].t())
+    return logits.force()
+
+
+def lower_multinomial_logits(logits):
+    """`log(softmax(latent) @ phi)` (leading-axes reshapes anywhere in
+    between) -> LogMixture over the latent; any other symbol -> its value."""
+    if not isinstance(logits, Sym):
+        return logits
+    from .distributions.multivariate import LogMixture
+    s = _strip_reshapes(logits)
+    if _kind(s) == 'log' and logits._meta[1] == torch.float32:
+        m = _strip_reshapes(s._expr[1])
+        if _kind(m) == 'matmul':
+            t = _strip_reshapes(m._expr[1])
+            if _kind(t) == 'softmax':
+                latent = t._expr[1]._expr[1]
+                return LogMixture.of_softmax(latent, m._expr[2],
+                                             _shape_of(logits)[:-1])
+    return logits.force()

@@ -87,7 +87,21 @@ class ChainSharding(object):
             return 0
         return int(_capi.load().zshmc_comm_world_size(self._comm))
 
+    def relayout(self, chain_offset=None, n_chains_global=None):
+        """The same communicator for another sampler whose chains sit
+        differently in the global chain axis (None, None: derived from the
+        ranks' local counts at plan build).  The view does not own the
+        communicator: close the original."""
+        import copy
+        view = copy.copy(self)
+        view._chain_offset = chain_offset
+        view._n_chains_global = n_chains_global
+        view._owner = False
+        return view
+
     def close(self):
+        if not getattr(self, '_owner', True):
+            return
         if self._comm is not None:
             _capi.call('zshmc_comm_destroy', self._comm)
             self._comm = None

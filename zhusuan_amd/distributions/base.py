@@ -3,22 +3,30 @@ and the sample(n_samples) squeeze rule.  Mirrors reference
 zhusuan/distributions/base.py:17-332 on torch device tensors."""
 import torch
 
+from .. import _symbolic
+
 from ..utils import broadcast_shapes
 
 __all__ = ['Distribution']
 
 
-def as_tensor(value, dtype=None, device=None):
+def as_tensor(value, dtype=None, device=None, keep_symbolic=False):
     """tf.convert_to_tensor analogue.  Python / NumPy values become tensors
-    on `device` (default: current HIP device when available)."""
+    on `device` (default: current HIP device when available).  A symbolic
+    latent expression (zhusuan_amd/_symbolic.py) is replaced by its value
+    unless the caller keeps it symbolic (an observed latent stays a symbol so
+    that the model function's own ops on it can be recognised)."""
     if isinstance(value, torch.Tensor):
+        if isinstance(value, _symbolic.Sym) and not (
+                keep_symbolic and (dtype is None or value.dtype == dtype)):
+            value = value.force()
         t = value
         if dtype is not None and t.dtype != dtype:
             t = t.to(dtype)
         return t
     if hasattr(value, 'tensor') and not isinstance(value, (list, tuple)):
         # StochasticTensor -> its current value (bn.py:164-175)
-        return as_tensor(value.tensor, dtype, device)
+        return as_tensor(value.tensor, dtype, device, keep_symbolic)
     if device is None:
         device = default_device()
     return torch.as_tensor(value, dtype=dtype, device=device)

@@ -7,7 +7,7 @@ import torch
 
 from ..utils import broadcast_shapes
 
-from .. import _capi, _ops
+from .. import _capi, _ops, _symbolic
 from ..utils import next_op_offset
 from .base import Distribution, as_tensor, common_device, default_device
 from .univariate import _assert_same_float_dtype, _require_f32, _FLOATS, _INTS
@@ -132,27 +132,69 @@ class LogMixture(object):
     `.dense()`."""
 
     def __init__(self, theta, phi):
+        src = _symbolic.softmax_source(theta)
+        if src is not None:
+            # theta = softmax(latent) still symbolic: formed only on demand
+            made = LogMixture.of_softmax(src, phi, tuple(theta.shape[:-1]))
+            self.__dict__.update(made.__dict__)
+            return
         theta, phi = as_tensor(theta), as_tensor(phi)
         if phi.dim() != 2 or theta.dim() < 1 or theta.shape[-1] != phi.shape[0]:
             raise ValueError(
                 "log_mixture: theta[..., K] and phi[K, V] expected, got {} and {}"
                 .format(tuple(theta.shape), tuple(phi.shape)))
-        self.theta, self.phi = theta, phi
+        self._theta, self.phi = theta, phi
+        self.softmax_source = None
+        self._batch = tuple(theta.shape[:-1])
+        self._dtype, self._device = theta.dtype, theta.device
+
+    @classmethod
+    def of_softmax(cls, source, phi, batch_shape):
+        """`log(softmax(source, -1).reshape(batch_shape + [K]) @ phi)` with
+        theta formed only if somebody asks (the native HMC plan computes the
+        softmax inside its own element-wise launch): what the literal
+        spelling `torch.log(torch.softmax(eta, -1) @ phi)` lowers to
+        (zhusuan_amd/_symbolic.py)."""
+        phi = as_tensor(phi)
+        k = int(source.shape[-1])
+        rows = 1
+        for d in batch_shape:
+            rows *= int(d)
+        if phi.dim() != 2 or phi.shape[0] != k or \
+                rows * k != source.numel():
+            raise ValueError(
+                "log_mixture: softmax source {} and phi {} do not fit batch "
+                "shape {}".format(tuple(source.shape), tuple(phi.shape),
+                                  tuple(batch_shape)))
+        self = cls.__new__(cls)
+        self._theta, self.phi = None, phi
+        self.softmax_source = source
+        self._batch = tuple(int(d) for d in batch_shape)
+        self._dtype, self._device = source.dtype, source.device
+        return self
+
+    @property
+    def theta(self):
+        if self._theta is None:
+            src = self.softmax_source
+            self._theta = torch.softmax(src, -1).reshape(
+                self._batch + (int(src.shape[-1]),))
+        return self._theta
 
     @property
     def shape(self):
-        return torch.Size(tuple(self.theta.shape[:-1]) + (self.phi.shape[1],))
+        return torch.Size(self._batch + (self.phi.shape[1],))
 
     @property
     def dtype(self):
-        return self.theta.dtype
+        return self._dtype
 
     @property
     def device(self):
-        return self.theta.device
+        return self._device
 
     def dim(self):
-        return self.theta.dim()
+        return len(self._batch) + 1
 
     def dense(self):
         return torch.log(self.theta @ self.phi)
@@ -166,6 +208,7 @@ class UnnormalizedMultinomial(Distribution):
     def __init__(self, logits, normalize_logits=True, dtype=torch.int32,
                  group_ndims=0, **kwargs):
         self._lazy = None
+        logits = _symbolic.lower_multinomial_logits(logits)
         if isinstance(logits, LogMixture):
             if logits.dtype != torch.float32:
                 raise TypeError("UnnormalizedMultinomial: log_mixture must be "

@@ -7,7 +7,7 @@ import torch
 
 from ..utils import broadcast_shapes
 
-from .. import _capi, _ops
+from .. import _capi, _ops, _symbolic
 from ..utils import next_op_offset
 from .base import Distribution, as_tensor, common_device, default_device
 
@@ -195,7 +195,7 @@ class LinearLogits(object):
     (csrc/linear_bernoulli.hip); anything else falls back to `.dense()`."""
 
     def __init__(self, w, X):
-        w = as_tensor(w)
+        w = as_tensor(w)          # (a symbolic latent: the latent itself)
         X = as_tensor(X)
         if X.dim() != 2 or w.dim() < 1 or w.shape[-1] != X.shape[-1]:
             raise ValueError(
@@ -229,6 +229,7 @@ class Bernoulli(Distribution):
 
     def __init__(self, logits, dtype=torch.int32, group_ndims=0, **kwargs):
         self._lazy = None
+        logits = _symbolic.lower_bernoulli_logits(logits)
         if isinstance(logits, LinearLogits):
             if logits.dtype != torch.float32:
                 raise TypeError("Bernoulli: linear_logits must be float32")

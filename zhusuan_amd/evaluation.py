@@ -24,6 +24,7 @@ import math
 import numpy as np
 import torch
 
+from . import _symbolic
 from .utils import merge_dicts
 
 __all__ = ['AIS']
@@ -64,13 +65,14 @@ def _proposal_is_prior_of(target, proposal, observed, latent):
            for k, v in observed.items()}
     probe = value.detach().requires_grad_(True)
     try:
-        bn_p = proposal.observe(**merge_dicts(obs, {name: probe}))
+        sym_probe = _symbolic.wrap_latent(probe)   # literal dense spellings
+        bn_p = proposal.observe(**merge_dicts(obs, {name: sym_probe}))
         lp = bn_p.log_joint()
         prior_node = bn_p.get(name)
         if not isinstance(prior_node, StochasticTensor) or \
                 lp is not prior_node.__dict__.get('_cond_log_p'):
             return False
-        bn_t = target.observe(**merge_dicts(obs, {name: probe}))
+        bn_t = target.observe(**merge_dicts(obs, {name: sym_probe}))
         nodes = [n for n in bn_t.nodes.values()
                  if isinstance(n, StochasticTensor)]
         if target.log_joint is not None:

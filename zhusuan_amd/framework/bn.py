@@ -34,7 +34,8 @@ class StochasticTensor(object):
         type_msg = "Incompatible types of {}('{}') and its observation: {}"
         try:
             observation = as_tensor(observation, dtype=self._dtype,
-                                    device=self._dist._device())
+                                    device=self._dist._device(),
+                                    keep_symbolic=True)
         except (ValueError, TypeError, RuntimeError) as e:
             raise ValueError(type_msg.format(self.__class__.__name__,
                                              self._name, e))
