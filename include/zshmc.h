@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ZSHMC_VERSION 201 /* 0.2.1 */
+#define ZSHMC_VERSION 300 /* 0.3.0 */
 
 /* status codes */
 #define ZSHMC_OK 0
@@ -156,7 +156,27 @@ typedef struct zshmc_adapt_link {
                               search (hmc.py:308-345); NaN otherwise */
   float delta, gamma, t0, kappa; /* StepsizeTuner parameters, hmc.py:67-78 */
   float mu;                /* 10 * initial step size (hmc.py:79, sic) */
+  /* Column statistics of the state the transition ENDS in, for the NEXT
+   * iteration's mass update (hmc.py:130-148 takes them of the state an
+   * iteration starts from, :288): with colstats_parts != NULL a committing
+   * launch writes zshmc_fused_colstats_rows(n_chains, ...) rows of
+   * 2*n_data doubles, row b = workgroup b's
+   *   [ sum_c (q'_cd - colstats_mean_d) | sum_c (q'_cd - colstats_mean_d)^2 ]
+   * over its chains (q' = the proposal where accepted, else the start row),
+   * so mass adaptation costs no read pass of its own.  Reduce the rows with
+   * zshmc_mass_colstats_reduce / zshmc_mass_update_fused.  Only shapes for
+   * which zshmc_fused_colstats_rows returns > 0; NULL otherwise. */
+  const float* colstats_mean; /* device [n_data]: the EWMV mean */
+  double* colstats_parts;     /* device [rows, 2*n_data] */
 } zshmc_adapt_link;
+
+/* Rows of colstats_parts a launch of zshmc_hmc_diag_normal_step on this shape
+ * fills (one per workgroup), or 0 if the kernel of this shape cannot produce
+ * the column statistics (rows of <= 128 or > 1 536 latents, not a multiple
+ * of 4): use zshmc_mass_colstats then.  All device pointers of the call must
+ * be 16-byte aligned. */
+int64_t zshmc_fused_colstats_rows(int64_t n_chains, int64_t n_data,
+                                  int has_mass, int zero_mean);
 
 int zshmc_hmc_diag_normal_step(
     float* q, const float* mean, const float* logstd, const float* mass,
@@ -233,6 +253,23 @@ int zshmc_state_set(float* state, int index, float value, void* stream);
 int zshmc_mass_colstats(const float* q, const float* ewmv_mean,
                         int64_t n_chains, int64_t n_data, double* colsum,
                         void* stream);
+/* colsum[0:2*n_data] = sum over the n_parts rows of `parts` (the per-workgroup
+ * partials a fused launch left in link->colstats_parts), added in row order:
+ * deterministic.  Overwrites colsum -- what travels in the one all-reduce of
+ * a sharded run. */
+int zshmc_mass_colstats_reduce(const double* parts, int64_t n_parts,
+                               int64_t n_data, double* colsum, void* stream);
+/* zshmc_mass_update(update = 1) in ONE launch, fed by n_parts rows of column
+ * sums (the partials of a fused launch; or 1 row: an already reduced /
+ * all-reduced colsum): row reduction in fixed order, EWMV update, mass, and
+ * the advance of tau by the workgroup that finishes last (counter in
+ * `workspace`: 4 bytes of device memory, zero between calls).  `parts` is not
+ * modified. */
+int zshmc_mass_update_fused(float* state, float* ewmv_mean, float* ewmv_var,
+                            const double* parts, int64_t n_parts,
+                            int64_t n_chains_global, int64_t n_data,
+                            float decay, int use_ones, float* mass_out,
+                            void* workspace, void* stream);
 int zshmc_mass_update(float* state, float* ewmv_mean, float* ewmv_var,
                       double* colsum, int64_t n_chains_global,
                       int64_t n_data, float decay, int update, int use_ones,

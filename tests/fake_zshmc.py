@@ -172,3 +172,31 @@ class FakeLibrary(object):
             _f32(mass_out, D)[...] = F32(1) if use_ones else F32(1) / var
         if update == 1:
             st[_capi.ST_EWMV_T] = tau_new
+
+    # -- zshmc_mass_update_fused: rows of column sums -> EWMV update, mass,
+    # tau, in one call (csrc/adapt.hip) ---------------------------------------
+    def zshmc_mass_update_fused(self, state, ewmv_mean, ewmv_var, parts,
+                                n_parts, n_chains_global, n_data, decay,
+                                use_ones, mass_out, workspace, stream):
+        D = int(n_data)
+        rows = _view(parts, int(n_parts) * 2 * D, ctypes.c_double,
+                     np.float64).reshape(int(n_parts), 2 * D)
+        total = np.zeros(2 * D, np.float64)
+        for r in rows:                       # row order: deterministic
+            total += r
+        keep = total.copy()
+        buf = (ctypes.c_double * (2 * D))(*total)
+        self.zshmc_mass_update(state, ewmv_mean, ewmv_var,
+                               ctypes.addressof(buf), n_chains_global, n_data,
+                               decay, 1, use_ones, mass_out, stream)
+        assert np.array_equal(rows.sum(0) if n_parts > 1 else rows[0], keep)
+
+    def zshmc_mass_colstats_reduce(self, parts, n_parts, n_data, colsum,
+                                   stream):
+        D = int(n_data)
+        rows = _view(parts, int(n_parts) * 2 * D, ctypes.c_double,
+                     np.float64).reshape(int(n_parts), 2 * D)
+        _view(colsum, 2 * D, ctypes.c_double, np.float64)[...] = rows.sum(0)
+
+    def zshmc_zero(self, ptr, n_bytes, stream):
+        ctypes.memset(int(ptr), 0, int(n_bytes))

@@ -70,9 +70,12 @@ class FusedKernel(object):
 
     def link(self, use_state=False, pending=0, fresh=0, used=float('nan'),
              delta=0.8, gamma=0.05, t0=100.0, kappa=0.75, mu=0.5,
-             collect=True):
+             collect=True, colstats_mean=None, colstats_parts=None):
         c = self.capi
         k = c.AdaptLink()
+        if colstats_parts is not None:
+            k.colstats_mean = colstats_mean.data_ptr()
+            k.colstats_parts = colstats_parts.data_ptr()
         k.state = self.state.data_ptr() if use_state else None
         k.stats = self.stats.data_ptr() if collect else None
         k.workspace = self.workspace.data_ptr()

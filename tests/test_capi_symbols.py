@@ -50,7 +50,7 @@ def test_adapt_link_layout_matches_header():
         names.append(parts[0].split()[-1].lstrip('*'))
         names.extend(parts[1:])
     assert names == [f[0] for f in _capi.AdaptLink._fields_], names
-    assert ctypes.sizeof(_capi.AdaptLink) == 3 * 8 + 8 + 3 * 4 + 6 * 4 + 4
+    assert ctypes.sizeof(_capi.AdaptLink) == 3 * 8 + 8 + 3 * 4 + 6 * 4 + 4 + 2 * 8
 
 
 def test_header_declares_functions():
@@ -90,7 +90,7 @@ def test_ctypes_table_matches_header(lib):
 
 
 def test_version_and_limits_callable_without_gpu(lib):
-    assert lib.zshmc_version() == 201
+    assert lib.zshmc_version() == 300
     assert lib.zshmc_fused_max_n_data() == 2048
     assert lib.zshmc_last_error() is not None
 

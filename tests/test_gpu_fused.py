@@ -420,3 +420,107 @@ def test_fused_plan_follows_fed_and_updated_parameters(env):
         xg.copy_(xf)
     # and the zero-mean specialisation was left when the mean stopped being 0
     assert hf._plan.zero_mean is False
+
+
+# (C, D): every ring instantiation that can produce the column statistics
+# (NCH = 1..6), ragged last chunks, fewer turns than CUs, many chains per CU
+COLSTATS_SHAPES = [(40, 132), (300, 256), (999, 260), (64, 512), (5000, 700),
+                   (4100, 768), (20000, 1024), (70, 1028), (600, 1280),
+                   (257, 1536)]
+
+
+@pytest.mark.parametrize('C,D', COLSTATS_SHAPES)
+@pytest.mark.parametrize('has_mass,has_mean', [(False, False), (True, False),
+                                               (False, True), (True, True)])
+def test_column_statistics_of_the_end_state_come_out_of_the_launch(
+        env, C, D, has_mass, has_mean):
+    """zshmc_adapt_link.colstats_*: the committing launch leaves, per
+    workgroup, the column sums of (q' - m) and (q' - m)^2 of the state it
+    ENDS in (proposal where accepted, start row where rejected) -- what the
+    next iteration's EWMV update consumes (hmc.py:130-148, :288) -- and is
+    otherwise bit-identical to the launch without them."""
+    zs, torch = env
+    from zhusuan_amd import _capi
+    dev = torch.device('cuda', 0)
+    g = torch.Generator(device='cpu').manual_seed(C + D)
+    mean = torch.randn(D, generator=g).to(dev) if has_mean else None
+    logstd = (0.5 * torch.rand(D, generator=g) - 0.25).to(dev)
+    mass = (0.5 + torch.rand(D, generator=g)).to(dev) if has_mass else None
+    q0 = torch.randn(C, D, generator=g).to(dev)
+    m = (0.3 * torch.randn(D, generator=g)).to(dev)
+    rows = int(_capi.load().zshmc_fused_colstats_rows(
+        C, D, int(has_mass), int(not has_mean)))
+    assert 0 < rows <= 256
+    k = FusedKernel(torch, C, D)
+    # a step size whose acceptance is well inside (0, 1): dry runs
+    for eps in (3.0, 2.2, 1.6, 1.2, 0.9, 0.65, 0.45, 0.3, 0.2):
+        eps = eps / D ** 0.25
+        k.step(q0.clone(), mean, logstd, mass, eps, 4, 123, 7, commit=0)
+        if 0.3 < float(k.stats[0].item()) / C < 0.85:
+            break
+    qa = q0.clone()
+    k.step(qa, mean, logstd, mass, eps, 4, 123, 7)
+    info_a = [x.clone() for x in k.info]
+    parts = torch.full((rows, 2 * D), float('nan'), dtype=torch.float64,
+                       device=dev)
+    qb = q0.clone()
+    k.step(qb, mean, logstd, mass, eps, 4, 123, 7,
+           link=k.link(colstats_mean=m, colstats_parts=parts))
+    assert torch.equal(qa, qb)
+    for x, y in zip(info_a, k.info):
+        assert torch.equal(x, y)
+    moved = (qb != q0).any(1)
+    assert 0 < int(moved.sum()) < C        # both branches exercised
+    d = (qb - m).double()                   # float32 difference, as the kernel
+    want = torch.cat([d.sum(0), (qb - m).square().double().sum(0)])
+    got = parts.sum(0)
+    torch.testing.assert_close(got, want, rtol=1e-12, atol=1e-9)
+    # the two reducers: one row for the all-reduce; EWMV update in one launch
+    colsum = torch.empty(2 * D, dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    _capi.call('zshmc_mass_colstats_reduce', parts.data_ptr(), rows, D,
+               colsum.data_ptr(), stream)
+    torch.testing.assert_close(colsum, want, rtol=1e-12, atol=1e-9)
+    state = torch.zeros(_capi.STATE_WORDS, device=dev)
+    state[_capi.ST_EWMV_T] = 3.0
+    out = []
+    for src, n in ((parts, rows), (colsum, 1)):
+        st, mean_e = state.clone(), m.clone()
+        var_e = torch.full((D,), 0.7, device=dev)
+        mass_o = torch.empty(D, device=dev)
+        ws = torch.zeros(2, dtype=torch.int32, device=dev)
+        _capi.call('zshmc_mass_update_fused', st.data_ptr(), mean_e.data_ptr(),
+                   var_e.data_ptr(), src.data_ptr(), n, C, D, 0.99, 0,
+                   mass_o.data_ptr(), ws.data_ptr(), stream)
+        assert float(st[_capi.ST_EWMV_T]) == 4.0 and int(ws[0]) == 0
+        out.append((mean_e, var_e, mass_o))
+    # against the two-launch form on the same sums
+    st, mean_e = state.clone(), m.clone()
+    var_e = torch.full((D,), 0.7, device=dev)
+    mass_o = torch.empty(D, device=dev)
+    _capi.call('zshmc_mass_update', st.data_ptr(), mean_e.data_ptr(),
+               var_e.data_ptr(), colsum.clone().data_ptr(), C, D, 0.99, 1, 0,
+               mass_o.data_ptr(), stream)
+    assert float(st[_capi.ST_EWMV_T]) == 4.0
+    for got3 in out:
+        for a, b in zip(got3, (mean_e, var_e, mass_o)):
+            torch.testing.assert_close(a, b, rtol=1e-6, atol=0)
+    for a, b in zip(out[1], (mean_e, var_e, mass_o)):
+        assert torch.equal(a, b)            # same row, same arithmetic
+
+
+def test_column_statistics_are_refused_where_the_kernel_has_none(env):
+    zs, torch = env
+    from zhusuan_amd import _capi
+    lib = _capi.load()
+    for D in (4, 10, 128, 130, 1540, 2048):
+        assert lib.zshmc_fused_colstats_rows(1000, D, 0, 1) == 0
+    dev = torch.device('cuda', 0)
+    C, D = 64, 96
+    k = FusedKernel(torch, C, D)
+    parts = torch.zeros(256, 2 * D, dtype=torch.float64, device=dev)
+    with pytest.raises(_capi.ZshmcError, match='colstats'):
+        k.step(torch.zeros(C, D, device=dev), None, torch.zeros(D, device=dev),
+               None, 0.1, 2, 1, 1,
+               link=k.link(colstats_mean=torch.zeros(D, device=dev),
+                           colstats_parts=parts))

@@ -91,8 +91,17 @@ def test_single_process_orchestration_matches_oracle(monkeypatch, mass):
     np.testing.assert_allclose(eps, want_eps, rtol=5e-5 if mass else 2e-6)
     np.testing.assert_allclose(q, want_q, rtol=0, atol=2e-4 if mass else 1e-6)
     if mass:
-        # the step size is searched again at t == mass_collect_iters
-        assert fake.calls.count('zshmc_mass_update') == ITERS
+        # the step size is searched again at t == mass_collect_iters.  One
+        # mass launch per iteration WHILE THE FLAG IS ON (rows of column sums
+        # -> EWMV update -> mass -> tau); with the flag off the mass stays
+        # what it was and nothing is launched.  The column sums are taken at
+        # the END of a run for the next one (they travel in that run's one
+        # all-reduce when sharded): once before the first update, then one
+        # per adaptive run.
+        n_adaptive = sum(_flags(i) for i in range(ITERS))
+        assert fake.calls.count('zshmc_mass_update_fused') == n_adaptive
+        assert fake.calls.count('zshmc_mass_update') == 0
+        assert fake.calls.count('zshmc_mass_colstats') == n_adaptive + 1
         return
     # one launch per transition once the search at t = 1 is over, the update
     # carried by the launch (no separate update call, no flush work)

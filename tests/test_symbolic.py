@@ -123,3 +123,51 @@ def test_model_function_with_literal_spelling_builds_fused_nodes():
         return bn
     bn = blr2().observe(w=sym.wrap_latent(w), y=y)
     assert bn.get('y').dist._lazy.w is w
+
+
+def test_product_autograd_functions_keep_the_tape_through_a_symbol():
+    """`Function.apply` hands its arguments to `forward` without
+    `__torch_function__` dispatch: the product's ops force symbols first."""
+    from zhusuan_amd import _ops
+
+    class Twice(_ops._Function):
+        @staticmethod
+        def forward(ctx, x, k):
+            assert type(x) is torch.Tensor
+            return x * k
+
+        @staticmethod
+        def backward(ctx, g):
+            return g * 2, None
+    w = _latent(5).requires_grad_(True)
+    y = Twice.apply(sym.wrap_latent(w), 2.0)
+    g, = torch.autograd.grad(y.sum(), w)
+    torch.testing.assert_close(g, torch.full((5,), 2.0))
+
+
+def test_a_foreign_autograd_function_is_detected_not_silently_cut():
+    class Foreign(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x * 3.0          # forces the symbol with autograd off
+
+        @staticmethod
+        def backward(ctx, g):
+            return g * 3.0
+    w = _latent(5).requires_grad_(True)
+    with pytest.raises(sym.SymbolicCut):
+        Foreign.apply(sym.wrap_latent(w))
+    # the sampler's evaluation falls back to plain tensors (and stays there)
+    hmc = zs.HMC(step_size=0.1)
+    hmc._log_joint = lambda obs: Foreign.apply(obs['w']).sum(-1) * 0 - \
+        0.5 * (Foreign.apply(obs['w']) ** 2).sum(-1)
+    hmc._observed = {}
+    q = _latent(4, 5).requires_grad_(True)
+    lp = hmc._eval_log_joint(['w'], [q])
+    g, = torch.autograd.grad(lp.sum(), q)
+    torch.testing.assert_close(g, -9.0 * q.detach())
+    assert hmc._symbolic_latents is False
+    # without grad nothing can be cut: symbols may be forced anywhere
+    with torch.no_grad():
+        assert torch.equal(Foreign.apply(sym.wrap_latent(_latent(3))),
+                           _latent(3) * 3.0)

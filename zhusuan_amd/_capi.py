@@ -43,7 +43,8 @@ class AdaptLink(Structure):
                 ('fresh_start', c_int32),
                 ('used_step_size', c_float), ('delta', c_float),
                 ('gamma', c_float), ('t0', c_float), ('kappa', c_float),
-                ('mu', c_float)]
+                ('mu', c_float), ('colstats_mean', c_void_p),
+                ('colstats_parts', c_void_p)]
 
 
 BCAST_FULL = 0
@@ -102,6 +103,11 @@ PROTOTYPES = {
         c_float, _p]),
     'zshmc_state_set': (c_int, [_p, c_int, c_float, _p]),
     'zshmc_mass_colstats': (c_int, [_p, _p, c_int64, c_int64, _p, _p]),
+    'zshmc_mass_colstats_reduce': (c_int, [_p, c_int64, c_int64, _p, _p]),
+    'zshmc_mass_update_fused': (c_int, [
+        _p, _p, _p, _p, c_int64, c_int64, c_int64, c_float, c_int, _p, _p,
+        _p]),
+    'zshmc_fused_colstats_rows': (c_int64, [c_int64, c_int64, c_int, c_int]),
     'zshmc_mass_update': (c_int, [
         _p, _p, _p, _p, c_int64, c_int64, c_float, c_int, c_int, _p, _p]),
     'zshmc_momentum': (c_int, [

@@ -9,9 +9,22 @@ import torch
 
 from .utils import broadcast_shapes
 
-from . import _capi
+from . import _capi, _symbolic
 
 _F32 = torch.float32
+
+
+class _Function(torch.autograd.Function):
+    """autograd.Function whose `apply` first replaces symbolic latent
+    expressions (zhusuan_amd/_symbolic.py) by their values:
+    `Function.apply` hands its arguments to `forward` WITHOUT going through
+    `__torch_function__`, and a wrapper that reached `forward` would cut the
+    tape between the op and the latent it stands for."""
+
+    @classmethod
+    def apply(cls, *args):
+        return super(_Function, cls).apply(
+            *[_symbolic.force(a) for a in args])
 
 
 def require_device(*tensors):
@@ -87,7 +100,7 @@ def _sum_to(g_full, target_shape):
         target_shape) else g_full
 
 
-class NormalLogProb(torch.autograd.Function):
+class NormalLogProb(_Function):
     """Normal._log_prob + group_ndims sum (reference
     distributions/univariate.py:174-181, base.py:302-304)."""
 
@@ -128,7 +141,7 @@ class NormalLogProb(torch.autograd.Function):
                 _sum_to(gs, ss) if need_s else None, None)
 
 
-class Uni2LogProb(torch.autograd.Function):
+class Uni2LogProb(_Function):
     """Laplace / Gamma / InverseGamma / Beta `_log_prob` + group_ndims sum
     (reference distributions/univariate.py:1268-1275, :735-748, :1145-1157,
     :834-853; base.py:302-304) and their analytic gradients w.r.t. the value
@@ -204,7 +217,7 @@ def _pair_csr(index, n_rows, slot):
     return val
 
 
-class GatheredDot(torch.autograd.Function):
+class GatheredDot(_Function):
     """out[..., e] = sum_d u[..., su[e], d] * v[..., sv[e], d]
     (examples/probabilistic_matrix_factorization/pmf_hmc.py:26-28 without the
     [K, E, D] gathers) and its gradients by deterministic segmented sums
@@ -285,7 +298,7 @@ def gathered_dot(u, select_u, v, select_v):
     return GatheredDot.apply(u, select_u, v, select_v)
 
 
-class MvnTrilLogProb(torch.autograd.Function):
+class MvnTrilLogProb(_Function):
     """MultivariateNormalCholesky._log_prob (reference distributions/
     multivariate.py:166-188) and its gradients: d/dgiven = -L^-T z from the
     kernel's back substitution; d/dmean = -d/dgiven; d/dL = tril(w z^T) -
@@ -341,7 +354,7 @@ class MvnTrilLogProb(torch.autograd.Function):
         return (g if need_x else None), gm, gt
 
 
-class BernoulliLogProb(torch.autograd.Function):
+class BernoulliLogProb(_Function):
     """Bernoulli._log_prob (reference univariate.py:398-403)."""
 
     @staticmethod
@@ -374,7 +387,7 @@ class BernoulliLogProb(torch.autograd.Function):
         return _sum_to(gl, ls), None, None
 
 
-class CategoricalLogProb(torch.autograd.Function):
+class CategoricalLogProb(_Function):
     """Categorical._log_prob (reference univariate.py:496-548); logits
     [rows, n_cat] and int64 labels [rows], already broadcast."""
 
@@ -402,7 +415,7 @@ class CategoricalLogProb(torch.autograd.Function):
         return gl, None
 
 
-class UnnormalizedMultinomialLogProb(torch.autograd.Function):
+class UnnormalizedMultinomialLogProb(_Function):
     """UnnormalizedMultinomial._log_prob (reference
     distributions/multivariate.py:435-443)."""
 
@@ -477,7 +490,7 @@ def _row_splits(n_blocks_rows, n_inner, device):
     return max(1, min(16, (2 * cus) // n_wg, (n_inner + 511) // 512))
 
 
-class LinearBernoulliLogLik(torch.autograd.Function):
+class LinearBernoulliLogLik(_Function):
     """ll[c] = sum_n Bernoulli(w_c . x_n).log_prob(y_n) and its gradient in one
     pass over X (logits are never materialised)."""
 
@@ -554,7 +567,7 @@ def _padded_counts(x):
     return xp, vp
 
 
-class MixtureMultinomialLogLik(torch.autograd.Function):
+class MixtureMultinomialLogLik(_Function):
     """ll[r] = sum_v x[r % R0, v] log((theta . phi)[r, v]) and d/dtheta in one
     pass over phi (the [rows, V] product is never materialised): the fused
     fp32-MFMA kernel of csrc/linear_bernoulli.hip in its multinomial mode.

@@ -28,8 +28,17 @@ the same native plans as `zs.linear_logits` / `zs.log_mixture`.
 import torch
 from torch.utils._pytree import tree_map
 
-__all__ = ['Sym', 'wrap_latent', 'force', 'lower_bernoulli_logits',
-           'lower_multinomial_logits']
+__all__ = ['Sym', 'SymbolicCut', 'wrap_latent', 'force',
+           'lower_bernoulli_logits', 'lower_multinomial_logits']
+
+
+class SymbolicCut(RuntimeError):
+    """A symbol over a latent that requires grad was evaluated with autograd
+    disabled -- in practice inside the `forward` of a custom
+    torch.autograd.Function, which receives its arguments without
+    `__torch_function__` dispatch: the op's output would not be connected to
+    the latent and its gradient silently lost.  The sampler catches this and
+    evaluates the model on plain tensors from then on."""
 
 _T = torch.Tensor
 
@@ -71,6 +80,7 @@ class Sym(torch.Tensor):
         r._expr = expr
         r._value = None
         r._meta = (tuple(int(d) for d in shape), dtype, torch.device(device))
+        r._root = expr[1] if expr[0] == 'latent' else expr[1]._root
         return r
 
     def __init__(self, *a, **k):
@@ -79,6 +89,11 @@ class Sym(torch.Tensor):
     # -- the value of the expression (computed once) -------------------------
     def force(self):
         if self._value is None:
+            if self._root.requires_grad and not torch.is_grad_enabled():
+                raise SymbolicCut(
+                    "symbolic latent expression %r evaluated with autograd "
+                    "disabled (inside a custom autograd.Function.forward?)"
+                    % (self,))
             e = self._expr
             kind = e[0]
             if kind == 'latent':

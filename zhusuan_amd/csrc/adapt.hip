@@ -111,6 +111,81 @@ __global__ void mass_update_kernel(float* __restrict__ state,
   mass_out[d] = use_ones ? 1.0f : 1.0f / var;
 }
 
+// Rows of column sums -> one row, fixed order.  Block (64 x 4): 64 columns,
+// 4 row lanes striding over the rows; LDS-reduced in lane order.
+__device__ __forceinline__ double parts_column_sum(
+    const double* __restrict__ parts, int64_t n_parts, int64_t stride,
+    int64_t col, bool valid, double (*sh)[kColsPerBlock]) {
+  const int tx = threadIdx.x % kColsPerBlock;
+  const int ty = threadIdx.x / kColsPerBlock;
+  double s = 0.0;
+  if (valid)
+    for (int64_t r = ty; r < n_parts; r += kRowLanes)
+      s += parts[r * stride + col];
+  __syncthreads();  // (sh may still be read from a previous call)
+  sh[ty][tx] = s;
+  __syncthreads();
+  double tot = 0.0;
+#pragma unroll
+  for (int i = 0; i < kRowLanes; ++i) tot += sh[i][tx];
+  return tot;
+}
+
+__global__ __launch_bounds__(256) void mass_colstats_reduce_kernel(
+    const double* __restrict__ parts, int64_t n_parts, int64_t n_data,
+    double* __restrict__ colsum) {
+  __shared__ double sh[kRowLanes][kColsPerBlock];
+  const int tx = threadIdx.x % kColsPerBlock;
+  const int ty = threadIdx.x / kColsPerBlock;
+  // blockIdx.x walks the 2*n_data columns of a row
+  const int64_t col = (int64_t)blockIdx.x * kColsPerBlock + tx;
+  const bool valid = col < 2 * n_data;
+  const double tot =
+      parts_column_sum(parts, n_parts, 2 * n_data, col, valid, sh);
+  if (ty == 0 && valid) colsum[col] = tot;
+}
+
+// zshmc_mass_update(update = 1) fed by rows of column sums, tau advanced by
+// the block that finishes last (every block has read tau by then: the
+// increment of the retirement counter comes after the block's barrier).
+__global__ __launch_bounds__(256) void mass_update_fused_kernel(
+    float* __restrict__ state, float* __restrict__ ewmv_mean,
+    float* __restrict__ ewmv_var, const double* __restrict__ parts,
+    int64_t n_parts, double inv_chains, int64_t n_data, float decay,
+    int use_ones, float* __restrict__ mass_out,
+    unsigned int* __restrict__ retired) {
+  __shared__ double sh[kRowLanes][kColsPerBlock];
+  const int tx = threadIdx.x % kColsPerBlock;
+  const int ty = threadIdx.x / kColsPerBlock;
+  const int64_t d = (int64_t)blockIdx.x * kColsPerBlock + tx;
+  const bool valid = d < n_data;
+  const float tau_new = state[ZSHMC_ST_EWMV_T] + 1.0f;
+  const double c1 = parts_column_sum(parts, n_parts, 2 * n_data, d, valid, sh);
+  const double c2 =
+      parts_column_sum(parts, n_parts, 2 * n_data, n_data + d, valid, sh);
+  if (ty == 0 && valid) {
+    // the arithmetic of mass_update_kernel (hmc.py:130-152)
+    const float w = (1.0f - decay) / (1.0f - powf(decay, tau_new));
+    const double s1 = c1 * inv_chains, s2 = c2 * inv_chains;
+    const double delta = (double)w * s1;
+    ewmv_mean[d] = (float)((double)ewmv_mean[d] + delta);
+    const float var = (float)((1.0 - (double)w) * (double)ewmv_var[d] +
+                              (double)w * s2 - delta * delta);
+    ewmv_var[d] = var;
+    mass_out[d] = use_ones ? 1.0f : 1.0f / var;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int before = __hip_atomic_fetch_add(
+        retired, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (before == gridDim.x - 1) {
+      state[ZSHMC_ST_EWMV_T] = tau_new;
+      __hip_atomic_store(retired, 0u, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 __global__ void mass_tau_bump_kernel(float* state) {
   if (threadIdx.x == 0 && blockIdx.x == 0) state[ZSHMC_ST_EWMV_T] += 1.0f;
 }
@@ -188,5 +263,37 @@ extern "C" int zshmc_mass_update(float* state, float* ewmv_mean,
     hipLaunchKernelGGL(mass_tau_bump_kernel, dim3(1), dim3(64), 0, s, state);
     ZS_LAUNCH_CHECK("mass_tau_bump_kernel launch");
   }
+  return ZSHMC_OK;
+}
+
+extern "C" int zshmc_mass_colstats_reduce(const double* parts, int64_t n_parts,
+                                          int64_t n_data, double* colsum,
+                                          void* stream) {
+  ZS_REQUIRE(parts && colsum, "zshmc_mass_colstats_reduce: null pointer");
+  ZS_REQUIRE(n_parts >= 1 && n_data >= 1,
+             "zshmc_mass_colstats_reduce: bad shape");
+  const int blocks = (int)((2 * n_data + kColsPerBlock - 1) / kColsPerBlock);
+  hipLaunchKernelGGL(mass_colstats_reduce_kernel, dim3(blocks), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), parts, n_parts,
+                     n_data, colsum);
+  ZS_LAUNCH_CHECK("mass_colstats_reduce_kernel launch");
+  return ZSHMC_OK;
+}
+
+extern "C" int zshmc_mass_update_fused(
+    float* state, float* ewmv_mean, float* ewmv_var, const double* parts,
+    int64_t n_parts, int64_t n_chains_global, int64_t n_data, float decay,
+    int use_ones, float* mass_out, void* workspace, void* stream) {
+  ZS_REQUIRE(state && ewmv_mean && ewmv_var && parts && mass_out && workspace,
+             "zshmc_mass_update_fused: null pointer");
+  ZS_REQUIRE(n_parts >= 1 && n_chains_global > 0 && n_data >= 1,
+             "zshmc_mass_update_fused: bad shape");
+  const int blocks = (int)((n_data + kColsPerBlock - 1) / kColsPerBlock);
+  hipLaunchKernelGGL(mass_update_fused_kernel, dim3(blocks), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), state, ewmv_mean,
+                     ewmv_var, parts, n_parts, 1.0 / (double)n_chains_global,
+                     n_data, decay, use_ones, mass_out,
+                     reinterpret_cast<unsigned int*>(workspace));
+  ZS_LAUNCH_CHECK("mass_update_fused_kernel launch");
   return ZSHMC_OK;
 }

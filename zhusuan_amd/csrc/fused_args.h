@@ -104,6 +104,11 @@ struct AdaptLink {
   float used_step_size;  // epsilon the updated-for transition used if it came
                          // from the search (NaN: it used state[STEP_SIZE])
   TunerCfg tuner;
+  // column statistics of the END state for the next mass update
+  // (zshmc_adapt_link.colstats_*): EWMV mean [n_data]; one row of 2*n_data
+  // doubles per workgroup.  NULL: not asked for.
+  const float* cs_mean;
+  double* cs_parts;
 };
 
 // state <- update(state, acc_sum) and the two diagnostic words; one thread.
@@ -227,6 +232,11 @@ int launch_fused_ring(const FusedArgs& a, hipStream_t stream);
 bool fused_ring_config(int64_t n_data, bool has_mass, bool zero_mean, int* nch,
                        int* k);
 bool fused_ring_enabled();  // ZSHMC_FUSED_RING != 0
+// grid of the ring launch for this many chains (= rows of colstats partials)
+int64_t fused_ring_grid(int64_t n_chains);
+// whether the ring instantiation of this shape can produce the column
+// statistics of the end state
+bool fused_ring_colstats(int64_t n_data, bool has_mass, bool zero_mean);
 // largest grid either fused kernel launches (sizes the link workspace)
 constexpr int kFusedMaxGrid = 4096;
 

@@ -401,6 +401,14 @@ using namespace zshmc;
 
 extern "C" int64_t zshmc_fused_max_n_data(void) { return kFusedMaxData; }
 
+extern "C" int64_t zshmc_fused_colstats_rows(int64_t n_chains, int64_t n_data,
+                                             int has_mass, int zero_mean) {
+  if (n_chains <= 0 ||
+      !fused_ring_colstats(n_data, has_mass != 0, zero_mean != 0))
+    return 0;
+  return fused_ring_grid(n_chains);
+}
+
 extern "C" const char* zshmc_fused_kernel_name(int64_t n_data, int has_mass,
                                                int zero_mean) {
   static thread_local char buf[96];
@@ -474,6 +482,10 @@ static int make_link(const zshmc_adapt_link* link, AdaptLink* out,
     k.used_step_size = link->used_step_size;
     k.tuner = TunerCfg{link->delta, link->gamma, link->t0, link->kappa,
                        link->mu};
+    ZS_REQUIRE(!link->colstats_parts || link->colstats_mean,
+               "%s: link->colstats_parts needs link->colstats_mean", who);
+    k.cs_mean = link->colstats_mean;
+    k.cs_parts = link->colstats_parts;
   }
   *out = k;
   return ZSHMC_OK;
@@ -576,12 +588,18 @@ extern "C" int zshmc_hmc_diag_normal_step(
   a.orig_hamiltonian = nullptr;
 #endif
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  // a dry run (the step-size search) does not move the state: no statistics
+  if (!a.commit) a.link.cs_parts = nullptr;
   // rows of more than 128 latents, 16-B aligned: the LDS-DMA ring kernel
   // (ZSHMC_FUSED_RING=0 keeps the register-prefetch kernel, for A/B runs)
   if (fused_ring_enabled()) {
     const int rc = launch_fused_ring(a, s);
     if (rc != ZSHMC_ERR_UNSUPPORTED) return rc;
   }
+  ZS_REQUIRE(!a.link.cs_parts,
+             "zshmc_hmc_diag_normal_step: link->colstats_parts given, but the "
+             "kernel of this shape / alignment does not produce column "
+             "statistics (zshmc_fused_colstats_rows)");
   const int64_t ng = (n_data + 3) / 4;  // 4-element chunks per chain
   if (ng <= 1) return launch_cfg<1, 1>(a, s);
   if (ng <= 2) return launch_cfg<2, 1>(a, s);

@@ -278,20 +278,36 @@ constexpr int ring_waves_for(int nch, bool has_mass) {
 // the trip loop (hand-counted, in the ledger).
 // ZERO_MEAN: a.mean == NULL (every mean is 0, the usual prior): no mean tile
 // in LDS, no subtraction after the slot read, no re-addition before the store.
-template <int NCH, int K, bool HAS_MASS, bool STAGE, bool ZERO_MEAN>
+// COLSTATS: the launch also leaves, per workgroup, the column sums over its
+// chains of (q' - m) and (q' - m)^2 of the state the transition ENDS in (q' =
+// the proposal if accepted, else the start row) around the EWMV mean m --
+// what the NEXT iteration's mass update consumes (hmc.py:130-148 uses the
+// state an iteration starts from, :288), so mass adaptation costs no read
+// pass of its own.  The start row of a rejected chain is still needed at the
+// end of its trip: the ring gets one more physical slot per wave (the row of
+// trip i stays in slot i % (K+1) until trip i+1 refills it) and the sums are
+// accumulated with ds_add_f64 into one [2][row] double tile per workgroup.
+template <int NCH, int K, bool HAS_MASS, bool STAGE, bool ZERO_MEAN,
+          bool COLSTATS>
 __global__ __launch_bounds__(256 * ring_waves_for(NCH, HAS_MASS)) void
 hmc_diag_normal_ring_kernel(FusedArgs a) {
   constexpr int kLedgerInfo = STAGE ? 0 : kInfoStores;
   constexpr int kRow = NCH * 256;  // padded row length (floats) of one chain
   constexpr int kRowB = kRow * 4;
   constexpr int kWavesPerBlock = 4 * ring_waves_for(NCH, HAS_MASS);  // a CU
+  constexpr int kSlots = COLSTATS ? K + 1 : K;  // physical slots per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int kTiles = (ZERO_MEAN ? 0 : 1) + (HAS_MASS ? 1 : 0);
+  constexpr int kTiles =
+      (ZERO_MEAN ? 0 : 1) + (HAS_MASS ? 1 : 0) + (COLSTATS ? 1 : 0);
   float* __restrict__ s_mean = reinterpret_cast<float*>(smem);  // !ZERO_MEAN
   float* __restrict__ s_sqrtm = s_mean + (ZERO_MEAN ? 0 : kRow);  // HAS_MASS
+  float* __restrict__ s_cm = s_sqrtm + (HAS_MASS ? kRow : 0);     // COLSTATS
   float* __restrict__ s_ring = s_mean + kTiles * kRow;
-  double* __restrict__ s_acc =
-      reinterpret_cast<double*>(s_ring + kWavesPerBlock * K * kRow);
+  // COLSTATS: [2][NCH*4][64] doubles, element (k, j) of lane l at
+  // (k*4 + j)*64 + l (lanes contiguous: conflict-free ds_add_f64)
+  double* __restrict__ s_cs =
+      reinterpret_cast<double*>(s_ring + kWavesPerBlock * kSlots * kRow);
+  double* __restrict__ s_acc = s_cs + (COLSTATS ? 2 * kRow : 0);
   int* __restrict__ s_bad = reinterpret_cast<int*>(s_acc + kWavesPerBlock);
   int* __restrict__ s_ticket = s_bad + 1;
   // [2] = "the update's acceptance-independent half is in s_prep"
@@ -335,10 +351,15 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
                              a.iteration, a.k0, a.k1);
 
   // ---- stage mean / sqrt(mass) in LDS (zero padding beyond n_data) --------
-  if (!ZERO_MEAN || HAS_MASS)
+  if (!ZERO_MEAN || HAS_MASS || COLSTATS)
     for (int d = threadIdx.x; d < kRow; d += blockDim.x) {
       if (!ZERO_MEAN) s_mean[d] = d < D ? a.mean[d] : 0.f;
       if (HAS_MASS) s_sqrtm[d] = d < D ? sqrtf(a.mass[d]) : 0.f;
+      if (COLSTATS) {
+        s_cm[d] = d < D ? a.link.cs_mean[d] : 0.f;
+        s_cs[d] = 0.0;
+        s_cs[kRow + d] = 0.0;
+      }
     }
   if (threadIdx.x == 0) {
     *s_bad = 0;
@@ -423,7 +444,7 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
 
   const uint32_t ticket_addr =
       (uint32_t)reinterpret_cast<uintptr_t>(s_ticket);
-  float* __restrict__ ring_w = s_ring + wib * K * kRow;
+  float* __restrict__ ring_w = s_ring + wib * kSlots * kRow;
   const uint32_t ring_addr = __builtin_amdgcn_readfirstlane(
       (uint32_t)reinterpret_cast<uintptr_t>(ring_w));
   const uint32_t voff = (uint32_t)lane * 16u;
@@ -474,6 +495,9 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
     const float* late_src;
     uint32_t late_dst;
     bool late_on;
+    // COLSTATS: the row read now stays in its slot to the end of the trip;
+    // the refill goes to the slot the PREVIOUS trip read
+    const int slot_rd = slot;
     {
       const float* __restrict__ sl = ring_w + slot * kRow;
 #pragma unroll
@@ -489,13 +513,15 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
       int64_t nrow = ZS_CHAIN_OF(nt);
       nrow = nrow < last_row ? nrow : last_row;
       late_src = a.q + uni64(nrow * D);
-      late_dst = uni32(ring_addr + (uint32_t)slot * kRowB);
+      late_dst = uni32(ring_addr +
+                       (uint32_t)(COLSTATS ? (slot == 0 ? K : slot - 1) : slot) *
+                           kRowB);
       late_on = nt < count;
 #if ZS_RING_DMA_POS == 0
       issue_row<NCH>(voff, voff_last, late_src, late_dst,
                      mask_if<true>(late_on));
 #endif
-      slot = slot + 1 == K ? 0 : slot + 1;
+      slot = slot + 1 == kSlots ? 0 : slot + 1;
 #pragma unroll
       for (int j = 0; j + 1 < K; ++j) tk[j] = tk[j + 1];
       tk[K - 1] = nt;
@@ -699,6 +725,31 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
                   a.acceptance_rate, a.orig_hamiltonian, a.hamiltonian,
                   a.orig_log_prob, a.log_prob, a.commit_direct);
     }
+
+    // ---- COLSTATS: this chain's END state into the workgroup's column
+    // sums.  r holds q' (mean re-added above); a rejected chain's state is
+    // the start row, still in its ring slot.  LDS traffic only (no VMEM:
+    // the ledger does not change); `accept` is wave-uniform.
+    if (COLSTATS) {
+      const bool took = accept && a.commit != 0;
+      const float* __restrict__ sl = ring_w + slot_rd * kRow;
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) {
+        if (k == NCH - 1 && !valid_last) continue;  // padding lanes
+        f4 v = r[k];
+        if (!took) v = *reinterpret_cast<const f4*>(sl + (k * kWave + lane) * 4);
+        const f4 d = v - *reinterpret_cast<const f4*>(s_cm + (k * kWave + lane) * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int idx = (k * 4 + j) * kWave + lane;
+          __hip_atomic_fetch_add(&s_cs[idx], (double)d[j], __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(&s_cs[kRow + idx], (double)(d[j] * d[j]),
+                                 __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+    }
   }
   // no DMA may outlive the wave (its LDS would be handed to another block)
   wait_vmcnt<0>();
@@ -718,6 +769,16 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
   // total over workgroups (link_retire) --------------------------------------
   if (bad_old) *s_bad = 1;
   __syncthreads();  // all waves done: s_info complete, s_bad final
+  if (COLSTATS) {
+    // this workgroup's row of the partials: [sum (q'-m) | sum (q'-m)^2]
+    double* __restrict__ out = a.link.cs_parts + (int64_t)blockIdx.x * 2 * D;
+    for (int d = threadIdx.x; d < (int)D; d += blockDim.x) {
+      const int chunk = d >> 2, j = d & 3;
+      const int idx = ((chunk / kWave) * 4 + j) * kWave + chunk % kWave;
+      out[d] = s_cs[idx];
+      out[D + d] = s_cs[kRow + idx];
+    }
+  }
   if (STAGE) {
     acc_local = 0.0;
     for (int t = threadIdx.x; t < count; t += blockDim.x)
@@ -749,36 +810,48 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
 
 constexpr size_t kLdsLimit = 160 * 1024;
 
-template <int NCH, int K, bool HAS_MASS, bool ZERO_MEAN>
+// ring depth of the COLSTATS instantiations (one more physical slot per wave
+// has to fit in LDS next to the double tile): NCH <= 2 keep K = 3, the wider
+// rows run one row ahead like NCH = 4 does anyway
+constexpr int ring_cs_k(int nch) { return nch <= 2 ? 3 : 1; }
+constexpr int kRingCsMaxNch = 6;  // 7, 8: LDS / VGPR budget exhausted
+
+constexpr size_t ring_lds_base(int nch, int k, bool has_mass, bool zero_mean,
+                               bool colstats) {
+  const int waves = 4 * ring_waves_for(nch, has_mass);
+  return (size_t)((zero_mean ? 0 : 1) + (has_mass ? 1 : 0) +
+                  (colstats ? 1 : 0) + waves * (colstats ? k + 1 : k)) *
+             nch * 1024 +
+         (colstats ? (size_t)nch * 4096 : 0) + waves * sizeof(double) + 48;
+}
+
+template <int NCH, int K, bool HAS_MASS, bool ZERO_MEAN, bool COLSTATS>
 static int launch_ring_cfg(const FusedArgs& a_in, hipStream_t stream) {
   constexpr int kWaves = 4 * ring_waves_for(NCH, HAS_MASS);
   constexpr size_t lds_base =
-      (size_t)((ZERO_MEAN ? 0 : 1) + (HAS_MASS ? 1 : 0) + kWaves * K) * NCH *
-          1024 +
-      kWaves * sizeof(double) + 48;
+      ring_lds_base(NCH, K, HAS_MASS, ZERO_MEAN, COLSTATS);
   static_assert(lds_base <= kLdsLimit, "ring does not fit in LDS");
   static bool ready = false;
   if (!ready) {
     // the ring needs more than the default 64 KiB dynamic-LDS cap
     hipError_t e = hipFuncSetAttribute(
         reinterpret_cast<const void*>(
-            hmc_diag_normal_ring_kernel<NCH, K, HAS_MASS, true, ZERO_MEAN>),
+            hmc_diag_normal_ring_kernel<NCH, K, HAS_MASS, true, ZERO_MEAN,
+                                        COLSTATS>),
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
     if (e == hipSuccess)
       e = hipFuncSetAttribute(
           reinterpret_cast<const void*>(
-              hmc_diag_normal_ring_kernel<NCH, K, HAS_MASS, false, ZERO_MEAN>),
+              hmc_diag_normal_ring_kernel<NCH, K, HAS_MASS, false, ZERO_MEAN,
+                                          COLSTATS>),
           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
     if (e != hipSuccess) return check_hip(e, "ring kernel: LDS size attribute");
     ready = true;
   }
-  // one workgroup per CU; fewer when there are not even that many turns
-  constexpr int G = ZS_RING_GRANULE;
-  const int64_t cus = device_cu_count();
-  const int64_t turns = (a_in.n_chains + G - 1) / G;
-  const int64_t grid = turns < cus ? turns : cus;
+  const int64_t grid = fused_ring_grid(a_in.n_chains);
   // largest per-workgroup share (workgroup 0); stage the per-chain scalars in
   // LDS when they fit beside the ring
+  constexpr int G = ZS_RING_GRANULE;
   const int64_t round = G * grid;
   const int64_t tail = a_in.n_chains % round;
   const int64_t share = (a_in.n_chains / round) * G + (tail > G ? G : tail);
@@ -796,23 +869,50 @@ static int launch_ring_cfg(const FusedArgs& a_in, hipStream_t stream) {
   const dim3 gdim(grid > 0 ? (unsigned)grid : 1u), bdim(64 * kWaves);
   if (stage)
     hipLaunchKernelGGL(
-        (hmc_diag_normal_ring_kernel<NCH, K, HAS_MASS, true, ZERO_MEAN>), gdim,
-        bdim, lds, stream, a);
+        (hmc_diag_normal_ring_kernel<NCH, K, HAS_MASS, true, ZERO_MEAN,
+                                     COLSTATS>),
+        gdim, bdim, lds, stream, a);
   else
     hipLaunchKernelGGL(
-        (hmc_diag_normal_ring_kernel<NCH, K, HAS_MASS, false, ZERO_MEAN>), gdim,
-        bdim, lds, stream, a);
+        (hmc_diag_normal_ring_kernel<NCH, K, HAS_MASS, false, ZERO_MEAN,
+                                     COLSTATS>),
+        gdim, bdim, lds, stream, a);
   ZS_LAUNCH_CHECK("hmc_diag_normal_ring_kernel launch");
   return ZSHMC_OK;
 }
 
 template <int NCH, int K>
 static int launch_ring_k(const FusedArgs& a, hipStream_t stream) {
+  if constexpr (NCH <= kRingCsMaxNch) {
+    if (a.link.cs_parts) {
+      constexpr int KC = ring_cs_k(NCH);
+      if (a.mean)
+        return a.mass ? launch_ring_cfg<NCH, KC, true, false, true>(a, stream)
+                      : launch_ring_cfg<NCH, KC, false, false, true>(a, stream);
+      return a.mass ? launch_ring_cfg<NCH, KC, true, true, true>(a, stream)
+                    : launch_ring_cfg<NCH, KC, false, true, true>(a, stream);
+    }
+  }
   if (a.mean)
-    return a.mass ? launch_ring_cfg<NCH, K, true, false>(a, stream)
-                  : launch_ring_cfg<NCH, K, false, false>(a, stream);
-  return a.mass ? launch_ring_cfg<NCH, K, true, true>(a, stream)
-                : launch_ring_cfg<NCH, K, false, true>(a, stream);
+    return a.mass ? launch_ring_cfg<NCH, K, true, false, false>(a, stream)
+                  : launch_ring_cfg<NCH, K, false, false, false>(a, stream);
+  return a.mass ? launch_ring_cfg<NCH, K, true, true, false>(a, stream)
+                : launch_ring_cfg<NCH, K, false, true, false>(a, stream);
+}
+
+// one workgroup per CU; fewer when there are not even that many turns
+int64_t fused_ring_grid(int64_t n_chains) {
+  constexpr int G = ZS_RING_GRANULE;
+  const int64_t cus = device_cu_count();
+  const int64_t turns = (n_chains + G - 1) / G;
+  return turns < cus ? turns : cus;
+}
+
+bool fused_ring_colstats(int64_t D, bool has_mass, bool zero_mean) {
+  int nch = 0, k = 0;
+  return fused_ring_enabled() &&
+         fused_ring_config(D, has_mass, zero_mean, &nch, &k) &&
+         nch <= kRingCsMaxNch;
 }
 
 bool fused_ring_config(int64_t D, bool has_mass, bool zero_mean, int* nch_out,
@@ -848,6 +948,9 @@ int launch_fused_ring(const FusedArgs& a, hipStream_t stream) {
                   (!a.mass || (reinterpret_cast<uintptr_t>(a.mass) & 15) == 0) &&
                   a.n_chains + 0 < (1ll << 30);  // 4*chain fits 32 bits
   if (!ok) return ZSHMC_ERR_UNSUPPORTED;
+  // column statistics were asked for (the caller checked
+  // zshmc_fused_colstats_rows): only the instantiations that produce them
+  if (a.link.cs_parts && nch > kRingCsMaxNch) return ZSHMC_ERR_UNSUPPORTED;
   switch (nch) {
     case 1: return launch_ring_k<1, 3>(a, stream);
     case 2: return launch_ring_k<2, 3>(a, stream);
@@ -858,12 +961,12 @@ int launch_fused_ring(const FusedArgs& a, hipStream_t stream) {
     case 7:
       if (a.mass && a.mean) return ZSHMC_ERR_UNSUPPORTED;  // (not reached)
       if (a.mean)
-        return launch_ring_cfg<7, 2, false, false>(a, stream);
-      return a.mass ? launch_ring_cfg<7, 2, true, true>(a, stream)
-                    : launch_ring_cfg<7, 2, false, true>(a, stream);
+        return launch_ring_cfg<7, 2, false, false, false>(a, stream);
+      return a.mass ? launch_ring_cfg<7, 2, true, true, false>(a, stream)
+                    : launch_ring_cfg<7, 2, false, true, false>(a, stream);
     default:
-      return a.mean ? launch_ring_cfg<8, 2, false, false>(a, stream)
-                    : launch_ring_cfg<8, 2, false, true>(a, stream);
+      return a.mean ? launch_ring_cfg<8, 2, false, false, false>(a, stream)
+                    : launch_ring_cfg<8, 2, false, true, false>(a, stream);
   }
 }
 

@@ -236,6 +236,7 @@ class HMC(object):
         self.native_plans = bool(native_plans)
         self._plan = None
         self._pending_check = False
+        self._symbolic_latents = True
 
     # -- sample(): builds the execution plan (hmc.py:382-522) -------------
     def sample(self, meta_bn, observed, latent):
@@ -317,10 +318,25 @@ class HMC(object):
         # spellings (`w @ X.T`, `log(softmax(eta) @ phi)`) reach the fused
         # likelihood kernels instead of materialising the logits
         # (zhusuan_amd/_symbolic.py); any other op sees the plain tensor
-        joint_obs = merge_dicts(
-            {k: _symbolic.wrap_latent(v) for k, v in zip(names, values)},
-            self._resolved_observed())
-        return _symbolic.force(self._log_joint(joint_obs))   # hmc.py:426-428
+        if self._symbolic_latents:
+            try:
+                joint_obs = merge_dicts(
+                    {k: _symbolic.wrap_latent(v)
+                     for k, v in zip(names, values)},
+                    self._resolved_observed())
+                return _symbolic.force(self._log_joint(joint_obs))
+            except _symbolic.SymbolicCut:
+                # a custom autograd.Function took a symbol into its forward:
+                # plain tensors from now on (nothing is lost but the
+                # recognition of the literal dense spellings)
+                self._symbolic_latents = False
+        joint_obs = merge_dicts(dict(zip(names, values)),
+                                self._resolved_observed())
+        return self._log_joint(joint_obs)                # hmc.py:426-428
+
+    def _as_symbol(self, value):
+        return _symbolic.wrap_latent(value) if self._symbolic_latents \
+            else value
 
     def _resolved_observed(self):
         return {k: (v.value if isinstance(v, (placeholder, deferred)) else v)
@@ -484,8 +500,9 @@ class HMC(object):
     def set_state(self, state):
         plan = self._plan
         plan.pending = None
-        if plan.colsum_state == 'fresh':
+        if plan.colsum_state in ('fresh', 'parts'):
             plan.colsum_state = 'dirty'   # taken around the EWMV mean of before
+        plan._mass_ones = None
         self._nonadaptive_streak = 0
         self.t = int(state['t'])
         self.seed = int(state['seed'])
@@ -555,6 +572,9 @@ class _PlanBase(object):
                 off += 2 * d
         self.colsum_state = 'zero'
         self._colsum_versions = []
+        self._mass_ones = None        # `use_ones` the mass buffers reflect
+        self.cs_parts, self._cs_rows = None, 0
+        self.mass_ws = torch.zeros(2, dtype=torch.int32, device=device)
         self.last_t = 0
 
     def refresh_model(self):
@@ -566,7 +586,7 @@ class _PlanBase(object):
     # zshmc_mass_colstats need), 'fresh' (global column sums of the CURRENT
     # latents around the current EWMV mean, summed over the ranks), 'dirty'.
     def _colstats_fresh(self):
-        return self.colsum_state == 'fresh' and all(
+        return self.colsum_state in ('fresh', 'parts') and all(
             q._version == v for q, v in zip(self.q, self._colsum_versions))
 
     def compute_colstats(self, stream):
@@ -598,7 +618,27 @@ class _PlanBase(object):
                 if sharding is not None and sharding.active:
                     sharding.all_reduce_sum(
                         self.comm_buf[_capi.STATS_WORDS:])
+            self._mass_ones = None
+            if len(self.q) == 1:
+                # one launch: rows of column sums (the per-workgroup partials
+                # a fused transition left behind, or the one reduced row) ->
+                # EWMV update -> mass -> tau
+                parts, rows = (self.cs_parts, self._cs_rows) \
+                    if self.colsum_state == 'parts' else (self.colsum[0], 1)
+                _capi.call('zshmc_mass_update_fused', self.state.data_ptr(),
+                           self.ewmv_mean[0].data_ptr(),
+                           self.ewmv_var[0].data_ptr(), parts.data_ptr(), rows,
+                           self.n_chains_global, self.n_data[0],
+                           hmc.mass_decay, int(use_ones),
+                           self.mass[0].data_ptr(),
+                           self.mass_ws.data_ptr(), stream)
+                self.colsum_state = 'dirty'
+                self._mass_ones = bool(use_ones)
+                return
             self.colsum_state = 'zero'       # consumed and cleared below
+        elif self._mass_ones == bool(use_ones):
+            return          # mass is what it was (hmc.py:158-159, :299-302)
+        self._mass_ones = None if update else bool(use_ones)
         for k in range(len(self.q)):
             # EWMV.t is shared by all latents (hmc.py:118,131): bump once,
             # after the last latent
@@ -628,9 +668,15 @@ class _PlanBase(object):
         if want_colstats:
             if not self._colstats_fresh():
                 self.compute_colstats(stream)
-        elif self.colsum_state == 'fresh':
+        elif self.colsum_state in ('fresh', 'parts'):
             self.colsum_state = 'dirty'      # q moved on, sums did not
         if sharded:
+            if want_colstats and self.colsum_state == 'parts':
+                # the partials of this rank -> the row that crosses the ranks
+                _capi.call('zshmc_mass_colstats_reduce',
+                           self.cs_parts.data_ptr(), self._cs_rows,
+                           self.n_data[0], self.colsum[0].data_ptr(), stream)
+                self.colsum_state = 'fresh'
             if want_colstats:
                 sharding.all_reduce_sum(self.comm_buf)
             elif update is not None:
@@ -686,6 +732,7 @@ class _FusedDiagNormalPlan(_PlanBase):
                                                    chain_shape, device)
         self._probe = probe
         self._src = None
+        self._cs_rows_cache = {}
         self.workspace = torch.zeros(_capi.LINK_WORKSPACE_BYTES,
                                      dtype=torch.uint8, device=device)
         f32 = dict(dtype=torch.float32, device=device)
@@ -728,9 +775,30 @@ class _FusedDiagNormalPlan(_PlanBase):
         self._src = (mean_src, spread_src, mean_src._version,
                      spread_src._version)
 
-    def _link(self, eps_host, collect, retire=None):
+    def _colstats_rows(self):
+        """Rows of per-workgroup column sums the launch of the current
+        configuration leaves behind (0: this shape's kernel cannot)."""
+        key = (self.use_mass, self.zero_mean)
+        if key not in self._cs_rows_cache:
+            ok = all(t.data_ptr() % 16 == 0 for t in
+                     (self.q[0], self.mean, self.logstd, self.mass[0]))
+            self._cs_rows_cache[key] = int(
+                _capi.load().zshmc_fused_colstats_rows(
+                    self.n_chains, self.n_data[0], int(self.use_mass),
+                    int(self.zero_mean))) if ok else 0
+        return self._cs_rows_cache[key]
+
+    def _link(self, eps_host, collect, retire=None, colstats_rows=0):
         hmc = self.hmc
         k = _capi.AdaptLink()
+        if colstats_rows:
+            if self.cs_parts is None or \
+                    self.cs_parts.shape[0] < colstats_rows:
+                self.cs_parts = torch.empty(
+                    colstats_rows, 2 * self.n_data[0], dtype=torch.float64,
+                    device=self.device)
+            k.colstats_mean = self.ewmv_mean[0].data_ptr()
+            k.colstats_parts = self.cs_parts.data_ptr()
         # (an in-kernel update needs the state block even when this launch
         # integrates with the step size the search just returned)
         k.state = None if (eps_host is not None and retire is None) \
@@ -756,7 +824,8 @@ class _FusedDiagNormalPlan(_PlanBase):
                 k.used_step_size = float(used)
         return k
 
-    def _launch(self, t, eps_host, commit, n_leapfrogs, stream, retire=None):
+    def _launch(self, t, eps_host, commit, n_leapfrogs, stream, retire=None,
+                colstats_rows=0):
         info = commit
         if self.pending is not None and eps_host is not None:
             raise RuntimeError("a pending step-size update must be flushed "
@@ -764,7 +833,7 @@ class _FusedDiagNormalPlan(_PlanBase):
         # a launch that carries an update also publishes its sum
         collect = (self.collect_acc or not commit or
                    self.pending is not None or retire is not None)
-        link = self._link(eps_host, collect, retire)
+        link = self._link(eps_host, collect, retire, colstats_rows)
         _capi.call(
             'zshmc_hmc_diag_normal_step', self.q[0].data_ptr(),
             None if self.zero_mean else self.mean.data_ptr(),
@@ -816,7 +885,14 @@ class _FusedDiagNormalPlan(_PlanBase):
             _capi.call('zshmc_state_set', self.state.data_ptr(),
                        _capi.ST_STEP_SIZE, float(eps_host), stream)
             eps_host = None
-        self._launch(t, eps_host, 1, self.hmc.n_leapfrogs, stream, retire)
+        # the column sums of the end state come out of the same launch where
+        # the kernel of this shape can produce them
+        rows = self._colstats_rows() if want_colstats else 0
+        self._launch(t, eps_host, 1, self.hmc.n_leapfrogs, stream, retire, rows)
+        if rows:
+            self._cs_rows = rows
+            self.colsum_state = 'parts'
+            self._colsum_versions = [q._version for q in self.q]
         if sharded and update is not None:
             # applied by the next launch's prologue (or flush()) once the
             # acceptance sums of all ranks have been added
@@ -1260,7 +1336,7 @@ def _try_dense_likelihood_plan(hmc, meta_bn, names, values, chain_shape,
     def analyse(value):
         """(kind, [prior mean, prior spread-as-logstd, inner, observation])."""
         bn = meta_bn.observe(**merge_dicts(
-            {name: _symbolic.wrap_latent(value)}, hmc._resolved_observed()))
+            {name: hmc._as_symbol(value)}, hmc._resolved_observed()))
         stoch = [n for n in bn.nodes.values()
                  if isinstance(n, StochasticTensor)]
         if meta_bn.log_joint is not None:
@@ -1387,8 +1463,10 @@ def _try_fused_plan(hmc, meta_bn, names, values, chain_shape, device):
         return None
 
     def node_dist(value):
-        bn = meta_bn.observe(**merge_dicts({name: value},
-                                           hmc._resolved_observed()))
+        # (as a symbol: a dense-likelihood model written with the reference's
+        # literal spelling must not materialise its logits here)
+        bn = meta_bn.observe(**merge_dicts(
+            {name: hmc._as_symbol(value)}, hmc._resolved_observed()))
         stoch = [n for n in bn.nodes.values()
                  if isinstance(n, StochasticTensor)]
         if len(stoch) != 1 or stoch[0].name != name:
