@@ -213,15 +213,18 @@ def _tuned_start(torch, zs, build, n_sub, n_burn, n_draws, flags_on):
     for _ in range(n_burn):
         op.run(feed_dict=feed_on, sync=False)
     hmc.check_numerics()
-    state = hmc.get_state()
-    q_end = q.clone()
     feed_off = {f: False for f in flags}
     rec = torch.empty((n_draws,) + tuple(q.shape), device=q.device)
-    acc = 0.0
+    acc = torch.zeros((), device=q.device)
     for i in range(n_draws):
         op.run(feed_dict=feed_off, sync=False)
         rec[i].copy_(q)
-        acc += float(info.acceptance_rate.mean().item()) / n_draws
+        acc += info.acceptance_rate.mean()
+    acc = float(acc.item()) / n_draws
+    # the state AFTER the held phase: step size = exp(log_epsilon_bar), the
+    # dual-averaged one (hmc.py:108-110), not the last noisy iterate
+    state = hmc.get_state()
+    q_end = q.clone()
     burn = n_draws // 3
     ess = zs.diagnostics.effective_sample_size_device(rec, burn_in=burn)
     ok = torch.isfinite(ess)
@@ -237,13 +240,15 @@ def _time_transitions(torch, hmc, op, info, feed, n_warm, n_timed, barrier):
     for _ in range(n_warm):
         op.run(feed_dict=feed, sync=False)
     hmc.check_numerics()
+    acc = torch.zeros((), device=hmc._plan.device)
     barrier()
     t0 = time.perf_counter()
     for _ in range(n_timed):
         op.run(feed_dict=feed, sync=False)
+        acc += info.acceptance_rate.mean()     # (device-side, no sync)
     barrier()
     elapsed = time.perf_counter() - t0
-    acc = float(info.acceptance_rate.mean().item())
+    acc = float(acc.item()) / n_timed          # mean over the timed region
     plan = hmc._plan
     stream = torch.cuda.current_stream().cuda_stream
     plan._likelihood(plan.q_new, stream)
@@ -310,20 +315,22 @@ def extra_config3(torch, zs, dev, n_rows=1000000, n_chains=32768, n_feat=256,
         return hmc, op, info, w, (flag,)
 
     state, w_sub, ess_pt, acc_sub = _tuned_start(
-        torch, zs, build, n_sub, 40, 240, (True,))
+        torch, zs, build, n_sub, 60, 240, (True,))
     hmc, op, info, w, flags = build(n_chains, None)
     w.copy_(w_sub.repeat(n_chains // n_sub, 1))
     hmc.set_state(state)
 
     def barrier():
         torch.cuda.synchronize()
+    # adaptation held in the timed region: step size = the dual-averaged one
     elapsed, kern_ms, acc = _time_transitions(
-        torch, hmc, op, info, {flags[0]: True}, 1, n_timed, barrier)
+        torch, hmc, op, info, {flags[0]: False}, 1, n_timed, barrier)
     ms = elapsed / n_timed * 1e3
     flop_eval = 4.0 * n_rows * n_feat * n_chains
     return {
         'workload': 'configs[2]: Bayesian logistic regression, synthetic '
-                    '%d x %d, %d chains, L=%d, step-size adaptation on, the '
+                    '%d x %d, %d chains, L=%d, step size adapted on a subset '
+                    'and held in the timed region, the '
                     'model written with the reference\'s literal '
                     '`w @ X.T` logits' % (
                         n_rows, n_feat, n_chains, n_leapfrogs),
@@ -333,11 +340,13 @@ def extra_config3(torch, zs, dev, n_rows=1000000, n_chains=32768, n_feat=256,
         'value': n_chains * n_leapfrogs / (ms * 1e-3),
         'unit': 'chain-leapfrog-steps/s',
         'mean_acceptance': acc,
+        'mean_acceptance_subset_held_phase': acc_sub,
         'target_acceptance': 0.8,
         'step_size': float(info.updated_step_size.item()),
-        'start': TUNED_START_NOTE + ' Subset: %d chains, 40 adaptive + 240 '
-                 'recorded transitions (mean acceptance %.3f).' % (
-                     n_sub, acc_sub),
+        'start': TUNED_START_NOTE.replace(
+            'run with adaptation ON', 'run with adaptation HELD (config 3)') +
+                 ' Subset: %d chains, 60 adaptive + 240 recorded transitions '
+                 '(mean acceptance %.3f).' % (n_sub, acc_sub),
         'ess': {
             'ess_per_chain_per_transition': ess_pt,
             'ess_per_sec': ess_pt * n_chains * 1e3 / ms,
@@ -457,6 +466,7 @@ def lntm_workload(torch, zs, dev, n_chains, sharding=None, dist=None,
         'value': rows * n_leapfrogs / (ms * 1e-3),
         'unit': '(chain, document)-leapfrog-steps/s',
         'mean_acceptance': acc,
+        'mean_acceptance_subset_held_phase': acc_sub,
         'target_acceptance': 0.6,
         'step_size': float(info.updated_step_size.item()),
         'collective': 'none' if world == 1 else
@@ -565,6 +575,12 @@ def run_lntm_line(args, torch, zs, dist, ChainSharding, dev, world, rank,
         except Exception as e:                       # noqa: BLE001
             sys.stderr.write('communicator teardown: %r\n' % (e,))
         dist.destroy_process_group()
+
+
+def _capi_kernel_name(n_data, has_mass, zero_mean):
+    from zhusuan_amd import _capi
+    return _capi.load().zshmc_fused_kernel_name(n_data, has_mass,
+                                                zero_mean).decode()
 
 
 def main():
@@ -772,13 +788,56 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         other_elapsed = float(tt.item())
     hmc.set_state(saved)
-    gc.enable()
     other_mode = {
         'adaptation': 'off' if adapt_timed else 'on',
         'ms_per_step': other_elapsed / n_other * 1e3,
         'value': total_chains * L * n_other / other_elapsed,
         'steps': n_other,
     }
+
+    # mass adaptation (config 1's first 50 iterations, config 5): a second
+    # sampler on the same state with adapt_mass declared, so that the mass
+    # tile is part of the kernel.  Step size + mass adapting on every
+    # transition -- the column sums of the end state come out of the
+    # transition launch, one more launch reduces them + EWMV + mass + tau, and
+    # when sharded they travel in the same all-reduce as the acceptance sum --
+    # against the same sampler with both flags off.
+    f_ss, f_m = zs.placeholder(bool), zs.placeholder(bool)
+    hmc_m = zs.HMC(step_size=0.05, n_leapfrogs=L, adapt_step_size=f_ss,
+                   adapt_mass=f_m, target_acceptance_rate=0.8, seed=1,
+                   sharding=sharding)
+    op_m, info_m = hmc_m.sample(gaussian(), {}, {'x': x})
+    for _ in range(30):
+        op_m.run(feed_dict={f_ss: True, f_m: True}, sync=False)
+    hmc_m.check_numerics()
+    mass_modes = {}
+    for label, on in (('step size + mass adapting', True),
+                      ('both flags off', False)):
+        feed_m = {f_ss: on, f_m: on}
+        for _ in range(60):
+            op_m.run(feed_dict=feed_m, sync=False)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(n_other):
+            op_m.run(feed_dict=feed_m, sync=False)
+        barrier()
+        el = time.perf_counter() - t1
+        if world > 1:
+            tt = torch.tensor([el], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        mass_modes[label] = {
+            'ms_per_step': el / n_other * 1e3,
+            'value': total_chains * L * n_other / el,
+            'steps': n_other,
+            'mean_acceptance': float(info_m.acceptance_rate.mean().item()),
+        }
+    mass_modes['kernel'] = _capi_kernel_name(D, 1, 1)
+    mass_modes['overhead_of_adapting'] = (
+        mass_modes['step size + mass adapting']['ms_per_step'] /
+        mass_modes['both flags off']['ms_per_step'] - 1.0)
+    del hmc_m, op_m, info_m
+    gc.enable()
 
     # ESS/s (reference estimator, zhusuan/diagnostics.py:17-64) over EVERY
     # chain of this rank: record n_draws snapshots of the state on the device,
@@ -850,6 +909,7 @@ def main():
             'elem_leapfrog_steps_per_sec': value * D,
             'mean_acceptance': acc_mean,
             'other_adaptation_mode': other_mode,
+            'mass_adaptation_modes': mass_modes,
             'step_size': eps,
             'roofline': {
                 'bound': 'hbm',
