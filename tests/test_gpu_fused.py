@@ -423,10 +423,9 @@ def test_fused_plan_follows_fed_and_updated_parameters(env):
 
 
 # (C, D): every ring instantiation that can produce the column statistics
-# (NCH = 1..6), ragged last chunks, fewer turns than CUs, many chains per CU
+# (NCH = 1..5), ragged last chunks, fewer turns than CUs, many chains per CU
 COLSTATS_SHAPES = [(40, 132), (300, 256), (999, 260), (64, 512), (5000, 700),
-                   (4100, 768), (20000, 1024), (70, 1028), (600, 1280),
-                   (257, 1536)]
+                   (4100, 768), (20000, 1024), (70, 1028), (600, 1280)]
 
 
 @pytest.mark.parametrize('C,D', COLSTATS_SHAPES)
@@ -453,11 +452,15 @@ def test_column_statistics_of_the_end_state_come_out_of_the_launch(
     assert 0 < rows <= 256
     k = FusedKernel(torch, C, D)
     # a step size whose acceptance is well inside (0, 1): dry runs
-    for eps in (3.0, 2.2, 1.6, 1.2, 0.9, 0.65, 0.45, 0.3, 0.2):
-        eps = eps / D ** 0.25
-        k.step(q0.clone(), mean, logstd, mass, eps, 4, 123, 7, commit=0)
-        if 0.3 < float(k.stats[0].item()) / C < 0.85:
-            break
+    best = None
+    for f in np.geomspace(4.0, 0.05, 24):
+        e = float(f) / D ** 0.25
+        k.step(q0.clone(), mean, logstd, mass, e, 4, 123, 7, commit=0)
+        a = float(k.stats[0].item()) / C
+        if best is None or abs(a - 0.6) < abs(best[0] - 0.6):
+            best = (a, e)
+    assert 0.1 < best[0] < 0.95, best
+    eps = best[1]
     qa = q0.clone()
     k.step(qa, mean, logstd, mass, eps, 4, 123, 7)
     info_a = [x.clone() for x in k.info]
@@ -472,7 +475,7 @@ def test_column_statistics_of_the_end_state_come_out_of_the_launch(
     moved = (qb != q0).any(1)
     assert 0 < int(moved.sum()) < C        # both branches exercised
     d = (qb - m).double()                   # float32 difference, as the kernel
-    want = torch.cat([d.sum(0), (qb - m).square().double().sum(0)])
+    want = torch.cat([d.sum(0), d.square().sum(0)])
     got = parts.sum(0)
     torch.testing.assert_close(got, want, rtol=1e-12, atol=1e-9)
     # the two reducers: one row for the all-reduce; EWMV update in one launch
@@ -513,7 +516,7 @@ def test_column_statistics_are_refused_where_the_kernel_has_none(env):
     zs, torch = env
     from zhusuan_amd import _capi
     lib = _capi.load()
-    for D in (4, 10, 128, 130, 1540, 2048):
+    for D in (4, 10, 128, 130, 1284, 1536, 2048):
         assert lib.zshmc_fused_colstats_rows(1000, D, 0, 1) == 0
     dev = torch.device('cuda', 0)
     C, D = 64, 96

@@ -5,8 +5,11 @@ repetitions).  Libraries of ABI 0.1 (round 1: step_size_dev / acc_sum
 arguments) and 0.2 (zshmc_adapt_link) are both understood, so that a build of
 an earlier commit can sit in the same table.
 Usage: python tools/kbench.py lib1.so lib2.so ... [--mass] [--mean] [--adapt]
+                              [--colstats]
   --mean   non-zero mean vector (0.2: the mean-tile instantiation)
-  --adapt  0.2 only: every launch carries a pending dual-averaging update"""
+  --adapt  0.2 only: every launch carries a pending dual-averaging update
+  --colstats  0.3 only: the launch also leaves the column sums of its end
+           state (zshmc_adapt_link.colstats_*)"""
 import ctypes
 import os
 import sys
@@ -38,6 +41,7 @@ def main():
     mass_on = '--mass' in sys.argv
     mean_on = '--mean' in sys.argv
     adapt_on = '--adapt' in sys.argv
+    cs_on = '--colstats' in sys.argv
     C = int(os.environ.get('KB_C', '65536'))
     D = int(os.environ.get('KB_D', '1024'))
     L = int(os.environ.get('KB_L', '10'))
@@ -66,6 +70,12 @@ def main():
     link.fresh_start, link.used_step_size = 0, float('nan')
     link.delta, link.gamma, link.t0, link.kappa, link.mu = \
         0.8, 0.05, 100.0, 0.75, 10 * eps
+
+    if cs_on:
+        cs_mean = torch.zeros(D, device=dev)
+        cs_parts = torch.zeros(512, 2 * D, dtype=torch.float64, device=dev)
+        link.colstats_mean = cs_mean.data_ptr()
+        link.colstats_parts = cs_parts.data_ptr()
 
     def run(ver, fn, q, it):
         mptr = None if mass is None else mass.data_ptr()

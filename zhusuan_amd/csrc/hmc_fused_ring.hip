@@ -266,10 +266,35 @@ __device__ __forceinline__ void store_row(uint32_t voff, uint32_t voff_last,
 // Waves per SIMD = the register budget that compiles WITHOUT scratch spills
 // (a spill is a VMEM instruction the vmcnt ledger does not know about;
 // tests/test_build_resources.py asserts "VGPRs Spill: 0" per instantiation).
-constexpr int ring_waves_for(int nch, bool has_mass) {
-  return nch <= 3 ? 4
-                  : (nch == 4 ? (has_mass ? 3 : ZS_RING_WAVES)
-                              : (nch == 5 && !has_mass ? 3 : 2));
+// COLSTATS instantiations (column sums of the end state, see the kernel):
+// ZS_CS_MODE 1 (default): every lane accumulates its 4*NCH columns in DOUBLE
+//   registers over all the chains its wave runs (8*NCH more VGPRs: two waves
+//   per SIMD) and adds them to the workgroup's LDS tile once, after the
+//   loop.  Double sums differ from run to run only by the order of the waves'
+//   chains, at the 1e-16 level -- what the stand-alone column-statistics
+//   kernel's double atomics gave.
+// ZS_CS_MODE 0: one ds_add_f64 per element per chain straight into the LDS
+//   tile (no extra registers): measured +45 % per launch at 65 536 x 1 024,
+//   the LDS atomic unit retires a wave-wide f64 add every ~13 clocks.
+// ZS_CS_MODE 2: float registers (A/B probe: what determinism costs).
+#ifndef ZS_CS_MODE
+#define ZS_CS_MODE 1
+#endif
+// waves per SIMD of the COLSTATS variants: what 8*NCH more VGPRs leave room
+// for without spills (ZS_CS_WAVES overrides, A/B)
+#ifndef ZS_CS_K
+#define ZS_CS_K 2  // ring depth of the COLSTATS variants where LDS has room
+#endif
+constexpr int ring_waves_for(int nch, bool has_mass, bool colstats = false) {
+  const int w = nch <= 3 ? 4
+                         : (nch == 4 ? (has_mass ? 3 : ZS_RING_WAVES)
+                                     : (nch == 5 && !has_mass ? 3 : 2));
+#ifdef ZS_CS_WAVES
+  const int cap = ZS_CS_WAVES;
+#else
+  const int cap = ZS_CS_MODE == 0 ? 4 : (nch <= 2 ? 4 : (nch == 3 ? 3 : 2));
+#endif
+  return (colstats && w > cap) ? cap : w;
 }
 
 // STAGE: the workgroup's per-chain scalars (MH uniform in, five HMCInfo values
@@ -289,12 +314,13 @@ constexpr int ring_waves_for(int nch, bool has_mass) {
 // accumulated with ds_add_f64 into one [2][row] double tile per workgroup.
 template <int NCH, int K, bool HAS_MASS, bool STAGE, bool ZERO_MEAN,
           bool COLSTATS>
-__global__ __launch_bounds__(256 * ring_waves_for(NCH, HAS_MASS)) void
+__global__ __launch_bounds__(256 * ring_waves_for(NCH, HAS_MASS, COLSTATS)) void
 hmc_diag_normal_ring_kernel(FusedArgs a) {
   constexpr int kLedgerInfo = STAGE ? 0 : kInfoStores;
   constexpr int kRow = NCH * 256;  // padded row length (floats) of one chain
   constexpr int kRowB = kRow * 4;
-  constexpr int kWavesPerBlock = 4 * ring_waves_for(NCH, HAS_MASS);  // a CU
+  constexpr int kWavesPerBlock =
+      4 * ring_waves_for(NCH, HAS_MASS, COLSTATS);  // a CU
   constexpr int kSlots = COLSTATS ? K + 1 : K;  // physical slots per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int kTiles =
@@ -470,6 +496,17 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
 #ifdef ZS_TIMING
   unsigned long long n_done = 0;
 #endif
+#if ZS_CS_MODE == 2
+  typedef float cs_t;
+#else
+  typedef double cs_t;
+#endif
+  // COLSTATS, register modes: this lane's column sums over its wave's chains
+  cs_t cs1[COLSTATS ? NCH : 1][4], cs2[COLSTATS ? NCH : 1][4];
+#pragma unroll
+  for (int k = 0; k < (COLSTATS ? NCH : 1); ++k)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cs1[k][j] = cs2[k][j] = 0;
   int slot = 0;
   for (int it = 0; tk[0] < count; ++it) {
     const int t_cur = tk[0];
@@ -741,16 +778,40 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
         const f4 d = v - *reinterpret_cast<const f4*>(s_cm + (k * kWave + lane) * 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+#if ZS_CS_MODE == 0
           const int idx = (k * 4 + j) * kWave + lane;
           __hip_atomic_fetch_add(&s_cs[idx], (double)d[j], __ATOMIC_RELAXED,
                                  __HIP_MEMORY_SCOPE_WORKGROUP);
-          __hip_atomic_fetch_add(&s_cs[kRow + idx], (double)(d[j] * d[j]),
-                                 __ATOMIC_RELAXED,
+          __hip_atomic_fetch_add(&s_cs[kRow + idx],
+                                 (double)d[j] * (double)d[j], __ATOMIC_RELAXED,
                                  __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+          const cs_t dj = (cs_t)d[j];
+          cs1[k][j] += dj;
+          cs2[k][j] += dj * dj;  // (double: exact product, as the
+                                 // stand-alone kernel's)
+#endif
         }
       }
     }
   }
+#if ZS_CS_MODE != 0
+  if (COLSTATS) {
+    // this wave's sums into the workgroup's tile, once
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      if (k == NCH - 1 && !valid_last) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int idx = (k * 4 + j) * kWave + lane;
+        __hip_atomic_fetch_add(&s_cs[idx], (double)cs1[k][j], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&s_cs[kRow + idx], (double)cs2[k][j],
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+  }
+#endif
   // no DMA may outlive the wave (its LDS would be handed to another block)
   wait_vmcnt<0>();
 #ifdef ZS_TIMING
@@ -813,12 +874,14 @@ constexpr size_t kLdsLimit = 160 * 1024;
 // ring depth of the COLSTATS instantiations (one more physical slot per wave
 // has to fit in LDS next to the double tile): NCH <= 2 keep K = 3, the wider
 // rows run one row ahead like NCH = 4 does anyway
-constexpr int ring_cs_k(int nch) { return nch <= 2 ? 3 : 1; }
-constexpr int kRingCsMaxNch = 6;  // 7, 8: LDS / VGPR budget exhausted
+constexpr int ring_cs_k(int nch) {
+  return nch <= 2 ? 3 : (nch <= 5 && ZS_CS_MODE != 0 ? ZS_CS_K : 1);
+}
+constexpr int kRingCsMaxNch = 5;  // 6..8: VGPR budget exhausted (spills)
 
 constexpr size_t ring_lds_base(int nch, int k, bool has_mass, bool zero_mean,
                                bool colstats) {
-  const int waves = 4 * ring_waves_for(nch, has_mass);
+  const int waves = 4 * ring_waves_for(nch, has_mass, colstats);
   return (size_t)((zero_mean ? 0 : 1) + (has_mass ? 1 : 0) +
                   (colstats ? 1 : 0) + waves * (colstats ? k + 1 : k)) *
              nch * 1024 +
@@ -827,7 +890,7 @@ constexpr size_t ring_lds_base(int nch, int k, bool has_mass, bool zero_mean,
 
 template <int NCH, int K, bool HAS_MASS, bool ZERO_MEAN, bool COLSTATS>
 static int launch_ring_cfg(const FusedArgs& a_in, hipStream_t stream) {
-  constexpr int kWaves = 4 * ring_waves_for(NCH, HAS_MASS);
+  constexpr int kWaves = 4 * ring_waves_for(NCH, HAS_MASS, COLSTATS);
   constexpr size_t lds_base =
       ring_lds_base(NCH, K, HAS_MASS, ZERO_MEAN, COLSTATS);
   static_assert(lds_base <= kLdsLimit, "ring does not fit in LDS");
