@@ -172,7 +172,7 @@ typedef struct zshmc_adapt_link {
 
 /* Rows of colstats_parts a launch of zshmc_hmc_diag_normal_step on this shape
  * fills (one per workgroup), or 0 if the kernel of this shape cannot produce
- * the column statistics (rows of <= 128 or > 1 280 latents, not a multiple
+ * the column statistics (rows of <= 128 or > 1 536 latents, not a multiple
  * of 4): use zshmc_mass_colstats then.  All device pointers of the call must
  * be 16-byte aligned. */
 int64_t zshmc_fused_colstats_rows(int64_t n_chains, int64_t n_data,

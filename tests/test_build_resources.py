@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, 'zhusuan_amd', 'csrc', 'hmc_fused_ring.hip')
 
 
-N_RING_KERNELS = 2 * (6 * 4 + 3 + 2) + 2 * 5 * 4   # + the COLSTATS variants
+N_RING_KERNELS = 2 * (6 * 4 + 3 + 2) + 2 * 6 * 4   # + the COLSTATS variants
 
 
 def _hipcc():

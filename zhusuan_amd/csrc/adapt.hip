@@ -111,30 +111,41 @@ __global__ void mass_update_kernel(float* __restrict__ state,
   mass_out[d] = use_ones ? 1.0f : 1.0f / var;
 }
 
-// Rows of column sums -> one row, fixed order.  Block (64 x 4): 64 columns,
-// 4 row lanes striding over the rows; LDS-reduced in lane order.
+// Rows of column sums -> one row, fixed order.  Block (64 x 16): 64 columns,
+// 16 row lanes striding over the rows with four loads in flight each (the
+// 4 MB of partials of a 256-workgroup launch at D = 1 024 are read by 32
+// blocks: latency-, not bandwidth-bound); LDS-reduced in lane order.
+constexpr int kPartLanes = 16;
+
 __device__ __forceinline__ double parts_column_sum(
     const double* __restrict__ parts, int64_t n_parts, int64_t stride,
     int64_t col, bool valid, double (*sh)[kColsPerBlock]) {
   const int tx = threadIdx.x % kColsPerBlock;
   const int ty = threadIdx.x / kColsPerBlock;
-  double s = 0.0;
-  if (valid)
-    for (int64_t r = ty; r < n_parts; r += kRowLanes)
-      s += parts[r * stride + col];
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  if (valid) {
+    int64_t r = ty;
+    for (; r + 3 * kPartLanes < n_parts; r += 4 * kPartLanes) {
+      s0 += parts[r * stride + col];
+      s1 += parts[(r + kPartLanes) * stride + col];
+      s2 += parts[(r + 2 * kPartLanes) * stride + col];
+      s3 += parts[(r + 3 * kPartLanes) * stride + col];
+    }
+    for (; r < n_parts; r += kPartLanes) s0 += parts[r * stride + col];
+  }
   __syncthreads();  // (sh may still be read from a previous call)
-  sh[ty][tx] = s;
+  sh[ty][tx] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   double tot = 0.0;
 #pragma unroll
-  for (int i = 0; i < kRowLanes; ++i) tot += sh[i][tx];
+  for (int i = 0; i < kPartLanes; ++i) tot += sh[i][tx];
   return tot;
 }
 
-__global__ __launch_bounds__(256) void mass_colstats_reduce_kernel(
+__global__ __launch_bounds__(1024) void mass_colstats_reduce_kernel(
     const double* __restrict__ parts, int64_t n_parts, int64_t n_data,
     double* __restrict__ colsum) {
-  __shared__ double sh[kRowLanes][kColsPerBlock];
+  __shared__ double sh[kPartLanes][kColsPerBlock];
   const int tx = threadIdx.x % kColsPerBlock;
   const int ty = threadIdx.x / kColsPerBlock;
   // blockIdx.x walks the 2*n_data columns of a row
@@ -148,13 +159,13 @@ __global__ __launch_bounds__(256) void mass_colstats_reduce_kernel(
 // zshmc_mass_update(update = 1) fed by rows of column sums, tau advanced by
 // the block that finishes last (every block has read tau by then: the
 // increment of the retirement counter comes after the block's barrier).
-__global__ __launch_bounds__(256) void mass_update_fused_kernel(
+__global__ __launch_bounds__(1024) void mass_update_fused_kernel(
     float* __restrict__ state, float* __restrict__ ewmv_mean,
     float* __restrict__ ewmv_var, const double* __restrict__ parts,
     int64_t n_parts, double inv_chains, int64_t n_data, float decay,
     int use_ones, float* __restrict__ mass_out,
     unsigned int* __restrict__ retired) {
-  __shared__ double sh[kRowLanes][kColsPerBlock];
+  __shared__ double sh[kPartLanes][kColsPerBlock];
   const int tx = threadIdx.x % kColsPerBlock;
   const int ty = threadIdx.x / kColsPerBlock;
   const int64_t d = (int64_t)blockIdx.x * kColsPerBlock + tx;
@@ -273,7 +284,8 @@ extern "C" int zshmc_mass_colstats_reduce(const double* parts, int64_t n_parts,
   ZS_REQUIRE(n_parts >= 1 && n_data >= 1,
              "zshmc_mass_colstats_reduce: bad shape");
   const int blocks = (int)((2 * n_data + kColsPerBlock - 1) / kColsPerBlock);
-  hipLaunchKernelGGL(mass_colstats_reduce_kernel, dim3(blocks), dim3(256), 0,
+  hipLaunchKernelGGL(mass_colstats_reduce_kernel, dim3(blocks),
+                     dim3(kColsPerBlock * kPartLanes), 0,
                      reinterpret_cast<hipStream_t>(stream), parts, n_parts,
                      n_data, colsum);
   ZS_LAUNCH_CHECK("mass_colstats_reduce_kernel launch");
@@ -289,7 +301,8 @@ extern "C" int zshmc_mass_update_fused(
   ZS_REQUIRE(n_parts >= 1 && n_chains_global > 0 && n_data >= 1,
              "zshmc_mass_update_fused: bad shape");
   const int blocks = (int)((n_data + kColsPerBlock - 1) / kColsPerBlock);
-  hipLaunchKernelGGL(mass_update_fused_kernel, dim3(blocks), dim3(256), 0,
+  hipLaunchKernelGGL(mass_update_fused_kernel, dim3(blocks),
+                     dim3(kColsPerBlock * kPartLanes), 0,
                      reinterpret_cast<hipStream_t>(stream), state, ewmv_mean,
                      ewmv_var, parts, n_parts, 1.0 / (double)n_chains_global,
                      n_data, decay, use_ones, mass_out,

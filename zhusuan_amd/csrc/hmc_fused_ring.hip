@@ -266,19 +266,26 @@ __device__ __forceinline__ void store_row(uint32_t voff, uint32_t voff_last,
 // Waves per SIMD = the register budget that compiles WITHOUT scratch spills
 // (a spill is a VMEM instruction the vmcnt ledger does not know about;
 // tests/test_build_resources.py asserts "VGPRs Spill: 0" per instantiation).
-// COLSTATS instantiations (column sums of the end state, see the kernel):
-// ZS_CS_MODE 1 (default): every lane accumulates its 4*NCH columns in DOUBLE
-//   registers over all the chains its wave runs (8*NCH more VGPRs: two waves
-//   per SIMD) and adds them to the workgroup's LDS tile once, after the
-//   loop.  Double sums differ from run to run only by the order of the waves'
-//   chains, at the 1e-16 level -- what the stand-alone column-statistics
-//   kernel's double atomics gave.
-// ZS_CS_MODE 0: one ds_add_f64 per element per chain straight into the LDS
-//   tile (no extra registers): measured +45 % per launch at 65 536 x 1 024,
-//   the LDS atomic unit retires a wave-wide f64 add every ~13 clocks.
-// ZS_CS_MODE 2: float registers (A/B probe: what determinism costs).
+// COLSTATS instantiations (column sums of the end state, see the kernel); how
+// a chain's 4*NCH (q' - m) and (q' - m)^2 per lane reach the workgroup's
+// double tile, measured at 65 536 x 1 024, L = 10 (gpurun_out/r03c/kbench.txt;
+// plain launch 0.0924 ms, with a mass vector 0.0920 ms):
+// ZS_CS_MODE 0 (default): one ds_add_f64 per element per chain straight into
+//   the tile, no extra registers, the plain instantiation's waves per SIMD:
+//   0.1018 / 0.1022 ms (+10 / +11 %).  Double adds: the sums differ from run
+//   to run only by the order of the chains, at the 1e-16 level -- what the
+//   stand-alone column-statistics kernel's double atomics gave.
+// ZS_CS_MODE 1: DOUBLE register accumulators per lane over the chains its
+//   wave runs, added to the tile once after the loop: 8*NCH more VGPRs, two
+//   waves per SIMD at NCH >= 4: 0.1069 / 0.1045 ms at ring depth 1, 0.1117 /
+//   0.1071 at depth 2 (+14..+21 %): the lost occupancy costs more than the
+//   atomics.
+// ZS_CS_MODE 2: FLOAT register accumulators, three waves per SIMD: 0.0967 /
+//   0.0990 ms (+5 / +8 %) -- cheapest, but a float32 partial sum over the
+//   ~20 chains a wave happens to draw (tickets are dynamic) moves in its last
+//   bits from run to run, and with it the mass and every later transition.
 #ifndef ZS_CS_MODE
-#define ZS_CS_MODE 1
+#define ZS_CS_MODE 0
 #endif
 // waves per SIMD of the COLSTATS variants: what 8*NCH more VGPRs leave room
 // for without spills (ZS_CS_WAVES overrides, A/B)
@@ -877,7 +884,7 @@ constexpr size_t kLdsLimit = 160 * 1024;
 constexpr int ring_cs_k(int nch) {
   return nch <= 2 ? 3 : (nch <= 5 && ZS_CS_MODE != 0 ? ZS_CS_K : 1);
 }
-constexpr int kRingCsMaxNch = 5;  // 6..8: VGPR budget exhausted (spills)
+constexpr int kRingCsMaxNch = 6;  // 7, 8: LDS / VGPR budget exhausted
 
 constexpr size_t ring_lds_base(int nch, int k, bool has_mass, bool zero_mean,
                                bool colstats) {

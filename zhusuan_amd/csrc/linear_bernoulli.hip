@@ -367,7 +367,14 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2
   for (int t = 0; t < FB; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) G[t][r] = 0.f;
-  float ll_lane = 0.f;
+  // log-likelihood of this lane's rows: summed per tile in float32 (16
+  // terms), tile sums in float64.  One float32 accumulator over all tiles
+  // reaches ~1e5 at N = 10^6 (ulp 0.016) and random-walks to an error of
+  // O(1) in the log-density -- acceptance at BASELINE configs[2]'s full size
+  // fell from 0.90 to 0.41 on it (gpurun_out/r03b); the reference's
+  // tf.reduce_sum is a tree reduction and has no such growth.
+  double ll_lane = 0.0;
+  float ll_tile = 0.f;
 
   // gridDim.y > 1: the data rows are split into gridDim.y contiguous ranges of
   // whole tiles and this workgroup writes PARTIAL sums (reduced afterwards by
@@ -516,7 +523,7 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2
         const float lp = sv * yv - fmaxf(sv, 0.f) -
                          0.6931471805599453f * __builtin_amdgcn_logf(t1);
         S[r] = valid ? yv - sig : 0.f;
-        ll_lane += valid ? lp : 0.f;
+        ll_tile += valid ? lp : 0.f;
       } else {
         // sum_v x_v log((theta.phi)_v) and d/d(theta.phi) = x / (theta.phi);
         // x = 0 contributes nothing (also where the product underflows)
@@ -524,7 +531,7 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2
         const bool on = valid && xv != 0.f;
         const float lp = xv * (0.6931471805599453f * __builtin_amdgcn_logf(sv));
         S[r] = on ? xv * __builtin_amdgcn_rcpf(sv) : 0.f;
-        ll_lane += on ? lp : 0.f;
+        ll_tile += on ? lp : 0.f;
       }
     };
     // B operand of phase 3: X[row][b*HALF + lo*FB .. +FB-1]
@@ -606,6 +613,8 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2
       for (int r = 0; r < 16; ++r) xcnt[r] = xnext[r];
     }
     __syncthreads();  // tile+1 published; this buffer free for tile+2
+    ll_lane += (double)ll_tile;
+    ll_tile = 0.f;
     ZS_LB_MARK(5)  // DMA wait + barrier 2
   }
 #ifdef ZS_LB_TIMING
@@ -632,12 +641,13 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2
   }
   // ll of chain a*32+lo: this lane's 16 rows per tile + lane^32's + the
   // sibling wave's 32 rows (through the exchange slots, now idle)
-  const float ll_half = ll_lane + __shfl_xor(ll_lane, 32, 64);
-  if (hi == 0) sR[wave * 32 + lo] = ll_half;
+  const double ll_half = ll_lane + __shfl_xor(ll_lane, 32, 64);
+  double* __restrict__ sRd = reinterpret_cast<double*>(sR);  // 64 doubles
+  if (hi == 0) sRd[wave * 32 + lo] = ll_half;
   __syncthreads();
   if (b == 0 && hi == 0) {
     const int64_t chain = c0 + a * 32 + lo;
-    if (chain < C) ll[chain] = ll_half + sR[(wave ^ 1) * 32 + lo];
+    if (chain < C) ll[chain] = (float)(ll_half + sRd[(wave ^ 1) * 32 + lo]);
   }
 }
 
