@@ -187,6 +187,34 @@ int zshmc_hmc_diag_normal_step(
     float* orig_log_prob, float* log_prob,
     uint32_t* flags, const zshmc_adapt_link* link, void* stream);
 
+/* n_transitions consecutive transitions (iterations iteration_first,
+ * iteration_first + 1, ...) from ONE call: the launch loop runs on this side
+ * of the boundary, so a host language pays its per-call cost once per run.
+ * Same arguments as zshmc_hmc_diag_normal_step (commit = 1); the link applies
+ * to every transition of the run:
+ *   - comm == NULL (all chains on this GPU): link->pending, fresh_start and
+ *     used_step_size belong to the FIRST transition; link->retire_update
+ *     (ZSHMC_PEND_ADAPT / _HOLD / _NONE) is what every transition of the run
+ *     owes and retires itself;
+ *   - comm != NULL (a zshmc_comm_create communicator: chains sharded over
+ *     GPUs): after every launch stats[0..1] are all-reduced on the stream and
+ *     the update of kind link->retire_update is applied by the NEXT launch's
+ *     prologue; on return the LAST transition's update is still pending (pass
+ *     it as link->pending of the next call, or zshmc_stepsize_flush it).
+ * The mass vector is the same for the whole run and no column statistics are
+ * taken (link->colstats_parts must be NULL): iterations that adapt the mass or
+ * search the step size (hmc.py:284-345) go through zshmc_hmc_diag_normal_step.
+ * HMCInfo arrays hold the LAST transition's values. */
+int zshmc_hmc_diag_normal_run(
+    float* q, const float* mean, const float* logstd, const float* mass,
+    float step_size_host,
+    int64_t n_chains, int64_t n_data, int64_t chain_offset,
+    int n_leapfrogs, uint64_t seed, uint32_t iteration_first,
+    int n_transitions,
+    float* acceptance_rate, float* orig_hamiltonian, float* hamiltonian,
+    float* orig_log_prob, float* log_prob,
+    uint32_t* flags, const zshmc_adapt_link* link, void* comm, void* stream);
+
 /* Apply link->pending to link->state from link->stats[0] (one tiny launch);
  * the caller then resets its pending marker to ZSHMC_PEND_NONE. */
 int zshmc_stepsize_flush(const zshmc_adapt_link* link, void* stream);

@@ -200,3 +200,22 @@ class FakeLibrary(object):
 
     def zshmc_zero(self, ptr, n_bytes, stream):
         ctypes.memset(int(ptr), 0, int(n_bytes))
+
+    # -- zshmc_hmc_diag_normal_run: the launch loop of csrc/hmc_fused_normal.hip
+    def zshmc_hmc_diag_normal_run(
+            self, q, mean, logstd, mass, step_size_host, n_chains, n_data,
+            chain_offset, n_leapfrogs, seed, iteration_first, n_transitions,
+            acc_out, h0, h1, lp0, lp1, flags, link_ref, comm, stream):
+        link = link_ref._obj
+        kind = link.retire_update
+        assert not comm, 'the fake has no communicator'
+        for i in range(int(n_transitions)):
+            l = _capi.AdaptLink.from_buffer_copy(link)
+            if i > 0:
+                l.fresh_start, l.used_step_size = 0, float('nan')
+                l.pending = _capi.PEND_NONE
+            l.retire_update = kind
+            self.zshmc_hmc_diag_normal_step(
+                q, mean, logstd, mass, step_size_host, n_chains, n_data,
+                chain_offset, n_leapfrogs, seed, int(iteration_first) + i, 1,
+                acc_out, h0, h1, lp0, lp1, flags, ctypes.byref(l), stream)

@@ -177,3 +177,56 @@ def test_two_rank_orchestration_matches_oracle(tmp_path, read_every_run, mass):
             assert int(d['n_launch']) == ITERS + int(d['n_search'])
     np.testing.assert_allclose(np.concatenate(rows), want_q, rtol=0,
                                atol=2e-4 if mass else 1e-6)
+
+
+@pytest.mark.parametrize('mass', [False, True])
+def test_run_many_equals_a_loop_of_runs(monkeypatch, mass):
+    """sample_op.run_many(n): the stretches that need nothing from the host
+    (no search, mass not adapting) are one zshmc_hmc_diag_normal_run call;
+    state, step size and iteration counter equal n single runs."""
+    import zhusuan_amd as zs
+    from zhusuan_amd import _capi, hmc as H
+    from fake_zshmc import FakeLibrary
+    mean, logstd, q0 = _problem()
+    out = []
+    for many in (False, True):
+        fake = FakeLibrary()
+        monkeypatch.setattr(_capi, 'call', fake.call)
+        monkeypatch.setattr(H._capi, 'current_stream', lambda: 0)
+        mean_t, logstd_t = torch.tensor(mean), torch.tensor(logstd)
+        q = torch.tensor(q0.copy())
+        f_ss, f_m = zs.placeholder(bool), zs.placeholder(bool)
+        kw = dict(adapt_mass=f_m, mass_collect_iters=MASS_COLLECT) \
+            if mass else {}
+        hmc = zs.HMC(step_size=0.05, n_leapfrogs=L, adapt_step_size=f_ss,
+                     target_acceptance_rate=0.8, seed=SEED, **kw)
+        node = zs.distributions.Normal(mean_t, logstd=logstd_t, group_ndims=1)
+        plan = H._FusedDiagNormalPlan(hmc, ['x'], [q], (q.shape[0],),
+                                      torch.device('cpu'),
+                                      lambda: (mean_t, logstd_t, node))
+        hmc._plan = plan
+        plan.state[_capi.ST_STEP_SIZE] = 0.05
+        op = H._SampleOp(hmc)
+        # 6 adaptive (search at t = 1 and, with mass, t = 4), 7 adaptive step
+        # size only, 9 with everything held
+        for n, feed in ((6, {f_ss: True, f_m: True}),
+                        (7, {f_ss: True, f_m: False}),
+                        (9, {f_ss: False, f_m: False})):
+            if many:
+                hmc._run_many(n, feed, sync=False)
+            else:
+                for _ in range(n):
+                    hmc._run(feed, sync=False)
+        hmc.flush()
+        out.append((q.numpy().copy(), plan.state.numpy().copy(), hmc.t,
+                    fake.calls))
+    (qa, sa, ta, ca), (qb, sb, tb, cb) = out
+    np.testing.assert_array_equal(qa, qb)
+    np.testing.assert_array_equal(sa, sb)
+    assert ta == tb == 22
+    assert 'zshmc_hmc_diag_normal_run' not in ca
+    # adaptive-step-size stretch: one block (after the searches); held
+    # stretch: two HOLD updates singly, then one block
+    assert cb.count('zshmc_hmc_diag_normal_run') >= 2
+    assert cb.count('zshmc_hmc_diag_normal_step') < \
+        ca.count('zshmc_hmc_diag_normal_step')

@@ -92,6 +92,10 @@ PROTOTYPES = {
         _p, _p, _p, _p, c_float, c_int64, c_int64, c_int64, c_int,
         c_uint64, c_uint32, c_int, _p, _p, _p, _p, _p, _p,
         POINTER(AdaptLink), _p]),
+    'zshmc_hmc_diag_normal_run': (c_int, [
+        _p, _p, _p, _p, c_float, c_int64, c_int64, c_int64, c_int,
+        c_uint64, c_uint32, c_int, _p, _p, _p, _p, _p, _p,
+        POINTER(AdaptLink), _p, _p]),
     'zshmc_stepsize_flush': (c_int, [POINTER(AdaptLink), _p]),
     'zshmc_comm_unique_id': (c_int, [_p]),
     'zshmc_comm_create': (c_int, [_p, c_int, c_int, POINTER(c_void_p)]),

@@ -614,3 +614,52 @@ extern "C" int zshmc_hmc_diag_normal_step(
   if (ng <= 384) return launch_cfg<64, 6>(a, s);
   return launch_cfg<64, 8>(a, s);
 }
+
+// K transitions from one call: the launch loop runs on THIS side of the C-ABI
+// (a host language pays its per-call overhead once per run, not once per
+// transition; at BASELINE configs[0]'s size a transition is a few
+// microseconds of device time).
+extern "C" int zshmc_hmc_diag_normal_run(
+    float* q, const float* mean, const float* logstd, const float* mass,
+    float step_size_host, int64_t n_chains, int64_t n_data,
+    int64_t chain_offset, int n_leapfrogs, uint64_t seed,
+    uint32_t iteration_first, int n_transitions, float* acceptance_rate,
+    float* orig_hamiltonian, float* hamiltonian, float* orig_log_prob,
+    float* log_prob, uint32_t* flags, const zshmc_adapt_link* link, void* comm,
+    void* stream) {
+  ZS_REQUIRE(n_transitions >= 0, "zshmc_hmc_diag_normal_run: n_transitions < 0");
+  ZS_REQUIRE(link, "zshmc_hmc_diag_normal_run: null link");
+  ZS_REQUIRE(!link->colstats_parts,
+             "zshmc_hmc_diag_normal_run: column statistics belong to the "
+             "mass-adapting iterations, which run one zshmc_hmc_diag_normal_"
+             "step at a time");
+  ZS_REQUIRE(!comm || link->retire_update == ZSHMC_PEND_NONE || link->stats,
+             "zshmc_hmc_diag_normal_run: an update across ranks needs stats");
+  const int kind = link->retire_update;
+  for (int i = 0; i < n_transitions; ++i) {
+    zshmc_adapt_link l = *link;
+    if (i > 0) {
+      l.fresh_start = 0;
+      l.used_step_size = __builtin_nanf("");
+    }
+    if (comm) {
+      // sharded chains: this transition's update is applied by the NEXT
+      // launch's prologue, from the all-reduced sum
+      l.retire_update = ZSHMC_PEND_NONE;
+      l.pending = i == 0 ? link->pending : kind;
+    } else if (i > 0) {
+      l.pending = ZSHMC_PEND_NONE;
+    }
+    int rc = zshmc_hmc_diag_normal_step(
+        q, mean, logstd, mass, step_size_host, n_chains, n_data, chain_offset,
+        n_leapfrogs, seed, iteration_first + (uint32_t)i, 1, acceptance_rate,
+        orig_hamiltonian, hamiltonian, orig_log_prob, log_prob, flags, &l,
+        stream);
+    if (rc != ZSHMC_OK) return rc;
+    if (comm && l.stats) {
+      rc = zshmc_comm_all_reduce_sum(comm, l.stats, ZSHMC_STATS_WORDS, stream);
+      if (rc != ZSHMC_OK) return rc;
+    }
+  }
+  return ZSHMC_OK;
+}

@@ -197,6 +197,16 @@ class _SampleOp(object):
 
     __call__ = run
 
+    def run_many(self, n, feed_dict=None, sync=True):
+        """`n` consecutive transitions with the same feeds -- what a loop of
+        `n` `sess.run(sample_op, feed_dict)` does.  Stretches of the run that
+        need nothing from the host between transitions (fused plan, mass not
+        adapting, no step-size search) are ONE call into libzshmc.so, which
+        launches them back to back (zshmc_hmc_diag_normal_run): the
+        per-transition cost of the Python front-end (~25 us) is paid once.
+        HMCInfo holds the last transition's values."""
+        self._hmc._run_many(int(n), feed_dict, sync)
+
 
 class HMC(object):
     """Hamiltonian Monte Carlo with dual-averaging step-size adaptation and
@@ -414,6 +424,56 @@ class HMC(object):
         # communicate; then the step-size update where it is its own launch
         plan.finish(update, eps_host, want_colstats, stream, sh)
         self._pending_check = True
+        if sync:
+            self.check_numerics()
+
+    # -- many transitions, one call where nothing needs the host ----------
+    def _block_length(self, n_left, feed_dict):
+        """How many of the next transitions can run as one block, and the
+        dual-averaging update each of them owes (ZSHMC_PEND_*)."""
+        plan = self._plan
+        if n_left < 2 or not getattr(plan, 'can_run_block', False):
+            return 0, None
+        sh = self.sharding
+        if sh is not None and sh.active and sh.backend != 'rccl':
+            return 0, None              # the collective is not ours to enqueue
+        t = self.t + 1
+        if self.adapt_mass is not None:
+            if _flag_value(self.adapt_mass, feed_dict, 'adapt_mass'):
+                return 0, None          # column statistics, mass update
+            use_ones = t < self.mass_collect_iters
+            if use_ones or plan._mass_ones is not False:
+                return 0, None          # the mass buffer has to be (re)made
+        kind = _capi.PEND_NONE
+        if self.adapt_step_size is not None:
+            if t == 1 or t <= self.mass_collect_iters:
+                return 0, None          # a step-size search lies ahead
+            if _flag_value(self.adapt_step_size, feed_dict, 'adapt_step_size'):
+                kind = _capi.PEND_ADAPT
+            elif self._nonadaptive_streak < 2:
+                return 0, None          # HOLD updates until the fixed point
+        return n_left, kind
+
+    def _run_many(self, n, feed_dict, sync):
+        plan = self._plan
+        done = 0
+        while done < n:
+            k, kind = self._block_length(n - done, feed_dict)
+            if k < 2:
+                self._run(feed_dict, sync=False)
+                done += 1
+                continue
+            bind_feed(feed_dict, plan.device)
+            plan.refresh_model()
+            plan.use_mass = self.adapt_mass is not None
+            self.last_init = False
+            if kind == _capi.PEND_ADAPT:
+                self._nonadaptive_streak = 0
+            plan.run_block(self.t + 1, k, kind, _capi.current_stream(),
+                           self.sharding)
+            self.t += k
+            self._pending_check = True
+            done += k
         if sync:
             self.check_numerics()
 
@@ -853,6 +913,39 @@ class _FusedDiagNormalPlan(_PlanBase):
         if collect:
             sh = self.hmc.sharding
             self.stats_local = sh is not None and sh.active
+
+    can_run_block = True
+
+    def run_block(self, t_first, n, kind, stream, sharding):
+        """`n` plain transitions (mass fixed, no search) from one call:
+        zshmc_hmc_diag_normal_run.  Sharded chains: the C side enqueues the
+        all-reduce of [sum acc, flag] between the launches on the same
+        communicator; the last transition's update stays pending."""
+        sharded = sharding is not None and sharding.active
+        update = None if kind == _capi.PEND_NONE else (kind, False, None)
+        link = self._link(None, update is not None or self.pending is not None,
+                          update)
+        if self.pending is not None:
+            # (fresh_start / used_step_size describe the FIRST launch's
+            # pending update; the run's own updates are never fresh)
+            link.fresh_start = int(self.pending[1])
+            link.used_step_size = float('nan') if self.pending[2] is None \
+                else float(self.pending[2])
+        _capi.call(
+            'zshmc_hmc_diag_normal_run', self.q[0].data_ptr(),
+            None if self.zero_mean else self.mean.data_ptr(),
+            self.logstd.data_ptr(), self.mass_ptr(0), 0.0, self.n_chains,
+            self.n_data[0], self.chain_offset, self.hmc.n_leapfrogs,
+            self.hmc.seed, t_first & 0xFFFFFFFF, n,
+            self.acceptance_rate.data_ptr(), self.orig_hamiltonian.data_ptr(),
+            self.hamiltonian.data_ptr(), self.orig_log_prob.data_ptr(),
+            self.log_prob.data_ptr(), self.flags.data_ptr(),
+            ctypes.byref(link), sharding._comm if sharded else None, stream)
+        self.last_t = t_first + n - 1
+        self.pending = update if sharded else None
+        self.stats_local = False
+        if self.colsum_state in ('fresh', 'parts'):
+            self.colsum_state = 'dirty'
 
     def flush(self, stream, sharding):
         """Retire the pending update from the (already all-reduced)
