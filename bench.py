@@ -276,6 +276,68 @@ def _mfma_roofline(kernel, kern_ms, flop_eval, n_evals, ms_transition):
     }
 
 
+def extra_config1(torch, zs, dev, n_chains=1000, n_x=10, n_leapfrogs=5):
+    """BASELINE configs[0]: examples/toy_examples/gaussian.py (:29, :36-58):
+    1 000 chains, 10-D, stdev_j = 1/(j+1), L = 5, target acceptance 0.9, step
+    size and mass adapting for the first 50 of 200 iterations, the last 100
+    kept.  On the device the kernel is a few microseconds: the line is about
+    the front-end -- one Python call per transition against one
+    `run_many` call for a stretch."""
+    stdev = 1.0 / (torch.arange(n_x, device=dev, dtype=torch.float32) + 1.0)
+
+    @zs.meta_bayesian_net()
+    def gaussian():
+        bn = zs.BayesianNet()
+        bn.normal('x', torch.zeros(n_x, device=dev), std=stdev,
+                  n_samples=n_chains, group_ndims=1)
+        return bn
+    out = {}
+    for mode in ('python_loop', 'run_many'):
+        x = torch.zeros(n_chains, n_x, device=dev)
+        f_ss, f_m = zs.placeholder(bool), zs.placeholder(bool)
+        hmc = zs.HMC(step_size=1e-3, n_leapfrogs=n_leapfrogs,
+                     adapt_step_size=f_ss, adapt_mass=f_m,
+                     target_acceptance_rate=0.9, seed=1)
+        op, info = hmc.sample(gaussian(), {}, {'x': x})
+        on, off = {f_ss: True, f_m: True}, {f_ss: False, f_m: False}
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if mode == 'run_many':
+            op.run_many(50, feed_dict=on, sync=False)
+            op.run_many(50, feed_dict=off, sync=False)
+        else:
+            for i in range(100):
+                op.run(feed_dict=on if i < 50 else off, sync=False)
+        hmc.check_numerics()
+        t_burn = time.perf_counter() - t0
+        # the recorded phase of gaussian.py, lengthened to 2 000 transitions
+        n = 2000
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if mode == 'run_many':
+            op.run_many(n, feed_dict=off, sync=False)
+        else:
+            for _ in range(n):
+                op.run(feed_dict=off, sync=False)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        out[mode] = {
+            'transitions_per_sec': n / el,
+            'us_per_transition': el / n * 1e6,
+            'chain_leapfrog_steps_per_sec': n_chains * n_leapfrogs * n / el,
+            'burn_in_100_transitions_ms': t_burn * 1e3,
+            'mean_acceptance': float(info.acceptance_rate.mean().item()),
+            'sample_std_over_stdev': float(
+                (x.std(0) / stdev).mean().item()),
+        }
+    out['workload'] = ('configs[0]: gaussian.py, %d chains x %d-D, L=%d, '
+                       'delta 0.9; 2 000 non-adaptive transitions after 50 '
+                       'adaptive (step size + mass) + 50 held' % (
+                           n_chains, n_x, n_leapfrogs))
+    out['kernel'] = _capi_kernel_name(n_x, 1, 1)
+    return out
+
+
 def extra_config3(torch, zs, dev, n_rows=1000000, n_chains=32768, n_feat=256,
                   n_leapfrogs=10, n_sub=256, n_timed=2):
     """BASELINE configs[2]: Bayesian logistic regression, synthetic
@@ -675,10 +737,11 @@ def main():
     # (per-launch durations 77 -> 130 -> 108 us in profiles/r01i_rocprofv3_
     # summary.txt); keep that transient out of the timed region whatever
     # --warmup is
-    for _ in range(SETTLE):
-        sample_op.run(feed_dict=feed, sync=False)
-    for _ in range(args.warmup):
-        sample_op.run(feed_dict=feed, sync=False)
+    # (run_many: the launch loop runs inside libzshmc.so -- one call for the
+    # whole stretch, zshmc_hmc_diag_normal_run; sharded over RCCL ranks the
+    # all-reduce between the launches is enqueued there too)
+    sample_op.run_many(SETTLE, feed_dict=feed, sync=False)
+    sample_op.run_many(args.warmup, feed_dict=feed, sync=False)
     barrier()
     # ONE HIP-event pair on the launch stream brackets the K launches of the
     # timed region: nothing is recorded between the launches (event records
@@ -690,8 +753,7 @@ def main():
     ev1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
-    for _ in range(args.steps):
-        sample_op.run(feed_dict=feed, sync=False)
+    sample_op.run_many(args.steps, feed_dict=feed, sync=False)
     ev1.record()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -774,13 +836,11 @@ def main():
     # (config 4: all-reduce + update kernel in the loop)
     saved = hmc.get_state()
     other_feed = {adapt: not adapt_timed}
-    for _ in range(5):
-        sample_op.run(feed_dict=other_feed, sync=False)
+    sample_op.run_many(5, feed_dict=other_feed, sync=False)
     barrier()
     t1 = time.perf_counter()
     n_other = max(20, min(args.steps, 100))
-    for _ in range(n_other):
-        sample_op.run(feed_dict=other_feed, sync=False)
+    sample_op.run_many(n_other, feed_dict=other_feed, sync=False)
     barrier()
     other_elapsed = time.perf_counter() - t1
     if world > 1:
@@ -793,6 +853,27 @@ def main():
         'ms_per_step': other_elapsed / n_other * 1e3,
         'value': total_chains * L * n_other / other_elapsed,
         'steps': n_other,
+    }
+
+    # the same transitions driven one `sample_op.run` at a time from Python
+    # (what a loop of sess.run is): the front-end's per-transition cost
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(n_other):
+        sample_op.run(feed_dict=feed, sync=False)
+    barrier()
+    loop_elapsed = time.perf_counter() - t1
+    if world > 1:
+        tt = torch.tensor([loop_elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        loop_elapsed = float(tt.item())
+    hmc.set_state(saved)
+    python_loop = {
+        'ms_per_step': loop_elapsed / n_other * 1e3,
+        'value': total_chains * L * n_other / loop_elapsed,
+        'steps': n_other,
+        'what': 'one sample_op.run per transition from Python instead of '
+                'one run_many call (zshmc_hmc_diag_normal_run)',
     }
 
     # mass adaptation (config 1's first 50 iterations, config 5): a second
@@ -906,9 +987,12 @@ def main():
             'rccl_ranks': 0 if sharding is None else sharding.rccl_ranks,
             'collective': collective_note,
             'launches_per_transition': 1,
+            'driver': 'sample_op.run_many(K): one call into libzshmc.so launches '
+                      'the K transitions of the timed region',
             'elem_leapfrog_steps_per_sec': value * D,
             'mean_acceptance': acc_mean,
             'other_adaptation_mode': other_mode,
+            'python_loop': python_loop,
             'mass_adaptation_modes': mass_modes,
             'step_size': eps,
             'roofline': {
@@ -988,7 +1072,7 @@ def main():
         from zhusuan_amd import _ops
         extras = []
         if world == 1:
-            todo = ((extra_config3, {}),
+            todo = ((extra_config1, {}), (extra_config3, {}),
                     (extra_config5, {'n_chains': args.config5_chains}))
         else:
             todo = ((lntm_workload, dict(

@@ -530,3 +530,56 @@ def test_column_statistics_are_refused_where_the_kernel_has_none(env):
                None, 0.1, 2, 1, 1,
                link=k.link(colstats_mean=torch.zeros(D, device=dev),
                            colstats_parts=parts))
+
+
+@pytest.mark.parametrize('C,D', [(1000, 10), (3000, 260), (70000, 1024)])
+def test_run_many_is_bit_identical_to_a_loop_of_runs(env, C, D):
+    """sample_op.run_many(n): the stretches that need nothing from the host
+    are ONE zshmc_hmc_diag_normal_run call (launch loop on the C side); every
+    state word, the latent and the last HMCInfo equal n single runs."""
+    zs, torch = env
+    dev = torch.device('cuda', 0)
+    logstd = torch.linspace(-0.5, 0.5, D, device=dev)
+    mean = torch.linspace(-1, 1, D, device=dev)
+    out = []
+    for many in (False, True):
+        @zs.meta_bayesian_net()
+        def model():
+            bn = zs.BayesianNet()
+            bn.normal('x', mean, logstd=logstd, n_samples=C, group_ndims=1)
+            return bn
+        f_ss, f_m = zs.placeholder(bool), zs.placeholder(bool)
+        h = zs.HMC(step_size=0.1, n_leapfrogs=4, adapt_step_size=f_ss,
+                   adapt_mass=f_m, mass_collect_iters=6, seed=5)
+        x = torch.zeros(C, D, device=dev)
+        op, info = h.sample(model(), {}, {'x': x})
+        calls = []
+        from zhusuan_amd import _capi
+        real = _capi.call
+
+        def spy(name, *a):
+            calls.append(name)
+            return real(name, *a)
+        _capi.call = spy
+        try:
+            for n, feed in ((9, {f_ss: True, f_m: True}),
+                            (8, {f_ss: True, f_m: False}),
+                            (11, {f_ss: False, f_m: False})):
+                if many:
+                    op.run_many(n, feed_dict=feed, sync=False)
+                else:
+                    for _ in range(n):
+                        op.run(feed_dict=feed, sync=False)
+            h.check_numerics()
+        finally:
+            _capi.call = real
+        out.append((x.clone(), h.get_state()['state'].clone(),
+                    info.acceptance_rate.clone(), info.log_prob.clone(), h.t,
+                    calls))
+    (xa, sa, aa, la, ta, ca), (xb, sb, ab, lb, tb, cb) = out
+    assert torch.equal(xa, xb) and torch.equal(sa, sb)
+    assert torch.equal(aa, ab) and torch.equal(la, lb) and ta == tb == 28
+    assert 'zshmc_hmc_diag_normal_run' not in ca
+    assert cb.count('zshmc_hmc_diag_normal_run') == 2   # 8 adaptive; 11 - 2 held
+    assert cb.count('zshmc_hmc_diag_normal_step') == \
+        ca.count('zshmc_hmc_diag_normal_step') - 8 - 9

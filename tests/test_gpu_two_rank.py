@@ -189,6 +189,14 @@ for i in range(16):
         eps.append(float(info.updated_step_size.item()))
 hmc.check_numerics()
 eps.append(float(info.updated_step_size.item()))
+# a stretch through the C-side launch loop (zshmc_hmc_diag_normal_run with the
+# communicator: the all-reduce between the launches is enqueued there), step
+# size adapting, mass held
+adapt2, hold2 = zs.placeholder(bool), zs.placeholder(bool)
+hmc.adapt_step_size, hmc.adapt_mass = adapt2, hold2
+op.run_many(7, feed_dict={adapt2: True, hold2: False}, sync=False)
+hmc.check_numerics()
+eps.append(float(info.updated_step_size.item()))
 np.savez(os.path.join(%(out)r, 'rccl_rank%%d.npz' %% rank), lo=lo, hi=hi,
          x=x.cpu().numpy(), eps=np.array(eps),
          mass=hmc._plan.mass[0].cpu().numpy(),
@@ -220,6 +228,12 @@ def _single_process_reference(torch, zs):
         op.run(feed_dict={flag: i < 12}, sync=(i % 5 == 0))
         if i % 3 == 2:
             eps.append(float(info.updated_step_size.item()))
+    hmc.check_numerics()
+    eps.append(float(info.updated_step_size.item()))
+    adapt2, hold2 = zs.placeholder(bool), zs.placeholder(bool)
+    hmc.adapt_step_size, hmc.adapt_mass = adapt2, hold2
+    for _ in range(7):                       # the same stretch, run by run
+        op.run(feed_dict={adapt2: True, hold2: False}, sync=False)
     hmc.check_numerics()
     eps.append(float(info.updated_step_size.item()))
     return (x.cpu().numpy(), np.array(eps), hmc._plan.mass[0].cpu().numpy(),

@@ -1,0 +1,57 @@
+#!/usr/bin/env python
+"""Workload for tools/profile_native_full.sh: the two modes of the fused
+fp32-MFMA likelihood kernel AT THE SHAPES THE BENCH LINE QUOTES -- BASELINE
+configs[2] (32 768 chains x 10^6 rows x 256) and configs[4] (8 192 x 5 000
+(chain, document) rows x K = 128 x V = 12 419) -- launched straight through
+the C-ABI, two launches each, so that rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+can put their HBM traffic next to the algorithmic bytes.
+  python tools/native_kernel_pmc.py [n_chains_config5]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from zhusuan_amd import _capi, _ops  # noqa: E402
+
+dev = torch.device('cuda', 0)
+s = torch.cuda.current_stream().cuda_stream
+g = torch.Generator(device=dev).manual_seed(0)
+
+# ---- configs[2]: Bernoulli mode --------------------------------------------
+C, N, D = 32768, 1000000, 256
+X = torch.randn(N, D, device=dev, generator=g)
+y = (torch.rand(N, device=dev, generator=g) < 0.5).float()
+W = torch.randn(C, D, device=dev, generator=g) * 0.05
+ll = torch.empty(C, device=dev)
+gw = torch.empty(C, D, device=dev)
+for _ in range(2):
+    _capi.call('zshmc_linear_bernoulli_log_lik', W.data_ptr(), X.data_ptr(),
+               y.data_ptr(), C, N, D, ll.data_ptr(), gw.data_ptr(), 1, None, s)
+torch.cuda.synchronize()
+print('config3 shape: C=%d N=%d D=%d; algorithmic bytes per launch: X %.3e '
+      '(streamed once per 64-chain block: x%d = %.3e) + W, grad 2 x %.3e' % (
+          C, N, D, 4.0 * N * D, C // 64, 4.0 * N * D * (C // 64), 4.0 * C * D))
+del X, y, W, ll, gw
+torch.cuda.empty_cache()
+
+# ---- configs[4]: multinomial mode ------------------------------------------
+n_chains = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+n_docs, K, V = 5000, 128, 12419
+rows = n_chains * n_docs
+phi = torch.softmax(torch.randn(K, V, device=dev, generator=g), -1)
+x = torch.poisson(torch.full((n_docs, V), 0.08, device=dev), generator=g)
+theta = torch.softmax(torch.randn(rows, K, device=dev, generator=g), -1)
+phi_t = _ops._padded_phi_t(phi, K)
+xp, stride = _ops._padded_counts(x)
+ll = torch.empty(rows, device=dev)
+gt = torch.empty(rows, K, device=dev)
+for _ in range(2):
+    _capi.call('zshmc_linear_multinomial_log_lik', theta.data_ptr(),
+               phi_t.data_ptr(), xp.data_ptr(), xp.shape[0], stride, rows, V,
+               K, ll.data_ptr(), gt.data_ptr(), 1, None, s)
+torch.cuda.synchronize()
+print('config5 shape: rows=%d K=%d V=%d; algorithmic bytes per launch: theta + '
+      'grad 2 x %.3e, phi^T %.3e (x%d row blocks = %.3e), counts gathered '
+      '%.3e' % (rows, K, V, 4.0 * rows * K, 4.0 * V * K, rows // 64,
+                4.0 * V * K * (rows // 64), 4.0 * rows * V))

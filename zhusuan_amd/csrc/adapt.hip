@@ -111,17 +111,19 @@ __global__ void mass_update_kernel(float* __restrict__ state,
   mass_out[d] = use_ones ? 1.0f : 1.0f / var;
 }
 
-// Rows of column sums -> one row, fixed order.  Block (64 x 16): 64 columns,
-// 16 row lanes striding over the rows with four loads in flight each (the
-// 4 MB of partials of a 256-workgroup launch at D = 1 024 are read by 32
-// blocks: latency-, not bandwidth-bound); LDS-reduced in lane order.
-constexpr int kPartLanes = 16;
+// Rows of column sums -> one row, fixed order.  Block (16 x 64): 16 columns
+// (one 128-byte segment per row), 64 row lanes striding over the rows -- the
+// 4 MB of partials of a 256-workgroup launch at D = 1 024 are read by 128 / 64
+// blocks with every load in flight at once (latency-, not bandwidth-bound);
+// LDS-reduced in lane order.
+constexpr int kPartCols = 16;
+constexpr int kPartLanes = 64;
 
 __device__ __forceinline__ double parts_column_sum(
     const double* __restrict__ parts, int64_t n_parts, int64_t stride,
-    int64_t col, bool valid, double (*sh)[kColsPerBlock]) {
-  const int tx = threadIdx.x % kColsPerBlock;
-  const int ty = threadIdx.x / kColsPerBlock;
+    int64_t col, bool valid, double (*sh)[kPartCols]) {
+  const int tx = threadIdx.x % kPartCols;
+  const int ty = threadIdx.x / kPartCols;
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
   if (valid) {
     int64_t r = ty;
@@ -136,20 +138,27 @@ __device__ __forceinline__ double parts_column_sum(
   __syncthreads();  // (sh may still be read from a previous call)
   sh[ty][tx] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  double tot = 0.0;
+  // 64 -> 4 by four threads per column, then lane order
+  double t = 0.0;
+  if (ty < 4) {
 #pragma unroll
-  for (int i = 0; i < kPartLanes; ++i) tot += sh[i][tx];
-  return tot;
+    for (int i = 0; i < kPartLanes / 4; ++i)
+      t += sh[ty * (kPartLanes / 4) + i][tx];
+  }
+  __syncthreads();
+  if (ty < 4) sh[ty][tx] = t;
+  __syncthreads();
+  return (sh[0][tx] + sh[1][tx]) + (sh[2][tx] + sh[3][tx]);
 }
 
 __global__ __launch_bounds__(1024) void mass_colstats_reduce_kernel(
     const double* __restrict__ parts, int64_t n_parts, int64_t n_data,
     double* __restrict__ colsum) {
-  __shared__ double sh[kPartLanes][kColsPerBlock];
-  const int tx = threadIdx.x % kColsPerBlock;
-  const int ty = threadIdx.x / kColsPerBlock;
+  __shared__ double sh[kPartLanes][kPartCols];
+  const int tx = threadIdx.x % kPartCols;
+  const int ty = threadIdx.x / kPartCols;
   // blockIdx.x walks the 2*n_data columns of a row
-  const int64_t col = (int64_t)blockIdx.x * kColsPerBlock + tx;
+  const int64_t col = (int64_t)blockIdx.x * kPartCols + tx;
   const bool valid = col < 2 * n_data;
   const double tot =
       parts_column_sum(parts, n_parts, 2 * n_data, col, valid, sh);
@@ -165,10 +174,10 @@ __global__ __launch_bounds__(1024) void mass_update_fused_kernel(
     int64_t n_parts, double inv_chains, int64_t n_data, float decay,
     int use_ones, float* __restrict__ mass_out,
     unsigned int* __restrict__ retired) {
-  __shared__ double sh[kPartLanes][kColsPerBlock];
-  const int tx = threadIdx.x % kColsPerBlock;
-  const int ty = threadIdx.x / kColsPerBlock;
-  const int64_t d = (int64_t)blockIdx.x * kColsPerBlock + tx;
+  __shared__ double sh[kPartLanes][kPartCols];
+  const int tx = threadIdx.x % kPartCols;
+  const int ty = threadIdx.x / kPartCols;
+  const int64_t d = (int64_t)blockIdx.x * kPartCols + tx;
   const bool valid = d < n_data;
   const float tau_new = state[ZSHMC_ST_EWMV_T] + 1.0f;
   const double c1 = parts_column_sum(parts, n_parts, 2 * n_data, d, valid, sh);
@@ -283,9 +292,9 @@ extern "C" int zshmc_mass_colstats_reduce(const double* parts, int64_t n_parts,
   ZS_REQUIRE(parts && colsum, "zshmc_mass_colstats_reduce: null pointer");
   ZS_REQUIRE(n_parts >= 1 && n_data >= 1,
              "zshmc_mass_colstats_reduce: bad shape");
-  const int blocks = (int)((2 * n_data + kColsPerBlock - 1) / kColsPerBlock);
+  const int blocks = (int)((2 * n_data + kPartCols - 1) / kPartCols);
   hipLaunchKernelGGL(mass_colstats_reduce_kernel, dim3(blocks),
-                     dim3(kColsPerBlock * kPartLanes), 0,
+                     dim3(kPartCols * kPartLanes), 0,
                      reinterpret_cast<hipStream_t>(stream), parts, n_parts,
                      n_data, colsum);
   ZS_LAUNCH_CHECK("mass_colstats_reduce_kernel launch");
@@ -300,9 +309,9 @@ extern "C" int zshmc_mass_update_fused(
              "zshmc_mass_update_fused: null pointer");
   ZS_REQUIRE(n_parts >= 1 && n_chains_global > 0 && n_data >= 1,
              "zshmc_mass_update_fused: bad shape");
-  const int blocks = (int)((n_data + kColsPerBlock - 1) / kColsPerBlock);
+  const int blocks = (int)((n_data + kPartCols - 1) / kPartCols);
   hipLaunchKernelGGL(mass_update_fused_kernel, dim3(blocks),
-                     dim3(kColsPerBlock * kPartLanes), 0,
+                     dim3(kPartCols * kPartLanes), 0,
                      reinterpret_cast<hipStream_t>(stream), state, ewmv_mean,
                      ewmv_var, parts, n_parts, 1.0 / (double)n_chains_global,
                      n_data, decay, use_ones, mass_out,
