@@ -22,6 +22,12 @@ constexpr uint32_t kStreamMomentum = 0;
 constexpr uint32_t kStreamMH = 1;
 constexpr uint32_t kStreamDist = 2;
 
+// A/B probe only (tools/kbench.py): Random123 documents 7 rounds as the
+// fewest that pass BigCrush; the product and every golden fixture use 10.
+#ifndef ZS_PHILOX_ROUNDS
+#define ZS_PHILOX_ROUNDS 10
+#endif
+
 struct U4 {
   uint32_t x, y, z, w;
 };
@@ -42,7 +48,7 @@ __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1,
                                             uint32_t c2, uint32_t c3,
                                             uint32_t k0, uint32_t k1) {
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < ZS_PHILOX_ROUNDS; ++r) {
     const uint64_t p0 = (uint64_t)kPhiloxM0 * c0;
     const uint64_t p1 = (uint64_t)kPhiloxM1 * c2;
     const uint32_t n0 = xor3((uint32_t)(p1 >> 32), c1, k0);
@@ -115,7 +121,7 @@ __device__ __forceinline__ void philox4x32_10_x2(
     uint32_t k0, uint32_t k1, U4& ra, U4& rb) {
   uint32_t a1 = c1, a2 = c2, a3 = c3, b1 = c1, b2 = c2, b3 = c3;
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < ZS_PHILOX_ROUNDS; ++r) {
     const uint64_t pa0 = (uint64_t)kPhiloxM0 * a0;
     const uint64_t pb0 = (uint64_t)kPhiloxM0 * b0;
     const uint64_t pa1 = (uint64_t)kPhiloxM1 * a2;
