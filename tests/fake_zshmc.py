@@ -3,12 +3,15 @@ calls, so that the HOST ORCHESTRATION of zhusuan_amd/hmc.py (`HMC._run`: flag
 handling, the step-size search loop, pending / retired dual-averaging
 updates, flush, chain sharding and its all-reduces) can be exercised on a box
 without a GPU -- where the driver runs `-m "not gpu"`.  Test infrastructure:
-the transition itself is the oracle's (oracle/hmc_ref.py pieces); what is
-restated here is the host-visible CONTRACT of include/zshmc.h for
-zshmc_hmc_diag_normal_step / zshmc_adapt_link / zshmc_stepsize_flush /
-zshmc_mass_colstats / zshmc_mass_update (csrc/adapt.hip) /
-zshmc_state_set (csrc/fused_args.h: link_step_size, link_retire,
-tuner_persist).  Tensors are torch CPU tensors addressed through data_ptr()."""
+the transition itself is the oracle's (oracle/hmc_ref.py pieces); the
+step-size link between transitions -- which update is applied when, from
+which sum (zshmc_adapt_link: pending / retire_update / fresh_start /
+used_step_size) -- is NOT restated: it is csrc/fused_args.h itself
+(link_step_size, link_retire, tuner_persist: the code the kernels run)
+compiled for the host, tests/host_link/zs_link_host.cpp.  What is restated
+here is the mass estimator of csrc/adapt.hip (zshmc_mass_colstats /
+zshmc_mass_update[_fused]) and zshmc_state_set.  Tensors are torch CPU
+tensors addressed through data_ptr()."""
 import ctypes
 
 import numpy as np
@@ -29,30 +32,38 @@ def _f32(ptr, n):
     return _view(ptr, n, ctypes.c_float, np.float32)
 
 
-def _tuner_apply(state, acc, kind, fresh, link):
-    """csrc/fused_args.h::tuner_apply on the state block: returns the new
-    (step_size, step, log_eps_bar, h_bar)."""
-    t = hmc_ref.StepsizeTuner(F32(link.mu) / F32(10), link.gamma, link.t0,
-                              link.kappa, link.delta)
-    t.mu = F32(link.mu)
-    t.step = F32(state[_capi.ST_TUNER_STEP])
-    t.log_epsilon_bar = F32(state[_capi.ST_LOG_EPS_BAR])
-    t.h_bar = F32(state[_capi.ST_H_BAR])
-    eps = t.tune(F32(acc), F32(fresh), kind == _capi.PEND_ADAPT)
-    return F32(eps), t.step, t.log_epsilon_bar, t.h_bar
+def _host_link():
+    """csrc/fused_args.h (link_step_size / link_retire / tuner_persist -- the
+    code the kernels run) compiled for the host: tests/host_link/."""
+    import os
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    src = os.path.join(here, 'host_link', 'zs_link_host.cpp')
+    hdr = os.path.join(os.path.dirname(here), 'zhusuan_amd', 'csrc',
+                       'fused_args.h')
+    out = os.path.join(here, '_build', 'libzs_link_host.so')
+    if not os.path.exists(out) or os.path.getmtime(out) < max(
+            os.path.getmtime(src), os.path.getmtime(hdr)):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        cxx = '/opt/rocm/lib/llvm/bin/clang++'      # (ext_vector_type)
+        tmp = out + '.%d.tmp' % os.getpid()
+        subprocess.check_call([cxx, '-O2', '-ffp-contract=off',
+                               '-DZS_HOST_ONLY', '-shared', '-fPIC', src,
+                               '-o', tmp])
+        os.replace(tmp, out)
+    lib = ctypes.CDLL(out)
+    lib.zs_host_link_step_size.restype = ctypes.c_float
+    lib.zs_host_link_step_size.argtypes = [ctypes.POINTER(_capi.AdaptLink),
+                                           ctypes.c_float]
+    lib.zs_host_link_retire.restype = None
+    lib.zs_host_link_retire.argtypes = [ctypes.POINTER(_capi.AdaptLink),
+                                        ctypes.c_double, ctypes.c_uint]
+    lib.zs_host_link_flush.restype = None
+    lib.zs_host_link_flush.argtypes = [ctypes.POINTER(_capi.AdaptLink)]
+    return lib
 
 
-def _tuner_persist(state, link, kind, acc_sum):
-    acc = F32(acc_sum / float(link.n_chains_global))
-    old_eps = F32(state[_capi.ST_STEP_SIZE])
-    eps, step, leb, hb = _tuner_apply(state, acc, kind, link.fresh_start, link)
-    used = F32(link.used_step_size)
-    state[_capi.ST_MEAN_ACCEPT] = acc
-    state[_capi.ST_USED_STEP_SIZE] = used if used == used else old_eps
-    state[_capi.ST_STEP_SIZE] = eps
-    state[_capi.ST_TUNER_STEP] = step
-    state[_capi.ST_LOG_EPS_BAR] = leb
-    state[_capi.ST_H_BAR] = hb
+_LINK = _host_link()
 
 
 class FakeLibrary(object):
@@ -71,12 +82,7 @@ class FakeLibrary(object):
 
     # -- zshmc_stepsize_flush(link, stream) ------------------------------------
     def zshmc_stepsize_flush(self, link_ref, stream):
-        link = link_ref._obj
-        if link.pending != _capi.PEND_NONE:
-            state = _f32(link.state, _capi.STATE_WORDS)
-            stats = _view(link.stats, _capi.STATS_WORDS, ctypes.c_double,
-                          np.float64)
-            _tuner_persist(state, link, link.pending, stats[0])
+        _LINK.zs_host_link_flush(link_ref)
 
     # -- zshmc_hmc_diag_normal_step -------------------------------------------
     def zshmc_hmc_diag_normal_step(
@@ -90,18 +96,10 @@ class FakeLibrary(object):
         model = hmc_ref.DiagNormalModel(mean_v.copy(),
                                         logstd=_f32(logstd, D).copy())
         m = [(_f32(mass, D) if mass else np.ones(D, F32)).reshape(1, D)]
-        state = _f32(link.state, _capi.STATE_WORDS)
-        stats = _view(link.stats, _capi.STATS_WORDS, ctypes.c_double,
-                      np.float64)
-        # prologue: the step size of THIS transition (link_step_size)
-        if state is None:
-            eps = F32(step_size_host)
-        elif link.pending != _capi.PEND_NONE:
-            eps = _tuner_apply(state, F32(stats[0] /
-                                          float(link.n_chains_global)),
-                               link.pending, link.fresh_start, link)[0]
-        else:
-            eps = F32(state[_capi.ST_STEP_SIZE])
+        # prologue: the step size of THIS transition -- the product's own
+        # link_step_size (pending update applied to a copy of the state)
+        eps = F32(_LINK.zs_host_link_step_size(link_ref,
+                                               float(step_size_host)))
         # the transition (hmc.py:458-498), oracle pieces
         p0 = hmc_ref.random_momentum(seed, int(iteration), [(C, D)], m, 1,
                                      int(chain_offset))
@@ -129,16 +127,10 @@ class FakeLibrary(object):
                     _f32(ptr, C)[...] = val
         if bad and flags:
             _view(flags, 1, ctypes.c_uint32, np.uint32)[0] |= 1
-        # epilogue (link_retire): persist the pending update from the OLD
-        # sum, then this transition's own update, then publish the new sum
+        # epilogue: the product's own link_retire (pending update from the
+        # OLD sum, this transition's own update, publication of the new sum)
         total = float(np.sum(acc.astype(np.float64)))
-        if state is not None and link.pending != _capi.PEND_NONE:
-            _tuner_persist(state, link, link.pending, stats[0])
-        if state is not None and link.retire_update != _capi.PEND_NONE:
-            _tuner_persist(state, link, link.retire_update, total)
-        if stats is not None:
-            stats[0] = total
-            stats[1] = 1.0 if bad else 0.0
+        _LINK.zs_host_link_retire(link_ref, total, 1 if bad else 0)
 
     # -- zshmc_mass_colstats / zshmc_mass_update (csrc/adapt.hip) -------------
     def zshmc_mass_colstats(self, q, ewmv_mean, n_chains, n_data, colsum,

@@ -345,3 +345,46 @@ def test_native_plan_reprobes_the_model_on_a_meta_latent(monkeypatch):
     assert seen == ['meta', 'cpu']
     plan2.probe()
     assert seen == ['meta', 'cpu', 'cpu']
+
+
+def test_normal_derived_spread_keeps_the_tape_after_a_no_grad_first_use():
+    """Normal.logstd / .std are derived lazily; a first access
+    under torch.no_grad() must not cache a tensor without grad_fn."""
+    import zhusuan_amd as zs
+    std = torch.tensor([0.5, 2.0], requires_grad=True)
+    d = zs.distributions.Normal(torch.zeros(2), std=std)
+    with torch.no_grad():
+        first = d.logstd
+    assert not first.requires_grad
+    later = d.logstd
+    assert later.requires_grad and later.grad_fn is not None
+    g, = torch.autograd.grad(later.sum(), std)
+    torch.testing.assert_close(g, 1.0 / std.detach())
+    assert d.logstd is later                 # cached from then on
+    logstd = torch.tensor([0.1, -0.3], requires_grad=True)
+    d2 = zs.distributions.Normal(torch.zeros(2), logstd=logstd)
+    with torch.no_grad():
+        d2.std
+    assert d2.std.requires_grad
+    # constants are cached whatever the mode
+    d3 = zs.distributions.Normal(torch.zeros(2), std=torch.ones(2))
+    with torch.no_grad():
+        a = d3.logstd
+    assert d3.logstd is a
+
+
+def test_row_period_parameters_are_16_byte_aligned_copies_of_views():
+    """a contiguous slice of a user tensor is a view whose storage
+    offset can break the 16-byte alignment the row kernels require."""
+    from zhusuan_amd.hmc import _to_row_period, _aligned16
+    base = torch.arange(9 * 8, dtype=torch.float32).reshape(9, 8)
+    view = base[:, 1:5].contiguous()[1:]          # contiguous, offset 16 B
+    odd = torch.arange(33, dtype=torch.float32)[1:]   # offset 4 B
+    assert odd.data_ptr() % 16 != 0
+    fixed = _aligned16(odd)
+    assert fixed.data_ptr() % 16 == 0 and torch.equal(fixed, odd)
+    mat, rows = _to_row_period(odd[:32].reshape(4, 8), (5, 4), 8)
+    assert rows == 4 and mat.data_ptr() % 16 == 0
+    assert torch.equal(mat, odd[:32].reshape(4, 8))
+    same, _ = _to_row_period(view, (3, 8), 4)
+    assert same.data_ptr() % 16 == 0

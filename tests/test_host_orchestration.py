@@ -89,7 +89,10 @@ def test_single_process_orchestration_matches_oracle(monkeypatch, mass):
     # (with mass adaptation: the one-pass float64 column statistics of
     # csrc/adapt.hip against the reference's two-pass float32 form)
     np.testing.assert_allclose(eps, want_eps, rtol=5e-5 if mass else 2e-6)
-    np.testing.assert_allclose(q, want_q, rtol=0, atol=2e-4 if mass else 1e-6)
+    # (the step size comes from csrc/fused_args.h compiled for the host --
+    # libm's powf / expf against NumPy's in the oracle: last-bit differences
+    # of epsilon, hence of the states)
+    np.testing.assert_allclose(q, want_q, rtol=0, atol=2e-4 if mass else 1e-5)
     if mass:
         # the step size is searched again at t == mass_collect_iters.  One
         # mass launch per iteration WHILE THE FLAG IS ON (rows of column sums
@@ -176,7 +179,7 @@ def test_two_rank_orchestration_matches_oracle(tmp_path, read_every_run, mass):
         if not mass:
             assert int(d['n_launch']) == ITERS + int(d['n_search'])
     np.testing.assert_allclose(np.concatenate(rows), want_q, rtol=0,
-                               atol=2e-4 if mass else 1e-6)
+                               atol=2e-4 if mass else 1e-5)
 
 
 @pytest.mark.parametrize('mass', [False, True])

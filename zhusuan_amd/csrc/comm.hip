@@ -14,8 +14,11 @@
 // (torch loads one) if there is one, else the ROCm one.  A single-GPU user
 // never touches it.
 #include <dlfcn.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+
+#include <mutex>
 
 #include "common.h"
 
@@ -40,11 +43,10 @@ struct Rccl {
   const char* (*GetErrorString)(int) = nullptr;
 };
 
-static Rccl* rccl() {
-  static Rccl lib;
-  static bool tried = false;
-  if (tried) return lib.handle ? &lib : nullptr;
-  tried = true;
+// why the library could not be set up (filled once, by rccl_load)
+static char g_rccl_why[256] = "";
+
+static bool rccl_load(Rccl* lib) {
   const char* names[] = {getenv("ZSHMC_RCCL_PATH"), "librccl.so.1",
                          "librccl.so", "/opt/rocm/lib/librccl.so.1",
                          "/opt/rocm/lib/librccl.so"};
@@ -54,18 +56,34 @@ static Rccl* rccl() {
     if (n && !h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
   for (const char* n : names)
     if (n && !h) h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-  if (!h) return nullptr;
-#define ZS_SYM(field, name)                                        \
-  lib.field = reinterpret_cast<decltype(lib.field)>(dlsym(h, name)); \
-  if (!lib.field) return nullptr;
+  if (!h) {
+    const char* e = dlerror();  // (one call: dlerror clears what it returns)
+    snprintf(g_rccl_why, sizeof(g_rccl_why), "%s", e ? e : "dlopen failed");
+    return false;
+  }
+#define ZS_SYM(field, name)                                              \
+  lib->field = reinterpret_cast<decltype(lib->field)>(dlsym(h, name));   \
+  if (!lib->field) {                                                     \
+    snprintf(g_rccl_why, sizeof(g_rccl_why), "symbol %s missing", name); \
+    dlclose(h);                                                          \
+    return false;                                                        \
+  }
   ZS_SYM(GetUniqueId, "ncclGetUniqueId")
   ZS_SYM(CommInitRank, "ncclCommInitRank")
   ZS_SYM(AllReduce, "ncclAllReduce")
   ZS_SYM(CommDestroy, "ncclCommDestroy")
   ZS_SYM(GetErrorString, "ncclGetErrorString")
 #undef ZS_SYM
-  lib.handle = h;
-  return &lib;
+  lib->handle = h;
+  return true;
+}
+
+static Rccl* rccl() {
+  static Rccl lib;
+  static std::once_flag once;
+  static bool ok = false;
+  std::call_once(once, [] { ok = rccl_load(&lib); });
+  return ok ? &lib : nullptr;
 }
 
 struct Comm {
@@ -82,8 +100,8 @@ static int check_nccl(Rccl* r, int rc, const char* what) {
 #define ZS_NEED_RCCL(r)                                                      \
   Rccl* r = rccl();                                                          \
   if (!r) {                                                                  \
-    set_error("librccl.so could not be opened (set ZSHMC_RCCL_PATH): %s",    \
-              dlerror() ? dlerror() : "symbol missing");                     \
+    set_error("librccl.so could not be set up (set ZSHMC_RCCL_PATH): %s",    \
+              g_rccl_why);                                                   \
     return ZSHMC_ERR_COMM;                                                   \
   }
 

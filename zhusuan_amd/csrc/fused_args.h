@@ -3,7 +3,38 @@
 //  hmc_fused_ring.hip: LDS-DMA ring kernel for 16-B aligned rows > 512 B)
 // and the dual-averaging step-size update they carry.
 #pragma once
+#ifdef ZS_HOST_ONLY
+// tests/host_link: the link / dual-averaging logic below compiled for the
+// HOST (one thread standing for one workgroup), so that the CPU tests of the
+// front-end's orchestration run the product's update code, not a restatement
+#include <math.h>
+#define __device__
+#define __forceinline__ inline
+#define __HIP_MEMORY_SCOPE_AGENT 0
+typedef void* hipStream_t;
+namespace zshmc {
+struct HostDim {
+  unsigned x;
+};
+static HostDim gridDim = {1};
+template <class T>
+inline T __hip_atomic_fetch_add(T* p, T v, int, int) {
+  const T old = *p;
+  *p = old + v;
+  return old;
+}
+template <class T>
+inline T __hip_atomic_load(const T* p, int, int) {
+  return *p;
+}
+template <class T>
+inline void __hip_atomic_store(T* p, T v, int, int) {
+  *p = v;
+}
+}  // namespace zshmc
+#else
 #include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
 
 #include "../../include/zshmc.h"

@@ -112,17 +112,28 @@ class Normal(Distribution):
         given (the other one is derived on first use)."""
         return self._given_spread
 
+    # The parameter the constructor was not given is derived on first use
+    # and kept -- unless that first use happens with autograd off while the
+    # given one requires grad (an evaluation pass under torch.no_grad()): a
+    # cached tensor without grad_fn would silently cut every later
+    # differentiable use of this distribution from its parameter.
     @property
     def logstd(self):
-        if self._logstd is None:
-            self._logstd = torch.log(self._std)
-        return self._logstd
+        if self._logstd is not None:
+            return self._logstd
+        out = torch.log(self._std)
+        if torch.is_grad_enabled() or not self._std.requires_grad:
+            self._logstd = out
+        return out
 
     @property
     def std(self):
-        if self._std is None:
-            self._std = torch.exp(self._logstd)
-        return self._std
+        if self._std is not None:
+            return self._std
+        out = torch.exp(self._logstd)
+        if torch.is_grad_enabled() or not self._logstd.requires_grad:
+            self._std = out
+        return out
 
     def _device(self):
         return self._mean.device

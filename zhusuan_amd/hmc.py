@@ -1195,13 +1195,14 @@ class _DenseLikelihoodPlan(_PlanBase):
         ops = self._ops
         if self.kind == 'linear_bernoulli':
             X, y = t[2], t[3]
-            self.inner = ops._padded_x(X, self.width)
-            self.obs = y.detach().to(torch.float32).contiguous()
+            self.inner = _aligned16(ops._padded_x(X, self.width))
+            self.obs = _aligned16(y.detach().to(torch.float32).contiguous())
             n_inner = self.inner.shape[0]
         else:
             phi, x = t[2], t[3]
-            self.inner = ops._padded_phi_t(phi, self.width)
+            self.inner = _aligned16(ops._padded_phi_t(phi, self.width))
             self.obs, self.obs_stride = ops._padded_counts(x)
+            self.obs = _aligned16(self.obs)
             n_inner = self.inner.shape[0]
             if C % self.obs.shape[0] != 0:
                 raise ValueError("counts rows do not divide the chain rows")
@@ -1371,7 +1372,14 @@ def _to_row_period(param, chain_shape, n_data):
     rows = 1
     for d in tail[:-1]:
         rows *= int(d)
-    return t.reshape(rows, n_data), rows
+    return _aligned16(t.reshape(rows, n_data)), rows
+
+
+def _aligned16(t):
+    """`t` itself, or a copy if its storage offset breaks the 16-byte
+    alignment the row kernels require (a contiguous slice `param[1:]` of a
+    user tensor is a view)."""
+    return t if t.data_ptr() % 16 == 0 else t.clone()
 
 
 def _softmax_of(theta, probe):
@@ -1491,6 +1499,15 @@ def _try_dense_likelihood_plan(hmc, meta_bn, names, values, chain_shape,
     if found is None:
         return None
     kind = found[0]
+    # prior parameters that do not fit the row-period addressing (more axes
+    # than the latent, leading axes that are neither 1 nor the chain axes):
+    # the generic plan, not an exception out of HMC.sample
+    try:
+        _to_row_period(found[1][0], chain_shape, D)
+        spread = found[1][1][1]
+        _to_row_period(spread, chain_shape, D)
+    except (RuntimeError, ValueError):
+        return None
 
     # The per-run re-evaluation of the model function only has to find the
     # parameter tensors again, so it is given a META tensor for the latent:
