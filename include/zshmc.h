@@ -18,7 +18,7 @@
  *     thread-local message of the last failing call;
  *   - the caller owns every buffer.  Nothing is allocated by the library.
  *
- * Random numbers: Philox4x32-10, key = seed, counter =
+ * Random numbers: Philox4x32-7, key = seed, counter =
  *   (d/4, global chain index, iteration, stream id | latent_id<<8); see
  *   DESIGN.md "RNG".  Results are invariant to how chains are sharded.
  */

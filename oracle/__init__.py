@@ -18,7 +18,7 @@ Pinning status (see DESIGN.md section "Oracle"):
   * ESS -- PINNED against outputs of the reference's own
     zhusuan/diagnostics.py imported in the build container
     (oracle/make_golden.py -> tests/golden/ess_fixture.npz).
-  * Philox4x32-10 -- PINNED against the Random123 known-answer vectors.
+  * Philox4x32-7 -- PINNED against the Random123 known-answer vectors.
   * HMC transition numerics (leapfrog / MH / dual averaging / mass / step-size
     search) -- PINNED against traces of the reference's own zhusuan/hmc.py,
     run unmodified over the eager TensorFlow-API shim oracle/tf_shim.py

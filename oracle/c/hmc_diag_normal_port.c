@@ -12,7 +12,7 @@
  *   :46-61   get_acceptance_rate      exp(min(H0 - H1, 0)); non-finite -> 0
  *   :479-498 MH                       u < acc (strict), in-place select
  * and zhusuan/distributions/univariate.py:174-181 (Normal._log_prob summed
- * over the data axis, base.py:302-304).  Random numbers: Philox4x32-10 with
+ * over the data axis, base.py:302-304).  Random numbers: Philox4x32-7 with
  * the counter mapping of oracle/philox.py (momentum: (d/4, chain, iteration,
  * 0); MH uniform: (0, chain, iteration, 1)), Box-Muller in double rounded
  * once to float, exactly as oracle/philox.py:box_muller.
@@ -29,9 +29,9 @@
 #include <omp.h>
 #endif
 
-static void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+static void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                           uint32_t k0, uint32_t k1, uint32_t out[4]) {
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < 7; ++r) { /* oracle/philox.py: PHILOX_ROUNDS */
     const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
     const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
     const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
@@ -101,7 +101,7 @@ int zs_oracle_hmc_diag_normal_step(float* q, const float* mean,
       for (int64_t g = 0; g < (D + 3) / 4; ++g) {
         uint32_t x[4];
         float z[4];
-        philox4x32_10((uint32_t)g, gchain, iteration, 0u, k0, k1, x);
+        philox4x32((uint32_t)g, gchain, iteration, 0u, k0, k1, x);
         box_muller(x[0], x[1], &z[0], &z[1]);
         box_muller(x[2], x[3], &z[2], &z[3]);
         for (int j = 0; j < 4 && g * 4 + j < D; ++j) p[g * 4 + j] = z[j];
@@ -136,7 +136,7 @@ int zs_oracle_hmc_diag_normal_step(float* q, const float* mean,
       if (!(dh == dh) || !isfinite(acc) || !isfinite(lp_new)) acc = 0.f;
       if (!isfinite(lp_old)) bad |= 1;
       uint32_t x[4];
-      philox4x32_10(0u, gchain, iteration, 1u, k0, k1, x);
+      philox4x32(0u, gchain, iteration, 1u, k0, k1, x);
       const float u = (float)(x[0] >> 8) * (1.0f / 16777216.0f);
       const int accept = u < acc;                   /* strict, hmc.py:486 */
       if (accept)

@@ -1,12 +1,12 @@
-"""Philox4x32-10 counter-based RNG, NumPy restatement shared bit-for-bit with
+"""Philox4x32-7 counter-based RNG, NumPy restatement shared bit-for-bit with
 the device code (zhusuan_amd/csrc/philox.h).  TEST INFRASTRUCTURE (see
 oracle/__init__.py).
 
 The reference draws momentum / MH uniforms with tf.random_normal /
-tf.random_uniform (hmc.py:22, hmc.py:485), i.e. TensorFlow's Philox4x32-10
+tf.random_uniform (hmc.py:22, hmc.py:485), i.e. TensorFlow's Philox4x32-7
 stream keyed by graph seed + op id.  TensorFlow (requirements-dev.txt:2,
 "tensorflow>=1.13.0") is not vendored, so the stream itself cannot be
-reproduced; we restate the published Philox4x32-10 algorithm (Salmon et al.,
+reproduced; we restate the published Philox4x32-7 algorithm (Salmon et al.,
 SC'11, Random123) and define our own counter mapping:
 
     key     = (seed_lo, seed_hi)
@@ -31,14 +31,18 @@ STREAM_DIST = 2
 STREAM_NOISE = 3
 
 
-def philox4x32_10(c0, c1, c2, c3, k0, k1):
-    """Vectorised Philox4x32-10.  All counter words broadcast together;
-    returns four uint32 arrays."""
+PHILOX_ROUNDS = 7      # csrc/philox.h: ZS_PHILOX_ROUNDS
+
+
+def philox4x32(c0, c1, c2, c3, k0, k1, rounds=PHILOX_ROUNDS):
+    """Vectorised Philox4x32-R (R = 7: the fewest rounds Random123 lists as
+    Crush-resistant; its default is 10).  All counter words broadcast
+    together; returns four uint32 arrays."""
     c0, c1, c2, c3 = np.broadcast_arrays(
         *[np.asarray(c, dtype=np.uint64) & MASK32 for c in (c0, c1, c2, c3)])
     k0 = int(k0) & 0xFFFFFFFF
     k1 = int(k1) & 0xFFFFFFFF
-    for _ in range(10):
+    for _ in range(rounds):
         p0 = PHILOX_M0 * c0
         p1 = PHILOX_M1 * c2
         hi0, lo0 = p0 >> np.uint64(32), p0 & MASK32
@@ -115,7 +119,7 @@ def normal_chain_major(seed, iteration, n_chains, n_data, chain_offset=0,
     n_groups = (n_data + 3) // 4
     g = np.arange(n_groups, dtype=np.uint64)[None, :]
     c = _chain_ids(n_chains, chain_offset)[:, None]
-    x0, x1, x2, x3 = philox4x32_10(g, c, np.uint64(iteration & 0xFFFFFFFF),
+    x0, x1, x2, x3 = philox4x32(g, c, np.uint64(iteration & 0xFFFFFFFF),
                                    np.uint64(stream | (latent_id << 8)),
                                    k0, k1)
     z0, z1 = box_muller(x0, x1)
@@ -129,7 +133,7 @@ def uniform_per_chain(seed, iteration, n_chains, chain_offset=0,
     """U[0,1) float32 per chain from counter (0, chain, iteration, stream)."""
     k0, k1 = seed_key(seed)
     c = _chain_ids(n_chains, chain_offset)
-    x0, _, _, _ = philox4x32_10(np.uint64(0), c,
+    x0, _, _, _ = philox4x32(np.uint64(0), c,
                                 np.uint64(iteration & 0xFFFFFFFF),
                                 np.uint64(stream), k0, k1)
     return u01(x0)
@@ -142,7 +146,7 @@ def uniform_flat(seed, offset, n, stream=STREAM_DIST):
     k0, k1 = seed_key(seed)
     ng = (n + 3) // 4
     g = np.arange(ng, dtype=np.uint64)
-    xs = philox4x32_10(g & MASK32, g >> np.uint64(32),
+    xs = philox4x32(g & MASK32, g >> np.uint64(32),
                        np.uint64(offset & 0xFFFFFFFF), np.uint64(stream),
                        k0, k1)
     return u01(np.stack(xs, axis=-1).reshape(-1)[:n])
@@ -154,7 +158,7 @@ def normal_flat(seed, offset, n, stream=STREAM_DIST):
     k0, k1 = seed_key(seed)
     ng = (n + 3) // 4
     g = np.arange(ng, dtype=np.uint64)
-    x0, x1, x2, x3 = philox4x32_10(g & MASK32, g >> np.uint64(32),
+    x0, x1, x2, x3 = philox4x32(g & MASK32, g >> np.uint64(32),
                                    np.uint64(offset & 0xFFFFFFFF),
                                    np.uint64(stream), k0, k1)
     z0, z1 = box_muller(x0, x1)

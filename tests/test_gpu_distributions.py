@@ -213,7 +213,7 @@ def test_empty_inputs(env):
 
 
 def test_device_philox_matches_oracle(env):
-    """Momentum kernel = Philox4x32-10 + Box-Muller on the hardware
+    """Momentum kernel = Philox4x32-7 + Box-Muller on the hardware
     log/sqrt/sin/cos units; uniform bits are exact, normals agree with the
     float64-evaluated oracle to a few 1e-6."""
     zs, torch, dev = env

@@ -267,7 +267,10 @@ def test_direct_rccl_communicator(tmp_path, world):
         # same sums in the same order; the update itself runs in the NEXT
         # launch's prologue here (sharded path) and in the retiring workgroup
         # there: same equations, possibly different last-bit rounding
-        np.testing.assert_allclose(ranks[0]['eps'], eps1, rtol=2e-6)
+        # (the last entry follows 7 more adaptive updates through the C-side
+        # launch loop: the differences compound a little)
+        np.testing.assert_allclose(ranks[0]['eps'][:-1], eps1[:-1], rtol=2e-6)
+        np.testing.assert_allclose(ranks[0]['eps'][-1], eps1[-1], rtol=2e-5)
         np.testing.assert_allclose(ranks[0]['state'], state1, rtol=2e-6,
                                    atol=1e-7)
         close = np.isclose(x, x1, atol=1e-4).all(axis=1)

@@ -1,24 +1,35 @@
-"""Pin oracle/philox.py: Random123 known-answer vectors for Philox4x32-10
-and basic statistical sanity of the derived uniform / normal streams."""
+"""Pin oracle/philox.py: Random123 known-answer vectors for Philox4x32 with 7
+(in use) and 10 rounds, and basic statistical sanity of the derived uniform / normal streams."""
 import numpy as np
 
 from oracle import philox
 
 
-def _kat(c, k):
-    return [int(x) for x in philox.philox4x32_10(
-        *[np.uint64(v) for v in c], k[0], k[1])]
+def _kat(c, k, rounds):
+    return [int(x) for x in philox.philox4x32(
+        *[np.uint64(v) for v in c], k[0], k[1], rounds=rounds)]
+
+
+KAT_INPUTS = (([0, 0, 0, 0], [0, 0]),
+              ([0xffffffff] * 4, [0xffffffff] * 2),
+              ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344],
+               [0xa4093822, 0x299f31d0]))
 
 
 def test_random123_known_answers():
-    # Random123 kat_vectors, philox4x32 10 rounds
-    assert _kat([0, 0, 0, 0], [0, 0]) == [
-        0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
-    assert _kat([0xffffffff] * 4, [0xffffffff] * 2) == [
-        0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
-    assert _kat([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344],
-                [0xa4093822, 0x299f31d0]) == [
-        0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    # Random123 kat_vectors, "philox4x32 7" (the round count in use) ...
+    want7 = ([0x5f6fb709, 0x0d893f64, 0x4f121f81, 0x4f730a48],
+             [0x5207ddc2, 0x45165e59, 0x4d8ee751, 0x8c52f662],
+             [0x4dfccaba, 0x190a87f0, 0xc47362ba, 0xb6b5242a])
+    # ... and "philox4x32 10"
+    want10 = ([0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8],
+              [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd],
+              [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1])
+    for (c, k), w7, w10 in zip(KAT_INPUTS, want7, want10):
+        assert _kat(c, k, 7) == w7
+        assert _kat(c, k, 10) == w10
+    assert philox.PHILOX_ROUNDS == 7
+    assert [int(x) for x in philox.philox4x32(0, 0, 0, 0, 0, 0)] == want7[0]
 
 
 def test_uniform_range_and_exactness():

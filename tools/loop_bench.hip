@@ -1,6 +1,6 @@
 // Isolated cost of the fused kernel's two VALU hot spots at W waves/SIMD:
 //   lf : the leapfrog trip (16 v_pk_fma_f32: r += eps*p ; p += nep*r)
-//   rng: normal4 x4 (Philox4x32-10 + Box-Muller for 16 normals)
+//   rng: normal4 x4 (Philox4x32-7 + Box-Muller for 16 normals)
 // Reports cycles per trip per SIMD (wall clock x assumed 2.0-2.4 GHz is
 // avoided: uses s_memtime of one wave as the clock and the wall time).
 #include <hip/hip_runtime.h>

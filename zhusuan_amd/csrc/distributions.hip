@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void bernoulli_sample_kernel(
   const int64_t n_groups = (n + 3) / 4;
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_groups;
        g += (int64_t)gridDim.x * blockDim.x) {
-    const U4 r = philox4x32_10((uint32_t)g, (uint32_t)((uint64_t)g >> 32),
+    const U4 r = philox4x32((uint32_t)g, (uint32_t)((uint64_t)g >> 32),
                                offset, kStreamDist, k0, k1);
     const uint32_t w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256) void categorical_sample_kernel(
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t g = i >> 2;
-    const U4 r = philox4x32_10((uint32_t)g, (uint32_t)((uint64_t)g >> 32),
+    const U4 r = philox4x32((uint32_t)g, (uint32_t)((uint64_t)g >> 32),
                                offset, kStreamDist, k0, k1);
     const uint32_t w[4] = {r.x, r.y, r.z, r.w};
     const float u = u01(w[i & 3]);

@@ -138,7 +138,7 @@ __device__ __forceinline__ float std_gamma(float alpha, uint64_t i,
   float out = d;  // fallback after 64 rejections (probability < 1e-80)
   float u_boost = 1.0f;
   for (uint32_t t = 0; t < 64; ++t) {
-    const U4 r = philox4x32_10((uint32_t)i, (uint32_t)(i >> 32), offset,
+    const U4 r = philox4x32((uint32_t)i, (uint32_t)(i >> 32), offset,
                                kStreamDist | (sub << 4) | (t << 8), k0, k1);
     float z, z_unused;
     box_muller(r.x, r.y, z, z_unused);
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void uni2_sample_kernel(
     const float pa = mode_a == ZSHMC_BCAST_SCALAR ? a[0] : a[j];
     const float pb = mode_b == ZSHMC_BCAST_SCALAR ? b[0] : b[j];
     if (KIND == kLaplace) {
-      const U4 r = philox4x32_10((uint32_t)i, (uint32_t)((uint64_t)i >> 32),
+      const U4 r = philox4x32((uint32_t)i, (uint32_t)((uint64_t)i >> 32),
                                  offset, kStreamDist, k0, k1);
       // u in (-1, 1): sign from one word, magnitude in [0, 1) from another
       const float mag = u01(r.x);

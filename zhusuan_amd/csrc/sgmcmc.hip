@@ -1,6 +1,6 @@
 // Stochastic-gradient MCMC update kernels on gfx950:
 // the element-wise updates of reference zhusuan/sgmcmc.py with the Gaussian
-// noise generated in the kernel (Philox4x32-10 + Box-Muller, counter
+// noise generated in the kernel (Philox4x32-7 + Box-Muller, counter
 // (i/4 lo, i/4 hi, iteration, STREAM_SG | sub<<4 | latent<<8) over the flat
 // element index i), so one launch per latent replaces the reference's
 // random_normal op + 5-10 element-wise TF ops + assigns.  The gradient of the

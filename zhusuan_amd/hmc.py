@@ -12,7 +12,7 @@ What differs from the reference, and why (no TensorFlow):
   * `adapt_step_size` / `adapt_mass` accept None, a Python bool, or a
     `placeholder()` whose value comes from `feed_dict` per run (the
     tf.placeholder idiom of examples/toy_examples/gaussian.py:40-41,57-58);
-  * random numbers come from the documented Philox4x32-10 counter mapping
+  * random numbers come from the documented Philox4x32-7 counter mapping
     (csrc/philox.h), not TensorFlow's graph-seeded stream.
 
 Two execution plans, chosen in `sample()`:
