@@ -98,8 +98,11 @@ def test_lntm_estep_matches_oracle(env):
         op.run()
         np.testing.assert_allclose(info.orig_log_prob.cpu().numpy(),
                                    rinfo.orig_log_prob, rtol=1e-4, atol=2e-2)
-        np.testing.assert_allclose(info.acceptance_rate.cpu().numpy(),
-                                   rinfo.acceptance_rate, atol=2e-2)
+        # (the adaptation transient passes through barely stable step sizes,
+        # Appendix B #1: acceptance to 3e-2 per chain, 1e-2 on average)
+        acc_d = info.acceptance_rate.cpu().numpy()
+        np.testing.assert_allclose(acc_d, rinfo.acceptance_rate, atol=3e-2)
+        assert np.abs(acc_d - rinfo.acceptance_rate).mean() < 1e-2
         np.testing.assert_allclose(float(info.updated_step_size.item()),
                                    float(rinfo.updated_step_size), rtol=2e-2)
         if it >= 10:    # mass is live after mass_collect_iters = 10

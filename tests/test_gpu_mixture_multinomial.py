@@ -227,7 +227,10 @@ def test_lntm_native_plan_equals_generic_plan(env, user_log_joint, adaptive):
             # through their acceptance, which is 0 on both sides)
             ha_, hb_ = (info_a.hamiltonian.cpu().numpy(),
                         info_b.hamiltonian.cpu().numpy())
-            tame = (hb_ - info_b.orig_hamiltonian.cpu().numpy()) < 20.0
+            # (an energy error of e.g. 10 already means the integrator is
+            # amplifying differences exponentially: two float32 evaluation
+            # orders agree to 4e-3 only on trajectories that stay tame)
+            tame = (hb_ - info_b.orig_hamiltonian.cpu().numpy()) < 2.0
             if tame.any():
                 ok = np.isclose(ha_[tame], hb_[tame], rtol=3e-4, atol=4e-3)
                 assert ok.mean() >= 0.85, ok.mean()
@@ -331,3 +334,68 @@ def test_config5_full_size_properties(env):
             g1[c, r].cpu().numpy(),
             ((x1[r].double() / dw) @ phi.double().t()).cpu().numpy(),
             rtol=2e-4, atol=1e-3)
+
+
+DOC_MAJOR_WORKER = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, %(tests)r)
+import zhusuan_amd as zs
+from test_gpu_mixture_multinomial import _data
+dev = torch.device('cuda', 0)
+out = {}
+for n_chains, n_docs, K, V in %(shapes)r:
+    phi, x, theta = _data(n_chains, n_docs, K, V, seed=K + V + n_chains)
+    tt = torch.tensor(theta, device=dev, requires_grad=True)
+    d = zs.distributions.UnnormalizedMultinomial(
+        zs.log_mixture(tt, torch.tensor(phi, device=dev)),
+        normalize_logits=False, dtype=torch.float32)
+    ll = d.log_prob(torch.tensor(x, device=dev))
+    ll.sum().backward()
+    out['ll_%%d_%%d' %% (n_chains, n_docs)] = ll.detach().cpu().numpy()
+    out['g_%%d_%%d' %% (n_chains, n_docs)] = tt.grad.cpu().numpy()
+np.savez(%(out)r, **out)
+'''
+
+# chain axes that fill 64-chain tiles (document-major tiles), with a ragged
+# last group, with row-range splits (few workgroups), and one that does not
+DOC_MAJOR_SHAPES = [(64, 5, 64, 300), (128, 9, 100, 1003), (520, 3, 128, 200),
+                    (640, 2, 20, 77), (40, 6, 64, 130)]
+
+
+def test_document_major_tiles_equal_consecutive_rows(env, tmp_path):
+    """Rows r = chain * n_docs + doc of the topic model's chain axes are tiled
+    64 CHAINS OF ONE DOCUMENT when the chain axis fills such tiles (the
+    counts of a workgroup are then one row of the matrix, not a 32-row gather
+    per load): same arithmetic per row, so bit-identical to the
+    consecutive-row tiling (ZSHMC_LB_DOC_MAJOR=0, run in a second process) and
+    equal to the float64 evaluation."""
+    import os
+    import subprocess
+    import sys
+    zs, torch, dev = env
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tag, flag in (('doc', '1'), ('row', '0')):
+        script = tmp_path / ('w_%s.py' % tag)
+        out = str(tmp_path / ('%s.npz' % tag))
+        script.write_text(DOC_MAJOR_WORKER % dict(
+            root=root, tests=os.path.join(root, 'tests'),
+            shapes=DOC_MAJOR_SHAPES, out=out))
+        r = subprocess.run([sys.executable, str(script)],
+                           env=dict(os.environ, ZSHMC_LB_DOC_MAJOR=flag),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[tag] = np.load(out)
+    for k in res['doc'].files:
+        np.testing.assert_array_equal(res['doc'][k], res['row'][k], err_msg=k)
+    for n_chains, n_docs, K, V in DOC_MAJOR_SHAPES:
+        phi, x, theta = _data(n_chains, n_docs, K, V, seed=K + V + n_chains)
+        dw = theta.astype(np.float64) @ phi.astype(np.float64)
+        np.testing.assert_allclose(res['doc']['ll_%d_%d' % (n_chains, n_docs)],
+                                   (x[None] * np.log(dw)).sum(-1), rtol=3e-5,
+                                   atol=3e-4)
+        g_ref = (x[None] / dw) @ phi.astype(np.float64).T
+        np.testing.assert_allclose(res['doc']['g_%d_%d' % (n_chains, n_docs)],
+                                   g_ref, rtol=2e-4,
+                                   atol=2e-4 * np.abs(g_ref).max())

@@ -286,7 +286,8 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2
     const float* __restrict__ W, const float* __restrict__ X,
     const float* __restrict__ y, const float* __restrict__ yc,
     int64_t yc_rows, int64_t ldy, int64_t C, int64_t N, int64_t ldw,
-    int64_t ldx, float* __restrict__ ll, float* __restrict__ gW) {
+    int64_t ldx, float* __restrict__ ll, float* __restrict__ gW,
+    int doc_major) {
   constexpr int LD = D + 4;          // padded LDS row: conflict-free b128 reads
   constexpr int kRows = 64;          // data rows per tile
   constexpr int KK = D / 8;          // phase-1 steps of 4 MFMAs (8 features)
@@ -307,7 +308,28 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2
   const int wave = tid >> 6;
   const int a = wave >> 1, b = wave & 1;
   const int lo = lane & 31, hi = lane >> 5;
-  const int64_t c0 = (int64_t)blockIdx.x * kMC;
+  // The 64 rows of W this workgroup owns: consecutive (row_stride 1), or --
+  // OP 1, doc_major: rows r = chain * yc_rows + doc of the topic model's
+  // [n_chains, n_docs] chain axes -- 64 CHAINS OF ONE DOCUMENT (row_stride =
+  // n_docs).  With consecutive rows every lane gathers its own document's
+  // counts (32 different rows of the [n_docs, V] matrix per instruction, 2 TB
+  // of gathered bytes per launch at BASELINE configs[4],
+  // profiles/r03e_native_full_shape_rocprofv3_summary.txt); with one document
+  // per workgroup the same four loads per tile are broadcasts of one row.
+  int64_t row_base = (int64_t)blockIdx.x * kMC, row_stride = 1;
+  int64_t n_valid = C - row_base;
+  if (OP == 1 && doc_major) {
+    const int64_t grp = blockIdx.x / yc_rows, doc = blockIdx.x % yc_rows;
+    row_base = grp * kMC * yc_rows + doc;
+    row_stride = yc_rows;
+    n_valid = C / yc_rows - grp * kMC;
+  }
+  n_valid = n_valid < kMC ? n_valid : kMC;
+  // row of position i (0..63) of the tile; positions past the end re-read the
+  // last valid row (their results are never stored)
+  auto row_at = [&](int i) -> int64_t {
+    return row_base + (int64_t)(i < n_valid ? i : (int)n_valid - 1) * row_stride;
+  };
   // OP 1: counts rows are 16-B aligned and zero-padded to 4-float groups
   const bool yc_vec = OP == 1 && (ldy & 3) == 0 && ldy >= ((N + 3) & ~3ll) &&
                       (reinterpret_cast<uintptr_t>(yc) & 15) == 0;
@@ -315,8 +337,7 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2
   // ---- this wave's W block -> registers (B operand: k-slot = lane half) ----
   float wreg[KK * 4];
   {
-    int64_t cr = c0 + a * 32 + lo;
-    cr = cr < C ? cr : C - 1;
+    const int64_t cr = row_at(a * 32 + lo);
     const float* __restrict__ wrow = W + cr * ldw + hi * 4;
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) {
@@ -429,8 +450,7 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2
   // 16 B per lane instead of 16 x 4 B.
   float xcnt[16], xnext[16];
   auto load_counts = [&](int64_t t, float* dst) {
-    int64_t cr = c0 + a * 32 + lo;
-    cr = cr < C ? cr : C - 1;
+    const int64_t cr = row_at(a * 32 + lo);
     // counts rows repeat with period yc_rows (x[n_docs, V] shared by chains)
     const float* __restrict__ xrow0 =
         yc + (cr % yc_rows) * ldy + t * kRows + b * 32 + 4 * hi;
@@ -631,8 +651,9 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2
   if (GRAD) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int64_t chain = c0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      if (chain < C) {
+      const int pos = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (pos < n_valid) {
+        const int64_t chain = row_base + pos * row_stride;
 #pragma unroll
         for (int t = 0; t < FB; ++t)
           gW[chain * ldw + b * HALF + lo * FB + t] = G[t][r];
@@ -646,8 +667,10 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2
   if (hi == 0) sRd[wave * 32 + lo] = ll_half;
   __syncthreads();
   if (b == 0 && hi == 0) {
-    const int64_t chain = c0 + a * 32 + lo;
-    if (chain < C) ll[chain] = (float)(ll_half + sRd[(wave ^ 1) * 32 + lo]);
+    const int pos = a * 32 + lo;
+    if (pos < n_valid)
+      ll[row_base + pos * row_stride] =
+          (float)(ll_half + sRd[(wave ^ 1) * 32 + lo]);
   }
 }
 
@@ -676,7 +699,7 @@ static int launch_v2(const float* W, const float* X, const float* y,
                      const float* yc, int64_t yc_rows, int64_t ldy, int64_t C,
                      int64_t N, int64_t ldw, int64_t ldx, float* ll, float* gW,
                      hipStream_t s, int n_splits = 1,
-                     float* workspace = nullptr) {
+                     float* workspace = nullptr, int doc_major = 0) {
   constexpr int LD = D + 4;
   const size_t lds =
       (size_t)(ZS_LB_BUF(D) * 64 * LD + 2 * 64 + 4 * 16 * 64) * sizeof(float);
@@ -692,7 +715,10 @@ static int launch_v2(const float* W, const float* X, const float* y,
     if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(LDS)");
     attr2 = true;
   }
-  const int gx = (int)((C + kMC - 1) / kMC);
+  // doc_major: one workgroup per (group of 64 chains, document)
+  const int gx = doc_major
+                     ? (int)(((C / yc_rows + kMC - 1) / kMC) * yc_rows)
+                     : (int)((C + kMC - 1) / kMC);
   const int S = (n_splits > 1 && workspace) ? n_splits : 1;
   float* ll_out = S > 1 ? workspace : ll;
   float* g_out = S > 1 ? (gW ? workspace + (int64_t)S * C : nullptr) : gW;
@@ -700,11 +726,11 @@ static int launch_v2(const float* W, const float* X, const float* y,
   if (gW)
     hipLaunchKernelGGL((linear_bernoulli_kernel_v2<D, true, OP>), grid,
                        dim3(256), lds, s, W, X, y, yc, yc_rows, ldy, C, N, ldw, ldx,
-                       ll_out, g_out);
+                       ll_out, g_out, doc_major);
   else
     hipLaunchKernelGGL((linear_bernoulli_kernel_v2<D, false, OP>), grid,
                        dim3(256), lds, s, W, X, y, yc, yc_rows, ldy, C, N, ldw, ldx,
-                       ll_out, g_out);
+                       ll_out, g_out, doc_major);
   ZS_LAUNCH_CHECK("linear_bernoulli_kernel_v2 launch");
   if (S > 1) {
     const int64_t n = C + (gW ? C * ldw : 0);
@@ -809,23 +835,34 @@ extern "C" int zshmc_linear_multinomial_log_lik(const float* theta,
              "zshmc_linear_multinomial_log_lik: 1 <= n_splits <= 64 and a "
              "workspace of n_splits*n_rows*(n_topics+1) floats when > 1");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  // Rows r = chain * count_rows + doc (the topic model's [n_chains, n_docs]
+  // chain axes): tiles of 64 chains of ONE document when the chain axis fills
+  // them well (a multiple of 64, or at least 512 chains: >= 89 % of the
+  // slots used), so that a workgroup's counts are one row of the matrix.
+  // Same arithmetic per row either way (bit-identical results);
+  // ZSHMC_LB_DOC_MAJOR=0 keeps consecutive rows (A/B, tests).
+  static const bool allow_doc_major = [] {
+    const char* e = getenv("ZSHMC_LB_DOC_MAJOR");
+    return !(e && e[0] == '0');
+  }();
+  const int64_t n_chains = n_rows / count_rows;
+  const int doc_major =
+      allow_doc_major && count_rows > 1 &&
+      (n_chains % kMC == 0 || n_chains >= 512);
   switch (n_topics) {
     case 64:
       return launch_v2<64, 1>(theta, phi_t, nullptr, counts, count_rows,
-                              count_stride, n_rows,
-                              n_vocab, 64,
-                              64, log_lik, grad_theta, s, n_splits, workspace);
+                              count_stride, n_rows, n_vocab, 64, 64, log_lik,
+                              grad_theta, s, n_splits, workspace, doc_major);
     case 128:
       return launch_v2<128, 1>(theta, phi_t, nullptr, counts, count_rows,
-                              count_stride, n_rows,
-                              n_vocab,
-                               128, 128, log_lik, grad_theta, s, n_splits,
-                               workspace);
+                               count_stride, n_rows, n_vocab, 128, 128,
+                               log_lik, grad_theta, s, n_splits, workspace,
+                               doc_major);
     default:
       return launch_v2<256, 1>(theta, phi_t, nullptr, counts, count_rows,
-                              count_stride, n_rows,
-                              n_vocab,
-                               256, 256, log_lik, grad_theta, s, n_splits,
-                               workspace);
+                               count_stride, n_rows, n_vocab, 256, 256,
+                               log_lik, grad_theta, s, n_splits, workspace,
+                               doc_major);
   }
 }
