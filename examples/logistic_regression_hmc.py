@@ -1,10 +1,13 @@
 #!/usr/bin/env python
 """BASELINE config 3: Bayesian logistic regression by many-chain HMC.
 A synthetic N x D design matrix, w ~ N(0, I), y ~ Bernoulli(sigmoid(X w)).
-The likelihood is written `zs.linear_logits(w, X)` instead of
-`tf.matmul(w, X, transpose_b=True)`: the Bernoulli log-likelihood of all
-chains and its gradient then run in the fused fp32-MFMA kernel -- X is read
-once per evaluation and the [n_chains, N] logits never exist in memory.
+The likelihood is written as in the reference, `logits = w @ X^T`
+(tf.matmul(w, X, transpose_b=True)): the sampler hands the model function a
+symbolic latent (zhusuan_amd/_symbolic.py), the matmul stays symbolic, and
+`bn.bernoulli` lowers it to the fused fp32-MFMA kernel -- the Bernoulli
+log-likelihood of all chains and its gradient in one pass over X; the
+[n_chains, N] logits (131 GB at the default size) never exist in memory.
+(`zs.linear_logits(w, X)` is the explicit spelling of the same thing.)
 
     python examples/logistic_regression_hmc.py [--n 1000000] [--d 256]
         [--chains 32768] [--iters 100]
@@ -43,7 +46,7 @@ if __name__ == "__main__":
         bn = zs.BayesianNet()
         w = bn.normal('w', torch.zeros(D, device=dev), std=1.,
                       n_samples=C, group_ndims=1)
-        bn.bernoulli('y', zs.linear_logits(w.tensor, X), group_ndims=1,
+        bn.bernoulli('y', w.tensor @ X.t(), group_ndims=1,
                      dtype=torch.float32)
         return bn
 

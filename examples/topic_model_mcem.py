@@ -3,10 +3,11 @@
 reference's LNTM example; BASELINE config 5 shape).
 
   E step   HMC over the document logits eta[n_chains, batch, n_topics] -- the
-           hot path.  The word likelihood is declared with
-           `zs.log_mixture(theta, phi)`, so the multinomial term and its
-           gradient run in the fused fp32-MFMA kernel and the [rows, n_vocab]
-           mixture never exists in memory.
+           hot path.  The word likelihood is written as in lntm_mcem.py:39-46,
+           log(softmax(eta) @ phi): under the sampler the latent is symbolic
+           (zhusuan_amd/_symbolic.py), the expression is lowered to the fused
+           fp32-MFMA kernel and the [rows, n_vocab] mixture never exists in
+           memory (`zs.log_mixture(theta, phi)` is the explicit spelling).
   M step   Adam on the topic logits beta (torch.optim, outside the hot path);
            with a gradient flowing into phi the same model takes the dense
            route automatically.
@@ -65,9 +66,12 @@ class TopicModel(object):
                             group_ndims=1)
             beta = bn.normal('beta', torch.zeros(K, V, device=dev),
                              logstd=LOG_DELTA, group_ndims=1)
-            words = zs.log_mixture(torch.softmax(eta.tensor, -1),
-                                   torch.softmax(beta.tensor, -1))
-            bn.unnormalized_multinomial('x', words, normalize_logits=False,
+            theta = torch.softmax(eta.tensor, -1)          # lntm_mcem.py:39
+            phi = torch.softmax(beta.tensor, -1)
+            pred = (theta.reshape(-1, K) @ phi).reshape(
+                n_chains, n_docs, V)                       # :40-45
+            bn.unnormalized_multinomial('x', torch.log(pred),
+                                        normalize_logits=False,
                                         dtype=torch.float32)
             return bn
 
