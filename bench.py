@@ -335,6 +335,14 @@ def extra_config1(torch, zs, dev, n_chains=1000, n_x=10, n_leapfrogs=5):
                        'adaptive (step size + mass) + 50 held' % (
                            n_chains, n_x, n_leapfrogs))
     out['kernel'] = _capi_kernel_name(n_x, 1, 1)
+    # the reference's OWN hmc.py over the TensorFlow-API shim on this shape: a
+    # RECORDED number (its sources do not travel to the GPU box)
+    try:
+        with open(os.path.join(ROOT, 'profiles',
+                               'r03_cpu_reference_over_shim_config1.json')) as f:
+            out['cpu_reference_over_shim'] = json.load(f)
+    except Exception:
+        out['cpu_reference_over_shim'] = None
     return out
 
 

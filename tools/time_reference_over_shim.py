@@ -10,7 +10,9 @@ bench.py therefore carries this number as a recorded value
 (profiles/r02_cpu_reference_over_shim.json, `measured_on` says where), next to
 the baselines it measures live on the GPU box's own cores.
 
-    python tools/time_reference_over_shim.py [seconds]
+    python tools/time_reference_over_shim.py [seconds] [C D L out.json]
+(e.g. `10 1000 10 5 profiles/r03_cpu_reference_over_shim_config1.json`:
+BASELINE configs[0], the gaussian.py shape)
 """
 import json
 import os
@@ -27,15 +29,21 @@ from oracle.make_golden_hmc import gaussian_model, load_reference  # noqa: E402
 
 C, D, L = 4096, 1024, 10
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 20.0
+OUT = os.path.join(ROOT, 'profiles', 'r02_cpu_reference_over_shim.json')
+if len(sys.argv) > 5:
+    C, D, L = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    OUT = os.path.join(ROOT, sys.argv[5])
 threads = os.cpu_count()
 torch.set_num_threads(threads)
 tf, zs = load_reference()
 tf_shim._VARS[:] = []
 tf_shim.end_replay()
 logstd = np.linspace(-1, 1, D).astype(np.float32)
+if D == 10:      # gaussian.py:29
+    logstd = np.log(1.0 / (np.arange(D, dtype=np.float32) + 1.0))
 model = gaussian_model(np.zeros(D, np.float32), logstd)(tf, zs, C)
 x = tf.Variable(np.zeros((C, D), np.float32), name='x')
-hmc = zs.hmc.HMC(step_size=0.14, n_leapfrogs=L)
+hmc = zs.hmc.HMC(step_size=0.14 if D != 10 else 0.05, n_leapfrogs=L)
 # tf.random_normal / tf.random_uniform: torch's generators (a TF kernel would
 # also be a fast C++ Philox; the NumPy Philox of the parity harness would
 # dominate the time and is not what is being measured)
@@ -69,7 +77,7 @@ out = {
     'measured_on': 'build container (%d host threads), NOT the GPU box: the '
                    'reference sources do not travel there' % threads,
     'elem_leapfrog_steps_per_sec': C * D * L * n / el,
+    'transitions_per_sec': n / el,
 }
-path = os.path.join(ROOT, 'profiles', 'r02_cpu_reference_over_shim.json')
-json.dump(out, open(path, 'w'), indent=1)
+json.dump(out, open(OUT, 'w'), indent=1)
 print(json.dumps(out, indent=1))
