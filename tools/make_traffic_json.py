@@ -27,8 +27,8 @@ out = {
     'hbm_write_bytes_per_launch': wr,
     'hbm_bytes_per_launch': rd + wr,
     'algorithmic_bytes_per_launch': 8.0 * 65536 * 1024,
-    'note': 'measured < algorithmic because rejected chains (about 8 % at this '
-            'step size) are not written back',
+    'note': 'measured < algorithmic because rejected chains are not written '
+            'back (mean over the second half of the traced run)',
 }
 json.dump(out, open('profiles/pmc_traffic.json', 'w'), indent=1)
 print(json.dumps(out, indent=1))
