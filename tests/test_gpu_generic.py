@@ -237,3 +237,66 @@ def test_session_shim_and_hmcinfo_fields(env):
     assert st['t'] == 1
     with pytest.raises(RuntimeError, match='once per HMC instance'):
         hmc.sample(lambda o: o['x'].sum(-1), {}, {'x': xg})
+
+
+def test_foreign_autograd_function_falls_back_to_plain_tensors(env):
+    """A model whose log-joint passes the latent through a user-defined
+    torch.autograd.Function: `Function.apply` hands a symbolic latent to
+    `forward` without dispatch, which would cut the tape -- the sampler
+    notices (zhusuan_amd/_symbolic.py: SymbolicCut), evaluates on plain
+    tensors from then on and samples exactly as the same model written
+    without the Function."""
+    zs, torch, dev = env
+    C, D = 64, 6
+
+    class Scale(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x * 1.5
+
+        @staticmethod
+        def backward(ctx, g):
+            return g * 1.5
+
+    def make(use_function):
+        def log_joint(obs):
+            x = obs['x']
+            y = Scale.apply(x) if use_function else x * 1.5
+            return -0.5 * (y ** 2).sum(-1)
+        h = zs.HMC(step_size=0.2, n_leapfrogs=5, seed=9)
+        q = torch.linspace(-1, 1, C * D, device=dev).reshape(C, D).contiguous()
+        op, info = h.sample(log_joint, {}, {'x': q})
+        for _ in range(6):
+            op.run()
+        return h, q, info.acceptance_rate.clone()
+
+    ha, qa, acc_a = make(True)
+    hb, qb, acc_b = make(False)
+    assert ha._symbolic_latents is False and hb._symbolic_latents is True
+    assert torch.equal(qa, qb) and torch.equal(acc_a, acc_b)
+    assert float((qa != torch.linspace(-1, 1, C * D, device=dev).reshape(
+        C, D)).float().mean()) > 0.5          # the chains moved
+
+
+def test_run_many_on_the_generic_plan_is_a_loop_of_runs(env):
+    zs, torch, dev = env
+    C, D = 128, 5
+
+    def make(many):
+        def log_joint(obs):
+            return -0.5 * (obs['x'] ** 2).sum(-1) - 0.1 * (obs['x'] ** 4).sum(-1)
+        flag = zs.placeholder(bool)
+        h = zs.HMC(step_size=0.1, n_leapfrogs=4, adapt_step_size=flag, seed=4)
+        q = torch.zeros(C, D, device=dev)
+        op, info = h.sample(log_joint, {}, {'x': q})
+        assert h.plan_kind == 'generic'
+        if many:
+            op.run_many(9, feed_dict={flag: True})
+            op.run_many(5, feed_dict={flag: False})
+        else:
+            for i in range(14):
+                op.run(feed_dict={flag: i < 9})
+        return q, float(info.updated_step_size.item()), h.t
+    qa, ea, ta = make(False)
+    qb, eb, tb = make(True)
+    assert torch.equal(qa, qb) and ea == eb and ta == tb == 14

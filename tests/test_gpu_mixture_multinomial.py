@@ -230,7 +230,10 @@ def test_lntm_native_plan_equals_generic_plan(env, user_log_joint, adaptive):
             # (an energy error of e.g. 10 already means the integrator is
             # amplifying differences exponentially: two float32 evaluation
             # orders agree to 4e-3 only on trajectories that stay tame)
-            tame = (hb_ - info_b.orig_hamiltonian.cpu().numpy()) < 2.0
+            # -- on BOTH sides: at the edge of stability one float32
+            # evaluation order may blow up where the other does not
+            tame = ((hb_ - info_b.orig_hamiltonian.cpu().numpy()) < 2.0) & \
+                ((ha_ - info_a.orig_hamiltonian.cpu().numpy()) < 2.0)
             if tame.any():
                 # (the median: one chain at the edge of stability may still
                 # differ by more)
