@@ -33,6 +33,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# RCCL across processes: the host driver only supports dmabuf IPC (without
+# this, hipIpcGetMemHandle fails with "invalid argument"); normally already
+# exported on the GPU boxes
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
 N_CHAINS_PER_GPU = 65536
 N_DATA = 1024
