@@ -171,3 +171,18 @@ def test_a_foreign_autograd_function_is_detected_not_silently_cut():
     with torch.no_grad():
         assert torch.equal(Foreign.apply(sym.wrap_latent(_latent(3))),
                            _latent(3) * 3.0)
+
+
+def test_odd_calls_on_symbols_compute_on_the_plain_tensor():
+    w = _latent(6, 8).requires_grad_(True)
+    s = sym.wrap_latent(w)
+    assert s.requires_grad is True          # the latent's, not the wrapper's
+    assert sym.wrap_latent(_latent(2, 2)).requires_grad is False
+    v = s.view(torch.int32)                 # a dtype, not a shape
+    assert not isinstance(v, sym.Sym) and v.dtype == torch.int32
+    assert torch.equal(s.t(), w.t()) and len(s) == 6
+    assert s.is_contiguous() and float(s.sum()) == float(w.sum())
+    r = torch.reshape(s, shape=(8, 6))      # keyword form: plain tensor
+    assert not isinstance(r, sym.Sym) and r.shape == (8, 6)
+    z = s.reshape(3, 16)                    # last axis changes: plain tensor
+    assert not isinstance(z, sym.Sym)

@@ -51,12 +51,14 @@ def _getter(name):
 _METADATA = {
     _getter('shape'), _getter('dtype'), _getter('device'), _getter('ndim'),
     _getter('is_cuda'), _getter('is_meta'), _getter('layout'),
-    _getter('requires_grad'), _getter('grad_fn'), _getter('is_leaf'),
+    _getter('grad_fn'), _getter('is_leaf'),
     _getter('is_sparse'), _getter('is_quantized'), _getter('names'),
     _T.dim, _T.size, _T.numel, _T.nelement, _T.ndimension,
     _T.is_floating_point, _T.is_complex, _T.element_size, _T.__len__,
     _T.get_device, _T.__repr__, _T.__hash__, _T.__format__,
 }
+
+_REQUIRES_GRAD = _getter('requires_grad')
 
 _SOFTMAX = {torch.softmax, torch.nn.functional.softmax, _T.softmax}
 _MATMUL = {torch.matmul, _T.matmul, _T.__matmul__, torch.mm, _T.mm}
@@ -118,6 +120,8 @@ class Sym(torch.Tensor):
         if func in _METADATA:
             with torch._C.DisableTorchFunctionSubclass():
                 return func(*args, **kwargs)
+        if func is _REQUIRES_GRAD:      # of the latent the symbol stands on
+            return args[0]._root.requires_grad
         out = _symbolic_rule(func, args, kwargs)
         if out is not None:
             return out
@@ -181,7 +185,10 @@ def _resolve_shape(shape_args, numel):
     if len(shape_args) == 1 and isinstance(shape_args[0], (tuple, list,
                                                            torch.Size)):
         shape_args = tuple(shape_args[0])
-    shape = [int(s) for s in shape_args]
+    try:
+        shape = [int(s) for s in shape_args]
+    except (TypeError, ValueError):      # e.g. Tensor.view(dtype)
+        return None
     if shape.count(-1) > 1:
         return None
     if -1 in shape:
