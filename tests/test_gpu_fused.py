@@ -535,8 +535,9 @@ def test_column_statistics_are_refused_where_the_kernel_has_none(env):
 @pytest.mark.parametrize('C,D', [(1000, 10), (3000, 260), (70000, 1024)])
 def test_run_many_is_bit_identical_to_a_loop_of_runs(env, C, D):
     """sample_op.run_many(n): the stretches that need nothing from the host
-    are ONE zshmc_hmc_diag_normal_run call (launch loop on the C side); every
-    state word, the latent and the last HMCInfo equal n single runs."""
+    are ONE zshmc_hmc_diag_normal_run call (launch loop on the C side,
+    stretches of 16 launches replayed from a hipGraph); every state word, the
+    latent and the last HMCInfo equal n single runs."""
     zs, torch = env
     dev = torch.device('cuda', 0)
     logstd = torch.linspace(-0.5, 0.5, D, device=dev)
@@ -562,9 +563,12 @@ def test_run_many_is_bit_identical_to_a_loop_of_runs(env, C, D):
             return real(name, *a)
         _capi.call = spy
         try:
+            # (blocks of 40 and 48: one plain launch, then stretches of 16
+            # replayed from a hipGraph with the iteration in a device
+            # counter, then the remainder as plain launches)
             for n, feed in ((9, {f_ss: True, f_m: True}),
-                            (8, {f_ss: True, f_m: False}),
-                            (11, {f_ss: False, f_m: False})):
+                            (40, {f_ss: True, f_m: False}),
+                            (50, {f_ss: False, f_m: False})):
                 if many:
                     op.run_many(n, feed_dict=feed, sync=False)
                 else:
@@ -578,8 +582,8 @@ def test_run_many_is_bit_identical_to_a_loop_of_runs(env, C, D):
                     calls))
     (xa, sa, aa, la, ta, ca), (xb, sb, ab, lb, tb, cb) = out
     assert torch.equal(xa, xb) and torch.equal(sa, sb)
-    assert torch.equal(aa, ab) and torch.equal(la, lb) and ta == tb == 28
+    assert torch.equal(aa, ab) and torch.equal(la, lb) and ta == tb == 99
     assert 'zshmc_hmc_diag_normal_run' not in ca
-    assert cb.count('zshmc_hmc_diag_normal_run') == 2   # 8 adaptive; 11 - 2 held
+    assert cb.count('zshmc_hmc_diag_normal_run') == 2   # 40 adaptive; 50 - 2 held
     assert cb.count('zshmc_hmc_diag_normal_step') == \
-        ca.count('zshmc_hmc_diag_normal_step') - 8 - 9
+        ca.count('zshmc_hmc_diag_normal_step') - 40 - 48

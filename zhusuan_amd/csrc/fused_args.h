@@ -140,6 +140,10 @@ struct AdaptLink {
   // doubles per workgroup.  NULL: not asked for.
   const float* cs_mean;
   double* cs_parts;
+  // launches replayed from a hipGraph (zshmc_hmc_diag_normal_run): the
+  // iteration of the Philox counters is args.iteration + *iter_dev, and the
+  // workgroup that retires last advances *iter_dev.  NULL: args.iteration.
+  uint32_t* iter_dev;
 };
 
 // state <- update(state, acc_sum) and the two diagnostic words; one thread.
@@ -216,12 +220,24 @@ __device__ __forceinline__ void link_retire(const AdaptLink& k, double wg_sum,
     tuner_persist(k, k.pending, k.stats[0]);
   if (k.state && k.retire != ZSHMC_PEND_NONE)
     tuner_persist(k, k.retire, total, prep);
-  k.stats[0] = total;
-  uint32_t f = 0;
-  if (flags)
-    f = __hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  k.stats[1] = (f & ZSHMC_FLAG_OLD_LOGPROB_NONFINITE) ? 1.0 : 0.0;
+  if (k.stats) {
+    k.stats[0] = total;
+    uint32_t f = 0;
+    if (flags)
+      f = __hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    k.stats[1] = (f & ZSHMC_FLAG_OLD_LOGPROB_NONFINITE) ? 1.0 : 0.0;
+  }
+  // (every other workgroup has retired, hence read the counter long ago)
+  if (k.iter_dev) *k.iter_dev += 1u;
   __hip_atomic_store(k.accum, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// the iteration word of this launch's Philox counters (wave-uniform)
+__device__ __forceinline__ uint32_t link_iteration(const AdaptLink& k,
+                                                   uint32_t iteration) {
+  if (!k.iter_dev) return iteration;
+  return iteration + __hip_atomic_load(k.iter_dev, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
 }
 
 struct FusedArgs {

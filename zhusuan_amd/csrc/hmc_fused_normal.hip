@@ -91,6 +91,8 @@ __global__ __launch_bounds__(256, ZS_WAVES_PER_EU) void hmc_diag_normal_kernel(
       (int64_t)blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
   const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x / kWave);
   const int64_t D = a.n_data;
+  const uint32_t iteration = __builtin_amdgcn_readfirstlane(
+      link_iteration(a.link, a.iteration));
 
   // ---- stage mean / sqrt(mass) in LDS (zero padding beyond n_data) --------
   for (int d = threadIdx.x; d < kPad; d += blockDim.x) {
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(256, ZS_WAVES_PER_EU) void hmc_diag_normal_kernel(
       z0 = __uint_as_float(0x3f000000u | ((group * 2654435761u + gchain) & 0x7fffffu));
       z1 = z0 - 0.75f; z2 = 0.6f - z0; z3 = z0 * z1;
 #else
-      normal4(group, gchain, a.iteration, kStreamMomentum, key0, key1, z0, z1,
+      normal4(group, gchain, iteration, kStreamMomentum, key0, key1, z0, z1,
               z2, z3);
 #endif
       p[k] = f4{z0, z1, z2, z3};
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(256, ZS_WAVES_PER_EU) void hmc_diag_normal_kernel(
     if (!(dh == dh) || !isfinite(acc) || !isfinite(lp_new)) acc = 0.f;
     if (active && !isfinite(lp_old)) bad_old = true;
 
-    const float u = uniform_chain(gchain, a.iteration, key0, key1);
+    const float u = uniform_chain(gchain, iteration, key0, key1);
     const bool accept = u < acc;  // strict, hmc.py:486
 
 #ifdef ZS_TIMING
@@ -521,13 +523,17 @@ extern "C" int zshmc_stepsize_flush(const zshmc_adapt_link* link,
   return ZSHMC_OK;
 }
 
-extern "C" int zshmc_hmc_diag_normal_step(
+// iter_from_device: the launch is (being captured as) a node of a hipGraph --
+// its iteration is `iteration` + the device counter at workspace + 16, which
+// the workgroup that retires last advances (so the retirement atomic runs
+// even when no statistics are collected)
+static int step_impl(
     float* q, const float* mean, const float* logstd, const float* mass,
     float step_size_host, int64_t n_chains, int64_t n_data,
     int64_t chain_offset, int n_leapfrogs, uint64_t seed, uint32_t iteration,
     int commit, float* acceptance_rate, float* orig_hamiltonian,
     float* hamiltonian, float* orig_log_prob, float* log_prob, uint32_t* flags,
-    const zshmc_adapt_link* link, void* stream) {
+    const zshmc_adapt_link* link, void* stream, int iter_from_device) {
   ZS_REQUIRE(q && logstd, "zshmc_hmc_diag_normal_step: null q/logstd");
   ZS_REQUIRE(n_chains >= 0 && n_data >= 1,
              "zshmc_hmc_diag_normal_step: bad shape [%lld, %lld]",
@@ -543,6 +549,13 @@ extern "C" int zshmc_hmc_diag_normal_step(
   {
     const int rc = make_link(link, &a.link, "zshmc_hmc_diag_normal_step");
     if (rc != ZSHMC_OK) return rc;
+  }
+  if (iter_from_device) {
+    ZS_REQUIRE(link && link->workspace && n_chains > 0,
+               "zshmc_hmc_diag_normal_run: graph replay needs link->workspace");
+    char* ws = reinterpret_cast<char*>(link->workspace);
+    a.link.accum = reinterpret_cast<unsigned long long*>(ws);
+    a.link.iter_dev = reinterpret_cast<uint32_t*>(ws + 16);
   }
   if (n_chains == 0) {
     if (a.link.stats || a.link.pending != ZSHMC_PEND_NONE ||
@@ -615,10 +628,62 @@ extern "C" int zshmc_hmc_diag_normal_step(
   return launch_cfg<64, 8>(a, s);
 }
 
+extern "C" int zshmc_hmc_diag_normal_step(
+    float* q, const float* mean, const float* logstd, const float* mass,
+    float step_size_host, int64_t n_chains, int64_t n_data,
+    int64_t chain_offset, int n_leapfrogs, uint64_t seed, uint32_t iteration,
+    int commit, float* acceptance_rate, float* orig_hamiltonian,
+    float* hamiltonian, float* orig_log_prob, float* log_prob, uint32_t* flags,
+    const zshmc_adapt_link* link, void* stream) {
+  return step_impl(q, mean, logstd, mass, step_size_host, n_chains, n_data,
+                   chain_offset, n_leapfrogs, seed, iteration, commit,
+                   acceptance_rate, orig_hamiltonian, hamiltonian,
+                   orig_log_prob, log_prob, flags, link, stream, 0);
+}
+
 // K transitions from one call: the launch loop runs on THIS side of the C-ABI
 // (a host language pays its per-call overhead once per run, not once per
 // transition; at BASELINE configs[0]'s size a transition is a few
-// microseconds of device time).
+// microseconds of device time), and stretches of kGraphNodes launches are
+// replayed from a hipGraph: one graph launch instead of kGraphNodes kernel
+// launches.  The nodes of a graph cannot carry a per-launch iteration in their
+// arguments, so a replayed launch takes it from a device counter that the
+// workgroup retiring last advances (fused_args.h: link_iteration).
+namespace zshmc {
+
+constexpr int kGraphNodes = 16;
+
+__global__ void set_u32_kernel(uint32_t* p, uint32_t v) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *p = v;
+}
+
+struct RunKey {
+  const void *q, *mean, *logstd, *mass, *acc, *h0, *h1, *lp0, *lp1, *flags;
+  const void *state, *stats, *workspace;
+  int64_t n_chains, n_data, chain_offset, n_chains_global;
+  uint64_t seed;
+  float step_size_host, delta, gamma, t0, kappa, mu;
+  int n_leapfrogs, kind;
+  hipStream_t stream;
+};
+
+struct RunGraph {
+  RunKey key;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  unsigned long long stamp = 0;
+};
+
+static bool run_graph_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("ZSHMC_RUN_GRAPH");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
+}  // namespace zshmc
+
 extern "C" int zshmc_hmc_diag_normal_run(
     float* q, const float* mean, const float* logstd, const float* mass,
     float step_size_host, int64_t n_chains, int64_t n_data,
@@ -636,7 +701,10 @@ extern "C" int zshmc_hmc_diag_normal_run(
   ZS_REQUIRE(!comm || link->retire_update == ZSHMC_PEND_NONE || link->stats,
              "zshmc_hmc_diag_normal_run: an update across ranks needs stats");
   const int kind = link->retire_update;
-  for (int i = 0; i < n_transitions; ++i) {
+  hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
+  int done = 0;
+  // one transition as its own launch (i = index within the run)
+  auto single = [&](int i) -> int {
     zshmc_adapt_link l = *link;
     if (i > 0) {
       l.fresh_start = 0;
@@ -650,16 +718,110 @@ extern "C" int zshmc_hmc_diag_normal_run(
     } else if (i > 0) {
       l.pending = ZSHMC_PEND_NONE;
     }
-    int rc = zshmc_hmc_diag_normal_step(
-        q, mean, logstd, mass, step_size_host, n_chains, n_data, chain_offset,
-        n_leapfrogs, seed, iteration_first + (uint32_t)i, 1, acceptance_rate,
-        orig_hamiltonian, hamiltonian, orig_log_prob, log_prob, flags, &l,
-        stream);
+    int rc = step_impl(q, mean, logstd, mass, step_size_host, n_chains, n_data,
+                       chain_offset, n_leapfrogs, seed,
+                       iteration_first + (uint32_t)i, 1, acceptance_rate,
+                       orig_hamiltonian, hamiltonian, orig_log_prob, log_prob,
+                       flags, &l, stream, 0);
     if (rc != ZSHMC_OK) return rc;
-    if (comm && l.stats) {
+    if (comm && l.stats)
       rc = zshmc_comm_all_reduce_sum(comm, l.stats, ZSHMC_STATS_WORDS, stream);
-      if (rc != ZSHMC_OK) return rc;
+    return rc;
+  };
+
+  // ---- graph replay: all chains on this GPU, a workspace for the counter,
+  // at least one graph's worth of transitions after the first ---------------
+  const bool graphable = run_graph_enabled() && !comm && link->workspace &&
+                         n_chains > 0 &&
+                         n_transitions - 1 >= kGraphNodes;
+  if (graphable) {
+    // the first transition carries what belongs to it alone (pending update,
+    // fresh start, searched step size) and completes every one-time set-up
+    // of the launch path (function attributes, occupancy query) outside the
+    // capture
+    int rc = single(0);
+    if (rc != ZSHMC_OK) return rc;
+    done = 1;
+    static RunGraph cache[4];
+    static unsigned long long clock = 0;
+    RunKey key;
+    memset(&key, 0, sizeof(key));
+    key.q = q; key.mean = mean; key.logstd = logstd; key.mass = mass;
+    key.acc = acceptance_rate; key.h0 = orig_hamiltonian; key.h1 = hamiltonian;
+    key.lp0 = orig_log_prob; key.lp1 = log_prob; key.flags = flags;
+    key.state = link->state; key.stats = link->stats;
+    key.workspace = link->workspace;
+    key.n_chains = n_chains; key.n_data = n_data;
+    key.chain_offset = chain_offset;
+    key.n_chains_global = link->n_chains_global;
+    key.seed = seed; key.step_size_host = step_size_host;
+    key.delta = link->delta; key.gamma = link->gamma; key.t0 = link->t0;
+    key.kappa = link->kappa; key.mu = link->mu;
+    key.n_leapfrogs = n_leapfrogs; key.kind = kind; key.stream = hs;
+    RunGraph* g = nullptr;
+    for (RunGraph& c : cache)
+      if (c.exec && memcmp(&c.key, &key, sizeof(key)) == 0) g = &c;
+    if (!g) {
+      g = &cache[0];
+      for (RunGraph& c : cache)
+        if (c.stamp < g->stamp) g = &c;
+      if (g->exec) hipGraphExecDestroy(g->exec);
+      if (g->graph) hipGraphDestroy(g->graph);
+      g->exec = nullptr;
+      g->graph = nullptr;
+      zshmc_adapt_link l = *link;
+      l.pending = ZSHMC_PEND_NONE;
+      l.fresh_start = 0;
+      l.used_step_size = __builtin_nanf("");
+      // captured on a stream of our own (the caller's may be the legacy
+      // default stream, which cannot be captured); the instantiated graph is
+      // launched on the caller's stream
+      static hipStream_t cap = nullptr;
+      hipError_t e = hipSuccess;
+      if (!cap) e = hipStreamCreateWithFlags(&cap, hipStreamNonBlocking);
+      if (e == hipSuccess)
+        e = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
+      if (e == hipSuccess) {
+        int crc = ZSHMC_OK;
+        for (int j = 0; j < kGraphNodes && crc == ZSHMC_OK; ++j)
+          crc = step_impl(q, mean, logstd, mass, step_size_host, n_chains,
+                          n_data, chain_offset, n_leapfrogs, seed, 0u, 1,
+                          acceptance_rate, orig_hamiltonian, hamiltonian,
+                          orig_log_prob, log_prob, flags, &l, cap, 1);
+        e = hipStreamEndCapture(cap, &g->graph);
+        if (crc != ZSHMC_OK) e = hipErrorUnknown;
+      }
+      if (e == hipSuccess)
+        e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+      if (e != hipSuccess) {
+        // no graph on this runtime / for this launch: the plain loop below
+        if (g->graph) hipGraphDestroy(g->graph);
+        g->graph = nullptr;
+        g->exec = nullptr;
+        (void)hipGetLastError();
+        g = nullptr;
+      } else {
+        g->key = key;
+      }
     }
+    if (g) {
+      g->stamp = ++clock;
+      uint32_t* counter = reinterpret_cast<uint32_t*>(
+          reinterpret_cast<char*>(link->workspace) + 16);
+      hipLaunchKernelGGL(set_u32_kernel, dim3(1), dim3(64), 0, hs, counter,
+                         iteration_first + (uint32_t)done);
+      ZS_LAUNCH_CHECK("set_u32_kernel launch");
+      while (n_transitions - done >= kGraphNodes) {
+        const hipError_t e = hipGraphLaunch(g->exec, hs);
+        if (e != hipSuccess)
+          return check_hip(e, "zshmc_hmc_diag_normal_run: hipGraphLaunch");
+        done += kGraphNodes;
+      }
+    }
+  }
+  for (int i = done; i < n_transitions; ++i) {
+    const int rc = single(i);
+    if (rc != ZSHMC_OK) return rc;
   }
   return ZSHMC_OK;
 }

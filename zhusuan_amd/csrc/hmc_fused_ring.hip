@@ -358,6 +358,10 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
 #endif
   const int64_t D = a.n_data;
   const int64_t C = a.n_chains;
+  // the iteration word of the Philox counters: the argument, or -- a launch
+  // replayed from a hipGraph -- the argument plus a device counter; pinned
+  // into an SGPR here, i.e. its load is waited for before any DMA is issued
+  const uint32_t iteration = uni32(link_iteration(a.link, a.iteration));
 
   // ---- this workgroup's chains; tickets index into them -------------------
   const int64_t nblk = gridDim.x, blk = blockIdx.x;
@@ -381,7 +385,7 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
   if (STAGE)
     for (int t = threadIdx.x; t < count; t += blockDim.x)
       s_u[t] = uniform_chain((uint32_t)(ZS_CHAIN_OF(t) + a.chain_offset),
-                             a.iteration, a.k0, a.k1);
+                             iteration, a.k0, a.k1);
 
   // ---- stage mean / sqrt(mass) in LDS (zero padding beyond n_data) --------
   if (!ZERO_MEAN || HAS_MASS || COLSTATS)
@@ -617,13 +621,13 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
       if (NCH >= 7) asm volatile("" : "+v"(group));
       if (kPair == 2 && k + 1 < NCH) {
         float za[4], zb[4];
-        normal4x2(group, group + kWave, gchain, a.iteration, kStreamMomentum,
+        normal4x2(group, group + kWave, gchain, iteration, kStreamMomentum,
                   key0, key1, za, zb);
         start_chunk(k, za[0], za[1], za[2], za[3]);
         start_chunk(k + 1, zb[0], zb[1], zb[2], zb[3]);
       } else {
         float z0, z1, z2, z3;
-        normal4(group, gchain, a.iteration, kStreamMomentum, key0, key1, z0,
+        normal4(group, gchain, iteration, kStreamMomentum, key0, key1, z0,
                 z1, z2, z3);
         start_chunk(k, z0, z1, z2, z3);
       }
@@ -720,7 +724,7 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
     if (STAGE)
       u = s_u[t_cur];
     else
-      u = uniform_chain(gchain, a.iteration, key0, key1);
+      u = uniform_chain(gchain, iteration, key0, key1);
 #endif
     const bool accept = u < acc;  // strict, hmc.py:486
 
