@@ -532,13 +532,17 @@ def test_column_statistics_are_refused_where_the_kernel_has_none(env):
                            colstats_parts=parts))
 
 
+@pytest.mark.parametrize('graph', ['0', '1'])
 @pytest.mark.parametrize('C,D', [(1000, 10), (3000, 260), (70000, 1024)])
-def test_run_many_is_bit_identical_to_a_loop_of_runs(env, C, D):
+def test_run_many_is_bit_identical_to_a_loop_of_runs(env, C, D, graph,
+                                                     monkeypatch):
     """sample_op.run_many(n): the stretches that need nothing from the host
-    are ONE zshmc_hmc_diag_normal_run call (launch loop on the C side,
-    stretches of 16 launches replayed from a hipGraph); every state word, the
-    latent and the last HMCInfo equal n single runs."""
+    are ONE zshmc_hmc_diag_normal_run call (launch loop on the C side; with
+    ZSHMC_RUN_GRAPH=1 stretches of 16 launches replayed from a hipGraph, the
+    iteration of the Philox counters in a device counter); every state word,
+    the latent and the last HMCInfo equal n single runs."""
     zs, torch = env
+    monkeypatch.setenv('ZSHMC_RUN_GRAPH', graph)
     dev = torch.device('cuda', 0)
     logstd = torch.linspace(-0.5, 0.5, D, device=dev)
     mean = torch.linspace(-1, 1, D, device=dev)
@@ -563,9 +567,9 @@ def test_run_many_is_bit_identical_to_a_loop_of_runs(env, C, D):
             return real(name, *a)
         _capi.call = spy
         try:
-            # (blocks of 40 and 48: one plain launch, then stretches of 16
-            # replayed from a hipGraph with the iteration in a device
-            # counter, then the remainder as plain launches)
+            # (blocks of 40 and 48; graph = '1': one plain launch, then
+            # stretches of 16 replayed from a hipGraph, then the remainder as
+            # plain launches)
             for n, feed in ((9, {f_ss: True, f_m: True}),
                             (40, {f_ss: True, f_m: False}),
                             (50, {f_ss: False, f_m: False})):

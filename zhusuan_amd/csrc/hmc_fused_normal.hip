@@ -644,11 +644,12 @@ extern "C" int zshmc_hmc_diag_normal_step(
 // K transitions from one call: the launch loop runs on THIS side of the C-ABI
 // (a host language pays its per-call overhead once per run, not once per
 // transition; at BASELINE configs[0]'s size a transition is a few
-// microseconds of device time), and stretches of kGraphNodes launches are
-// replayed from a hipGraph: one graph launch instead of kGraphNodes kernel
-// launches.  The nodes of a graph cannot carry a per-launch iteration in their
-// arguments, so a replayed launch takes it from a device counter that the
-// workgroup retiring last advances (fused_args.h: link_iteration).
+// microseconds of device time).  Optionally (ZSHMC_RUN_GRAPH=1) stretches of
+// kGraphNodes launches are replayed from a hipGraph: one graph launch instead
+// of kGraphNodes kernel launches.  The nodes of a graph cannot carry a
+// per-launch iteration in their arguments, so a replayed launch takes it from
+// a device counter that the workgroup retiring last advances (fused_args.h:
+// link_iteration).
 namespace zshmc {
 
 constexpr int kGraphNodes = 16;
@@ -674,12 +675,14 @@ struct RunGraph {
   unsigned long long stamp = 0;
 };
 
+// OFF unless ZSHMC_RUN_GRAPH=1 (read on every call): on ROCm 7.2 a replayed
+// kernel node costs MORE than a plain launch -- 5.85 against 4.39 us per
+// transition at 1 000 x 10, 8.74 against 4.37 at 4 096 x 64, 99.2 against 95.3
+// at 65 536 x 1 024 (profiles/r03l_run_graph.txt) -- so the plain C-side loop
+// is the default and the graph path is kept as a measured alternative.
 static bool run_graph_enabled() {
-  static const bool on = [] {
-    const char* e = getenv("ZSHMC_RUN_GRAPH");
-    return !(e && e[0] == '0');
-  }();
-  return on;
+  const char* e = getenv("ZSHMC_RUN_GRAPH");
+  return e && e[0] == '1';
 }
 
 }  // namespace zshmc
