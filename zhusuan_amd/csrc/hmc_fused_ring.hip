@@ -43,14 +43,20 @@
 
 namespace zshmc {
 
-// cache-policy suffixes of the row traffic (A/B knobs; rows are read once and
-// written once per launch, so neither side wants to stay in L2)
+// cache-policy suffixes of the row traffic (rows are read once and written
+// once per launch, so neither side wants to stay in L2)
 // ZS_LD_POL / ZS_ST_POL: 0 = default, 1 = nt, 2 = sc0 sc1, 3 = sc1
+// Round 3, with the seven-round generator (the launch sits closer to its
+// memory bound than in round 2, where no policy moved it by more than 1 %):
+// row STORES non-temporal: 0.0910 -> 0.0877..0.0891 ms without a mass vector,
+// 0.0908 -> 0.0886 with one, 0.0931 -> 0.0901 with a mean tile; `sc0 sc1`
+// stores within 0.5 % of that; nt LOADS alone 0.0883, but nt loads AND nt
+// stores together 0.1033 (profiles/r03n_cache_policy_kbench.txt).
 #ifndef ZS_LD_POL
 #define ZS_LD_POL 0
 #endif
 #ifndef ZS_ST_POL
-#define ZS_ST_POL 0
+#define ZS_ST_POL 1
 #endif
 #define ZS_POL_STR_0 ""
 #define ZS_POL_STR_1 " nt"
