@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Workload for tools/profile_native.sh: a few transitions of the two native
-dense-likelihood plans (BASELINE configs[2] and configs[4], reduced so that a
-traced run takes seconds), bracketed by marker launches (min_positive_rows_kernel) so
+dense-likelihood plans (BASELINE configs[2] and configs[4] as bench.py builds
+them -- the reference's literal dense spellings, tuned start -- reduced so that
+a traced run takes seconds), bracketed by marker launches (min_positive_rows_kernel) so
 that the kernel trace can be cut to the transitions alone.
   python tools/native_plan_trace.py [n_rows_config3] [n_chains_config5]"""
 import os
@@ -27,10 +28,10 @@ def mark():
                marker_out.data_ptr(), torch.cuda.current_stream().cuda_stream)
 
 
-orig = bench._time_native_plan
+orig = bench._time_transitions
 
 
-def traced(torch_, hmc, op, feed, n_warm, n_timed):
+def traced(torch_, hmc, op, info, feed, n_warm, n_timed, barrier):
     for _ in range(n_warm):
         op.run(feed_dict=feed, sync=False)
     hmc.check_numerics()
@@ -40,10 +41,10 @@ def traced(torch_, hmc, op, feed, n_warm, n_timed):
         op.run(feed_dict=feed, sync=False)
     mark()
     torch_.cuda.synchronize()
-    return orig(torch_, hmc, op, feed, 0, 2)
+    return orig(torch_, hmc, op, info, feed, 0, 2, barrier)
 
 
-bench._time_native_plan = traced
+bench._time_transitions = traced
 r3 = bench.extra_config3(torch, zs, dev, n_rows=n_rows)
 print('config3 slice: %.2f ms/transition, kernel %.3f ms = %.1f TFLOP/s (%.1f%%), plan %s' % (
     r3['ms_per_step'], r3['roofline']['kernel_ms'], r3['roofline']['achieved'],
