@@ -20,13 +20,21 @@ for f in glob.glob(os.path.join(out, tag + '_native_trace', '**', '*kernel_trace
     rows = list(csv.DictReader(open(f)))
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
     inside, section, sections = False, collections.OrderedDict(), []
-    for r in rows:
+    # a boundary is TWO marker launches back to back (the ESS estimator
+    # launches the same kernel, one at a time)
+    is_mark = ['min_positive_rows_kernel' in r['Kernel_Name'] for r in rows]
+    skip = False
+    for i, r in enumerate(rows):
         name = r['Kernel_Name']
-        if 'min_positive_rows_kernel' in name:
+        if skip:
+            skip = False
+            continue
+        if is_mark[i] and i + 1 < len(rows) and is_mark[i + 1]:
             if inside:
                 sections.append(section)
                 section = collections.OrderedDict()
             inside = not inside
+            skip = True
             continue
         if inside:
             # 'void (anonymous namespace)::softmax_warp_forward<...>(...)':
