@@ -42,7 +42,13 @@ def _ref(W, X, y):
 # kernel width (64/128/256) and zero-padded feature counts
 @pytest.mark.parametrize('C,N,D', [(64, 32, 64), (100, 1000, 256), (7, 45, 128),
                                    (130, 333, 20), (64, 4096, 200), (1, 1, 3),
-                                   (256, 10000, 256)])
+                                   (256, 10000, 256),
+                                   # the feature-split kernel (512 / 1024):
+                                   # ragged 32-chain blocks, ragged 32-row
+                                   # tiles, one-row and one-chain shapes
+                                   (100, 1000, 512), (33, 77, 300),
+                                   (70, 2051, 1024), (64, 333, 700), (1, 1, 257),
+                                   (31, 32, 1000)])
 def test_loglik_and_grad_match_float64_reference(env, C, N, D):
     zs, torch, dev = env
     X, y, W = _data(C, N, D, seed=C + N + D)
@@ -188,7 +194,7 @@ def test_config3_full_size_properties(env):
                                    atol=2e-5 * np.abs(g_ref).max())
 
 
-@pytest.mark.parametrize('D', [64, 256])
+@pytest.mark.parametrize('D', [64, 256, 512, 1024])
 def test_row_range_splits_match_single_pass(D):
     """n_splits > 1 (small chain counts) is the same sum in a different, fixed
     association: equal to the unsplit launch within fp32 re-association, and

@@ -448,7 +448,16 @@ class UnnormalizedMultinomialLogProb(_Function):
 # ----------------------------------------------------------------------------
 # dense-logit Bernoulli likelihood (fp32 MFMA, csrc/linear_bernoulli.hip)
 # ----------------------------------------------------------------------------
-LINEAR_BERNOULLI_WIDTHS = (64, 128, 256)
+# padded feature counts of the fused likelihood kernels: the 64-chain-block
+# kernel of csrc/linear_bernoulli.hip (both modes) up to 256, the
+# feature-split kernel of csrc/linear_bernoulli_wide.hip (Bernoulli mode) above
+MIXTURE_WIDTHS = (64, 128, 256)
+LINEAR_BERNOULLI_WIDTHS = MIXTURE_WIDTHS + (512, 1024)
+
+
+def _chain_block(width):
+    """Chains (rows of W) per workgroup of the kernel for this width."""
+    return 64 if width <= 256 else 32
 
 
 def _pad_features(t, width):
@@ -479,11 +488,12 @@ def _padded_x(X, width):
     return Xp
 
 
-def _row_splits(n_blocks_rows, n_inner, device):
-    """Fewer 64-row chain blocks than compute units: cut the inner (data row /
-    vocabulary) range so that about two workgroups land on every CU, at least
-    512 inner rows per slice."""
-    n_wg = (n_blocks_rows + 63) // 64
+def _row_splits(n_blocks_rows, n_inner, device, width=256):
+    """Fewer chain blocks (64 rows; 32 for the wide kernel) than compute
+    units: cut the inner (data row / vocabulary) range so that about two
+    workgroups land on every CU, at least 512 inner rows per slice."""
+    block = _chain_block(width)
+    n_wg = (n_blocks_rows + block - 1) // block
     cus = torch.cuda.get_device_properties(device).multi_processor_count
     if n_wg >= cus:
         return 1
@@ -506,7 +516,7 @@ class LinearBernoulliLogLik(_Function):
         ll = torch.empty(C, dtype=_F32, device=w.device)
         need_grad = ctx.needs_input_grad[0]
         gw = torch.empty_like(w2) if need_grad else None
-        splits = _row_splits(C, N, w.device)
+        splits = _row_splits(C, N, w.device, width)
         ws = torch.empty(splits * C * (width + 1), dtype=_F32,
                          device=w.device) if splits > 1 else None
         _capi.call('zshmc_linear_bernoulli_log_lik', w2.data_ptr(),
@@ -578,7 +588,7 @@ class MixtureMultinomialLogLik(_Function):
     def forward(ctx, theta, phi, x):
         require_device(theta, phi, x)
         k = theta.shape[-1]
-        width = next(v for v in LINEAR_BERNOULLI_WIDTHS if v >= k)
+        width = next(v for v in MIXTURE_WIDTHS if v >= k)
         t2 = _pad_features(theta.detach().reshape(-1, k).to(_F32), width)
         pt = _padded_phi_t(phi, width)
         xf, x_stride = _padded_counts(x)

@@ -772,6 +772,12 @@ static int launch_lb(const float* W, const float* X, const float* y, int64_t C,
   return ZSHMC_OK;
 }
 
+// csrc/linear_bernoulli_wide.hip: 256 < n_features <= 1024
+int linear_bernoulli_wide(const float* W, const float* X, const float* y,
+                          int64_t n_chains, int64_t n_rows, int64_t n_features,
+                          float* ll, float* gW, int n_splits, float* workspace,
+                          hipStream_t s);
+
 }  // namespace zshmc
 
 using namespace zshmc;
@@ -786,9 +792,10 @@ extern "C" int zshmc_linear_bernoulli_log_lik(const float* W, const float* X,
   ZS_REQUIRE(W && X && y && log_lik, "zshmc_linear_bernoulli_log_lik: null pointer");
   ZS_REQUIRE(n_chains > 0 && n_rows > 0,
              "zshmc_linear_bernoulli_log_lik: bad shape");
-  ZS_REQUIRE(n_features == 64 || n_features == 128 || n_features == 256,
-             "zshmc_linear_bernoulli_log_lik: n_features must be 64, 128 or 256 "
-             "(zero-pad W and X), got %lld", (long long)n_features);
+  ZS_REQUIRE(n_features == 64 || n_features == 128 || n_features == 256 ||
+                 n_features == 512 || n_features == 1024,
+             "zshmc_linear_bernoulli_log_lik: n_features must be 64, 128, 256, "
+             "512 or 1024 (zero-pad W and X), got %lld", (long long)n_features);
   ZS_REQUIRE((reinterpret_cast<uintptr_t>(W) & 15) == 0 &&
                  (reinterpret_cast<uintptr_t>(X) & 15) == 0 &&
                  (!grad_w || (reinterpret_cast<uintptr_t>(grad_w) & 3) == 0),
@@ -797,6 +804,12 @@ extern "C" int zshmc_linear_bernoulli_log_lik(const float* W, const float* X,
              "zshmc_linear_bernoulli_log_lik: 1 <= n_splits <= 64 and a "
              "workspace of n_splits*n_chains*(n_features+1) floats when > 1");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (n_features > 256) {
+    ZS_REQUIRE(!grad_w || (reinterpret_cast<uintptr_t>(grad_w) & 15) == 0,
+               "zshmc_linear_bernoulli_log_lik: grad_w must be 16-byte aligned");
+    return linear_bernoulli_wide(W, X, y, n_chains, n_rows, n_features, log_lik,
+                                 grad_w, n_splits, workspace, s);
+  }
   switch (n_features) {
     case 64:
       return launch_lb<64>(W, X, y, n_chains, n_rows, 64, 64, log_lik, grad_w, s,

@@ -1,0 +1,369 @@
+// The dense-logit Bernoulli log-likelihood + gradient of
+// csrc/linear_bernoulli.hip for WIDE rows: 256 < D <= 1024 features (padded to
+// 512 or 1024).  Same mathematics (reference
+// zhusuan/distributions/univariate.py:398-403 summed by group_ndims = 1, the
+// gradient tf.gradients yields through the matmul, hmc.py:430-432), same fp32
+// matrix cores, different decomposition -- at D = 1024 a 64-chain block of W
+// is 256 KB and its gradient accumulators another 256 KB: neither fits what a
+// workgroup of the 256-wide kernel keeps in registers.
+//
+// A workgroup owns 32 chains and streams X in 32-row tiles; its 4 waves split
+// the FEATURES, wave f owning the quarter [f*D/4, (f+1)*D/4) for both GEMMs:
+//   W[32 chains, quarter]    in registers for the whole kernel (D/8 VGPRs, the
+//                            B operand of phase 1)
+//   X[32 rows, quarter]      the wave's PRIVATE slice of the LDS tile, moved by
+//                            its own LDS-DMA instructions: no barrier guards X
+//   G[32 chains, quarter]    the gradient accumulators (D/8 registers)
+//   phase 1   S_f[n, i] = sum_{d in quarter} X[n,d] W[i,d]: partial logits,
+//             D/8 MFMAs (v_mfma_f32_32x32x2_f32)
+//   exchange  the four partials meet in LDS (16 KB); wave f sums register
+//             group f (rows 8f .. 8f+7 of the tile, fixed order) and applies
+//             the Bernoulli residual y - sigmoid(l) and the log-likelihood
+//             term to its 4 elements per lane; the residuals go back to LDS
+//             (4 KB)
+//   phase 3   G[i, d] += sum_n R[n, i] X[n, d] over the 32 rows and the wave's
+//             quarter: D/8 MFMAs, A = the residuals from LDS, B = the wave's
+//             X slice.  Rows 8g .. 8g+7 of the NEXT tile are DMA'd into the
+//             slice as soon as row group g has been consumed (the slice is
+//             single-buffered: 4 x 32 x (D/4 + 4) floats = 130 KB at D = 1024
+//             leaves no room for a second one).
+// Two barriers per tile, both for the 20 KB exchange.  Roofline: MFMA,
+// 4*N*D*C flop per call as in the narrow kernel.
+#include "common.h"
+
+namespace zshmc {
+
+typedef float w4 __attribute__((ext_vector_type(4)));
+typedef float w16 __attribute__((ext_vector_type(16)));
+
+constexpr int kWC = 32;  // chains per workgroup
+constexpr int kWR = 32;  // data rows per tile
+
+// global -> LDS, 16 or 8 (= 2 x 4) bytes per lane, LDS dest = dst + lane*BYTES
+template <int BYTES>
+__device__ __forceinline__ void wide_dma_row(const float* src, uint32_t dst,
+                                             uint32_t lane) {
+  static_assert(BYTES == 16 || BYTES == 8, "a slice row is 1 KB or 512 B");
+  if constexpr (BYTES == 16) {
+    const uint32_t voff = lane * 16u;
+    asm volatile(
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %0, %1"
+        :
+        : "v"(voff), "s"(src), "s"(dst)
+        : "memory");
+  } else {
+    const uint32_t voff = lane * 4u;
+    asm volatile(
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dword %0, %1\n\t"
+        "global_load_lds_dword %0, %1 offset:256"
+        :
+        : "v"(voff), "s"(src), "s"(dst)
+        : "memory");
+  }
+}
+
+template <int D, bool GRAD>
+__global__ __launch_bounds__(256, 1) void linear_bernoulli_wide_kernel(
+    const float* __restrict__ W, const float* __restrict__ X,
+    const float* __restrict__ y, int64_t C, int64_t N, int64_t ldw,
+    int64_t ldx, float* __restrict__ ll, float* __restrict__ gW) {
+  static_assert(D == 512 || D == 1024, "padded widths of the wide kernel");
+  constexpr int FQ = D / 4;    // features per wave
+  constexpr int LDQ = FQ + 4;  // padded LDS row: conflict-free b128 reads
+  constexpr int KK = FQ / 8;   // phase-1 steps of 4 MFMAs (8 features)
+  constexpr int NT = FQ / 32;  // 32-wide feature blocks = accumulators (4, 8)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* __restrict__ sX = reinterpret_cast<float*>(smem);  // [4][kWR][LDQ]
+  float* __restrict__ sY = sX + 4 * kWR * LDQ;              // [2][kWR]
+  float* __restrict__ sP = sY + 2 * kWR;                    // [4][4][64][4]
+  float* __restrict__ sR = sP + 4 * 4 * 64 * 4;             // [4][64][4]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int f = __builtin_amdgcn_readfirstlane(tid >> 6);  // feature quarter
+  const int lo = lane & 31, hi = lane >> 5;
+  const int64_t c0 = (int64_t)blockIdx.x * kWC;
+  const int n_valid = (int)(C - c0 < kWC ? C - c0 : kWC);
+
+  // ---- this wave's W slice -> registers (B operand: k-slot = lane half) ----
+  float wreg[KK * 4];
+  {
+    const int64_t cr = c0 + (lo < n_valid ? lo : n_valid - 1);
+    const float* __restrict__ wrow = W + cr * ldw + f * FQ + hi * 4;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      const w4 v = *reinterpret_cast<const w4*>(wrow + kk * 8);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) wreg[kk * 4 + m] = v[m];
+    }
+  }
+
+  // ---- this wave's X slice: global -> LDS by DMA, one row per instruction --
+  // (hipcc does not count these loads: the explicit `s_waitcnt vmcnt(0)` at
+  // the end of a tile lands them)
+  float* __restrict__ sXw = sX + f * kWR * LDQ;
+  const uint32_t dst_wave = __builtin_amdgcn_readfirstlane(
+      (uint32_t)reinterpret_cast<uintptr_t>(sXw));
+  const int ldx32 = (int)ldx;
+  struct TileSrc {
+    const float* base;  // &X[n0, f*FQ]
+    int last;           // rows past N re-read row N-1 (masked in the residual)
+  };
+  auto tile_src = [&](int64_t n0) {
+    const int64_t left = N - 1 - n0;
+    return TileSrc{X + n0 * ldx + f * FQ,
+                   (int)(left < kWR - 1 ? left : kWR - 1)};
+  };
+  auto dma_row = [&](const TileSrc& t, int row) {
+    const int r = row < t.last ? row : t.last;
+    wide_dma_row<FQ / 16>(t.base + r * ldx32,
+                          dst_wave + (uint32_t)(row * LDQ * 4), (uint32_t)lane);
+  };
+
+  w16 G[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) G[t][r] = 0.f;
+  // per tile in float32 (4 terms), tile sums in float64 (csrc/linear_bernoulli.hip)
+  double ll_lane = 0.0;
+
+  // gridDim.y > 1: contiguous ranges of whole tiles, PARTIAL sums out
+  const int64_t n_tiles_all = (N + kWR - 1) / kWR;
+  const int64_t tiles_per_split = (n_tiles_all + gridDim.y - 1) / gridDim.y;
+  const int64_t tile_begin = (int64_t)blockIdx.y * tiles_per_split;
+  const int64_t n_tiles = tile_begin + tiles_per_split < n_tiles_all
+                              ? tile_begin + tiles_per_split
+                              : n_tiles_all;
+  if (gridDim.y > 1) {
+    ll += (int64_t)blockIdx.y * C;
+    if (GRAD) gW += (int64_t)blockIdx.y * C * ldw;
+  }
+  if (tile_begin < n_tiles) {
+    const TileSrc t0 = tile_src(tile_begin * kWR);
+#pragma unroll
+    for (int j = 0; j < kWR; ++j) dma_row(t0, j);
+  }
+  if (tid < kWR) {
+    const int64_t nr = tile_begin * kWR + tid;
+    sY[tid] = nr < N ? y[nr] : 0.f;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  float yr = 0.f;
+  for (int64_t tile = tile_begin; tile < n_tiles; ++tile) {
+    const int buf = (int)((tile - tile_begin) & 1);  // sY slot
+    const bool more = tile + 1 < n_tiles;
+    const int64_t n_next = (more ? tile + 1 : tile) * kWR;
+    const TileSrc tnext = tile_src(n_next);
+    if (tid < kWR) {
+      const int64_t nr = n_next + tid;
+      yr = nr < N ? y[nr] : 0.f;
+    }
+
+    // ---- phase 1: partial logits over the wave's feature quarter -----------
+    w16 S;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) S[r] = 0.f;
+    {
+      const float* __restrict__ arow = sXw + lo * LDQ + hi * 4;
+      w4 av = *reinterpret_cast<const w4*>(arow);
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        w4 an = av;
+        if (kk + 1 < KK) an = *reinterpret_cast<const w4*>(arow + (kk + 1) * 8);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          S = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], wreg[kk * 4 + m], S, 0,
+                                                   0, 0);
+        av = an;
+      }
+    }
+    // lane holds chain lo, rows (r&3) + 8*(r>>2) + 4*hi: register group g =
+    // r>>2 is rows 8g .. 8g+7
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<w4*>(sP + ((f * 4 + g) * 64 + lane) * 4) =
+          w4{S[g * 4], S[g * 4 + 1], S[g * 4 + 2], S[g * 4 + 3]};
+    if (!GRAD && more) {
+      // nothing reads the slice again: the next tile may come in now
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int j = 0; j < kWR; ++j) dma_row(tnext, j);
+    }
+    __syncthreads();  // the four partials are in LDS
+
+    // ---- residual of register group f (fixed summation order) --------------
+    // Bernoulli._log_prob (univariate.py:398-403):
+    //   l*y - max(l,0) - log1p(exp(-|l|));   d/dl = y - sigmoid(l)
+    {
+      w4 s = *reinterpret_cast<const w4*>(sP + ((0 * 4 + f) * 64 + lane) * 4);
+#pragma unroll
+      for (int w = 1; w < 4; ++w)
+        s += *reinterpret_cast<const w4*>(sP + ((w * 4 + f) * 64 + lane) * 4);
+      const int rows_left =
+          (int)((N - tile * kWR) < kWR ? (N - tile * kWR) : kWR);
+      float ll_tile = 0.f;
+      w4 res;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int nl = j + 8 * f + 4 * hi;
+        const bool valid = nl < rows_left;
+        const float sv = s[j];
+        const float yv = sY[buf * kWR + nl];
+        const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * fabsf(sv));
+        const float t1 = 1.0f + e;
+        const float inv = __builtin_amdgcn_rcpf(t1);
+        const float sig = sv >= 0.f ? inv : 1.0f - inv;
+        const float lp = sv * yv - fmaxf(sv, 0.f) -
+                         0.6931471805599453f * __builtin_amdgcn_logf(t1);
+        res[j] = valid ? yv - sig : 0.f;
+        ll_tile += valid ? lp : 0.f;
+      }
+      ll_lane += (double)ll_tile;
+      if (GRAD) *reinterpret_cast<w4*>(sR + (f * 64 + lane) * 4) = res;
+    }
+    __syncthreads();  // residuals published; sP free for the next tile
+
+    if (GRAD) {
+      // ---- phase 3: G[i, d] += sum_n R[n, i] X[n, d], d in the quarter -----
+      // accumulator t: features (t>>2)*128 + lo*4 + (t&3) of the quarter (a
+      // lane reads 16 contiguous bytes, a half-wave 512 contiguous bytes)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const w4 rs = *reinterpret_cast<const w4*>(sR + (g * 64 + lane) * 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float* __restrict__ xr = sXw + (q + 8 * g + 4 * hi) * LDQ + lo * 4;
+#pragma unroll
+          for (int t2 = 0; t2 < NT / 4; ++t2) {
+            const w4 xv = *reinterpret_cast<const w4*>(xr + t2 * 128);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+              G[t2 * 4 + m] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                  rs[q], xv[m], G[t2 * 4 + m], 0, 0, 0);
+          }
+        }
+        if (more) {
+          // rows 8g .. 8g+7 are consumed: their LDS reads have returned
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int j = 0; j < 8; ++j) dma_row(tnext, 8 * g + j);
+        }
+      }
+    }
+    if (tid < kWR) sY[(buf ^ 1) * kWR + tid] = yr;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the slice has landed
+  }
+
+  // ---- epilogue -------------------------------------------------------------
+  // G[t][r]: chain = c0 + (r&3) + 8*(r>>2) + 4*hi,
+  //          feature = f*FQ + (t>>2)*128 + lo*4 + (t&3)
+  if (GRAD) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int pos = (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (pos < n_valid) {
+        float* __restrict__ grow = gW + (c0 + pos) * ldw + f * FQ + lo * 4;
+#pragma unroll
+        for (int t2 = 0; t2 < NT / 4; ++t2)
+          *reinterpret_cast<w4*>(grow + t2 * 128) =
+              w4{G[t2 * 4][r], G[t2 * 4 + 1][r], G[t2 * 4 + 2][r],
+                 G[t2 * 4 + 3][r]};
+      }
+    }
+  }
+  // ll of chain lo: this lane's 4 rows per tile + lane^32's + the other three
+  // waves' (through the exchange area, now idle)
+  const double ll_half = ll_lane + __shfl_xor(ll_lane, 32, 64);
+  __syncthreads();
+  double* __restrict__ sLd = reinterpret_cast<double*>(sP);  // [4][32]
+  if (hi == 0) sLd[f * 32 + lo] = ll_half;
+  __syncthreads();
+  if (f == 0 && hi == 0 && lo < n_valid)
+    ll[c0 + lo] =
+        (float)(((sLd[lo] + sLd[32 + lo]) + sLd[64 + lo]) + sLd[96 + lo]);
+}
+
+// out[c(, f)] = sum over the S row-range partials written by a split launch
+__global__ __launch_bounds__(256) void lb_wide_reduce_splits_kernel(
+    const float* __restrict__ ws, int64_t C, int64_t ldw, int S,
+    float* __restrict__ ll, float* __restrict__ gW) {
+  const int64_t n_ll = C, n_g = gW ? C * ldw : 0;
+  const float* __restrict__ gpart = ws + (int64_t)S * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_ll + n_g;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float acc = 0.f;
+    if (i < n_ll) {
+      for (int s = 0; s < S; ++s) acc += ws[(int64_t)s * C + i];
+      ll[i] = acc;
+    } else {
+      const int64_t j = i - n_ll;
+      for (int s = 0; s < S; ++s) acc += gpart[(int64_t)s * C * ldw + j];
+      gW[j] = acc;
+    }
+  }
+}
+
+template <int D>
+static int launch_wide(const float* W, const float* X, const float* y,
+                       int64_t C, int64_t N, float* ll, float* gW,
+                       hipStream_t s, int n_splits, float* workspace) {
+  constexpr int LDQ = D / 4 + 4;
+  const size_t lds =
+      (size_t)(4 * kWR * LDQ + 2 * kWR + 4 * 4 * 64 * 4 + 4 * 64 * 4) *
+      sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(
+        reinterpret_cast<const void*>(linear_bernoulli_wide_kernel<D, true>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(
+          reinterpret_cast<const void*>(linear_bernoulli_wide_kernel<D, false>),
+          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(LDS)");
+    attr = true;
+  }
+  const int S = (n_splits > 1 && workspace) ? n_splits : 1;
+  float* ll_out = S > 1 ? workspace : ll;
+  float* g_out = S > 1 ? (gW ? workspace + (int64_t)S * C : nullptr) : gW;
+  const dim3 grid((unsigned)((C + kWC - 1) / kWC), S);
+  if (gW)
+    hipLaunchKernelGGL((linear_bernoulli_wide_kernel<D, true>), grid, dim3(256),
+                       lds, s, W, X, y, C, N, (int64_t)D, (int64_t)D, ll_out,
+                       g_out);
+  else
+    hipLaunchKernelGGL((linear_bernoulli_wide_kernel<D, false>), grid,
+                       dim3(256), lds, s, W, X, y, C, N, (int64_t)D, (int64_t)D,
+                       ll_out, g_out);
+  ZS_LAUNCH_CHECK("linear_bernoulli_wide_kernel launch");
+  if (S > 1) {
+    const int64_t n = C + (gW ? C * D : 0);
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(lb_wide_reduce_splits_kernel, dim3((int)blocks),
+                       dim3(256), 0, s, workspace, C, (int64_t)D, S, ll, gW);
+    ZS_LAUNCH_CHECK("lb_wide_reduce_splits_kernel launch");
+  }
+  return ZSHMC_OK;
+}
+
+// n_features 512 or 1024 (called by zshmc_linear_bernoulli_log_lik)
+int linear_bernoulli_wide(const float* W, const float* X, const float* y,
+                          int64_t n_chains, int64_t n_rows, int64_t n_features,
+                          float* ll, float* gW, int n_splits, float* workspace,
+                          hipStream_t s) {
+  if (n_features == 512)
+    return launch_wide<512>(W, X, y, n_chains, n_rows, ll, gW, s, n_splits,
+                            workspace);
+  return launch_wide<1024>(W, X, y, n_chains, n_rows, ll, gW, s, n_splits,
+                           workspace);
+}
+
+}  // namespace zshmc

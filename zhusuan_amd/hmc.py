@@ -1206,7 +1206,7 @@ class _DenseLikelihoodPlan(_PlanBase):
             n_inner = self.inner.shape[0]
             if C % self.obs.shape[0] != 0:
                 raise ValueError("counts rows do not divide the chain rows")
-        self.splits = ops._row_splits(C, n_inner, self.device)
+        self.splits = ops._row_splits(C, n_inner, self.device, self.width)
         need = self.splits * C * (self.width + 1) if self.splits > 1 else 0
         if need and (self._ws is None or self._ws.numel() < need):
             self._ws = torch.empty(need, dtype=torch.float32,
