@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ZSHMC_VERSION 300 /* 0.3.0 */
+#define ZSHMC_VERSION 301 /* 0.3.1 */
 
 /* status codes */
 #define ZSHMC_OK 0
@@ -315,6 +315,13 @@ int zshmc_momentum(float* p, const float* mass, int64_t n_chains,
                    int64_t n_data, int64_t chain_offset, uint64_t seed,
                    uint32_t iteration, uint32_t latent_id, float* kinetic,
                    void* stream);
+/* The same draw into the leading n_data columns of rows that are row_stride
+ * floats apart (a latent's columns of a plan's packed momentum; counters are
+ * those of the contiguous form, so both lay down the same numbers). */
+int zshmc_momentum_rows(float* p, int64_t row_stride, const float* mass,
+                        int64_t n_chains, int64_t n_data, int64_t chain_offset,
+                        uint64_t seed, uint32_t iteration, uint32_t latent_id,
+                        float* kinetic, void* stream);
 /* p += kick_scale*eps*grad ; then q += drift_scale*eps*p/mass
  * (hmc.py:38-43 with the schedule of :352-364; drift_scale==0 skips q).
  * kinetic[c] += 0.5*sum_d p_new^2/mass when kinetic != NULL. */
@@ -335,6 +342,13 @@ int zshmc_mh_accept(const float* log_prob_old, const float* log_prob_new,
 /* q[c,:] = accept[c] ? q_new[c,:] : q[c,:]   (hmc.py:488-497) */
 int zshmc_select_rows(float* q, const float* q_new, const uint8_t* accept,
                       int64_t n_chains, int64_t n_data, void* stream);
+/* dst[r, 0:n_cols] = src[r, 0:n_cols] for the rows with accept[r] != 0 (all
+ * rows when accept == NULL); rows dst_stride / src_stride floats apart: a
+ * latent's own tensor on one side, its columns of a packed state on the
+ * other (several latents, or a row padded to a multiple of 4). */
+int zshmc_copy_rows(float* dst, int64_t dst_stride, const float* src,
+                    int64_t src_stride, const uint8_t* accept, int64_t n_rows,
+                    int64_t n_cols, void* stream);
 
 /* ------------------------------------------------------------------------
  * One trip of HMC._leapfrog (hmc.py:348-372, :38-43) for the NATIVE plans of
@@ -357,9 +371,14 @@ int zshmc_select_rows(float* q, const float* q_new, const uint8_t* accept,
  * (1 - T) log prior + T (log prior + log lik) = log prior + T log lik
  * (evaluation.py:101-103).
  * grad_lik [n_chains, grad_stride] or NULL (= 0); prior_mean / prior_logstd
- * are [rows, n_data] used with row period (r % rows) -- 1 row: shared by all
- * chains; n_docs rows: lntm's per-document eta_mean.  n_data a multiple of 4,
- * <= 1024; all buffers 16-byte aligned.
+ * are [rows, row_stride] used with row period (r % rows) -- 1 row: shared by
+ * all chains; n_docs rows: lntm's per-document eta_mean.  Rows of q, p and the
+ * prior are row_stride floats apart (a multiple of 4, <= 1024; mass has
+ * row_stride entries); the n_data leading columns are the latent -- several
+ * Normal-prior latents packed side by side, or one whose size is not a
+ * multiple of 4 -- and the columns behind them are zero padding (kept zero by
+ * the caller) that enters neither the prior nor the softmax.  All buffers
+ * 16-byte aligned.
  */
 int zshmc_model_kick_drift(
     float* q, float* p, const float* grad_lik, int64_t grad_stride,
@@ -367,8 +386,8 @@ int zshmc_model_kick_drift(
     const float* prior_mean, int64_t mean_rows, const float* prior_logstd,
     int64_t logstd_rows, const float* mass, const float* step_size_dev,
     float step_size_host, float kick_scale, float drift_scale,
-    float lik_scale, int64_t n_chains, int64_t n_data, const float* ll_in,
-    float* lp_out, float* kinetic, void* stream);
+    float lik_scale, int64_t n_chains, int64_t n_data, int64_t row_stride,
+    const float* ll_in, float* lp_out, float* kinetic, void* stream);
 
 /* ------------------------------------------------------------------------
  * Stand-alone distribution ops (forward, analytic backward, sampling).
@@ -433,8 +452,11 @@ int zshmc_unnormalized_multinomial_log_prob_grad(
  * tf.gradients (hmc.py:430-432) computes through them; the [C, N] logits are
  * never materialised.  W [n_chains, n_features], X [n_rows, n_features]
  * row-major, 16-byte aligned; y [n_rows] float (0/1); n_features in
- * {64, 128, 256} (zero-pad otherwise); grad_w may be NULL.
- * n_splits > 1 cuts the n_rows range into that many slices per 64-chain block
+ * {64, 128, 256, 512, 1024} (zero-pad otherwise; up to 256: 64-chain blocks
+ * with W in registers, csrc/linear_bernoulli.hip; 512 and 1024: 32-chain
+ * blocks whose four waves split the features,
+ * csrc/linear_bernoulli_wide.hip); grad_w may be NULL (16-byte aligned).
+ * n_splits > 1 cuts the n_rows range into that many slices per chain block
  * (for chain counts that would otherwise leave compute units idle); the
  * partial sums go to `workspace` (n_splits * n_chains * (n_features + 1)
  * floats) and are added in a fixed order, so the result is deterministic.

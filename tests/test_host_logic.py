@@ -310,14 +310,14 @@ def test_native_plan_reprobes_the_model_on_a_meta_latent(monkeypatch):
     assert plan is not None and plan.kind == 'mixture_multinomial'
     assert seen == ['cpu']          # the build-time analysis: real latent
     del seen[:]
-    mean, (how, spread), phi_seen, x_seen = plan.probe()
+    ((mean, (how, spread)),), (phi_seen,), x_seen = plan.probe()
     assert seen == ['meta']
     assert mean is eta_mean.value and spread is eta_logstd and how == 'logstd'
     assert phi_seen is phi and x_seen is x
     # a newly fed prior mean is what the next probe returns
     new_mean = torch.ones(n_docs, K)
     eta_mean._value = new_mean
-    assert plan.probe()[0] is new_mean and seen == ['meta', 'meta']
+    assert plan.probe()[0][0][0] is new_mean and seen == ['meta', 'meta']
 
     # a model function that mixes the latent with device tensors cannot run
     # on a meta latent: it is evaluated on the latent itself from then on

@@ -186,3 +186,67 @@ def test_odd_calls_on_symbols_compute_on_the_plain_tensor():
     assert not isinstance(r, sym.Sym) and r.shape == (8, 6)
     z = s.reshape(3, 16)                    # last axis changes: plain tensor
     assert not isinstance(z, sym.Sym)
+
+
+def test_sums_of_linear_terms_and_a_bias_lower_to_one_fused_operand():
+    """logits = w1 @ X1^T + w2 @ X2^T + b (every spelling of `+` and of the
+    bias column) -> one LinearLogits whose terms are the latents themselves."""
+    C, N = 6, 40
+    w1, w2 = _latent(C, 8), _latent(C, 3, seed=3)
+    b1, b0 = _latent(C, 1, seed=4), _latent(C, seed=5)
+    X1, X2 = _latent(N, 8, seed=1), _latent(N, 3, seed=2)
+    s1, s2, sb1, sb0 = (sym.wrap_latent(t) for t in (w1, w2, b1, b0))
+    cases = [
+        (s1 @ X1.t() + sb1, [(w1, X1, False), (b1, None, False)]),
+        (sb1 + s1 @ X1.t(), [(b1, None, False), (w1, X1, False)]),
+        (torch.add(s1 @ X1.t(), sb0[:, None]),
+         [(w1, X1, False), (b0, None, True)]),
+        ((s1 @ X1.t()).add(sb0.unsqueeze(-1)),
+         [(w1, X1, False), (b0, None, True)]),
+        (s1 @ X1.t() + sb0[..., None], [(w1, X1, False), (b0, None, True)]),
+        (s1 @ X1.t() + s2 @ X2.t() + torch.unsqueeze(sb0, 1),
+         [(w1, X1, False), (w2, X2, False), (b0, None, True)]),
+    ]
+    for logits, want in cases:
+        assert isinstance(logits, sym.Sym) and logits.shape == (C, N)
+        lazy = sym.lower_bernoulli_logits(logits)
+        assert isinstance(lazy, zs.distributions.LinearLogits)
+        assert len(lazy.terms) == len(want)
+        for (w, X, sc), (w_w, X_w, sc_w) in zip(lazy.terms, want):
+            assert w is w_w and sc == sc_w
+            assert (X is None) == (X_w is None)
+            if X is not None:
+                assert X.data_ptr() == X_w.data_ptr() and X.shape == X_w.shape
+        dense = sum((w.unsqueeze(-1) if sc else w) if X is None else w @ X.t()
+                    for w, X, sc in want)
+        torch.testing.assert_close(logits.force(), dense)
+        torch.testing.assert_close(lazy.dense(), dense)
+        assert lazy.n_rows == N and tuple(lazy.shape) == (C, N)
+        assert lazy.n_features == sum(1 if X is None else X.shape[1]
+                                      for _, X, _ in want)
+    # the explicit form
+    lazy = zs.linear_logits(w1, X1, bias=b0)
+    assert lazy.terms[1][0] is b0 and lazy.terms[1][2] is True
+    lazy = zs.linear_logits(w1, X1, bias=b1)
+    assert lazy.terms[1][0] is b1 and lazy.terms[1][2] is False
+    with pytest.raises(ValueError):
+        zs.linear_logits(w1, X1, bias=_latent(C, 2))
+
+
+@pytest.mark.parametrize('near_miss', [
+    lambda s, b, X: s @ X.t() + 1.0,                   # constant offset
+    lambda s, b, X: s @ X.t() + torch.ones(40),        # constant row
+    lambda s, b, X: torch.add(s @ X.t(), b[:, None], alpha=2.0),
+    lambda s, b, X: s @ X.t() + s @ X.t(),             # the same latent twice
+    lambda s, b, X: s @ X.t() - b[:, None],
+    lambda s, b, X: b[:, None] + b[:, None],           # no design matrix
+    lambda s, b, X: s @ X.t() + b[None, :6].t(),       # not the bias column
+])
+def test_sums_outside_the_spelling_compute_on_the_plain_tensor(near_miss):
+    w, b = _latent(6, 8), _latent(6, seed=4)
+    X = _latent(40, 8, seed=1)
+    want = near_miss(w, b, X)
+    out = near_miss(sym.wrap_latent(w), sym.wrap_latent(b), X)
+    got = sym.lower_bernoulli_logits(out) if isinstance(out, sym.Sym) else out
+    assert not isinstance(got, (sym.Sym, zs.distributions.LinearLogits))
+    torch.testing.assert_close(got, want, rtol=0, atol=0)

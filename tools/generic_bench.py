@@ -153,7 +153,7 @@ for (Cc, Dm, width, soft) in ((32768, 256, 256, 0), (1280000, 128, 128, 1)):
     ms = time_ms(lambda: _capi.call(
         'zshmc_model_kick_drift', qq.data_ptr(), pp.data_ptr(), gg.data_ptr(),
         width, None if op is None else op.data_ptr(), width, soft, pm.data_ptr(), 1,
-        pl.data_ptr(), 1, None, None, 1e-3, 1.0, 1.0, 1.0, Cc, Dm, llv.data_ptr(),
+        pl.data_ptr(), 1, None, None, 1e-3, 1.0, 1.0, 1.0, Cc, Dm, Dm, llv.data_ptr(),
         lpo.data_ptr(), None, s))
     b = (5 + (3 if soft else 0)) * 4      # rw q, rw p, r grad (+ r theta, r theta, w theta)
     print('model_kick_drift %s [%d, %d]   %7.3f ms  %6.0f GB/s (%d B/elem)' % (

@@ -117,6 +117,9 @@ PROTOTYPES = {
     'zshmc_momentum': (c_int, [
         _p, _p, c_int64, c_int64, c_int64, c_uint64, c_uint32, c_uint32, _p,
         _p]),
+    'zshmc_momentum_rows': (c_int, [
+        _p, c_int64, _p, c_int64, c_int64, c_int64, c_uint64, c_uint32,
+        c_uint32, _p, _p]),
     'zshmc_kick_drift': (c_int, [
         _p, _p, _p, _p, _p, c_float, c_float, c_float, c_int64, c_int64, _p,
         _p]),
@@ -124,10 +127,12 @@ PROTOTYPES = {
         _p, _p, _p, _p, c_int64, c_int64, c_uint64, c_uint32, _p, _p, _p, _p,
         _p, _p, _p, _p]),
     'zshmc_select_rows': (c_int, [_p, _p, _p, c_int64, c_int64, _p]),
+    'zshmc_copy_rows': (c_int, [
+        _p, c_int64, _p, c_int64, _p, c_int64, c_int64, _p]),
     'zshmc_model_kick_drift': (c_int, [
         _p, _p, _p, c_int64, _p, c_int64, c_int, _p, c_int64, _p, c_int64, _p,
-        _p, c_float, c_float, c_float, c_float, c_int64, c_int64, _p, _p, _p,
-        _p]),
+        _p, c_float, c_float, c_float, c_float, c_int64, c_int64, c_int64, _p,
+        _p, _p, _p]),
     'zshmc_normal_log_prob': (c_int, [
         _p, _p, _p, _p, c_int64, c_int64, c_int, c_int, c_int, _p]),
     'zshmc_normal_log_prob_grad': (c_int, [

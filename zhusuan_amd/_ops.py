@@ -284,6 +284,7 @@ def clear_caches():
     to release those references (e.g. a 1 GB design matrix) when a model is
     done."""
     _x_cache.clear()
+    _design_cache.clear()
     _phi_cache.clear()
     _counts_cache.clear()
     _csr_cache.clear()
@@ -486,6 +487,35 @@ def _padded_x(X, width):
     # X's address, so (address, version) identifies the contents
     _x_cache['x'] = (key, Xp, X)
     return Xp
+
+
+_design_cache = {}
+
+
+def packed_design(blocks, n_rows, device, width=None):
+    """The design matrices of a multi-term linear_logits side by side,
+    [n_rows, sum D_k] float32 (a column of ones where a block is None: the
+    bias), zero-padded to `width` columns if given; cached while the SAME
+    tensors (storage, version) are passed again."""
+    key = tuple(None if X is None else
+                (X.data_ptr(), tuple(X.shape), tuple(X.stride()), X._version)
+                for X in blocks) + (width,)
+    hit = _design_cache.get('x')
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    total = sum(1 if X is None else int(X.shape[-1]) for X in blocks)
+    out = torch.zeros(n_rows, width or total, dtype=_F32, device=device)
+    off = 0
+    for X in blocks:
+        d = 1 if X is None else int(X.shape[-1])
+        if X is None:
+            out[:, off] = 1.0
+        else:
+            out[:, off:off + d] = X.detach().to(_F32)
+        off += d
+    # (the entry holds the blocks: their addresses cannot be reused meanwhile)
+    _design_cache['x'] = (key, out, list(blocks))
+    return out
 
 
 def _row_splits(n_blocks_rows, n_inner, device, width=256):

@@ -7,6 +7,11 @@ The reference writes its dense-likelihood models with ordinary graph ops:
     x ~ UnnormalizedMultinomial(tf.log(tf.matmul(tf.nn.softmax(eta), phi)))
                                         (examples/topic_models/lntm_mcem.py:39-46)
 
+and the usual extensions of the first one -- a bias, several weight blocks --
+
+    logits = tf.matmul(w, X, transpose_b=True) + b
+    logits = tf.matmul(w1, X1, transpose_b=True) + tf.matmul(w2, X2, ...)
+
 TensorFlow builds a graph first, so nothing is materialised before the
 executor runs.  torch is eager: `w @ X.T` at BASELINE configs[2] is a
 [32 768, 10^6] tensor (131 GB) before any distribution sees it.  So the
@@ -16,6 +21,7 @@ those two spellings symbolic
 
     latent -> softmax(., -1) -> reshape(leading axes) -> matmul(., constant)
            -> reshape(leading axes) -> log
+    latent @ constant + latent @ constant + latent[..., None] ...
 
 and executes everything else on the real tensors (the wrapper is forced --
 replaced by the value of its expression -- the moment an op outside the
@@ -64,6 +70,8 @@ _SOFTMAX = {torch.softmax, torch.nn.functional.softmax, _T.softmax}
 _MATMUL = {torch.matmul, _T.matmul, _T.__matmul__, torch.mm, _T.mm}
 _RESHAPE = {torch.reshape, _T.reshape, _T.view}
 _LOG = {torch.log, _T.log}
+_ADD = {torch.add, _T.add, _T.__add__, _T.__radd__}
+_UNSQUEEZE = {torch.unsqueeze, _T.unsqueeze}
 
 
 class Sym(torch.Tensor):
@@ -73,6 +81,9 @@ class Sym(torch.Tensor):
          ('reshape', Sym)                 leading axes only (last axis kept)
          ('matmul', Sym, tensor[K, N])
          ('log', Sym)
+         ('col', Sym)                     latent[..., None]: a per-chain scalar
+         ('add', Sym, Sym)                sum of linear terms (matmul of a
+                                          latent, a bias latent [..., 1])
     """
 
     @staticmethod
@@ -82,7 +93,12 @@ class Sym(torch.Tensor):
         r._expr = expr
         r._value = None
         r._meta = (tuple(int(d) for d in shape), dtype, torch.device(device))
-        r._root = expr[1] if expr[0] == 'latent' else expr[1]._root
+        if expr[0] == 'latent':
+            r._roots = (expr[1],)
+        elif expr[0] == 'add':
+            r._roots = expr[1]._roots + expr[2]._roots
+        else:
+            r._roots = expr[1]._roots
         return r
 
     def __init__(self, *a, **k):
@@ -91,7 +107,8 @@ class Sym(torch.Tensor):
     # -- the value of the expression (computed once) -------------------------
     def force(self):
         if self._value is None:
-            if self._root.requires_grad and not torch.is_grad_enabled():
+            if any(t.requires_grad for t in self._roots) and \
+                    not torch.is_grad_enabled():
                 raise SymbolicCut(
                     "symbolic latent expression %r evaluated with autograd "
                     "disabled (inside a custom autograd.Function.forward?)"
@@ -106,6 +123,10 @@ class Sym(torch.Tensor):
                 v = e[1].force().reshape(tuple(_shape_of(self)))
             elif kind == 'matmul':
                 v = e[1].force() @ e[2]
+            elif kind == 'col':
+                v = e[1].force().unsqueeze(-1)
+            elif kind == 'add':
+                v = e[1].force() + e[2].force()
             else:
                 v = torch.log(e[1].force())
             self._value = v
@@ -121,7 +142,7 @@ class Sym(torch.Tensor):
             with torch._C.DisableTorchFunctionSubclass():
                 return func(*args, **kwargs)
         if func is _REQUIRES_GRAD:      # of the latent the symbol stands on
-            return args[0]._root.requires_grad
+            return any(t.requires_grad for t in args[0]._roots)
         out = _symbolic_rule(func, args, kwargs)
         if out is not None:
             return out
@@ -147,6 +168,8 @@ def _describe(e):
     if e[0] == 'matmul':
         return 'matmul(%s, const%s)' % (_describe(e[1]._expr),
                                         list(e[2].shape))
+    if e[0] == 'add':
+        return 'add(%s, %s)' % (_describe(e[1]._expr), _describe(e[2]._expr))
     return '%s(%s)' % (e[0], _describe(e[1]._expr))
 
 
@@ -205,9 +228,43 @@ def _resolve_shape(shape_args, numel):
     return tuple(shape) if n == numel else None
 
 
+def _linear_term(s):
+    """'w' for latent @ const, 'b' for a bias-shaped latent ([..., 1] or
+    latent[..., None]), 'sum' for a sum of such terms, else None."""
+    k = _kind(s)
+    if k == 'matmul':
+        return 'w' if _kind(s._expr[1]) == 'latent' else None
+    if k == 'latent':
+        return 'b' if s._meta[0] and s._meta[0][-1] == 1 else None
+    if k == 'col':
+        return 'b'
+    return 'sum' if k == 'add' else None
+
+
+def _add_rule(args, kwargs):
+    if len(args) != 2 or kwargs.get('alpha', 1) != 1 or \
+            any(k != 'alpha' for k in kwargs):
+        return None
+    a, b = args
+    if not (isinstance(a, Sym) and isinstance(b, Sym)):
+        return None
+    ka, kb = _linear_term(a), _linear_term(b)
+    if ka is None or kb is None or (ka == 'b' and kb == 'b'):
+        return None
+    (sa, dt, dev), (sb, dtb, devb) = a._meta, b._meta
+    if dt != dtb or dev != devb or len(sa) != len(sb) or sa[:-1] != sb[:-1]:
+        return None
+    if sa[-1] != sb[-1] and 'b' not in (ka, kb):
+        return None
+    n = sb[-1] if ka == 'b' else sa[-1]
+    return Sym(('add', a, b), sa[:-1] + (n,), dt, dev)
+
+
 def _symbolic_rule(func, args, kwargs):
-    """The new symbol if `func(*args)` continues one of the two spellings,
-    else None."""
+    """The new symbol if `func(*args)` continues one of the spellings, else
+    None."""
+    if func in _ADD:
+        return _add_rule(args, kwargs)
     if not args or not isinstance(args[0], Sym):
         return None
     x = args[0]
@@ -246,6 +303,23 @@ def _symbolic_rule(func, args, kwargs):
             return None
         return Sym(('matmul', x, rhs), xs[:-1] + (int(rhs.shape[1]),),
                    x_dtype, x_device)
+    if func in _UNSQUEEZE:
+        dim = kwargs.get('dim', args[1] if len(args) > 1 else None)
+        if _kind(x) == 'latent' and isinstance(dim, int) and \
+                len(args) + len(kwargs) == 2 and dim in (-1, len(xs)):
+            return Sym(('col', x), xs + (1,), x_dtype, x_device)
+        return None
+    if func is _T.__getitem__:
+        # latent[:, None] / latent[..., None]: the same per-chain column
+        idx = args[1] if len(args) == 2 else None
+        idx = idx if isinstance(idx, tuple) else (idx,)
+        if _kind(x) == 'latent' and not kwargs and idx and idx[-1] is None and (
+                idx[:-1] == (Ellipsis,) or
+                (len(idx) - 1 == len(xs) and
+                 all(isinstance(i, slice) and i == slice(None)
+                     for i in idx[:-1]))):
+            return Sym(('col', x), xs + (1,), x_dtype, x_device)
+        return None
     if func in _LOG:
         if kwargs or len(args) != 1 or _chain_kind(x) != 'matmul':
             return None
@@ -273,17 +347,37 @@ def softmax_source(theta):
     return t._expr[1]._expr[1] if _kind(t) == 'softmax' else None
 
 
+def _linear_terms(s, out):
+    k = _kind(s)
+    if k == 'add':
+        return _linear_terms(s._expr[1], out) and \
+            _linear_terms(s._expr[2], out)
+    if k == 'matmul' and _kind(s._expr[1]) == 'latent':
+        out.append((s._expr[1]._expr[1], s._expr[2].t(), False))
+        return True
+    if k == 'latent' and s._meta[0] and s._meta[0][-1] == 1:
+        out.append((s._expr[1], None, False))
+        return True
+    if k == 'col':
+        out.append((s._expr[1]._expr[1], None, True))
+        return True
+    return False
+
+
 def lower_bernoulli_logits(logits):
-    """`latent @ const[D, N]` -> LinearLogits(latent, const^T); any other
-    symbol -> its value."""
+    """`latent @ const[D, N]` (+ more such terms, + a bias latent) ->
+    LinearLogits over the latents; any other symbol -> its value."""
     if not isinstance(logits, Sym):
         return logits
     from .distributions.univariate import LinearLogits
-    s = logits
-    if _kind(s) == 'matmul' and _kind(s._expr[1]) == 'latent' and \
-            s._meta[1] == torch.float32:
-        w = s._expr[1]._expr[1]
-        return LinearLogits(w, s._expr[2].t())
+    terms = []
+    if logits._meta[1] == torch.float32 and _kind(logits) in ('matmul', 'add') \
+            and _linear_terms(logits, terms) and \
+            any(X is not None for _, X, _ in terms) and \
+            len({id(w) for w, _, _ in terms}) == len(terms):
+        n = [X.shape[0] for _, X, _ in terms if X is not None]
+        if all(v == n[0] for v in n):
+            return LinearLogits.of_terms(terms)
     return logits.force()
 
 

@@ -25,16 +25,17 @@ typedef float g4 __attribute__((ext_vector_type(4)));
 // VEC: rows are 16-B aligned multiples of 4 floats -> one 16-B access per lane
 template <bool VEC>
 __global__ __launch_bounds__(256) void momentum_kernel(
-    float* __restrict__ p, const float* __restrict__ mass, int64_t n_chains,
-    int64_t n_data, int64_t chain_offset, uint32_t k0, uint32_t k1,
-    uint32_t iteration, uint32_t stream_word, float* __restrict__ kinetic) {
+    float* __restrict__ p, int64_t ld, const float* __restrict__ mass,
+    int64_t n_chains, int64_t n_data, int64_t chain_offset, uint32_t k0,
+    uint32_t k1, uint32_t iteration, uint32_t stream_word,
+    float* __restrict__ kinetic) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
   const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x / 64);
   const int64_t n_groups = (n_data + 3) / 4;
   for (int64_t c = wave; c < n_chains; c += n_waves) {
     const uint32_t gchain = (uint32_t)(c + chain_offset);
-    float* __restrict__ row = p + c * n_data;
+    float* __restrict__ row = p + c * ld;
     float kin = 0.f;
     if (VEC) {
       // two 4-latent groups per trip, their Philox calls advanced together
@@ -201,34 +202,38 @@ __global__ __launch_bounds__(256) void mh_accept_kernel(
   }
 }
 
-// Accepted rows only are copied (a rejected row costs one byte of `accept`):
-// the row copy is EXEC-uniform per wave.  VEC: 16 B per lane, up to four
-// 1-KiB chunks of the row loaded before the first store so that a wave has
-// 4 KiB in flight (the scalar form had 256 B).
+// Accepted rows only are copied (a rejected row costs one byte of `accept`;
+// accept == NULL: every row): the row copy is EXEC-uniform per wave.  Rows of
+// dst / src are ld_dst / ld_src floats apart (a latent's own [n_rows, n_cols]
+// tensor on one side, its columns of a plan's packed state on the other).
+// VEC: 16 B per lane, up to four 1-KiB chunks of the row loaded before the
+// first store so that a wave has 4 KiB in flight (the scalar form had 256 B).
 template <bool VEC>
 __global__ __launch_bounds__(256) void select_rows_kernel(
-    float* __restrict__ q, const float* __restrict__ q_new,
-    const uint8_t* __restrict__ accept, int64_t n_chains, int64_t n_data) {
+    float* __restrict__ q, int64_t ld_dst, const float* __restrict__ q_new,
+    int64_t ld_src, const uint8_t* __restrict__ accept, int64_t n_chains,
+    int64_t n_data) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
   const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x / 64);
   for (int64_t c = wave; c < n_chains; c += n_waves) {
-    if (!accept[c]) continue;  // wave-uniform
-    const int64_t off = c * n_data;
+    if (accept && !accept[c]) continue;  // wave-uniform
+    float* __restrict__ drow = q + c * ld_dst;
+    const float* __restrict__ srow = q_new + c * ld_src;
     if (VEC) {
       for (int64_t d0 = (int64_t)lane * 4; d0 < n_data; d0 += 4 * 256) {
         g4 v[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k)
           if (d0 + k * 256 < n_data)
-            v[k] = *reinterpret_cast<const g4*>(q_new + off + d0 + k * 256);
+            v[k] = *reinterpret_cast<const g4*>(srow + d0 + k * 256);
 #pragma unroll
         for (int k = 0; k < 4; ++k)
           if (d0 + k * 256 < n_data)
-            *reinterpret_cast<g4*>(q + off + d0 + k * 256) = v[k];
+            *reinterpret_cast<g4*>(drow + d0 + k * 256) = v[k];
       }
     } else {
-      for (int64_t d = lane; d < n_data; d += 64) q[off + d] = q_new[off + d];
+      for (int64_t d = lane; d < n_data; d += 64) drow[d] = srow[d];
     }
   }
 }
@@ -248,32 +253,52 @@ static inline int row_grid(int64_t n_rows) {
 
 using namespace zshmc;
 
-extern "C" int zshmc_momentum(float* p, const float* mass, int64_t n_chains,
-                              int64_t n_data, int64_t chain_offset,
-                              uint64_t seed, uint32_t iteration,
-                              uint32_t latent_id, float* kinetic,
-                              void* stream) {
-  ZS_REQUIRE(p, "zshmc_momentum: null p");
-  ZS_REQUIRE(n_chains >= 0 && n_data >= 1, "zshmc_momentum: bad shape");
-  ZS_REQUIRE(latent_id < (1u << 24), "zshmc_momentum: latent_id too large");
+static int momentum_rows(float* p, int64_t ld, const float* mass,
+                         int64_t n_chains, int64_t n_data, int64_t chain_offset,
+                         uint64_t seed, uint32_t iteration, uint32_t latent_id,
+                         float* kinetic, void* stream, const char* who) {
+  ZS_REQUIRE(p, "%s: null p", who);
+  ZS_REQUIRE(n_chains >= 0 && n_data >= 1 && ld >= n_data, "%s: bad shape", who);
+  ZS_REQUIRE(latent_id < (1u << 24), "%s: latent_id too large", who);
   ZS_REQUIRE(n_chains + chain_offset <= 0xFFFFFFFFll,
-             "zshmc_momentum: global chain index exceeds 2^32");
+             "%s: global chain index exceeds 2^32", who);
   if (n_chains == 0) return ZSHMC_OK;
-  const bool vec = n_data % 4 == 0 && aligned16(p) && aligned16(mass);
+  const bool vec =
+      n_data % 4 == 0 && ld % 4 == 0 && aligned16(p) && aligned16(mass);
   if (vec)
     hipLaunchKernelGGL(momentum_kernel<true>, dim3(row_grid(n_chains)),
                        dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p,
-                       mass, n_chains, n_data, chain_offset,
+                       ld, mass, n_chains, n_data, chain_offset,
                        (uint32_t)(seed & 0xFFFFFFFFull), (uint32_t)(seed >> 32),
                        iteration, kStreamMomentum | (latent_id << 8), kinetic);
   else
     hipLaunchKernelGGL(momentum_kernel<false>, dim3(row_grid(n_chains)),
                        dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p,
-                       mass, n_chains, n_data, chain_offset,
+                       ld, mass, n_chains, n_data, chain_offset,
                        (uint32_t)(seed & 0xFFFFFFFFull), (uint32_t)(seed >> 32),
                        iteration, kStreamMomentum | (latent_id << 8), kinetic);
   ZS_LAUNCH_CHECK("momentum_kernel launch");
   return ZSHMC_OK;
+}
+
+extern "C" int zshmc_momentum(float* p, const float* mass, int64_t n_chains,
+                              int64_t n_data, int64_t chain_offset,
+                              uint64_t seed, uint32_t iteration,
+                              uint32_t latent_id, float* kinetic,
+                              void* stream) {
+  return momentum_rows(p, n_data, mass, n_chains, n_data, chain_offset, seed,
+                       iteration, latent_id, kinetic, stream, "zshmc_momentum");
+}
+
+extern "C" int zshmc_momentum_rows(float* p, int64_t row_stride,
+                                   const float* mass, int64_t n_chains,
+                                   int64_t n_data, int64_t chain_offset,
+                                   uint64_t seed, uint32_t iteration,
+                                   uint32_t latent_id, float* kinetic,
+                                   void* stream) {
+  return momentum_rows(p, row_stride, mass, n_chains, n_data, chain_offset,
+                       seed, iteration, latent_id, kinetic, stream,
+                       "zshmc_momentum_rows");
 }
 
 extern "C" int zshmc_kick_drift(float* q, float* p, const float* grad,
@@ -329,20 +354,39 @@ extern "C" int zshmc_mh_accept(const float* log_prob_old,
   return ZSHMC_OK;
 }
 
+static int copy_rows(float* dst, int64_t ld_dst, const float* src,
+                     int64_t ld_src, const uint8_t* accept, int64_t n_rows,
+                     int64_t n_cols, void* stream) {
+  if (n_cols % 4 == 0 && ld_dst % 4 == 0 && ld_src % 4 == 0 && aligned16(dst) &&
+      aligned16(src))
+    hipLaunchKernelGGL(select_rows_kernel<true>, dim3(row_grid(n_rows)),
+                       dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dst,
+                       ld_dst, src, ld_src, accept, n_rows, n_cols);
+  else
+    hipLaunchKernelGGL(select_rows_kernel<false>, dim3(row_grid(n_rows)),
+                       dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dst,
+                       ld_dst, src, ld_src, accept, n_rows, n_cols);
+  ZS_LAUNCH_CHECK("select_rows_kernel launch");
+  return ZSHMC_OK;
+}
+
 extern "C" int zshmc_select_rows(float* q, const float* q_new,
                                  const uint8_t* accept, int64_t n_chains,
                                  int64_t n_data, void* stream) {
   ZS_REQUIRE(q && q_new && accept, "zshmc_select_rows: null pointer");
   ZS_REQUIRE(n_chains >= 0 && n_data >= 1, "zshmc_select_rows: bad shape");
   if (n_chains == 0) return ZSHMC_OK;
-  if (n_data % 4 == 0 && aligned16(q) && aligned16(q_new))
-    hipLaunchKernelGGL(select_rows_kernel<true>, dim3(row_grid(n_chains)),
-                       dim3(256), 0, reinterpret_cast<hipStream_t>(stream), q,
-                       q_new, accept, n_chains, n_data);
-  else
-    hipLaunchKernelGGL(select_rows_kernel<false>, dim3(row_grid(n_chains)),
-                       dim3(256), 0, reinterpret_cast<hipStream_t>(stream), q,
-                       q_new, accept, n_chains, n_data);
-  ZS_LAUNCH_CHECK("select_rows_kernel launch");
-  return ZSHMC_OK;
+  return copy_rows(q, n_data, q_new, n_data, accept, n_chains, n_data, stream);
+}
+
+extern "C" int zshmc_copy_rows(float* dst, int64_t dst_stride, const float* src,
+                               int64_t src_stride, const uint8_t* accept,
+                               int64_t n_rows, int64_t n_cols, void* stream) {
+  ZS_REQUIRE(dst && src, "zshmc_copy_rows: null pointer");
+  ZS_REQUIRE(n_rows >= 0 && n_cols >= 1 && dst_stride >= n_cols &&
+                 src_stride >= n_cols,
+             "zshmc_copy_rows: bad shape");
+  if (n_rows == 0) return ZSHMC_OK;
+  return copy_rows(dst, dst_stride, src, src_stride, accept, n_rows, n_cols,
+                   stream);
 }

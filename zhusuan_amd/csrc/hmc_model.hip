@@ -27,8 +27,11 @@
 //                the next likelihood evaluation reads it directly.
 // One wave per row -- two / four rows per wave when a row is at most 128 / 64
 // floats wide, so that no lane idles (config 5: K = 128 topics) -- the row in
-// registers (n_data <= 1024, multiple of 4, 16-B aligned), 16 B per lane and
-// access, row sums by shuffles inside the row's lane group.
+// registers (row stride ld <= 1024 floats, a multiple of 4, 16-B aligned; the
+// n_data <= ld leading columns are the latent -- several latents packed side by
+// side by the caller -- the rest is zero padding that takes no part in the
+// prior, the softmax or the sums), 16 B per lane and access, row sums by
+// shuffles inside the row's lane group.
 // HBM-bound: 4-6 row passes of 4*n_data bytes per call, noise next to the
 // 2*N*D*C flop likelihood it sits between.
 #include "common.h"
@@ -54,7 +57,8 @@ struct ModelStepArgs {
   float step_size_host;
   float kick_scale, drift_scale;
   float lik_scale;  // multiplies log_lik and its gradient (AIS temperature)
-  int64_t n_chains, n_data;
+  int64_t n_chains, n_data;  // n_data: valid leading columns of a row
+  int64_t ld;                // row stride of q, p, the prior rows; mass length
   const float* ll_in;  // [C] or NULL
   float* lp_out;       // [C] or NULL
   float* kinetic;      // [C] or NULL
@@ -77,7 +81,7 @@ __global__ __launch_bounds__(256) void model_kick_drift_kernel(ModelStepArgs a) 
   const int sub = (threadIdx.x & 63) / LANES;     // which row of the wave
   const int64_t wave = (int64_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
   const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x / 64);
-  const int64_t D = a.n_data;
+  const int64_t D = a.n_data, LD = a.ld;
   const float eps = a.step_size_dev ? *a.step_size_dev : a.step_size_host;
   const float s2 = a.kick_scale * eps;
   const float s1 = a.drift_scale * eps;
@@ -90,10 +94,10 @@ __global__ __launch_bounds__(256) void model_kick_drift_kernel(ModelStepArgs a) 
        base += n_waves * kRows) {
     const bool row_on = base + sub < a.n_chains;
     const int64_t c = row_on ? base + sub : a.n_chains - 1;
-    float* __restrict__ qrow = a.q + c * D;
-    float* __restrict__ prow = a.p + c * D;
-    const float* __restrict__ mrow = a.prior_mean + (c % a.mean_rows) * D;
-    const float* __restrict__ lrow = a.prior_logstd + (c % a.logstd_rows) * D;
+    float* __restrict__ qrow = a.q + c * LD;
+    float* __restrict__ prow = a.p + c * LD;
+    const float* __restrict__ mrow = a.prior_mean + (c % a.mean_rows) * LD;
+    const float* __restrict__ lrow = a.prior_logstd + (c % a.logstd_rows) * LD;
     m4 q[NV], p[NV], g[NV], im[NV];
     bool in[NV];
     float prior = 0.f, dot = 0.f;
@@ -123,10 +127,12 @@ __global__ __launch_bounds__(256) void model_kick_drift_kernel(ModelStepArgs a) 
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         // Normal._log_prob and d/dx, univariate.py:174-181
+        const bool on = d + j < D;  // (the last group of a padded row)
         const float prec = expf(-2.0f * ls[j]);
         const float r = q[k][j] - mu[j];
-        prior += kNegHalfLog2Pi - ls[j] - 0.5f * prec * r * r;
-        g[k][j] = -prec * r;  // prior part; the likelihood part joins below
+        prior += on ? kNegHalfLog2Pi - ls[j] - 0.5f * prec * r * r : 0.f;
+        g[k][j] = on ? -prec * r : 0.f;  // prior part; the likelihood part
+                                         // joins below
         if (SOFTMAX) dot += gl[j] * th[j];
       }
       // likelihood part: J_f^T g_lik.  softmax: theta * (g - <g, theta>);
@@ -166,9 +172,11 @@ __global__ __launch_bounds__(256) void model_kick_drift_kernel(ModelStepArgs a) 
       }
       const m4 e = p[k] * vel;
       kin += (e[0] + e[1]) + (e[2] + e[3]);
-      if (SOFTMAX)
-        qmax = fmaxf(fmaxf(fmaxf(q[k][0], q[k][1]), fmaxf(q[k][2], q[k][3])),
-                     qmax);
+      if (SOFTMAX) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (d + j < D) qmax = fmaxf(q[k][j], qmax);
+      }
     }
     if (a.kinetic) {
       kin = group_sum<LANES>(kin);
@@ -185,9 +193,10 @@ __global__ __launch_bounds__(256) void model_kick_drift_kernel(ModelStepArgs a) 
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
           if (!in[k]) continue;
+          const int64_t d = (int64_t)(k * LANES + lane) * 4;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            q[k][j] = expf(q[k][j] - qmax);
+            q[k][j] = d + j < D ? expf(q[k][j] - qmax) : 0.f;
             sum += q[k][j];
           }
         }
@@ -231,18 +240,21 @@ extern "C" int zshmc_model_kick_drift(
     const float* prior_mean, int64_t mean_rows, const float* prior_logstd,
     int64_t logstd_rows, const float* mass, const float* step_size_dev,
     float step_size_host, float kick_scale, float drift_scale,
-    float lik_scale, int64_t n_chains, int64_t n_data, const float* ll_in,
-    float* lp_out, float* kinetic, void* stream) {
+    float lik_scale, int64_t n_chains, int64_t n_data, int64_t row_stride,
+    const float* ll_in, float* lp_out, float* kinetic, void* stream) {
+  const int64_t ld = row_stride;
   ZS_REQUIRE(q && p && prior_mean && prior_logstd,
              "zshmc_model_kick_drift: null q/p/prior");
-  ZS_REQUIRE(n_chains >= 0 && n_data >= 4 && n_data <= 1024 && n_data % 4 == 0,
-             "zshmc_model_kick_drift: n_data %lld must be a multiple of 4 in "
-             "[4, 1024]", (long long)n_data);
+  ZS_REQUIRE(n_chains >= 0 && n_data >= 1 && ld >= n_data && ld <= 1024 &&
+                 ld % 4 == 0,
+             "zshmc_model_kick_drift: 1 <= n_data %lld <= row_stride %lld <= "
+             "1024, row_stride a multiple of 4", (long long)n_data,
+             (long long)ld);
   ZS_REQUIRE(mean_rows >= 1 && logstd_rows >= 1,
              "zshmc_model_kick_drift: prior row periods must be >= 1");
-  ZS_REQUIRE(!grad_lik || (grad_stride >= n_data && grad_stride % 4 == 0),
+  ZS_REQUIRE(!grad_lik || (grad_stride >= ld && grad_stride % 4 == 0),
              "zshmc_model_kick_drift: bad grad_stride");
-  ZS_REQUIRE(!operand || (operand_stride >= n_data && operand_stride % 4 == 0 &&
+  ZS_REQUIRE(!operand || (operand_stride >= ld && operand_stride % 4 == 0 &&
                           operand_stride <= 1024),
              "zshmc_model_kick_drift: bad operand_stride");
   ZS_REQUIRE(!softmax || operand, "zshmc_model_kick_drift: softmax needs operand");
@@ -256,9 +268,9 @@ extern "C" int zshmc_model_kick_drift(
   ModelStepArgs a{q, p, grad_lik, grad_stride, operand, operand_stride,
                   prior_mean, mean_rows, prior_logstd, logstd_rows, mass,
                   step_size_dev, step_size_host, kick_scale, drift_scale,
-                  lik_scale, n_chains, n_data, ll_in, lp_out, kinetic};
+                  lik_scale, n_chains, n_data, ld, ll_in, lp_out, kinetic};
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const int64_t width = operand && operand_stride > n_data ? operand_stride : n_data;
+  const int64_t width = operand && operand_stride > ld ? operand_stride : ld;
   const int nv = (int)((width + 255) / 256);
   // a row of at most 64 / 128 floats leaves lanes of a 64-lane group idle:
   // pack four / two rows into a wave

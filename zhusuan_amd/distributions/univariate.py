@@ -200,24 +200,85 @@ class Normal(Distribution):
 
 
 class LinearLogits(object):
-    """Lazy `w @ X^T`: logits of shape w.shape[:-1] + [n_rows] that are never
-    materialised.  `Bernoulli(linear_logits(w, X), group_ndims=1)` evaluates
-    log_prob and its gradient with the fused fp32-MFMA kernel
-    (csrc/linear_bernoulli.hip); anything else falls back to `.dense()`."""
+    """Lazy `w @ X^T` -- or a sum of such terms over several latents plus a
+    per-chain bias, `w1 @ X1^T + w2 @ X2^T + b` -- : logits of shape
+    w.shape[:-1] + [n_rows] that are never materialised.
+    `Bernoulli(linear_logits(w, X), group_ndims=1)` evaluates log_prob and
+    its gradient with the fused fp32-MFMA kernels (csrc/linear_bernoulli.hip,
+    linear_bernoulli_wide.hip; up to 1024 features in total); anything else
+    falls back to `.dense()`.
 
-    def __init__(self, w, X):
+    `terms`: [(w_k, X_k, scalar_k)]; X_k None stands for a column of ones
+    (w_k is a bias: [..., 1], or [...] when scalar_k)."""
+
+    def __init__(self, w, X, bias=None):
         w = as_tensor(w)          # (a symbolic latent: the latent itself)
         X = as_tensor(X)
         if X.dim() != 2 or w.dim() < 1 or w.shape[-1] != X.shape[-1]:
             raise ValueError(
                 "linear_logits: w[..., D] and X[N, D] expected, got {} and {}"
                 .format(tuple(w.shape), tuple(X.shape)))
-        self.w = w
-        self.X = X
+        self.terms = [(w, X, False)]
+        if bias is not None:
+            b = as_tensor(bias)
+            lead = tuple(w.shape[:-1])
+            if tuple(b.shape) == lead + (1,):
+                self.terms.append((b, None, False))
+            elif tuple(b.shape) == lead:
+                self.terms.append((b, None, True))
+            else:
+                raise ValueError(
+                    "linear_logits: bias of shape {} or {} expected, got {}"
+                    .format(lead + (1,), lead, tuple(b.shape)))
+
+    @classmethod
+    def of_terms(cls, terms):
+        """From [(w_k, X_k | None, scalar_k)] with equal leading shapes (the
+        lowering of the literal spelling, _symbolic.lower_bernoulli_logits)."""
+        self = cls.__new__(cls)
+        self.terms = [(as_tensor(w), None if X is None else as_tensor(X),
+                       bool(sc)) for w, X, sc in terms]
+        lead = {tuple(w.shape if sc else w.shape[:-1])
+                for w, _, sc in self.terms}
+        rows = {int(X.shape[0]) for _, X, _ in self.terms if X is not None}
+        if len(lead) != 1 or len(rows) != 1 or any(
+                X is not None and (X.dim() != 2 or sc or
+                                   w.shape[-1] != X.shape[-1])
+                for w, X, sc in self.terms):
+            raise ValueError("linear_logits: inconsistent terms")
+        return self
+
+    # the single-term view (one weight latent, no bias)
+    @property
+    def w(self):
+        return self.terms[0][0]
+
+    @property
+    def X(self):
+        return self.terms[0][1]
+
+    @property
+    def single(self):
+        return len(self.terms) == 1
+
+    @property
+    def n_rows(self):
+        return next(int(X.shape[0]) for _, X, _ in self.terms
+                    if X is not None)
+
+    @property
+    def n_features(self):
+        return sum(1 if X is None else int(X.shape[-1])
+                   for _, X, _ in self.terms)
+
+    @property
+    def lead_shape(self):
+        w, _, sc = self.terms[0]
+        return tuple(w.shape if sc else w.shape[:-1])
 
     @property
     def shape(self):
-        return torch.Size(tuple(self.w.shape[:-1]) + (self.X.shape[0],))
+        return torch.Size(self.lead_shape + (self.n_rows,))
 
     @property
     def dtype(self):
@@ -227,12 +288,28 @@ class LinearLogits(object):
     def device(self):
         return self.w.device
 
+    def design_requires_grad(self):
+        return any(X is not None and X.requires_grad for _, X, _ in self.terms)
+
+    def packed(self):
+        """(w [..., D_total], X [N, D_total]): the terms side by side -- the
+        weights by torch.cat (differentiable), the design matrices cached."""
+        if self.single:
+            return self.w, self.X
+        ws = [w.unsqueeze(-1) if sc else w for w, _, sc in self.terms]
+        return torch.cat(ws, -1), _ops.packed_design(
+            [X for _, X, _ in self.terms], self.n_rows, self.w.device)
+
     def dense(self):
-        return self.w @ self.X.t()
+        out = None
+        for w, X, sc in self.terms:
+            t = (w.unsqueeze(-1) if sc else w) if X is None else w @ X.t()
+            out = t if out is None else out + t
+        return out
 
 
-def linear_logits(w, X):
-    return LinearLogits(w, X)
+def linear_logits(w, X, bias=None):
+    return LinearLogits(w, X, bias)
 
 
 class Bernoulli(Distribution):
@@ -300,13 +377,14 @@ class Bernoulli(Distribution):
         given = given.to(self.param_dtype)          # :399
         lazy = self._lazy
         if (lazy is not None and self._group_ndims >= 1 and
-                given.dim() == 1 and given.shape[0] == lazy.X.shape[0] and
+                given.dim() == 1 and given.shape[0] == lazy.n_rows and
                 # the fused kernel differentiates w.r.t. w only: a design
                 # matrix that needs a gradient takes the dense path
-                not lazy.X.requires_grad and not given.requires_grad and
-                lazy.w.shape[-1] <= _ops.LINEAR_BERNOULLI_WIDTHS[-1] and
-                lazy.w.dim() - 1 >= self._group_ndims - 1):
-            ll = _ops.LinearBernoulliLogLik.apply(lazy.w, lazy.X, given)
+                not lazy.design_requires_grad() and not given.requires_grad and
+                lazy.n_features <= _ops.LINEAR_BERNOULLI_WIDTHS[-1] and
+                len(lazy.lead_shape) >= self._group_ndims - 1):
+            w_all, x_all = lazy.packed()
+            ll = _ops.LinearBernoulliLogLik.apply(w_all, x_all, given)
             extra = self._group_ndims - 1
             return ll if extra == 0 else ll.sum(
                 dim=tuple(range(-extra, 0)))

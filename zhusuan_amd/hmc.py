@@ -1122,13 +1122,22 @@ class _GenericPlan(_PlanBase):
 
 class _DenseLikelihoodPlan(_PlanBase):
     """Native plan for the dense-likelihood families (BASELINE configs 3 / 5):
-    one latent with a Normal prior (group_ndims = 1) and one observed node
-    whose log-likelihood and gradient come from the fused fp32-MFMA kernels --
+    latents with Normal priors and one observed node whose log-likelihood and
+    gradient come from the fused fp32-MFMA kernels --
 
-      'linear_bernoulli'    y ~ Bernoulli(linear_logits(w, X), group_ndims=1)
+      'linear_bernoulli'    y ~ Bernoulli(w @ X^T [+ w2 @ X2^T ...] [+ b],
+                                          group_ndims=1)
+                            one latent per term, up to 1024 features in total
       'mixture_multinomial' x ~ UnnormalizedMultinomial(
                                     log_mixture(softmax(eta), phi),
                                     normalize_logits=False)   (lntm_mcem.py:33-48)
+                            one latent, up to 256 topics
+
+    The plan works on a PACKED state: the latents' columns side by side in
+    rows of `ld` floats (the total rounded up to a multiple of 4; the columns
+    behind the last latent stay zero) -- what the likelihood kernel takes as
+    its W operand once the design matrices are laid out the same way.  A
+    single latent whose size is a multiple of 4 is its own packed state.
 
     A transition is momentum + (L+1) x [likelihood kernel, one element-wise
     launch doing prior gradient / softmax Jacobian / kick / drift / next
@@ -1147,16 +1156,27 @@ class _DenseLikelihoodPlan(_PlanBase):
         self.kind = kind
         self._probe = probe
         f32 = dict(dtype=torch.float32, device=device)
-        C, D = self.n_chains, self.n_data[0]
-        self.width = next(v for v in _ops.LINEAR_BERNOULLI_WIDTHS if v >= D)
+        C = self.n_chains
+        self.offsets = [sum(self.n_data[:k]) for k in range(len(self.n_data))]
+        D = self.n_total = sum(self.n_data)
+        self.ld = ld = (D + 3) // 4 * 4
+        self.packed = len(self.q) > 1 or ld != D
+        self.width = next(v for v in _ops.LINEAR_BERNOULLI_WIDTHS if v >= ld)
         self.softmax = kind == 'mixture_multinomial'
-        self.q_flat = self.q[0].view(C, D)      # chain axes flattened
-        self.p = torch.empty(C, D, **f32)
-        self.q_new = torch.empty(C, D, **f32)
+        # chain axes flattened: [C, D_k] views of the latents
+        self.q_rows = [q.view(C, d) for q, d in zip(self.q, self.n_data)]
+        self.p = torch.zeros(C, ld, **f32)
+        self.q_new = torch.zeros(C, ld, **f32)
         self.grad = torch.empty(C, self.width, **f32)
         # operand of the likelihood kernel: theta = softmax(q) / zero-padded q
         self.operand = torch.zeros(C, self.width, **f32) \
-            if (self.softmax or self.width != D) else None
+            if (self.softmax or self.width != ld) else None
+        if hmc.adapt_mass is not None:
+            # the latents' mass vectors are the columns of ONE packed vector
+            # (what the step kernel reads); the padding keeps mass 1
+            self.mass_pack = torch.ones(ld, **f32)
+            self.mass = [self.mass_pack[o:o + d]
+                         for o, d in zip(self.offsets, self.n_data)]
         self.ll = torch.empty(C, **f32)
         self.lp_old = self.orig_log_prob      # HMCInfo.orig_log_prob itself
         self.lp_new = torch.empty(C, **f32)
@@ -1174,9 +1194,10 @@ class _DenseLikelihoodPlan(_PlanBase):
 
     # -- model tensors -------------------------------------------------------
     def refresh_model(self):
-        t = list(self._probe())
-        how, spread = t[1]           # ('std' | 'logstd', tensor as given)
-        t[1] = spread
+        priors, inner, obs = self._probe()
+        # priors: [(mean, ('std' | 'logstd', tensor as given))] per latent
+        t = [m for m, _ in priors] + [sp[1] for _, sp in priors] + \
+            [a for a in inner if a is not None] + [obs]
         # same storage, layout and version counter as last run (the tensors
         # are held, so an address cannot have been handed to another one;
         # `X.t()` of the literal spelling is a new view object every time)
@@ -1185,21 +1206,20 @@ class _DenseLikelihoodPlan(_PlanBase):
         if self._src is not None and key == self._src[0]:
             return
         self._src = (key, t)
-        C, D = self.n_chains, self.n_data[0]
-        mean = t[0]
-        logstd = torch.log(spread) if how == 'std' else spread  # :96-103
-        self.prior_mean, self.mean_rows = _to_row_period(
-            mean, self.chain_shape, D)
-        self.prior_logstd, self.logstd_rows = _to_row_period(
-            logstd, self.chain_shape, D)
+        C = self.n_chains
+        self._pack_prior(priors)
         ops = self._ops
         if self.kind == 'linear_bernoulli':
-            X, y = t[2], t[3]
-            self.inner = _aligned16(ops._padded_x(X, self.width))
+            y = obs
+            if self.packed:
+                self.inner = _aligned16(ops.packed_design(
+                    inner, int(y.shape[0]), self.device, self.width))
+            else:
+                self.inner = _aligned16(ops._padded_x(inner[0], self.width))
             self.obs = _aligned16(y.detach().to(torch.float32).contiguous())
             n_inner = self.inner.shape[0]
         else:
-            phi, x = t[2], t[3]
+            phi, x = inner[0], obs
             self.inner = _aligned16(ops._padded_phi_t(phi, self.width))
             self.obs, self.obs_stride = ops._padded_counts(x)
             self.obs = _aligned16(self.obs)
@@ -1212,7 +1232,60 @@ class _DenseLikelihoodPlan(_PlanBase):
             self._ws = torch.empty(need, dtype=torch.float32,
                                    device=self.device)
 
+    def _pack_prior(self, priors):
+        """Prior mean / log-std as [rows, ld] matrices used with row period
+        `rows` over the flattened chain axes (_to_row_period); several
+        latents: their columns side by side, a common row period."""
+        parts = []
+        for (mean, (how, spread)), d, q in zip(priors, self.n_data, self.q):
+            logstd = torch.log(spread) if how == 'std' else spread  # :96-103
+            if q.dim() == len(self.chain_shape):    # per-chain scalar latent
+                mean, logstd = mean.unsqueeze(-1), logstd.unsqueeze(-1)
+            try:
+                parts.append((_to_row_period(mean, self.chain_shape, d),
+                              _to_row_period(logstd, self.chain_shape, d)))
+            except (RuntimeError, ValueError) as e:
+                raise _Unsupported(str(e))
+        if not self.packed:
+            (self.prior_mean, self.mean_rows), \
+                (self.prior_logstd, self.logstd_rows) = parts[0]
+            return
+        out = []
+        for which in (0, 1):
+            rows = max(p[which][1] for p in parts)
+            m = torch.zeros(rows, self.ld, dtype=torch.float32,
+                            device=self.device)
+            for p, o, d in zip(parts, self.offsets, self.n_data):
+                t, r = p[which]
+                if r not in (1, rows):
+                    raise _Unsupported(
+                        "HMC (native %s plan): the priors' parameters vary "
+                        "along different chain axes" % self.kind)
+                m[:, o:o + d] = t
+            out.append((m, rows))
+        (self.prior_mean, self.mean_rows), \
+            (self.prior_logstd, self.logstd_rows) = out
+
     # -- building blocks -----------------------------------------------------
+    def _load_state(self, stream):
+        """The latents -> the packed working state q_new."""
+        if not self.packed:
+            self.q_new.copy_(self.q_rows[0])
+            return
+        for k, qk in enumerate(self.q_rows):
+            _capi.call('zshmc_copy_rows',
+                       self.q_new.data_ptr() + 4 * self.offsets[k], self.ld,
+                       qk.data_ptr(), self.n_data[k], None, self.n_chains,
+                       self.n_data[k], stream)
+
+    def _store_state(self, stream):
+        """where(accept, q_new, q) for every latent (hmc.py:488-497)."""
+        for k, qk in enumerate(self.q_rows):
+            _capi.call('zshmc_copy_rows', qk.data_ptr(), self.n_data[k],
+                       self.q_new.data_ptr() + 4 * self.offsets[k], self.ld,
+                       self.accept.data_ptr(), self.n_chains, self.n_data[k],
+                       stream)
+
     def _likelihood(self, q, stream):
         """ll[c] and d ll / d operand at the operand derived from q."""
         w = self.operand if self.operand is not None else q
@@ -1239,21 +1312,26 @@ class _DenseLikelihoodPlan(_PlanBase):
             self.grad.data_ptr() if use_grad else None, self.width,
             _capi.ptr(self.operand), self.width, int(self.softmax),
             self.prior_mean.data_ptr(), self.mean_rows,
-            self.prior_logstd.data_ptr(), self.logstd_rows, self.mass_ptr(0),
+            self.prior_logstd.data_ptr(), self.logstd_rows,
+            self.mass_pack.data_ptr() if self.use_mass else None,
             None if eps_host is not None else self.state.data_ptr(),
             0.0 if eps_host is None else float(eps_host), float(kick),
             float(drift), float(self.lik_scale()), self.n_chains,
-            self.n_data[0],
+            self.n_total, self.ld,
             self.ll.data_ptr() if use_grad else None, _capi.ptr(lp_out),
             _capi.ptr(kinetic), stream)
 
     def _momentum(self, t, stream):
         _capi.call('zshmc_zero', self.kin_old.data_ptr(),
                    4 * self.n_chains, stream)
-        _capi.call('zshmc_momentum', self.p.data_ptr(), self.mass_ptr(0),
-                   self.n_chains, self.n_data[0], self.chain_offset,
-                   self.hmc.seed, t & 0xFFFFFFFF, 0, self.kin_old.data_ptr(),
-                   stream)
+        # per latent, with the latent's own counters (the generic plan's and
+        # regenerate_momentum's: Philox stream word = latent index)
+        for k, d in enumerate(self.n_data):
+            _capi.call('zshmc_momentum_rows',
+                       self.p.data_ptr() + 4 * self.offsets[k], self.ld,
+                       self.mass_ptr(k), self.n_chains, d, self.chain_offset,
+                       self.hmc.seed, t & 0xFFFFFFFF, k,
+                       self.kin_old.data_ptr(), stream)
 
     def _first_evaluation(self, q, stream):
         """operand(q), then likelihood + gradient at q (self.ll, self.grad)."""
@@ -1275,7 +1353,7 @@ class _DenseLikelihoodPlan(_PlanBase):
 
     def begin_search(self, t, stream):
         self._momentum(t, stream)
-        self.q_new.copy_(self.q_flat)
+        self._load_state(stream)
         self._first_evaluation(self.q_new, stream)
         self._search_cache = (self.ll.clone(), self.grad.clone(),
                               None if self.operand is None
@@ -1287,7 +1365,7 @@ class _DenseLikelihoodPlan(_PlanBase):
         copy: config 5 holds 21 GB per [rows, K] buffer), the evaluation from
         the search cache."""
         ll0, g0, op0 = self._search_cache
-        self.q_new.copy_(self.q_flat)
+        self._load_state(stream)
         self._momentum(t, stream)
         self.ll.copy_(ll0)
         self.grad.copy_(g0)
@@ -1321,7 +1399,7 @@ class _DenseLikelihoodPlan(_PlanBase):
             self._restore_start(t, stream)
             self._search_cache = None
         else:
-            q.copy_(self.q_flat)
+            self._load_state(stream)
             self._momentum(t, stream)
             self._first_evaluation(q, stream)
         _capi.call('zshmc_zero', self.kin_new.data_ptr(), 4 * self.n_chains,
@@ -1347,9 +1425,7 @@ class _DenseLikelihoodPlan(_PlanBase):
                    self.hamiltonian.data_ptr(), self.log_prob.data_ptr(),
                    self.accept.data_ptr(), self.acc_sum.data_ptr(),
                    self.flags.data_ptr(), stream)
-        _capi.call('zshmc_select_rows', self.q[0].data_ptr(), q.data_ptr(),
-                   self.accept.data_ptr(), self.n_chains, self.n_data[0],
-                   stream)
+        self._store_state(stream)
 
 
 def _to_row_period(param, chain_shape, n_data):
@@ -1420,24 +1496,35 @@ def _summands_of(lp, nodes):
     return picked
 
 
+class _Unsupported(ValueError):
+    """The model is outside what a native plan handles: the caller falls back
+    to the generic plan."""
+
+
 def _try_dense_likelihood_plan(hmc, meta_bn, names, values, chain_shape,
                                device):
     from .distributions import Bernoulli, UnnormalizedMultinomial
     if not isinstance(meta_bn, MetaBayesianNet):
         return None
-    if len(names) != 1:
+    n_chain = len(chain_shape)
+    # every latent: one data axis, or none (a per-chain scalar: a bias)
+    if any(q.dim() not in (n_chain, n_chain + 1) or q.data_ptr() % 16 != 0 or
+           not q.is_contiguous() or q.dtype != torch.float32
+           for q in values):
         return None
-    name, q = names[0], values[0]
-    if q.dim() != len(chain_shape) + 1:
+    sizes = [int(q.shape[-1]) if q.dim() == n_chain + 1 else 1
+             for q in values]
+    if min(sizes) < 1 or sum(sizes) > 1024:
         return None
-    D = int(q.shape[-1])
-    if D % 4 != 0 or D < 4 or D > 256 or q.data_ptr() % 16 != 0:
+    if len(names) > 1 and meta_bn.log_joint is not None:
         return None
 
-    def analyse(value):
-        """(kind, [prior mean, prior spread-as-logstd, inner, observation])."""
+    def analyse(vals):
+        """(kind, [(prior mean, prior spread)], [inner tensors], observation)
+        for the latents given as `vals`, or None."""
         bn = meta_bn.observe(**merge_dicts(
-            {name: hmc._as_symbol(value)}, hmc._resolved_observed()))
+            {n: hmc._as_symbol(v) for n, v in zip(names, vals)},
+            hmc._resolved_observed()))
         stoch = [n for n in bn.nodes.values()
                  if isinstance(n, StochasticTensor)]
         if meta_bn.log_joint is not None:
@@ -1447,35 +1534,53 @@ def _try_dense_likelihood_plan(hmc, meta_bn, names, values, chain_shape,
             # -- checked on the autograd graph (a tempered or re-weighted
             # joint, e.g. AIS's, has multiplications on top and is refused)
             stoch = _summands_of(bn.log_joint(), stoch) \
-                if value.requires_grad else [
+                if vals[0].requires_grad else [
                     n for n in stoch if n.name in analyse.accepted]
             if stoch is None:
                 return None
             analyse.accepted = [n.name for n in stoch]
-        if len(stoch) != 2:
+        if len(stoch) != len(names) + 1:
             return None
-        prior = [n for n in stoch if n.name == name]
-        lik = [n for n in stoch if n.name != name]
-        if len(prior) != 1 or len(lik) != 1 or not lik[0].is_observed():
+        lik = [n for n in stoch if n.name not in names]
+        if len(lik) != 1 or not lik[0].is_observed():
             return None
-        pd, ld = prior[0].dist, lik[0].dist
-        if type(pd) is not Normal or pd.group_ndims != 1 or \
-                pd.use_path_derivative:
-            return None
-        if pd.mean.requires_grad or pd.given_spread[1].requires_grad:
-            return None
+        priors = []
+        for name, v in zip(names, vals):
+            node = [n for n in stoch if n.name == name]
+            if len(node) != 1:
+                return None
+            pd = node[0].dist
+            if type(pd) is not Normal or pd.use_path_derivative or \
+                    pd.group_ndims != v.dim() - n_chain:
+                return None
+            # (a prior whose parameters depend on another latent -- a
+            # hierarchical scale -- requires grad here: the generic plan)
+            if pd.mean.requires_grad or pd.given_spread[1].requires_grad:
+                return None
+            priors.append((pd.mean, pd.given_spread))
+        ld = lik[0].dist
         obs = lik[0].tensor
         lazy = getattr(ld, '_lazy', None)
         if lazy is None:
             return None
         if type(ld) is Bernoulli:
-            if ld.group_ndims != 1 or lazy.w is not value or \
-                    lazy.X.requires_grad or obs.dim() != 1 or \
-                    obs.shape[0] != lazy.X.shape[0] or obs.requires_grad:
+            if ld.group_ndims != 1 or lazy.design_requires_grad() or \
+                    obs.dim() != 1 or obs.shape[0] != lazy.n_rows or \
+                    obs.requires_grad or len(lazy.terms) != len(vals):
                 return None
-            return 'linear_bernoulli', [pd.mean, pd.given_spread, lazy.X, obs]
+            # one term per latent, in the order of the latents
+            inner = []
+            for v in vals:
+                term = [t for t in lazy.terms if t[0] is v]
+                if len(term) != 1 or term[0][2] != (v.dim() == n_chain):
+                    return None
+                inner.append(term[0][1])
+            return 'linear_bernoulli', priors, inner, obs
         if type(ld) is UnnormalizedMultinomial:
-            if ld.group_ndims != 0 or ld.normalize_logits or \
+            value = vals[0]
+            if len(vals) != 1 or value.dim() != n_chain + 1 or \
+                    value.shape[-1] % 4 != 0 or value.shape[-1] > 256 or \
+                    ld.group_ndims != 0 or ld.normalize_logits or \
                     lazy.phi.requires_grad or obs.requires_grad:
                 return None
             if lazy.softmax_source is not None:
@@ -1491,33 +1596,24 @@ def _try_dense_likelihood_plan(hmc, meta_bn, names, values, chain_shape,
                     len(gs) - 1 <= len(batch) and
                     gs[:-1] == batch[len(batch) - (len(gs) - 1):]):
                 return None
-            return 'mixture_multinomial', [pd.mean, pd.given_spread, lazy.phi, obs]
+            return 'mixture_multinomial', priors, [lazy.phi], obs
         return None
 
     analyse.accepted = []
-    found = analyse(q.detach().requires_grad_(True))
+    found = analyse([q.detach().requires_grad_(True) for q in values])
     if found is None:
         return None
     kind = found[0]
-    # prior parameters that do not fit the row-period addressing (more axes
-    # than the latent, leading axes that are neither 1 nor the chain axes):
-    # the generic plan, not an exception out of HMC.sample
-    try:
-        _to_row_period(found[1][0], chain_shape, D)
-        spread = found[1][1][1]
-        _to_row_period(spread, chain_shape, D)
-    except (RuntimeError, ValueError):
-        return None
 
     # The per-run re-evaluation of the model function only has to find the
-    # parameter tensors again, so it is given a META tensor for the latent:
-    # whatever the function computes from it before the lazy contraction
+    # parameter tensors again, so it is given META tensors for the latents:
+    # whatever the function computes from them before the lazy contraction
     # (torch.softmax(eta, -1), lntm_mcem.py:39) is shape arithmetic, not a
     # launch and not a [rows, K] temporary on the device.  A function that
-    # does more with the latent than that (mixes it with device tensors)
-    # fails on the meta tensor and is evaluated on the latent itself from
-    # then on.
-    q_meta = torch.empty_like(q, device='meta')
+    # does more with a latent than that (mixes it with device tensors)
+    # fails on the meta tensor and is evaluated on the latents themselves
+    # from then on.
+    q_meta = [torch.empty_like(q, device='meta') for q in values]
     on_meta = [True]
 
     def probe():
@@ -1530,15 +1626,22 @@ def _try_dense_likelihood_plan(hmc, meta_bn, names, values, chain_shape,
             if f is None or f[0] != kind:
                 on_meta[0], f = False, None
         if f is None:
-            f = analyse(q)
+            f = analyse(list(values))
         if f is None or f[0] != kind:
             raise ValueError(
                 "HMC (native %s plan): the model changed structure between "
                 "runs; build a new HMC." % kind)
-        return f[1]
+        return f[1], f[2], f[3]
 
-    return _DenseLikelihoodPlan(hmc, names, values, chain_shape, device, probe,
-                                kind)
+    # prior parameters that do not fit the row-period addressing (more axes
+    # than the latent, leading axes that are neither 1 nor the chain axes,
+    # different periods for different latents): the generic plan, not an
+    # exception out of HMC.sample
+    try:
+        return _DenseLikelihoodPlan(hmc, names, values, chain_shape, device,
+                                    probe, kind)
+    except _Unsupported:
+        return None
 
 
 def _to_data_shape(param, data_shape):
