@@ -29,6 +29,20 @@ def blr_problem():
                 q0=(0.1 * rng.normal(size=(n_chains, D))).astype(np.float32))
 
 
+def blrb_problem():
+    """Weights (13: not a multiple of 4) + a per-chain scalar bias, written
+    with the literal spelling: the packed state of the native plan."""
+    rng = np.random.RandomState(33)
+    n_rows, D, n_chains = 60, 13, 14
+    X = rng.normal(size=(n_rows, D)).astype(np.float32)
+    w = rng.normal(size=D).astype(np.float32)
+    y = (rng.uniform(size=n_rows) < 1 / (1 + np.exp(-X @ w - 0.5))
+         ).astype(np.float32)
+    return dict(X=X, y=y,
+                q0=(0.1 * rng.normal(size=(n_chains, D))).astype(np.float32),
+                b0=(0.1 * rng.normal(size=n_chains)).astype(np.float32))
+
+
 def build(zs, torch, dev, family, lo, hi, adapt, sharding, native, seed=21):
     """(hmc, sample_op, info, latent, flag placeholders) of rows [lo, hi)."""
     if family == 'lntm':
@@ -52,6 +66,25 @@ def build(zs, torch, dev, family, lo, hi, adapt, sharding, native, seed=21):
         observed = {'x': t['x']}
         name, plan = 'eta', 'mixture_multinomial'
         kw = dict(step_size=5e-3, n_leapfrogs=5, target_acceptance_rate=0.6)
+    elif family == 'blrb':
+        p = blrb_problem()
+        t = {k: torch.tensor(v, device=dev) for k, v in p.items()}
+        n, D = hi - lo, p['q0'].shape[1]
+
+        @zs.meta_bayesian_net()
+        def model():
+            bn = zs.BayesianNet()
+            w = bn.normal('w', torch.zeros(D, device=dev), std=1.,
+                          n_samples=n, group_ndims=1)
+            b = bn.normal('b', torch.zeros((), device=dev), std=2.,
+                          n_samples=n)
+            bn.bernoulli('y', w.tensor @ t['X'].t() + b.tensor[:, None],
+                         group_ndims=1, dtype=torch.float32)
+            return bn
+        m = model()
+        observed = {'y': t['y']}
+        name, plan = 'w', 'linear_bernoulli'
+        kw = dict(step_size=0.02, n_leapfrogs=6, target_acceptance_rate=0.8)
     else:
         p = blr_problem()
         t = {k: torch.tensor(v, device=dev) for k, v in p.items()}
@@ -70,14 +103,19 @@ def build(zs, torch, dev, family, lo, hi, adapt, sharding, native, seed=21):
         name, plan = 'w', 'linear_bernoulli'
         kw = dict(step_size=0.02, n_leapfrogs=6, target_acceptance_rate=0.8)
     q = t['q0'][lo:hi].clone().contiguous()
+    latent = {name: q}
+    if family == 'blrb':
+        latent['b'] = t['b0'][lo:hi].clone().contiguous()
     flags = None
     if adapt:
         flags = (zs.placeholder(bool), zs.placeholder(bool))
         kw.update(adapt_step_size=flags[0], adapt_mass=flags[1],
                   mass_collect_iters=MASS_COLLECT)
     hmc = zs.HMC(seed=seed, sharding=sharding, native_plans=native, **kw)
-    op, info = hmc.sample(m, observed, {name: q})
+    op, info = hmc.sample(m, observed, latent)
     assert hmc.plan_kind == (plan if native else 'generic'), hmc.plan_kind
+    if len(latent) > 1:     # reported side by side: [n, D + 1]
+        q = [latent['w'], latent['b']]
     return hmc, op, info, q, flags
 
 
@@ -102,12 +140,14 @@ def run(zs, torch, dev, family, lo, hi, adapt, sharding, native,
             eps.append(float(info.updated_step_size.item()))
             hmc.get_state()
     hmc.check_numerics()
+    if isinstance(q, list):
+        q = torch.cat([v.reshape(v.shape[0], -1) for v in q], 1)
     out = dict(q=q.cpu().numpy(),
                acc=info.acceptance_rate.cpu().numpy(),
                step_size=float(info.updated_step_size.item()),
                state=hmc.get_state()['state'].numpy())
     if adapt:
-        out['mass'] = hmc._plan.mass[0].cpu().numpy()
+        out['mass'] = torch.cat(list(hmc._plan.mass)).cpu().numpy()
     if eps:
         out['eps'] = np.array(eps)
     return out

@@ -21,7 +21,7 @@ def main(out_dir):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     dev = torch.device('cuda', 0)
     out = {}
-    for family in ('lntm', 'blr'):
+    for family in ('lntm', 'blr', 'blrb'):
         prob = getattr(cases, family + '_problem')()
         lo, hi = shard_bounds(prob['q0'].shape[0], rank, world)
         for native in (True, False):

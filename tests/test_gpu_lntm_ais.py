@@ -28,7 +28,8 @@ def _softmax(a):
     return e / e.sum(-1, keepdims=True)
 
 
-def test_lntm_estep_matches_oracle(env):
+@pytest.mark.parametrize('native', [True, False])
+def test_lntm_estep_matches_oracle(env, native):
     zs, torch, dev = env
     n_chains, n_docs, K, V = 3, 7, 5, 40
     rng = np.random.RandomState(0)
@@ -63,13 +64,13 @@ def test_lntm_estep_matches_oracle(env):
     eta_t = T(eta0)
     kw = dict(step_size=1e-3, n_leapfrogs=8, adapt_step_size=True,
               adapt_mass=True, target_acceptance_rate=0.6, seed=21)
-    hmc = zs.HMC(**kw)
+    hmc = zs.HMC(native_plans=native, **kw)
     op, info = hmc.sample(model, {'x': x_t}, {'eta': eta_t})
-    # (the literal spelling of lntm_mcem.py:39-46 is recognised symbolically,
-    # but K = 5 is not a multiple of 4: the native plan's rows are 16-byte
-    # groups, so this model samples on the generic plan -- with the fused
-    # likelihood op inside it)
-    assert hmc.plan_kind == 'generic'
+    # (the literal spelling of lntm_mcem.py:39-46 is recognised symbolically;
+    # K = 5 is not a multiple of 4: the native plan pads its rows to 8 floats
+    # and keeps the padding out of the prior and the softmax; the generic
+    # plan runs autograd around the same fused likelihood)
+    assert hmc.plan_kind == ('mixture_multinomial' if native else 'generic')
     assert tuple(info.acceptance_rate.shape) == (n_chains, n_docs)
 
     def lj(q):

@@ -3,7 +3,9 @@
 topic-model E step (BASELINE configs[4] family, `_DenseLikelihoodPlan`, mass
 adaptation on: ONE all-reduce of [sum acc, flag, colsum[2 K]] per
 transition) and of Bayesian logistic regression, on the native plans and on
-the autograd-driven generic plan.  Adaptation off: the rank-concatenated
+the autograd-driven generic plan ('blrb': weights of a size that is not a
+multiple of 4 plus a per-chain bias -- the native plan's packed state, two
+latents' column sums in the one all-reduce).  Adaptation off: the rank-concatenated
 states equal the single-process run bit for bit (RNG keyed by the GLOBAL
 chain index; per-document prior rows addressed with a row period under the
 chain offset).  Adaptation on: step size, tuner state and mass agree across
@@ -47,7 +49,7 @@ def ranks(tmp_path_factory):
     return [np.load(str(out / ('rank%d.npz' % i))) for i in range(2)]
 
 
-@pytest.mark.parametrize('family', ['lntm', 'blr'])
+@pytest.mark.parametrize('family', ['lntm', 'blr', 'blrb'])
 @pytest.mark.parametrize('native', [True, False])
 def test_sharded_plan_matches_single_process(ranks, family, native):
     import torch

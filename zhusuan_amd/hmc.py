@@ -1579,7 +1579,7 @@ def _try_dense_likelihood_plan(hmc, meta_bn, names, values, chain_shape,
         if type(ld) is UnnormalizedMultinomial:
             value = vals[0]
             if len(vals) != 1 or value.dim() != n_chain + 1 or \
-                    value.shape[-1] % 4 != 0 or value.shape[-1] > 256 or \
+                    value.shape[-1] > 256 or \
                     ld.group_ndims != 0 or ld.normalize_logits or \
                     lazy.phi.requires_grad or obs.requires_grad:
                 return None
