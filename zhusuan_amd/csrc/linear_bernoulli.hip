@@ -804,7 +804,11 @@ extern "C" int zshmc_linear_bernoulli_log_lik(const float* W, const float* X,
              "zshmc_linear_bernoulli_log_lik: 1 <= n_splits <= 64 and a "
              "workspace of n_splits*n_chains*(n_features+1) floats when > 1");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (n_features > 256) {
+  static const bool split256 = [] {
+    const char* e = getenv("ZSHMC_LB_SPLIT256");
+    return e && e[0] == '1';
+  }();
+  if (n_features > 256 || (n_features == 256 && split256)) {
     ZS_REQUIRE(!grad_w || (reinterpret_cast<uintptr_t>(grad_w) & 15) == 0,
                "zshmc_linear_bernoulli_log_lik: grad_w must be 16-byte aligned");
     return linear_bernoulli_wide(W, X, y, n_chains, n_rows, n_features, log_lik,

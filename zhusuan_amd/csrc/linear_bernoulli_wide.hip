@@ -43,7 +43,8 @@ constexpr int kWR = 32;  // data rows per tile
 template <int BYTES>
 __device__ __forceinline__ void wide_dma_row(const float* src, uint32_t dst,
                                              uint32_t lane) {
-  static_assert(BYTES == 16 || BYTES == 8, "a slice row is 1 KB or 512 B");
+  static_assert(BYTES == 16 || BYTES == 8 || BYTES == 4,
+                "a slice row is 1 KB, 512 B or 256 B");
   if constexpr (BYTES == 16) {
     const uint32_t voff = lane * 16u;
     asm volatile(
@@ -53,7 +54,7 @@ __device__ __forceinline__ void wide_dma_row(const float* src, uint32_t dst,
         :
         : "v"(voff), "s"(src), "s"(dst)
         : "memory");
-  } else {
+  } else if constexpr (BYTES == 8) {
     const uint32_t voff = lane * 4u;
     asm volatile(
         "s_mov_b32 m0, %2\n\t"
@@ -63,19 +64,33 @@ __device__ __forceinline__ void wide_dma_row(const float* src, uint32_t dst,
         :
         : "v"(voff), "s"(src), "s"(dst)
         : "memory");
+  } else {
+    const uint32_t voff = lane * 4u;
+    asm volatile(
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dword %0, %1"
+        :
+        : "v"(voff), "s"(src), "s"(dst)
+        : "memory");
   }
 }
 
+// (D = 256: an A/B of this decomposition against the 64-chain-block kernel of
+// csrc/linear_bernoulli.hip -- 54 KB of LDS and ~100 registers let two
+// workgroups share a CU; ZSHMC_LB_SPLIT256=1 routes 256-wide calls here)
 template <int D, bool GRAD>
-__global__ __launch_bounds__(256, 1) void linear_bernoulli_wide_kernel(
+__global__ __launch_bounds__(256, D == 256 ? 2 : 1) void linear_bernoulli_wide_kernel(
     const float* __restrict__ W, const float* __restrict__ X,
     const float* __restrict__ y, int64_t C, int64_t N, int64_t ldw,
     int64_t ldx, float* __restrict__ ll, float* __restrict__ gW) {
-  static_assert(D == 512 || D == 1024, "padded widths of the wide kernel");
+  static_assert(D == 256 || D == 512 || D == 1024,
+                "padded widths of the wide kernel");
   constexpr int FQ = D / 4;    // features per wave
   constexpr int LDQ = FQ + 4;  // padded LDS row: conflict-free b128 reads
   constexpr int KK = FQ / 8;   // phase-1 steps of 4 MFMAs (8 features)
-  constexpr int NT = FQ / 32;  // 32-wide feature blocks = accumulators (4, 8)
+  constexpr int NT = FQ / 32;  // 32-wide feature blocks = accumulators (2, 4, 8)
+  typedef float w2 __attribute__((ext_vector_type(2)));
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* __restrict__ sX = reinterpret_cast<float*>(smem);  // [4][kWR][LDQ]
   float* __restrict__ sY = sX + 4 * kWR * LDQ;              // [2][kWR]
@@ -239,14 +254,23 @@ __global__ __launch_bounds__(256, 1) void linear_bernoulli_wide_kernel(
         const w4 rs = *reinterpret_cast<const w4*>(sR + (g * 64 + lane) * 4);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const float* __restrict__ xr = sXw + (q + 8 * g + 4 * hi) * LDQ + lo * 4;
+          const float* __restrict__ xrow = sXw + (q + 8 * g + 4 * hi) * LDQ;
+          if constexpr (NT == 2) {  // accumulator t: feature lo*2 + t
+            const w2 xv = *reinterpret_cast<const w2*>(xrow + lo * 2);
 #pragma unroll
-          for (int t2 = 0; t2 < NT / 4; ++t2) {
-            const w4 xv = *reinterpret_cast<const w4*>(xr + t2 * 128);
+            for (int m = 0; m < 2; ++m)
+              G[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(rs[q], xv[m], G[m], 0,
+                                                          0, 0);
+          } else {
+            const float* __restrict__ xr = xrow + lo * 4;
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
-              G[t2 * 4 + m] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                  rs[q], xv[m], G[t2 * 4 + m], 0, 0, 0);
+            for (int t2 = 0; t2 < NT / 4; ++t2) {
+              const w4 xv = *reinterpret_cast<const w4*>(xr + t2 * 128);
+#pragma unroll
+              for (int m = 0; m < 4; ++m)
+                G[t2 * 4 + m] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                    rs[q], xv[m], G[t2 * 4 + m], 0, 0, 0);
+            }
           }
         }
         if (more) {
@@ -269,12 +293,16 @@ __global__ __launch_bounds__(256, 1) void linear_bernoulli_wide_kernel(
     for (int r = 0; r < 16; ++r) {
       const int pos = (r & 3) + 8 * (r >> 2) + 4 * hi;
       if (pos < n_valid) {
-        float* __restrict__ grow = gW + (c0 + pos) * ldw + f * FQ + lo * 4;
+        float* __restrict__ grow = gW + (c0 + pos) * ldw + f * FQ;
+        if constexpr (NT == 2) {
+          *reinterpret_cast<w2*>(grow + lo * 2) = w2{G[0][r], G[1][r]};
+        } else {
 #pragma unroll
-        for (int t2 = 0; t2 < NT / 4; ++t2)
-          *reinterpret_cast<w4*>(grow + t2 * 128) =
-              w4{G[t2 * 4][r], G[t2 * 4 + 1][r], G[t2 * 4 + 2][r],
-                 G[t2 * 4 + 3][r]};
+          for (int t2 = 0; t2 < NT / 4; ++t2)
+            *reinterpret_cast<w4*>(grow + lo * 4 + t2 * 128) =
+                w4{G[t2 * 4][r], G[t2 * 4 + 1][r], G[t2 * 4 + 2][r],
+                   G[t2 * 4 + 3][r]};
+        }
       }
     }
   }
@@ -359,6 +387,9 @@ int linear_bernoulli_wide(const float* W, const float* X, const float* y,
                           int64_t n_chains, int64_t n_rows, int64_t n_features,
                           float* ll, float* gW, int n_splits, float* workspace,
                           hipStream_t s) {
+  if (n_features == 256)
+    return launch_wide<256>(W, X, y, n_chains, n_rows, ll, gW, s, n_splits,
+                            workspace);
   if (n_features == 512)
     return launch_wide<512>(W, X, y, n_chains, n_rows, ll, gW, s, n_splits,
                             workspace);
