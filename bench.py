@@ -16,7 +16,9 @@ HBM before the timed region.  Prints ONE JSON line (see the task contract):
               of the reference's own hmc.py over the TensorFlow-API shim
   extra_configs = BASELINE configs[2] (logistic regression, 10^6 x 256, 32 768
               chains) and configs[4] (topic model, 5 000 docs x 128 topics),
-              MFMA-bound, through the native plans
+              MFMA-bound, through the native plans; and, beyond
+              BASELINE.json, a 1 000-feature + bias regression (two latents on
+              the packed native plan, the feature-split MFMA kernel)
 
     python bench.py --gpus 1 --steps 200 --warmup 20
     python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8
@@ -432,6 +434,61 @@ def extra_config3(torch, zs, dev, n_rows=1000000, n_chains=32768, n_feat=256,
         'roofline': _mfma_roofline(
             'linear_bernoulli_kernel_v2<%d>' % n_feat, kern_ms, flop_eval,
             n_leapfrogs + 1, ms),
+    }
+
+
+def extra_wide_regression(torch, zs, dev, n_rows=65536, n_chains=8192,
+                          n_feat=1000, n_leapfrogs=10, n_warm=4, n_timed=3):
+    """Beyond BASELINE.json: logistic regression with
+    1 000 features AND a per-chain bias, written `w @ X.T + b[:, None]`: two
+    Normal-prior latents on the native plan's packed state (rows of 1 004
+    floats), likelihood on the feature-split MFMA kernel
+    (csrc/linear_bernoulli_wide.hip, padded width 1 024)."""
+    g = torch.Generator(device=dev).manual_seed(0)
+    X = torch.randn(n_rows, n_feat, device=dev, generator=g)
+    w_true = torch.randn(n_feat, device=dev, generator=g)
+    y = (torch.rand(n_rows, device=dev, generator=g) < torch.sigmoid(
+        X @ w_true / n_feat ** 0.5 + 0.3)).float()
+    zero, one = torch.zeros(n_feat, device=dev), torch.ones(n_feat, device=dev)
+
+    @zs.meta_bayesian_net()
+    def blr():
+        bn = zs.BayesianNet()
+        w = bn.normal('w', zero, std=one, n_samples=n_chains, group_ndims=1)
+        b = bn.normal('b', torch.zeros((), device=dev), std=2.,
+                      n_samples=n_chains)
+        bn.bernoulli('y', w.tensor @ X.t() + b.tensor[:, None], group_ndims=1,
+                     dtype=torch.float32)
+        return bn
+    w = (w_true / n_feat ** 0.5).repeat(n_chains, 1).contiguous()
+    b = torch.full((n_chains,), 0.3, device=dev)
+    # fixed step size ~ posterior width (1/sqrt(N)) * D^(-1/4)
+    eps = 1.0 / n_rows ** 0.5 / n_feat ** 0.25
+    hmc = zs.HMC(step_size=eps, n_leapfrogs=n_leapfrogs, seed=4)
+    op, info = hmc.sample(blr(), {'y': y}, {'w': w, 'b': b})
+    elapsed, kern_ms, acc = _time_transitions(
+        torch, hmc, op, info, {}, n_warm, n_timed, torch.cuda.synchronize)
+    ms = elapsed / n_timed * 1e3
+    width = hmc._plan.width
+    flop_eval = 4.0 * n_rows * width * n_chains
+    return {
+        'workload': 'beyond BASELINE.json: logistic regression, %d features + '
+                    'a per-chain bias (two latents, literal `w @ X.T + '
+                    'b[:, None]`), synthetic %d rows, %d chains, L=%d, fixed '
+                    'step size %.2e' % (n_feat, n_rows, n_chains, n_leapfrogs,
+                                        eps),
+        'plan': hmc.plan_kind,
+        'packed_row_floats': hmc._plan.ld,
+        'ms_per_step': ms,
+        'steps': n_timed,
+        'value': n_chains * n_leapfrogs / (ms * 1e-3),
+        'unit': 'chain-leapfrog-steps/s',
+        'mean_acceptance': acc,
+        'roofline': dict(_mfma_roofline(
+            'linear_bernoulli_wide_kernel<%d>' % width, kern_ms, flop_eval,
+            n_leapfrogs + 1, ms),
+            note='flops counted at the padded width %d (%d useful columns)'
+                 % (width, n_feat + 1)),
     }
 
 
@@ -1085,7 +1142,8 @@ def main():
         extras = []
         if world == 1:
             todo = ((extra_config1, {}), (extra_config3, {}),
-                    (extra_config5, {'n_chains': args.config5_chains}))
+                    (extra_config5, {'n_chains': args.config5_chains}),
+                    (extra_wide_regression, {}))
         else:
             todo = ((lntm_workload, dict(
                 n_chains=args.lntm_chains_per_gpu,
