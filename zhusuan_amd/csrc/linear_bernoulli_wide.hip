@@ -39,6 +39,18 @@ typedef float w16 __attribute__((ext_vector_type(16)));
 constexpr int kWC = 32;  // chains per workgroup
 constexpr int kWR = 32;  // data rows per tile
 
+// Sets of X slices in LDS.  Two fit at D = 512 (2 x 66 KB: the DMA of tile
+// t+1 then runs under the whole of tile t) -- measured, no gain: 110.4 against
+// 110.0 TFLOP/s with gradient, 91 against 96 without
+// (profiles/r03x_lb_wide_buffers.txt).  What D = 512 loses against D = 1024 is
+// the fixed cost of a tile (two barriers, the 20 KB exchange, the residual:
+// ~3 600 cycles with one wave per SIMD and nobody to overlap it) over half the
+// MFMAs, not the exposed DMA.
+#ifndef ZS_LBW_BUF512
+#define ZS_LBW_BUF512 1
+#endif
+constexpr int wide_buffers(int d) { return d == 512 ? ZS_LBW_BUF512 : 1; }
+
 // global -> LDS, 16 or 8 (= 2 x 4) bytes per lane, LDS dest = dst + lane*BYTES
 template <int BYTES>
 __device__ __forceinline__ void wide_dma_row(const float* src, uint32_t dst,
@@ -91,9 +103,11 @@ __global__ __launch_bounds__(256, D == 256 ? 2 : 1) void linear_bernoulli_wide_k
   constexpr int KK = FQ / 8;   // phase-1 steps of 4 MFMAs (8 features)
   constexpr int NT = FQ / 32;  // 32-wide feature blocks = accumulators (2, 4, 8)
   typedef float w2 __attribute__((ext_vector_type(2)));
+  // X slices: one set (wide_buffers above; -DZS_LBW_BUF512=2: two at D = 512)
+  constexpr int kBuf = wide_buffers(D);
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* __restrict__ sX = reinterpret_cast<float*>(smem);  // [4][kWR][LDQ]
-  float* __restrict__ sY = sX + 4 * kWR * LDQ;              // [2][kWR]
+  float* __restrict__ sX = reinterpret_cast<float*>(smem);  // [kBuf][4][kWR][LDQ]
+  float* __restrict__ sY = sX + kBuf * 4 * kWR * LDQ;       // [2][kWR]
   float* __restrict__ sP = sY + 2 * kWR;                    // [4][4][64][4]
   float* __restrict__ sR = sP + 4 * 4 * 64 * 4;             // [4][64][4]
 
@@ -120,9 +134,10 @@ __global__ __launch_bounds__(256, D == 256 ? 2 : 1) void linear_bernoulli_wide_k
   // ---- this wave's X slice: global -> LDS by DMA, one row per instruction --
   // (hipcc does not count these loads: the explicit `s_waitcnt vmcnt(0)` at
   // the end of a tile lands them)
-  float* __restrict__ sXw = sX + f * kWR * LDQ;
+  float* __restrict__ sXw0 = sX + f * kWR * LDQ;
   const uint32_t dst_wave = __builtin_amdgcn_readfirstlane(
-      (uint32_t)reinterpret_cast<uintptr_t>(sXw));
+      (uint32_t)reinterpret_cast<uintptr_t>(sXw0));
+  constexpr int kSetFloats = 4 * kWR * LDQ;  // one set of four slices
   const int ldx32 = (int)ldx;
   struct TileSrc {
     const float* base;  // &X[n0, f*FQ]
@@ -133,10 +148,12 @@ __global__ __launch_bounds__(256, D == 256 ? 2 : 1) void linear_bernoulli_wide_k
     return TileSrc{X + n0 * ldx + f * FQ,
                    (int)(left < kWR - 1 ? left : kWR - 1)};
   };
-  auto dma_row = [&](const TileSrc& t, int row) {
+  auto dma_row = [&](const TileSrc& t, int row, int set = 0) {
     const int r = row < t.last ? row : t.last;
-    wide_dma_row<FQ / 16>(t.base + r * ldx32,
-                          dst_wave + (uint32_t)(row * LDQ * 4), (uint32_t)lane);
+    wide_dma_row<FQ / 16>(
+        t.base + r * ldx32,
+        dst_wave + (uint32_t)((set * kSetFloats + row * LDQ) * 4),
+        (uint32_t)lane);
   };
 
   w16 G[NT];
@@ -173,12 +190,20 @@ __global__ __launch_bounds__(256, D == 256 ? 2 : 1) void linear_bernoulli_wide_k
   float yr = 0.f;
   for (int64_t tile = tile_begin; tile < n_tiles; ++tile) {
     const int buf = (int)((tile - tile_begin) & 1);  // sY slot
+    const int xset = kBuf == 2 ? buf : 0;            // X slice set
+    const float* __restrict__ sXw = sXw0 + xset * kSetFloats;
     const bool more = tile + 1 < n_tiles;
     const int64_t n_next = (more ? tile + 1 : tile) * kWR;
     const TileSrc tnext = tile_src(n_next);
     if (tid < kWR) {
       const int64_t nr = n_next + tid;
       yr = nr < N ? y[nr] : 0.f;
+    }
+    if (kBuf == 2 && more) {
+      // the other set was last read in the previous tile's phase 3
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int j = 0; j < kWR; ++j) dma_row(tnext, j, xset ^ 1);
     }
 
     // ---- phase 1: partial logits over the wave's feature quarter -----------
@@ -205,7 +230,7 @@ __global__ __launch_bounds__(256, D == 256 ? 2 : 1) void linear_bernoulli_wide_k
     for (int g = 0; g < 4; ++g)
       *reinterpret_cast<w4*>(sP + ((f * 4 + g) * 64 + lane) * 4) =
           w4{S[g * 4], S[g * 4 + 1], S[g * 4 + 2], S[g * 4 + 3]};
-    if (!GRAD && more) {
+    if (kBuf == 1 && !GRAD && more) {
       // nothing reads the slice again: the next tile may come in now
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -273,7 +298,7 @@ __global__ __launch_bounds__(256, D == 256 ? 2 : 1) void linear_bernoulli_wide_k
             }
           }
         }
-        if (more) {
+        if (kBuf == 1 && more) {
           // rows 8g .. 8g+7 are consumed: their LDS reads have returned
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -343,9 +368,9 @@ static int launch_wide(const float* W, const float* X, const float* y,
                        int64_t C, int64_t N, float* ll, float* gW,
                        hipStream_t s, int n_splits, float* workspace) {
   constexpr int LDQ = D / 4 + 4;
-  const size_t lds =
-      (size_t)(4 * kWR * LDQ + 2 * kWR + 4 * 4 * 64 * 4 + 4 * 64 * 4) *
-      sizeof(float);
+  const size_t lds = (size_t)(wide_buffers(D) * 4 * kWR * LDQ + 2 * kWR +
+                              4 * 4 * 64 * 4 + 4 * 64 * 4) *
+                     sizeof(float);
   static bool attr = false;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute(
