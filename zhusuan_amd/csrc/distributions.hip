@@ -252,8 +252,13 @@ __global__ __launch_bounds__(256) void softmax_family_kernel(
 // Register-resident variant for rows of up to NPL*256 categories that are
 // 16-B aligned multiples of 4: the logits row is read ONCE into NPL float4 per
 // lane (chunk layout (k*64 + lane)*4), max / logsumexp / outputs come from
-// registers.  MODE as softmax_family_kernel.
-template <int MODE, int NPL>
+// registers.  MODE as softmax_family_kernel.  A wave works on U adjacent rows
+// at once: U = 1.  U = 2 (both rows' loads in flight before the first of the
+// two wave reductions per row, interleaved shuffle chains) was measured for
+// the slowest of these passes, the categorical gradient at [65 536, 1 024]:
+// 4.34-4.40 TB/s against 4.68 with one row (profiles/r03y_softmax_rows.txt)
+// -- the pass is not short of bytes in flight; -DZS_SMX_ROWS=2 keeps the A/B.
+template <int MODE, int NPL, int U>
 __global__ __launch_bounds__(256) void softmax_family_reg_kernel(
     const float* __restrict__ logits, const int64_t* __restrict__ labels,
     const float* __restrict__ given, const float* __restrict__ gout,
@@ -261,93 +266,150 @@ __global__ __launch_bounds__(256) void softmax_family_reg_kernel(
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
   const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x / 64);
-  for (int64_t r = wave; r < rows; r += n_waves) {
-    const float* __restrict__ row = logits + r * n_cat;
-    d4 x[NPL];
-    float mx = -INFINITY;
+  constexpr bool kKeepExp = MODE == 1 || MODE == 3;
+  for (int64_t r0 = wave * U; r0 < rows; r0 += n_waves * U) {
+    // rows r0 .. r0 + U - 1 of this trip (adjacent: U * n_cat contiguous
+    // floats per wave; wave-uniform, `on` masks the tail)
+    int64_t rr[U];
+    bool on[U];
+    d4 x[U][NPL];
+    float mx[U];
 #pragma unroll
-    for (int k = 0; k < NPL; ++k) {
-      const int64_t j0 = (int64_t)(k * 64 + lane) * 4;
-      if (j0 < n_cat) {
-        x[k] = *reinterpret_cast<const d4*>(row + j0);
-        mx = fmaxf(mx, fmaxf(fmaxf(x[k][0], x[k][1]), fmaxf(x[k][2], x[k][3])));
-      } else {
-        x[k] = d4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-      }
-    }
-    float lse = 0.f, inv_se = 0.f;
-    if (MODE < 2 || normalize) {
-      mx = wave_max(mx);
-      const float shift = isfinite(mx) ? mx : 0.f;
-      float se = 0.f;
-      // the gradients need softmax = exp(x - shift) / sum: keep the
-      // exponentials in place of x (one expf per element instead of two)
-      constexpr bool kKeepExp = MODE == 1 || MODE == 3;
-#pragma unroll
-      for (int k = 0; k < NPL; ++k)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float e = expf(x[k][j] - shift);
-          se += e;
-          if (kKeepExp) x[k][j] = e;
-        }
-      se = group_sum<64>(se);
-      lse = shift + logf(se);
-      inv_se = 1.0f / se;
-    }
-    if (MODE == 0) {
-      if (lane == 0) {
-        const int64_t kk = labels[r];
-        out[r] = (kk >= 0 && kk < n_cat) ? row[kk] - lse : NAN;
-      }
-    } else if (MODE == 1) {
-      const int64_t kk = labels[r];
-      const float g = gout[r];
+    for (int u = 0; u < U; ++u) {
+      rr[u] = r0 + u;
+      on[u] = rr[u] < rows;
+      if (!on[u]) rr[u] = r0;  // (re-reads row r0; nothing of it is stored)
+      const float* __restrict__ row = logits + rr[u] * n_cat;
+      mx[u] = -INFINITY;
 #pragma unroll
       for (int k = 0; k < NPL; ++k) {
-        const int64_t j0 = (int64_t)(k * 64 + lane) * 4;
+        const int j0 = (k * 64 + lane) * 4;
         if (j0 < n_cat) {
-          d4 o;
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            o[j] = g * ((j0 + j == kk ? 1.0f : 0.0f) - x[k][j] * inv_se);
-          *reinterpret_cast<d4*>(out + r * n_cat + j0) = o;
+          x[u][k] = *reinterpret_cast<const d4*>(row + j0);
+          mx[u] = fmaxf(mx[u], fmaxf(fmaxf(x[u][k][0], x[u][k][1]),
+                                     fmaxf(x[u][k][2], x[u][k][3])));
+        } else {
+          x[u][k] = d4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         }
       }
-    } else {
-      d4 gv[NPL];
-      float tot = 0.f, sdot = 0.f;
+    }
+    d4 gv[(MODE >= 2) ? U : 1][(MODE >= 2) ? NPL : 1];
+    if (MODE >= 2) {
 #pragma unroll
-      for (int k = 0; k < NPL; ++k) {
-        const int64_t j0 = (int64_t)(k * 64 + lane) * 4;
-        gv[k] = d4{0.f, 0.f, 0.f, 0.f};
-        if (j0 < n_cat) {
-          gv[k] = *reinterpret_cast<const d4*>(given + r * n_cat + j0);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            tot += gv[k][j];
-            if (MODE == 2) sdot += gv[k][j] * (x[k][j] - lse);
-          }
-        }
-      }
-      if (MODE == 2) {
-        sdot = group_sum<64>(sdot);
-        if (lane == 0) out[r] = sdot;
-      } else {
-        const float g = gout[r];
-        if (normalize) tot = group_sum<64>(tot);
+      for (int u = 0; u < U; ++u)
 #pragma unroll
         for (int k = 0; k < NPL; ++k) {
-          const int64_t j0 = (int64_t)(k * 64 + lane) * 4;
+          const int j0 = (k * 64 + lane) * 4;
+          gv[u][k] = d4{0.f, 0.f, 0.f, 0.f};
+          if (j0 < n_cat)
+            gv[u][k] =
+                *reinterpret_cast<const d4*>(given + rr[u] * n_cat + j0);
+        }
+    }
+    float lse[U], inv_se[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) lse[u] = inv_se[u] = 0.f;
+    if (MODE < 2 || normalize) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) mx[u] = wave_max(mx[u]);
+      float se[U], shift[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        shift[u] = isfinite(mx[u]) ? mx[u] : 0.f;
+        se[u] = 0.f;
+        // the gradients need softmax = exp(x - shift) / sum: keep the
+        // exponentials in place of x (one expf per element instead of two)
+#pragma unroll
+        for (int k = 0; k < NPL; ++k)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float e = expf(x[u][k][j] - shift[u]);
+            se[u] += e;
+            if (kKeepExp) x[u][k][j] = e;
+          }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) se[u] = group_sum<64>(se[u]);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        lse[u] = shift[u] + logf(se[u]);
+        inv_se[u] = 1.0f / se[u];
+      }
+    }
+    if (MODE == 0) {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (lane == 0 && on[u]) {
+          const int64_t kk = labels[rr[u]];
+          out[rr[u]] = (kk >= 0 && kk < n_cat)
+                           ? logits[rr[u] * n_cat + kk] - lse[u]
+                           : NAN;
+        }
+    } else if (MODE == 1) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (!on[u]) continue;
+        const int64_t k64 = labels[rr[u]];
+        const int kk = (k64 >= 0 && k64 < n_cat) ? (int)k64 : -1;
+        const float g = gout[rr[u]];
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+          const int j0 = (k * 64 + lane) * 4;
           if (j0 < n_cat) {
             d4 o;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              float v = gv[k][j];
-              if (normalize) v -= tot * (x[k][j] * inv_se);
-              o[j] = g * v;
+            for (int j = 0; j < 4; ++j)
+              o[j] = g * ((j0 + j == kk ? 1.0f : 0.0f) -
+                          x[u][k][j] * inv_se[u]);
+            *reinterpret_cast<d4*>(out + rr[u] * n_cat + j0) = o;
+          }
+        }
+      }
+    } else {
+      float tot[U], sdot[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        tot[u] = sdot[u] = 0.f;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            // (chunks past the row hold given = 0 and x = -inf: skipped)
+            const int j0 = (k * 64 + lane) * 4;
+            if (j0 < n_cat) {
+              tot[u] += gv[u][k][j];
+              if (MODE == 2) sdot[u] += gv[u][k][j] * (x[u][k][j] - lse[u]);
             }
-            *reinterpret_cast<d4*>(out + r * n_cat + j0) = o;
+          }
+      }
+      if (MODE == 2) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) sdot[u] = group_sum<64>(sdot[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (lane == 0 && on[u]) out[rr[u]] = sdot[u];
+      } else {
+        if (normalize) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) tot[u] = group_sum<64>(tot[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (!on[u]) continue;
+          const float g = gout[rr[u]];
+#pragma unroll
+          for (int k = 0; k < NPL; ++k) {
+            const int j0 = (k * 64 + lane) * 4;
+            if (j0 < n_cat) {
+              d4 o;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                float v = gv[u][k][j];
+                if (normalize) v -= tot[u] * (x[u][k][j] * inv_se[u]);
+                o[j] = g * v;
+              }
+              *reinterpret_cast<d4*>(out + rr[u] * n_cat + j0) = o;
+            }
           }
         }
       }
@@ -356,6 +418,10 @@ __global__ __launch_bounds__(256) void softmax_family_reg_kernel(
 }
 
 static inline int wave_row_grid(int64_t rows);
+
+#ifndef ZS_SMX_ROWS  // rows a wave of the register-resident kernel works on at once
+#define ZS_SMX_ROWS 1
+#endif
 
 template <int MODE>
 static bool launch_softmax_reg(const float* logits, const int64_t* labels,
@@ -368,14 +434,14 @@ static bool launch_softmax_reg(const float* logits, const int64_t* labels,
                   (MODE == 0 || MODE == 2 ||
                    (reinterpret_cast<uintptr_t>(out) & 15) == 0);
   if (!ok) return false;
-#define ZS_SMX(NPL)                                                            \
-  hipLaunchKernelGGL((softmax_family_reg_kernel<MODE, NPL>), dim3(grid),       \
+#define ZS_SMX(NPL, U)                                                         \
+  hipLaunchKernelGGL((softmax_family_reg_kernel<MODE, NPL, U>), dim3(grid),    \
                      dim3(256), 0, s, logits, labels, given, gout, out, rows,  \
                      n_cat, normalize)
-  if (n_cat <= 256) ZS_SMX(1);
-  else if (n_cat <= 512) ZS_SMX(2);
-  else if (n_cat <= 1024) ZS_SMX(4);
-  else ZS_SMX(8);
+  if (n_cat <= 256) ZS_SMX(1, ZS_SMX_ROWS);
+  else if (n_cat <= 512) ZS_SMX(2, ZS_SMX_ROWS);
+  else if (n_cat <= 1024) ZS_SMX(4, ZS_SMX_ROWS);
+  else ZS_SMX(8, 1);
 #undef ZS_SMX
   return true;
 }
