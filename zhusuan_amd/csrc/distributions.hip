@@ -264,7 +264,11 @@ __global__ __launch_bounds__(256) void softmax_family_reg_kernel(
     const float* __restrict__ given, const float* __restrict__ gout,
     float* __restrict__ out, int64_t rows, int64_t n_cat, int normalize) {
   const int lane = threadIdx.x & 63;
-  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+  // (wave-uniform by construction; said so to the compiler: row pointers,
+  // labels[r] and gout[r] become scalar loads issued at the top of a row)
+  const int64_t wave =
+      (int64_t)blockIdx.x * (blockDim.x / 64) +
+      __builtin_amdgcn_readfirstlane((int)(threadIdx.x / 64));
   const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x / 64);
   constexpr bool kKeepExp = MODE == 1 || MODE == 3;
   for (int64_t r0 = wave * U; r0 < rows; r0 += n_waves * U) {
@@ -274,11 +278,15 @@ __global__ __launch_bounds__(256) void softmax_family_reg_kernel(
     bool on[U];
     d4 x[U][NPL];
     float mx[U];
+    int64_t lab[U];
+    float gr[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       rr[u] = r0 + u;
       on[u] = rr[u] < rows;
       if (!on[u]) rr[u] = r0;  // (re-reads row r0; nothing of it is stored)
+      lab[u] = MODE < 2 ? labels[rr[u]] : 0;
+      gr[u] = (MODE == 1 || MODE == 3) ? gout[rr[u]] : 0.f;
       const float* __restrict__ row = logits + rr[u] * n_cat;
       mx[u] = -INFINITY;
 #pragma unroll
@@ -340,7 +348,7 @@ __global__ __launch_bounds__(256) void softmax_family_reg_kernel(
 #pragma unroll
       for (int u = 0; u < U; ++u)
         if (lane == 0 && on[u]) {
-          const int64_t kk = labels[rr[u]];
+          const int64_t kk = lab[u];
           out[rr[u]] = (kk >= 0 && kk < n_cat)
                            ? logits[rr[u] * n_cat + kk] - lse[u]
                            : NAN;
@@ -349,9 +357,9 @@ __global__ __launch_bounds__(256) void softmax_family_reg_kernel(
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         if (!on[u]) continue;
-        const int64_t k64 = labels[rr[u]];
+        const int64_t k64 = lab[u];
         const int kk = (k64 >= 0 && k64 < n_cat) ? (int)k64 : -1;
-        const float g = gout[rr[u]];
+        const float g = gr[u];
 #pragma unroll
         for (int k = 0; k < NPL; ++k) {
           const int j0 = (k * 64 + lane) * 4;
@@ -396,7 +404,7 @@ __global__ __launch_bounds__(256) void softmax_family_reg_kernel(
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           if (!on[u]) continue;
-          const float g = gout[rr[u]];
+          const float g = gr[u];
 #pragma unroll
           for (int k = 0; k < NPL; ++k) {
             const int j0 = (k * 64 + lane) * 4;
