@@ -8,9 +8,13 @@ symbolic latent (zhusuan_amd/_symbolic.py), the matmul stays symbolic, and
 log-likelihood of all chains and its gradient in one pass over X; the
 [n_chains, N] logits (131 GB at the default size) never exist in memory.
 (`zs.linear_logits(w, X)` is the explicit spelling of the same thing.)
+`--bias` adds a per-chain intercept b ~ N(0, 2^2), `logits = w @ X^T +
+b[:, None]`: two latents, still one fused likelihood (the sum lowers to one
+lazy operand; the sampler packs w and b side by side), and `--d` may be
+anything up to 1 024 -- not only a multiple of 4 below 256.
 
     python examples/logistic_regression_hmc.py [--n 1000000] [--d 256]
-        [--chains 32768] [--iters 100]
+        [--chains 32768] [--iters 100] [--bias]
 """
 import argparse
 import os
@@ -30,6 +34,8 @@ if __name__ == "__main__":
     ap.add_argument('--chains', type=int, default=4096)
     ap.add_argument('--iters', type=int, default=100)
     ap.add_argument('--leapfrogs', type=int, default=10)
+    ap.add_argument('--bias', action='store_true',
+                    help='add a per-chain intercept latent')
     args = ap.parse_args()
     zs.set_random_seed(7)
     dev = torch.device('cuda', 0)
@@ -38,16 +44,21 @@ if __name__ == "__main__":
     N, D, C = args.n, args.d, args.chains
     X = torch.randn(N, D, device=dev, generator=g) / D ** 0.5
     w_true = torch.randn(D, device=dev, generator=g) * 2.0
+    b_true = 0.5 if args.bias else 0.0
     y = (torch.rand(N, device=dev, generator=g) <
-         torch.sigmoid(X @ w_true)).to(torch.float32)
+         torch.sigmoid(X @ w_true + b_true)).to(torch.float32)
 
     @zs.meta_bayesian_net()
     def blr():
         bn = zs.BayesianNet()
         w = bn.normal('w', torch.zeros(D, device=dev), std=1.,
                       n_samples=C, group_ndims=1)
-        bn.bernoulli('y', w.tensor @ X.t(), group_ndims=1,
-                     dtype=torch.float32)
+        logits = w.tensor @ X.t()
+        if args.bias:
+            b = bn.normal('b', torch.zeros((), device=dev), std=2.,
+                          n_samples=C)
+            logits = logits + b.tensor[:, None]
+        bn.bernoulli('y', logits, group_ndims=1, dtype=torch.float32)
         return bn
 
     model = blr()
@@ -56,7 +67,11 @@ if __name__ == "__main__":
                  adapt_step_size=adapt, adapt_mass=adapt,
                  target_acceptance_rate=0.8)
     w = torch.zeros(C, D, device=dev)
-    sample_op, info = hmc.sample(model, {'y': y}, {'w': w})
+    latent = {'w': w}
+    if args.bias:
+        latent['b'] = torch.zeros(C, device=dev)
+    sample_op, info = hmc.sample(model, {'y': y}, latent)
+    print('plan:', hmc.plan_kind)
     burnin = args.iters // 2
     draws = []
     torch.cuda.synchronize()
@@ -70,7 +85,8 @@ if __name__ == "__main__":
                       float(info.updated_step_size),
                       info.log_prob.mean().item()))
         if i >= burnin:
-            draws.append(w.mean(0))
+            draws.append(torch.cat([w.mean(0), latent['b'].mean(0, True)])
+                         if args.bias else w.mean(0))
     torch.cuda.synchronize()
     dt = time.time() - t_start
     evals = args.iters * (args.leapfrogs + 1)
@@ -80,14 +96,17 @@ if __name__ == "__main__":
               4.0 * C * N * D * evals / dt / 1e12))
     post_mean = torch.stack(draws).mean(0)
     # Laplace check: the posterior mean should sit near the MAP estimate
-    wm = torch.zeros(D, device=dev, requires_grad=True)
+    # (with --bias the last entry is the intercept, prior N(0, 2^2))
+    wm = torch.zeros(D + int(args.bias), device=dev, requires_grad=True)
     opt = torch.optim.LBFGS([wm], max_iter=200, line_search_fn='strong_wolfe')
 
     def closure():
         opt.zero_grad()
-        z = X @ wm
+        z = X @ wm[:D] + (wm[D] if args.bias else 0.0)
         loss = torch.nn.functional.binary_cross_entropy_with_logits(
-            z, y, reduction='sum') + 0.5 * (wm ** 2).sum()
+            z, y, reduction='sum') + 0.5 * (wm[:D] ** 2).sum()
+        if args.bias:
+            loss = loss + 0.5 * (wm[D] / 2.0) ** 2
         loss.backward()
         return loss
     opt.step(closure)

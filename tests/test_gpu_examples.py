@@ -34,6 +34,17 @@ def test_logistic_regression_example():
     out = _run('examples/logistic_regression_hmc.py', '--n', '20000',
                '--chains', '512', '--iters', '60')
     assert '|posterior mean - MAP|' in out
+    assert 'plan: linear_bernoulli' in out
+
+
+def test_logistic_regression_example_wide_with_intercept():
+    """300 features + a per-chain intercept (two latents): still the native
+    plan, on the feature-split MFMA kernel; the example's own check (posterior
+    mean near the MAP estimate, intercept included) holds."""
+    out = _run('examples/logistic_regression_hmc.py', '--n', '20000',
+               '--d', '300', '--bias', '--chains', '512', '--iters', '60')
+    assert 'plan: linear_bernoulli' in out
+    assert '|posterior mean - MAP|' in out
 
 
 def test_lntm_example():
