@@ -187,6 +187,21 @@ __global__ __launch_bounds__(256, D == 256 ? 2 : 1) void linear_bernoulli_wide_k
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
+#ifdef ZS_LBW_TIMING  // debug: per-phase shader clocks of every wave of block 0
+  long long tacc[6] = {0, 0, 0, 0, 0, 0};
+  long long tmark = clock64();
+#define ZS_LBW_MARK(i)                                        \
+  {                                                           \
+    __builtin_amdgcn_sched_barrier(0);                        \
+    asm volatile("" ::"v"(G[0][0]), "v"(G[NT - 1][15]));      \
+    const long long _t = clock64();                           \
+    tacc[i] += _t - tmark;                                    \
+    tmark = _t;                                               \
+    __builtin_amdgcn_sched_barrier(0);                        \
+  }
+#else
+#define ZS_LBW_MARK(i)
+#endif
   float yr = 0.f;
   for (int64_t tile = tile_begin; tile < n_tiles; ++tile) {
     const int buf = (int)((tile - tile_begin) & 1);  // sY slot
@@ -236,7 +251,9 @@ __global__ __launch_bounds__(256, D == 256 ? 2 : 1) void linear_bernoulli_wide_k
 #pragma unroll
       for (int j = 0; j < kWR; ++j) dma_row(tnext, j);
     }
+    ZS_LBW_MARK(0)  // head + phase 1 + partials out
     __syncthreads();  // the four partials are in LDS
+    ZS_LBW_MARK(1)  // barrier 1
 
     // ---- residual of register group f (fixed summation order) --------------
     // Bernoulli._log_prob (univariate.py:398-403):
@@ -268,7 +285,9 @@ __global__ __launch_bounds__(256, D == 256 ? 2 : 1) void linear_bernoulli_wide_k
       ll_lane += (double)ll_tile;
       if (GRAD) *reinterpret_cast<w4*>(sR + (f * 64 + lane) * 4) = res;
     }
+    ZS_LBW_MARK(2)  // sum + residual
     __syncthreads();  // residuals published; sP free for the next tile
+    ZS_LBW_MARK(3)  // barrier 2
 
     if (GRAD) {
       // ---- phase 3: G[i, d] += sum_n R[n, i] X[n, d], d in the quarter -----
@@ -306,9 +325,18 @@ __global__ __launch_bounds__(256, D == 256 ? 2 : 1) void linear_bernoulli_wide_k
         }
       }
     }
+    ZS_LBW_MARK(4)  // phase 3 + DMA issue
     if (tid < kWR) sY[(buf ^ 1) * kWR + tid] = yr;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the slice has landed
+    ZS_LBW_MARK(5)  // DMA wait
   }
+#ifdef ZS_LBW_TIMING
+  if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && GRAD) {
+    for (int i = 0; i < 6; ++i) gW[f * 8 + i] = (float)tacc[i];
+    gW[f * 8 + 6] = (float)(n_tiles - tile_begin);
+  }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && GRAD) return;
+#endif
 
   // ---- epilogue -------------------------------------------------------------
   // G[t][r]: chain = c0 + (r&3) + 8*(r>>2) + 4*hi,
