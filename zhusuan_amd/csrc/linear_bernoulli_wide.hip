@@ -52,7 +52,11 @@ constexpr int kWR = 32;  // data rows per tile
 constexpr int wide_buffers(int d) { return d == 512 ? ZS_LBW_BUF512 : 1; }
 
 // global -> LDS, 16 or 8 (= 2 x 4) bytes per lane, LDS dest = dst + lane*BYTES
-template <int BYTES>
+// (HALF: a 512-byte row as the 16-byte form with the upper half of the wave
+// masked off -- one instruction, for the rows issued one at a time under
+// MFMAs -- instead of two dword forms, which do better issued back to back:
+// ll-only at D = 512 95.5 against 87.9 TFLOP/s)
+template <int BYTES, bool HALF = false>
 __device__ __forceinline__ void wide_dma_row(const float* src, uint32_t dst,
                                              uint32_t lane) {
   static_assert(BYTES == 16 || BYTES == 8 || BYTES == 4,
@@ -66,7 +70,7 @@ __device__ __forceinline__ void wide_dma_row(const float* src, uint32_t dst,
         :
         : "v"(voff), "s"(src), "s"(dst)
         : "memory");
-  } else if constexpr (BYTES == 8) {
+  } else if constexpr (BYTES == 8 && !HALF) {
     const uint32_t voff = lane * 4u;
     asm volatile(
         "s_mov_b32 m0, %2\n\t"
@@ -76,6 +80,16 @@ __device__ __forceinline__ void wide_dma_row(const float* src, uint32_t dst,
         :
         : "v"(voff), "s"(src), "s"(dst)
         : "memory");
+  } else if constexpr (BYTES == 8) {
+    const uint32_t voff = lane * 16u;
+    if (lane < 32)
+      asm volatile(
+          "s_mov_b32 m0, %2\n\t"
+          "s_nop 0\n\t"
+          "global_load_lds_dwordx4 %0, %1"
+          :
+          : "v"(voff), "s"(src), "s"(dst)
+          : "memory");
   } else {
     const uint32_t voff = lane * 4u;
     asm volatile(
@@ -150,7 +164,7 @@ __global__ __launch_bounds__(256, D == 256 ? 2 : 1) void linear_bernoulli_wide_k
   };
   auto dma_row = [&](const TileSrc& t, int row, int set = 0) {
     const int r = row < t.last ? row : t.last;
-    wide_dma_row<FQ / 16>(
+    wide_dma_row<FQ / 16, GRAD>(
         t.base + r * ldx32,
         dst_wave + (uint32_t)((set * kSetFloats + row * LDQ) * 4),
         (uint32_t)lane);
@@ -292,37 +306,66 @@ __global__ __launch_bounds__(256, D == 256 ? 2 : 1) void linear_bernoulli_wide_k
     if (GRAD) {
       // ---- phase 3: G[i, d] += sum_n R[n, i] X[n, d], d in the quarter -----
       // accumulator t: features (t>>2)*128 + lo*4 + (t&3) of the quarter (a
-      // lane reads 16 contiguous bytes, a half-wave 512 contiguous bytes)
+      // lane reads 16 contiguous bytes, a half-wave 512 contiguous bytes).
+      // 16 steps (g, q) of NT MFMAs: rows q + 8g + 4hi.  Hand-pipelined like
+      // phase 1 -- the operands of step+1 are read from LDS in front of the
+      // MFMAs of step; left to hipcc every step started with its own reads
+      // and exposed their latency (~115 clocks x 16 of a 20 300-clock tile at
+      // D = 1024, gpurun_out/r03z).
+      auto load_x = [&](int step, float* dst) {
+        const int g = step >> 2, q = step & 3;
+        const float* __restrict__ xrow = sXw + (q + 8 * g + 4 * hi) * LDQ;
+        if constexpr (NT == 2) {  // accumulator t: feature lo*2 + t
+          const w2 v = *reinterpret_cast<const w2*>(xrow + lo * 2);
+          dst[0] = v[0];
+          dst[1] = v[1];
+        } else {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const w4 rs = *reinterpret_cast<const w4*>(sR + (g * 64 + lane) * 4);
+          for (int t2 = 0; t2 < NT / 4; ++t2) {
+            const w4 v = *reinterpret_cast<const w4*>(xrow + lo * 4 + t2 * 128);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float* __restrict__ xrow = sXw + (q + 8 * g + 4 * hi) * LDQ;
-          if constexpr (NT == 2) {  // accumulator t: feature lo*2 + t
-            const w2 xv = *reinterpret_cast<const w2*>(xrow + lo * 2);
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-              G[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(rs[q], xv[m], G[m], 0,
-                                                          0, 0);
-          } else {
-            const float* __restrict__ xr = xrow + lo * 4;
-#pragma unroll
-            for (int t2 = 0; t2 < NT / 4; ++t2) {
-              const w4 xv = *reinterpret_cast<const w4*>(xr + t2 * 128);
-#pragma unroll
-              for (int m = 0; m < 4; ++m)
-                G[t2 * 4 + m] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                    rs[q], xv[m], G[t2 * 4 + m], 0, 0, 0);
-            }
+            for (int m = 0; m < 4; ++m) dst[t2 * 4 + m] = v[m];
           }
         }
-        if (kBuf == 1 && more) {
-          // rows 8g .. 8g+7 are consumed: their LDS reads have returned
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      };
+      float xc[NT], xn[NT];
+      w4 rs = *reinterpret_cast<const w4*>(sR + lane * 4), rs_next = rs;
+      load_x(0, xc);
+      // The two rows of a step are free once its operands sit in registers
+      // (read one step earlier): their successors of the NEXT tile come in
+      // under this step's MFMAs, one DMA instruction in front of each half.
+      // The texture path moves 64 B per clock and CU -- the 128 KB of a
+      // D = 1024 tile are 2 048 clocks of it -- and a DMA instruction costs
+      // its wave ~50 clocks of scalar set-up and issue: 8 rows back to back
+      // after each row group (the first form of this loop) held the MFMAs
+      // behind them for ~1 650 clocks per tile, two rows at the end of each
+      // step for ~1 150 (gpurun_out/r03z).
 #pragma unroll
-          for (int j = 0; j < 8; ++j) dma_row(tnext, 8 * g + j);
+      for (int step = 0; step < 16; ++step) {
+        const int g = step >> 2, q = step & 3;
+        const bool dma = kBuf == 1 && more;
+        if (dma) {
+          // (outstanding LDS reads: this step's operands, issued NT MFMAs ago)
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          dma_row(tnext, q + 8 * g);
         }
+        if (step + 1 < 16) {
+          load_x(step + 1, xn);
+          if (q == 3)
+            rs_next = *reinterpret_cast<const w4*>(sR + ((g + 1) * 64 + lane) * 4);
+        }
+#pragma unroll
+        for (int t = 0; t < NT / 2; ++t)
+          G[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(rs[q], xc[t], G[t], 0, 0,
+                                                      0);
+        if (dma) dma_row(tnext, q + 8 * g + 4);
+#pragma unroll
+        for (int t = NT / 2; t < NT; ++t)
+          G[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(rs[q], xc[t], G[t], 0, 0,
+                                                      0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) xc[t] = xn[t];
+        if (q == 3) rs = rs_next;
       }
     }
     ZS_LBW_MARK(4)  // phase 3 + DMA issue
