@@ -564,14 +564,45 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2
     if (GRAD) {
       // ---- phase 3a: own rows, A = the residual registers; the residual of
       // group g+1 (VALU) is issued under the MFMAs of group g ----------------
+      // The B operands (four X rows per group) can be read from LDS ONE GROUP
+      // AHEAD: read at the top of their own group they expose an LDS round
+      // trip per group (phase 3a 5 514 and 3b 4 604 clocks against 4 096 of
+      // MFMAs each at D = 256, profiles/r03z_lb_phase_timing_v2.txt).
+      // Measured per width and phase (profiles/r03z_prefetch3_ab.txt, four
+      // builds side by side): D = 128 (the topic model's K) gains 1.9 % --
+      // 123.5 -> 125.9 TFLOP/s -- and all of it from phase 3a; at D = 256
+      // phase 3b reading ahead changes nothing (129.4 / 129.3) and phase 3a
+      // reading ahead LOSES 2.6 % (126.0: what that phase is short of is
+      // issue slots for the residual's VALU, and the extra live registers do
+      // not help); at D = 64 the registers would spill under the 168-VGPR
+      // bound of three workgroups per CU.  So: D = 128 only.
+#ifndef ZS_LB_PREFETCH3A
+#define ZS_LB_PREFETCH3A(D) ((D) == 128)
+#endif
+#ifndef ZS_LB_PREFETCH3B
+#define ZS_LB_PREFETCH3B(D) ((D) == 128)
+#endif
+      constexpr bool kPreA = ZS_LB_PREFETCH3A(D), kPreB = ZS_LB_PREFETCH3B(D);
+      static_assert(!kPreA || kPreB, "phase 3a hands phase 3b its first group");
+      V xv[4], xn[4];
+      if (kPreA) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xv[q] = xrow(b, q);
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) residual(r);
       ZS_LB_MARK(1)  // first residual group
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        V xv[4];
+        if (kPreA) {
+          // group g+1's rows; past the last group: the first of phase 3b
 #pragma unroll
-        for (int q = 0; q < 4; ++q) xv[q] = xrow(b, g * 4 + q);
+          for (int q = 0; q < 4; ++q)
+            xn[q] = g + 1 < 4 ? xrow(b, (g + 1) * 4 + q) : xrow(b ^ 1, q);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) xv[q] = xrow(b, g * 4 + q);
+        }
         *reinterpret_cast<f4*>(sr_mine + g * 256) =
             f4{S[g * 4], S[g * 4 + 1], S[g * 4 + 2], S[g * 4 + 3]};
 #pragma unroll
@@ -587,7 +618,12 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2
           // A wave issues in order: left alone, hipcc emits the 4*FB MFMAs of
           // this group back to back and the ~60 VALU / transcendental ops of the
           // next group's residual after them, where only the last MFMA is
-          // left to hide them.  Ask for one MFMA, then a slice of the VALU.
+          // left to hide them.  Ask for the LDS traffic first (the next
+          // group's rows), then one MFMA, then a slice of the VALU.
+          if (kPreA) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);  // DS read
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write
+          }
 #pragma unroll
           for (int i = 0; i < 4 * FB; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             // MFMA
@@ -596,23 +632,44 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2
           }
 #endif
         }
+        if (kPreA) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) xv[q] = xn[q];
+        }
       }
       ZS_LB_MARK(2)  // phase 3a
       __syncthreads();  // the sibling's residuals are in LDS
       ZS_LB_MARK(3)  // barrier 1
       // ---- phase 3b: the sibling's rows, A from LDS ----------------------------
+      f4 rs = *reinterpret_cast<const f4*>(sr_sib), rs_next = rs;
+      if (kPreB && !kPreA) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xv[q] = xrow(b ^ 1, q);
+      }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const f4 rs = *reinterpret_cast<const f4*>(sr_sib + g * 256);
-        V xv[4];
+        if (kPreB) {
+          if (g + 1 < 4) {
+            rs_next = *reinterpret_cast<const f4*>(sr_sib + (g + 1) * 256);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) xv[q] = xrow(b ^ 1, g * 4 + q);
+            for (int q = 0; q < 4; ++q) xn[q] = xrow(b ^ 1, (g + 1) * 4 + q);
+          }
+        } else {
+          rs = *reinterpret_cast<const f4*>(sr_sib + g * 256);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) xv[q] = xrow(b ^ 1, g * 4 + q);
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
           for (int t = 0; t < FB; ++t)
             G[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(
                 rs[q], vget<FB>(xv[q], t), G[t], 0, 0, 0);
+        if (kPreB) {
+          rs = rs_next;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) xv[q] = xn[q];
+        }
       }
     } else {
 #pragma unroll
