@@ -538,7 +538,9 @@ int zshmc_mvn_tril_sample(float* out, const float* mean, const float* tril,
  *             .log_prob(counts)                     multivariate.py:435-443
  *   grad_theta[r,k] = sum_v counts[.,v] * phi_t[v,k] / (theta.phi)[r,v]
  * theta [n_rows, n_topics], phi_t = phi^T [n_vocab, n_topics] (n_topics 64,
- * 128 or 256: zero-pad), counts [count_rows, n_vocab] with `count_stride`
+ * 128, 256, 512 or 1024: zero-pad; above 256 the feature-split kernel of
+ * csrc/linear_bernoulli_wide.hip, grad_theta 16-byte aligned), counts
+ * [count_rows, n_vocab] with `count_stride`
  * floats between rows, shared by the rows with period count_rows.  A
  * count_stride that is a multiple of 4 (>= n_vocab rounded up to 4, the pad
  * zero-filled) on a 16-byte aligned base lets every lane fetch its counts --

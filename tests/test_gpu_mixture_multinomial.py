@@ -34,7 +34,16 @@ def _data(n_chains, n_docs, K, V, seed):
 # multiple of 64, counts shared across the chain axis
 @pytest.mark.parametrize('n_chains,n_docs,K,V', [(3, 7, 5, 40), (2, 50, 100, 1003),
                                                   (1, 130, 128, 777), (4, 33, 200, 129),
-                                                  (1, 1, 3, 1)])
+                                                  (1, 1, 3, 1),
+                                                  # the feature-split kernel
+                                                  # (K padded to 512 / 1024):
+                                                  # ragged 32-row blocks,
+                                                  # ragged 32-word tiles, with
+                                                  # and without document-major
+                                                  # tiles (n_chains % 32)
+                                                  (2, 41, 300, 1003), (32, 5, 512, 77),
+                                                  (3, 7, 1000, 130), (1, 1, 257, 1),
+                                                  (64, 3, 700, 333)])
 def test_loglik_and_grad_match_float64(env, n_chains, n_docs, K, V):
     zs, torch, dev = env
     phi, x, theta = _data(n_chains, n_docs, K, V, seed=K + V)
@@ -375,7 +384,9 @@ np.savez(%(out)r, **out)
 # chain axes that fill 64-chain tiles (document-major tiles), with a ragged
 # last group, with row-range splits (few workgroups), and one that does not
 DOC_MAJOR_SHAPES = [(64, 5, 64, 300), (128, 9, 100, 1003), (520, 3, 128, 200),
-                    (640, 2, 20, 77), (40, 6, 64, 130)]
+                    (640, 2, 20, 77), (40, 6, 64, 130),
+                    # the feature-split kernel: 32-chain tiles of one document
+                    (32, 5, 300, 130), (260, 3, 600, 77), (40, 4, 300, 99)]
 
 
 def test_document_major_tiles_equal_consecutive_rows(env, tmp_path):

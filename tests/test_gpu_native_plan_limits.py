@@ -215,3 +215,57 @@ def test_one_latent_per_term_is_required(env):
     assert hmc.plan_kind == 'generic'
     op.run()
     assert bool(torch.isfinite(info.log_prob).all())
+
+
+@pytest.mark.parametrize('K', [260, 6])
+def test_topic_model_beyond_256_topics_and_ragged_k(env, K):
+    """The logistic-normal topic model E step (lntm_mcem.py:33-48,97-102) with
+    K = 260 topics (padded to 512: the feature-split kernel's multinomial
+    mode) and K = 6 (rows padded to 8, the padding out of the softmax): the
+    native plan, equal to the generic plan's free run."""
+    zs, torch, dev = env
+    n_chains, n_docs, V = 4, 6, 50
+    g = torch.Generator(device=dev).manual_seed(K)
+    phi = torch.softmax(torch.randn(K, V, device=dev, generator=g), -1)
+    x = torch.poisson(torch.full((n_docs, V), 1.5, device=dev), generator=g)
+    eta_mean = 0.2 * torch.randn(n_docs, K, device=dev, generator=g)
+    eta0 = 0.3 * torch.randn(n_chains, n_docs, K, device=dev, generator=g)
+    runs = {}
+    for native in (True, False):
+        @zs.meta_bayesian_net()
+        def lntm():
+            bn = zs.BayesianNet()
+            eta = bn.normal('eta', eta_mean, logstd=torch.zeros(K, device=dev),
+                            n_samples=n_chains, group_ndims=1)
+            theta = torch.softmax(eta.tensor, -1)
+            bn.unnormalized_multinomial(
+                'x', torch.log(theta.reshape(-1, K).matmul(phi).reshape(
+                    n_chains, n_docs, V)),
+                normalize_logits=False, dtype=torch.float32)
+            return bn
+        model = lntm()
+        model.log_joint = lambda bn: (bn.cond_log_prob('eta') +
+                                      bn.cond_log_prob('x'))
+        eta = eta0.clone()
+        hmc = zs.HMC(step_size=0.02, n_leapfrogs=4, adapt_step_size=True,
+                     adapt_mass=True, mass_collect_iters=3,
+                     target_acceptance_rate=0.6, seed=5, native_plans=native)
+        op, info = hmc.sample(model, {'x': x}, {'eta': eta})
+        assert hmc.plan_kind == ('mixture_multinomial' if native
+                                 else 'generic')
+        if native:
+            assert hmc._plan.width == (512 if K > 256 else 64)
+        lps, eps = [], []
+        for it in range(7):
+            op.run()
+            lps.append(info.log_prob.cpu().numpy().copy())
+            eps.append(float(info.updated_step_size.item()))
+        runs[native] = (np.array(lps), eps, eta.cpu().numpy())
+    np.testing.assert_allclose(runs[True][1], runs[False][1], rtol=5e-3)
+    # the first transitions coincide chain by chain; later ones wherever no
+    # accept decision sat on its threshold
+    np.testing.assert_allclose(runs[True][0][0], runs[False][0][0], rtol=2e-4,
+                               atol=2e-2)
+    same = np.isclose(runs[True][2], runs[False][2], atol=5e-3).reshape(
+        n_chains * n_docs, -1).all(1).mean()
+    assert same >= 0.75, same

@@ -120,8 +120,6 @@ def _trip_ref(q, p, g_lik, theta, mean, logstd, mass, eps, kick, drift, scale,
 def test_model_kick_drift_on_padded_rows(env, softmax, D, ld, width, rows_m,
                                          rows_l):
     torch, capi, dev, s = env
-    if softmax and width > 256:
-        pytest.skip('the multinomial mode stops at 256 topics')
     C = 50
     rng = np.random.RandomState(D + softmax)
     f32 = np.float32

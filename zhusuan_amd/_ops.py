@@ -449,11 +449,11 @@ class UnnormalizedMultinomialLogProb(_Function):
 # ----------------------------------------------------------------------------
 # dense-logit Bernoulli likelihood (fp32 MFMA, csrc/linear_bernoulli.hip)
 # ----------------------------------------------------------------------------
-# padded feature counts of the fused likelihood kernels: the 64-chain-block
-# kernel of csrc/linear_bernoulli.hip (both modes) up to 256, the
-# feature-split kernel of csrc/linear_bernoulli_wide.hip (Bernoulli mode) above
-MIXTURE_WIDTHS = (64, 128, 256)
-LINEAR_BERNOULLI_WIDTHS = MIXTURE_WIDTHS + (512, 1024)
+# padded feature / topic counts of the fused likelihood kernels (both modes):
+# the 64-chain-block kernel of csrc/linear_bernoulli.hip up to 256, the
+# feature-split kernel of csrc/linear_bernoulli_wide.hip above
+LINEAR_BERNOULLI_WIDTHS = (64, 128, 256, 512, 1024)
+MIXTURE_WIDTHS = LINEAR_BERNOULLI_WIDTHS
 
 
 def _chain_block(width):
@@ -627,7 +627,7 @@ class MixtureMultinomialLogLik(_Function):
         need_grad = ctx.needs_input_grad[0]
         gt = torch.empty_like(t2) if need_grad else None
         # fewer 64-row chain blocks than CUs: split the vocabulary range
-        splits = _row_splits(rows, vocab, theta.device)
+        splits = _row_splits(rows, vocab, theta.device, width)
         ws = torch.empty(splits * rows * (width + 1), dtype=_F32,
                          device=theta.device) if splits > 1 else None
         _capi.call('zshmc_linear_multinomial_log_lik', t2.data_ptr(),

@@ -829,7 +829,13 @@ static int launch_lb(const float* W, const float* X, const float* y, int64_t C,
   return ZSHMC_OK;
 }
 
-// csrc/linear_bernoulli_wide.hip: 256 < n_features <= 1024
+// csrc/linear_bernoulli_wide.hip: 256 < n_features / n_topics <= 1024
+int linear_multinomial_wide(const float* theta, const float* phi_t,
+                            const float* counts, int64_t count_rows,
+                            int64_t count_stride, int64_t n_rows,
+                            int64_t n_vocab, int64_t n_topics, float* ll,
+                            float* g_theta, int n_splits, float* workspace,
+                            int doc_major, hipStream_t s);
 int linear_bernoulli_wide(const float* W, const float* X, const float* y,
                           int64_t n_chains, int64_t n_rows, int64_t n_features,
                           float* ll, float* gW, int n_splits, float* workspace,
@@ -899,9 +905,11 @@ extern "C" int zshmc_linear_multinomial_log_lik(const float* theta,
   ZS_REQUIRE(n_rows > 0 && n_vocab > 0 && count_rows > 0 &&
                  n_rows % count_rows == 0 && count_stride >= n_vocab,
              "zshmc_linear_multinomial_log_lik: bad shape");
-  ZS_REQUIRE(n_topics == 64 || n_topics == 128 || n_topics == 256,
-             "zshmc_linear_multinomial_log_lik: n_topics must be 64, 128 or 256 "
-             "(zero-pad theta and phi^T), got %lld", (long long)n_topics);
+  ZS_REQUIRE(n_topics == 64 || n_topics == 128 || n_topics == 256 ||
+                 n_topics == 512 || n_topics == 1024,
+             "zshmc_linear_multinomial_log_lik: n_topics must be 64, 128, 256, "
+             "512 or 1024 (zero-pad theta and phi^T), got %lld",
+             (long long)n_topics);
   ZS_REQUIRE((reinterpret_cast<uintptr_t>(theta) & 15) == 0 &&
                  (reinterpret_cast<uintptr_t>(phi_t) & 15) == 0,
              "zshmc_linear_multinomial_log_lik: theta and phi^T must be 16-byte aligned");
@@ -920,6 +928,18 @@ extern "C" int zshmc_linear_multinomial_log_lik(const float* theta,
     return !(e && e[0] == '0');
   }();
   const int64_t n_chains = n_rows / count_rows;
+  if (n_topics > 256) {
+    // 32-row blocks (csrc/linear_bernoulli_wide.hip): same rule, half the size
+    ZS_REQUIRE(!grad_theta || (reinterpret_cast<uintptr_t>(grad_theta) & 15) == 0,
+               "zshmc_linear_multinomial_log_lik: grad_theta must be 16-byte "
+               "aligned");
+    const int dm = allow_doc_major && count_rows > 1 &&
+                   (n_chains % 32 == 0 || n_chains >= 256);
+    return linear_multinomial_wide(theta, phi_t, counts, count_rows,
+                                   count_stride, n_rows, n_vocab, n_topics,
+                                   log_lik, grad_theta, n_splits, workspace, dm,
+                                   s);
+  }
   const int doc_major =
       allow_doc_major && count_rows > 1 &&
       (n_chains % kMC == 0 || n_chains >= 512);

@@ -105,11 +105,18 @@ __device__ __forceinline__ void wide_dma_row(const float* src, uint32_t dst,
 // (D = 256: an A/B of this decomposition against the 64-chain-block kernel of
 // csrc/linear_bernoulli.hip -- 54 KB of LDS and ~100 registers let two
 // workgroups share a CU; ZSHMC_LB_SPLIT256=1 routes 256-wide calls here)
-template <int D, bool GRAD>
+// OP as in csrc/linear_bernoulli.hip: 0 = Bernoulli over dense logits (y[n]
+// per data row); 1 = UnnormalizedMultinomial over a mixture (W = theta, X =
+// phi^T, the counts x[c, n] from `yc` [yc_rows, ldy] with row period yc_rows
+// over the chain rows; doc_major: a workgroup's 32 rows are 32 CHAINS OF ONE
+// DOCUMENT of the topic model's [n_chains, n_docs] chain axes, so that its
+// counts are one row of the matrix).
+template <int D, bool GRAD, int OP>
 __global__ __launch_bounds__(256, D == 256 ? 2 : 1) void linear_bernoulli_wide_kernel(
     const float* __restrict__ W, const float* __restrict__ X,
-    const float* __restrict__ y, int64_t C, int64_t N, int64_t ldw,
-    int64_t ldx, float* __restrict__ ll, float* __restrict__ gW) {
+    const float* __restrict__ y, const float* __restrict__ yc, int64_t yc_rows,
+    int64_t ldy, int64_t C, int64_t N, int64_t ldw, int64_t ldx,
+    float* __restrict__ ll, float* __restrict__ gW, int doc_major) {
   static_assert(D == 256 || D == 512 || D == 1024,
                 "padded widths of the wide kernel");
   constexpr int FQ = D / 4;    // features per wave
@@ -129,13 +136,25 @@ __global__ __launch_bounds__(256, D == 256 ? 2 : 1) void linear_bernoulli_wide_k
   const int lane = tid & 63;
   const int f = __builtin_amdgcn_readfirstlane(tid >> 6);  // feature quarter
   const int lo = lane & 31, hi = lane >> 5;
-  const int64_t c0 = (int64_t)blockIdx.x * kWC;
-  const int n_valid = (int)(C - c0 < kWC ? C - c0 : kWC);
+  int64_t row_base = (int64_t)blockIdx.x * kWC, row_stride = 1;
+  int64_t n_valid64 = C - row_base;
+  if (OP == 1 && doc_major) {
+    const int64_t grp = blockIdx.x / yc_rows, doc = blockIdx.x % yc_rows;
+    row_base = grp * kWC * yc_rows + doc;
+    row_stride = yc_rows;
+    n_valid64 = C / yc_rows - grp * kWC;
+  }
+  const int n_valid = (int)(n_valid64 < kWC ? n_valid64 : kWC);
+  // row of position i (0..31) of the block; positions past the end re-read
+  // the last valid row (their results are never stored)
+  auto row_at = [&](int i) -> int64_t {
+    return row_base + (int64_t)(i < n_valid ? i : n_valid - 1) * row_stride;
+  };
 
   // ---- this wave's W slice -> registers (B operand: k-slot = lane half) ----
   float wreg[KK * 4];
   {
-    const int64_t cr = c0 + (lo < n_valid ? lo : n_valid - 1);
+    const int64_t cr = row_at(lo);
     const float* __restrict__ wrow = W + cr * ldw + f * FQ + hi * 4;
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) {
@@ -194,10 +213,32 @@ __global__ __launch_bounds__(256, D == 256 ? 2 : 1) void linear_bernoulli_wide_k
 #pragma unroll
     for (int j = 0; j < kWR; ++j) dma_row(t0, j);
   }
-  if (tid < kWR) {
+  if (OP == 0 && tid < kWR) {
     const int64_t nr = tile_begin * kWR + tid;
     sY[tid] = nr < N ? y[nr] : 0.f;
   }
+  // OP 1: this lane's 4 counts of a tile -- chain lo, rows 8f + 4hi .. +3, the
+  // elements whose residual this wave computes -- 16 contiguous bytes of the
+  // chain's counts row (rows zero-padded to 4-float groups and 16-B aligned:
+  // the caller's count_stride), else element by element
+  const bool yc_vec = OP == 1 && (ldy & 3) == 0 && ldy >= ((N + 3) & ~3ll) &&
+                      (reinterpret_cast<uintptr_t>(yc) & 15) == 0;
+  auto load_counts = [&](int64_t t) -> w4 {
+    const int64_t n0 = t * kWR + 8 * f + 4 * hi;
+    const float* __restrict__ xrow = yc + (row_at(lo) % yc_rows) * ldy + n0;
+    const int64_t left = N - n0;  // may be <= 0
+    w4 v = w4{0.f, 0.f, 0.f, 0.f};
+    if (yc_vec) {
+      if (left > 0) v = *reinterpret_cast<const w4*>(xrow);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j < left) v[j] = xrow[j];
+    }
+    return v;
+  };
+  w4 xcnt = w4{0.f, 0.f, 0.f, 0.f}, xnext = xcnt;
+  if (OP == 1 && tile_begin < n_tiles) xcnt = load_counts(tile_begin);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -224,10 +265,13 @@ __global__ __launch_bounds__(256, D == 256 ? 2 : 1) void linear_bernoulli_wide_k
     const bool more = tile + 1 < n_tiles;
     const int64_t n_next = (more ? tile + 1 : tile) * kWR;
     const TileSrc tnext = tile_src(n_next);
-    if (tid < kWR) {
+    if (OP == 0 && tid < kWR) {
       const int64_t nr = n_next + tid;
       yr = nr < N ? y[nr] : 0.f;
     }
+    // (consumed one tile later: a load used in THIS tile's residual would
+    // make hipcc's own vmcnt wait for the DMA rows queued behind it)
+    if (OP == 1) xnext = load_counts(more ? tile + 1 : tile);
     if (kBuf == 2 && more) {
       // the other set was last read in the previous tile's phase 3
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -286,15 +330,27 @@ __global__ __launch_bounds__(256, D == 256 ? 2 : 1) void linear_bernoulli_wide_k
         const int nl = j + 8 * f + 4 * hi;
         const bool valid = nl < rows_left;
         const float sv = s[j];
-        const float yv = sY[buf * kWR + nl];
-        const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * fabsf(sv));
-        const float t1 = 1.0f + e;
-        const float inv = __builtin_amdgcn_rcpf(t1);
-        const float sig = sv >= 0.f ? inv : 1.0f - inv;
-        const float lp = sv * yv - fmaxf(sv, 0.f) -
-                         0.6931471805599453f * __builtin_amdgcn_logf(t1);
-        res[j] = valid ? yv - sig : 0.f;
-        ll_tile += valid ? lp : 0.f;
+        if (OP == 0) {
+          const float yv = sY[buf * kWR + nl];
+          const float e =
+              __builtin_amdgcn_exp2f(-1.4426950408889634f * fabsf(sv));
+          const float t1 = 1.0f + e;
+          const float inv = __builtin_amdgcn_rcpf(t1);
+          const float sig = sv >= 0.f ? inv : 1.0f - inv;
+          const float lp = sv * yv - fmaxf(sv, 0.f) -
+                           0.6931471805599453f * __builtin_amdgcn_logf(t1);
+          res[j] = valid ? yv - sig : 0.f;
+          ll_tile += valid ? lp : 0.f;
+        } else {
+          // sum_v x_v log((theta.phi)_v) and d/d(theta.phi) = x / (theta.phi)
+          // (multivariate.py:435-443, normalize_logits = False); x = 0
+          // contributes nothing (also where the product underflows)
+          const float xv = xcnt[j];
+          const bool on = valid && xv != 0.f;
+          const float lp = xv * (0.6931471805599453f * __builtin_amdgcn_logf(sv));
+          res[j] = on ? xv * __builtin_amdgcn_rcpf(sv) : 0.f;
+          ll_tile += on ? lp : 0.f;
+        }
       }
       ll_lane += (double)ll_tile;
       if (GRAD) *reinterpret_cast<w4*>(sR + (f * 64 + lane) * 4) = res;
@@ -369,8 +425,9 @@ __global__ __launch_bounds__(256, D == 256 ? 2 : 1) void linear_bernoulli_wide_k
       }
     }
     ZS_LBW_MARK(4)  // phase 3 + DMA issue
-    if (tid < kWR) sY[(buf ^ 1) * kWR + tid] = yr;
+    if (OP == 0 && tid < kWR) sY[(buf ^ 1) * kWR + tid] = yr;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the slice has landed
+    if (OP == 1) xcnt = xnext;
     ZS_LBW_MARK(5)  // DMA wait
   }
 #ifdef ZS_LBW_TIMING
@@ -382,14 +439,15 @@ __global__ __launch_bounds__(256, D == 256 ? 2 : 1) void linear_bernoulli_wide_k
 #endif
 
   // ---- epilogue -------------------------------------------------------------
-  // G[t][r]: chain = c0 + (r&3) + 8*(r>>2) + 4*hi,
+  // G[t][r]: row position (r&3) + 8*(r>>2) + 4*hi of the block,
   //          feature = f*FQ + (t>>2)*128 + lo*4 + (t&3)
   if (GRAD) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int pos = (r & 3) + 8 * (r >> 2) + 4 * hi;
       if (pos < n_valid) {
-        float* __restrict__ grow = gW + (c0 + pos) * ldw + f * FQ;
+        float* __restrict__ grow =
+            gW + (row_base + pos * row_stride) * ldw + f * FQ;
         if constexpr (NT == 2) {
           *reinterpret_cast<w2*>(grow + lo * 2) = w2{G[0][r], G[1][r]};
         } else {
@@ -410,7 +468,7 @@ __global__ __launch_bounds__(256, D == 256 ? 2 : 1) void linear_bernoulli_wide_k
   if (hi == 0) sLd[f * 32 + lo] = ll_half;
   __syncthreads();
   if (f == 0 && hi == 0 && lo < n_valid)
-    ll[c0 + lo] =
+    ll[row_base + lo * row_stride] =
         (float)(((sLd[lo] + sLd[32 + lo]) + sLd[64 + lo]) + sLd[96 + lo]);
 }
 
@@ -434,10 +492,12 @@ __global__ __launch_bounds__(256) void lb_wide_reduce_splits_kernel(
   }
 }
 
-template <int D>
+template <int D, int OP>
 static int launch_wide(const float* W, const float* X, const float* y,
+                       const float* yc, int64_t yc_rows, int64_t ldy,
                        int64_t C, int64_t N, float* ll, float* gW,
-                       hipStream_t s, int n_splits, float* workspace) {
+                       hipStream_t s, int n_splits, float* workspace,
+                       int doc_major) {
   constexpr int LDQ = D / 4 + 4;
   const size_t lds = (size_t)(wide_buffers(D) * 4 * kWR * LDQ + 2 * kWR +
                               4 * 4 * 64 * 4 + 4 * 64 * 4) *
@@ -445,11 +505,12 @@ static int launch_wide(const float* W, const float* X, const float* y,
   static bool attr = false;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(linear_bernoulli_wide_kernel<D, true>),
+        reinterpret_cast<const void*>(linear_bernoulli_wide_kernel<D, true, OP>),
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e == hipSuccess)
       e = hipFuncSetAttribute(
-          reinterpret_cast<const void*>(linear_bernoulli_wide_kernel<D, false>),
+          reinterpret_cast<const void*>(
+              linear_bernoulli_wide_kernel<D, false, OP>),
           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(LDS)");
     attr = true;
@@ -457,15 +518,18 @@ static int launch_wide(const float* W, const float* X, const float* y,
   const int S = (n_splits > 1 && workspace) ? n_splits : 1;
   float* ll_out = S > 1 ? workspace : ll;
   float* g_out = S > 1 ? (gW ? workspace + (int64_t)S * C : nullptr) : gW;
-  const dim3 grid((unsigned)((C + kWC - 1) / kWC), S);
+  // doc_major: one workgroup per (group of 32 chains, document)
+  const int64_t gx = doc_major ? ((C / yc_rows + kWC - 1) / kWC) * yc_rows
+                               : (C + kWC - 1) / kWC;
+  const dim3 grid((unsigned)gx, S);
   if (gW)
-    hipLaunchKernelGGL((linear_bernoulli_wide_kernel<D, true>), grid, dim3(256),
-                       lds, s, W, X, y, C, N, (int64_t)D, (int64_t)D, ll_out,
-                       g_out);
+    hipLaunchKernelGGL((linear_bernoulli_wide_kernel<D, true, OP>), grid,
+                       dim3(256), lds, s, W, X, y, yc, yc_rows, ldy, C, N,
+                       (int64_t)D, (int64_t)D, ll_out, g_out, doc_major);
   else
-    hipLaunchKernelGGL((linear_bernoulli_wide_kernel<D, false>), grid,
-                       dim3(256), lds, s, W, X, y, C, N, (int64_t)D, (int64_t)D,
-                       ll_out, g_out);
+    hipLaunchKernelGGL((linear_bernoulli_wide_kernel<D, false, OP>), grid,
+                       dim3(256), lds, s, W, X, y, yc, yc_rows, ldy, C, N,
+                       (int64_t)D, (int64_t)D, ll_out, g_out, doc_major);
   ZS_LAUNCH_CHECK("linear_bernoulli_wide_kernel launch");
   if (S > 1) {
     const int64_t n = C + (gW ? C * D : 0);
@@ -478,19 +542,36 @@ static int launch_wide(const float* W, const float* X, const float* y,
   return ZSHMC_OK;
 }
 
-// n_features 512 or 1024 (called by zshmc_linear_bernoulli_log_lik)
+// n_features 512 or 1024 (256: the A/B switch); called by
+// zshmc_linear_bernoulli_log_lik
 int linear_bernoulli_wide(const float* W, const float* X, const float* y,
                           int64_t n_chains, int64_t n_rows, int64_t n_features,
                           float* ll, float* gW, int n_splits, float* workspace,
                           hipStream_t s) {
   if (n_features == 256)
-    return launch_wide<256>(W, X, y, n_chains, n_rows, ll, gW, s, n_splits,
-                            workspace);
+    return launch_wide<256, 0>(W, X, y, nullptr, 1, n_rows, n_chains, n_rows,
+                               ll, gW, s, n_splits, workspace, 0);
   if (n_features == 512)
-    return launch_wide<512>(W, X, y, n_chains, n_rows, ll, gW, s, n_splits,
-                            workspace);
-  return launch_wide<1024>(W, X, y, n_chains, n_rows, ll, gW, s, n_splits,
-                           workspace);
+    return launch_wide<512, 0>(W, X, y, nullptr, 1, n_rows, n_chains, n_rows,
+                               ll, gW, s, n_splits, workspace, 0);
+  return launch_wide<1024, 0>(W, X, y, nullptr, 1, n_rows, n_chains, n_rows, ll,
+                              gW, s, n_splits, workspace, 0);
+}
+
+// n_topics 512 or 1024; called by zshmc_linear_multinomial_log_lik
+int linear_multinomial_wide(const float* theta, const float* phi_t,
+                            const float* counts, int64_t count_rows,
+                            int64_t count_stride, int64_t n_rows,
+                            int64_t n_vocab, int64_t n_topics, float* ll,
+                            float* g_theta, int n_splits, float* workspace,
+                            int doc_major, hipStream_t s) {
+  if (n_topics == 512)
+    return launch_wide<512, 1>(theta, phi_t, nullptr, counts, count_rows,
+                               count_stride, n_rows, n_vocab, ll, g_theta, s,
+                               n_splits, workspace, doc_major);
+  return launch_wide<1024, 1>(theta, phi_t, nullptr, counts, count_rows,
+                              count_stride, n_rows, n_vocab, ll, g_theta, s,
+                              n_splits, workspace, doc_major);
 }
 
 }  // namespace zshmc

@@ -1131,7 +1131,7 @@ class _DenseLikelihoodPlan(_PlanBase):
       'mixture_multinomial' x ~ UnnormalizedMultinomial(
                                     log_mixture(softmax(eta), phi),
                                     normalize_logits=False)   (lntm_mcem.py:33-48)
-                            one latent, up to 256 topics
+                            one latent, up to 1024 topics
 
     The plan works on a PACKED state: the latents' columns side by side in
     rows of `ld` floats (the total rounded up to a multiple of 4; the columns
@@ -1579,7 +1579,6 @@ def _try_dense_likelihood_plan(hmc, meta_bn, names, values, chain_shape,
         if type(ld) is UnnormalizedMultinomial:
             value = vals[0]
             if len(vals) != 1 or value.dim() != n_chain + 1 or \
-                    value.shape[-1] > 256 or \
                     ld.group_ndims != 0 or ld.normalize_logits or \
                     lazy.phi.requires_grad or obs.requires_grad:
                 return None
