@@ -3,7 +3,7 @@
 full shape (n_chains x 5 000 documents, K = 128, V = 12 419), document-major
 tiles against consecutive-row tiles: run once with ZSHMC_LB_DOC_MAJOR=1 and
 once with =0 (the switch is read once per process).
-  python tools/lntm_docmajor_bench.py [n_chains]"""
+  python tools/lntm_docmajor_bench.py [n_chains] [n_topics]"""
 import os
 import sys
 
@@ -16,7 +16,8 @@ dev = torch.device('cuda', 0)
 s = torch.cuda.current_stream().cuda_stream
 g = torch.Generator(device=dev).manual_seed(0)
 n_chains = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
-n_docs, K, V = 5000, 128, 12419
+# (third argument: the number of topics -- above 256 the feature-split kernel)
+n_docs, K, V = 5000, int(sys.argv[2]) if len(sys.argv) > 2 else 128, 12419
 rows = n_chains * n_docs
 phi = torch.softmax(torch.randn(K, V, device=dev, generator=g), -1)
 mix = torch.softmax(torch.randn(n_docs, K, device=dev, generator=g), -1)
@@ -46,8 +47,8 @@ e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 2
 flop = 4.0 * rows * K * V
-print('ZSHMC_LB_DOC_MAJOR=%s  n_chains=%d  %.1f ms per evaluation = %.1f TFLOP/s '
+print('ZSHMC_LB_DOC_MAJOR=%s  K=%d n_chains=%d  %.1f ms per evaluation = %.1f TFLOP/s '
       '= %.3f of the fp32-MFMA peak; checksum ll %.6e grad %.6e' % (
-          os.environ.get('ZSHMC_LB_DOC_MAJOR', '(unset: on)'), n_chains, ms,
+          os.environ.get('ZSHMC_LB_DOC_MAJOR', '(unset: on)'), K, n_chains, ms,
           flop / ms / 1e9, flop / ms / 1e9 / 157.3, float(ll.double().sum()),
           float(gt.double().abs().sum())))
