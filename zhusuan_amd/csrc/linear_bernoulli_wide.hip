@@ -1,9 +1,11 @@
 // The dense-logit Bernoulli log-likelihood + gradient of
-// csrc/linear_bernoulli.hip for WIDE rows: 256 < D <= 1024 features (padded to
-// 512 or 1024).  Same mathematics (reference
+// csrc/linear_bernoulli.hip -- and its mixture-multinomial mode, the topic
+// model's likelihood -- for WIDE rows: 256 < D <= 1024 features or topics
+// (padded to 512 or 1024).  Same mathematics (reference
 // zhusuan/distributions/univariate.py:398-403 summed by group_ndims = 1, the
-// gradient tf.gradients yields through the matmul, hmc.py:430-432), same fp32
-// matrix cores, different decomposition -- at D = 1024 a 64-chain block of W
+// gradient tf.gradients yields through the matmul, hmc.py:430-432;
+// multivariate.py:435-443 over examples/topic_models/lntm_mcem.py:39-46), same
+// fp32 matrix cores, different decomposition -- at D = 1024 a 64-chain block of W
 // is 256 KB and its gradient accumulators another 256 KB: neither fits what a
 // workgroup of the 256-wide kernel keeps in registers.
 //
@@ -23,10 +25,11 @@
 //             (4 KB)
 //   phase 3   G[i, d] += sum_n R[n, i] X[n, d] over the 32 rows and the wave's
 //             quarter: D/8 MFMAs, A = the residuals from LDS, B = the wave's
-//             X slice.  Rows 8g .. 8g+7 of the NEXT tile are DMA'd into the
-//             slice as soon as row group g has been consumed (the slice is
-//             single-buffered: 4 x 32 x (D/4 + 4) floats = 130 KB at D = 1024
-//             leaves no room for a second one).
+//             X slice.  The rows of the NEXT tile are DMA'd into the slice
+//             as the steps of this phase free them, one instruction in front
+//             of each half of a step's MFMAs (the slice is single-buffered:
+//             4 x 32 x (D/4 + 4) floats = 130 KB at D = 1024 leaves no room
+//             for a second one).
 // Two barriers per tile, both for the 20 KB exchange.  Roofline: MFMA,
 // 4*N*D*C flop per call as in the narrow kernel.
 #include "common.h"
