@@ -43,12 +43,14 @@ constexpr int kWC = 32;  // chains per workgroup
 constexpr int kWR = 32;  // data rows per tile
 
 // Sets of X slices in LDS.  Two fit at D = 512 (2 x 66 KB: the DMA of tile
-// t+1 then runs under the whole of tile t) -- measured, no gain: 110.4 against
-// 110.0 TFLOP/s with gradient, 91 against 96 without
-// (profiles/r03x_lb_wide_buffers.txt).  What D = 512 loses against D = 1024 is
-// the fixed cost of a tile (two barriers, the 20 KB exchange, the residual:
-// ~3 600 cycles with one wave per SIMD and nobody to overlap it) over half the
-// MFMAs, not the exposed DMA.
+// t+1 is then free of the "row consumed" order) -- measured twice, no gain:
+// all rows at the top of the tile 110.4 against 110.0 TFLOP/s
+// (profiles/r03x_lb_wide_buffers.txt, before the DMA issue was spread); two
+// rows in front of each phase-1 step 106.9 against 120.6 with one set and the
+// rows spread under phase 3 (profiles/r03bb_lb_wide_buf2_ab.txt): phase 1 is
+// ONE dependent MFMA chain, a DMA instruction's ~50 clocks of issue between
+// its links are not hidden, while the independent accumulators of phase 3
+// absorb them.
 #ifndef ZS_LBW_BUF512
 #define ZS_LBW_BUF512 1
 #endif
@@ -275,12 +277,9 @@ __global__ __launch_bounds__(256, D == 256 ? 2 : 1) void linear_bernoulli_wide_k
     // (consumed one tile later: a load used in THIS tile's residual would
     // make hipcc's own vmcnt wait for the DMA rows queued behind it)
     if (OP == 1) xnext = load_counts(more ? tile + 1 : tile);
-    if (kBuf == 2 && more) {
-      // the other set was last read in the previous tile's phase 3
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int j = 0; j < kWR; ++j) dma_row(tnext, j, xset ^ 1);
-    }
+    // (two slice sets: the other one was last read in the previous tile's
+    // phase 3; the next tile comes in under phase 1, kWR / KK rows per step)
+    constexpr int kDmaStep = (kWR + KK - 1) / KK;
 
     // ---- phase 1: partial logits over the wave's feature quarter -----------
     w16 S;
@@ -293,6 +292,12 @@ __global__ __launch_bounds__(256, D == 256 ? 2 : 1) void linear_bernoulli_wide_k
       for (int kk = 0; kk < KK; ++kk) {
         w4 an = av;
         if (kk + 1 < KK) an = *reinterpret_cast<const w4*>(arow + (kk + 1) * 8);
+        if (kBuf == 2 && more) {
+#pragma unroll
+          for (int j = 0; j < kDmaStep; ++j)
+            if (kk * kDmaStep + j < kWR)
+              dma_row(tnext, kk * kDmaStep + j, xset ^ 1);
+        }
 #pragma unroll
         for (int m = 0; m < 4; ++m)
           S = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], wreg[kk * 4 + m], S, 0,
