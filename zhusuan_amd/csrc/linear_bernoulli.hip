@@ -278,6 +278,14 @@ __device__ __forceinline__ void lds_dma_row(const float* src, uint32_t dst,
 #ifndef ZS_LB_BUF
 #define ZS_LB_BUF(D) ((D) <= 128 ? 1 : 2)
 #endif
+// D = 256 with gradient: the next tile's DMA rows under phase 3b (independent
+// accumulators) instead of in front of the first 16 steps of phase 1 (one
+// dependent chain) -- what pays in csrc/linear_bernoulli_wide.hip was measured
+// here and LOSES: 128.0 against 129.3 TFLOP/s (Bernoulli), 125.5 against 130.0
+// (multinomial, K = 256), profiles/r03cc_dma_phase3_ab.txt.  Off.
+#ifndef ZS_LB_DMA_PHASE3
+#define ZS_LB_DMA_PHASE3 0
+#endif
 #ifndef ZS_LB_MINW  // min waves per SIMD: D = 64 fits three workgroups per CU
 #define ZS_LB_MINW(D) ((D) == 64 ? 3 : 1)
 #endif
@@ -509,7 +517,9 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2
         // one DMA row of tile t+1 per step over the first 16 steps (KK >= 16)
         // or kDmaPer rows per step (KK = 8): issued as early as the buffer is
         // free, in front of the step's MFMAs
-        if (kBuf == 2 && KK >= 16 && kk < 16) dma_row(tnext, kk);
+        // (ZS_LB_DMA_PHASE3, an A/B switch: the rows under phase 3b instead)
+        if (kBuf == 2 && KK >= 16 && kk < 16 && !(GRAD && ZS_LB_DMA_PHASE3))
+          dma_row(tnext, kk);
         if (kBuf == 2 && KK < 16) {
 #pragma unroll
           for (int j = 0; j < kDmaPer; ++j) dma_row(tnext, kk * kDmaPer + j);
@@ -660,11 +670,15 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2
           for (int q = 0; q < 4; ++q) xv[q] = xrow(b ^ 1, g * 4 + q);
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < 4; ++q) {
+          // one DMA row of tile t+1 in front of each q's MFMAs (independent
+          // accumulators: the issue hides under the previous MFMA)
+          if (kBuf == 2 && KK >= 16 && ZS_LB_DMA_PHASE3) dma_row(tnext, g * 4 + q);
 #pragma unroll
           for (int t = 0; t < FB; ++t)
             G[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(
                 rs[q], vget<FB>(xv[q], t), G[t], 0, 0, 0);
+        }
         if (kPreB) {
           rs = rs_next;
 #pragma unroll
