@@ -585,12 +585,24 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2
       // reading ahead LOSES 2.6 % (126.0: what that phase is short of is
       // issue slots for the residual's VALU, and the extra live registers do
       // not help); at D = 64 the registers would spill under the 168-VGPR
-      // bound of three workgroups per CU.  So: D = 128 only.
+      // bound of three workgroups per CU.
+      // Second pass (profiles/r03dd_prefetch_fence_ab.txt): the ISA showed why
+      // D = 256 gained nothing -- hipcc sinks every read back to just in front
+      // of the MFMAs that use it (`ds_read, s_waitcnt, 4 MFMAs` per row).  A
+      // scheduling fence behind the next group's reads holds them in place:
+      // with it phase 3b reading ahead gains 2.1 % at D = 256 (129.5 -> 132.3
+      // TFLOP/s, 0.823 -> 0.841; with phase 3a too: 131.0), while D = 128 --
+      // two workgroups per CU, whose reads the other workgroup's MFMAs cover
+      // -- loses 1 % to the fence (126.3 -> 125.0).  So: D = 128 both phases,
+      // unfenced; D = 256 phase 3b, fenced.
+#ifndef ZS_LB_PREFETCH_FENCE
+#define ZS_LB_PREFETCH_FENCE(D) ((D) == 256)
+#endif
 #ifndef ZS_LB_PREFETCH3A
 #define ZS_LB_PREFETCH3A(D) ((D) == 128)
 #endif
 #ifndef ZS_LB_PREFETCH3B
-#define ZS_LB_PREFETCH3B(D) ((D) == 128)
+#define ZS_LB_PREFETCH3B(D) ((D) >= 128)
 #endif
       constexpr bool kPreA = ZS_LB_PREFETCH3A(D), kPreB = ZS_LB_PREFETCH3B(D);
       static_assert(!kPreA || kPreB, "phase 3a hands phase 3b its first group");
@@ -615,6 +627,11 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2
         }
         *reinterpret_cast<f4*>(sr_mine + g * 256) =
             f4{S[g * 4], S[g * 4 + 1], S[g * 4 + 2], S[g * 4 + 3]};
+        // (ZS_LB_PREFETCH_FENCE: hipcc sinks each of the reads above to just in
+        // front of the MFMAs that use it -- `ds_read, s_waitcnt, 4 MFMAs` per
+        // row in the ISA, an LDS round trip exposed per row; the fence keeps
+        // the next group's reads in front of this group's MFMAs)
+        if (kPreA && ZS_LB_PREFETCH_FENCE(D)) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -630,7 +647,7 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2
           // next group's residual after them, where only the last MFMA is
           // left to hide them.  Ask for the LDS traffic first (the next
           // group's rows), then one MFMA, then a slice of the VALU.
-          if (kPreA) {
+          if (kPreA && !ZS_LB_PREFETCH_FENCE(D)) {
             __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);  // DS read
             __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write
           }
@@ -669,6 +686,7 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2
 #pragma unroll
           for (int q = 0; q < 4; ++q) xv[q] = xrow(b ^ 1, g * 4 + q);
         }
+        if (kPreB && ZS_LB_PREFETCH_FENCE(D)) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           // one DMA row of tile t+1 in front of each q's MFMAs (independent
