@@ -250,3 +250,45 @@ def test_sums_outside_the_spelling_compute_on_the_plain_tensor(near_miss):
     got = sym.lower_bernoulli_logits(out) if isinstance(out, sym.Sym) else out
     assert not isinstance(got, (sym.Sym, zs.distributions.LinearLogits))
     torch.testing.assert_close(got, want, rtol=0, atol=0)
+
+
+def test_packed_operands_of_a_multi_term_linear_logits():
+    """LinearLogits.packed(): the weights side by side (torch.cat, so autograd
+    splits the gradient back), the design matrices side by side with a column
+    of ones for the bias -- and the same product as the dense sum."""
+    from zhusuan_amd import _ops
+    C, N = 5, 17
+    w1 = _latent(C, 6).requires_grad_(True)
+    w2 = _latent(C, 3, seed=3).requires_grad_(True)
+    b = _latent(C, seed=5).requires_grad_(True)
+    X1, X2 = _latent(N, 6, seed=1), _latent(N, 3, seed=2)
+    lazy = zs.distributions.LinearLogits.of_terms(
+        [(w1, X1, False), (b, None, True), (w2, X2, False)])
+    w_all, x_all = lazy.packed()
+    assert tuple(w_all.shape) == (C, 10) and tuple(x_all.shape) == (N, 10)
+    torch.testing.assert_close(x_all[:, :6], X1)
+    torch.testing.assert_close(x_all[:, 6], torch.ones(N))
+    torch.testing.assert_close(x_all[:, 7:], X2)
+    dense = w1 @ X1.t() + b[:, None] + w2 @ X2.t()
+    torch.testing.assert_close(w_all @ x_all.t(), dense)
+    torch.testing.assert_close(lazy.dense(), dense)
+    (w_all @ x_all.t()).sum().backward()
+    torch.testing.assert_close(w1.grad, X1.sum(0).expand(C, 6))
+    torch.testing.assert_close(b.grad, torch.full((C,), float(N)))
+    # the cached design matrix is rebuilt when a block changes in place
+    again = _ops.packed_design([X1, None, X2], N, X1.device)
+    assert again.data_ptr() == x_all.data_ptr()
+    X2.mul_(2.0)
+    fresh = _ops.packed_design([X1, None, X2], N, X1.device)
+    torch.testing.assert_close(fresh[:, 7:], X2)
+    # zero padding to a kernel width
+    wide = _ops.packed_design([X1, None], N, X1.device, 64)
+    assert tuple(wide.shape) == (N, 64) and not wide[:, 7:].any()
+    _ops.clear_caches()
+    # inconsistent terms are refused
+    with pytest.raises(ValueError):
+        zs.distributions.LinearLogits.of_terms(
+            [(w1, X1, False), (w2, _latent(N + 1, 3), False)])
+    with pytest.raises(ValueError):
+        zs.distributions.LinearLogits.of_terms(
+            [(w1, X1, False), (_latent(C + 1, 3), X2, False)])
