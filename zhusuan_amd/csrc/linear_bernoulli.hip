@@ -601,6 +601,9 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2
 #ifndef ZS_LB_PREFETCH3A
 #define ZS_LB_PREFETCH3A(D) ((D) == 128)
 #endif
+#ifndef ZS_LB_PREFETCH3A_INSIDE
+#define ZS_LB_PREFETCH3A_INSIDE 0
+#endif
 #ifndef ZS_LB_PREFETCH3B
 #define ZS_LB_PREFETCH3B(D) ((D) >= 128)
 #endif
@@ -647,13 +650,18 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2
           // next group's residual after them, where only the last MFMA is
           // left to hide them.  Ask for the LDS traffic first (the next
           // group's rows), then one MFMA, then a slice of the VALU.
-          if (kPreA && !ZS_LB_PREFETCH_FENCE(D)) {
+          // (ZS_LB_PREFETCH3A_INSIDE, unmeasured, for the next round: the
+          // next group's four reads as slots INSIDE the pipeline, one behind
+          // each of the first four MFMAs, instead of in front of it)
+          if (kPreA && !ZS_LB_PREFETCH_FENCE(D) && !ZS_LB_PREFETCH3A_INSIDE) {
             __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);  // DS read
             __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write
           }
 #pragma unroll
           for (int i = 0; i < 4 * FB; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             // MFMA
+            if (kPreA && ZS_LB_PREFETCH3A_INSIDE && i < 4)
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);           // DS read
             __builtin_amdgcn_sched_group_barrier(0x002, 16 / FB, 0);       // VALU
             __builtin_amdgcn_sched_group_barrier(0x400, (2 + FB) / FB, 0);  // trans
           }
