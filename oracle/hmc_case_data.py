@@ -72,3 +72,19 @@ def bnn_data():
         logstds.append((0.1 * rng.normal(size=(n_out, n_in + 1))).astype(
             np.float32))
     return x, y, ws0, logstds, layer_sizes, n_train
+
+
+def blr_bias_data():
+    """Round 3: logistic regression with TWO weight blocks (7 and 6 features:
+    neither a multiple of 4) and a per-chain scalar intercept -- the model
+    family of the native plan's packed state."""
+    rng = np.random.RandomState(81)
+    n_rows, d1, d2, n_chains = 45, 7, 6, 14
+    X1 = rng.normal(size=(n_rows, d1)).astype(np.float32)
+    X2 = rng.normal(size=(n_rows, d2)).astype(np.float32)
+    logit = X1 @ rng.normal(size=d1) + X2 @ rng.normal(size=d2) + 0.4
+    y = (rng.uniform(size=n_rows) < 1 / (1 + np.exp(-logit))).astype(np.int32)
+    u0 = (0.1 * rng.normal(size=(n_chains, d1))).astype(np.float32)
+    v0 = (0.1 * rng.normal(size=(n_chains, d2))).astype(np.float32)
+    b0 = (0.1 * rng.normal(size=n_chains)).astype(np.float32)
+    return X1, X2, y, u0, v0, b0

@@ -5,8 +5,8 @@ import numpy as np
 
 from oracle import distributions_ref as dref
 from oracle import pmf_ref
-from oracle.hmc_case_data import (blr_data, lntm_data, pmf_data,
-                                  softmax_regression_data)
+from oracle.hmc_case_data import (blr_bias_data, blr_data, lntm_data,
+                                  pmf_data, softmax_regression_data)
 
 F32 = np.float32
 
@@ -206,3 +206,44 @@ def cases():
                params=dict(su=su, sv=sv, r=r, v=v_obs),
                hmc_kwargs=dict(step_size=0.4, n_leapfrogs=6),
                n_iters=6, flags=lambda i: (None, None), seed=18)
+
+
+def blr_bias_model(X1, X2, y):
+    """u ~ N(0, 1), v ~ N(0, 0.5^2) (group_ndims 1), b ~ N(0, 2^2) per chain
+    (group_ndims 0), y ~ Bernoulli(u X1^T + v X2^T + b[:, None])
+    (group_ndims 1): the three-latent model of oracle/make_golden_hmc_r3.py."""
+    X1, X2 = X1.astype(F32), X2.astype(F32)
+
+    def parts(u, v, b):
+        pri = (dref.Normal(F32(0), std=F32(1), group_ndims=1),
+               dref.Normal(F32(0), std=F32(0.5), group_ndims=1),
+               dref.Normal(F32(0), std=F32(2)))
+        logits = (u @ X1.T + v @ X2.T + b[:, None]).astype(F32)
+        return pri, dref.Bernoulli(logits, group_ndims=1)
+
+    def log_joint(qs):
+        pri, lik = parts(*qs)
+        return (pri[0].log_prob(qs[0]) + pri[1].log_prob(qs[1]) +
+                pri[2].log_prob(qs[2]) + lik.log_prob(y)).astype(F32)
+
+    def grad(qs):
+        pri, lik = parts(*qs)
+        res = lik.grad_logits(y)
+        return [(pri[0].grad_given(qs[0]) + res @ X1).astype(F32),
+                (pri[1].grad_given(qs[1]) + res @ X2).astype(F32),
+                (pri[2].grad_given(qs[2]) + res.sum(-1)).astype(F32)]
+    return log_joint, grad
+
+
+def cases_r3():
+    """tests/golden/hmc_reference_traces_r3.npz (oracle/make_golden_hmc_r3.py):
+    several latents feeding one dense likelihood."""
+    X1, X2, y, _, _, _ = blr_bias_data()
+    yield dict(name='blr_bias', latent_names=['u', 'v', 'b'],
+               model=blr_bias_model(X1, X2, y),
+               params=dict(X1=X1, X2=X2, y=y),
+               hmc_kwargs=dict(step_size=0.02, n_leapfrogs=5,
+                               adapt_step_size=True, adapt_mass=True,
+                               target_acceptance_rate=0.8,
+                               mass_collect_iters=3),
+               n_iters=12, flags=lambda i: (i < 10, i < 8), seed=19)

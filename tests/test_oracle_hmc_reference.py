@@ -9,13 +9,30 @@ import numpy as np
 import pytest
 
 from oracle import hmc_ref
-from helpers_hmc_cases import cases
+from helpers_hmc_cases import cases, cases_r3
 
 
 @pytest.fixture(scope='module')
 def traces():
     return np.load(os.path.join(os.path.dirname(__file__), 'golden',
                                 'hmc_reference_traces.npz'))
+
+
+@pytest.fixture(scope='module')
+def traces_r3():
+    return np.load(os.path.join(os.path.dirname(__file__), 'golden',
+                                'hmc_reference_traces_r3.npz'))
+
+
+@pytest.mark.parametrize('case', list(cases_r3()), ids=lambda c: c['name'])
+def test_oracle_reproduces_reference_hmc_traces_several_latents(traces_r3,
+                                                                case):
+    """Round 3 (oracle/make_golden_hmc_r3.py): the reference's own hmc.py on
+    `matmul(u, X1^T) + matmul(v, X2^T) + expand_dims(b, 1)` -- two weight
+    blocks and a per-chain scalar intercept, step-size and mass adaptation
+    fed per run.  The device's packed native plan is compared with this same
+    oracle (tests/test_gpu_native_plan_limits.py)."""
+    test_oracle_reproduces_reference_hmc_traces(traces_r3, case)
 
 
 @pytest.mark.parametrize('case', list(cases()), ids=lambda c: c['name'])
