@@ -88,3 +88,19 @@ def blr_bias_data():
     v0 = (0.1 * rng.normal(size=(n_chains, d2))).astype(np.float32)
     b0 = (0.1 * rng.normal(size=n_chains)).astype(np.float32)
     return X1, X2, y, u0, v0, b0
+
+
+def lntm_ragged_data():
+    """Round 3: the topic model with K = 6 topics (not a multiple of 4: the
+    native plan pads its rows to 8 and keeps the padding out of the
+    softmax)."""
+    rng = np.random.RandomState(82)
+    n_chains, n_docs, n_topics, n_vocab = 3, 5, 6, 23
+    beta = rng.normal(size=(n_topics, n_vocab)).astype(np.float32)
+    x = rng.poisson(1.5, size=(n_docs, n_vocab)).astype(np.float32)
+    # (per topic: lntm_mcem.py:36 tiles it over the documents itself)
+    eta_mean = (0.3 * rng.normal(size=n_topics)).astype(np.float32)
+    eta_logstd = (0.2 * rng.normal(size=n_topics)).astype(np.float32)
+    eta0 = (0.5 * rng.normal(size=(n_chains, n_docs, n_topics))).astype(
+        np.float32)
+    return beta, x, eta_mean, eta_logstd, eta0

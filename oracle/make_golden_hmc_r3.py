@@ -6,7 +6,9 @@ with SEVERAL latents feeding one dense likelihood --
            + tf.matmul(v, X2, transpose_b=True) + tf.expand_dims(b, 1)
 
 (two weight blocks of 7 and 6 features, a per-chain scalar intercept with a
-group_ndims = 0 prior) -- the family the native plan's packed state samples.
+group_ndims = 0 prior) -- the family the native plan's packed state samples;
+and the topic model of lntm_mcem.py with K = 6 topics (rows padded to 8 on the
+device).
 Same machinery as oracle/make_golden_hmc.py (the reference's unmodified
 zhusuan/hmc.py and model layer over oracle/tf_shim.py, the shared Philox
 stream); writes tests/golden/hmc_reference_traces_r3.npz, which
@@ -19,8 +21,8 @@ import os
 
 import numpy as np
 
-from oracle.hmc_case_data import blr_bias_data
-from oracle.make_golden_hmc import ROOT, load_reference, run_case
+from oracle.hmc_case_data import blr_bias_data, lntm_ragged_data
+from oracle.make_golden_hmc import ROOT, load_reference, lntm_model, run_case
 
 
 def blr_bias_model(X1, X2):
@@ -61,7 +63,27 @@ def cases():
                         adapt_step_size='placeholder',
                         adapt_mass='placeholder',
                         target_acceptance_rate=0.8, mass_collect_iters=3),
-        n_iters=12, flags=lambda i: (i < 10, i < 8), seed=19)]
+        n_iters=12, flags=lambda i: (i < 10, i < 8), seed=19),
+        _lntm_ragged()]
+
+
+def _lntm_ragged():
+    # the reference's own `lntm` (examples/topic_models/lntm_mcem.py:31-48,
+    # imported) with K = 6 topics
+    beta, x, eta_mean, eta_logstd, eta0 = lntm_ragged_data()
+    n_c, n_d, n_k = eta0.shape
+    return dict(
+        name='lntm_k6', chain_shape=(n_c, n_d),
+        make_log_joint=lntm_model(eta_mean, eta_logstd, n_d, n_k, x.shape[1]),
+        make_observed=lambda tf: {
+            'x': tf.constant(np.tile(x[None], (n_c, 1, 1))),
+            'beta': tf.constant(beta)},
+        latents={'eta': eta0},
+        hmc_kwargs=dict(step_size=5e-3, n_leapfrogs=5,
+                        adapt_step_size='placeholder',
+                        adapt_mass='placeholder',
+                        target_acceptance_rate=0.6, mass_collect_iters=3),
+        n_iters=12, flags=lambda i: (i < 10, i < 8), seed=20)
 
 
 def main():

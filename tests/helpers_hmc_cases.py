@@ -6,7 +6,8 @@ import numpy as np
 from oracle import distributions_ref as dref
 from oracle import pmf_ref
 from oracle.hmc_case_data import (blr_bias_data, blr_data, lntm_data,
-                                  pmf_data, softmax_regression_data)
+                                  lntm_ragged_data, pmf_data,
+                                  softmax_regression_data)
 
 F32 = np.float32
 
@@ -247,3 +248,13 @@ def cases_r3():
                                target_acceptance_rate=0.8,
                                mass_collect_iters=3),
                n_iters=12, flags=lambda i: (i < 10, i < 8), seed=19)
+    beta, x, eta_mean, eta_logstd, _ = lntm_ragged_data()
+    yield dict(name='lntm_k6', latent_names=['eta'],
+               model=lntm_model(beta, x, eta_mean, eta_logstd),
+               params=dict(beta=beta, x=x, eta_mean=eta_mean,
+                           eta_logstd=eta_logstd),
+               hmc_kwargs=dict(step_size=5e-3, n_leapfrogs=5,
+                               adapt_step_size=True, adapt_mass=True,
+                               target_acceptance_rate=0.6,
+                               mass_collect_iters=3),
+               n_iters=12, flags=lambda i: (i < 10, i < 8), seed=20)
