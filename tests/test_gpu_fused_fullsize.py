@@ -195,6 +195,64 @@ def test_free_running_config1_full_size(env):
     assert abs(got[2] - want[2]) <= 0.01 * want[2], (got, want)
 
 
+def test_free_running_config2_full_size_against_the_c_port(env):
+    """BASELINE configs[1] at its FULL size, free-running: 65 536 chains x
+    1 024 latents, std_j = exp(linspace(-1, 1)), q0 = 0, eps0 = 0.05, L = 10,
+    delta = 0.8, Philox seed 1 -- the step-size search at t = 1,
+    40 adaptive transitions through the reference's start-up transient
+    (mu = 10 eps0 used as a log step size, Appendix B 1: eps jumps to ~ 1.6,
+    acceptance sits at 0 until dual averaging pulls it back), then 10 with
+    adaptation held -- device vs the C + OpenMP port of the oracle on ALL
+    65 536 chains (oracle/hmc_c.py::DiagNormalFreeRun: every host thread;
+    ~0.1 s per transition on the GPU box), nothing re-synchronised.  Every
+    iteration: the mean acceptance of all chains within 1 % (1e-3 absolute
+    while it is ~ 0), the step size for the next iteration within 1 %; at the
+    end: the per-chain acceptance of the last transition, and the states of
+    the chains that never met a borderline MH decision."""
+    from oracle import hmc_c
+    zs, torch = env
+    C, D, L = 65536, 1024, 10
+    logstd = np.linspace(-1, 1, D).astype(np.float32)
+    mean = np.zeros(D, np.float32)
+    q0 = np.zeros((C, D), np.float32)
+    flag = zs.placeholder(bool)
+    hmc, op, info, xg = gpu_sampler(
+        zs, torch, mean, logstd, q0, step_size=0.05, n_leapfrogs=L,
+        adapt_step_size=flag, target_acceptance_rate=0.8, seed=1)
+    assert hmc.plan_kind == 'fused_diag_normal'
+    xr = q0.copy()
+    ref = hmc_c.DiagNormalFreeRun(xr, mean, logstd, 0.05, L,
+                                  target_acceptance_rate=0.8, seed=1)
+    n_adapt, n_hold = 40, 10
+    acc_g = acc_r = 0.0
+    for i in range(n_adapt + n_hold):
+        a = i < n_adapt
+        rinfo, racc = ref.run(a)
+        op.run(feed_dict={flag: a})
+        gacc = float(info.acceptance_rate.mean(dtype=torch.float64).item())
+        assert abs(gacc - float(racc)) <= 0.01 * float(racc) + 1e-3, \
+            (i, gacc, float(racc))
+        eps_g = float(info.updated_step_size.item())
+        assert abs(eps_g - float(ref.step_size)) <= \
+            0.01 * float(ref.step_size), (i, eps_g, float(ref.step_size))
+        if i == 0:
+            assert hmc.n_init_trips == ref.n_init_trips
+        if not a:
+            acc_g += gacc / n_hold
+            acc_r += float(racc) / n_hold
+    assert abs(acc_g - acc_r) <= 0.01 * acc_r, (acc_g, acc_r)
+    assert 0.6 < acc_g < 0.95
+    # chain by chain after 50 free transitions: a chain whose MH test was
+    # numerically borderline once is on another trajectory from then on;
+    # all others still agree to float32 rounding carried through 500 steps
+    got = xg.cpu().numpy()
+    same = np.isclose(got, xr, rtol=2e-3, atol=2e-3).all(axis=1)
+    assert same.mean() > 0.95, same.mean()
+    ga = info.acceptance_rate.cpu().numpy()
+    np.testing.assert_allclose(ga[same], rinfo['acceptance_rate'][same],
+                               atol=5e-3)
+
+
 def test_adapted_step_size_is_bit_stable_run_to_run(env):
     """The acceptance sum that drives dual averaging (hmc.py:377) is added in
     a fixed order (per-workgroup partials, index-ordered final sum), so two

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers_hmc_cases import cases
+from helpers_hmc_cases import cases, cases_r3
 
 pytestmark = pytest.mark.gpu
 
@@ -17,8 +17,13 @@ def env():
     import torch
     import zhusuan_amd as zs
     assert torch.cuda.is_available()
-    traces = np.load(os.path.join(os.path.dirname(__file__), 'golden',
-                                  'hmc_reference_traces.npz'))
+    golden = os.path.join(os.path.dirname(__file__), 'golden')
+    # round 3's traces (several latents feeding one dense likelihood, ragged
+    # topic count: oracle/make_golden_hmc_r3.py) carry their own case names
+    traces = {}
+    for f in ('hmc_reference_traces.npz', 'hmc_reference_traces_r3.npz'):
+        z = np.load(os.path.join(golden, f))
+        traces.update({k: z[k] for k in z.files})
     return zs, torch, torch.device('cuda', 0), traces
 
 
@@ -30,6 +35,10 @@ def env():
 # still reproduce the traces
 VARIANTS = {'blr': ('native', 'generic', 'dense', 'nearmiss'),
             'lntm': ('native', 'generic', 'dense', 'nearmiss'),
+            # the packed native plan: three latents in one row of 16 floats
+            # (7 + 6 + 1, padded), topic rows of 6 padded to 8
+            'blr_bias': ('dense', 'generic', 'nearmiss'),
+            'lntm_k6': ('native', 'generic', 'dense', 'nearmiss'),
             'pmf': ('fused', 'dense')}
 
 
@@ -52,6 +61,30 @@ def _build_blr(zs, torch, dev, case, qs, variant):
         bn.bernoulli('y', logits, group_ndims=1)
         return bn
     plan = 'linear_bernoulli' if variant in ('native', 'dense') else 'generic'
+    return model(), plan, {'y': y}
+
+
+def _build_blr_bias(zs, torch, dev, case, qs, variant):
+    """oracle/make_golden_hmc_r3.py::blr_bias_model in the reference's literal
+    spelling: matmul(u, X1^T) + matmul(v, X2^T) + expand_dims(b, 1)."""
+    X1 = torch.tensor(case['params']['X1'], device=dev)
+    X2 = torch.tensor(case['params']['X2'], device=dev)
+    y = torch.tensor(case['params']['y'], device=dev)        # int32
+    C = qs['u'].shape[0]
+
+    @zs.meta_bayesian_net()
+    def model():
+        bn = zs.BayesianNet()
+        u = bn.normal('u', torch.zeros(X1.shape[1], device=dev), std=1.,
+                      n_samples=C, group_ndims=1)
+        v = bn.normal('v', torch.zeros(X2.shape[1], device=dev), std=0.5,
+                      n_samples=C, group_ndims=1)
+        b = bn.normal('b', torch.zeros((), device=dev), std=2., n_samples=C)
+        ut = u.tensor * 1.0 if variant == 'nearmiss' else u.tensor
+        logits = ut @ X1.t() + v.tensor @ X2.t() + b.tensor.unsqueeze(1)
+        bn.bernoulli('y', logits, group_ndims=1)
+        return bn
+    plan = 'linear_bernoulli' if variant == 'dense' else 'generic'
     return model(), plan, {'y': y}
 
 
@@ -144,7 +177,9 @@ def _build(zs, torch, dev, case, qs, variant=None):
     name = case['name']
     if name == 'blr':
         return _build_blr(zs, torch, dev, case, qs, variant)
-    if name == 'lntm':
+    if name == 'blr_bias':
+        return _build_blr_bias(zs, torch, dev, case, qs, variant)
+    if name in ('lntm', 'lntm_k6'):
         return _build_lntm(zs, torch, dev, case, qs, variant)
     if name == 'pmf':
         return _build_pmf(zs, torch, dev, case, qs, variant)
@@ -181,7 +216,7 @@ def _build_plain(zs, torch, dev, case, qs):
 
 
 def _case_variants():
-    for c in cases():
+    for c in list(cases()) + list(cases_r3()):
         for v in VARIANTS.get(c['name'], (None,)):
             yield pytest.param(c, v, id=c['name'] + ('' if v is None
                                                      else '-' + v))

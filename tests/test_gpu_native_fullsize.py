@@ -134,11 +134,18 @@ def test_config3_full_size_transition_matches_oracle_on_a_subset(env):
     zs, torch, dev = env
     from oracle.hmc_ref import HMC as RefHMC
     C, N, D, L, eps, seed = 32768, 1000000, 256, 10, 2e-4, 31
+    # the data BASELINE.md / SURVEY 8d c3 name, as bench.py::extra_config3
+    # draws them: X ~ N(0, 1) float32, w* ~ N(0, 1), y ~ Bernoulli(
+    # sigmoid(X w* / sqrt(D))) from numpy.random.default_rng(0)
+    rng0 = np.random.default_rng(0)
+    X_h = rng0.standard_normal((N, D), dtype=np.float32)
+    w_h = rng0.standard_normal(D).astype(np.float32)
+    y_h = rng0.random(N) < 1.0 / (1.0 + np.exp(-(X_h @ w_h) / F32(D ** 0.5)))
+    X = torch.from_numpy(X_h).to(dev)
+    w_true = torch.from_numpy(w_h).to(dev)
+    y = torch.from_numpy(y_h.astype(np.float32)).to(dev)
+    del X_h, y_h
     g = torch.Generator(device=dev).manual_seed(0)
-    X = torch.randn(N, D, device=dev, generator=g)
-    w_true = torch.randn(D, device=dev, generator=g)
-    y = (torch.rand(N, device=dev, generator=g) <
-         torch.sigmoid(X @ w_true / D ** 0.5)).float()
     # chains scattered over the posterior's bulk (width ~2e-3 at N = 10^6)
     w = (w_true / D ** 0.5 +
          2e-3 * torch.randn(C, D, device=dev, generator=g)).contiguous()

@@ -60,3 +60,31 @@ def test_c_port_thread_count_invariance_and_bad_start():
     q[3, 0] = np.inf
     _, bad = hmc_c.step(q, mean, logstd, 4, 0.2, 9, 1)
     assert bad
+
+
+def test_c_port_free_run_follows_the_numpy_oracle():
+    """hmc_c.DiagNormalFreeRun (the C transition + the step-size search +
+    oracle/hmc_ref.py's tuner) against hmc_ref.HMC free-running from the same
+    seed: search at t == 1, 30 adaptive transitions through the mu = 10 eps0
+    transient (acceptance 0 for a few iterations), 10 with adaptation held."""
+    C, D = 256, 64
+    logstd = np.linspace(-1, 1, D).astype(np.float32)
+    mean = np.zeros(D, np.float32)
+    q = np.zeros((C, D), np.float32)
+    fr = hmc_c.DiagNormalFreeRun(q, mean, logstd, 0.05, 10, seed=1)
+    m = DiagNormalModel(mean, logstd=logstd)
+    xr = np.zeros((C, D), np.float32)
+    ref = RefHMC(step_size=0.05, n_leapfrogs=10, adapt_step_size=True,
+                 seed=1)
+    ref.sample(m.log_joint, m.grad, [xr])
+    for i in range(40):
+        a = i < 30
+        info, acc = fr.run(a)
+        ri = ref.step(adapt_step_size=a)
+        if i == 0:
+            assert fr.n_init_trips == ref.n_init_trips
+        np.testing.assert_allclose(acc, np.mean(ri.acceptance_rate),
+                                   atol=2e-5)
+        np.testing.assert_allclose(fr.step_size, ref.step_size, rtol=1e-5)
+    same = np.isclose(q, xr, rtol=1e-4, atol=1e-4).all(axis=1)
+    assert same.mean() > 0.97
