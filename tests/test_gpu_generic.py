@@ -278,6 +278,51 @@ def test_foreign_autograd_function_falls_back_to_plain_tensors(env):
         C, D)).float().mean()) > 0.5          # the chains moved
 
 
+def test_foreign_autograd_function_in_a_meta_bayesian_net(env):
+    """the same through a MetaBayesianNet -- the cut fires inside
+    the plan recognisers (latents that require grad), not in sample()'s first
+    evaluation; HMC.sample must fall back to plain tensors on the generic
+    plan and sample exactly as the model written without the Function."""
+    zs, torch, dev = env
+    C, D, N = 48, 5, 40
+    g = torch.Generator(device=dev).manual_seed(3)
+    X = torch.randn(N, D, device=dev, generator=g)
+    y = (torch.rand(N, device=dev, generator=g) < 0.5).float()
+
+    class Scale(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x * 1.5
+
+        @staticmethod
+        def backward(ctx, g):
+            return g * 1.5
+
+    def make(use_function):
+        @zs.meta_bayesian_net()
+        def model():
+            bn = zs.BayesianNet()
+            w = bn.normal('w', torch.zeros(D, device=dev), std=1.,
+                          n_samples=C, group_ndims=1)
+            s = Scale.apply(w.tensor) if use_function else w.tensor * 1.5
+            bn.bernoulli('y', s @ X.t(), group_ndims=1, dtype=torch.float32)
+            return bn
+        h = zs.HMC(step_size=0.05, n_leapfrogs=4, seed=5)
+        q = torch.zeros(C, D, device=dev)
+        op, info = h.sample(model(), {'y': y}, {'w': q})
+        assert h.plan_kind == 'generic'
+        for _ in range(5):
+            op.run()
+        return h, q, info.acceptance_rate.clone()
+
+    ha, qa, acc_a = make(True)
+    hb, qb, acc_b = make(False)
+    assert ha._symbolic_latents is False and hb._symbolic_latents is True
+    torch.testing.assert_close(qa, qb, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(acc_a, acc_b, rtol=1e-5, atol=1e-6)
+    assert float((qa != 0).float().mean()) > 0.5
+
+
 def test_run_many_on_the_generic_plan_is_a_loop_of_runs(env):
     zs, torch, dev = env
     C, D = 128, 5

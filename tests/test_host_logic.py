@@ -509,3 +509,52 @@ def test_native_plan_recognises_several_latents_per_likelihood(monkeypatch):
                      dtype=torch.float32)
         return bn
     assert plan_of(too_wide, {'w': torch.zeros(C, 1100)}) is None
+
+
+def test_plan_recognition_survives_a_foreign_autograd_function(monkeypatch):
+    """a MetaBayesianNet model that passes a latent
+    through a user torch.autograd.Function.  sample()'s first evaluation runs
+    on latents without grad, so no SymbolicCut fires there; the plan
+    recognisers then re-run the model with requires_grad symbols and the cut
+    fires inside THEM -- it must not escape HMC.sample(): plain tensors from
+    then on, generic plan."""
+    import torch
+    import zhusuan_amd as zs
+    from zhusuan_amd import _symbolic, hmc as H
+    C, D, N = 5, 4, 12
+    X = torch.randn(N, D)
+    y = (torch.rand(N) < 0.5).to(torch.float32)
+
+    class Scale(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x * 1.5
+
+        @staticmethod
+        def backward(ctx, g):
+            return g * 1.5
+
+    @zs.meta_bayesian_net()
+    def model():
+        bn = zs.BayesianNet()
+        w = bn.normal('w', torch.zeros(D), std=1., n_samples=C,
+                      group_ndims=1)
+        bn.bernoulli('y', Scale.apply(w.tensor) @ X.t(), group_ndims=1,
+                     dtype=torch.float32)
+        return bn
+
+    class Stub(object):
+        def __init__(self, *a):
+            raise AssertionError('a native plan was built')
+
+    monkeypatch.setattr(H, '_DenseLikelihoodPlan', Stub)
+    q = torch.zeros(C, D)
+    hmc = zs.HMC(step_size=1e-3)
+    hmc._observed = {'y': y}
+    # the recogniser alone raises (what used to escape) ...
+    with pytest.raises(_symbolic.SymbolicCut):
+        H._try_dense_likelihood_plan(hmc, model(), ['w'], [q], (C,), q.device)
+    # ... the sampler's wrapper turns it into the generic plan
+    assert hmc._symbolic_latents is True
+    assert hmc._recognise_plan(model(), ['w'], [q], (C,), q.device) is None
+    assert hmc._symbolic_latents is False

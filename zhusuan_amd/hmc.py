@@ -300,11 +300,8 @@ class HMC(object):
                     "match the chain shape {} of the log joint."
                     .format(k, tuple(v.shape), chain_shape))
         device = latent_v[0].device
-        plan = _try_fused_plan(self, meta_bn, latent_k, latent_v, chain_shape,
-                               device)
-        if plan is None and self.native_plans:
-            plan = _try_dense_likelihood_plan(self, meta_bn, latent_k,
-                                              latent_v, chain_shape, device)
+        plan = self._recognise_plan(meta_bn, latent_k, latent_v, chain_shape,
+                                    device)
         if plan is None:
             plan = _GenericPlan(self, latent_k, latent_v, chain_shape, device)
         self._plan = plan
@@ -322,6 +319,28 @@ class HMC(object):
             log_prob=plan.log_prob.view(chain_shape))
         self.hmc_info = info
         return _SampleOp(self), info
+
+    def _recognise_plan(self, meta_bn, names, values, chain_shape, device):
+        """The fused or a native dense-likelihood plan for this model, or
+        None (generic plan).  The recognisers re-run the model on latents
+        that require grad: a user autograd.Function (or a torch.no_grad()
+        block) that takes a symbolic latent raises SymbolicCut THERE, not in
+        sample()'s first evaluation (whose latents carry no grad).  Same
+        answer as in _eval_log_joint: plain tensors from now on, and the
+        recognisers run once more on those."""
+        for _ in range(2):
+            try:
+                plan = _try_fused_plan(self, meta_bn, names, values,
+                                       chain_shape, device)
+                if plan is None and self.native_plans:
+                    plan = _try_dense_likelihood_plan(
+                        self, meta_bn, names, values, chain_shape, device)
+                return plan
+            except _symbolic.SymbolicCut:
+                if not self._symbolic_latents:
+                    raise
+                self._symbolic_latents = False
+        return None
 
     def _eval_log_joint(self, names, values):
         # the latents travel as symbols so that the reference's literal dense
