@@ -68,6 +68,12 @@ def parse():
                     default='gaussian',
                     help="gaussian: configs[1]/[3] (the headline); lntm: "
                          "configs[4], chains sharded over --gpus ranks")
+    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak',
+                    help="weak: --chains-per-gpu chains on every GPU "
+                         "(configs[3] at N = 8); strong: --chains-per-gpu "
+                         "chains IN TOTAL, split over the ranks (SURVEY 8d "
+                         "c4's fixed-total mode); at N > 1 the weak line also "
+                         "carries a `strong_scaling` block")
     ap.add_argument('--lntm-chains-per-gpu', type=int, default=1024)
     ap.add_argument('--lntm-docs', type=int, default=5000)
     ap.add_argument('--lntm-vocab', type=int, default=12419)
@@ -635,10 +641,14 @@ def extra_config5(torch, zs, dev, n_chains=None, **kw):
 
 def make_sharding(dist, torch, ChainSharding, backend, dev, **layout):
     """The direct RCCL communicator, proven with one all-reduce before it is
-    trusted; if its bootstrap fails or does not come back within two minutes
-    on ANY rank, every rank falls back to torch.distributed over the gloo
-    bootstrap group (device tensors staged through the host) so that the run
-    still produces its line -- which then says so (`rccl_ranks` 0)."""
+    trusted.  If its bootstrap fails or does not come back within two minutes
+    on ANY rank, every rank EXITS NON-ZERO (a scaling curve measured over a
+    host-staged gloo fallback would be a curve of the wrong thing): rank 0
+    says why on stderr.  torch.distributed over the gloo bootstrap group
+    (device tensors staged through the host) is used only when asked for --
+    ZSHMC_DIST_BACKEND=gloo (two ranks sharing one GPU in the functional
+    tests), or ZSHMC_ALLOW_GLOO_FALLBACK=1 to keep a failed RCCL bootstrap
+    from costing the line (which then says so: `rccl_ranks` 0)."""
     import threading
     if backend != 'rccl':
         return ChainSharding(backend='torch', **layout), \
@@ -652,10 +662,12 @@ def make_sharding(dist, torch, ChainSharding, backend, dev, **layout):
             probe = torch.ones(2, dtype=torch.float64, device=dev)
             sh.all_reduce_sum(probe)
             torch.cuda.synchronize()
-            if probe.tolist() == [float(sh.world_size)] * 2:
+            if probe.tolist() == [float(sh.world_size)] * 2 and \
+                    sh.rccl_ranks == sh.world_size:
                 box['sh'] = sh
             else:
-                box['err'] = 'probe all-reduce returned %r' % (probe.tolist(),)
+                box['err'] = 'probe all-reduce returned %r over %d RCCL ' \
+                    'ranks' % (probe.tolist(), sh.rccl_ranks)
         except Exception as e:                       # noqa: BLE001
             box['err'] = repr(e)[:300]
     th = threading.Thread(target=attempt, daemon=True)
@@ -665,9 +677,50 @@ def make_sharding(dist, torch, ChainSharding, backend, dev, **layout):
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     if float(ok.item()) == 1.0:
         return box['sh'], 'RCCL (ncclAllReduce through zshmc_comm_*)'
+    why = box.get('err', 'this rank was fine; a peer failed' if 'sh' in box
+                  else 'bootstrap did not return within 120 s')
+    if os.environ.get('ZSHMC_ALLOW_GLOO_FALLBACK') != '1':
+        sys.stderr.write(json.dumps({
+            'error': 'RCCL communicator unavailable on rank %d of %d: %s' % (
+                dist.get_rank(), dist.get_world_size(), why),
+            'hint': 'ZSHMC_DIST_BACKEND=gloo runs the collectives over '
+                    'torch.distributed/gloo on purpose; '
+                    'ZSHMC_ALLOW_GLOO_FALLBACK=1 falls back to it'}) + '\n')
+        sys.stderr.flush()
+        os._exit(3)
     return ChainSharding(backend='torch', **layout), (
         'FALLBACK torch.distributed/gloo: RCCL communicator unavailable (%s)'
-        % box.get('err', 'bootstrap did not return within 120 s'))
+        % why)
+
+
+def allreduce_latency(torch, sharding, dev, n_iter=1000):
+    """The transition's collective alone: `n_iter` all-reduces of the 2-double
+    statistics message back to back on the compute stream under one HIP-event
+    pair (what each adaptive transition adds to its kernel when the chains
+    are sharded)."""
+    buf = torch.zeros(2, dtype=torch.float64, device=dev)
+    for _ in range(20):
+        sharding.all_reduce_sum(buf)
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n_iter):
+        sharding.all_reduce_sum(buf)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n_iter * 1e3
+
+
+def _over_ranks(dist, torch, world, x):
+    """(min, max) of a per-rank host number."""
+    if world == 1:
+        return x, x
+    lo = torch.tensor([x], dtype=torch.float64)
+    hi = lo.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    return float(lo.item()), float(hi.item())
 
 
 def run_lntm_line(args, torch, zs, dist, ChainSharding, dev, world, rank,
@@ -750,12 +803,26 @@ def main():
                       backend)
         return
     if world > 1:
+        per_rank = args.chains_per_gpu // world if args.scaling == 'strong' \
+            else args.chains_per_gpu
         sharding, collective_note = make_sharding(
             dist, torch, ChainSharding, backend, dev,
-            chain_offset=rank * args.chains_per_gpu,
-            n_chains_global=world * args.chains_per_gpu)
+            chain_offset=rank * per_rank, n_chains_global=world * per_rank)
 
     C, D, L = args.chains_per_gpu, args.n_data, args.leapfrogs
+    if args.scaling == 'strong':
+        if C % world:
+            raise SystemExit('--scaling strong: %d chains do not split over '
+                             '%d ranks' % (C, world))
+        C //= world
+    ar_us = None
+    if world > 1:
+        lo, hi = _over_ranks(dist, torch, world,
+                             allreduce_latency(torch, sharding, dev))
+        ar_us = {'min_over_ranks': lo, 'max_over_ranks': hi,
+                 'what': '1000 all-reduces of the 2-double statistics '
+                         'message back to back on the compute stream, us '
+                         'per call'}
     logstd = torch.linspace(-1.0, 1.0, D, device=dev)     # std = e^[-1, 1]
     mean = torch.zeros(D, device=dev)
 
@@ -826,10 +893,7 @@ def main():
     ev1.record()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    el_min, elapsed = _over_ranks(dist, torch, world, elapsed)
     hmc.check_numerics()
     acc_mean = float(info.acceptance_rate.mean().item())
     eps = float(info.updated_step_size.item())
@@ -945,6 +1009,49 @@ def main():
                 'one run_many call (zshmc_hmc_diag_normal_run)',
     }
 
+    # strong scaling next to the weak headline ("fixed-total
+    # strong scaling"): the SAME --chains-per-gpu chains in total, split over
+    # the ranks, adaptation on so that the all-reduce is in the loop
+    strong = None
+    if world > 1 and args.scaling == 'weak' and \
+            args.chains_per_gpu % world == 0:
+        Cs = args.chains_per_gpu // world
+
+        @zs.meta_bayesian_net()
+        def gaussian_s():
+            bn = zs.BayesianNet()
+            bn.normal('x', mean, logstd=logstd, n_samples=Cs, group_ndims=1)
+            return bn
+        xs = torch.zeros(Cs, D, device=dev)
+        f_s = zs.placeholder(bool)
+        hmc_s = zs.HMC(step_size=0.05, n_leapfrogs=L, adapt_step_size=f_s,
+                       target_acceptance_rate=0.8, seed=1,
+                       sharding=sharding.relayout(
+                           chain_offset=rank * Cs,
+                           n_chains_global=args.chains_per_gpu))
+        op_s, info_s = hmc_s.sample(gaussian_s(), {}, {'x': xs})
+        for _ in range(BURN_IN_ADAPT):
+            op_s.run(feed_dict={f_s: True}, sync=False)
+        hmc_s.check_numerics()
+        op_s.run_many(100 + args.warmup, feed_dict={f_s: True}, sync=False)
+        barrier()
+        t1 = time.perf_counter()
+        op_s.run_many(args.steps, feed_dict={f_s: True}, sync=False)
+        barrier()
+        s_min, s_el = _over_ranks(dist, torch, world,
+                                  time.perf_counter() - t1)
+        hmc_s.check_numerics()
+        strong = {
+            'n_chains_total': args.chains_per_gpu, 'chains_per_gpu': Cs,
+            'adaptation': 'on', 'steps': args.steps,
+            'ms_per_step': s_el / args.steps * 1e3,
+            'ms_per_step_fastest_rank': s_min / args.steps * 1e3,
+            'value': args.chains_per_gpu * L * args.steps / s_el,
+            'mean_acceptance': float(info_s.acceptance_rate.mean().item()),
+            'kernel': _capi_kernel_name(D, 0, 1),
+        }
+        del hmc_s, op_s, info_s, xs
+
     # mass adaptation (config 1's first 50 iterations, config 5): a second
     # sampler on the same state with adapt_mass declared, so that the mass
     # tile is part of the kernel.  Step size + mass adapting on every
@@ -1036,11 +1143,12 @@ def main():
             'warmup': args.warmup,
             'ms_per_step': ms_per_step,
             'higher_is_better': True,
-            'scaling': 'weak',
+            'scaling': args.scaling,
             'vs_baseline': None,
             'dtype': 'f32',
             'data': 'synthetic',
             'config': {
+                'rng': rng_name,
                 'workload': 'configs[1]: %d chains/GPU x %d-D diagonal '
                             'Gaussian (std=exp(linspace(-1,1))), L=%d, q0=0, '
                             '50 adaptive burn-in transitions, timed with '
@@ -1055,6 +1163,10 @@ def main():
             },
             'rccl_ranks': 0 if sharding is None else sharding.rccl_ranks,
             'collective': collective_note,
+            'allreduce_latency_us': ar_us,
+            'ms_per_step_ranks': {'min': el_min / args.steps * 1e3,
+                                  'max': elapsed / args.steps * 1e3},
+            'strong_scaling': strong,
             'launches_per_transition': 1,
             'driver': 'sample_op.run_many(K): one call into libzshmc.so launches '
                       'the K transitions of the timed region',
