@@ -942,6 +942,45 @@ def main():
     hmc.t = t_iter + 1 + n_pre + reps
     algo_bytes = ALGO_BYTES_PER_ELEM * C * D
     from zhusuan_amd import _capi
+    # which generator produced the headline, and the same kernel built with
+    # the other round count (lib/libzshmc_philox10.so: Random123's and
+    # TensorFlow's ten rounds) timed the same way right behind it
+    rounds = int(_capi.load().zshmc_philox_rounds())
+    rng_name = 'philox4x32-%d' % rounds
+    other_generator = None
+    alt_path = os.path.join(os.path.dirname(_capi.LIB_PATH),
+                            'libzshmc_philox10.so')
+    if world == 1 and rounds != 10 and os.path.exists(alt_path):
+        alt = _capi.load_build(alt_path)
+        for i in range(n_pre):
+            plan._launch(hmc.t + i, None, 1, L, stream, lib=alt)
+        e0.record()
+        for i in range(reps):
+            plan._launch(hmc.t + n_pre + i, None, 1, L, stream, lib=alt)
+        e1.record()
+        # ... and the default build once more, so that the pair shares the
+        # chip's state (clocks, temperature) as closely as one stream allows
+        e2, e3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(
+            enable_timing=True)
+        for i in range(n_pre):
+            plan._launch(hmc.t + i, None, 1, L, stream)
+        e2.record()
+        for i in range(reps):
+            plan._launch(hmc.t + n_pre + i, None, 1, L, stream)
+        e3.record()
+        torch.cuda.synchronize()
+        alt_ms, same_ms = e0.elapsed_time(e1) / reps, e2.elapsed_time(e3) / reps
+        hmc.t += 2 * (n_pre + reps)
+        other_generator = {
+            'rng': 'philox4x32-%d' % int(alt.zshmc_philox_rounds()),
+            'library': 'zhusuan_amd/lib/libzshmc_philox10.so '
+                       '(-DZS_PHILOX_ROUNDS=10, same sources)',
+            'kernel_ms_back_to_back': alt_ms,
+            'frac': algo_bytes / (alt_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            'default_build_right_after': {
+                'rng': rng_name, 'kernel_ms_back_to_back': same_ms,
+                'frac': algo_bytes / (same_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+        }
     kernel_name = _capi.load().zshmc_fused_kernel_name(D, 0, 1).decode()
     achieved = algo_bytes / (kern_ms * 1e-3) / 1e9
     # HBM bytes per launch from the PMC counters: NOT collected in this run
@@ -1191,6 +1230,8 @@ def main():
                 'kernel_launches_timed': n_timed,
                 'kernel_timing': kernel_timing,
                 'algorithmic_bytes_per_launch': algo_bytes,
+                'rng': rng_name,
+                'other_generator': other_generator,
             },
         }
         if ess is not None:

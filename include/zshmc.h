@@ -61,6 +61,12 @@ extern "C" {
 
 const char* zshmc_last_error(void);
 int zshmc_version(void);
+/* Rounds of the Philox4x32 generator this library was built with: 7 (the
+ * default: Random123's minimum Crush-resistant count, SC'11 table 2) or 10
+ * (-DZS_PHILOX_ROUNDS=10: Random123's and TensorFlow's default;
+ * zhusuan_amd/lib/libzshmc_philox10.so).  The counter mapping is the same;
+ * the streams differ, so a run is reproducible only on one of them. */
+int zshmc_philox_rounds(void);
 /* Clear n_bytes of device memory on `stream` (the += accumulators below:
  * kinetic energies, column sums). */
 int zshmc_zero(void* ptr, int64_t n_bytes, void* stream);

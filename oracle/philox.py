@@ -3,11 +3,13 @@ the device code (zhusuan_amd/csrc/philox.h).  TEST INFRASTRUCTURE (see
 oracle/__init__.py).
 
 The reference draws momentum / MH uniforms with tf.random_normal /
-tf.random_uniform (hmc.py:22, hmc.py:485), i.e. TensorFlow's Philox4x32-7
+tf.random_uniform (hmc.py:22, hmc.py:485), i.e. TensorFlow's Philox4x32-10
 stream keyed by graph seed + op id.  TensorFlow (requirements-dev.txt:2,
 "tensorflow>=1.13.0") is not vendored, so the stream itself cannot be
-reproduced; we restate the published Philox4x32-7 algorithm (Salmon et al.,
-SC'11, Random123) and define our own counter mapping:
+reproduced; we restate the published Philox4x32-R algorithm (Salmon et al.,
+SC'11, Random123) with R = 7 rounds -- THIS repository's choice, not
+TensorFlow's (csrc/philox.h says why; R = 10 is libzshmc_philox10.so) -- and
+define our own counter mapping:
 
     key     = (seed_lo, seed_hi)
     counter = (c0, c1, c2, c3) =

@@ -58,6 +58,7 @@ _p = c_void_p  # every device pointer / stream travels as void*
 PROTOTYPES = {
     'zshmc_last_error': (c_char_p, []),
     'zshmc_version': (c_int, []),
+    'zshmc_philox_rounds': (c_int, []),
     'zshmc_zero': (c_int, [_p, c_int64, _p]),
     'zshmc_fused_max_n_data': (c_int64, []),
     'zshmc_fused_kernel_name': (c_char_p, [c_int64, c_int, c_int]),
@@ -211,6 +212,28 @@ def call(name, *args):
     rc = getattr(load(), name)(*args)
     if rc != ZSHMC_OK:
         raise ZshmcError('%s failed (status %d): %s' % (name, rc, last_error()))
+
+
+def call_on(lib, name, *args):
+    """`call` on a library handle of `load_build`."""
+    rc = getattr(lib, name)(*args)
+    if rc != ZSHMC_OK:
+        msg = lib.zshmc_last_error()
+        raise ZshmcError('%s failed (status %d): %s' % (
+            name, rc, msg.decode('utf-8', 'replace') if msg else ''))
+
+
+def load_build(path):
+    """Another build of the same library (the Philox4x32-10 build,
+    lib/libzshmc_philox10.so) with the same prototypes -- for measurements
+    that put two builds side by side in one process (bench.py's
+    `other_generator`).  The product itself always runs `load()`."""
+    lib = ctypes.CDLL(path)
+    for name, (restype, argtypes) in PROTOTYPES.items():
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    return lib
 
 
 def ptr(t):

@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include "common.h"
+#include "philox.h"
 
 namespace zshmc {
 
@@ -36,6 +37,7 @@ int device_cu_count() {
 
 extern "C" const char* zshmc_last_error(void) { return zshmc::g_err; }
 extern "C" int zshmc_version(void) { return ZSHMC_VERSION; }
+extern "C" int zshmc_philox_rounds(void) { return ZS_PHILOX_ROUNDS; }
 
 // hipMemsetAsync(0) on the caller's stream: the per-chain accumulators of the
 // transition (kinetic energies) are cleared without an ATen fill kernel.

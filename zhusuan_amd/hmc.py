@@ -904,7 +904,9 @@ class _FusedDiagNormalPlan(_PlanBase):
         return k
 
     def _launch(self, t, eps_host, commit, n_leapfrogs, stream, retire=None,
-                colstats_rows=0):
+                colstats_rows=0, lib=None):
+        # (`lib`: another build of the library, _capi.load_build -- only
+        # bench.py's side-by-side timing of the two generators passes one)
         info = commit
         if self.pending is not None and eps_host is not None:
             raise RuntimeError("a pending step-size update must be flushed "
@@ -913,7 +915,8 @@ class _FusedDiagNormalPlan(_PlanBase):
         collect = (self.collect_acc or not commit or
                    self.pending is not None or retire is not None)
         link = self._link(eps_host, collect, retire, colstats_rows)
-        _capi.call(
+        (_capi.call if lib is None else
+         (lambda *a: _capi.call_on(lib, *a)))(
             'zshmc_hmc_diag_normal_step', self.q[0].data_ptr(),
             None if self.zero_mean else self.mean.data_ptr(),
             self.logstd.data_ptr(), self.mass_ptr(0),
