@@ -448,6 +448,41 @@ int zshmc_unnormalized_multinomial_log_prob_grad(
     float* glogits, int64_t rows, int64_t n_cat, int normalize, void* stream);
 
 /* ------------------------------------------------------------------------
+ * zshmc_model_kick_drift for latents that are LONG per chain and whose
+ * likelihood gradient arrives in segments (csrc/hmc_model_seg.hip): the
+ * dense-logit Categorical -- a chain's latent w[c, 0:K, 0:F] is K class rows
+ * of seg_len = F features, rows c * groups + k of the likelihood kernel's
+ * [n_chains * groups, stride] operand / gradient matrices (groups = the class
+ * stride of zshmc_linear_categorical_log_lik) -- and the gathered-dot rating
+ * model (pmf_hmc.py:19-31), whose gradient is a plain [n_chains, n_data]
+ * matrix (groups = 1, seg_len = n_data).  f = identity, Normal prior
+ * (univariate.py:174-181); per element e = k * seg_len + j of chain c:
+ *   grad = lik_scale * grad_lik[(c*groups + k), j] - exp(-2 logstd)(q - mean)
+ *   p += kick_scale*eps*grad ;  q += drift_scale*eps*p/mass      (hmc.py:38-43)
+ *   operand[(c*groups + k), j] = q'   (if not NULL; rows k >= ceil(n_data /
+ *                                      seg_len) and columns j >= seg_len are
+ *                                      never touched: zero them once)
+ * and per chain
+ *   lp_out[c]   = lik_scale * sum_{k<groups} ll_in[c*groups + k] + log N(q_c)
+ *                 AT the evaluation point;  kinetic[c] += 1/2 sum p'^2/mass.
+ * q, p, prior rows: row stride `row_stride` (a multiple of 4, >= n_data);
+ * mass [row_stride] or NULL; all 16-byte aligned.  seg_len need not be a
+ * multiple of 4 (element-wise gradient / operand addressing then).
+ * `workspace`: zshmc_model_seg_workspace(n_chains, n_data) floats -- the
+ * per-chunk sums, added per chain in chunk order by a second small launch:
+ * deterministic, no atomics. */
+int64_t zshmc_model_seg_workspace(int64_t n_chains, int64_t n_data);
+int zshmc_model_kick_drift_seg(
+    float* q, float* p, const float* grad_lik, int64_t grad_stride,
+    int64_t seg_len, int64_t groups, float* operand, int64_t operand_stride,
+    const float* prior_mean, int64_t mean_rows, const float* prior_logstd,
+    int64_t logstd_rows, const float* mass, const float* step_size_dev,
+    float step_size_host, float kick_scale, float drift_scale,
+    float lik_scale, int64_t n_chains, int64_t n_data, int64_t row_stride,
+    const float* ll_in, float* lp_out, float* kinetic, float* workspace,
+    void* stream);
+
+/* ------------------------------------------------------------------------
  * Fused dense-logit Bernoulli likelihood on the fp32 matrix cores
  * (BASELINE config 3, Bayesian logistic regression):
  *     logits[c, n] = sum_d W[c, d] * X[n, d]
@@ -472,6 +507,36 @@ int zshmc_linear_bernoulli_log_lik(const float* W, const float* X,
                                    int64_t n_rows, int64_t n_features,
                                    float* log_lik, float* grad_w, int n_splits,
                                    float* workspace, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Fused dense-logit Categorical likelihood on the fp32 matrix cores (softmax
+ * regression: w[c, k, :] ~ Normal, y_n ~ Categorical(logits = X w[c]^T)):
+ *     logits[c, n, k] = sum_f X[n, f] * w[c, k, f]
+ *     log_lik[c]      = sum_n logits[c, n, y_n] - logsumexp_k logits[c, n, :]
+ *     grad_w[c, k, :] = sum_n ([k == y_n] - softmax_k(logits[c, n, :])) X[n, :]
+ * Replaces Categorical._log_prob (univariate.py:496-548:
+ * -sparse_softmax_cross_entropy_with_logits) with group_ndims = 1
+ * (base.py:302-304) on logits = matmul(X, transpose(w)), and what tf.gradients
+ * (hmc.py:430-432) computes through them; the [C, N, K] logits are never
+ * materialised.  The same two-GEMM kernels as zshmc_linear_bernoulli_log_lik
+ * with the (chain, class) pairs as their "chain rows" and the softmax taken
+ * over the lanes of the accumulator that hold one chain's classes:
+ *   W      [n_cols, n_features], n_cols = n_chains * class_stride: row
+ *          c * class_stride + k is w[c, k, :]; class_stride = a power of two
+ *          <= 32, >= n_classes; the rows k >= n_classes are padding (zero: they
+ *          take no part in the softmax and get a zero gradient)
+ *   X      [n_rows, n_features]; labels [n_rows] float32 holding 0..n_classes-1
+ *   log_lik[n_cols]: the terms of class k's lane (those rows n with y_n = k) --
+ *          log_lik[c] of the formula is the sum over the chain's class_stride
+ *          entries (zshmc_model_kick_drift_seg adds them)
+ *   grad_w [n_cols, n_features] or NULL.
+ * n_features, alignment, n_splits / workspace as zshmc_linear_bernoulli_log_lik
+ * (workspace: n_splits * n_cols * (n_features + 1) floats). */
+int zshmc_linear_categorical_log_lik(
+    const float* W, const float* X, const float* labels, int64_t n_cols,
+    int64_t n_rows, int64_t n_features, int n_classes, int class_stride,
+    float* log_lik, float* grad_w, int n_splits, float* workspace,
+    void* stream);
 
 /* Sampling (Normal._sample univariate.py:161-172, Bernoulli._sample
  * :386-396, Categorical._sample :478-494) on Philox stream STREAM_DIST with

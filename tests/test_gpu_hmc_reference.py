@@ -39,6 +39,11 @@ VARIANTS = {'blr': ('native', 'generic', 'dense', 'nearmiss'),
             # (7 + 6 + 1, padded), topic rows of 6 padded to 8
             'blr_bias': ('dense', 'generic', 'nearmiss'),
             'lntm_k6': ('native', 'generic', 'dense', 'nearmiss'),
+            # north_star's third likelihood: X @ w^T under a Categorical --
+            # the reference's literal spelling and zs.linear_class_logits on
+            # the native plan (fp32-MFMA, csrc/lb_ops.h), the generic plan,
+            # and a near miss
+            'softmax_reg': ('dense', 'native', 'generic', 'nearmiss'),
             'pmf': ('fused', 'dense')}
 
 
@@ -122,7 +127,7 @@ def _build_lntm(zs, torch, dev, case, qs, variant):
     return model, plan, {'x': p['x'], 'beta': p['beta']}
 
 
-def _build_softmax_regression(zs, torch, dev, case, qs):
+def _build_softmax_regression(zs, torch, dev, case, qs, variant):
     X = torch.tensor(case['params']['X'], device=dev)
     y = torch.tensor(case['params']['y'], device=dev)        # int32 labels
     C, K, F = qs['w'].shape
@@ -132,10 +137,17 @@ def _build_softmax_regression(zs, torch, dev, case, qs):
         bn = zs.BayesianNet()
         w = bn.normal('w', torch.zeros(K, F, device=dev), std=1., n_samples=C,
                       group_ndims=2)
-        logits = X.unsqueeze(0) @ w.tensor.transpose(-1, -2)  # [C, N, K]
+        if variant == 'native':
+            logits = zs.linear_class_logits(w.tensor, X)
+        elif variant == 'nearmiss':
+            logits = X.unsqueeze(0) @ (w.tensor * 1.0).transpose(-1, -2)
+        else:     # tf.matmul(Xc, w, transpose_b=True): [C, N, K]
+            logits = X.unsqueeze(0) @ w.tensor.transpose(-1, -2)
         bn.categorical('y', logits, group_ndims=1)
         return bn
-    return model(), 'generic', {'y': y}
+    plan = 'linear_categorical' if variant in ('dense', 'native') \
+        else 'generic'
+    return model(), plan, {'y': y}
 
 
 def _build_pmf(zs, torch, dev, case, qs, variant):
@@ -184,7 +196,7 @@ def _build(zs, torch, dev, case, qs, variant=None):
     if name == 'pmf':
         return _build_pmf(zs, torch, dev, case, qs, variant)
     if name == 'softmax_reg':
-        return _build_softmax_regression(zs, torch, dev, case, qs)
+        return _build_softmax_regression(zs, torch, dev, case, qs, variant)
     return _build_plain(zs, torch, dev, case, qs) + ({},)
 
 

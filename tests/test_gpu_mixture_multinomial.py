@@ -360,27 +360,6 @@ def test_config5_full_size_properties(env):
             rtol=2e-4, atol=1e-3)
 
 
-DOC_MAJOR_WORKER = r'''
-import sys, numpy as np, torch
-sys.path.insert(0, %(root)r)
-sys.path.insert(0, %(tests)r)
-import zhusuan_amd as zs
-from test_gpu_mixture_multinomial import _data
-dev = torch.device('cuda', 0)
-out = {}
-for n_chains, n_docs, K, V in %(shapes)r:
-    phi, x, theta = _data(n_chains, n_docs, K, V, seed=K + V + n_chains)
-    tt = torch.tensor(theta, device=dev, requires_grad=True)
-    d = zs.distributions.UnnormalizedMultinomial(
-        zs.log_mixture(tt, torch.tensor(phi, device=dev)),
-        normalize_logits=False, dtype=torch.float32)
-    ll = d.log_prob(torch.tensor(x, device=dev))
-    ll.sum().backward()
-    out['ll_%%d_%%d' %% (n_chains, n_docs)] = ll.detach().cpu().numpy()
-    out['g_%%d_%%d' %% (n_chains, n_docs)] = tt.grad.cpu().numpy()
-np.savez(%(out)r, **out)
-'''
-
 # chain axes that fill 64-chain tiles (document-major tiles), with a ragged
 # last group, with row-range splits (few workgroups), and one that does not
 DOC_MAJOR_SHAPES = [(64, 5, 64, 300), (128, 9, 100, 1003), (520, 3, 128, 200),
@@ -389,31 +368,36 @@ DOC_MAJOR_SHAPES = [(64, 5, 64, 300), (128, 9, 100, 1003), (520, 3, 128, 200),
                     (32, 5, 300, 130), (260, 3, 600, 77), (40, 4, 300, 99)]
 
 
-def test_document_major_tiles_equal_consecutive_rows(env, tmp_path):
+def test_document_major_tiles_equal_consecutive_rows(env):
     """Rows r = chain * n_docs + doc of the topic model's chain axes are tiled
     64 CHAINS OF ONE DOCUMENT when the chain axis fills such tiles (the
     counts of a workgroup are then one row of the matrix, not a 32-row gather
     per load): same arithmetic per row, so bit-identical to the
-    consecutive-row tiling (ZSHMC_LB_DOC_MAJOR=0, run in a second process) and
-    equal to the float64 evaluation."""
-    import os
-    import subprocess
-    import sys
+    consecutive-row tiling -- which the same rows get when they are handed
+    over as ONE chain of n_chains * n_docs "documents", each with its own
+    (repeated) counts row -- and equal to the float64 evaluation."""
     zs, torch, dev = env
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    res = {}
-    for tag, flag in (('doc', '1'), ('row', '0')):
-        script = tmp_path / ('w_%s.py' % tag)
-        out = str(tmp_path / ('%s.npz' % tag))
-        script.write_text(DOC_MAJOR_WORKER % dict(
-            root=root, tests=os.path.join(root, 'tests'),
-            shapes=DOC_MAJOR_SHAPES, out=out))
-        r = subprocess.run([sys.executable, str(script)],
-                           env=dict(os.environ, ZSHMC_LB_DOC_MAJOR=flag),
-                           capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-3000:]
-        res[tag] = np.load(out)
-    for k in res['doc'].files:
+
+    def evaluate(theta, x, phi):
+        tt = torch.tensor(theta, device=dev, requires_grad=True)
+        d = zs.distributions.UnnormalizedMultinomial(
+            zs.log_mixture(tt, torch.tensor(phi, device=dev)),
+            normalize_logits=False, dtype=torch.float32)
+        ll = d.log_prob(torch.tensor(x, device=dev))
+        ll.sum().backward()
+        return ll.detach().cpu().numpy(), tt.grad.cpu().numpy()
+
+    res = {'doc': {}, 'row': {}}
+    for n_chains, n_docs, K, V in DOC_MAJOR_SHAPES:
+        phi, x, theta = _data(n_chains, n_docs, K, V, seed=K + V + n_chains)
+        key = '%d_%d' % (n_chains, n_docs)
+        ll, g = evaluate(theta, x, phi)
+        res['doc']['ll_' + key], res['doc']['g_' + key] = ll, g
+        ll, g = evaluate(theta.reshape(1, n_chains * n_docs, K),
+                         np.tile(x, (n_chains, 1)), phi)
+        res['row']['ll_' + key] = ll.reshape(n_chains, n_docs)
+        res['row']['g_' + key] = g.reshape(n_chains, n_docs, K)
+    for k in res['doc']:
         np.testing.assert_array_equal(res['doc'][k], res['row'][k], err_msg=k)
     for n_chains, n_docs, K, V in DOC_MAJOR_SHAPES:
         phi, x, theta = _data(n_chains, n_docs, K, V, seed=K + V + n_chains)

@@ -134,6 +134,11 @@ PROTOTYPES = {
         _p, _p, _p, c_int64, _p, c_int64, c_int, _p, c_int64, _p, c_int64, _p,
         _p, c_float, c_float, c_float, c_float, c_int64, c_int64, c_int64, _p,
         _p, _p, _p]),
+    'zshmc_model_seg_workspace': (c_int64, [c_int64, c_int64]),
+    'zshmc_model_kick_drift_seg': (c_int, [
+        _p, _p, _p, c_int64, c_int64, c_int64, _p, c_int64, _p, c_int64, _p,
+        c_int64, _p, _p, c_float, c_float, c_float, c_float, c_int64, c_int64,
+        c_int64, _p, _p, _p, _p, _p]),
     'zshmc_normal_log_prob': (c_int, [
         _p, _p, _p, _p, c_int64, c_int64, c_int, c_int, c_int, _p]),
     'zshmc_normal_log_prob_grad': (c_int, [
@@ -152,6 +157,9 @@ PROTOTYPES = {
         _p, _p, _p, _p, c_int64, c_int64, c_int, _p]),
     'zshmc_linear_bernoulli_log_lik': (c_int, [
         _p, _p, _p, c_int64, c_int64, c_int64, _p, _p, c_int, _p, _p]),
+    'zshmc_linear_categorical_log_lik': (c_int, [
+        _p, _p, _p, c_int64, c_int64, c_int64, c_int, c_int, _p, _p, c_int, _p,
+        _p]),
     'zshmc_gather_dot': (c_int, [
         _p, _p, _p, _p, c_int64, c_int64, c_int64, c_int64, c_int64, _p, _p]),
     'zshmc_gather_dot_grad': (c_int, [

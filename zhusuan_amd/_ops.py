@@ -470,7 +470,39 @@ def _pad_features(t, width):
     return out
 
 
-_x_cache = {}
+class _Lru(object):
+    """A few entries keyed by what identifies the source tensors' contents
+    (address, layout, dtype, device, version counter).  An entry pins its
+    sources, so an address in a live key cannot have been handed to another
+    tensor.  Several entries, because one model is evaluated through more
+    than one padded width (LinearLogits.packed() on the generic plan, the
+    native plan's kernel width) and two models may alternate: a single slot
+    rebuilt a copy of up to a GB on every call."""
+
+    def __init__(self, size=4):
+        self.size, self.items = size, []
+
+    def get(self, key):
+        for i, (k, val, _) in enumerate(self.items):
+            if k == key:
+                self.items.insert(0, self.items.pop(i))
+                return val
+        return None
+
+    def put(self, key, val, pins):
+        self.items.insert(0, (key, val, pins))
+        del self.items[self.size:]
+
+    def clear(self):
+        del self.items[:]
+
+
+def _tensor_key(t):
+    return (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t.dtype,
+            str(t.device), t._version)
+
+
+_x_cache = _Lru()
 
 
 def _padded_x(X, width):
@@ -478,18 +510,16 @@ def _padded_x(X, width):
     version (the model builder re-runs on every joint evaluation)."""
     if X.shape[-1] == width and X.is_contiguous() and X.dtype == _F32:
         return X
-    key = (X.data_ptr(), tuple(X.shape), tuple(X.stride()), X._version, width)
-    hit = _x_cache.get('x')
-    if hit is not None and hit[0] == key:
-        return hit[1]
+    key = (_tensor_key(X), width)
+    hit = _x_cache.get(key)
+    if hit is not None:
+        return hit
     Xp = _pad_features(X.detach().to(_F32), width)
-    # the entry holds X itself: while it lives, no other tensor can be handed
-    # X's address, so (address, version) identifies the contents
-    _x_cache['x'] = (key, Xp, X)
+    _x_cache.put(key, Xp, X)
     return Xp
 
 
-_design_cache = {}
+_design_cache = _Lru()
 
 
 def packed_design(blocks, n_rows, device, width=None):
@@ -497,12 +527,11 @@ def packed_design(blocks, n_rows, device, width=None):
     [n_rows, sum D_k] float32 (a column of ones where a block is None: the
     bias), zero-padded to `width` columns if given; cached while the SAME
     tensors (storage, version) are passed again."""
-    key = tuple(None if X is None else
-                (X.data_ptr(), tuple(X.shape), tuple(X.stride()), X._version)
-                for X in blocks) + (width,)
-    hit = _design_cache.get('x')
-    if hit is not None and hit[0] == key:
-        return hit[1]
+    key = tuple(None if X is None else _tensor_key(X) for X in blocks) + (
+        width, int(n_rows), str(device))
+    hit = _design_cache.get(key)
+    if hit is not None:
+        return hit
     total = sum(1 if X is None else int(X.shape[-1]) for X in blocks)
     out = torch.zeros(n_rows, width or total, dtype=_F32, device=device)
     off = 0
@@ -513,8 +542,7 @@ def packed_design(blocks, n_rows, device, width=None):
         else:
             out[:, off:off + d] = X.detach().to(_F32)
         off += d
-    # (the entry holds the blocks: their addresses cannot be reused meanwhile)
-    _design_cache['x'] = (key, out, list(blocks))
+    _design_cache.put(key, out, list(blocks))
     return out
 
 
@@ -563,6 +591,87 @@ class LinearBernoulliLogLik(_Function):
         (gw,) = ctx.saved_tensors
         d = ctx.w_shape[-1]
         g = gw[:, :d] * gout.reshape(-1, 1)
+        return g.reshape(ctx.w_shape), None, None
+
+
+# ----------------------------------------------------------------------------
+# dense-logit Categorical likelihood (softmax regression; OP = 2 of the same
+# fp32-MFMA kernels, csrc/lb_ops.h)
+# ----------------------------------------------------------------------------
+MAX_CLASSES = 32          # class stride: a power of two <= 32 lanes
+
+
+def class_stride(n_classes):
+    """Rows of the kernel's W operand per chain: the class count rounded up
+    to a power of two (the classes of a chain sit in that many consecutive
+    lanes of the logits accumulator)."""
+    g = 1
+    while g < n_classes:
+        g *= 2
+    return g
+
+
+def pack_class_rows(w, stride, width):
+    """w [C, K, F] -> the kernel's operand [C * stride, width]: row
+    c * stride + k = w[c, k, :], zero padding rows / columns."""
+    C, K, F = w.shape
+    if K == stride and F == width and w.is_contiguous():
+        return w.reshape(C * K, F)
+    out = torch.zeros(C, stride, width, dtype=_F32, device=w.device)
+    out[:, :K, :F] = w
+    return out.reshape(C * stride, width)
+
+
+def labels_as_float(y, n_classes):
+    """Class labels [N] (any int / float dtype) as the float32 vector the
+    kernel compares its lane's class with; out-of-range labels are an error
+    (tf.nn.sparse_softmax_cross_entropy_with_logits raises / returns NaN)."""
+    yl = y.detach().reshape(-1)
+    if yl.numel() and (int(yl.min()) < 0 or int(yl.max()) >= n_classes):
+        raise ValueError("Categorical: labels must lie in [0, {})"
+                         .format(n_classes))
+    return yl.to(_F32).contiguous()
+
+
+class LinearCategoricalLogLik(_Function):
+    """ll[c] = sum_n Categorical(X w_c^T).log_prob(y_n) for w [..., K, F] and
+    its gradient in one pass over X; the [..., N, K] logits are never
+    materialised (zshmc_linear_categorical_log_lik)."""
+
+    @staticmethod
+    def forward(ctx, w, X, labels_f):
+        require_device(w, X, labels_f)
+        K, F = int(w.shape[-2]), int(w.shape[-1])
+        G = class_stride(K)
+        width = next(v for v in LINEAR_BERNOULLI_WIDTHS if v >= F)
+        w3 = w.detach().reshape(-1, K, F).to(_F32)
+        C = w3.shape[0]
+        wp = pack_class_rows(w3, G, width)
+        Xp = _padded_x(X, width)
+        N = Xp.shape[0]
+        ll = torch.empty(C * G, dtype=_F32, device=w.device)
+        need_grad = ctx.needs_input_grad[0]
+        gw = torch.empty(C * G, width, dtype=_F32, device=w.device) \
+            if need_grad else None
+        splits = _row_splits(C * G, N, w.device, width)
+        ws = torch.empty(splits * C * G * (width + 1), dtype=_F32,
+                         device=w.device) if splits > 1 else None
+        _capi.call('zshmc_linear_categorical_log_lik', wp.data_ptr(),
+                   Xp.data_ptr(), labels_f.data_ptr(), C * G, N, width, K, G,
+                   ll.data_ptr(), _capi.ptr(gw), splits, _capi.ptr(ws),
+                   _capi.current_stream())
+        ctx.w_shape, ctx.stride = tuple(w.shape), G
+        if need_grad:
+            ctx.save_for_backward(gw)
+        # (lane k of a chain's group holds the terms of the rows labelled k)
+        return ll.reshape(C, G).sum(-1).reshape(w.shape[:-2])
+
+    @staticmethod
+    def backward(ctx, gout):
+        (gw,) = ctx.saved_tensors
+        K, F = ctx.w_shape[-2:]
+        g = gw.reshape(-1, ctx.stride, gw.shape[-1])[:, :K, :F] * \
+            gout.reshape(-1, 1, 1)
         return g.reshape(ctx.w_shape), None, None
 
 

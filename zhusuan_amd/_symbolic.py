@@ -35,7 +35,8 @@ import torch
 from torch.utils._pytree import tree_map
 
 __all__ = ['Sym', 'SymbolicCut', 'wrap_latent', 'force',
-           'lower_bernoulli_logits', 'lower_multinomial_logits']
+           'lower_bernoulli_logits', 'lower_multinomial_logits',
+           'lower_categorical_logits']
 
 
 class SymbolicCut(RuntimeError):
@@ -72,6 +73,9 @@ _RESHAPE = {torch.reshape, _T.reshape, _T.view}
 _LOG = {torch.log, _T.log}
 _ADD = {torch.add, _T.add, _T.__add__, _T.__radd__}
 _UNSQUEEZE = {torch.unsqueeze, _T.unsqueeze}
+_TRANSPOSE = {torch.transpose, _T.transpose, torch.swapaxes, _T.swapaxes,
+              torch.swapdims, _T.swapdims}
+_MT = _getter('mT')
 
 
 class Sym(torch.Tensor):
@@ -84,6 +88,9 @@ class Sym(torch.Tensor):
          ('col', Sym)                     latent[..., None]: a per-chain scalar
          ('add', Sym, Sym)                sum of linear terms (matmul of a
                                           latent, a bias latent [..., 1])
+         ('transpose', Sym)               last two axes of a latent [..., K, F]
+         ('classlogits', Sym, tensor[N, F])   X @ latent^T: [..., N, K], the
+                                          class logits of a softmax regression
     """
 
     @staticmethod
@@ -127,6 +134,13 @@ class Sym(torch.Tensor):
                 v = e[1].force().unsqueeze(-1)
             elif kind == 'add':
                 v = e[1].force() + e[2].force()
+            elif kind == 'transpose':
+                v = e[1].force().transpose(-1, -2)
+            elif kind == 'classlogits':
+                # (forced, the symbol computes what the user wrote -- bit for
+                # bit: e[3] is the `latent @ const` the transpose was taken of)
+                v = e[3].force().transpose(-1, -2) if e[3] is not None \
+                    else torch.matmul(e[2], e[1].force().transpose(-1, -2))
             else:
                 v = torch.log(e[1].force())
             self._value = v
@@ -143,6 +157,8 @@ class Sym(torch.Tensor):
                 return func(*args, **kwargs)
         if func is _REQUIRES_GRAD:      # of the latent the symbol stands on
             return any(t.requires_grad for t in args[0]._roots)
+        if func == _MT:
+            func, args = torch.transpose, (args[0], -2, -1)
         out = _symbolic_rule(func, args, kwargs)
         if out is not None:
             return out
@@ -170,6 +186,9 @@ def _describe(e):
                                         list(e[2].shape))
     if e[0] == 'add':
         return 'add(%s, %s)' % (_describe(e[1]._expr), _describe(e[2]._expr))
+    if e[0] == 'classlogits':
+        return 'matmul(const%s, transpose(%s))' % (list(e[2].shape),
+                                                   _describe(e[1]._expr))
     return '%s(%s)' % (e[0], _describe(e[1]._expr))
 
 
@@ -265,6 +284,9 @@ def _symbolic_rule(func, args, kwargs):
     None."""
     if func in _ADD:
         return _add_rule(args, kwargs)
+    if func in _MATMUL and len(args) == 2 and not kwargs and \
+            isinstance(args[1], Sym) and not isinstance(args[0], Sym):
+        return _class_logits_rule(args[0], args[1])
     if not args or not isinstance(args[0], Sym):
         return None
     x = args[0]
@@ -303,6 +325,25 @@ def _symbolic_rule(func, args, kwargs):
             return None
         return Sym(('matmul', x, rhs), xs[:-1] + (int(rhs.shape[1]),),
                    x_dtype, x_device)
+    if func in _TRANSPOSE:
+        # the last two axes of a latent [..., K, F] (-> X @ w^T below), or of
+        # latent @ const[F, N] (= [..., K, N] -> the same class logits)
+        dims = tuple(args[1:]) + tuple(kwargs.get(k) for k in
+                                       ('dim0', 'dim1', 'axis0', 'axis1')
+                                       if k in kwargs)
+        if len(dims) != 2 or len(xs) < 2 or not all(
+                isinstance(d, int) for d in dims) or sorted(
+                _norm_dim(d, len(xs)) for d in dims) != [len(xs) - 2,
+                                                         len(xs) - 1]:
+            return None
+        if _kind(x) == 'latent':
+            return Sym(('transpose', x), xs[:-2] + (xs[-1], xs[-2]), x_dtype,
+                       x_device)
+        if _kind(x) == 'matmul' and _kind(x._expr[1]) == 'latent' and \
+                len(x._expr[1]._meta[0]) >= 2:
+            return Sym(('classlogits', x._expr[1], x._expr[2].t(), x),
+                       xs[:-2] + (xs[-1], xs[-2]), x_dtype, x_device)
+        return None
     if func in _UNSQUEEZE:
         dim = kwargs.get('dim', args[1] if len(args) > 1 else None)
         if _kind(x) == 'latent' and isinstance(dim, int) and \
@@ -330,6 +371,30 @@ def _symbolic_rule(func, args, kwargs):
                 not isinstance(args[1], Sym) and args[1].dim() == 2:
             return _symbolic_rule(torch.matmul, (x, args[1].t()), {})
     return None
+
+
+def _class_logits_rule(lhs, rhs):
+    """const @ transpose(latent): X [N, F] -- or its [1, ..., N, F] /
+    expanded [chains..., N, F] view, what tf.tile + tf.matmul(Xc, w,
+    transpose_b=True) spells -- times latent^T [..., F, K]."""
+    if _kind(rhs) != 'transpose' or not isinstance(lhs, torch.Tensor) or \
+            lhs.requires_grad or lhs.dim() < 2:
+        return None
+    ws, dt, dev = rhs._meta                     # [..., F, K]
+    if lhs.dtype != dt or lhs.shape[-1] != ws[-2] or \
+            (lhs.device != dev and dev.type != 'meta'):
+        return None
+    lead = tuple(lhs.shape[:-2])
+    if len(lead) > len(ws) - 2:
+        return None
+    # the leading axes must not carry data: size 1, or an expanded view
+    if any(n != 1 and st != 0 for n, st in zip(lead, lhs.stride())):
+        return None
+    if any(n != 1 and n != m for n, m in zip(lead[::-1], ws[:-2][::-1])):
+        return None
+    X = lhs[(0,) * len(lead)] if lead else lhs
+    return Sym(('classlogits', rhs._expr[1], X, None),
+               ws[:-2] + (int(lhs.shape[-2]), ws[-1]), dt, dev)
 
 
 def _strip_reshapes(s):
@@ -396,4 +461,16 @@ def lower_multinomial_logits(logits):
                 latent = t._expr[1]._expr[1]
                 return LogMixture.of_softmax(latent, m._expr[2],
                                              _shape_of(logits)[:-1])
+    return logits.force()
+
+
+def lower_categorical_logits(logits):
+    """`X @ transpose(latent)` (or `transpose(latent @ X^T)`), latent
+    [..., K, F] -> LinearClassLogits over the latent; any other symbol -> its
+    value."""
+    if not isinstance(logits, Sym):
+        return logits
+    from .distributions.univariate import LinearClassLogits
+    if _kind(logits) == 'classlogits' and logits._meta[1] == torch.float32:
+        return LinearClassLogits(logits._expr[1]._expr[1], logits._expr[2])
     return logits.force()

@@ -23,6 +23,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "lb_ops.h"
 
 namespace zshmc {
 
@@ -30,7 +31,6 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 
 constexpr int kMC = 64;  // chains per workgroup
-constexpr int kNT = 32;  // data rows per tile
 
 template <int FB>
 struct VecF {};
@@ -53,163 +53,6 @@ __device__ __forceinline__ float vget(const V& v, int t) {
     return v;
   else
     return v[t];
-}
-
-// D: padded feature count (64, 128 or 256).  4 waves: wave = (a, h), a =
-// chain block (32 chains), h = feature half.
-template <int D>
-__global__ __launch_bounds__(256, 1) void linear_bernoulli_kernel(
-    const float* __restrict__ W, const float* __restrict__ X,
-    const float* __restrict__ y, int64_t C, int64_t N, int64_t ldw,
-    int64_t ldx, float* __restrict__ ll, float* __restrict__ gW) {
-  constexpr int LD = D + 4;        // padded LDS row: conflict-free b128 reads
-  constexpr int HALF = D / 2;      // features per wave in each phase
-  constexpr int FB = HALF / 32;    // 32-wide feature blocks per half (1,2,4)
-  constexpr int X4 = kNT * D / 4 / 256;  // float4 per thread per X tile
-  constexpr int W4 = kMC * D / 4 / 256;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* __restrict__ sW = reinterpret_cast<float*>(smem);  // [kMC][LD]
-  float* __restrict__ sX = sW + kMC * LD;                   // [2][kNT][LD]
-  float* __restrict__ sY = sX + 2 * kNT * LD;               // [2][kNT]
-  float* __restrict__ sEx = sY + 2 * kNT;                   // [4][16][64]
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int a = wave >> 1, h = wave & 1;
-  const int lo = lane & 31, hi = lane >> 5;
-  const int64_t c0 = (int64_t)blockIdx.x * kMC;
-
-  // ---- W tile -> LDS (rows clamped; stores masked at the end) -------------
-#pragma unroll
-  for (int i = 0; i < W4; ++i) {
-    const int idx = i * 256 + tid;  // float4 index in [kMC][D/4]
-    const int row = idx / (D / 4), c4 = idx % (D / 4);
-    int64_t cr = c0 + row;
-    cr = cr < C ? cr : C - 1;
-    const f4 v = *reinterpret_cast<const f4*>(W + cr * ldw + c4 * 4);
-    *reinterpret_cast<f4*>(sW + row * LD + c4 * 4) = v;
-  }
-
-  // ---- X tile prefetch registers ------------------------------------------
-  f4 xr[X4];
-  float yr = 0.f;
-  auto load_tile = [&](int64_t n0) {
-#pragma unroll
-    for (int i = 0; i < X4; ++i) {
-      const int idx = i * 256 + tid;
-      const int row = idx / (D / 4), c4 = idx % (D / 4);
-      int64_t nr = n0 + row;
-      nr = nr < N ? nr : N - 1;
-      xr[i] = *reinterpret_cast<const f4*>(X + nr * ldx + c4 * 4);
-    }
-    if (tid < kNT) {
-      const int64_t nr = n0 + tid;
-      yr = nr < N ? y[nr] : 0.f;
-    }
-  };
-  auto store_tile = [&](int buf) {
-    float* __restrict__ dst = sX + buf * kNT * LD;
-#pragma unroll
-    for (int i = 0; i < X4; ++i) {
-      const int idx = i * 256 + tid;
-      const int row = idx / (D / 4), c4 = idx % (D / 4);
-      *reinterpret_cast<f4*>(dst + row * LD + c4 * 4) = xr[i];
-    }
-    if (tid < kNT) sY[buf * kNT + tid] = yr;
-  };
-
-  f16v G[FB];
-#pragma unroll
-  for (int t = 0; t < FB; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) G[t][r] = 0.f;
-  float ll_lane = 0.f;
-
-  const int64_t n_tiles = (N + kNT - 1) / kNT;
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
-
-  for (int64_t tile = 0; tile < n_tiles; ++tile) {
-    const int buf = (int)(tile & 1);
-    const float* __restrict__ xb = sX + buf * kNT * LD;
-    if (tile + 1 < n_tiles) load_tile((tile + 1) * kNT);  // in flight
-
-    // ---- phase 1: S'[n, i] = sum_d X[n,d] W[i,d] over this wave's K half --
-    f16v S;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) S[r] = 0.f;
-#pragma unroll 4
-    for (int kk = 0; kk < HALF / 8; ++kk) {
-      const int d = h * HALF + kk * 8 + hi * 4;
-      const f4 av = *reinterpret_cast<const f4*>(xb + lo * LD + d);
-      const f4 bv = *reinterpret_cast<const f4*>(sW + (a * 32 + lo) * LD + d);
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-        S = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[m], S, 0, 0, 0);
-    }
-    // ---- exchange the K-half partials with the sibling wave ----------------
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sEx[(wave * 16 + r) * 64 + lane] = S[r];
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 16; ++r) S[r] += sEx[((wave ^ 1) * 16 + r) * 64 + lane];
-
-    // ---- sigmoid residual in the accumulator layout -------------------------
-    // lane holds chain i = a*32 + lo, rows n = (r&3) + 8*(r>>2) + 4*hi
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int nl = (r & 3) + 8 * (r >> 2) + 4 * hi;
-      const bool valid = tile * kNT + nl < N;
-      const float s = S[r];
-      const float yv = sY[buf * kNT + nl];
-      const float e = __expf(-fabsf(s));
-      const float inv = __builtin_amdgcn_rcpf(1.0f + e);
-      const float sig = s >= 0.f ? inv : e * inv;
-      const float lp = s * yv - fmaxf(s, 0.f) - log1pf(e);
-      S[r] = valid ? yv - sig : 0.f;
-      ll_lane += valid ? lp : 0.f;
-    }
-
-    // ---- phase 3: G[i, f] += sum_n R'[n, i] X[n, f] over this feature half -
-    // A operand = the residual registers themselves (k-slot = lane half)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int nl = (r & 3) + 8 * (r >> 2) + 4 * hi;
-      typedef typename VecF<FB>::type V;
-      const V xv = *reinterpret_cast<const V*>(xb + nl * LD + h * HALF + lo * FB);
-#pragma unroll
-      for (int t = 0; t < FB; ++t)
-        G[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(S[r], vget<FB>(xv, t), G[t],
-                                                    0, 0, 0);
-    }
-
-    // ---- publish the prefetched tile into the other buffer -----------------
-    if (tile + 1 < n_tiles) store_tile(buf ^ 1);
-    __syncthreads();
-  }
-
-  // ---- epilogue -----------------------------------------------------------
-  // G[t][r]: chain = c0 + a*32 + (r&3) + 8*(r>>2) + 4*hi, feature =
-  // h*HALF + lo*FB + t
-  if (gW) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int64_t chain = c0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      if (chain < C) {
-#pragma unroll
-        for (int t = 0; t < FB; ++t)
-          gW[chain * ldw + h * HALF + lo * FB + t] = G[t][r];
-      }
-    }
-  }
-  // every lane's ll covers its 16 rows per tile; the other 16 sit in lane^32
-  const float ll_tot = ll_lane + __shfl_xor(ll_lane, 32, 64);
-  if (h == 0 && hi == 0) {
-    const int64_t chain = c0 + a * 32 + lo;
-    if (chain < C) ll[chain] = ll_tot;
-  }
 }
 
 // global -> LDS, BYTES (4, 8 = 2x4, 16) per lane, LDS dest = dst + lane*BYTES
@@ -246,7 +89,10 @@ __device__ __forceinline__ void lds_dma_row(const float* src, uint32_t dst,
 }
 
 // ---------------------------------------------------------------------------
-// v2: 64-row tiles, W in registers, residual exchange instead of a K-split.
+// 64-row tiles, W in registers, residual exchange between sibling waves.
+// (The first form of this kernel -- 32-row tiles, K split over two waves,
+// partial logits through LDS, 38 % of peak -- is gone; profiles/r01e_* has
+// its numbers.)
 //
 // The 4 waves of a workgroup are (a, b): chain block a (32 chains) x half b.
 //   phase 1  S'[n, i] = sum_d X[n,d] W[i,d] for the wave's 32 ROWS (b = row
@@ -275,6 +121,12 @@ __device__ __forceinline__ void lds_dma_row(const float* src, uint32_t dst,
 //           "logits" are log(theta.phi) (multivariate.py:435-443 with
 //           normalize_logits = False): term = x*log(S), residual = x / S with
 //           the counts x[c, n] streamed from `yc` [C, N] (chain-major).
+//   OP = 2  Categorical with dense logits (softmax regression,
+//           univariate.py:496-548): the rows of W are (chain, class) pairs,
+//           `n_classes` classes in groups of 2^cls_log2 consecutive rows; term =
+//           l[y] - logsumexp(l), residual = [k == y] - softmax, the softmax over
+//           the group's lanes of the accumulator (csrc/lb_ops.h); y[n] = the
+//           label of data row n as a float.
 #ifndef ZS_LB_BUF
 #define ZS_LB_BUF(D) ((D) <= 128 ? 1 : 2)
 #endif
@@ -295,7 +147,7 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2
     const float* __restrict__ y, const float* __restrict__ yc,
     int64_t yc_rows, int64_t ldy, int64_t C, int64_t N, int64_t ldw,
     int64_t ldx, float* __restrict__ ll, float* __restrict__ gW,
-    int doc_major) {
+    int doc_major, int n_classes, int cls_log2) {
   constexpr int LD = D + 4;          // padded LDS row: conflict-free b128 reads
   constexpr int kRows = 64;          // data rows per tile
   constexpr int KK = D / 8;          // phase-1 steps of 4 MFMAs (8 features)
@@ -423,12 +275,15 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2
 #pragma unroll
     for (int j = 0; j < 16; ++j) dma_row(t0, j);
   }
-  if (OP == 0 && tid < kRows) {
+  if (OP != 1 && tid < kRows) {
     const int64_t nr = tile_begin * kRows + tid;
     sY[tid] = nr < N ? y[nr] : 0.f;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  // OP 2: the class this lane's column (a*32 + lo of a 64-row block whose
+  // base is a multiple of the class stride) stands for
+  const CatLane cat = cat_lane(lo, n_classes, OP == 2 ? cls_log2 : 0);
 
   // residual exchange slots: [wave][r>>2][lane][r&3]  (b128, conflict-free)
   float* __restrict__ sr_mine = sR + (wave * 4 * 64 + lane) * 4;
@@ -488,7 +343,7 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2
     // rows of tile+1 (the last tile re-streams itself: clamped rows, unused)
     const int64_t n_next = (more ? tile + 1 : tile) * kRows;
     const TileSrc tnext = tile_src(n_next, kBuf == 2 ? (xbuf ^ 1) : 0);
-    if (OP == 0 && tid < kRows) {
+    if (OP != 1 && tid < kRows) {
       const int64_t nr = n_next + tid;
       yr = nr < N ? y[nr] : 0.f;
     }
@@ -554,6 +409,9 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2
                          0.6931471805599453f * __builtin_amdgcn_logf(t1);
         S[r] = valid ? yv - sig : 0.f;
         ll_tile += valid ? lp : 0.f;
+      } else if (OP == 2) {
+        S[r] = categorical_residual(sv, sY[buf * kRows + nl], cat, valid,
+                                    ll_tile);
       } else {
         // sum_v x_v log((theta.phi)_v) and d/d(theta.phi) = x / (theta.phi);
         // x = 0 contributes nothing (also where the product underflows)
@@ -717,7 +575,7 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2
       for (int r = 0; r < 16; ++r) residual(r);
     }
     ZS_LB_MARK(4)  // phase 3b
-    if (OP == 0 && tid < kRows) sY[(buf ^ 1) * kRows + tid] = yr;
+    if (OP != 1 && tid < kRows) sY[(buf ^ 1) * kRows + tid] = yr;
     if (kBuf == 1) {
       __syncthreads();  // every wave is done reading the only X buffer
       if (more) {
@@ -797,7 +655,8 @@ static int launch_v2(const float* W, const float* X, const float* y,
                      const float* yc, int64_t yc_rows, int64_t ldy, int64_t C,
                      int64_t N, int64_t ldw, int64_t ldx, float* ll, float* gW,
                      hipStream_t s, int n_splits = 1,
-                     float* workspace = nullptr, int doc_major = 0) {
+                     float* workspace = nullptr, int doc_major = 0,
+                     int n_classes = 0, int cls_log2 = 0) {
   constexpr int LD = D + 4;
   const size_t lds =
       (size_t)(ZS_LB_BUF(D) * 64 * LD + 2 * 64 + 4 * 16 * 64) * sizeof(float);
@@ -824,11 +683,11 @@ static int launch_v2(const float* W, const float* X, const float* y,
   if (gW)
     hipLaunchKernelGGL((linear_bernoulli_kernel_v2<D, true, OP>), grid,
                        dim3(256), lds, s, W, X, y, yc, yc_rows, ldy, C, N, ldw, ldx,
-                       ll_out, g_out, doc_major);
+                       ll_out, g_out, doc_major, n_classes, cls_log2);
   else
     hipLaunchKernelGGL((linear_bernoulli_kernel_v2<D, false, OP>), grid,
                        dim3(256), lds, s, W, X, y, yc, yc_rows, ldy, C, N, ldw, ldx,
-                       ll_out, g_out, doc_major);
+                       ll_out, g_out, doc_major, n_classes, cls_log2);
   ZS_LAUNCH_CHECK("linear_bernoulli_kernel_v2 launch");
   if (S > 1) {
     const int64_t n = C + (gW ? C * ldw : 0);
@@ -838,35 +697,6 @@ static int launch_v2(const float* W, const float* X, const float* y,
                        workspace, C, ldw, S, ll, gW);
     ZS_LAUNCH_CHECK("lb_reduce_splits_kernel launch");
   }
-  return ZSHMC_OK;
-}
-
-template <int D>
-static int launch_lb(const float* W, const float* X, const float* y, int64_t C,
-                     int64_t N, int64_t ldw, int64_t ldx, float* ll, float* gW,
-                     hipStream_t s, int n_splits, float* workspace) {
-  static const bool use_v1 = [] {
-    const char* e = getenv("ZSHMC_LB_V1");
-    return e && e[0] == '1';
-  }();
-  if (!use_v1)
-    return launch_v2<D, 0>(W, X, y, nullptr, 1, N, C, N, ldw, ldx, ll, gW, s,
-                           n_splits, workspace);
-  constexpr int LD = D + 4;
-  const size_t lds = (size_t)(kMC * LD + 2 * kNT * LD + 2 * kNT + 4 * 16 * 64) *
-                     sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(linear_bernoulli_kernel<D>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(LDS)");
-    attr_set = true;
-  }
-  const int grid = (int)((C + kMC - 1) / kMC);
-  hipLaunchKernelGGL(linear_bernoulli_kernel<D>, dim3(grid), dim3(256), lds, s,
-                     W, X, y, C, N, ldw, ldx, ll, gW);
-  ZS_LAUNCH_CHECK("linear_bernoulli_kernel launch");
   return ZSHMC_OK;
 }
 
@@ -881,6 +711,10 @@ int linear_bernoulli_wide(const float* W, const float* X, const float* y,
                           int64_t n_chains, int64_t n_rows, int64_t n_features,
                           float* ll, float* gW, int n_splits, float* workspace,
                           hipStream_t s);
+int linear_categorical_wide(const float* W, const float* X, const float* labels,
+                            int64_t n_cols, int64_t n_rows, int64_t n_features,
+                            int n_classes, int cls_log2, float* ll, float* gW,
+                            int n_splits, float* workspace, hipStream_t s);
 
 }  // namespace zshmc
 
@@ -908,11 +742,7 @@ extern "C" int zshmc_linear_bernoulli_log_lik(const float* W, const float* X,
              "zshmc_linear_bernoulli_log_lik: 1 <= n_splits <= 64 and a "
              "workspace of n_splits*n_chains*(n_features+1) floats when > 1");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  static const bool split256 = [] {
-    const char* e = getenv("ZSHMC_LB_SPLIT256");
-    return e && e[0] == '1';
-  }();
-  if (n_features > 256 || (n_features == 256 && split256)) {
+  if (n_features > 256) {
     ZS_REQUIRE(!grad_w || (reinterpret_cast<uintptr_t>(grad_w) & 15) == 0,
                "zshmc_linear_bernoulli_log_lik: grad_w must be 16-byte aligned");
     return linear_bernoulli_wide(W, X, y, n_chains, n_rows, n_features, log_lik,
@@ -920,14 +750,69 @@ extern "C" int zshmc_linear_bernoulli_log_lik(const float* W, const float* X,
   }
   switch (n_features) {
     case 64:
-      return launch_lb<64>(W, X, y, n_chains, n_rows, 64, 64, log_lik, grad_w, s,
-                           n_splits, workspace);
+      return launch_v2<64, 0>(W, X, y, nullptr, 1, n_rows, n_chains, n_rows, 64,
+                              64, log_lik, grad_w, s, n_splits, workspace);
     case 128:
-      return launch_lb<128>(W, X, y, n_chains, n_rows, 128, 128, log_lik, grad_w,
-                            s, n_splits, workspace);
+      return launch_v2<128, 0>(W, X, y, nullptr, 1, n_rows, n_chains, n_rows,
+                               128, 128, log_lik, grad_w, s, n_splits,
+                               workspace);
     default:
-      return launch_lb<256>(W, X, y, n_chains, n_rows, 256, 256, log_lik, grad_w,
-                            s, n_splits, workspace);
+      return launch_v2<256, 0>(W, X, y, nullptr, 1, n_rows, n_chains, n_rows,
+                               256, 256, log_lik, grad_w, s, n_splits,
+                               workspace);
+  }
+}
+
+// Dense-logit Categorical (softmax regression): see include/zshmc.h.
+extern "C" int zshmc_linear_categorical_log_lik(
+    const float* W, const float* X, const float* labels, int64_t n_cols,
+    int64_t n_rows, int64_t n_features, int n_classes, int class_stride,
+    float* log_lik, float* grad_w, int n_splits, float* workspace,
+    void* stream) {
+  if (n_cols == 0) return ZSHMC_OK;
+  ZS_REQUIRE(W && X && labels && log_lik,
+             "zshmc_linear_categorical_log_lik: null pointer");
+  int cls_log2 = 0;
+  while ((1 << cls_log2) < class_stride) ++cls_log2;
+  ZS_REQUIRE(class_stride >= 1 && class_stride <= 32 &&
+                 (1 << cls_log2) == class_stride && n_classes >= 1 &&
+                 n_classes <= class_stride,
+             "zshmc_linear_categorical_log_lik: class_stride must be a power "
+             "of two <= 32 and 1 <= n_classes <= class_stride, got %d / %d",
+             n_classes, class_stride);
+  ZS_REQUIRE(n_cols > 0 && n_rows > 0 && n_cols % class_stride == 0,
+             "zshmc_linear_categorical_log_lik: bad shape");
+  ZS_REQUIRE(n_features == 64 || n_features == 128 || n_features == 256 ||
+                 n_features == 512 || n_features == 1024,
+             "zshmc_linear_categorical_log_lik: n_features must be 64, 128, "
+             "256, 512 or 1024 (zero-pad W and X), got %lld",
+             (long long)n_features);
+  ZS_REQUIRE((reinterpret_cast<uintptr_t>(W) & 15) == 0 &&
+                 (reinterpret_cast<uintptr_t>(X) & 15) == 0 &&
+                 (!grad_w || (reinterpret_cast<uintptr_t>(grad_w) & 15) == 0),
+             "zshmc_linear_categorical_log_lik: W, X and grad_w must be "
+             "16-byte aligned");
+  ZS_REQUIRE(n_splits >= 1 && n_splits <= 64 && (n_splits == 1 || workspace),
+             "zshmc_linear_categorical_log_lik: 1 <= n_splits <= 64 and a "
+             "workspace of n_splits*n_cols*(n_features+1) floats when > 1");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (n_features > 256)
+    return linear_categorical_wide(W, X, labels, n_cols, n_rows, n_features,
+                                   n_classes, cls_log2, log_lik, grad_w,
+                                   n_splits, workspace, s);
+  switch (n_features) {
+    case 64:
+      return launch_v2<64, 2>(W, X, labels, nullptr, 1, n_rows, n_cols, n_rows,
+                              64, 64, log_lik, grad_w, s, n_splits, workspace,
+                              0, n_classes, cls_log2);
+    case 128:
+      return launch_v2<128, 2>(W, X, labels, nullptr, 1, n_rows, n_cols,
+                               n_rows, 128, 128, log_lik, grad_w, s, n_splits,
+                               workspace, 0, n_classes, cls_log2);
+    default:
+      return launch_v2<256, 2>(W, X, labels, nullptr, 1, n_rows, n_cols,
+                               n_rows, 256, 256, log_lik, grad_w, s, n_splits,
+                               workspace, 0, n_classes, cls_log2);
   }
 }
 
@@ -962,12 +847,10 @@ extern "C" int zshmc_linear_multinomial_log_lik(const float* theta,
   // chain axes): tiles of 64 chains of ONE document when the chain axis fills
   // them well (a multiple of 64, or at least 512 chains: >= 89 % of the
   // slots used), so that a workgroup's counts are one row of the matrix.
-  // Same arithmetic per row either way (bit-identical results);
-  // ZSHMC_LB_DOC_MAJOR=0 keeps consecutive rows (A/B, tests).
-  static const bool allow_doc_major = [] {
-    const char* e = getenv("ZSHMC_LB_DOC_MAJOR");
-    return !(e && e[0] == '0');
-  }();
+  // Same arithmetic per row either way: bit-identical results
+  // (tests/test_gpu_mixture_multinomial.py compares with the same rows given
+  // as one "document" each, which keeps consecutive rows).
+  const bool allow_doc_major = true;
   const int64_t n_chains = n_rows / count_rows;
   if (n_topics > 256) {
     // 32-row blocks (csrc/linear_bernoulli_wide.hip): same rule, half the size

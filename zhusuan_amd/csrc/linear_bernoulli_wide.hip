@@ -33,6 +33,7 @@
 // Two barriers per tile, both for the 20 KB exchange.  Roofline: MFMA,
 // 4*N*D*C flop per call as in the narrow kernel.
 #include "common.h"
+#include "lb_ops.h"
 
 namespace zshmc {
 
@@ -107,9 +108,10 @@ __device__ __forceinline__ void wide_dma_row(const float* src, uint32_t dst,
   }
 }
 
-// (D = 256: an A/B of this decomposition against the 64-chain-block kernel of
-// csrc/linear_bernoulli.hip -- 54 KB of LDS and ~100 registers let two
-// workgroups share a CU; ZSHMC_LB_SPLIT256=1 routes 256-wide calls here)
+// (D = 256 also instantiates -- 54 KB of LDS and ~100 registers, two workgroups
+// per CU -- and was measured against the 64-chain-block kernel of
+// csrc/linear_bernoulli.hip: 0.77 against 0.82 of peak,
+// profiles/r03v_split256_ab.txt; the library does not dispatch it)
 // OP as in csrc/linear_bernoulli.hip: 0 = Bernoulli over dense logits (y[n]
 // per data row); 1 = UnnormalizedMultinomial over a mixture (W = theta, X =
 // phi^T, the counts x[c, n] from `yc` [yc_rows, ldy] with row period yc_rows
@@ -121,7 +123,8 @@ __global__ __launch_bounds__(256, D == 256 ? 2 : 1) void linear_bernoulli_wide_k
     const float* __restrict__ W, const float* __restrict__ X,
     const float* __restrict__ y, const float* __restrict__ yc, int64_t yc_rows,
     int64_t ldy, int64_t C, int64_t N, int64_t ldw, int64_t ldx,
-    float* __restrict__ ll, float* __restrict__ gW, int doc_major) {
+    float* __restrict__ ll, float* __restrict__ gW, int doc_major,
+    int n_classes, int cls_log2) {
   static_assert(D == 256 || D == 512 || D == 1024,
                 "padded widths of the wide kernel");
   constexpr int FQ = D / 4;    // features per wave
@@ -218,10 +221,13 @@ __global__ __launch_bounds__(256, D == 256 ? 2 : 1) void linear_bernoulli_wide_k
 #pragma unroll
     for (int j = 0; j < kWR; ++j) dma_row(t0, j);
   }
-  if (OP == 0 && tid < kWR) {
+  if (OP != 1 && tid < kWR) {
     const int64_t nr = tile_begin * kWR + tid;
     sY[tid] = nr < N ? y[nr] : 0.f;
   }
+  // OP 2 (csrc/lb_ops.h): the class of this lane's column (lo of a 32-row
+  // block whose base is a multiple of the class stride)
+  const CatLane cat = cat_lane(lo, n_classes, OP == 2 ? cls_log2 : 0);
   // OP 1: this lane's 4 counts of a tile -- chain lo, rows 8f + 4hi .. +3, the
   // elements whose residual this wave computes -- 16 contiguous bytes of the
   // chain's counts row (rows zero-padded to 4-float groups and 16-B aligned:
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(256, D == 256 ? 2 : 1) void linear_bernoulli_wide_k
     const bool more = tile + 1 < n_tiles;
     const int64_t n_next = (more ? tile + 1 : tile) * kWR;
     const TileSrc tnext = tile_src(n_next);
-    if (OP == 0 && tid < kWR) {
+    if (OP != 1 && tid < kWR) {
       const int64_t nr = n_next + tid;
       yr = nr < N ? y[nr] : 0.f;
     }
@@ -349,6 +355,9 @@ __global__ __launch_bounds__(256, D == 256 ? 2 : 1) void linear_bernoulli_wide_k
                            0.6931471805599453f * __builtin_amdgcn_logf(t1);
           res[j] = valid ? yv - sig : 0.f;
           ll_tile += valid ? lp : 0.f;
+        } else if (OP == 2) {
+          res[j] = categorical_residual(sv, sY[buf * kWR + nl], cat, valid,
+                                        ll_tile);
         } else {
           // sum_v x_v log((theta.phi)_v) and d/d(theta.phi) = x / (theta.phi)
           // (multivariate.py:435-443, normalize_logits = False); x = 0
@@ -433,7 +442,7 @@ __global__ __launch_bounds__(256, D == 256 ? 2 : 1) void linear_bernoulli_wide_k
       }
     }
     ZS_LBW_MARK(4)  // phase 3 + DMA issue
-    if (OP == 0 && tid < kWR) sY[(buf ^ 1) * kWR + tid] = yr;
+    if (OP != 1 && tid < kWR) sY[(buf ^ 1) * kWR + tid] = yr;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the slice has landed
     if (OP == 1) xcnt = xnext;
     ZS_LBW_MARK(5)  // DMA wait
@@ -505,7 +514,7 @@ static int launch_wide(const float* W, const float* X, const float* y,
                        const float* yc, int64_t yc_rows, int64_t ldy,
                        int64_t C, int64_t N, float* ll, float* gW,
                        hipStream_t s, int n_splits, float* workspace,
-                       int doc_major) {
+                       int doc_major, int n_classes = 0, int cls_log2 = 0) {
   constexpr int LDQ = D / 4 + 4;
   const size_t lds = (size_t)(wide_buffers(D) * 4 * kWR * LDQ + 2 * kWR +
                               4 * 4 * 64 * 4 + 4 * 64 * 4) *
@@ -533,11 +542,13 @@ static int launch_wide(const float* W, const float* X, const float* y,
   if (gW)
     hipLaunchKernelGGL((linear_bernoulli_wide_kernel<D, true, OP>), grid,
                        dim3(256), lds, s, W, X, y, yc, yc_rows, ldy, C, N,
-                       (int64_t)D, (int64_t)D, ll_out, g_out, doc_major);
+                       (int64_t)D, (int64_t)D, ll_out, g_out, doc_major, n_classes,
+                       cls_log2);
   else
     hipLaunchKernelGGL((linear_bernoulli_wide_kernel<D, false, OP>), grid,
                        dim3(256), lds, s, W, X, y, yc, yc_rows, ldy, C, N,
-                       (int64_t)D, (int64_t)D, ll_out, g_out, doc_major);
+                       (int64_t)D, (int64_t)D, ll_out, g_out, doc_major, n_classes,
+                       cls_log2);
   ZS_LAUNCH_CHECK("linear_bernoulli_wide_kernel launch");
   if (S > 1) {
     const int64_t n = C + (gW ? C * D : 0);
@@ -550,20 +561,31 @@ static int launch_wide(const float* W, const float* X, const float* y,
   return ZSHMC_OK;
 }
 
-// n_features 512 or 1024 (256: the A/B switch); called by
-// zshmc_linear_bernoulli_log_lik
+// n_features 512 or 1024; called by zshmc_linear_bernoulli_log_lik
 int linear_bernoulli_wide(const float* W, const float* X, const float* y,
                           int64_t n_chains, int64_t n_rows, int64_t n_features,
                           float* ll, float* gW, int n_splits, float* workspace,
                           hipStream_t s) {
-  if (n_features == 256)
-    return launch_wide<256, 0>(W, X, y, nullptr, 1, n_rows, n_chains, n_rows,
-                               ll, gW, s, n_splits, workspace, 0);
   if (n_features == 512)
     return launch_wide<512, 0>(W, X, y, nullptr, 1, n_rows, n_chains, n_rows,
                                ll, gW, s, n_splits, workspace, 0);
   return launch_wide<1024, 0>(W, X, y, nullptr, 1, n_rows, n_chains, n_rows, ll,
                               gW, s, n_splits, workspace, 0);
+}
+
+// n_features 512 or 1024; called by zshmc_linear_categorical_log_lik: the
+// rows of W are (chain, class) pairs in groups of 2^cls_log2
+int linear_categorical_wide(const float* W, const float* X, const float* labels,
+                            int64_t n_cols, int64_t n_rows, int64_t n_features,
+                            int n_classes, int cls_log2, float* ll, float* gW,
+                            int n_splits, float* workspace, hipStream_t s) {
+  if (n_features == 512)
+    return launch_wide<512, 2>(W, X, labels, nullptr, 1, n_rows, n_cols,
+                               n_rows, ll, gW, s, n_splits, workspace, 0,
+                               n_classes, cls_log2);
+  return launch_wide<1024, 2>(W, X, labels, nullptr, 1, n_rows, n_cols, n_rows,
+                              ll, gW, s, n_splits, workspace, 0, n_classes,
+                              cls_log2);
 }
 
 // n_topics 512 or 1024; called by zshmc_linear_multinomial_log_lik

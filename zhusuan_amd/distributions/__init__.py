@@ -1,6 +1,7 @@
 from .base import Distribution
 from .univariate import (Normal, Bernoulli, Categorical, Discrete,
-                         LinearLogits, linear_logits)
+                         LinearLogits, linear_logits, LinearClassLogits,
+                         linear_class_logits)
 from .univariate2 import Laplace, Gamma, InverseGamma, Beta
 from .multivariate import (UnnormalizedMultinomial, BagofCategoricals,
                            LogMixture, log_mixture,
@@ -9,4 +10,4 @@ from .multivariate import (UnnormalizedMultinomial, BagofCategoricals,
 __all__ = ['Distribution', 'Laplace', 'Gamma', 'InverseGamma', 'Beta', 'Normal', 'Bernoulli', 'Categorical', 'Discrete',
            'UnnormalizedMultinomial', 'BagofCategoricals', 'LinearLogits',
            'LogMixture', 'log_mixture', 'MultivariateNormalCholesky',
-           'linear_logits']
+           'linear_logits', 'LinearClassLogits', 'linear_class_logits']

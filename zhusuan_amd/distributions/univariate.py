@@ -12,7 +12,7 @@ from ..utils import next_op_offset
 from .base import Distribution, as_tensor, common_device, default_device
 
 __all__ = ['Normal', 'Bernoulli', 'Categorical', 'Discrete', 'LinearLogits',
-           'linear_logits']
+           'linear_logits', 'LinearClassLogits', 'linear_class_logits']
 
 _FLOATS = (torch.float16, torch.float32, torch.float64)
 _INTS = (torch.int16, torch.int32, torch.int64)
@@ -407,10 +407,87 @@ class Bernoulli(Distribution):
             self.logits, given.to(self.param_dtype), 0)
 
 
+class LinearClassLogits(object):
+    """Lazy class logits of a softmax regression,
+    `logits[..., n, k] = sum_f X[n, f] * w[..., k, f]` -- what the reference
+    spells `tf.matmul(X, w, transpose_b=True)` on a [chains, N, F] tiling of X
+    -- of shape w.shape[:-2] + [N, K], never materialised:
+    `Categorical(linear_class_logits(w, X), group_ndims=1)` evaluates log_prob
+    and its gradient with the fused fp32-MFMA kernels
+    (zshmc_linear_categorical_log_lik; up to 32 classes x 1024 features);
+    anything else falls back to `.dense()`."""
+
+    def __init__(self, w, X):
+        w = as_tensor(w)          # (a symbolic latent: the latent itself)
+        X = as_tensor(X)
+        if X.dim() != 2 or w.dim() < 2 or w.shape[-1] != X.shape[-1]:
+            raise ValueError(
+                "linear_class_logits: w[..., K, F] and X[N, F] expected, got "
+                "{} and {}".format(tuple(w.shape), tuple(X.shape)))
+        self.w, self.X = w, X
+
+    @property
+    def n_rows(self):
+        return int(self.X.shape[0])
+
+    @property
+    def n_classes(self):
+        return int(self.w.shape[-2])
+
+    @property
+    def n_features(self):
+        return int(self.w.shape[-1])
+
+    @property
+    def lead_shape(self):
+        return tuple(self.w.shape[:-2])
+
+    @property
+    def shape(self):
+        return torch.Size(self.lead_shape + (self.n_rows, self.n_classes))
+
+    @property
+    def dtype(self):
+        return self.w.dtype
+
+    @property
+    def device(self):
+        return self.w.device
+
+    def fused_ok(self):
+        return (self.n_classes <= _ops.MAX_CLASSES and
+                self.n_features <= _ops.LINEAR_BERNOULLI_WIDTHS[-1] and
+                not self.X.requires_grad and self.dtype == torch.float32)
+
+    def dense(self):
+        return torch.matmul(self.X, self.w.transpose(-1, -2))
+
+
+def linear_class_logits(w, X):
+    return LinearClassLogits(w, X)
+
+
 class Categorical(Distribution):
     """Univariate Categorical (univariate.py:409-551)."""
 
     def __init__(self, logits, dtype=torch.int32, group_ndims=0, **kwargs):
+        self._lazy = None
+        logits = _symbolic.lower_categorical_logits(logits)
+        if isinstance(logits, LinearClassLogits):
+            if logits.dtype != torch.float32:
+                raise TypeError(
+                    "Categorical: linear_class_logits must be float32")
+            if dtype not in (torch.float32, torch.float64, torch.int32,
+                             torch.int64):
+                raise TypeError(
+                    "`dtype`({}) not in allowed dtypes.".format(dtype))
+            self._lazy = logits
+            self._logits_dense = None
+            self._n_categories = logits.n_classes
+            super(Categorical, self).__init__(
+                dtype=dtype, param_dtype=torch.float32, is_continuous=False,
+                is_reparameterized=False, group_ndims=group_ndims, **kwargs)
+            return
         dev = common_device(logits) or default_device()
         self._logits = as_tensor(logits, dtype=None if isinstance(
             logits, torch.Tensor) else torch.float32, device=dev)
@@ -427,9 +504,20 @@ class Categorical(Distribution):
             raise ValueError(
                 "Categorical.logits should have rank >= 1, got a scalar.")
         self._n_categories = int(self._logits.shape[-1])
+        self._logits_dense = self._logits
         super(Categorical, self).__init__(
             dtype=dtype, param_dtype=self._logits.dtype, is_continuous=False,
             is_reparameterized=False, group_ndims=group_ndims, **kwargs)
+
+    @property
+    def _logits(self):
+        if self._logits_dense is None:
+            self._logits_dense = self._lazy.dense()
+        return self._logits_dense
+
+    @_logits.setter
+    def _logits(self, value):
+        self._logits_dense = value
 
     @property
     def logits(self):
@@ -440,13 +528,31 @@ class Categorical(Distribution):
         return self._n_categories
 
     def _device(self):
-        return self._logits.device
+        return self._lazy.device if self._lazy is not None \
+            else self._logits.device
 
     def _get_value_shape(self):
         return torch.Size([])
 
     def _get_batch_shape(self):
-        return self._logits.shape[:-1]
+        return self._lazy.shape[:-1] if self._lazy is not None \
+            else self._logits.shape[:-1]
+
+    def _log_prob_grouped(self, given):
+        lazy = self._lazy
+        if (lazy is not None and self._group_ndims >= 1 and lazy.fused_ok()
+                and not given.requires_grad
+                and given.numel() == lazy.n_rows and given.dim() >= 1
+                and given.shape[-1] == lazy.n_rows
+                and len(lazy.lead_shape) >= self._group_ndims - 1):
+            # labels [N] (or [1, ..., N]) shared by every chain, the data rows
+            # the innermost grouped axis: the fused likelihood
+            labels = _ops.labels_as_float(given, lazy.n_classes)
+            ll = _ops.LinearCategoricalLogLik.apply(lazy.w, lazy.X, labels)
+            extra = self._group_ndims - 1
+            return ll if extra == 0 else ll.sum(
+                dim=tuple(range(-extra, 0)))
+        return super(Categorical, self)._log_prob_grouped(given)
 
     def _sample(self, n_samples):
         """univariate.py:478-494; inverse-CDF on the Philox stream."""

@@ -35,10 +35,18 @@ from .framework.bn import StochasticTensor
 from .framework.meta_bn import MetaBayesianNet
 from .utils import merge_dicts, next_sampler_seed
 
-__all__ = ['deferred', 'HMCInfo', 'HMC', 'placeholder', 'InvalidArgumentError']
+__all__ = ['deferred', 'HMCInfo', 'HMC', 'placeholder', 'InvalidArgumentError',
+           'NativePlanFallbackWarning']
 
 OLD_LOG_PROB_MSG = ('HMC: old_log_prob has numeric errors! Try better '
                     'initialization.')
+
+
+class NativePlanFallbackWarning(UserWarning):
+    """A model with a dense likelihood was refused by the native plans and
+    runs on the autograd-driven generic plan (every gradient evaluation an
+    autograd graph over torch / rocBLAS kernels): `hmc.plan_reason` says
+    which construct was refused."""
 
 
 class InvalidArgumentError(ArithmeticError):
@@ -247,6 +255,8 @@ class HMC(object):
         self._plan = None
         self._pending_check = False
         self._symbolic_latents = True
+        self._refusal = None
+        self.plan_reason = None
 
     # -- sample(): builds the execution plan (hmc.py:382-522) -------------
     def sample(self, meta_bn, observed, latent):
@@ -304,6 +314,18 @@ class HMC(object):
                                     device)
         if plan is None:
             plan = _GenericPlan(self, latent_k, latent_v, chain_shape, device)
+            reason, loud = self._refusal or ('no native plan applies', False)
+            if not self.native_plans:
+                reason, loud = 'native_plans=False', False
+            self.plan_reason = 'generic plan: ' + reason
+            if loud:
+                import warnings
+                warnings.warn(
+                    'HMC.sample: the model has a dense likelihood but runs '
+                    'on the autograd-driven generic plan -- %s.' % reason,
+                    NativePlanFallbackWarning, stacklevel=2)
+        else:
+            self.plan_reason = 'native plan: %s' % plan.kind
         self._plan = plan
         st = plan.state
         st[_capi.ST_STEP_SIZE] = self._init_step_size_value
@@ -341,6 +363,12 @@ class HMC(object):
                     raise
                 self._symbolic_latents = False
         return None
+
+    def _note_refusal(self, reason, loud=False):
+        """Why a native plan was not taken (the last, most specific reason
+        wins; a loud one is not overwritten by a quiet one)."""
+        if self._refusal is None or loud or not self._refusal[1]:
+            self._refusal = (reason, bool(loud))
 
     def _eval_log_joint(self, names, values):
         # the latents travel as symbols so that the reference's literal dense
@@ -1183,23 +1211,42 @@ class _DenseLikelihoodPlan(_PlanBase):
         D = self.n_total = sum(self.n_data)
         self.ld = ld = (D + 3) // 4 * 4
         self.packed = len(self.q) > 1 or ld != D
-        self.width = next(v for v in _ops.LINEAR_BERNOULLI_WIDTHS if v >= ld)
         self.softmax = kind == 'mixture_multinomial'
         # chain axes flattened: [C, D_k] views of the latents
         self.q_rows = [q.view(C, d) for q, d in zip(self.q, self.n_data)]
         self.p = torch.zeros(C, ld, **f32)
         self.q_new = torch.zeros(C, ld, **f32)
-        self.grad = torch.empty(C, self.width, **f32)
+        self.segmented = kind == 'linear_categorical'
+        if self.segmented:
+            # w[c, 0:K, 0:F]: K class rows of F features per chain; the
+            # likelihood kernel's "chain rows" are the (chain, class) pairs,
+            # `stride` of them per chain (K rounded up to a power of two)
+            K, F = (int(v) for v in self.q[0].shape[-2:])
+            self.n_classes, self.seg_len = K, F
+            self.stride = _ops.class_stride(K)
+            self.width = next(v for v in _ops.LINEAR_BERNOULLI_WIDTHS
+                              if v >= F)
+            self.lik_rows = C * self.stride
+            self.seg_ws = torch.empty(
+                int(_capi.load().zshmc_model_seg_workspace(C, D)), **f32)
+            need_operand = not (K == self.stride and F == self.width)
+        else:
+            self.width = next(v for v in _ops.LINEAR_BERNOULLI_WIDTHS
+                              if v >= ld)
+            self.lik_rows = C
+            need_operand = self.softmax or self.width != ld
+        self.grad = torch.empty(self.lik_rows, self.width, **f32)
         # operand of the likelihood kernel: theta = softmax(q) / zero-padded q
-        self.operand = torch.zeros(C, self.width, **f32) \
-            if (self.softmax or self.width != ld) else None
+        # / the class rows of q (padding rows and columns stay zero)
+        self.operand = torch.zeros(self.lik_rows, self.width, **f32) \
+            if need_operand else None
         if hmc.adapt_mass is not None:
             # the latents' mass vectors are the columns of ONE packed vector
             # (what the step kernel reads); the padding keeps mass 1
             self.mass_pack = torch.ones(ld, **f32)
             self.mass = [self.mass_pack[o:o + d]
                          for o, d in zip(self.offsets, self.n_data)]
-        self.ll = torch.empty(C, **f32)
+        self.ll = torch.empty(self.lik_rows, **f32)
         self.lp_old = self.orig_log_prob      # HMCInfo.orig_log_prob itself
         self.lp_new = torch.empty(C, **f32)
         self.kin_old = torch.zeros(C, **f32)
@@ -1240,6 +1287,10 @@ class _DenseLikelihoodPlan(_PlanBase):
                 self.inner = _aligned16(ops._padded_x(inner[0], self.width))
             self.obs = _aligned16(y.detach().to(torch.float32).contiguous())
             n_inner = self.inner.shape[0]
+        elif self.kind == 'linear_categorical':
+            self.inner = _aligned16(ops._padded_x(inner[0], self.width))
+            self.obs = _aligned16(ops.labels_as_float(obs, self.n_classes))
+            n_inner = self.inner.shape[0]
         else:
             phi, x = inner[0], obs
             self.inner = _aligned16(ops._padded_phi_t(phi, self.width))
@@ -1248,8 +1299,9 @@ class _DenseLikelihoodPlan(_PlanBase):
             n_inner = self.inner.shape[0]
             if C % self.obs.shape[0] != 0:
                 raise ValueError("counts rows do not divide the chain rows")
-        self.splits = ops._row_splits(C, n_inner, self.device, self.width)
-        need = self.splits * C * (self.width + 1) if self.splits > 1 else 0
+        R = self.lik_rows
+        self.splits = ops._row_splits(R, n_inner, self.device, self.width)
+        need = self.splits * R * (self.width + 1) if self.splits > 1 else 0
         if need and (self._ws is None or self._ws.numel() < need):
             self._ws = torch.empty(need, dtype=torch.float32,
                                    device=self.device)
@@ -1263,6 +1315,10 @@ class _DenseLikelihoodPlan(_PlanBase):
             logstd = torch.log(spread) if how == 'std' else spread  # :96-103
             if q.dim() == len(self.chain_shape):    # per-chain scalar latent
                 mean, logstd = mean.unsqueeze(-1), logstd.unsqueeze(-1)
+            elif q.dim() > len(self.chain_shape) + 1:   # [K, F] class rows
+                ds = tuple(q.shape[len(self.chain_shape):])
+                mean = _flatten_data_axes(mean, ds)
+                logstd = _flatten_data_axes(logstd, ds)
             try:
                 parts.append((_to_row_period(mean, self.chain_shape, d),
                               _to_row_period(logstd, self.chain_shape, d)))
@@ -1312,7 +1368,14 @@ class _DenseLikelihoodPlan(_PlanBase):
         """ll[c] and d ll / d operand at the operand derived from q."""
         w = self.operand if self.operand is not None else q
         ws = self._ws if self.splits > 1 else None
-        if self.kind == 'linear_bernoulli':
+        if self.kind == 'linear_categorical':
+            _capi.call('zshmc_linear_categorical_log_lik', w.data_ptr(),
+                       self.inner.data_ptr(), self.obs.data_ptr(),
+                       self.lik_rows, self.inner.shape[0], self.width,
+                       self.n_classes, self.stride, self.ll.data_ptr(),
+                       self.grad.data_ptr(), self.splits, _capi.ptr(ws),
+                       stream)
+        elif self.kind == 'linear_bernoulli':
             _capi.call('zshmc_linear_bernoulli_log_lik', w.data_ptr(),
                        self.inner.data_ptr(), self.obs.data_ptr(),
                        self.n_chains, self.inner.shape[0], self.width,
@@ -1329,6 +1392,23 @@ class _DenseLikelihoodPlan(_PlanBase):
     def _step(self, q, p, use_grad, eps_host, kick, drift, lp_out, kinetic,
               stream):
         """csrc/hmc_model.hip: prior + Jacobian + kick + drift + operand."""
+        if self.segmented:
+            # csrc/hmc_model_seg.hip: the class rows of a chain are rows
+            # c * stride + k of the gradient / operand matrices
+            _capi.call(
+                'zshmc_model_kick_drift_seg', q.data_ptr(), p.data_ptr(),
+                self.grad.data_ptr() if use_grad else None, self.width,
+                self.seg_len, self.stride, _capi.ptr(self.operand),
+                self.width, self.prior_mean.data_ptr(), self.mean_rows,
+                self.prior_logstd.data_ptr(), self.logstd_rows,
+                self.mass_pack.data_ptr() if self.use_mass else None,
+                None if eps_host is not None else self.state.data_ptr(),
+                0.0 if eps_host is None else float(eps_host), float(kick),
+                float(drift), float(self.lik_scale()), self.n_chains,
+                self.n_total, self.ld,
+                self.ll.data_ptr() if use_grad else None, _capi.ptr(lp_out),
+                _capi.ptr(kinetic), self.seg_ws.data_ptr(), stream)
+            return
         _capi.call(
             'zshmc_model_kick_drift', q.data_ptr(), p.data_ptr(),
             self.grad.data_ptr() if use_grad else None, self.width,
@@ -1473,6 +1553,16 @@ def _to_row_period(param, chain_shape, n_data):
     return _aligned16(t.reshape(rows, n_data)), rows
 
 
+def _flatten_data_axes(param, data_shape):
+    """A prior parameter of a latent with several data axes ([K, F] class
+    rows) broadcast over them and flattened to one, leading (chain) axes
+    kept."""
+    nd = len(data_shape)
+    lead = tuple(param.shape[:max(param.dim() - nd, 0)])
+    t = param.expand(lead + tuple(data_shape))
+    return t.reshape(lead + (-1,))
+
+
 def _aligned16(t):
     """`t` itself, or a copy if its storage offset breaks the 16-byte
     alignment the row kernels require (a contiguous slice `param[1:]` of a
@@ -1518,6 +1608,11 @@ def _summands_of(lp, nodes):
     return picked
 
 
+def _ops_max_classes():
+    from . import _ops
+    return _ops.MAX_CLASSES
+
+
 class _Unsupported(ValueError):
     """The model is outside what a native plan handles: the caller falls back
     to the generic plan."""
@@ -1525,21 +1620,46 @@ class _Unsupported(ValueError):
 
 def _try_dense_likelihood_plan(hmc, meta_bn, names, values, chain_shape,
                                device):
-    from .distributions import Bernoulli, UnnormalizedMultinomial
+    from .distributions import (Bernoulli, Categorical,
+                                UnnormalizedMultinomial)
+    # every `return no(...)` below is a drop to the autograd-driven generic
+    # plan; the reason is kept (hmc.plan_reason) and, once a dense likelihood
+    # has been seen in the model, said aloud (NativePlanFallbackWarning)
+    state = {'dense': False}
+
+    def no(reason):
+        hmc._note_refusal(reason, loud=state['dense'])
+        return None
+
     if not isinstance(meta_bn, MetaBayesianNet):
-        return None
+        return no('the log-joint is a plain callable: no model structure to '
+                  'lower')
     n_chain = len(chain_shape)
-    # every latent: one data axis, or none (a per-chain scalar: a bias)
-    if any(q.dim() not in (n_chain, n_chain + 1) or q.data_ptr() % 16 != 0 or
-           not q.is_contiguous() or q.dtype != torch.float32
-           for q in values):
-        return None
-    sizes = [int(q.shape[-1]) if q.dim() == n_chain + 1 else 1
+    # every latent: one data axis, or none (a per-chain scalar: a bias); a
+    # single latent may have two (the [K, F] class rows of a softmax
+    # regression)
+    for n, q in zip(names, values):
+        if q.dim() not in (n_chain, n_chain + 1) and not (
+                len(values) == 1 and q.dim() == n_chain + 2):
+            return no("latent '%s' has %d data axes" % (n, q.dim() - n_chain))
+        if q.data_ptr() % 16 != 0 or not q.is_contiguous() or \
+                q.dtype != torch.float32:
+            return no("latent '%s' is not a 16-byte aligned contiguous "
+                      "float32 tensor" % n)
+    two_axes = values[0].dim() == n_chain + 2
+    sizes = [int(q.shape[-1]) if q.dim() >= n_chain + 1 else 1
              for q in values]
-    if min(sizes) < 1 or sum(sizes) > 1024:
-        return None
+    if two_axes:
+        K, F = (int(v) for v in values[0].shape[-2:])
+        if not (1 <= K <= _ops_max_classes() and 1 <= F <= 1024):
+            return no('a [%d, %d] latent (the dense-logit Categorical kernel '
+                      'takes up to %d classes x 1 024 features)'
+                      % (K, F, _ops_max_classes()))
+    elif min(sizes) < 1 or sum(sizes) > 1024:
+        return no('%d latent columns (the dense-likelihood kernels take up '
+                  'to 1 024 features / topics)' % sum(sizes))
     if len(names) > 1 and meta_bn.log_joint is not None:
-        return None
+        return no('a user log-joint over several latents')
 
     def analyse(vals):
         """(kind, [(prior mean, prior spread)], [inner tensors], observation)
@@ -1559,66 +1679,98 @@ def _try_dense_likelihood_plan(hmc, meta_bn, names, values, chain_shape,
                 if vals[0].requires_grad else [
                     n for n in stoch if n.name in analyse.accepted]
             if stoch is None:
-                return None
+                return no('the user log-joint is not the plain sum of two '
+                          "nodes' cond_log_prob")
             analyse.accepted = [n.name for n in stoch]
-        if len(stoch) != len(names) + 1:
-            return None
         lik = [n for n in stoch if n.name not in names]
+        state['dense'] = any(
+            getattr(n.dist, '_lazy', None) is not None for n in lik)
+        if len(stoch) != len(names) + 1:
+            return no('%d stochastic nodes in the joint for %d latent(s): '
+                      'one likelihood node expected'
+                      % (len(stoch), len(names)))
         if len(lik) != 1 or not lik[0].is_observed():
-            return None
+            return no('no single observed likelihood node')
         priors = []
         for name, v in zip(names, vals):
             node = [n for n in stoch if n.name == name]
             if len(node) != 1:
-                return None
+                return no("latent '%s' is not a node of the joint" % name)
             pd = node[0].dist
             if type(pd) is not Normal or pd.use_path_derivative or \
                     pd.group_ndims != v.dim() - n_chain:
-                return None
+                return no("the prior of '%s' is not a Normal over its data "
+                          "axes (group_ndims = %d)" % (name,
+                                                       v.dim() - n_chain))
             # (a prior whose parameters depend on another latent -- a
             # hierarchical scale -- requires grad here: the generic plan)
             if pd.mean.requires_grad or pd.given_spread[1].requires_grad:
-                return None
+                return no("the prior of '%s' has parameters that depend on "
+                          "a latent (hierarchical prior)" % name)
             priors.append((pd.mean, pd.given_spread))
         ld = lik[0].dist
         obs = lik[0].tensor
         lazy = getattr(ld, '_lazy', None)
         if lazy is None:
-            return None
+            return no("the logits of '%s' are not a dense contraction of the "
+                      "latents that the symbolic layer recognises "
+                      "(zhusuan_amd/_symbolic.py): they are materialised"
+                      % lik[0].name)
         if type(ld) is Bernoulli:
+            if two_axes:
+                return no('a latent with two data axes under a Bernoulli')
             if ld.group_ndims != 1 or lazy.design_requires_grad() or \
                     obs.dim() != 1 or obs.shape[0] != lazy.n_rows or \
                     obs.requires_grad or len(lazy.terms) != len(vals):
-                return None
+                return no('Bernoulli likelihood outside the native shape: '
+                          'group_ndims = 1, labels [N], constant design '
+                          'matrices, one term per latent')
             # one term per latent, in the order of the latents
             inner = []
             for v in vals:
                 term = [t for t in lazy.terms if t[0] is v]
                 if len(term) != 1 or term[0][2] != (v.dim() == n_chain):
-                    return None
+                    return no('a latent enters the logits more than once '
+                              '(or not at all)')
                 inner.append(term[0][1])
             return 'linear_bernoulli', priors, inner, obs
+        if type(ld) is Categorical:
+            value = vals[0]
+            if not two_axes or lazy.w is not value:
+                return no('Categorical logits that are not X @ w^T of the '
+                          'one latent w[..., K, F]')
+            if ld.group_ndims != 1 or not lazy.fused_ok() or \
+                    obs.requires_grad or obs.dim() < 1 or \
+                    obs.numel() != lazy.n_rows or \
+                    obs.shape[-1] != lazy.n_rows:
+                return no('Categorical likelihood outside the native shape: '
+                          'group_ndims = 1, labels [N], at most %d classes x '
+                          '%d features' % (_ops_max_classes(), 1024))
+            return 'linear_categorical', priors, [lazy.X], obs
         if type(ld) is UnnormalizedMultinomial:
             value = vals[0]
             if len(vals) != 1 or value.dim() != n_chain + 1 or \
                     ld.group_ndims != 0 or ld.normalize_logits or \
                     lazy.phi.requires_grad or obs.requires_grad:
-                return None
+                return no('UnnormalizedMultinomial outside the native shape: '
+                          'one latent, group_ndims = 0, '
+                          'normalize_logits = False, constant phi')
             if lazy.softmax_source is not None:
                 # the literal spelling, lowered symbolically: theta IS
                 # softmax(latent) by construction
                 if lazy.softmax_source is not value:
-                    return None
+                    return no('theta is not softmax(latent)')
             elif value.requires_grad and not _softmax_of(lazy.theta, value):
-                return None
+                return no('theta is not softmax(latent)')
             batch = tuple(lazy.shape[:-1])
             gs = tuple(obs.shape)
             if not (len(gs) >= 1 and gs[-1] == lazy.phi.shape[1] and
                     len(gs) - 1 <= len(batch) and
                     gs[:-1] == batch[len(batch) - (len(gs) - 1):]):
-                return None
+                return no('the counts do not line up with the trailing '
+                          'chain axes')
             return 'mixture_multinomial', priors, [lazy.phi], obs
-        return None
+        return no('likelihood %s has no native kernel' % type(ld).__name__)
 
     analyse.accepted = []
     found = analyse([q.detach().requires_grad_(True) for q in values])
@@ -1661,8 +1813,8 @@ def _try_dense_likelihood_plan(hmc, meta_bn, names, values, chain_shape,
     try:
         return _DenseLikelihoodPlan(hmc, names, values, chain_shape, device,
                                     probe, kind)
-    except _Unsupported:
-        return None
+    except _Unsupported as e:
+        return no(str(e))
 
 
 def _to_data_shape(param, data_shape):
