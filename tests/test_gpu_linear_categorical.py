@@ -261,8 +261,10 @@ def test_native_plan_follows_the_oracle_and_the_generic_plan(env, C, K, F, N):
         op.run()
         opg.run()
         rinfo = ref.step()
-        h = np.abs(rinfo.orig_hamiltonian).max()
         for f in ('orig_hamiltonian', 'hamiltonian', 'orig_log_prob'):
+            # (the proposal's energy reaches 2e4 in the start-up transient,
+            # where eps jumps to ~1: float32 relative, a few ulps)
+            h = np.abs(getattr(rinfo, f)).max()
             np.testing.assert_allclose(getattr(info, f).cpu().numpy(),
                                        getattr(rinfo, f), rtol=0,
                                        atol=3e-5 * h + 1e-3)
