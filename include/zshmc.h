@@ -569,6 +569,28 @@ int zshmc_gather_dot(const float* u, const float* v, const int32_t* select_u,
                      const int32_t* select_v, int64_t n_chains, int64_t n_u,
                      int64_t n_v, int64_t n_pairs, int64_t n_dim, float* out,
                      void* stream);
+/* The rating likelihood of pmf_hmc.py:26-31 in one pass over the pair list
+ * (the per-trip evaluation of the gathered-dot model's NATIVE plan):
+ *   d[k, e]    = sum_j u[k, select_u[e], j] * v[k, select_v[e], j]
+ *   log_lik[k] = sum_e log N(obs[e]; sigmoid(d[k, e]), exp(logstd))
+ *                + (lp_const ? lp_const[k] : 0)
+ *                (bn.normal("r", tf.sigmoid(r_logits), std=alpha_pred) summed
+ *                over the pairs, univariate.py:174-181; lp_const: the
+ *                log-densities of the observed nodes that do not depend on
+ *                the latent, e.g. log p(v) while u is sampled)
+ *   g_out[k, e] = d log_lik[k] / d d[k, e]   (or NULL) -- what
+ *                zshmc_gather_dot_grad scatters into the latent's gradient.
+ * obs [obs_rows, n_pairs] with obs_rows 1 (shared by the chains) or n_chains.
+ * Per-block partial sums go to `workspace`
+ * (zshmc_gather_dot_normal_workspace(n_chains, n_pairs) floats) and are added
+ * per chain in block order: deterministic, no atomics. */
+int64_t zshmc_gather_dot_normal_workspace(int64_t n_chains, int64_t n_pairs);
+int zshmc_gather_dot_normal_lik(
+    const float* u, const float* v, const int32_t* select_u,
+    const int32_t* select_v, const float* obs, int64_t obs_rows, float logstd,
+    const float* lp_const, int64_t n_chains, int64_t n_u, int64_t n_v,
+    int64_t n_pairs, int64_t n_dim, float* g_out, float* log_lik,
+    float* workspace, void* stream);
 int zshmc_gather_dot_grad(const float* other, const float* gout,
                           const int32_t* seg_ptr, const int32_t* order,
                           const int32_t* other_index, int64_t n_chains,

@@ -44,7 +44,7 @@ VARIANTS = {'blr': ('native', 'generic', 'dense', 'nearmiss'),
             # the native plan (fp32-MFMA, csrc/lb_ops.h), the generic plan,
             # and a near miss
             'softmax_reg': ('dense', 'native', 'generic', 'nearmiss'),
-            'pmf': ('fused', 'dense')}
+            'pmf': ('fused', 'dense', 'generic')}
 
 
 def _build_blr(zs, torch, dev, case, qs, variant):
@@ -180,7 +180,10 @@ def _build_pmf(zs, torch, dev, case, qs, variant):
         log_pu, log_pv = bn.cond_log_prob(['u', 'v'])
         return log_pu.sum(-1) + log_pv.sum(-1) + bn.cond_log_prob('r').sum(-1)
     model.log_joint = log_joint
-    return model, 'generic', {'r': p['r'], 'v': p['v']}
+    # both spellings on the native gathered-dot plan (csrc/gather_dot.hip +
+    # csrc/hmc_model_seg.hip); `generic`: the fused spelling on autograd
+    return model, 'generic' if variant == 'generic' else 'gathered_dot', \
+        {'r': p['r'], 'v': p['v']}
 
 
 def _build(zs, torch, dev, case, qs, variant=None):

@@ -162,6 +162,10 @@ PROTOTYPES = {
         _p]),
     'zshmc_gather_dot': (c_int, [
         _p, _p, _p, _p, c_int64, c_int64, c_int64, c_int64, c_int64, _p, _p]),
+    'zshmc_gather_dot_normal_workspace': (c_int64, [c_int64, c_int64]),
+    'zshmc_gather_dot_normal_lik': (c_int, [
+        _p, _p, _p, _p, _p, c_int64, c_float, _p, c_int64, c_int64, c_int64,
+        c_int64, c_int64, _p, _p, _p, _p]),
     'zshmc_gather_dot_grad': (c_int, [
         _p, _p, _p, _p, _p, c_int64, c_int64, c_int64, c_int64, c_int64, _p,
         _p]),

@@ -296,6 +296,12 @@ def gathered_dot(u, select_u, v, select_v):
     1-D integer index tensors of equal length E; returns [..., E]."""
     u = u.tensor if hasattr(u, 'tensor') else u
     v = v.tensor if hasattr(v, 'tensor') else v
+    # one table a symbolic latent (HMC hands its latents over as symbols):
+    # stay symbolic, so that Normal(sigmoid(.)) can be lowered to the native
+    # gathered-dot plan; forced, the symbol is this very op
+    sym = _symbolic.make_gdot(u, select_u, v, select_v)
+    if sym is not None:
+        return sym
     return GatheredDot.apply(u, select_u, v, select_v)
 
 

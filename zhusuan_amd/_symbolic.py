@@ -73,6 +73,11 @@ _RESHAPE = {torch.reshape, _T.reshape, _T.view}
 _LOG = {torch.log, _T.log}
 _ADD = {torch.add, _T.add, _T.__add__, _T.__radd__}
 _UNSQUEEZE = {torch.unsqueeze, _T.unsqueeze}
+_SIGMOID = {torch.sigmoid, _T.sigmoid, torch.nn.functional.sigmoid}
+_MUL = {torch.mul, _T.mul, _T.__mul__, _T.__rmul__, torch.multiply,
+        _T.multiply}
+_SUM = {torch.sum, _T.sum}
+_INDEX_SELECT = {torch.index_select, _T.index_select}
 _TRANSPOSE = {torch.transpose, _T.transpose, torch.swapaxes, _T.swapaxes,
               torch.swapdims, _T.swapdims}
 _MT = _getter('mT')
@@ -134,6 +139,14 @@ class Sym(torch.Tensor):
                 v = e[1].force().unsqueeze(-1)
             elif kind == 'add':
                 v = e[1].force() + e[2].force()
+            elif kind == 'gather1':
+                v = e[1].force().index_select(len(_shape_of(self)) - 2, e[2])
+            elif kind == 'gmul':
+                v = e[1].force() * e[2]
+            elif kind == 'gdot':
+                v = _force_gdot(e)
+            elif kind == 'sigmoid':
+                v = torch.sigmoid(e[1].force())
             elif kind == 'transpose':
                 v = e[1].force().transpose(-1, -2)
             elif kind == 'classlogits':
@@ -287,6 +300,9 @@ def _symbolic_rule(func, args, kwargs):
     if func in _MATMUL and len(args) == 2 and not kwargs and \
             isinstance(args[1], Sym) and not isinstance(args[0], Sym):
         return _class_logits_rule(args[0], args[1])
+    if func in _MUL and len(args) == 2 and not kwargs and \
+            isinstance(args[1], Sym) and not isinstance(args[0], Sym):
+        args = (args[1], args[0])       # const * latent[:, idx]: commutes
     if not args or not isinstance(args[0], Sym):
         return None
     x = args[0]
@@ -325,6 +341,48 @@ def _symbolic_rule(func, args, kwargs):
             return None
         return Sym(('matmul', x, rhs), xs[:-1] + (int(rhs.shape[1]),),
                    x_dtype, x_device)
+    if func is _T.__getitem__ and _kind(x) == 'latent' and len(xs) >= 2 and \
+            len(args) == 2 and not kwargs and isinstance(args[1], tuple) and \
+            len(args[1]) == len(xs) - 1 and all(
+                isinstance(i, slice) and i == slice(None)
+                for i in args[1][:-1]) and _is_index(args[1][-1]):
+        # latent[:, idx]: rows of the axis in front of the last one
+        idx = args[1][-1]
+        return Sym(('gather1', x, idx), xs[:-2] + (int(idx.numel()), xs[-1]),
+                   x_dtype, x_device)
+    if func in _INDEX_SELECT:
+        dim = kwargs.get('dim', args[1] if len(args) > 1 else None)
+        idx = kwargs.get('index', args[2] if len(args) > 2 else None)
+        if _kind(x) == 'latent' and len(xs) >= 2 and isinstance(dim, int) and \
+                _norm_dim(dim, len(xs)) == len(xs) - 2 and _is_index(idx) and \
+                len(args) + len(kwargs) == 3:
+            return Sym(('gather1', x, idx),
+                       xs[:-2] + (int(idx.numel()), xs[-1]), x_dtype, x_device)
+        return None
+    if func in _MUL:
+        if kwargs or len(args) != 2:
+            return None
+        other = args[1]
+        if _kind(x) == 'gather1' and isinstance(other, _T) and \
+                not isinstance(other, Sym) and not other.requires_grad and \
+                tuple(other.shape) == xs and other.dtype == x_dtype:
+            return Sym(('gmul', x, other), xs, x_dtype, x_device)
+        return None
+    if func in _SUM:
+        dim = kwargs.get('dim', kwargs.get('axis',
+                                           args[1] if len(args) > 1 else None))
+        if _kind(x) == 'gmul' and isinstance(dim, int) and \
+                _norm_dim(dim, len(xs)) == len(xs) - 1 and \
+                not kwargs.get('keepdim', False) and \
+                kwargs.get('dtype') is None and len(args) <= 2:
+            g1 = x._expr[1]
+            return Sym(('gdot', g1._expr[1], 'u', x._expr[2], g1._expr[2],
+                        None, x), xs[:-1], x_dtype, x_device)
+        return None
+    if func in _SIGMOID:
+        if len(args) == 1 and not kwargs and _kind(x) == 'gdot':
+            return Sym(('sigmoid', x), xs, x_dtype, x_device)
+        return None
     if func in _TRANSPOSE:
         # the last two axes of a latent [..., K, F] (-> X @ w^T below), or of
         # latent @ const[F, N] (= [..., K, N] -> the same class logits)
@@ -371,6 +429,54 @@ def _symbolic_rule(func, args, kwargs):
                 not isinstance(args[1], Sym) and args[1].dim() == 2:
             return _symbolic_rule(torch.matmul, (x, args[1].t()), {})
     return None
+
+
+def _is_index(idx):
+    return isinstance(idx, _T) and not isinstance(idx, Sym) and \
+        idx.dim() == 1 and idx.dtype in (torch.int32, torch.int64)
+
+
+def _force_gdot(e):
+    _, lat, side, other, su, sv, via = e
+    if via is not None:          # the user's own expression, bit for bit
+        return via.force().sum(-1)
+    from ._ops import GatheredDot
+    if side == 'u':
+        return GatheredDot.apply(lat.force(), su, other, sv)
+    return GatheredDot.apply(other, su, lat.force(), sv)
+
+
+def make_gdot(u, su, v, sv):
+    """zs.gathered_dot with ONE of its tables a symbolic latent: the symbol
+    [..., E] (forced, it is the GatheredDot op itself); None if neither or
+    both are symbols."""
+    us = isinstance(u, Sym) and _kind(u) == 'latent'
+    vs = isinstance(v, Sym) and _kind(v) == 'latent'
+    if us == vs:
+        return None
+    lat, other, side = (u, v, 'u') if us else (v, u, 'v')
+    if isinstance(other, Sym) or other.requires_grad or not (
+            _is_index(su) and _is_index(sv)) or su.shape != sv.shape or \
+            len(lat._meta[0]) < 2 or other.dim() != len(lat._meta[0]) or \
+            tuple(other.shape[:-2]) != lat._meta[0][:-2] or \
+            other.shape[-1] != lat._meta[0][-1]:
+        return None
+    xs, dt, dev = lat._meta
+    return Sym(('gdot', lat, side, other, su, sv, None),
+               xs[:-2] + (int(su.numel()),), dt, dev)
+
+
+def gathered_dot_mean(mean):
+    """If `mean` is the symbol sigmoid(gathered_dot(latent, ...)): the parts
+    (latent tensor, side, other table, select_u, select_v -- select_v None
+    when `other` is already gathered pair by pair), else None."""
+    if not isinstance(mean, Sym) or _kind(mean) != 'sigmoid':
+        return None
+    g = mean._expr[1]
+    if _kind(g) != 'gdot' or g._meta[1] != torch.float32:
+        return None
+    _, lat, side, other, su, sv, _ = g._expr
+    return dict(latent=lat._expr[1], side=side, other=other, su=su, sv=sv)
 
 
 def _class_logits_rule(lhs, rhs):

@@ -74,6 +74,74 @@ __global__ __launch_bounds__(256) void gather_dot_grad_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------
+// The rating likelihood of pmf_hmc.py:26-31 in one pass over the pair list --
+// what the NATIVE plan of the gathered-dot model evaluates per leapfrog trip:
+//   d[k, e]   = sum_j u[k, su[e], j] * v[k, sv[e], j]
+//   pred      = sigmoid(d)                       (bn.normal("r", tf.sigmoid(..)))
+//   term      = log N(obs[e]; pred, exp(logstd)) (univariate.py:174-181)
+//   g[k, e]   = d term / d d = (obs - pred) exp(-2 logstd) pred (1 - pred)
+//               (what tf.gradients, hmc.py:430-432, yields through the sigmoid)
+// A workgroup owns kGdBlockPairs consecutive pairs of ONE chain: its terms are
+// added in a fixed order into partial[k, block]; gd_lik_finish_kernel adds a
+// chain's partials in block order (+ the constant of the observed nodes):
+// deterministic, no atomics.
+constexpr int kGdBlockPairs = 128;  // 16 groups x 8 pairs
+
+__global__ __launch_bounds__(256) void gather_dot_normal_lik_kernel(
+    const float* __restrict__ u, const float* __restrict__ v,
+    const int32_t* __restrict__ su, const int32_t* __restrict__ sv,
+    const float* __restrict__ obs, int64_t obs_rows, float logstd,
+    int64_t n_chains, int64_t n_u, int64_t n_v, int64_t n_pairs, int D,
+    float* __restrict__ g_out, float* __restrict__ partial, int64_t n_blocks) {
+  __shared__ float red[256 / kGdLanes];
+  const int sub = threadIdx.x % kGdLanes, grp = threadIdx.x / kGdLanes;
+  const float prec = expf(-2.0f * logstd);
+  const float c0 = -0.91893853320467274178f - logstd;
+  const int64_t n_work = n_chains * n_blocks;
+  for (int64_t wk = blockIdx.x; wk < n_work; wk += gridDim.x) {
+    const int64_t k = wk / n_blocks, blk = wk - k * n_blocks;
+    const float* __restrict__ ob = obs + (k % obs_rows) * n_pairs;
+    float acc_ll = 0.f;
+    for (int it = 0; it < kGdBlockPairs / (256 / kGdLanes); ++it) {
+      const int64_t e = blk * kGdBlockPairs + it * (256 / kGdLanes) + grp;
+      if (e < n_pairs) {      // (uniform inside a 16-lane group)
+        const float* __restrict__ ur = u + (k * n_u + su[e]) * D;
+        const float* __restrict__ vr = v + (k * n_v + sv[e]) * D;
+        float acc = 0.f;
+        for (int d = sub; d < D; d += kGdLanes) acc = fmaf(ur[d], vr[d], acc);
+        acc = group_sum<kGdLanes>(acc);
+        // sigmoid as tf.sigmoid: 1 / (1 + exp(-d))
+        const float pred = 1.0f / (1.0f + expf(-acc));
+        const float diff = ob[e] - pred;
+        acc_ll += c0 - 0.5f * prec * diff * diff;
+        if (g_out && sub == 0)
+          g_out[k * n_pairs + e] = diff * prec * pred * (1.0f - pred);
+      }
+    }
+    if (sub == 0) red[grp] = acc_ll;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < 256 / kGdLanes; ++i) t += red[i];
+      partial[wk] = t;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void gd_lik_finish_kernel(
+    const float* __restrict__ partial, int64_t n_blocks,
+    const float* __restrict__ lp_const, int64_t n_chains,
+    float* __restrict__ log_lik) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_chains) return;
+  float t = 0.f;
+  for (int64_t b = 0; b < n_blocks; ++b) t += partial[k * n_blocks + b];
+  log_lik[k] = t + (lp_const ? lp_const[k] : 0.f);
+}
+
 static int gd_grid(int64_t groups) {
   int64_t blocks = (groups + (256 / kGdLanes) - 1) / (256 / kGdLanes);
   const int64_t cap = (int64_t)device_cu_count() * 32;
@@ -121,5 +189,43 @@ extern "C" int zshmc_gather_dot_grad(const float* other, const float* gout,
                      gout, seg_ptr, order, other_index, n_chains, n_rows, n_other,
                      n_pairs, (int)n_dim, grad);
   ZS_LAUNCH_CHECK("gather_dot_grad_kernel launch");
+  return ZSHMC_OK;
+}
+
+extern "C" int64_t zshmc_gather_dot_normal_workspace(int64_t n_chains,
+                                                     int64_t n_pairs) {
+  return n_chains * ((n_pairs + kGdBlockPairs - 1) / kGdBlockPairs);
+}
+
+extern "C" int zshmc_gather_dot_normal_lik(
+    const float* u, const float* v, const int32_t* select_u,
+    const int32_t* select_v, const float* obs, int64_t obs_rows, float logstd,
+    const float* lp_const, int64_t n_chains, int64_t n_u, int64_t n_v,
+    int64_t n_pairs, int64_t n_dim, float* g_out, float* log_lik,
+    float* workspace, void* stream) {
+  if (n_chains == 0) return ZSHMC_OK;
+  ZS_REQUIRE(u && v && log_lik && (n_pairs == 0 || (select_u && select_v &&
+                                                    obs && workspace)),
+             "zshmc_gather_dot_normal_lik: null pointer");
+  ZS_REQUIRE(n_chains > 0 && n_u > 0 && n_v > 0 && n_pairs >= 0 && n_dim > 0 &&
+                 n_dim <= (1 << 20) && n_pairs < (1ll << 31) &&
+                 (obs_rows == 1 || obs_rows == n_chains),
+             "zshmc_gather_dot_normal_lik: bad shape");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int64_t n_blocks = (n_pairs + kGdBlockPairs - 1) / kGdBlockPairs;
+  if (n_blocks > 0) {
+    const int64_t n_work = n_chains * n_blocks;
+    const int64_t cap = (int64_t)device_cu_count() * 32;
+    hipLaunchKernelGGL(gather_dot_normal_lik_kernel,
+                       dim3((unsigned)(n_work < cap ? n_work : cap)), dim3(256),
+                       0, s, u, v, select_u, select_v, obs, obs_rows, logstd,
+                       n_chains, n_u, n_v, n_pairs, (int)n_dim, g_out, workspace,
+                       n_blocks);
+    ZS_LAUNCH_CHECK("gather_dot_normal_lik_kernel launch");
+  }
+  hipLaunchKernelGGL(gd_lik_finish_kernel,
+                     dim3((unsigned)((n_chains + 255) / 256)), dim3(256), 0, s,
+                     workspace, n_blocks, lp_const, n_chains, log_lik);
+  ZS_LAUNCH_CHECK("gd_lik_finish_kernel launch");
   return ZSHMC_OK;
 }

@@ -194,9 +194,14 @@ extern "C" int zshmc_model_kick_drift_seg(
              (long long)seg_len);
   ZS_REQUIRE(mean_rows >= 1 && logstd_rows >= 1,
              "zshmc_model_kick_drift_seg: prior row periods must be >= 1");
-  ZS_REQUIRE(!grad_lik || (grad_stride >= seg_len && grad_stride % 4 == 0),
+  // (a segment length that is a multiple of 4 is read / written 16 bytes at a
+  // time: the strides then have to keep that alignment)
+  const bool vec = seg_len % 4 == 0;
+  ZS_REQUIRE(!grad_lik || (grad_stride >= seg_len &&
+                           (!vec || grad_stride % 4 == 0)),
              "zshmc_model_kick_drift_seg: bad grad_stride");
-  ZS_REQUIRE(!operand || (operand_stride >= seg_len && operand_stride % 4 == 0),
+  ZS_REQUIRE(!operand || (operand_stride >= seg_len &&
+                          (!vec || operand_stride % 4 == 0)),
              "zshmc_model_kick_drift_seg: bad operand_stride");
   const uintptr_t align =
       reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(p) |

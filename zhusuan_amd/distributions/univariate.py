@@ -34,6 +34,34 @@ def _assert_same_float_dtype(tensors_with_name):
     return dtype
 
 
+_scalar_cache = {}
+
+
+def _scalar_param(value, device):
+    """A Python number given as a distribution parameter -> ONE float32
+    device tensor per (value, device), reused by every later construction: a
+    model function is re-evaluated on every run, and a fresh tensor each time
+    would cost a host-to-device copy per evaluation and defeat the native
+    plans' "parameters unchanged since last run" check (which goes by
+    storage and version)."""
+    key = (float(value), str(device))
+    t = _scalar_cache.get(key)
+    if t is None:
+        if len(_scalar_cache) > 256:
+            _scalar_cache.clear()
+        t = _scalar_cache[key] = torch.tensor(float(value),
+                                              dtype=torch.float32,
+                                              device=device)
+    return t
+
+
+def _as_param(value, device):
+    if isinstance(value, (int, float)) and not isinstance(value, bool):
+        return _scalar_param(value, device)
+    return as_tensor(value, dtype=None if isinstance(value, torch.Tensor)
+                     else torch.float32, device=device)
+
+
 def _require_f32(dtype, what):
     if dtype != torch.float32:
         raise TypeError(
@@ -58,15 +86,20 @@ class Normal(Distribution):
                 "that both are specified or both are not.")
         dev = common_device(mean, std, logstd) or default_device()
         f32 = torch.float32
+        # (a mean that is sigmoid(gathered_dot(latent, ...)) stays a symbol:
+        # the rating likelihood of pmf_hmc.py:26-31, which the native
+        # gathered-dot plan evaluates without materialising it; any use of it
+        # as a tensor forces it)
         self._mean = as_tensor(mean, dtype=None if isinstance(
-            mean, torch.Tensor) else f32, device=dev)
+            mean, torch.Tensor) else f32, device=dev,
+            keep_symbolic=_symbolic.gathered_dot_mean(mean) is not None) \
+            if not isinstance(mean, (int, float)) else _scalar_param(mean, dev)
         # The parameter that was not given is derived on first use (a model
         # function is re-evaluated on every transition: an eager exp / log
         # would be one more kernel launch per evaluation), unless
         # check_numerics wants it inspected here.
         if logstd is None:
-            self._std = as_tensor(std, dtype=None if isinstance(
-                std, torch.Tensor) else f32, device=dev)
+            self._std = _as_param(std, dev)
             dtype = _assert_same_float_dtype([(self._mean, 'Normal.mean'),
                                               (self._std, 'Normal.std')])
             self._logstd = None                          # log(std), :99
@@ -76,8 +109,7 @@ class Normal(Distribution):
             given = self._std
             self._given_spread = ('std', given)
         else:
-            self._logstd = as_tensor(logstd, dtype=None if isinstance(
-                logstd, torch.Tensor) else f32, device=dev)
+            self._logstd = _as_param(logstd, dev)
             dtype = _assert_same_float_dtype(
                 [(self._mean, 'Normal.mean'),
                  (self._logstd, 'Normal.logstd')])

@@ -160,7 +160,9 @@ class _BayesianNet(object):
 
     def deterministic(self, name, input_tensor):
         """Add a named deterministic node (bn.py:373-385)."""
-        input_tensor = as_tensor(input_tensor)
+        # (a symbolic latent expression stays one: nothing is computed until
+        # somebody uses the node's value)
+        input_tensor = as_tensor(input_tensor, keep_symbolic=True)
         self._nodes[name] = input_tensor
         return input_tensor
 

@@ -357,6 +357,9 @@ class HMC(object):
                 if plan is None and self.native_plans:
                     plan = _try_dense_likelihood_plan(
                         self, meta_bn, names, values, chain_shape, device)
+                if plan is None and self.native_plans:
+                    plan = _try_gathered_dot_plan(
+                        self, meta_bn, names, values, chain_shape, device)
                 return plan
             except _symbolic.SymbolicCut:
                 if not self._symbolic_latents:
@@ -1216,8 +1219,22 @@ class _DenseLikelihoodPlan(_PlanBase):
         self.q_rows = [q.view(C, d) for q, d in zip(self.q, self.n_data)]
         self.p = torch.zeros(C, ld, **f32)
         self.q_new = torch.zeros(C, ld, **f32)
-        self.segmented = kind == 'linear_categorical'
-        if self.segmented:
+        self.segmented = kind in ('linear_categorical', 'gathered_dot')
+        if kind == 'gathered_dot':
+            # pmf_hmc.py:19-31: the latent is one of the two factor tables,
+            # [chains, n, D] -- a handful of chains of 10^4..10^5 elements.
+            # The gradient comes back from zshmc_gather_dot_grad as a plain
+            # [C, n * D] matrix: one "segment" per chain.
+            self.n_classes, self.seg_len, self.stride = 1, D, 1
+            self.width = ld
+            self.lik_rows = C
+            self.seg_ws = torch.empty(
+                int(_capi.load().zshmc_model_seg_workspace(C, D)), **f32)
+            self.lp_const = torch.zeros(C, **f32)
+            self._host_scalars = {}
+            self._logstd_dev = torch.zeros(8, **f32)
+            need_operand = False
+        elif self.segmented:
             # w[c, 0:K, 0:F]: K class rows of F features per chain; the
             # likelihood kernel's "chain rows" are the (chain, class) pairs,
             # `stride` of them per chain (K rounded up to a power of two)
@@ -1266,7 +1283,7 @@ class _DenseLikelihoodPlan(_PlanBase):
         priors, inner, obs = self._probe()
         # priors: [(mean, ('std' | 'logstd', tensor as given))] per latent
         t = [m for m, _ in priors] + [sp[1] for _, sp in priors] + \
-            [a for a in inner if a is not None] + [obs]
+            [a for a in _flat_tensors(inner)] + [obs]
         # same storage, layout and version counter as last run (the tensors
         # are held, so an address cannot have been handed to another one;
         # `X.t()` of the literal spelling is a new view object every time)
@@ -1287,6 +1304,9 @@ class _DenseLikelihoodPlan(_PlanBase):
                 self.inner = _aligned16(ops._padded_x(inner[0], self.width))
             self.obs = _aligned16(y.detach().to(torch.float32).contiguous())
             n_inner = self.inner.shape[0]
+        elif self.kind == 'gathered_dot':
+            self._refresh_gathered_dot(inner, obs)
+            return
         elif self.kind == 'linear_categorical':
             self.inner = _aligned16(ops._padded_x(inner[0], self.width))
             self.obs = _aligned16(ops.labels_as_float(obs, self.n_classes))
@@ -1305,6 +1325,98 @@ class _DenseLikelihoodPlan(_PlanBase):
         if need and (self._ws is None or self._ws.numel() < need):
             self._ws = torch.empty(need, dtype=torch.float32,
                                    device=self.device)
+
+    # -- the gathered-dot rating model (pmf_hmc.py:19-31) -----------------------
+    def _host_scalar(self, t):
+        """float(t) of a one-element device tensor, read once per (storage,
+        version): the per-run path does not synchronise."""
+        key = (t.data_ptr(), t._version)
+        hit = self._host_scalars.get(key)
+        if hit is None:
+            if len(self._host_scalars) > 64:
+                self._host_scalars.clear()
+            hit = self._host_scalars[key] = (float(t.item()), t)
+        return hit[0]
+
+    def _refresh_gathered_dot(self, inner, obs):
+        """inner = [side ('u' | 'v': which table the latent is), other table,
+        select (latent side), select (other side) or None, likelihood spread ('std' | 'logstd', tensor), constant nodes
+        [(observed tensor, mean, (how, spread))...]]."""
+        import math
+        ops = self._ops
+        self.side, other, sel_lat, sel_other, spread, consts = inner
+        self.splits = 1
+        q = self.q[0]
+        n_lat, D = int(q.shape[-2]), int(q.shape[-1])
+        self.n_lat, self.n_dim = n_lat, D
+        self.other = _aligned16(other.detach().to(torch.float32).contiguous())
+        self.n_other = int(self.other.shape[-2])
+        E = int(sel_lat.numel())
+        self.n_pairs = E
+        # CSR view of the pair list by the latent's rows (deterministic
+        # scatter of the gradient) -- cached per index tensor version
+        self.idx_lat, self.seg, self.order = ops._pair_csr(
+            sel_lat, n_lat, 'native_lat')
+        if sel_other is None:       # `other` is already gathered pair by pair
+            if getattr(self, '_iota', None) is None or \
+                    self._iota.numel() != E:
+                self._iota = torch.arange(E, dtype=torch.int32,
+                                          device=self.device)
+            self.idx_other = self._iota
+        else:
+            self.idx_other = ops._pair_csr(sel_other, self.n_other,
+                                           'native_other')[0]
+        r = obs.detach().to(torch.float32).contiguous()
+        if r.numel() == E:
+            self.obs, self.obs_rows = r.reshape(-1), 1
+        elif r.numel() == self.n_chains * E:
+            self.obs, self.obs_rows = r.reshape(-1), self.n_chains
+        else:
+            raise ValueError("HMC (native gathered_dot plan): %d observed "
+                             "ratings for %d pairs" % (r.numel(), E))
+        how, sp = spread
+        sp_v = self._host_scalar(sp)
+        self.lik_logstd = math.log(sp_v) if how == 'std' else sp_v
+        need = int(_capi.load().zshmc_gather_dot_normal_workspace(
+            self.n_chains, E))
+        if self._ws is None or self._ws.numel() < max(need, 1):
+            self._ws = torch.empty(max(need, 1), dtype=torch.float32,
+                                   device=self.device)
+        if getattr(self, 'g_pairs', None) is None or \
+                self.g_pairs.numel() < self.n_chains * max(E, 1):
+            self.g_pairs = torch.empty(self.n_chains * max(E, 1),
+                                       dtype=torch.float32, device=self.device)
+        # the observed nodes that do not depend on the latent: their
+        # log-densities (a constant of this run) join every log-joint value
+        stream = _capi.current_stream()
+        if len(consts) > 1:
+            raise _Unsupported('more than one constant node in the joint')
+        if consts:
+            x, mean, (chow, csp) = consts[0]
+            xs = _aligned16(x.detach().to(torch.float32).contiguous())
+            cols = xs.numel() // self.n_chains
+            cv = self._host_scalar(csp)
+            _capi.call('zshmc_state_set', self._logstd_dev.data_ptr(), 0,
+                       math.log(cv) if chow == 'std' else cv, stream)
+            data_shape = tuple(xs.shape[len(self.chain_shape):])
+            m = mean.detach().to(torch.float32)
+            if m.numel() == 1:
+                m, mode = m.reshape(1), _capi.BCAST_SCALAR
+            elif tuple(m.shape[-len(data_shape):]) == data_shape and \
+                    m.numel() == cols:
+                m, mode = _aligned16(m.contiguous().reshape(-1)), \
+                    _capi.BCAST_ROW
+            else:
+                m, mode = _aligned16(m.expand(xs.shape).contiguous()), \
+                    _capi.BCAST_FULL
+            self._const_keep = (xs, m)
+            _capi.call('zshmc_normal_log_prob', xs.data_ptr(), m.data_ptr(),
+                       self._logstd_dev.data_ptr(), self.lp_const.data_ptr(),
+                       self.n_chains, cols, mode, _capi.BCAST_SCALAR, 1,
+                       stream)
+        else:
+            _capi.call('zshmc_zero', self.lp_const.data_ptr(),
+                       4 * self.n_chains, stream)
 
     def _pack_prior(self, priors):
         """Prior mean / log-std as [rows, ld] matrices used with row period
@@ -1368,7 +1480,33 @@ class _DenseLikelihoodPlan(_PlanBase):
         """ll[c] and d ll / d operand at the operand derived from q."""
         w = self.operand if self.operand is not None else q
         ws = self._ws if self.splits > 1 else None
-        if self.kind == 'linear_categorical':
+        if self.kind == 'gathered_dot':
+            # rating terms + d/d logit in one pass over the pairs, then the
+            # deterministic scatter into the latent's rows
+            lat_is_u = self.side == 'u'
+            _capi.call(
+                'zshmc_gather_dot_normal_lik',
+                q.data_ptr() if lat_is_u else self.other.data_ptr(),
+                self.other.data_ptr() if lat_is_u else q.data_ptr(),
+                (self.idx_lat if lat_is_u else self.idx_other).data_ptr(),
+                (self.idx_other if lat_is_u else self.idx_lat).data_ptr(),
+                self.obs.data_ptr(), self.obs_rows, self.lik_logstd,
+                self.lp_const.data_ptr(), self.n_chains,
+                self.n_lat if lat_is_u else self.n_other,
+                self.n_other if lat_is_u else self.n_lat, self.n_pairs,
+                self.n_dim, self.g_pairs.data_ptr(), self.ll.data_ptr(),
+                self._ws.data_ptr(), stream)
+            if self.n_pairs:
+                _capi.call('zshmc_gather_dot_grad', self.other.data_ptr(),
+                           self.g_pairs.data_ptr(), self.seg.data_ptr(),
+                           self.order.data_ptr(), self.idx_other.data_ptr(),
+                           self.n_chains, self.n_lat, self.n_other,
+                           self.n_pairs, self.n_dim, self.grad.data_ptr(),
+                           stream)
+            else:
+                _capi.call('zshmc_zero', self.grad.data_ptr(),
+                           4 * self.grad.numel(), stream)
+        elif self.kind == 'linear_categorical':
             _capi.call('zshmc_linear_categorical_log_lik', w.data_ptr(),
                        self.inner.data_ptr(), self.obs.data_ptr(),
                        self.lik_rows, self.inner.shape[0], self.width,
@@ -1551,6 +1689,16 @@ def _to_row_period(param, chain_shape, n_data):
     for d in tail[:-1]:
         rows *= int(d)
     return _aligned16(t.reshape(rows, n_data)), rows
+
+
+def _flat_tensors(x):
+    """The tensors inside a nested list / tuple (None and strings skipped)."""
+    if isinstance(x, torch.Tensor):
+        yield x
+    elif isinstance(x, (list, tuple)):
+        for y in x:
+            for t in _flat_tensors(y):
+                yield t
 
 
 def _flatten_data_axes(param, data_shape):
@@ -1815,6 +1963,180 @@ def _try_dense_likelihood_plan(hmc, meta_bn, names, values, chain_shape,
                                     probe, kind)
     except _Unsupported as e:
         return no(str(e))
+
+
+def _sum_tree_leaves(lp):
+    """The autograd leaves' grad_fns if `lp` is built from its differentiable
+    inputs by nothing but additions (alpha = 1) and sums over axes -- the
+    shape of pmf_hmc.py:135-141, `reduce_sum(log_pu) + reduce_sum(log_pv) +
+    reduce_sum(log_pr)` -- else None.  Constant summands (no grad_fn) are
+    invisible here; their value is checked numerically by the caller."""
+    leaves = []
+
+    def walk(fn):
+        if fn is None:
+            return True
+        name = type(fn).__name__
+        if name == 'AddBackward0':
+            if getattr(fn, '_saved_alpha', 1) != 1:
+                return False
+            return all(walk(f) for f, _ in fn.next_functions)
+        if name in ('SumBackward0', 'SumBackward1'):
+            return all(walk(f) for f, _ in fn.next_functions)
+        leaves.append(fn)
+        return True
+
+    fn = getattr(lp, 'grad_fn', None)
+    if fn is None or not walk(fn):
+        return None
+    return leaves
+
+
+def _try_gathered_dot_plan(hmc, meta_bn, names, values, chain_shape, device):
+    """The rating model of pmf_hmc.py:19-31: ONE latent factor table
+    [chains, n, D] with a Normal prior, an observed Normal node whose mean is
+    sigmoid(gathered_dot(latent, ...)) (zs.gathered_dot, or the reference's
+    two gathers, a product and a reduce_sum), any other observed Normal node
+    as a constant, and a log-joint that is the plain sum of the nodes'
+    log-densities over their non-chain axes (the default one, or
+    pmf_hmc.py:135-141)."""
+    state = {'dense': False}
+
+    def no(reason):
+        hmc._note_refusal(reason, loud=state['dense'])
+        return None
+
+    if not isinstance(meta_bn, MetaBayesianNet) or len(names) != 1:
+        return None
+    name, q = names[0], values[0]
+    n_chain = len(chain_shape)
+    if q.dim() != n_chain + 2 or q.dtype != torch.float32 or \
+            not q.is_contiguous() or q.data_ptr() % 16 != 0:
+        return None
+    n_total = int(q.shape[-1]) * int(q.shape[-2])
+
+    def nodes_of(val):
+        bn = meta_bn.observe(**merge_dicts(
+            {name: hmc._as_symbol(val)}, hmc._resolved_observed()))
+        return bn, [n for n in bn.nodes.values()
+                    if isinstance(n, StochasticTensor)]
+
+    def parts(stoch, accepted):
+        """(priors, inner, obs) from the nodes named in `accepted`."""
+        by_name = {n.name: n for n in stoch}
+        if any(k not in by_name for k in accepted):
+            return None
+        prior = by_name[name].dist
+        lik_name = accepted[1]
+        lik = by_name[lik_name]
+        gd = _symbolic.gathered_dot_mean(lik.dist._mean)
+        if type(prior) is not Normal or type(lik.dist) is not Normal or \
+                gd is None or not lik.is_observed():
+            return None
+        consts = []
+        for k in accepted[2:]:
+            d = by_name[k].dist
+            if type(d) is not Normal or not by_name[k].is_observed():
+                return None
+            consts.append((by_name[k].tensor, d.mean, d.given_spread))
+        sel_lat, sel_other = (gd['su'], gd['sv']) if gd['side'] == 'u' \
+            else (gd['sv'], gd['su'])
+        inner = [gd['side'], gd['other'], sel_lat, sel_other,
+                 lik.dist.given_spread, consts]
+        return [(prior.mean, prior.given_spread)], inner, lik.tensor, gd
+
+    # -- build-time analysis on the real latent, with the log-joint ----------
+    probe_q = q.detach().requires_grad_(True)
+    bn, stoch = nodes_of(probe_q)
+    lat_nodes = [n for n in stoch if n.name == name]
+    cands = [n for n in stoch if n.name != name and type(n.dist) is Normal
+             and _symbolic.gathered_dot_mean(n.dist._mean) is not None]
+    if len(lat_nodes) != 1 or len(cands) != 1:
+        return None
+    state['dense'] = True
+    lik = cands[0]
+    gd = _symbolic.gathered_dot_mean(lik.dist._mean)
+    if gd['latent'] is not probe_q:
+        return no('the gathered dot is not over the sampled latent')
+    pd = lat_nodes[0].dist
+    if type(pd) is not Normal or pd.use_path_derivative or \
+            pd.mean.requires_grad or pd.given_spread[1].requires_grad:
+        return no("the prior of '%s' is not a Normal with constant "
+                  "parameters" % name)
+    if lik.dist.given_spread[1].numel() != 1 or \
+            lik.dist.given_spread[1].requires_grad:
+        return no("the likelihood '%s' does not have ONE constant scale"
+                  % lik.name)
+    if n_total % 4 != 0:
+        return no('a latent table of %d elements per chain (the native '
+                  'gathered-dot plan needs a multiple of 4)' % n_total)
+    lp = bn.log_joint()
+    if tuple(lp.shape) != tuple(chain_shape):
+        return no('the log-joint does not have the chain shape')
+    leaves = _sum_tree_leaves(lp)
+    want = {id(lat_nodes[0].__dict__.get('_cond_log_p').grad_fn)
+            if lat_nodes[0].__dict__.get('_cond_log_p') is not None else None,
+            id(lik.__dict__.get('_cond_log_p').grad_fn)
+            if lik.__dict__.get('_cond_log_p') is not None else None}
+    if leaves is None or None in want or len(leaves) != 2 or \
+            {id(f) for f in leaves} != want:
+        return no('the log-joint is not the plain sum of the prior and the '
+                  "rating likelihood's log-densities (+ constants)")
+    # constant summands: the other evaluated nodes (observed, no gradient)
+    const_names = [n.name for n in stoch
+                   if n is not lat_nodes[0] and n is not lik and
+                   n.__dict__.get('_cond_log_p') is not None]
+    for k in const_names:
+        node = [n for n in stoch if n.name == k][0]
+        if node.__dict__['_cond_log_p'].requires_grad:
+            return no("node '%s' depends on the latent" % k)
+        if type(node.dist) is not Normal or not node.is_observed() or \
+                node.dist.given_spread[1].numel() != 1:
+            return no("constant node '%s' is not an observed Normal with "
+                      "one scale" % k)
+    if len(const_names) > 1:
+        return no('more than one constant node in the joint')
+    accepted = [name, lik.name] + const_names
+    lp_user = lp.detach().reshape(-1).to(torch.float32)
+
+    q_meta = torch.empty_like(q, device='meta')
+    on_meta = [True]
+
+    def probe():
+        f = None
+        if on_meta[0]:
+            try:
+                f = parts(nodes_of(q_meta)[1], accepted)
+            except Exception:                            # noqa: BLE001
+                f = None
+            if f is None:
+                on_meta[0] = False
+        if f is None:
+            f = parts(nodes_of(q)[1], accepted)
+        if f is None:
+            raise ValueError(
+                "HMC (native gathered_dot plan): the model changed structure "
+                "between runs; build a new HMC.")
+        return f[0], f[1], f[2]
+
+    try:
+        plan = _DenseLikelihoodPlan(hmc, names, values, chain_shape, device,
+                                    probe, 'gathered_dot')
+    except _Unsupported as e:
+        return no(str(e))
+    # the constants are invisible to the structural check: the native
+    # log-joint at the current state must equal the user's
+    stream = _capi.current_stream()
+    plan._load_state(stream)
+    plan._first_evaluation(plan.q_new, stream)
+    plan._step(plan.q_new, plan.p, True, 0.0, 0.0, 0.0, plan.lp_new, None,
+               stream)
+    diff = float((plan.lp_new - lp_user).abs().max().item())
+    scale = max(1.0, float(lp_user.abs().max().item()))
+    if not diff <= 2e-5 * scale + 1e-3:
+        return no('the log-joint holds terms the native plan does not '
+                  'account for (native - user = %.3g)' % diff)
+    return plan
 
 
 def _to_data_shape(param, data_shape):
