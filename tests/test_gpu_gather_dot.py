@@ -250,7 +250,7 @@ def test_native_gathered_dot_plan_follows_oracle_and_generic_plan(
     (autograd) plan on the same model."""
     zs, torch, dev = env
     rng = np.random.RandomState(11)
-    K, n, m, D, E = 6, 14, 9, 6, 150
+    K, n, m, D, E = 6, 14, 10, 6, 150
     su, sv, r, u0, v = _pmf_problem(rng, K, n, m, D, E)
     alpha_u, alpha_v, alpha_pred = 1.0, 0.8, 0.2
     T = lambda a, **kw: torch.tensor(a, device=dev, **kw)
@@ -363,13 +363,15 @@ def test_native_gathered_dot_plan_with_fed_minibatches(env):
         batches.append((su.astype(np.int32), sv.astype(np.int32), r, v))
 
     def run(native):
+        dflt = lambda a: torch.tensor(a, device=dev)
         sel_u = zs.placeholder(torch.int32, name='su',
-                               default=batches[0][0])
+                               default=dflt(batches[0][0]))
         sel_v = zs.placeholder(torch.int32, name='sv',
-                               default=batches[0][1])
+                               default=dflt(batches[0][1]))
         rating = zs.placeholder(torch.float32, name='r',
-                                default=batches[0][2] * 4 + 1)
-        v_obs = zs.placeholder(torch.float32, name='v', default=batches[0][3])
+                                default=dflt(batches[0][2] * 4 + 1))
+        v_obs = zs.placeholder(torch.float32, name='v',
+                               default=dflt(batches[0][3]))
 
         @zs.meta_bayesian_net(scope='pmf', reuse_variables=True)
         def pmf():
