@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ZSHMC_VERSION 301 /* 0.3.1 */
+#define ZSHMC_VERSION 400 /* 0.4.0 */
 
 /* status codes */
 #define ZSHMC_OK 0
@@ -446,6 +446,105 @@ int zshmc_unnormalized_multinomial_log_prob(const float* logits,
 int zshmc_unnormalized_multinomial_log_prob_grad(
     const float* logits, const float* given, const float* gout,
     float* glogits, int64_t rows, int64_t n_cat, int normalize, void* stream);
+
+/* ------------------------------------------------------------------------
+ * K transitions of a NATIVE model plan from one call
+ * (csrc/hmc_model_run.hip): the launch sequence of one transition of the
+ * dense-likelihood / dense-logit Categorical / gathered-dot plans --
+ *   [mass update]  momentum  likelihood  (L+1) x [step, likelihood]
+ *   MH accept  select  [column sums]  [all-reduce]  step-size update
+ * -- issued by the library itself, n_transitions times, so that a host
+ * language pays its foreign-function overhead once per run of transitions
+ * (the E-steps of lntm_mcem.py:157-182, the 1000 temperatures of AIS.run,
+ * evaluation.py:119-165).  Every launch is one of the entry points above with
+ * the plan's buffers: results are bit-identical to issuing them one by one.
+ * Outside a run (one transition at a time): the step-size search
+ * (hmc.py:308-345), iterations with the mass still at ones, anything that
+ * changes the model's tensors.
+ *
+ * The plan: plain pointers and sizes, filled by the caller (device pointers
+ * unless noted; the struct itself is read on the host during the call). */
+#define ZSHMC_MAX_LATENTS 8
+#define ZSHMC_PLAN_LINEAR_BERNOULLI 0   /* zshmc_linear_bernoulli_log_lik   */
+#define ZSHMC_PLAN_MIXTURE_MULTINOMIAL 1 /* zshmc_linear_multinomial_log_lik */
+#define ZSHMC_PLAN_LINEAR_CATEGORICAL 2 /* zshmc_linear_categorical_log_lik */
+#define ZSHMC_PLAN_GATHERED_DOT 3       /* zshmc_gather_dot_normal_lik      */
+typedef struct zshmc_model_plan {
+  int32_t kind, n_latents, n_leapfrogs, softmax; /* softmax: f = softmax (1) */
+  int32_t segmented, use_mass, n_splits, n_classes;
+  /* the latents (updated in place where accepted) and their columns of the
+   * packed working state */
+  float* latent[ZSHMC_MAX_LATENTS];
+  int64_t latent_size[ZSHMC_MAX_LATENTS], latent_offset[ZSHMC_MAX_LATENTS];
+  float* latent_mass[ZSHMC_MAX_LATENTS]; /* per latent, [size]: written by the
+                                          * mass update when adapt_mass */
+  float* q_new; /* [n_chains, ld] */
+  float* p;     /* [n_chains, ld] */
+  int64_t n_chains, n_total, ld;
+  /* likelihood: operand (or NULL: q_new itself), gradient, per-row values */
+  float* operand; /* [lik_rows, width] */
+  float* grad;    /* [lik_rows, width] */
+  float* ll;      /* [lik_rows] */
+  int64_t lik_rows, width;
+  const float* inner; /* X / phi^T / the other factor table */
+  int64_t n_inner;    /* data rows / vocabulary / rows of the other table */
+  const float* obs;   /* labels / counts / ratings */
+  int64_t obs_rows, obs_stride;
+  float* split_ws; /* row-range partials; gathered dot: per-block sums */
+  /* segmented step (zshmc_model_kick_drift_seg) */
+  int64_t seg_len, groups;
+  float* seg_ws;
+  /* gathered dot */
+  int32_t gd_latent_is_u, gd_pad;
+  const int32_t *gd_idx_latent, *gd_idx_other, *gd_seg, *gd_order;
+  int64_t gd_n_latent, gd_n_pairs, gd_n_dim;
+  float gd_logstd, gd_pad2;
+  const float* gd_lp_const;
+  float* gd_g_pairs;
+  /* prior (row periods as zshmc_model_kick_drift) and packed mass */
+  const float* prior_mean;
+  int64_t mean_rows;
+  const float* prior_logstd;
+  int64_t logstd_rows;
+  const float* mass; /* [ld] */
+  /* MH and HMCInfo */
+  float *lp_old, *lp_new, *kin_old, *kin_new;
+  uint8_t* accept;
+  float *acceptance_rate, *orig_hamiltonian, *hamiltonian, *log_prob;
+  double* acc_sum; /* = comm_buf: [sum acc, flag, column sums ...] */
+  uint32_t* flags;
+  float* state; /* ZSHMC_STATE_WORDS */
+  int64_t chain_offset, n_chains_global;
+  uint64_t seed;
+  float delta, gamma, t0, kappa, mu, mass_decay;
+  /* mass adaptation (hmc.py:115-159, :284-305) */
+  float* ewmv_mean[ZSHMC_MAX_LATENTS];
+  float* ewmv_var[ZSHMC_MAX_LATENTS];
+  double* colsum[ZSHMC_MAX_LATENTS];
+  double* comm_buf;
+  int64_t comm_words;
+  void* mass_ws;
+} zshmc_model_plan;
+
+/*   iteration_first   Philox iteration word of the first transition
+ *   update_kind       ZSHMC_PEND_NONE / _ADAPT / _HOLD: the dual-averaging
+ *                     update every transition of the run owes (hmc.py:501-505)
+ *   adapt_mass        1: every transition starts with the EWMV / mass update
+ *                     from the column sums of its start state and ends with
+ *                     the column sums of its end state (the caller provides
+ *                     the first ones in colsum[]); the mass is 1 / var
+ *   lik_scale_host    HOST array [n_transitions] multiplying the likelihood
+ *                     term of each transition (AIS temperatures,
+ *                     evaluation.py:101-103), or NULL (= 1)
+ *   ais_log_weights   [n_chains] or NULL: after each transition
+ *                     log_w += orig_log_prob - log_prob  (evaluation.py:150-163);
+ *                     ais_ends_here: the last transition of this call is the
+ *                     last temperature (its log_prob is not subtracted)
+ *   comm              RCCL communicator (chains sharded) or NULL */
+int zshmc_hmc_model_run(const zshmc_model_plan* plan, uint32_t iteration_first,
+                        int n_transitions, int update_kind, int adapt_mass,
+                        const float* lik_scale_host, float* ais_log_weights,
+                        int ais_ends_here, void* comm, void* stream);
 
 /* ------------------------------------------------------------------------
  * zshmc_model_kick_drift for latents that are LONG per chain and whose

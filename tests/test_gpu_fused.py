@@ -265,50 +265,37 @@ def test_full_size_properties(env):
     assert dH < 0.05 and float(i3.acceptance_rate.min().item()) > 0.95  # (2)
 
 
-def test_ring_kernel_staged_and_unstaged_paths_agree(tmp_path):
+def test_ring_kernel_staged_and_unstaged_paths_agree():
     """The ring kernel keeps the per-chain scalars (MH uniform in, HMCInfo out)
     in LDS when a workgroup's share fits and falls back to scalar-unit
-    uniforms + in-loop stores otherwise (> ~300k chains at D = 1024).  Force
-    the fallback with ZSHMC_RING_STAGE=0 in a child process and require
-    bit-identical results; also cover a chain count that takes the fallback by
-    itself."""
-    import os
-    import subprocess
-    import sys
-    script = r'''
-import sys, numpy as np, torch
-sys.path.insert(0, %r)
-sys.path.insert(0, %r)
-from helpers import FusedKernel
-dev = torch.device('cuda', 0)
-out = {}
-for C, D, mass in ((3001, 1024, False), (777, 516, True), (310000, 1024, False)):
-    g = torch.Generator(device='cpu').manual_seed(C)
+    uniforms + in-loop stores otherwise (> ~300k chains at D = 1024).  Chains
+    are independent and the random stream is keyed by the global chain index:
+    the first 3 001 chains of a 310 000-chain launch (the fallback) must come
+    out bit-identical to a 3 001-chain launch (staged) from the same rows --
+    states and all five HMCInfo vectors, over two transitions."""
+    import torch
+    from helpers import FusedKernel
+    from zhusuan_amd import _capi
+    dev = torch.device('cuda', 0)
+    D, C_small, C_big = 1024, 3001, 310000
+    g = torch.Generator(device='cpu').manual_seed(4)
     logstd = torch.linspace(-1, 1, D).to(dev)
     mean = torch.randn(D, generator=g).to(dev)
-    m = torch.exp(-2 * logstd) if mass else None
-    q = (torch.randn(min(C, 4096), D, generator=g).repeat((C + 4095) // 4096, 1)[:C]
-         * torch.exp(logstd.cpu()) + mean.cpu()).to(dev)
-    k = FusedKernel(torch, C, D, dev)
-    sums = []
+    rows = (torch.randn(4096, D, generator=g) * torch.exp(logstd.cpu()) +
+            mean.cpu()).to(dev)
+    q_big = rows.repeat((C_big + 4095) // 4096, 1)[:C_big].contiguous()
+    q_small = q_big[:C_small].clone()
+    name = _capi.load().zshmc_fused_kernel_name(D, 0, 0).decode()
+    assert 'ring' in name
+    kb = FusedKernel(torch, C_big, D, dev)
+    ks = FusedKernel(torch, C_small, D, dev)
     for t in range(2):
-        k.step(q, mean, logstd, m, 0.14, 5, 99, t, chain_offset=7)
-        sums.append(k.stats[:1].clone())
-    torch.cuda.synchronize()
-    h = torch.cat([q.reshape(-1)[::97].double().cumsum(0)[-1:]] +
-                  [x.double().sum().reshape(1) for x in k.info] + sums).cpu().numpy()
-    out['%%d_%%d' %% (C, D)] = h
-np.savez(sys.argv[1], **out)
-''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-       os.path.dirname(os.path.abspath(__file__)))
-    res = {}
-    for stage in ('1', '0'):
-        path = str(tmp_path / ('stage%s.npz' % stage))
-        env = dict(os.environ, ZSHMC_RING_STAGE=stage)
-        subprocess.check_call([sys.executable, '-c', script, path], env=env)
-        res[stage] = np.load(path)
-    for k in res['1'].files:
-        np.testing.assert_array_equal(res['1'][k], res['0'][k], err_msg=k)
+        kb.step(q_big, mean, logstd, None, 0.14, 5, 99, t, chain_offset=7)
+        ks.step(q_small, mean, logstd, None, 0.14, 5, 99, t, chain_offset=7)
+        assert torch.equal(q_big[:C_small], q_small)
+        for a, b in zip(kb.info, ks.info):
+            assert torch.equal(a[:C_small], b)
+    assert float(ks.info[0].min()) < 1.0 and float(ks.info[0].mean()) > 0.3
 
 
 def test_steady_nonadaptive_phase_is_a_pure_elision(monkeypatch):
@@ -532,17 +519,12 @@ def test_column_statistics_are_refused_where_the_kernel_has_none(env):
                            colstats_parts=parts))
 
 
-@pytest.mark.parametrize('graph', ['0', '1'])
 @pytest.mark.parametrize('C,D', [(1000, 10), (3000, 260), (70000, 1024)])
-def test_run_many_is_bit_identical_to_a_loop_of_runs(env, C, D, graph,
-                                                     monkeypatch):
+def test_run_many_is_bit_identical_to_a_loop_of_runs(env, C, D):
     """sample_op.run_many(n): the stretches that need nothing from the host
-    are ONE zshmc_hmc_diag_normal_run call (launch loop on the C side; with
-    ZSHMC_RUN_GRAPH=1 stretches of 16 launches replayed from a hipGraph, the
-    iteration of the Philox counters in a device counter); every state word,
-    the latent and the last HMCInfo equal n single runs."""
+    are ONE zshmc_hmc_diag_normal_run call (launch loop on the C side); every
+    state word, the latent and the last HMCInfo equal n single runs."""
     zs, torch = env
-    monkeypatch.setenv('ZSHMC_RUN_GRAPH', graph)
     dev = torch.device('cuda', 0)
     logstd = torch.linspace(-0.5, 0.5, D, device=dev)
     mean = torch.linspace(-1, 1, D, device=dev)
@@ -567,9 +549,7 @@ def test_run_many_is_bit_identical_to_a_loop_of_runs(env, C, D, graph,
             return real(name, *a)
         _capi.call = spy
         try:
-            # (blocks of 40 and 48; graph = '1': one plain launch, then
-            # stretches of 16 replayed from a hipGraph, then the remainder as
-            # plain launches)
+            # (blocks of 40 and 48)
             for n, feed in ((9, {f_ss: True, f_m: True}),
                             (40, {f_ss: True, f_m: False}),
                             (50, {f_ss: False, f_m: False})):

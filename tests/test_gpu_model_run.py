@@ -1,0 +1,258 @@
+"""sample_op.run_many / sample_op.anneal on the NATIVE model plans: the launch
+loop of n transitions inside libzshmc.so (zshmc_hmc_model_run,
+csrc/hmc_model_run.hip) against n single `sample_op.run` calls from Python --
+bit-identical latents, HMCInfo, step size, tuner state, EWMV state and mass,
+for every plan kind (dense-logit Bernoulli with one and with three latents,
+the topic model's mixture multinomial, dense-logit Categorical, the
+gathered-dot rating model), with the step size / mass adapting inside the
+block, held, or absent; and AIS's annealing loop (evaluation.py:119-165) from
+one call against its Python loop.  Reference: zhusuan/hmc.py:418-520 (one
+`sample_op` execution), examples/topic_models/lntm_mcem.py:157-182 (the
+E-step loop that motivates it)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def env():
+    import torch
+    import zhusuan_amd as zs
+    assert torch.cuda.is_available()
+    return zs, torch, torch.device('cuda', 0)
+
+
+def _blr(zs, torch, dev, C=96):
+    g = torch.Generator(device=dev).manual_seed(1)
+    N, D = 300, 20
+    X = torch.randn(N, D, device=dev, generator=g)
+    y = (torch.rand(N, device=dev, generator=g) < 0.5).float()
+    zero = torch.zeros(D, device=dev)
+
+    @zs.meta_bayesian_net()
+    def model():
+        bn = zs.BayesianNet()
+        w = bn.normal('w', zero, std=1., n_samples=C, group_ndims=1)
+        bn.bernoulli('y', w.tensor @ X.t(), group_ndims=1, dtype=torch.float32)
+        return bn
+    return model, {'y': y}, lambda: {'w': torch.zeros(C, D, device=dev)}, \
+        'linear_bernoulli'
+
+
+def _blr3(zs, torch, dev, C=64):
+    g = torch.Generator(device=dev).manual_seed(2)
+    N = 200
+    X1 = torch.randn(N, 7, device=dev, generator=g)
+    X2 = torch.randn(N, 6, device=dev, generator=g)
+    y = (torch.rand(N, device=dev, generator=g) < 0.5).float()
+    z7, z6, z0 = (torch.zeros(7, device=dev), torch.zeros(6, device=dev),
+                  torch.zeros((), device=dev))
+
+    @zs.meta_bayesian_net()
+    def model():
+        bn = zs.BayesianNet()
+        u = bn.normal('u', z7, std=1., n_samples=C, group_ndims=1)
+        v = bn.normal('v', z6, std=0.5, n_samples=C, group_ndims=1)
+        b = bn.normal('b', z0, std=2., n_samples=C)
+        bn.bernoulli('y', u.tensor @ X1.t() + v.tensor @ X2.t() +
+                     b.tensor.unsqueeze(1), group_ndims=1,
+                     dtype=torch.float32)
+        return bn
+    return model, {'y': y}, lambda: {
+        'u': torch.zeros(C, 7, device=dev), 'v': torch.zeros(C, 6, device=dev),
+        'b': torch.zeros(C, device=dev)}, 'linear_bernoulli'
+
+
+def _lntm(zs, torch, dev, n_chains=8, n_docs=12, K=10, V=60):
+    g = torch.Generator(device=dev).manual_seed(3)
+    phi = torch.softmax(torch.randn(K, V, device=dev, generator=g), -1)
+    x = torch.poisson(torch.full((n_docs, V), 1.5, device=dev), generator=g)
+    mean = 0.1 * torch.randn(n_docs, K, device=dev, generator=g)
+    logstd = torch.zeros(K, device=dev)
+
+    def build():
+        @zs.meta_bayesian_net()
+        def lntm():
+            bn = zs.BayesianNet()
+            eta = bn.normal('eta', mean, logstd=logstd, n_samples=n_chains,
+                            group_ndims=1)
+            theta = torch.softmax(eta.tensor, -1)
+            bn.unnormalized_multinomial(
+                'x', torch.log((theta.reshape(-1, K) @ phi).reshape(
+                    n_chains, n_docs, V)), normalize_logits=False,
+                dtype=torch.float32)
+            return bn
+        m = lntm()
+        m.log_joint = lambda bn: (bn.cond_log_prob('eta') +
+                                  bn.cond_log_prob('x'))
+        return m
+    return build, {'x': x}, lambda: {
+        'eta': torch.zeros(n_chains, n_docs, K, device=dev)}, \
+        'mixture_multinomial'
+
+
+def _softmax(zs, torch, dev, C=40, K=5, F=12, N=150):
+    g = torch.Generator(device=dev).manual_seed(4)
+    X = torch.randn(N, F, device=dev, generator=g)
+    y = torch.randint(0, K, (N,), device=dev, generator=g, dtype=torch.int32)
+    zero = torch.zeros(K, F, device=dev)
+
+    @zs.meta_bayesian_net()
+    def model():
+        bn = zs.BayesianNet()
+        w = bn.normal('w', zero, std=1., n_samples=C, group_ndims=2)
+        bn.categorical('y', X.unsqueeze(0) @ w.tensor.transpose(-1, -2),
+                       group_ndims=1)
+        return bn
+    return model, {'y': y}, lambda: {'w': torch.zeros(C, K, F, device=dev)}, \
+        'linear_categorical'
+
+
+def _pmf(zs, torch, dev, K=6, n=14, m=10, D=6, E=120):
+    g = torch.Generator(device=dev).manual_seed(5)
+    su = torch.randint(0, n, (E,), device=dev, generator=g, dtype=torch.int32)
+    sv = torch.randint(0, m, (E,), device=dev, generator=g, dtype=torch.int32)
+    r = torch.rand(E, device=dev, generator=g)
+    v = 0.5 * torch.randn(K, m, D, device=dev, generator=g)
+    zu, zv = torch.zeros(n, D, device=dev), torch.zeros(m, D, device=dev)
+
+    def build():
+        @zs.meta_bayesian_net(scope='pmf', reuse_variables=True)
+        def pmf():
+            bn = zs.BayesianNet()
+            u = bn.normal('u', zu, std=1.0, n_samples=K, group_ndims=1)
+            vv = bn.normal('v', zv, std=1.0, n_samples=K, group_ndims=1)
+            bn.normal('r', torch.sigmoid(zs.gathered_dot(u, su, vv, sv)),
+                      std=0.2)
+            return bn
+        mm = pmf()
+        mm.log_joint = lambda bn: (
+            bn.cond_log_prob('u').sum(-1) + bn.cond_log_prob('v').sum(-1) +
+            bn.cond_log_prob('r').sum(-1))
+        return mm
+    return build, {'r': r, 'v': v}, lambda: {
+        'u': 0.05 * torch.ones(K, n, D, device=dev)}, 'gathered_dot'
+
+
+MODELS = {'blr': _blr, 'blr3': _blr3, 'lntm': _lntm, 'softmax': _softmax,
+          'pmf': _pmf}
+
+
+@pytest.mark.parametrize('which', sorted(MODELS))
+@pytest.mark.parametrize('adaptive', ['none', 'step', 'step+mass'])
+def test_run_many_equals_a_loop_of_runs(env, which, adaptive):
+    zs, torch, dev = env
+    from zhusuan_amd import _capi
+    build, observed, latents, kind = MODELS[which](zs, torch, dev)
+    out = []
+    for many in (False, True):
+        f_ss, f_m = zs.placeholder(bool), zs.placeholder(bool)
+        kw = dict(step_size=0.02, n_leapfrogs=4, seed=8)
+        if adaptive != 'none':
+            kw.update(adapt_step_size=f_ss, target_acceptance_rate=0.7)
+        if adaptive == 'step+mass':
+            kw.update(adapt_mass=f_m, mass_collect_iters=3)
+        hmc = zs.HMC(**kw)
+        q = latents()
+        op, info = hmc.sample(build(), observed, q)
+        assert hmc.plan_kind == kind, hmc.plan_reason
+        calls = []
+        real = _capi.call
+
+        def spy(name, *a):
+            calls.append(name)
+            return real(name, *a)
+        _capi.call = spy
+        try:
+            # adaptation on (search at t = 1, re-initialisation at
+            # t = mass_collect_iters), then held, then on again
+            for n, feed in ((7, {f_ss: True, f_m: True}),
+                            (6, {f_ss: False, f_m: False}),
+                            (5, {f_ss: True, f_m: True})):
+                if many:
+                    op.run_many(n, feed_dict=feed)
+                else:
+                    for _ in range(n):
+                        op.run(feed_dict=feed)
+        finally:
+            _capi.call = real
+        st = hmc.get_state()
+        out.append(dict(
+            q={k: v.clone() for k, v in q.items()},
+            info={f: getattr(info, f).clone() for f in (
+                'acceptance_rate', 'orig_hamiltonian', 'hamiltonian',
+                'orig_log_prob', 'log_prob')},
+            state=st, calls=calls, t=hmc.t))
+    a, b = out
+    assert a['t'] == b['t'] == 18
+    assert b['calls'].count('zshmc_hmc_model_run') >= 2
+    # the block replaces the per-launch calls of the transitions it covers
+    assert len(b['calls']) < len(a['calls']) / 3
+    for k in a['q']:
+        assert torch.equal(a['q'][k], b['q'][k]), k
+    for f in a['info']:
+        assert torch.equal(a['info'][f], b['info'][f]), f
+    assert torch.equal(a['state']['state'], b['state']['state'])
+    if adaptive == 'step+mass':
+        for key in ('ewmv_mean', 'ewmv_var', 'mass'):
+            for x, y in zip(a['state'][key], b['state'][key]):
+                assert torch.equal(x, y), key
+
+
+def test_annealing_from_one_call_equals_the_python_loop(env):
+    """AIS on the topic model (lntm_mcem.py:116-141): the annealing loop and
+    its weight accumulation through sample_op.anneal against the reference
+    loop of single runs -- the same log-weights, bit for bit."""
+    zs, torch, dev = env
+    from zhusuan_amd import hmc as H
+    n_chains, n_docs, K, V = 6, 9, 8, 40
+    g = torch.Generator(device=dev).manual_seed(6)
+    phi = torch.softmax(torch.randn(K, V, device=dev, generator=g), -1)
+    x = torch.poisson(torch.full((n_docs, V), 2.0, device=dev), generator=g)
+    mean, logstd = torch.zeros(n_docs, K, device=dev), torch.zeros(K,
+                                                                   device=dev)
+
+    def models():
+        @zs.meta_bayesian_net()
+        def lntm(observe_x):
+            bn = zs.BayesianNet()
+            eta = bn.normal('eta', mean, logstd=logstd, n_samples=n_chains,
+                            group_ndims=1)
+            if observe_x:
+                bn.unnormalized_multinomial(
+                    'x', zs.log_mixture(torch.softmax(eta.tensor, -1), phi),
+                    normalize_logits=False, dtype=torch.float32)
+            return bn
+        target = lntm(True)
+        target.log_joint = lambda bn: (bn.cond_log_prob('eta') +
+                                       bn.cond_log_prob('x'))
+        proposal = lntm(False)
+        proposal.log_joint = lambda bn: bn.cond_log_prob('eta')
+        return target, proposal
+
+    res = []
+    for block in (True, False):
+        zs.set_random_seed(123)
+        target, proposal = models()
+        flag = zs.placeholder(bool, default=False)
+        hmc = zs.HMC(step_size=0.02, n_leapfrogs=3, adapt_step_size=flag,
+                     target_acceptance_rate=0.6, seed=77)
+        eta = torch.zeros(n_chains, n_docs, K, device=dev)
+        ais = zs.AIS(target, proposal, hmc, {'x': x}, {'eta': eta},
+                     n_temperatures=40, n_adapt=5)
+        assert hmc.plan_kind == 'mixture_multinomial'
+        if not block:
+            ais.verbose = True           # the Python loop (prints per step)
+            import builtins
+            real_print = builtins.print
+            builtins.print = lambda *a, **k: None
+        try:
+            val = ais.run(feed_dict={flag: False})
+        finally:
+            if not block:
+                builtins.print = real_print
+        res.append((val, ais.log_weights.clone(), eta.clone()))
+    assert torch.equal(res[0][1], res[1][1])
+    assert torch.equal(res[0][2], res[1][2])
+    assert res[0][0] == res[1][0]

@@ -47,6 +47,56 @@ class AdaptLink(Structure):
                 ('colstats_parts', c_void_p)]
 
 
+MAX_LATENTS = 8
+PLAN_KINDS = {'linear_bernoulli': 0, 'mixture_multinomial': 1,
+              'linear_categorical': 2, 'gathered_dot': 3}
+
+
+class ModelPlan(Structure):
+    """zshmc_model_plan (include/zshmc.h): the buffers of a native model
+    plan, for zshmc_hmc_model_run."""
+    _fields_ = [
+        ('kind', c_int32), ('n_latents', c_int32), ('n_leapfrogs', c_int32),
+        ('softmax', c_int32), ('segmented', c_int32), ('use_mass', c_int32),
+        ('n_splits', c_int32), ('n_classes', c_int32),
+        ('latent', c_void_p * MAX_LATENTS),
+        ('latent_size', c_int64 * MAX_LATENTS),
+        ('latent_offset', c_int64 * MAX_LATENTS),
+        ('latent_mass', c_void_p * MAX_LATENTS),
+        ('q_new', c_void_p), ('p', c_void_p),
+        ('n_chains', c_int64), ('n_total', c_int64), ('ld', c_int64),
+        ('operand', c_void_p), ('grad', c_void_p), ('ll', c_void_p),
+        ('lik_rows', c_int64), ('width', c_int64),
+        ('inner', c_void_p), ('n_inner', c_int64),
+        ('obs', c_void_p), ('obs_rows', c_int64), ('obs_stride', c_int64),
+        ('split_ws', c_void_p),
+        ('seg_len', c_int64), ('groups', c_int64), ('seg_ws', c_void_p),
+        ('gd_latent_is_u', c_int32), ('gd_pad', c_int32),
+        ('gd_idx_latent', c_void_p), ('gd_idx_other', c_void_p),
+        ('gd_seg', c_void_p), ('gd_order', c_void_p),
+        ('gd_n_latent', c_int64), ('gd_n_pairs', c_int64),
+        ('gd_n_dim', c_int64),
+        ('gd_logstd', c_float), ('gd_pad2', c_float),
+        ('gd_lp_const', c_void_p), ('gd_g_pairs', c_void_p),
+        ('prior_mean', c_void_p), ('mean_rows', c_int64),
+        ('prior_logstd', c_void_p), ('logstd_rows', c_int64),
+        ('mass', c_void_p),
+        ('lp_old', c_void_p), ('lp_new', c_void_p), ('kin_old', c_void_p),
+        ('kin_new', c_void_p), ('accept', c_void_p),
+        ('acceptance_rate', c_void_p), ('orig_hamiltonian', c_void_p),
+        ('hamiltonian', c_void_p), ('log_prob', c_void_p),
+        ('acc_sum', c_void_p), ('flags', c_void_p), ('state', c_void_p),
+        ('chain_offset', c_int64), ('n_chains_global', c_int64),
+        ('seed', c_uint64),
+        ('delta', c_float), ('gamma', c_float), ('t0', c_float),
+        ('kappa', c_float), ('mu', c_float), ('mass_decay', c_float),
+        ('ewmv_mean', c_void_p * MAX_LATENTS),
+        ('ewmv_var', c_void_p * MAX_LATENTS),
+        ('colsum', c_void_p * MAX_LATENTS),
+        ('comm_buf', c_void_p), ('comm_words', c_int64),
+        ('mass_ws', c_void_p)]
+
+
 BCAST_FULL = 0
 BCAST_ROW = 1
 BCAST_SCALAR = 2
@@ -134,6 +184,9 @@ PROTOTYPES = {
         _p, _p, _p, c_int64, _p, c_int64, c_int, _p, c_int64, _p, c_int64, _p,
         _p, c_float, c_float, c_float, c_float, c_int64, c_int64, c_int64, _p,
         _p, _p, _p]),
+    'zshmc_hmc_model_run': (c_int, [
+        POINTER(ModelPlan), c_uint32, c_int, c_int, c_int, _p, _p, c_int, _p,
+        _p]),
     'zshmc_model_seg_workspace': (c_int64, [c_int64, c_int64]),
     'zshmc_model_kick_drift_seg': (c_int, [
         _p, _p, _p, c_int64, c_int64, c_int64, _p, c_int64, _p, c_int64, _p,

@@ -644,49 +644,11 @@ extern "C" int zshmc_hmc_diag_normal_step(
 // K transitions from one call: the launch loop runs on THIS side of the C-ABI
 // (a host language pays its per-call overhead once per run, not once per
 // transition; at BASELINE configs[0]'s size a transition is a few
-// microseconds of device time).  Optionally (ZSHMC_RUN_GRAPH=1) stretches of
-// kGraphNodes launches are replayed from a hipGraph: one graph launch instead
-// of kGraphNodes kernel launches.  The nodes of a graph cannot carry a
-// per-launch iteration in their arguments, so a replayed launch takes it from
-// a device counter that the workgroup retiring last advances (fused_args.h:
-// link_iteration).
-namespace zshmc {
-
-constexpr int kGraphNodes = 16;
-
-__global__ void set_u32_kernel(uint32_t* p, uint32_t v) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) *p = v;
-}
-
-struct RunKey {
-  const void *q, *mean, *logstd, *mass, *acc, *h0, *h1, *lp0, *lp1, *flags;
-  const void *state, *stats, *workspace;
-  int64_t n_chains, n_data, chain_offset, n_chains_global;
-  uint64_t seed;
-  float step_size_host, delta, gamma, t0, kappa, mu;
-  int n_leapfrogs, kind;
-  hipStream_t stream;
-};
-
-struct RunGraph {
-  RunKey key;
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t exec = nullptr;
-  unsigned long long stamp = 0;
-};
-
-// OFF unless ZSHMC_RUN_GRAPH=1 (read on every call): on ROCm 7.2 a replayed
-// kernel node costs MORE than a plain launch -- 5.85 against 4.39 us per
-// transition at 1 000 x 10, 8.74 against 4.37 at 4 096 x 64, 99.2 against 95.3
-// at 65 536 x 1 024 (profiles/r03l_run_graph.txt) -- so the plain C-side loop
-// is the default and the graph path is kept as a measured alternative.
-static bool run_graph_enabled() {
-  const char* e = getenv("ZSHMC_RUN_GRAPH");
-  return e && e[0] == '1';
-}
-
-}  // namespace zshmc
-
+// microseconds of device time).  (Replaying stretches of the loop from a
+// hipGraph was built and measured in round 3 and is gone: on ROCm 7.2 a
+// replayed kernel node costs MORE than a plain launch into a busy queue --
+// 5.85 against 4.39 us per transition at 1 000 x 10, 99.2 against 95.3 at
+// 65 536 x 1 024, profiles/r03l_run_graph.txt.)
 extern "C" int zshmc_hmc_diag_normal_run(
     float* q, const float* mean, const float* logstd, const float* mass,
     float step_size_host, int64_t n_chains, int64_t n_data,
@@ -732,96 +694,6 @@ extern "C" int zshmc_hmc_diag_normal_run(
     return rc;
   };
 
-  // ---- graph replay: all chains on this GPU, a workspace for the counter,
-  // at least one graph's worth of transitions after the first ---------------
-  const bool graphable = run_graph_enabled() && !comm && link->workspace &&
-                         n_chains > 0 &&
-                         n_transitions - 1 >= kGraphNodes;
-  if (graphable) {
-    // the first transition carries what belongs to it alone (pending update,
-    // fresh start, searched step size) and completes every one-time set-up
-    // of the launch path (function attributes, occupancy query) outside the
-    // capture
-    int rc = single(0);
-    if (rc != ZSHMC_OK) return rc;
-    done = 1;
-    static RunGraph cache[4];
-    static unsigned long long clock = 0;
-    RunKey key;
-    memset(&key, 0, sizeof(key));
-    key.q = q; key.mean = mean; key.logstd = logstd; key.mass = mass;
-    key.acc = acceptance_rate; key.h0 = orig_hamiltonian; key.h1 = hamiltonian;
-    key.lp0 = orig_log_prob; key.lp1 = log_prob; key.flags = flags;
-    key.state = link->state; key.stats = link->stats;
-    key.workspace = link->workspace;
-    key.n_chains = n_chains; key.n_data = n_data;
-    key.chain_offset = chain_offset;
-    key.n_chains_global = link->n_chains_global;
-    key.seed = seed; key.step_size_host = step_size_host;
-    key.delta = link->delta; key.gamma = link->gamma; key.t0 = link->t0;
-    key.kappa = link->kappa; key.mu = link->mu;
-    key.n_leapfrogs = n_leapfrogs; key.kind = kind; key.stream = hs;
-    RunGraph* g = nullptr;
-    for (RunGraph& c : cache)
-      if (c.exec && memcmp(&c.key, &key, sizeof(key)) == 0) g = &c;
-    if (!g) {
-      g = &cache[0];
-      for (RunGraph& c : cache)
-        if (c.stamp < g->stamp) g = &c;
-      if (g->exec) hipGraphExecDestroy(g->exec);
-      if (g->graph) hipGraphDestroy(g->graph);
-      g->exec = nullptr;
-      g->graph = nullptr;
-      zshmc_adapt_link l = *link;
-      l.pending = ZSHMC_PEND_NONE;
-      l.fresh_start = 0;
-      l.used_step_size = __builtin_nanf("");
-      // captured on a stream of our own (the caller's may be the legacy
-      // default stream, which cannot be captured); the instantiated graph is
-      // launched on the caller's stream
-      static hipStream_t cap = nullptr;
-      hipError_t e = hipSuccess;
-      if (!cap) e = hipStreamCreateWithFlags(&cap, hipStreamNonBlocking);
-      if (e == hipSuccess)
-        e = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
-      if (e == hipSuccess) {
-        int crc = ZSHMC_OK;
-        for (int j = 0; j < kGraphNodes && crc == ZSHMC_OK; ++j)
-          crc = step_impl(q, mean, logstd, mass, step_size_host, n_chains,
-                          n_data, chain_offset, n_leapfrogs, seed, 0u, 1,
-                          acceptance_rate, orig_hamiltonian, hamiltonian,
-                          orig_log_prob, log_prob, flags, &l, cap, 1);
-        e = hipStreamEndCapture(cap, &g->graph);
-        if (crc != ZSHMC_OK) e = hipErrorUnknown;
-      }
-      if (e == hipSuccess)
-        e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
-      if (e != hipSuccess) {
-        // no graph on this runtime / for this launch: the plain loop below
-        if (g->graph) hipGraphDestroy(g->graph);
-        g->graph = nullptr;
-        g->exec = nullptr;
-        (void)hipGetLastError();
-        g = nullptr;
-      } else {
-        g->key = key;
-      }
-    }
-    if (g) {
-      g->stamp = ++clock;
-      uint32_t* counter = reinterpret_cast<uint32_t*>(
-          reinterpret_cast<char*>(link->workspace) + 16);
-      hipLaunchKernelGGL(set_u32_kernel, dim3(1), dim3(64), 0, hs, counter,
-                         iteration_first + (uint32_t)done);
-      ZS_LAUNCH_CHECK("set_u32_kernel launch");
-      while (n_transitions - done >= kGraphNodes) {
-        const hipError_t e = hipGraphLaunch(g->exec, hs);
-        if (e != hipSuccess)
-          return check_hip(e, "zshmc_hmc_diag_normal_run: hipGraphLaunch");
-        done += kGraphNodes;
-      }
-    }
-  }
   for (int i = done; i < n_transitions; ++i) {
     const int rc = single(i);
     if (rc != ZSHMC_OK) return rc;

@@ -937,12 +937,9 @@ static int launch_ring_cfg(const FusedArgs& a_in, hipStream_t stream) {
   const int64_t share = (a_in.n_chains / round) * G + (tail > G ? G : tail);
   FusedArgs a = a_in;
   // 6 floats per chain: 5 HMCInfo scalars + the MH uniform
-  // ZSHMC_RING_STAGE=0 forces the in-loop path (tests exercise both)
-  static const bool allow_stage = [] {
-    const char* e = getenv("ZSHMC_RING_STAGE");
-    return !(e && e[0] == '0');
-  }();
-  const bool stage = allow_stage && lds_base + (size_t)share * 24 <= kLdsLimit;
+  // (the in-loop path when the share does not fit: > ~300k chains at
+  // D = 1024; tests/test_gpu_fused.py compares the two chain by chain)
+  const bool stage = lds_base + (size_t)share * 24 <= kLdsLimit;
   a.info_cap = stage ? (int)share : 0;
   a.commit_direct = (a.commit && !stage) ? 1u : 0u;
   const size_t lds = lds_base + (stage ? (size_t)share * 24 : 0);
@@ -1011,13 +1008,7 @@ bool fused_ring_config(int64_t D, bool has_mass, bool zero_mean, int* nch_out,
   return true;
 }
 
-bool fused_ring_enabled() {
-  static const bool on = [] {
-    const char* e = getenv("ZSHMC_FUSED_RING");
-    return !(e && e[0] == '0');
-  }();
-  return on;
-}
+bool fused_ring_enabled() { return true; }
 
 int launch_fused_ring(const FusedArgs& a, hipStream_t stream) {
   int nch = 0, k = 0;

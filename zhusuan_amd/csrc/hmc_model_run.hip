@@ -1,0 +1,222 @@
+// K transitions of a NATIVE model plan from one call -- the launch loop of
+// zhusuan_amd/hmc.py::_DenseLikelihoodPlan.transition + _PlanBase.finish on
+// THIS side of the C-ABI (the counterpart of zshmc_hmc_diag_normal_run for
+// the dense-likelihood, dense-logit Categorical and gathered-dot plans).
+//
+// One transition (reference zhusuan/hmc.py:418-520) is
+//   [mass update from the column sums of the state it starts in]   (:284-305)
+//   momentum                                                        (:458)
+//   likelihood + gradient at q, then (L+1) x [element-wise step:
+//     prior + Jacobian + kick (+ drift + next operand), likelihood] (:348-372)
+//   MH accept, select                                               (:479-498)
+//   [column sums of the end state] [all-reduce] step-size update    (:501-505)
+// -- 2 (L + 1) + 5 .. 9 launches, every one of them an entry point of this
+// library.  Issued from a host language each costs a foreign-function call
+// (ctypes: ~4 us); at the sizes the reference's own loops run -- the E-steps
+// of lntm_mcem.py:157-182 on a minibatch of 100 documents, the 1000
+// temperatures of AIS.run (evaluation.py:119-165) -- that is what a
+// transition takes.  Here the loop is C: one call per run of transitions.
+// Nothing in it reads device memory; the sequence is exactly the one the
+// front-end issues, so results are bit-identical to a loop of single runs.
+#include "common.h"
+
+using namespace zshmc;
+
+namespace {
+
+__global__ void ais_accumulate_kernel(float* __restrict__ log_w,
+                                      const float* __restrict__ orig_lp,
+                                      const float* __restrict__ lp,
+                                      int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    // evaluation.py:150-163: log w += log p_k(x_{k-1}) [- log p_k(x_k)], the
+    // two float32 updates in the order the reference applies them
+    float w = log_w[i] + orig_lp[i];
+    if (lp) w -= lp[i];
+    log_w[i] = w;
+  }
+}
+
+#define ZS_TRY(call)                 \
+  do {                               \
+    const int _rc = (call);          \
+    if (_rc != ZSHMC_OK) return _rc; \
+  } while (0)
+
+int likelihood(const zshmc_model_plan& m, const float* q, void* s) {
+  const float* w = m.operand ? m.operand : q;
+  float* ws = m.n_splits > 1 ? m.split_ws : nullptr;
+  switch (m.kind) {
+    case ZSHMC_PLAN_LINEAR_BERNOULLI:
+      return zshmc_linear_bernoulli_log_lik(w, m.inner, m.obs, m.n_chains,
+                                            m.n_inner, m.width, m.ll, m.grad,
+                                            m.n_splits, ws, s);
+    case ZSHMC_PLAN_MIXTURE_MULTINOMIAL:
+      return zshmc_linear_multinomial_log_lik(
+          w, m.inner, m.obs, m.obs_rows, m.obs_stride, m.n_chains, m.n_inner,
+          m.width, m.ll, m.grad, m.n_splits, ws, s);
+    case ZSHMC_PLAN_LINEAR_CATEGORICAL:
+      return zshmc_linear_categorical_log_lik(
+          w, m.inner, m.obs, m.lik_rows, m.n_inner, m.width, m.n_classes,
+          (int)m.groups, m.ll, m.grad, m.n_splits, ws, s);
+    case ZSHMC_PLAN_GATHERED_DOT: {
+      const bool lat_u = m.gd_latent_is_u != 0;
+      ZS_TRY(zshmc_gather_dot_normal_lik(
+          lat_u ? q : m.inner, lat_u ? m.inner : q,
+          lat_u ? m.gd_idx_latent : m.gd_idx_other,
+          lat_u ? m.gd_idx_other : m.gd_idx_latent, m.obs, m.obs_rows,
+          m.gd_logstd, m.gd_lp_const, m.n_chains, lat_u ? m.gd_n_latent : m.n_inner,
+          lat_u ? m.n_inner : m.gd_n_latent, m.gd_n_pairs, m.gd_n_dim,
+          m.gd_g_pairs, m.ll, m.split_ws, s));
+      if (m.gd_n_pairs)
+        return zshmc_gather_dot_grad(m.inner, m.gd_g_pairs, m.gd_seg,
+                                     m.gd_order, m.gd_idx_other, m.n_chains,
+                                     m.gd_n_latent, m.n_inner, m.gd_n_pairs,
+                                     m.gd_n_dim, m.grad, s);
+      return zshmc_zero(m.grad, 4 * m.n_chains * m.ld, s);
+    }
+  }
+  set_error("zshmc_hmc_model_run: unknown plan kind %d", m.kind);
+  return ZSHMC_ERR_BAD_ARG;
+}
+
+int step(const zshmc_model_plan& m, bool use_grad, float kick, float drift,
+         float lik_scale, float* lp_out, float* kinetic, void* s) {
+  const float* mass = m.use_mass ? m.mass : nullptr;
+  if (m.segmented)
+    return zshmc_model_kick_drift_seg(
+        m.q_new, m.p, use_grad ? m.grad : nullptr, m.width, m.seg_len,
+        m.groups, m.operand, m.width, m.prior_mean, m.mean_rows,
+        m.prior_logstd, m.logstd_rows, mass, m.state, 0.f, kick, drift,
+        lik_scale, m.n_chains, m.n_total, m.ld, use_grad ? m.ll : nullptr,
+        lp_out, kinetic, m.seg_ws, s);
+  return zshmc_model_kick_drift(
+      m.q_new, m.p, use_grad ? m.grad : nullptr, m.width, m.operand, m.width,
+      m.softmax, m.prior_mean, m.mean_rows, m.prior_logstd, m.logstd_rows,
+      mass, m.state, 0.f, kick, drift, lik_scale, m.n_chains, m.n_total, m.ld,
+      use_grad ? m.ll : nullptr, lp_out, kinetic, s);
+}
+
+int transition(const zshmc_model_plan& m, uint32_t t, float lik_scale,
+               void* s) {
+  const int L = m.n_leapfrogs;
+  // the latents -> the packed working state
+  for (int k = 0; k < m.n_latents; ++k)
+    ZS_TRY(zshmc_copy_rows(m.q_new + m.latent_offset[k], m.ld, m.latent[k],
+                           m.latent_size[k], nullptr, m.n_chains,
+                           m.latent_size[k], s));
+  ZS_TRY(zshmc_zero(m.kin_old, 4 * m.n_chains, s));
+  for (int k = 0; k < m.n_latents; ++k)
+    ZS_TRY(zshmc_momentum_rows(m.p + m.latent_offset[k], m.ld,
+                               m.use_mass ? m.latent_mass[k] : nullptr,
+                               m.n_chains, m.latent_size[k], m.chain_offset,
+                               m.seed, t, (uint32_t)k, m.kin_old, s));
+  // operand(q), then likelihood + gradient at q
+  if (m.operand) ZS_TRY(step(m, false, 0.f, 0.f, lik_scale, nullptr, nullptr, s));
+  ZS_TRY(likelihood(m, m.q_new, s));
+  ZS_TRY(zshmc_zero(m.kin_new, 4 * m.n_chains, s));
+  // trip 0: zero-length drift, half kick (hmc.py:352-364); the drift of trip
+  // i+1 rides behind the kick of trip i
+  ZS_TRY(step(m, true, 0.5f, L >= 1 ? 1.f : 0.f, lik_scale, m.lp_old,
+              L == 0 ? m.kin_new : nullptr, s));
+  if (L == 0)
+    ZS_TRY(check_hip(hipMemcpyAsync(m.lp_new, m.lp_old, 4 * m.n_chains,
+                                    hipMemcpyDeviceToDevice,
+                                    reinterpret_cast<hipStream_t>(s)),
+                     "hipMemcpyAsync"));
+  for (int i = 1; i <= L; ++i) {
+    ZS_TRY(likelihood(m, m.q_new, s));
+    const bool last = i == L;
+    ZS_TRY(step(m, true, last ? 0.5f : 1.f, last ? 0.f : 1.f, lik_scale,
+                last ? m.lp_new : nullptr, last ? m.kin_new : nullptr, s));
+  }
+  ZS_TRY(zshmc_mh_accept(m.lp_old, m.lp_new, m.kin_old, m.kin_new, m.n_chains,
+                         m.chain_offset, m.seed, t, m.acceptance_rate,
+                         m.orig_hamiltonian, m.hamiltonian, m.log_prob,
+                         m.accept, m.acc_sum, m.flags, s));
+  // where(accept, q', q) for every latent (hmc.py:488-497)
+  for (int k = 0; k < m.n_latents; ++k)
+    ZS_TRY(zshmc_copy_rows(m.latent[k], m.latent_size[k],
+                           m.q_new + m.latent_offset[k], m.ld, m.accept,
+                           m.n_chains, m.latent_size[k], s));
+  return ZSHMC_OK;
+}
+
+int colstats(const zshmc_model_plan& m, void* s) {
+  ZS_TRY(zshmc_zero(m.comm_buf + ZSHMC_STATS_WORDS,
+                    8 * (m.comm_words - ZSHMC_STATS_WORDS), s));
+  for (int k = 0; k < m.n_latents; ++k)
+    ZS_TRY(zshmc_mass_colstats(m.latent[k], m.ewmv_mean[k], m.n_chains,
+                               m.latent_size[k], m.colsum[k], s));
+  return ZSHMC_OK;
+}
+
+int mass_update(const zshmc_model_plan& m, void* s) {
+  if (m.n_latents == 1)
+    return zshmc_mass_update_fused(m.state, m.ewmv_mean[0], m.ewmv_var[0],
+                                   m.colsum[0], 1, m.n_chains_global,
+                                   m.latent_size[0], m.mass_decay, 0,
+                                   m.latent_mass[0], m.mass_ws, s);
+  for (int k = 0; k < m.n_latents; ++k)
+    // EWMV.t is shared by the latents (hmc.py:118,131): bumped once, after
+    // the last one
+    ZS_TRY(zshmc_mass_update(m.state, m.ewmv_mean[k], m.ewmv_var[k],
+                             m.colsum[k], m.n_chains_global, m.latent_size[k],
+                             m.mass_decay, k == m.n_latents - 1 ? 1 : 2, 0,
+                             m.latent_mass[k], s));
+  return ZSHMC_OK;
+}
+
+}  // namespace
+
+extern "C" int zshmc_hmc_model_run(const zshmc_model_plan* plan,
+                                   uint32_t iteration_first, int n_transitions,
+                                   int update_kind, int adapt_mass,
+                                   const float* lik_scale_host,
+                                   float* ais_log_weights,
+                                   int ais_ends_here, void* comm,
+                                   void* stream) {
+  ZS_REQUIRE(plan && n_transitions >= 0, "zshmc_hmc_model_run: bad argument");
+  const zshmc_model_plan& m = *plan;
+  ZS_REQUIRE(m.n_latents >= 1 && m.n_latents <= ZSHMC_MAX_LATENTS &&
+                 m.n_chains > 0 && m.n_leapfrogs >= 0,
+             "zshmc_hmc_model_run: bad plan");
+  ZS_REQUIRE(update_kind == ZSHMC_PEND_NONE || update_kind == ZSHMC_PEND_ADAPT ||
+                 update_kind == ZSHMC_PEND_HOLD,
+             "zshmc_hmc_model_run: bad update_kind");
+  ZS_REQUIRE(!adapt_mass || (m.comm_buf && m.use_mass),
+             "zshmc_hmc_model_run: mass adaptation needs the column-sum "
+             "buffer and the mass vectors");
+  hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
+  for (int i = 0; i < n_transitions; ++i) {
+    const uint32_t t = iteration_first + (uint32_t)i;
+    // (the column sums of the state this transition starts in were taken at
+    // the end of the previous one -- by the caller before the first)
+    if (adapt_mass) ZS_TRY(mass_update(m, stream));
+    const float ls = lik_scale_host ? lik_scale_host[i] : 1.0f;
+    ZS_TRY(transition(m, t, ls, stream));
+    if (adapt_mass) ZS_TRY(colstats(m, stream));
+    if (comm) {
+      if (adapt_mass)
+        ZS_TRY(zshmc_comm_all_reduce_sum(comm, m.comm_buf, m.comm_words,
+                                         stream));
+      else if (update_kind != ZSHMC_PEND_NONE)
+        ZS_TRY(zshmc_comm_all_reduce_sum(comm, m.comm_buf, ZSHMC_STATS_WORDS,
+                                         stream));
+    }
+    if (update_kind != ZSHMC_PEND_NONE)
+      ZS_TRY(zshmc_stepsize_update(m.state, m.acc_sum, m.n_chains_global,
+                                   update_kind == ZSHMC_PEND_ADAPT, 0, m.delta,
+                                   m.gamma, m.t0, m.kappa, m.mu, stream));
+    if (ais_log_weights) {
+      const bool final = ais_ends_here && i == n_transitions - 1;
+      hipLaunchKernelGGL(ais_accumulate_kernel,
+                         dim3((unsigned)((m.n_chains + 255) / 256)), dim3(256),
+                         0, hs, ais_log_weights, m.lp_old,
+                         final ? nullptr : m.log_prob, m.n_chains);
+      ZS_LAUNCH_CHECK("ais_accumulate_kernel launch");
+    }
+  }
+  return ZSHMC_OK;
+}

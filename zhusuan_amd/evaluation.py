@@ -171,6 +171,18 @@ class AIS(object):
             log_w = -self.log_fn(merge_dicts(
                 self._fixed, dict(zip(self._names, self._state)))).clone()
         info = self.hmc_info
+        plan = self._hmc._plan
+        if hasattr(plan, 'lik_scale') and hasattr(plan, 'run_block') and \
+                not self.verbose and log_w.is_contiguous():
+            # native plan: the n annealing transitions and the weight updates
+            # from ONE call into libzshmc.so (zshmc_hmc_model_run with the
+            # temperature schedule as its lik_scale array) -- bit-identical
+            # to the loop below
+            self.sample_op.anneal(
+                [float(np.float32(t)) for t in self.schedule[1:]],
+                log_w, ends=True, feed_dict=feed_dict)
+            self.temperature = self.schedule[n]
+            n = 0
         for k in range(1, n + 1):
             self._transition(k, feed_dict, 'Finished step')
             log_w += info.orig_log_prob

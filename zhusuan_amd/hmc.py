@@ -215,6 +215,16 @@ class _SampleOp(object):
         HMCInfo holds the last transition's values."""
         self._hmc._run_many(int(n), feed_dict, sync)
 
+    def anneal(self, lik_scales, log_weights, ends=True, feed_dict=None):
+        """len(lik_scales) transitions, the i-th with the likelihood term of
+        a native plan's joint multiplied by lik_scales[i] (AIS temperatures,
+        evaluation.py:101-103), accumulating the importance log-weights
+        (evaluation.py:150-163) in `log_weights` -- the annealing loop of
+        AIS.run from one call (zshmc_hmc_model_run)."""
+        self._hmc._run_many(len(lik_scales), feed_dict, False,
+                            lik_scales=[float(v) for v in lik_scales],
+                            ais=(log_weights, bool(ends)))
+
 
 class HMC(object):
     """Hamiltonian Monte Carlo with dual-averaging step-size adaptation and
@@ -479,38 +489,64 @@ class HMC(object):
 
     # -- many transitions, one call where nothing needs the host ----------
     def _block_length(self, n_left, feed_dict):
-        """How many of the next transitions can run as one block, and the
-        dual-averaging update each of them owes (ZSHMC_PEND_*)."""
+        """How many of the next transitions can run as one block (ONE call
+        into libzshmc.so), the dual-averaging update each of them owes
+        (ZSHMC_PEND_*), and whether the mass adapts inside the block."""
         plan = self._plan
         if n_left < 2 or not getattr(plan, 'can_run_block', False):
-            return 0, None
+            return 0, None, False
         sh = self.sharding
         if sh is not None and sh.active and sh.backend != 'rccl':
-            return 0, None              # the collective is not ours to enqueue
+            return 0, None, False       # the collective is not ours to enqueue
         t = self.t + 1
+        mass_in_block = False
         if self.adapt_mass is not None:
+            if t <= self.mass_collect_iters:
+                return 0, None, False   # ones as mass / a search lies ahead
             if _flag_value(self.adapt_mass, feed_dict, 'adapt_mass'):
-                return 0, None          # column statistics, mass update
-            use_ones = t < self.mass_collect_iters
-            if use_ones or plan._mass_ones is not False:
-                return 0, None          # the mass buffer has to be (re)made
+                if not getattr(plan, 'block_adapts_mass', False):
+                    return 0, None, False   # column statistics, mass update
+                mass_in_block = True
+            elif plan._mass_ones is not False:
+                return 0, None, False   # the mass buffer has to be (re)made
         kind = _capi.PEND_NONE
         if self.adapt_step_size is not None:
             if t == 1 or t <= self.mass_collect_iters:
-                return 0, None          # a step-size search lies ahead
+                return 0, None, False   # a step-size search lies ahead
             if _flag_value(self.adapt_step_size, feed_dict, 'adapt_step_size'):
                 kind = _capi.PEND_ADAPT
+            elif not getattr(plan, 'can_skip_acc', False):
+                kind = _capi.PEND_HOLD  # (this plan runs the HOLD update as
+                #                         its own launch every time)
             elif self._nonadaptive_streak < 2:
-                return 0, None          # HOLD updates until the fixed point
-        return n_left, kind
+                return 0, None, False   # HOLD updates until the fixed point
+        return n_left, kind, mass_in_block
 
-    def _run_many(self, n, feed_dict, sync):
+    def _run_many(self, n, feed_dict, sync, lik_scales=None, ais=None):
+        """`lik_scales` (one per transition) / `ais` = (log-weight buffer,
+        the run ends with the last temperature): AIS.run's annealing loop on
+        a native plan (zshmc_hmc_model_run's lik_scale_host /
+        ais_log_weights)."""
         plan = self._plan
         done = 0
         while done < n:
-            k, kind = self._block_length(n - done, feed_dict)
+            k, kind, mass = self._block_length(n - done, feed_dict)
             if k < 2:
-                self._run(feed_dict, sync=False)
+                if lik_scales is not None:
+                    saved = plan.lik_scale
+                    plan.lik_scale = (lambda v: (lambda: v))(
+                        float(lik_scales[done]))
+                    try:
+                        self._run(feed_dict, sync=False)
+                    finally:
+                        plan.lik_scale = saved
+                else:
+                    self._run(feed_dict, sync=False)
+                if ais is not None:
+                    log_w, ends = ais
+                    log_w += self.hmc_info.orig_log_prob.reshape(log_w.shape)
+                    if not (ends and done == n - 1):
+                        log_w -= self.hmc_info.log_prob.reshape(log_w.shape)
                 done += 1
                 continue
             bind_feed(feed_dict, plan.device)
@@ -519,8 +555,17 @@ class HMC(object):
             self.last_init = False
             if kind == _capi.PEND_ADAPT:
                 self._nonadaptive_streak = 0
+            elif kind == _capi.PEND_HOLD:
+                self._nonadaptive_streak += k
+            extra = {}
+            if mass:
+                extra['adapt_mass'] = True
+            if lik_scales is not None:
+                extra['lik_scales'] = lik_scales[done:done + k]
+            if ais is not None:
+                extra['ais'] = (ais[0], ais[1] and done + k == n)
             plan.run_block(self.t + 1, k, kind, _capi.current_stream(),
-                           self.sharding)
+                           self.sharding, **extra)
             self.t += k
             self._pending_check = True
             done += k
@@ -1628,6 +1673,119 @@ class _DenseLikelihoodPlan(_PlanBase):
                    self.kin_new.data_ptr(), self.n_chains, self.chain_offset,
                    self.hmc.seed, t & 0xFFFFFFFF, None, None, None, None, None,
                    self.acc_sum.data_ptr(), self.flags.data_ptr(), stream)
+
+    # -- n transitions from ONE call (csrc/hmc_model_run.hip) ------------------
+    can_run_block = True
+    block_adapts_mass = True
+
+    def _descriptor(self):
+        """zshmc_model_plan of the current buffers (rebuilt per block: the
+        model's tensors may have been re-fed since the last one)."""
+        hmc, c = self.hmc, _capi
+        if len(self.q) > c.MAX_LATENTS:
+            return None
+        d = c.ModelPlan()
+        d.kind = c.PLAN_KINDS[self.kind]
+        d.n_latents, d.n_leapfrogs = len(self.q), hmc.n_leapfrogs
+        d.softmax, d.segmented = int(self.softmax), int(self.segmented)
+        d.use_mass = int(self.use_mass)
+        d.n_splits = int(self.splits)
+        d.n_classes = int(getattr(self, 'n_classes', 0))
+        for k, qk in enumerate(self.q_rows):
+            d.latent[k] = qk.data_ptr()
+            d.latent_size[k] = self.n_data[k]
+            d.latent_offset[k] = self.offsets[k]
+            if hmc.adapt_mass is not None:
+                d.latent_mass[k] = self.mass[k].data_ptr()
+                d.ewmv_mean[k] = self.ewmv_mean[k].data_ptr()
+                d.ewmv_var[k] = self.ewmv_var[k].data_ptr()
+                d.colsum[k] = self.colsum[k].data_ptr()
+        d.q_new, d.p = self.q_new.data_ptr(), self.p.data_ptr()
+        d.n_chains, d.n_total, d.ld = self.n_chains, self.n_total, self.ld
+        d.operand = c.ptr(self.operand)
+        d.grad, d.ll = self.grad.data_ptr(), self.ll.data_ptr()
+        d.lik_rows, d.width = self.lik_rows, self.width
+        d.split_ws = c.ptr(self._ws)
+        if self.segmented:
+            d.seg_len, d.groups = self.seg_len, self.stride
+            d.seg_ws = self.seg_ws.data_ptr()
+        if self.kind == 'gathered_dot':
+            d.inner, d.n_inner = self.other.data_ptr(), self.n_other
+            d.obs, d.obs_rows = self.obs.data_ptr(), self.obs_rows
+            d.gd_latent_is_u = int(self.side == 'u')
+            d.gd_idx_latent = self.idx_lat.data_ptr()
+            d.gd_idx_other = self.idx_other.data_ptr()
+            d.gd_seg, d.gd_order = self.seg.data_ptr(), self.order.data_ptr()
+            d.gd_n_latent, d.gd_n_pairs = self.n_lat, self.n_pairs
+            d.gd_n_dim, d.gd_logstd = self.n_dim, self.lik_logstd
+            d.gd_lp_const = self.lp_const.data_ptr()
+            d.gd_g_pairs = self.g_pairs.data_ptr()
+        else:
+            d.inner, d.n_inner = self.inner.data_ptr(), self.inner.shape[0]
+            d.obs = self.obs.data_ptr()
+            if self.kind == 'mixture_multinomial':
+                d.obs_rows, d.obs_stride = self.obs.shape[0], self.obs_stride
+        d.prior_mean, d.mean_rows = self.prior_mean.data_ptr(), self.mean_rows
+        d.prior_logstd = self.prior_logstd.data_ptr()
+        d.logstd_rows = self.logstd_rows
+        if hmc.adapt_mass is not None:
+            d.mass = self.mass_pack.data_ptr()
+            d.comm_buf = self.comm_buf.data_ptr()
+            d.comm_words = self.comm_buf.numel()
+            d.mass_ws = self.mass_ws.data_ptr()
+        d.lp_old, d.lp_new = self.lp_old.data_ptr(), self.lp_new.data_ptr()
+        d.kin_old, d.kin_new = self.kin_old.data_ptr(), self.kin_new.data_ptr()
+        d.accept = self.accept.data_ptr()
+        d.acceptance_rate = self.acceptance_rate.data_ptr()
+        d.orig_hamiltonian = self.orig_hamiltonian.data_ptr()
+        d.hamiltonian = self.hamiltonian.data_ptr()
+        d.log_prob = self.log_prob.data_ptr()
+        d.acc_sum, d.flags = self.acc_sum.data_ptr(), self.flags.data_ptr()
+        d.state = self.state.data_ptr()
+        d.chain_offset, d.n_chains_global = self.chain_offset, \
+            self.n_chains_global
+        d.seed = hmc.seed
+        d.delta, d.gamma = hmc.target_acceptance_rate, hmc.gamma
+        d.t0, d.kappa = hmc.t0, hmc.kappa
+        d.mu = 10.0 * hmc._init_step_size_value            # hmc.py:79 (sic)
+        d.mass_decay = hmc.mass_decay
+        return d
+
+    def run_block(self, t_first, n, kind, stream, sharding, adapt_mass=False,
+                  lik_scales=None, ais=None):
+        """`n` transitions with the same feeds and flags -- no step-size
+        search, the mass at 1 / var -- from one call into libzshmc.so; with
+        `adapt_mass` every one of them updates the mass from the column sums
+        of its start state and leaves those of its end state."""
+        sharded = sharding is not None and sharding.active
+        if adapt_mass and not self._colstats_fresh():
+            self.compute_colstats(stream)
+            if sharded:
+                sharding.all_reduce_sum(self.comm_buf[_capi.STATS_WORDS:])
+        self._search_cache = None
+        d = self._descriptor()
+        scales = None
+        if lik_scales is not None:
+            scales = (ctypes.c_float * n)(*[float(v) for v in lik_scales])
+        elif float(self.lik_scale()) != 1.0:
+            scales = (ctypes.c_float * n)(*([float(self.lik_scale())] * n))
+        log_w, ends = (None, False) if ais is None else ais
+        if log_w is not None and not (
+                log_w.is_contiguous() and log_w.dtype == torch.float32 and
+                log_w.numel() == self.n_chains):
+            raise ValueError("annealing: log_weights must be a contiguous "
+                             "float32 tensor with one entry per chain")
+        _capi.call('zshmc_hmc_model_run', ctypes.byref(d),
+                   t_first & 0xFFFFFFFF, n, kind, int(bool(adapt_mass)),
+                   scales, _capi.ptr(log_w), int(bool(ends)),
+                   sharding._comm if sharded else None, stream)
+        self.last_t = t_first + n - 1
+        self.stats_local = False
+        if adapt_mass:
+            self._mark_colstats()
+            self._mass_ones = False
+        elif self.colsum_state in ('fresh', 'parts'):
+            self.colsum_state = 'dirty'
 
     # -- one transition --------------------------------------------------------
     def transition(self, t, eps_host, stream, update=None,
