@@ -555,13 +555,17 @@ def packed_design(blocks, n_rows, device, width=None):
 def _row_splits(n_blocks_rows, n_inner, device, width=256):
     """Fewer chain blocks (64 rows; 32 for the wide kernel) than compute
     units: cut the inner (data row / vocabulary) range so that about two
-    workgroups land on every CU, at least 512 inner rows per slice."""
+    workgroups land on every CU, at least 256 inner rows per slice, at most
+    32 slices.  (Round 4, the E-step of lntm_mcem.py:157-182 -- 100 documents
+    x 100 topics x 12 419 words, two chain blocks: 16 slices of >= 512 rows
+    1 788 us per L = 20 transition, 32 of >= 256 rows 1 232 us, 64 of >= 128
+    rows 1 213 us; profiles/r04e_row_splits_ab.txt.)"""
     block = _chain_block(width)
     n_wg = (n_blocks_rows + block - 1) // block
     cus = torch.cuda.get_device_properties(device).multi_processor_count
     if n_wg >= cus:
         return 1
-    return max(1, min(16, (2 * cus) // n_wg, (n_inner + 511) // 512))
+    return max(1, min(32, (2 * cus) // n_wg, (n_inner + 255) // 256))
 
 
 class LinearBernoulliLogLik(_Function):
