@@ -595,7 +595,10 @@ int zshmc_model_kick_drift_seg(
  * {64, 128, 256, 512, 1024} (zero-pad otherwise; up to 256: 64-chain blocks
  * with W in registers, csrc/linear_bernoulli.hip; 512 and 1024: 32-chain
  * blocks whose four waves split the features,
- * csrc/linear_bernoulli_wide.hip); grad_w may be NULL (16-byte aligned).
+ * csrc/linear_bernoulli_wide.hip); grad_w may be NULL (16-byte aligned), or
+ * log_lik may be (ABI 0.4.0: gradient only -- what the interior evaluations
+ * of a leapfrog trajectory need, hmc.py:348-372; the element-wise stage then
+ * skips the log and the kernel is 2-4 % faster), not both.
  * n_splits > 1 cuts the n_rows range into that many slices per chain block
  * (for chain counts that would otherwise leave compute units idle); the
  * partial sums go to `workspace` (n_splits * n_chains * (n_features + 1)

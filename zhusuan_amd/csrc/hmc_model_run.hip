@@ -44,22 +44,26 @@ __global__ void ais_accumulate_kernel(float* __restrict__ log_w,
     if (_rc != ZSHMC_OK) return _rc; \
   } while (0)
 
-int likelihood(const zshmc_model_plan& m, const float* q, void* s) {
+// want_ll = false: the gradient alone (the interior evaluations of a
+// trajectory; the MFMA kernels then skip the log-likelihood terms)
+int likelihood(const zshmc_model_plan& m, const float* q, bool want_ll,
+               void* s) {
   const float* w = m.operand ? m.operand : q;
   float* ws = m.n_splits > 1 ? m.split_ws : nullptr;
+  float* ll = want_ll ? m.ll : nullptr;
   switch (m.kind) {
     case ZSHMC_PLAN_LINEAR_BERNOULLI:
       return zshmc_linear_bernoulli_log_lik(w, m.inner, m.obs, m.n_chains,
-                                            m.n_inner, m.width, m.ll, m.grad,
+                                            m.n_inner, m.width, ll, m.grad,
                                             m.n_splits, ws, s);
     case ZSHMC_PLAN_MIXTURE_MULTINOMIAL:
       return zshmc_linear_multinomial_log_lik(
           w, m.inner, m.obs, m.obs_rows, m.obs_stride, m.n_chains, m.n_inner,
-          m.width, m.ll, m.grad, m.n_splits, ws, s);
+          m.width, ll, m.grad, m.n_splits, ws, s);
     case ZSHMC_PLAN_LINEAR_CATEGORICAL:
       return zshmc_linear_categorical_log_lik(
           w, m.inner, m.obs, m.lik_rows, m.n_inner, m.width, m.n_classes,
-          (int)m.groups, m.ll, m.grad, m.n_splits, ws, s);
+          (int)m.groups, ll, m.grad, m.n_splits, ws, s);
     case ZSHMC_PLAN_GATHERED_DOT: {
       const bool lat_u = m.gd_latent_is_u != 0;
       ZS_TRY(zshmc_gather_dot_normal_lik(
@@ -114,7 +118,7 @@ int transition(const zshmc_model_plan& m, uint32_t t, float lik_scale,
                                m.seed, t, (uint32_t)k, m.kin_old, s));
   // operand(q), then likelihood + gradient at q
   if (m.operand) ZS_TRY(step(m, false, 0.f, 0.f, lik_scale, nullptr, nullptr, s));
-  ZS_TRY(likelihood(m, m.q_new, s));
+  ZS_TRY(likelihood(m, m.q_new, true, s));
   ZS_TRY(zshmc_zero(m.kin_new, 4 * m.n_chains, s));
   // trip 0: zero-length drift, half kick (hmc.py:352-364); the drift of trip
   // i+1 rides behind the kick of trip i
@@ -126,8 +130,8 @@ int transition(const zshmc_model_plan& m, uint32_t t, float lik_scale,
                                     reinterpret_cast<hipStream_t>(s)),
                      "hipMemcpyAsync"));
   for (int i = 1; i <= L; ++i) {
-    ZS_TRY(likelihood(m, m.q_new, s));
     const bool last = i == L;
+    ZS_TRY(likelihood(m, m.q_new, last, s));
     ZS_TRY(step(m, true, last ? 0.5f : 1.f, last ? 0.f : 1.f, lik_scale,
                 last ? m.lp_new : nullptr, last ? m.kin_new : nullptr, s));
   }

@@ -67,6 +67,7 @@ __device__ __forceinline__ CatLane cat_lane(int column, int n_classes,
 // (a float holding 0 .. n_classes-1): returns the residual
 // [k == label] - softmax_k and adds the row's log-likelihood term to `lp` on
 // the label's lane.  Every lane of the wave must call it (cross-lane ops).
+template <bool LL = true>
 __device__ __forceinline__ float categorical_residual(float sv, float label,
                                                       const CatLane& c,
                                                       bool valid, float& lp) {
@@ -78,7 +79,7 @@ __device__ __forceinline__ float categorical_residual(float sv, float label,
   const float z = lane_group_allreduce<false>(e, c.gl);   // in [1, G]
   const float p = e * __builtin_amdgcn_rcpf(z);
   const bool hit = valid && label == c.kcls;
-  lp += hit ? d - 0.6931471805599453f * __builtin_amdgcn_logf(z) : 0.f;
+  if (LL) lp += hit ? d - 0.6931471805599453f * __builtin_amdgcn_logf(z) : 0.f;
   return (valid && c.cls_on) ? (hit ? 1.0f : 0.f) - p : 0.f;
 }
 

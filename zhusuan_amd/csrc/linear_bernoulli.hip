@@ -22,6 +22,8 @@
 // 4*N*D*C flop per call.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "lb_ops.h"
 
@@ -141,7 +143,12 @@ __device__ __forceinline__ void lds_dma_row(const float* src, uint32_t dst,
 #ifndef ZS_LB_MINW  // min waves per SIMD: D = 64 fits three workgroups per CU
 #define ZS_LB_MINW(D) ((D) == 64 ? 3 : 1)
 #endif
-template <int D, bool GRAD, int OP>
+// LL = false (GRAD only): the log-likelihood terms are not formed -- the L - 1
+// interior evaluations of a leapfrog trajectory need the gradient alone
+// (hmc.py:348-372; the log-joint is read at its two ends, :46-61), and the
+// log (one of three transcendentals) + 5 VALU per element are ~40 % of the
+// element-wise stage a lone wave per SIMD cannot hide under its own MFMAs.
+template <int D, bool GRAD, int OP, bool LL = true>
 __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2(
     const float* __restrict__ W, const float* __restrict__ X,
     const float* __restrict__ y, const float* __restrict__ yc,
@@ -267,7 +274,7 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2
                               ? tile_begin + tiles_per_split
                               : n_tiles_all;
   if (gridDim.y > 1) {
-    ll += (int64_t)blockIdx.y * C;
+    if (LL) ll += (int64_t)blockIdx.y * C;
     if (GRAD) gW += (int64_t)blockIdx.y * C * ldw;
   }
   {
@@ -335,7 +342,11 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2
     }
   };
   if (OP == 1) load_counts(tile_begin, xcnt);
-  for (int64_t tile = tile_begin; tile < n_tiles; ++tile) {
+  // One tile.  FULL: all 64 rows of the tile exist (every tile but possibly
+  // the last of the row range): the row-validity compares and selects of the
+  // element-wise stage are compiled out.
+  auto tile_body = [&](auto full_tag, int64_t tile) {
+    constexpr bool FULL = decltype(full_tag)::value;
     const int buf = (int)((tile - tile_begin) & 1);       // sY slot
     const int xbuf = kBuf == 2 ? buf : 0;                 // sX slot
     const float* __restrict__ xb = sX + xbuf * kRows * LD;
@@ -397,29 +408,37 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2
                                                            : kRows);
     auto residual = [&](int r) {
       const int nl = b * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      const bool valid = nl < rows_left;
+      const bool valid = FULL || nl < rows_left;
       const float sv = S[r];
       if (OP == 0) {
         const float yv = sY[buf * kRows + nl];
         const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * fabsf(sv));
         const float t1 = 1.0f + e;
-        const float inv = __builtin_amdgcn_rcpf(t1);
-        const float sig = sv >= 0.f ? inv : 1.0f - inv;
-        const float lp = sv * yv - fmaxf(sv, 0.f) -
-                         0.6931471805599453f * __builtin_amdgcn_logf(t1);
+        const float inv = __builtin_amdgcn_rcpf(t1);  // sigmoid(|l|), >= 1/2
+        // sigmoid(l) = 1/2 + copysign(inv - 1/2, l): one v_bfi instead of a
+        // compare + select
+        const float sig = 0.5f + __builtin_copysignf(inv - 0.5f, sv);
         S[r] = valid ? yv - sig : 0.f;
-        ll_tile += valid ? lp : 0.f;
+        if (LL) {
+          const float lp = sv * yv - fmaxf(sv, 0.f) -
+                           0.6931471805599453f * __builtin_amdgcn_logf(t1);
+          ll_tile += valid ? lp : 0.f;
+        }
       } else if (OP == 2) {
-        S[r] = categorical_residual(sv, sY[buf * kRows + nl], cat, valid,
-                                    ll_tile);
+        S[r] = categorical_residual<LL>(sv, sY[buf * kRows + nl], cat, valid,
+                                        ll_tile);
       } else {
         // sum_v x_v log((theta.phi)_v) and d/d(theta.phi) = x / (theta.phi);
-        // x = 0 contributes nothing (also where the product underflows)
+        // x = 0 contributes nothing (also where the product underflows) --
+        // and the counts of rows past N are loaded as zeros
         const float xv = xcnt[r];
-        const bool on = valid && xv != 0.f;
-        const float lp = xv * (0.6931471805599453f * __builtin_amdgcn_logf(sv));
+        const bool on = xv != 0.f;
         S[r] = on ? xv * __builtin_amdgcn_rcpf(sv) : 0.f;
-        ll_tile += on ? lp : 0.f;
+        if (LL) {
+          const float lp =
+              xv * (0.6931471805599453f * __builtin_amdgcn_logf(sv));
+          ll_tile += on ? lp : 0.f;
+        }
       }
     };
     // B operand of phase 3: X[row][b*HALF + lo*FB .. +FB-1]
@@ -589,9 +608,24 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2
       for (int r = 0; r < 16; ++r) xcnt[r] = xnext[r];
     }
     __syncthreads();  // tile+1 published; this buffer free for tile+2
-    ll_lane += (double)ll_tile;
-    ll_tile = 0.f;
+    if (LL) {
+      ll_lane += (double)ll_tile;
+      ll_tile = 0.f;
+    }
     ZS_LB_MARK(5)  // DMA wait + barrier 2
+  };
+  // (two copies of the tile only in the gradient-only instantiations -- the
+  // ones a trajectory spends its time in: with the log-likelihood terms alive
+  // as well the second copy costs D = 128 its second workgroup per CU and
+  // D = 64 eleven spilled registers)
+  for (int64_t tile = tile_begin; tile < n_tiles; ++tile) {
+    if constexpr (!LL) {
+      if ((tile + 1) * kRows <= N) {
+        tile_body(std::true_type{}, tile);
+        continue;
+      }
+    }
+    tile_body(std::false_type{}, tile);
   }
 #ifdef ZS_LB_TIMING
   if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && GRAD) {
@@ -618,15 +652,17 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2
   }
   // ll of chain a*32+lo: this lane's 16 rows per tile + lane^32's + the
   // sibling wave's 32 rows (through the exchange slots, now idle)
-  const double ll_half = ll_lane + __shfl_xor(ll_lane, 32, 64);
-  double* __restrict__ sRd = reinterpret_cast<double*>(sR);  // 64 doubles
-  if (hi == 0) sRd[wave * 32 + lo] = ll_half;
-  __syncthreads();
-  if (b == 0 && hi == 0) {
-    const int pos = a * 32 + lo;
-    if (pos < n_valid)
-      ll[row_base + pos * row_stride] =
-          (float)(ll_half + sRd[(wave ^ 1) * 32 + lo]);
+  if (LL) {
+    const double ll_half = ll_lane + __shfl_xor(ll_lane, 32, 64);
+    double* __restrict__ sRd = reinterpret_cast<double*>(sR);  // 64 doubles
+    if (hi == 0) sRd[wave * 32 + lo] = ll_half;
+    __syncthreads();
+    if (b == 0 && hi == 0) {
+      const int pos = a * 32 + lo;
+      if (pos < n_valid)
+        ll[row_base + pos * row_stride] =
+            (float)(ll_half + sRd[(wave ^ 1) * 32 + lo]);
+    }
   }
 }
 
@@ -640,6 +676,7 @@ __global__ __launch_bounds__(256) void lb_reduce_splits_kernel(
        i += (int64_t)gridDim.x * blockDim.x) {
     float acc = 0.f;
     if (i < n_ll) {
+      if (!ll) continue;
       for (int s = 0; s < S; ++s) acc += ws[(int64_t)s * C + i];
       ll[i] = acc;
     } else {
@@ -669,6 +706,11 @@ static int launch_v2(const float* W, const float* X, const float* y,
       e = hipFuncSetAttribute(
           reinterpret_cast<const void*>(linear_bernoulli_kernel_v2<D, false, OP>),
           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(
+          reinterpret_cast<const void*>(
+              linear_bernoulli_kernel_v2<D, true, OP, false>),
+          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(LDS)");
     attr2 = true;
   }
@@ -680,7 +722,11 @@ static int launch_v2(const float* W, const float* X, const float* y,
   float* ll_out = S > 1 ? workspace : ll;
   float* g_out = S > 1 ? (gW ? workspace + (int64_t)S * C : nullptr) : gW;
   const dim3 grid(gx, S);
-  if (gW)
+  if (gW && !ll)
+    hipLaunchKernelGGL((linear_bernoulli_kernel_v2<D, true, OP, false>), grid,
+                       dim3(256), lds, s, W, X, y, yc, yc_rows, ldy, C, N, ldw, ldx,
+                       ll_out, g_out, doc_major, n_classes, cls_log2);
+  else if (gW)
     hipLaunchKernelGGL((linear_bernoulli_kernel_v2<D, true, OP>), grid,
                        dim3(256), lds, s, W, X, y, yc, yc_rows, ldy, C, N, ldw, ldx,
                        ll_out, g_out, doc_major, n_classes, cls_log2);
@@ -727,7 +773,8 @@ extern "C" int zshmc_linear_bernoulli_log_lik(const float* W, const float* X,
                                               int n_splits, float* workspace,
                                               void* stream) {
   if (n_chains == 0) return ZSHMC_OK;
-  ZS_REQUIRE(W && X && y && log_lik, "zshmc_linear_bernoulli_log_lik: null pointer");
+  ZS_REQUIRE(W && X && y && (log_lik || grad_w),
+             "zshmc_linear_bernoulli_log_lik: null pointer");
   ZS_REQUIRE(n_chains > 0 && n_rows > 0,
              "zshmc_linear_bernoulli_log_lik: bad shape");
   ZS_REQUIRE(n_features == 64 || n_features == 128 || n_features == 256 ||
@@ -770,7 +817,7 @@ extern "C" int zshmc_linear_categorical_log_lik(
     float* log_lik, float* grad_w, int n_splits, float* workspace,
     void* stream) {
   if (n_cols == 0) return ZSHMC_OK;
-  ZS_REQUIRE(W && X && labels && log_lik,
+  ZS_REQUIRE(W && X && labels && (log_lik || grad_w),
              "zshmc_linear_categorical_log_lik: null pointer");
   int cls_log2 = 0;
   while ((1 << cls_log2) < class_stride) ++cls_log2;
@@ -826,7 +873,7 @@ extern "C" int zshmc_linear_multinomial_log_lik(const float* theta,
                                                 float* grad_theta, int n_splits,
                                                 float* workspace, void* stream) {
   if (n_rows == 0) return ZSHMC_OK;
-  ZS_REQUIRE(theta && phi_t && counts && log_lik,
+  ZS_REQUIRE(theta && phi_t && counts && (log_lik || grad_theta),
              "zshmc_linear_multinomial_log_lik: null pointer");
   ZS_REQUIRE(n_rows > 0 && n_vocab > 0 && count_rows > 0 &&
                  n_rows % count_rows == 0 && count_stride >= n_vocab,

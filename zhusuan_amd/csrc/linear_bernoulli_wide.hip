@@ -118,7 +118,9 @@ __device__ __forceinline__ void wide_dma_row(const float* src, uint32_t dst,
 // over the chain rows; doc_major: a workgroup's 32 rows are 32 CHAINS OF ONE
 // DOCUMENT of the topic model's [n_chains, n_docs] chain axes, so that its
 // counts are one row of the matrix).
-template <int D, bool GRAD, int OP>
+// LL = false (GRAD only): no log-likelihood terms, as in
+// csrc/linear_bernoulli.hip -- the interior evaluations of a trajectory.
+template <int D, bool GRAD, int OP, bool LL = true>
 __global__ __launch_bounds__(256, D == 256 ? 2 : 1) void linear_bernoulli_wide_kernel(
     const float* __restrict__ W, const float* __restrict__ X,
     const float* __restrict__ y, const float* __restrict__ yc, int64_t yc_rows,
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(256, D == 256 ? 2 : 1) void linear_bernoulli_wide_k
                               ? tile_begin + tiles_per_split
                               : n_tiles_all;
   if (gridDim.y > 1) {
-    ll += (int64_t)blockIdx.y * C;
+    if (LL) ll += (int64_t)blockIdx.y * C;
     if (GRAD) gW += (int64_t)blockIdx.y * C * ldw;
   }
   if (tile_begin < n_tiles) {
@@ -350,26 +352,31 @@ __global__ __launch_bounds__(256, D == 256 ? 2 : 1) void linear_bernoulli_wide_k
               __builtin_amdgcn_exp2f(-1.4426950408889634f * fabsf(sv));
           const float t1 = 1.0f + e;
           const float inv = __builtin_amdgcn_rcpf(t1);
-          const float sig = sv >= 0.f ? inv : 1.0f - inv;
-          const float lp = sv * yv - fmaxf(sv, 0.f) -
-                           0.6931471805599453f * __builtin_amdgcn_logf(t1);
+          const float sig = 0.5f + __builtin_copysignf(inv - 0.5f, sv);
           res[j] = valid ? yv - sig : 0.f;
-          ll_tile += valid ? lp : 0.f;
+          if (LL) {
+            const float lp = sv * yv - fmaxf(sv, 0.f) -
+                             0.6931471805599453f * __builtin_amdgcn_logf(t1);
+            ll_tile += valid ? lp : 0.f;
+          }
         } else if (OP == 2) {
-          res[j] = categorical_residual(sv, sY[buf * kWR + nl], cat, valid,
-                                        ll_tile);
+          res[j] = categorical_residual<LL>(sv, sY[buf * kWR + nl], cat, valid,
+                                            ll_tile);
         } else {
           // sum_v x_v log((theta.phi)_v) and d/d(theta.phi) = x / (theta.phi)
           // (multivariate.py:435-443, normalize_logits = False); x = 0
           // contributes nothing (also where the product underflows)
           const float xv = xcnt[j];
           const bool on = valid && xv != 0.f;
-          const float lp = xv * (0.6931471805599453f * __builtin_amdgcn_logf(sv));
           res[j] = on ? xv * __builtin_amdgcn_rcpf(sv) : 0.f;
-          ll_tile += on ? lp : 0.f;
+          if (LL) {
+            const float lp =
+                xv * (0.6931471805599453f * __builtin_amdgcn_logf(sv));
+            ll_tile += on ? lp : 0.f;
+          }
         }
       }
-      ll_lane += (double)ll_tile;
+      if (LL) ll_lane += (double)ll_tile;
       if (GRAD) *reinterpret_cast<w4*>(sR + (f * 64 + lane) * 4) = res;
     }
     ZS_LBW_MARK(2)  // sum + residual
@@ -479,14 +486,16 @@ __global__ __launch_bounds__(256, D == 256 ? 2 : 1) void linear_bernoulli_wide_k
   }
   // ll of chain lo: this lane's 4 rows per tile + lane^32's + the other three
   // waves' (through the exchange area, now idle)
-  const double ll_half = ll_lane + __shfl_xor(ll_lane, 32, 64);
-  __syncthreads();
-  double* __restrict__ sLd = reinterpret_cast<double*>(sP);  // [4][32]
-  if (hi == 0) sLd[f * 32 + lo] = ll_half;
-  __syncthreads();
-  if (f == 0 && hi == 0 && lo < n_valid)
-    ll[row_base + lo * row_stride] =
-        (float)(((sLd[lo] + sLd[32 + lo]) + sLd[64 + lo]) + sLd[96 + lo]);
+  if (LL) {
+    const double ll_half = ll_lane + __shfl_xor(ll_lane, 32, 64);
+    __syncthreads();
+    double* __restrict__ sLd = reinterpret_cast<double*>(sP);  // [4][32]
+    if (hi == 0) sLd[f * 32 + lo] = ll_half;
+    __syncthreads();
+    if (f == 0 && hi == 0 && lo < n_valid)
+      ll[row_base + lo * row_stride] =
+          (float)(((sLd[lo] + sLd[32 + lo]) + sLd[64 + lo]) + sLd[96 + lo]);
+  }
 }
 
 // out[c(, f)] = sum over the S row-range partials written by a split launch
@@ -499,6 +508,7 @@ __global__ __launch_bounds__(256) void lb_wide_reduce_splits_kernel(
        i += (int64_t)gridDim.x * blockDim.x) {
     float acc = 0.f;
     if (i < n_ll) {
+      if (!ll) continue;
       for (int s = 0; s < S; ++s) acc += ws[(int64_t)s * C + i];
       ll[i] = acc;
     } else {
@@ -529,6 +539,11 @@ static int launch_wide(const float* W, const float* X, const float* y,
           reinterpret_cast<const void*>(
               linear_bernoulli_wide_kernel<D, false, OP>),
           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(
+          reinterpret_cast<const void*>(
+              linear_bernoulli_wide_kernel<D, true, OP, false>),
+          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(LDS)");
     attr = true;
   }
@@ -539,7 +554,12 @@ static int launch_wide(const float* W, const float* X, const float* y,
   const int64_t gx = doc_major ? ((C / yc_rows + kWC - 1) / kWC) * yc_rows
                                : (C + kWC - 1) / kWC;
   const dim3 grid((unsigned)gx, S);
-  if (gW)
+  if (gW && !ll)
+    hipLaunchKernelGGL((linear_bernoulli_wide_kernel<D, true, OP, false>), grid,
+                       dim3(256), lds, s, W, X, y, yc, yc_rows, ldy, C, N,
+                       (int64_t)D, (int64_t)D, ll_out, g_out, doc_major, n_classes,
+                       cls_log2);
+  else if (gW)
     hipLaunchKernelGGL((linear_bernoulli_wide_kernel<D, true, OP>), grid,
                        dim3(256), lds, s, W, X, y, yc, yc_rows, ldy, C, N,
                        (int64_t)D, (int64_t)D, ll_out, g_out, doc_major, n_classes,

@@ -1521,8 +1521,12 @@ class _DenseLikelihoodPlan(_PlanBase):
                        self.accept.data_ptr(), self.n_chains, self.n_data[k],
                        stream)
 
-    def _likelihood(self, q, stream):
-        """ll[c] and d ll / d operand at the operand derived from q."""
+    def _likelihood(self, q, stream, want_ll=True):
+        """ll[c] and d ll / d operand at the operand derived from q.
+        `want_ll=False`: the gradient alone -- the interior evaluations of a
+        trajectory (hmc.py:348-372 reads the log-joint at its two ends only);
+        the MFMA kernels then skip the log-likelihood terms."""
+        ll_ptr = self.ll.data_ptr() if want_ll else None
         w = self.operand if self.operand is not None else q
         ws = self._ws if self.splits > 1 else None
         if self.kind == 'gathered_dot':
@@ -1555,20 +1559,20 @@ class _DenseLikelihoodPlan(_PlanBase):
             _capi.call('zshmc_linear_categorical_log_lik', w.data_ptr(),
                        self.inner.data_ptr(), self.obs.data_ptr(),
                        self.lik_rows, self.inner.shape[0], self.width,
-                       self.n_classes, self.stride, self.ll.data_ptr(),
+                       self.n_classes, self.stride, ll_ptr,
                        self.grad.data_ptr(), self.splits, _capi.ptr(ws),
                        stream)
         elif self.kind == 'linear_bernoulli':
             _capi.call('zshmc_linear_bernoulli_log_lik', w.data_ptr(),
                        self.inner.data_ptr(), self.obs.data_ptr(),
                        self.n_chains, self.inner.shape[0], self.width,
-                       self.ll.data_ptr(), self.grad.data_ptr(), self.splits,
+                       ll_ptr, self.grad.data_ptr(), self.splits,
                        _capi.ptr(ws), stream)
         else:
             _capi.call('zshmc_linear_multinomial_log_lik', w.data_ptr(),
                        self.inner.data_ptr(), self.obs.data_ptr(),
                        self.obs.shape[0], self.obs_stride, self.n_chains,
-                       self.inner.shape[0], self.width, self.ll.data_ptr(),
+                       self.inner.shape[0], self.width, ll_ptr,
                        self.grad.data_ptr(), self.splits, _capi.ptr(ws),
                        stream)
 
@@ -1809,8 +1813,8 @@ class _DenseLikelihoodPlan(_PlanBase):
         if L == 0:
             self.lp_new.copy_(self.lp_old)
         for i in range(1, L + 1):
-            self._likelihood(q, stream)
             last = i == L
+            self._likelihood(q, stream, want_ll=last)
             self._step(q, p, True, eps_host, 0.5 if last else 1.0,
                        0.0 if last else 1.0, self.lp_new if last else None,
                        self.kin_new if last else None, stream)
