@@ -498,6 +498,128 @@ def extra_wide_regression(torch, zs, dev, n_rows=65536, n_chains=8192,
     }
 
 
+def extra_softmax_regression(torch, zs, dev, n_rows=60000, n_feat=784,
+                             n_classes=10, n_chains=1024, n_leapfrogs=10,
+                             n_warm=3, n_timed=3):
+    """north_star's third likelihood: softmax regression
+    at the MNIST shape -- 10 classes x 784 features per chain, 60 000 rows --
+    written with the reference's literal `matmul(X, w, transpose_b=True)` under
+    a Categorical (univariate.py:496-548): the native 'linear_categorical'
+    plan -- the two-GEMM fp32-MFMA kernel with the class softmax over
+    accumulator lanes (csrc/lb_ops.h; (chain, class) pairs as its rows, class
+    stride 16, padded width 1 024) + csrc/hmc_model_seg.hip."""
+    g = torch.Generator(device=dev).manual_seed(0)
+    X = torch.randn(n_rows, n_feat, device=dev, generator=g)
+    w_true = torch.randn(n_classes, n_feat, device=dev, generator=g)
+    y = torch.argmax(X @ w_true.t() / n_feat ** 0.5 - torch.log(-torch.log(
+        torch.rand(n_rows, n_classes, device=dev, generator=g))), -1).to(
+            torch.int32)
+    zero = torch.zeros(n_classes, n_feat, device=dev)
+
+    @zs.meta_bayesian_net()
+    def model():
+        bn = zs.BayesianNet()
+        w = bn.normal('w', zero, std=1., n_samples=n_chains, group_ndims=2)
+        bn.categorical('y', X.unsqueeze(0) @ w.tensor.transpose(-1, -2),
+                       group_ndims=1)
+        return bn
+    w = (w_true / n_feat ** 0.5).unsqueeze(0).repeat(n_chains, 1,
+                                                     1).contiguous()
+    eps = 0.5 / n_rows ** 0.5 / (n_feat * n_classes) ** 0.25
+    hmc = zs.HMC(step_size=eps, n_leapfrogs=n_leapfrogs, seed=6)
+    op, info = hmc.sample(model(), {'y': y}, {'w': w})
+    elapsed, kern_ms, acc = _time_transitions(
+        torch, hmc, op, info, {}, n_warm, n_timed, torch.cuda.synchronize)
+    ms = elapsed / n_timed * 1e3
+    plan = hmc._plan
+    flop_eval = 4.0 * n_rows * plan.width * plan.lik_rows
+    useful = (n_feat / plan.width) * (n_classes / plan.stride)
+    return {
+        'workload': 'beyond BASELINE.json (north_star\'s Categorical): '
+                    'softmax regression, %d classes x %d features, synthetic '
+                    '%d rows, %d chains, L=%d, literal X @ w^T, fixed step '
+                    'size %.2e' % (n_classes, n_feat, n_rows, n_chains,
+                                   n_leapfrogs, eps),
+        'plan': hmc.plan_kind, 'plan_reason': hmc.plan_reason,
+        'ms_per_step': ms, 'steps': n_timed,
+        'value': n_chains * n_leapfrogs / (ms * 1e-3),
+        'unit': 'chain-leapfrog-steps/s',
+        'mean_acceptance': acc,
+        'roofline': dict(_mfma_roofline(
+            'linear_bernoulli_wide_kernel<%d, OP=2 categorical>' % plan.width,
+            kern_ms, flop_eval, n_leapfrogs + 1, ms),
+            note='flops counted at the padded shape: width %d, class stride '
+                 '%d; useful fraction of them %.3f (%d features, %d classes)'
+                 % (plan.width, plan.stride, useful, n_feat, n_classes)),
+    }
+
+
+def extra_pmf(torch, zs, dev, n_particles=8, n_users=6040, n_items=3706,
+              n_factors=32, n_pairs=1000000, n_leapfrogs=10, n_warm=3,
+              n_timed=5):
+    """The rating model of pmf_hmc.py:19-31 at the MovieLens-1M shape (6 040
+    users x 3 706 items, 10^6 ratings, 8 particles; 32 factors): HMC over the
+    user table given the item table on the native 'gathered_dot' plan
+    (csrc/gather_dot.hip + csrc/hmc_model_seg.hip: no autograd graph).
+    HBM / L2-bound irregular access: the roofline entry is gathered bytes per
+    second of the rating-likelihood launch."""
+    g = torch.Generator(device=dev).manual_seed(0)
+    su = torch.randint(0, n_users, (n_pairs,), device=dev, generator=g,
+                       dtype=torch.int32)
+    sv = torch.randint(0, n_items, (n_pairs,), device=dev, generator=g,
+                       dtype=torch.int32)
+    r = torch.rand(n_pairs, device=dev, generator=g)
+    v = 0.3 * torch.randn(n_particles, n_items, n_factors, device=dev,
+                          generator=g)
+    zu = torch.zeros(n_users, n_factors, device=dev)
+    zv = torch.zeros(n_items, n_factors, device=dev)
+
+    @zs.meta_bayesian_net(scope='pmf', reuse_variables=True)
+    def pmf():
+        bn = zs.BayesianNet()
+        u = bn.normal('u', zu, std=1.0, n_samples=n_particles, group_ndims=1)
+        vv = bn.normal('v', zv, std=1.0, n_samples=n_particles, group_ndims=1)
+        bn.normal('r', torch.sigmoid(zs.gathered_dot(u, su, vv, sv)),
+                  std=0.25)
+        return bn
+    model = pmf()
+    model.log_joint = lambda bn: (
+        bn.cond_log_prob('u').sum(-1) + bn.cond_log_prob('v').sum(-1) +
+        bn.cond_log_prob('r').sum(-1))
+    u = 0.1 * torch.randn(n_particles, n_users, n_factors, device=dev,
+                          generator=g)
+    hmc = zs.HMC(step_size=2e-3, n_leapfrogs=n_leapfrogs, seed=7)
+    op, info = hmc.sample(model, {'r': r, 'v': v}, {'u': u})
+    elapsed, kern_ms, acc = _time_transitions(
+        torch, hmc, op, info, {}, n_warm, n_timed, torch.cuda.synchronize)
+    ms = elapsed / n_timed * 1e3
+    # rating terms + their scatter: per (particle, pair) two factor rows read
+    # twice (forward, scatter) + the residual written and read
+    gathered = n_particles * n_pairs * (3.0 * n_factors * 4 + 8 + 8)
+    return {
+        'workload': 'beyond BASELINE.json: the rating model of pmf_hmc.py at '
+                    'the MovieLens-1M shape (%d x %d, %d ratings, %d '
+                    'particles, %d factors), HMC over the user table, L=%d'
+                    % (n_users, n_items, n_pairs, n_particles, n_factors,
+                       n_leapfrogs),
+        'plan': hmc.plan_kind, 'plan_reason': hmc.plan_reason,
+        'ms_per_step': ms, 'steps': n_timed,
+        'value': n_particles * n_leapfrogs / (ms * 1e-3),
+        'unit': 'chain-leapfrog-steps/s',
+        'mean_acceptance': acc,
+        'roofline': {
+            'bound': 'hbm', 'unit': 'GB/s', 'peak': HBM_PEAK_GBPS,
+            'kernel': 'gather_dot_normal_lik_kernel + gather_dot_grad_kernel',
+            'kernel_ms': kern_ms, 'achieved': gathered / (kern_ms * 1e-3) / 1e9,
+            'frac': gathered / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            'traffic': None,
+            'note': 'gathered bytes (factor rows where they lie: the tables '
+                    'are L2 / Infinity-Cache resident, so this is a cache '
+                    'rate quoted against the HBM peak), not HBM traffic',
+        },
+    }
+
+
 def lntm_problem(torch, dev, n_docs, n_topics, n_vocab):
     """documents of ~1 000 tokens drawn from the mixture of a
     random phi (the "nips" file is not reachable offline); seed 0, so every
@@ -1296,7 +1418,8 @@ def main():
         if world == 1:
             todo = ((extra_config1, {}), (extra_config3, {}),
                     (extra_config5, {'n_chains': args.config5_chains}),
-                    (extra_wide_regression, {}))
+                    (extra_wide_regression, {}),
+                    (extra_softmax_regression, {}), (extra_pmf, {}))
         else:
             todo = ((lntm_workload, dict(
                 n_chains=args.lntm_chains_per_gpu,

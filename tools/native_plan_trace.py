@@ -1,9 +1,11 @@
 #!/usr/bin/env python
-"""Workload for tools/profile_native.sh: a few transitions of the two native
-dense-likelihood plans (BASELINE configs[2] and configs[4] as bench.py builds
-them -- the reference's literal dense spellings, tuned start -- reduced so that
-a traced run takes seconds), bracketed by marker launches (min_positive_rows_kernel) so
-that the kernel trace can be cut to the transitions alone.
+"""Workload for tools/profile_native.sh: a few transitions of the native
+plans -- BASELINE configs[2] and configs[4] as bench.py builds them (the
+reference's literal dense spellings, tuned start), and (round 4) the
+dense-logit Categorical (softmax regression) and the gathered-dot rating
+model of pmf_hmc.py -- reduced so that a traced run takes seconds, bracketed
+by marker launches (min_positive_rows_kernel) so that the kernel trace can be
+cut to the transitions alone.
   python tools/native_plan_trace.py [n_rows_config3] [n_chains_config5]"""
 import os
 import sys
@@ -61,3 +63,17 @@ print('config5 at n_chains=%d: %.2f ms/transition, kernel %.3f ms = %.1f TFLOP/s
           n_chains5, r5['ms_per_step'], r5['roofline']['kernel_ms'],
           r5['roofline']['achieved'], 100 * r5['roofline']['frac'],
           r5['roofline']['sustained_over_transition'], r5['plan']))
+_ops.clear_caches()
+torch.cuda.empty_cache()
+r6 = bench.extra_softmax_regression(torch, zs, dev, n_rows=6000, n_chains=256)
+print('config softmax regression slice: %.2f ms/transition, kernel %.3f ms = %.1f TFLOP/s '
+      '(%.1f%%), plan %s' % (r6['ms_per_step'], r6['roofline']['kernel_ms'],
+                             r6['roofline']['achieved'],
+                             100 * r6['roofline']['frac'], r6['plan']))
+_ops.clear_caches()
+torch.cuda.empty_cache()
+r7 = bench.extra_pmf(torch, zs, dev, n_pairs=200000)
+print('config pmf slice: %.2f ms/transition, rating likelihood + scatter %.3f ms = '
+      '%.0f GB/s gathered, plan %s' % (r7['ms_per_step'],
+                                       r7['roofline']['kernel_ms'],
+                                       r7['roofline']['achieved'], r7['plan']))

@@ -44,9 +44,13 @@ for f in glob.glob(os.path.join(out, tag + '_native_trace', '**', '*kernel_trace
             d = section.setdefault(key, [0, 0.0])
             d[0] += 1
             d[1] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) * 1e-3
+    names = ['config 3: dense-logit Bernoulli', 'config 5: mixture multinomial',
+             'softmax regression: dense-logit Categorical',
+             'pmf_hmc.py: gathered-dot rating model']
     for i, sec in enumerate(sections):
         lines.append('== kernels launched inside 3 transitions of native plan %d '
-                     '(config %s): name, launches, total us' % (i, '3' if i == 0 else '5'))
+                     '(%s): name, launches, total us' % (
+                         i, names[i] if i < len(names) else '?'))
         for k, (n, us) in sorted(sec.items(), key=lambda kv: -kv[1][1]):
             lines.append('  %-112s %5d %12.1f' % (k, n, us))
         # anything that is neither this library's nor the runtime's copy /

@@ -412,17 +412,24 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2
       const float sv = S[r];
       if (OP == 0) {
         const float yv = sY[buf * kRows + nl];
-        const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * fabsf(sv));
-        const float t1 = 1.0f + e;
-        const float inv = __builtin_amdgcn_rcpf(t1);  // sigmoid(|l|), >= 1/2
-        // sigmoid(l) = 1/2 + copysign(inv - 1/2, l): one v_bfi instead of a
-        // compare + select
-        const float sig = 0.5f + __builtin_copysignf(inv - 0.5f, sv);
-        S[r] = valid ? yv - sig : 0.f;
         if (LL) {
+          const float e =
+              __builtin_amdgcn_exp2f(-1.4426950408889634f * fabsf(sv));
+          const float t1 = 1.0f + e;
+          const float inv = __builtin_amdgcn_rcpf(t1);  // sigmoid(|l|) >= 1/2
+          // sigmoid(l) = 1/2 + copysign(inv - 1/2, l): one v_bfi instead of
+          // a compare + select
+          const float sig = 0.5f + __builtin_copysignf(inv - 0.5f, sv);
+          S[r] = valid ? yv - sig : 0.f;
           const float lp = sv * yv - fmaxf(sv, 0.f) -
                            0.6931471805599453f * __builtin_amdgcn_logf(t1);
           ll_tile += valid ? lp : 0.f;
+        } else {
+          // gradient only: sigmoid(l) = 1 / (1 + 2^(-l log2 e)) as it stands
+          // (l -> -inf: 1 / inf = 0; l -> +inf: 1 / 1): mul, exp, add, rcp, sub
+          const float sig = __builtin_amdgcn_rcpf(
+              1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * sv));
+          S[r] = valid ? yv - sig : 0.f;
         }
       } else if (OP == 2) {
         S[r] = categorical_residual<LL>(sv, sY[buf * kRows + nl], cat, valid,
