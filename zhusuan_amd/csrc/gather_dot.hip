@@ -131,15 +131,25 @@ __global__ __launch_bounds__(256) void gather_dot_normal_lik_kernel(
   }
 }
 
+// one workgroup per chain: thread i adds the partials i, i + 256, ... in that
+// order, then a fixed tree over the 256 threads -- the same bits every run
 __global__ __launch_bounds__(256) void gd_lik_finish_kernel(
     const float* __restrict__ partial, int64_t n_blocks,
     const float* __restrict__ lp_const, int64_t n_chains,
     float* __restrict__ log_lik) {
-  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n_chains) return;
+  __shared__ float red[256];
+  const int64_t k = blockIdx.x;
   float t = 0.f;
-  for (int64_t b = 0; b < n_blocks; ++b) t += partial[k * n_blocks + b];
-  log_lik[k] = t + (lp_const ? lp_const[k] : 0.f);
+  for (int64_t b = threadIdx.x; b < n_blocks; b += 256)
+    t += partial[k * n_blocks + b];
+  red[threadIdx.x] = t;
+  __syncthreads();
+#pragma unroll
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) log_lik[k] = red[0] + (lp_const ? lp_const[k] : 0.f);
 }
 
 static int gd_grid(int64_t groups) {
@@ -223,9 +233,8 @@ extern "C" int zshmc_gather_dot_normal_lik(
                        n_blocks);
     ZS_LAUNCH_CHECK("gather_dot_normal_lik_kernel launch");
   }
-  hipLaunchKernelGGL(gd_lik_finish_kernel,
-                     dim3((unsigned)((n_chains + 255) / 256)), dim3(256), 0, s,
-                     workspace, n_blocks, lp_const, n_chains, log_lik);
+  hipLaunchKernelGGL(gd_lik_finish_kernel, dim3((unsigned)n_chains), dim3(256),
+                     0, s, workspace, n_blocks, lp_const, n_chains, log_lik);
   ZS_LAUNCH_CHECK("gd_lik_finish_kernel launch");
   return ZSHMC_OK;
 }

@@ -143,25 +143,30 @@ __global__ __launch_bounds__(256) void model_seg_step_kernel(SegArgs a) {
   }
 }
 
+// A wave per chain: lane l adds the chunk sums l, l + 64, ... in that order,
+// then a fixed butterfly over the 64 lanes -- the same bits every run.
 __global__ __launch_bounds__(256) void model_seg_finish_kernel(
     const float* __restrict__ partials, int64_t n_chunks,
     const float* __restrict__ ll_in, int64_t groups, float lik_scale,
     int64_t n_chains, float* __restrict__ lp_out, float* __restrict__ kinetic) {
-  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= n_chains) return;
-  float prior = 0.f, kin = 0.f;
+  const int lane = threadIdx.x & 63;
+  const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= n_chains) return;        // (wave-uniform)
+  float prior = 0.f, kin = 0.f, ll = 0.f;
   const float* __restrict__ pc = partials + c * n_chunks * 2;
-  for (int64_t j = 0; j < n_chunks; ++j) {
+  for (int64_t j = lane; j < n_chunks; j += 64) {
     prior += pc[2 * j];
     kin += pc[2 * j + 1];
   }
-  if (lp_out) {
-    float ll = 0.f;
-    if (ll_in)
-      for (int64_t k = 0; k < groups; ++k) ll += ll_in[c * groups + k];
-    lp_out[c] = lik_scale * ll + prior;
+  if (lp_out && ll_in)
+    for (int64_t k = lane; k < groups; k += 64) ll += ll_in[c * groups + k];
+  prior = group_sum<64>(prior);
+  kin = group_sum<64>(kin);
+  ll = group_sum<64>(ll);
+  if (lane == 0) {
+    if (lp_out) lp_out[c] = lik_scale * ll + prior;
+    if (kinetic) kinetic[c] += 0.5f * kin;
   }
-  if (kinetic) kinetic[c] += 0.5f * kin;
 }
 
 }  // namespace zshmc
@@ -225,7 +230,7 @@ extern "C" int zshmc_model_kick_drift_seg(
   ZS_LAUNCH_CHECK("model_seg_step_kernel launch");
   if (lp_out || kinetic) {
     hipLaunchKernelGGL(model_seg_finish_kernel,
-                       dim3((unsigned)((n_chains + 255) / 256)), dim3(256), 0, s,
+                       dim3((unsigned)((n_chains + 3) / 4)), dim3(256), 0, s,
                        workspace, n_chunks, ll_in, groups, lik_scale, n_chains,
                        lp_out, kinetic);
     ZS_LAUNCH_CHECK("model_seg_finish_kernel launch");
