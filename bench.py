@@ -263,29 +263,51 @@ def _time_transitions(torch, hmc, op, info, feed, n_warm, n_timed, barrier):
     acc = float(acc.item()) / n_timed          # mean over the timed region
     plan = hmc._plan
     stream = torch.cuda.current_stream().cuda_stream
-    plan._likelihood(plan.q_new, stream)
-    k0 = torch.cuda.Event(enable_timing=True)
-    k1 = torch.cuda.Event(enable_timing=True)
-    reps = 3
-    k0.record()
-    for _ in range(reps):
-        plan._likelihood(plan.q_new, stream)
-    k1.record()
-    torch.cuda.synchronize()
-    return elapsed, k0.elapsed_time(k1) / reps, acc
+    # the likelihood kernel alone, in the two forms a transition launches:
+    # gradient only (the L - 1 interior evaluations of a trajectory: the
+    # dominant launch) and likelihood + gradient (its two ends)
+    kern = {}
+    for name, want_ll in (('grad', False), ('ll_grad', True)):
+        plan._likelihood(plan.q_new, stream, want_ll=want_ll)
+        k0 = torch.cuda.Event(enable_timing=True)
+        k1 = torch.cuda.Event(enable_timing=True)
+        reps = 3
+        k0.record()
+        for _ in range(reps):
+            plan._likelihood(plan.q_new, stream, want_ll=want_ll)
+        k1.record()
+        torch.cuda.synchronize()
+        kern[name] = k0.elapsed_time(k1) / reps
+    return elapsed, kern, acc
 
 
 def _mfma_roofline(kernel, kern_ms, flop_eval, n_evals, ms_transition):
-    ach = flop_eval / (kern_ms * 1e-3) / 1e12
-    return {
+    """`kern_ms`: {'grad': ms, 'll_grad': ms} of _time_transitions (or one
+    number).  The roofline entry is the gradient-only launch -- n_evals - 2 of
+    a transition's n_evals launches; the likelihood + gradient launch of the
+    two ends is reported beside it."""
+    both = kern_ms if isinstance(kern_ms, dict) else {'grad': kern_ms}
+    ms = both['grad']
+    ach = flop_eval / (ms * 1e-3) / 1e12
+    out = {
         'bound': 'mfma', 'dtype': 'f32', 'peak': MFMA_F32_PEAK_TFLOPS,
-        'unit': 'TFLOP/s', 'kernel': kernel, 'kernel_ms': kern_ms,
-        'achieved': ach, 'frac': ach / MFMA_F32_PEAK_TFLOPS,
+        'unit': 'TFLOP/s', 'kernel': kernel + ' gradient only (log_lik = NULL)',
+        'kernel_ms': ms, 'achieved': ach, 'frac': ach / MFMA_F32_PEAK_TFLOPS,
         'traffic': None,
         'algorithmic_flop_per_launch': flop_eval,
+        'launches_per_transition': {'gradient_only': n_evals - 2,
+                                    'likelihood_and_gradient': 2},
         'sustained_over_transition': n_evals * flop_eval /
         (ms_transition * 1e-3) / 1e12,
     }
+    if 'll_grad' in both:
+        ach2 = flop_eval / (both['ll_grad'] * 1e-3) / 1e12
+        out['likelihood_and_gradient'] = {
+            'kernel_ms': both['ll_grad'], 'achieved': ach2,
+            'frac': ach2 / MFMA_F32_PEAK_TFLOPS}
+    out['sustained_frac'] = out['sustained_over_transition'] / \
+        MFMA_F32_PEAK_TFLOPS
+    return out
 
 
 def extra_config1(torch, zs, dev, n_chains=1000, n_x=10, n_leapfrogs=5):
@@ -438,7 +460,7 @@ def extra_config3(torch, zs, dev, n_rows=1000000, n_chains=32768, n_feat=256,
                       'timed rate' % (n_sub, n_chains),
         },
         'roofline': _mfma_roofline(
-            'linear_bernoulli_kernel_v2<%d>' % n_feat, kern_ms, flop_eval,
+            'linear_bernoulli_kernel<%d>' % n_feat, kern_ms, flop_eval,
             n_leapfrogs + 1, ms),
     }
 
@@ -593,6 +615,7 @@ def extra_pmf(torch, zs, dev, n_particles=8, n_users=6040, n_items=3706,
     elapsed, kern_ms, acc = _time_transitions(
         torch, hmc, op, info, {}, n_warm, n_timed, torch.cuda.synchronize)
     ms = elapsed / n_timed * 1e3
+    kern_ms = kern_ms['ll_grad']     # (this plan's launch always forms both)
     # rating terms + their scatter: per (particle, pair) two factor rows read
     # twice (forward, scatter) + the residual written and read
     gathered = n_particles * n_pairs * (3.0 * n_factors * 4 + 8 + 8)
@@ -707,7 +730,7 @@ def lntm_workload(torch, zs, dev, n_chains, sharding=None, dist=None,
     rows = rows_rank * world
     flop_eval = 4.0 * rows_rank * n_topics * n_vocab      # per GPU per launch
     roof = _mfma_roofline(
-        'linear_bernoulli_kernel_v2<%d> (multinomial mode)' % n_topics,
+        'linear_bernoulli_kernel<%d> (multinomial mode)' % n_topics,
         kern_ms, flop_eval, n_leapfrogs + 1, ms)
     roof['note'] = 'per GPU (rank 0): one launch covers this rank\'s rows'
     return {

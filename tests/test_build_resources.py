@@ -105,3 +105,79 @@ def test_ring_trip_loop_has_only_hand_counted_vmem(ring_build):
         for i, op in stray:
             assert i < first_dma or i > last_store, (m.group(1), i, op)
     assert n_kernels == N_RING_KERNELS
+
+
+# ---------------------------------------------------------------------------
+# The two-GEMM likelihood kernel (csrc/linear_bernoulli.hip) writes its tile
+# loop as asm statements in issue order.  What this guards (hipcc pinned by the
+# image, but the properties are the contract the hand-placed waits rely on):
+# no instantiation spills (spill code is VMEM the waits do not count); the
+# occupancy each width is designed for; every MFMA of a kernel comes out of an
+# asm statement (the compiler schedules none of its own); and the hot
+# instantiation -- D = 256, gradient only -- moves no value between AGPRs and
+# VGPRs inside the tile loop.
+LB_SRC = os.path.join(ROOT, 'zhusuan_amd', 'csrc', 'linear_bernoulli.hip')
+
+
+@pytest.fixture(scope='module')
+def lb_build(tmp_path_factory):
+    out = tmp_path_factory.mktemp('lbasm')
+    import __graft_entry__ as ge
+    cmd = [_hipcc()] + ge.HIPCC_FLAGS + [
+        '-c', LB_SRC, '-save-temps', '-Rpass-analysis=kernel-resource-usage',
+        '-o', str(out / 'lb.o')]
+    p = subprocess.run(cmd, cwd=str(out), stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, universal_newlines=True)
+    assert p.returncode == 0, p.stdout[-4000:]
+    asm = [f for f in os.listdir(str(out)) if f.endswith('gfx950.s')]
+    assert asm, os.listdir(str(out))
+    return p.stdout, open(os.path.join(str(out), asm[0])).read()
+
+
+def test_likelihood_kernels_have_no_spills_and_keep_their_occupancy(lb_build):
+    remarks, _ = lb_build
+    table = {k: v for k, v in _kernels(remarks).items()
+             if 'linear_bernoulli_kernelILi' in k}
+    # 3 widths x 3 element-wise stages x {ll+grad, grad only, ll only}
+    assert len(table) == 27, sorted(table)
+    for name, row in table.items():
+        assert row['VGPRs Spill'] == 0, (name, row)
+        assert row['ScratchSize [bytes/lane]'] == 0, (name, row)
+        width = int(re.search(r'kernelILi(\d+)E', name).group(1))
+        want = {256: 1, 128: 2, 64: 3}[width]
+        assert row['Occupancy [waves/SIMD]'] >= want, (name, row)
+
+
+def test_likelihood_tile_loop_is_hand_ordered(lb_build):
+    _, asm = lb_build
+    n = 0
+    for m in re.finditer(r'^(_ZN5zshmc23linear_bernoulli_kernelILi(\d+)ELb(\d)'
+                         r'ELi(\d)ELb(\d)E\w+):[^\n]*\n(.*?)s_endpgm',
+                         asm, re.S | re.M):
+        n += 1
+        name, width, grad, op, ll, body = m.groups()
+        in_asm, mfma_out, mfma_in = False, 0, 0
+        for line in body.splitlines():
+            if '#ASMSTART' in line:
+                in_asm = True
+            elif '#ASMEND' in line:
+                in_asm = False
+            if line.strip().startswith('v_mfma'):
+                if in_asm:
+                    mfma_in += 1
+                else:
+                    mfma_out += 1
+        assert mfma_out == 0, name
+        # one copy of the tile: D/2 MFMAs of phase 1 (+ D/2 of phase 3)
+        assert mfma_in == int(width) // 2 * (2 if grad == '1' else 1), (
+            name, mfma_in)
+        if (width, grad, op, ll) == ('256', '1', '0', '0'):
+            lines = body.splitlines()
+            head = next(i for i, l in enumerate(lines) if 'Loop Header' in l)
+            first = next(i for i in range(head, len(lines))
+                         if lines[i].strip().startswith('v_mfma'))
+            last = max(i for i, l in enumerate(lines)
+                       if l.strip().startswith('v_mfma'))
+            moved = [l for l in lines[first:last] if 'v_accvgpr' in l]
+            assert not moved, moved[:4]
+    assert n == 27

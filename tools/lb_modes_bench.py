@@ -5,7 +5,9 @@ trajectory: log_lik = NULL), likelihood only (grad = NULL) -- at every padded
 width, Bernoulli (OP 0) / mixture-multinomial (OP 1) / Categorical (OP 2).
 TFLOP/s = 4 N D C (2 N D C without gradient) / HIP-event time, against the
 fp32-MFMA peak 157.3.
-    python tools/lb_modes_bench.py [flops_scale]"""
+    python tools/lb_modes_bench.py [flops_scale]
+Environment (this tool only): LB_LIB = another build of libzshmc.so to time
+(tools/build_lb_variants.sh), LB_WIDTHS = comma-separated widths to run."""
 import os
 import sys
 
@@ -15,6 +17,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from zhusuan_amd import _capi, _ops  # noqa: E402
 
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
+if os.environ.get('LB_LIB'):
+    _capi.LIB_PATH = os.path.abspath(os.environ['LB_LIB'])
+    print('# library: %s' % _capi.LIB_PATH, flush=True)
+WIDTHS = tuple(int(w) for w in os.environ.get(
+    'LB_WIDTHS', '64,128,256,512,1024').split(','))
 dev = torch.device('cuda', 0)
 s = torch.cuda.current_stream().cuda_stream
 PEAK = 157.3
@@ -43,7 +50,7 @@ def report(tag, D, flop_full, modes):
 
 
 g = torch.Generator(device=dev).manual_seed(1)
-for D in (64, 128, 256, 512, 1024):
+for D in WIDTHS:
     C = 32768 if D <= 256 else 8192
     N = int(scale * (32768 * 256 // D if D <= 256 else 65536 * 256 // D))
     X = torch.randn(N, D, device=dev, generator=g)
@@ -77,6 +84,8 @@ for D in (64, 128, 256, 512, 1024):
 # mixture multinomial at the topic model's shapes: rows = chains x documents
 for K, n_chains, n_docs in ((128, 256, 512), (256, 128, 512), (512, 64, 512),
                             (1024, 32, 512)):
+    if K not in WIDTHS:
+        continue
     V = int(scale * 12419)
     R = n_chains * n_docs
     theta = torch.softmax(torch.randn(R, K, device=dev, generator=g), -1)

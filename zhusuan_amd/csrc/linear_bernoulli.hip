@@ -23,6 +23,7 @@
 #include <stdlib.h>
 
 #include <type_traits>
+#include <utility>
 
 #include "common.h"
 #include "lb_ops.h"
@@ -91,29 +92,11 @@ __device__ __forceinline__ void lds_dma_row(const float* src, uint32_t dst,
 }
 
 // ---------------------------------------------------------------------------
-// 64-row tiles, W in registers, residual exchange between sibling waves.
-// (The first form of this kernel -- 32-row tiles, K split over two waves,
-// partial logits through LDS, 38 % of peak -- is gone; profiles/r01e_* has
-// its numbers.)
-//
-// The 4 waves of a workgroup are (a, b): chain block a (32 chains) x half b.
-//   phase 1  S'[n, i] = sum_d X[n,d] W[i,d] for the wave's 32 ROWS (b = row
-//            block), full K = D in one accumulator chain.  The wave's chain
-//            block of W stays in registers for the whole kernel (D/2 VGPRs,
-//            the B operand): no LDS traffic for W, no exchange of partial
-//            logits, D/2 MFMAs.
-//   residual R' = y - sigmoid(S') and the log-likelihood terms on the
-//            accumulator registers (3 hardware transcendentals per element),
-//            issued under the MFMAs of phase 3a; R' is also parked in LDS.
-//   phase 3  G[i, f] += sum_n R'[n, i] X[n, f] over ALL 64 rows but only the
-//            wave's HALF of the features (b = feature half): 3a takes the
-//            wave's own 32 rows straight from the residual registers (the
-//            C/D layout of phase 1 IS the A layout of phase 3), 3b the sibling
-//            wave's rows from LDS after the mid-tile barrier.  D/4 + D/4 MFMAs
-//            on D/4 accumulators; every wave stores its own slice of gW.
-// LDS: the double-buffered X tile (2 x 64 x (D+4) floats), streamed by
-// LDS-DMA one padded row per instruction, issued between the MFMAs of phase 1;
-// 16 KB for the residual exchange.  Two barriers per tile.
+// 64-row tiles, W in registers, rows stay with their wave.
+// (Earlier forms, numbers in profiles/ and docs/LABNOTES.md: 32-row tiles with K
+// split over two waves and partial logits through LDS, 38 % of peak; phase 3
+// as all 64 rows x half the features with the residual exchanged between
+// sibling waves through LDS and a mid-tile barrier, compiler-scheduled, 0.86.)
 //
 // OP selects the element-wise stage between the two GEMMs:
 //   OP = 0  Bernoulli with dense logits (config 3): term = l*y - max(l,0) -
@@ -129,27 +112,126 @@ __device__ __forceinline__ void lds_dma_row(const float* src, uint32_t dst,
 //           l[y] - logsumexp(l), residual = [k == y] - softmax, the softmax over
 //           the group's lanes of the accumulator (csrc/lb_ops.h); y[n] = the
 //           label of data row n as a float.
-#ifndef ZS_LB_BUF
-#define ZS_LB_BUF(D) ((D) <= 128 ? 1 : 2)
+// LL = false (log_lik = NULL): gradient only -- the L - 1 interior evaluations
+// of a leapfrog trajectory need the gradient alone (hmc.py:348-372; the
+// log-joint is read at its two ends, :46-61).
+//
+// The 4 waves of a workgroup are (a, b): chain block a (32 chains) x ROW block
+// b (32 of the tile's 64 data rows) -- for BOTH GEMMs:
+//   phase 1  S'[n, i] = sum_d X[n,d] W[i,d] for the wave's 32 rows, full K = D
+//            (the wave's W block in registers, as before).
+//   residual on the accumulator registers.
+//   phase 3  G[i, f] += sum_n R'[n, i] X[n, f] over the wave's OWN 32 rows and
+//            ALL D features (D/32 accumulators in AGPRs): the A operand is the
+//            residual register itself for every MFMA of the phase.
+// The two waves of a chain block hold partial gradients over disjoint rows;
+// they meet once, in the epilogue (LDS, a + b: commutative, so bit-stable).
+// No residual exchange, no mid-tile barrier, every phase-3 A operand a register
+// -- at the price of D/32 accumulators per wave, which the register file has
+// (D = 256: 128 W + 128 G + ~65).  One barrier per tile, two X buffers.
+//
+// The issue order is written out: every MFMA, LDS read and wait of a tile is
+// an `asm volatile` statement, in the order the wave should issue them
+// (hipcc's own schedule of the same loop written with builtins exposed an LDS
+// round trip per operand row -- `ds_read, s_waitcnt, 4 MFMAs` -- merged the
+// read-ahead registers of phase 1 into one, and moved 153 values per tile
+// between AGPRs and VGPRs).
+// Operands are read one step (phase 1) / one row (phase 3) ahead into
+// ping-pong registers; `s_waitcnt lgkmcnt(n)` with n = the reads issued behind
+// the one needed (LDS returns in order).  The element-wise stage stays C++
+// (three OPs x LL), fenced into its slot by sched_barrier.  What the compiler
+// cannot see it cannot protect: the wait states between an MFMA's write of S
+// and the first VALU read (s_nop) and the landing of LDS data before a
+// consumer are placed by hand below.
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f,
+                                                std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+template <int OFF>
+__device__ __forceinline__ void lds_read(f4& d, uint32_t addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read(f2& d, uint32_t addr) {
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+// 20 wait states: a 16-pass MFMA's result is in its VGPRs (and the compiler,
+// which cannot see the MFMA inside an asm statement, reads `acc` after this)
+__device__ __forceinline__ void mfma_drain(f16v& acc) {
+  asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc));
+}
+// the same for an AGPR tile, before the compiler's own reads of it
+__device__ __forceinline__ void mfma_drain_a(f16v& acc) {
+  asm volatile("s_nop 15\n\ts_nop 3" : "+a"(acc));
+}
+// lgkmcnt(0) with the destinations of pending asm reads held until then
+__device__ __forceinline__ void land_reads(f4& a) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a) : : "memory");
+}
+__device__ __forceinline__ void land_reads(f4& a, f4& b, f4& c, f4& d, f4& e) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e)
+               :
+               : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_lgkm() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+// accumulate into an AGPR tile (G: touched by MFMAs only until the epilogue)
+// (`s_nop 1`: hipcc may materialise an input with a VALU copy -- an AGPR-parked
+// value, a sub-register move -- right in front of the statement, and an MFMA
+// reading a VGPR needs two wait states behind a VALU write of it; inside an asm
+// statement that is ours to provide.  Under the previous MFMA's 16 passes the
+// two issue cycles are free.)
+__device__ __forceinline__ void mfma_a(f16v& acc, float a, float b) {
+  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0"
+               : "+a"(acc)
+               : "v"(a), "v"(b));
+}
+
+// One phase-1 step, 4 MFMAs of one accumulator chain, as ONE statement:
+// between two asm statements that pass a VGPR hipcc puts an `s_nop 0` (it
+// cannot see what the first one did to the register) and schedules its own
+// scalar arithmetic -- issue slots between dependent MFMAs of a chain.
+template <bool FIRST>
+__device__ __forceinline__ void p1_step(f16v& S, const f4& aa, float w0,
+                                        float w1, float w2, float w3) {
+  if constexpr (FIRST)
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_mfma_f32_32x32x2_f32 %0, %1, %5, 0\n\t"
+        "v_mfma_f32_32x32x2_f32 %0, %2, %6, %0\n\t"
+        "v_mfma_f32_32x32x2_f32 %0, %3, %7, %0\n\t"
+        "v_mfma_f32_32x32x2_f32 %0, %4, %8, %0"
+        : "=&v"(S)
+        : "v"(aa[0]), "v"(aa[1]), "v"(aa[2]), "v"(aa[3]), "v"(w0), "v"(w1),
+          "v"(w2), "v"(w3));
+  else
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_mfma_f32_32x32x2_f32 %0, %1, %5, %0\n\t"
+        "v_mfma_f32_32x32x2_f32 %0, %2, %6, %0\n\t"
+        "v_mfma_f32_32x32x2_f32 %0, %3, %7, %0\n\t"
+        "v_mfma_f32_32x32x2_f32 %0, %4, %8, %0"
+        : "+v"(S)
+        : "v"(aa[0]), "v"(aa[1]), "v"(aa[2]), "v"(aa[3]), "v"(w0), "v"(w1),
+          "v"(w2), "v"(w3));
+}
+#ifndef ZS_LB_MINW  // waves per SIMD the register budget is held to
+#define ZS_LB_MINW(D) ((D) == 256 ? 1 : (D) == 128 ? 2 : 3)
 #endif
-// D = 256 with gradient: the next tile's DMA rows under phase 3b (independent
-// accumulators) instead of in front of the first 16 steps of phase 1 (one
-// dependent chain) -- what pays in csrc/linear_bernoulli_wide.hip was measured
-// here and LOSES: 128.0 against 129.3 TFLOP/s (Bernoulli), 125.5 against 130.0
-// (multinomial, K = 256), profiles/r03cc_dma_phase3_ab.txt.  Off.
-#ifndef ZS_LB_DMA_PHASE3
-#define ZS_LB_DMA_PHASE3 0
-#endif
-#ifndef ZS_LB_MINW  // min waves per SIMD: D = 64 fits three workgroups per CU
-#define ZS_LB_MINW(D) ((D) == 64 ? 3 : 1)
-#endif
-// LL = false (GRAD only): the log-likelihood terms are not formed -- the L - 1
-// interior evaluations of a leapfrog trajectory need the gradient alone
-// (hmc.py:348-372; the log-joint is read at its two ends, :46-61), and the
-// log (one of three transcendentals) + 5 VALU per element are ~40 % of the
-// element-wise stage a lone wave per SIMD cannot hide under its own MFMAs.
+
 template <int D, bool GRAD, int OP, bool LL = true>
-__global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2(
+__global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel(
     const float* __restrict__ W, const float* __restrict__ X,
     const float* __restrict__ y, const float* __restrict__ yc,
     int64_t yc_rows, int64_t ldy, int64_t C, int64_t N, int64_t ldw,
@@ -158,17 +240,15 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2
   constexpr int LD = D + 4;          // padded LDS row: conflict-free b128 reads
   constexpr int kRows = 64;          // data rows per tile
   constexpr int KK = D / 8;          // phase-1 steps of 4 MFMAs (8 features)
-  constexpr int HALF = D / 2;        // features per wave in phase 3
-  constexpr int FB = HALF / 32;      // 32-wide feature blocks per half (1,2,4)
+  constexpr int NT = D / 32;         // phase-3 accumulators (32 features each)
+  constexpr int VW = NT >= 4 ? 4 : NT;  // floats per phase-3 operand read
+  constexpr int NH = NT / VW;        // operand reads per data row (1, 1, 2)
+  typedef typename VecF<VW>::type XV;
+  constexpr uint32_t kBufBytes = kRows * LD * 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // X tile buffers: two (the DMA of tile t+1 runs under the compute of tile
-  // t) where only one workgroup fits a CU anyway; ONE for D <= 128, where the
-  // smaller footprint (50 KB / 34 KB) lets a second (third) workgroup share
-  // the CU and its MFMAs fill this one's bubbles -- DMA latency included
-  constexpr int kBuf = ZS_LB_BUF(D);
-  float* __restrict__ sX = reinterpret_cast<float*>(smem);  // [kBuf][kRows][LD]
-  float* __restrict__ sY = sX + kBuf * kRows * LD;          // [2][kRows]
-  float* __restrict__ sR = sY + 2 * kRows;                  // [4][4][64][4]
+  float* __restrict__ sX = reinterpret_cast<float*>(smem);  // [2][kRows][LD]
+  float* __restrict__ sY = sX + 2 * kRows * LD;             // [2][kRows]
+  double* __restrict__ sE = reinterpret_cast<double*>(sY + 2 * kRows);  // [128]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -212,23 +292,32 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2
 #pragma unroll
       for (int m = 0; m < 4; ++m) wreg[kk * 4 + m] = v[m];
     }
+    // The loads are landed HERE, in the compiler's books too: left pending
+    // into the tile loop, hipcc waits for load kk in front of step kk of
+    // EVERY tile (`s_waitcnt vmcnt(31 - kk)`), and its count does not include
+    // the hand-issued DMA rows -- the last steps' vmcnt(1), vmcnt(0) then
+    // drain the next tile's DMA in the middle of this one.
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk)
+      asm volatile("" : "+v"(wreg[kk * 4]), "+v"(wreg[kk * 4 + 1]),
+                        "+v"(wreg[kk * 4 + 2]), "+v"(wreg[kk * 4 + 3]));
   }
 
   // ---- X tile: global -> LDS by DMA, one padded row per instruction --------
   // (global_load_lds writes lane-linear: a row of D floats is D/64 dwords per
   // lane, and the 4-float pad sits between rows, i.e. between instructions).
-  // Wave w moves rows 16w .. 16w+15; rows past N re-read row N-1 (masked in
-  // the residual).  hipcc does not count these loads: the `s_waitcnt
-  // vmcnt(0)` in front of the tile barrier lands them.
+  // Wave w moves rows 16w .. 16w+15 of tile t+1 while tile t is computed (two
+  // buffers); rows past N re-read row N-1.  hipcc does not count these
+  // loads: the `s_waitcnt vmcnt(0)` in front of the tile barrier lands them.
+  // All address arithmetic is scalar: the tile's first row pointer and the last
+  // valid row offset are formed once per tile (tile_src); a row then costs one
+  // s_min, one 32-bit s_mul and a 64-bit add.
   constexpr int kDmaB = D / 16;  // bytes per lane per row: 16 (D=256), 8, 4
-  // 16 rows per wave and tile, spread over the KK phase-1 steps
+  // 16 rows per wave and tile over the first phase-1 steps
   constexpr int kDmaPer = KK >= 16 ? 1 : 16 / KK;
   const uint32_t sx_addr = (uint32_t)reinterpret_cast<uintptr_t>(sX);
+  const uint32_t sy_addr = (uint32_t)reinterpret_cast<uintptr_t>(sY);
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  // Row j of this wave's 16: all address arithmetic is scalar and cheap -- the
-  // tile's first row pointer and the last valid row offset are formed once per
-  // tile (tile_src); a row then costs one s_min, one 32-bit s_mul and a 64-bit
-  // add (ldx <= 256 and row < 64, so the element offset fits 32 bits).
   const uint32_t dst_wave = __builtin_amdgcn_readfirstlane(
       sx_addr + (uint32_t)(wave_u * 16 * LD * 4));
   const int ldx32 = (int)ldx;
@@ -240,7 +329,7 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2
   auto tile_src = [&](int64_t n0, int buf) {
     const int64_t left = N - 1 - n0;
     return TileSrc{X + n0 * ldx, (int)(left < kRows - 1 ? left : kRows - 1),
-                   dst_wave + (uint32_t)(buf * kRows * LD * 4)};
+                   dst_wave + (uint32_t)buf * kBufBytes};
   };
   auto dma_row = [&](const TileSrc& t, int j) {
     const int row = wave_u * 16 + j;
@@ -248,11 +337,27 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2
     lds_dma_row<kDmaB>(t.base + r * ldx32, t.dst + (uint32_t)(j * LD * 4),
                        (uint32_t)lane);
   };
-  float yr = 0.f;
+  // the 64 labels of a tile: one more DMA row (wave 0), lane n <- y[n0 + n],
+  // clamped like the X rows (what a row past N carries never matters: masked
+  // with the log-likelihood, a zero operand row without)
+  const uint32_t lane_b = (uint32_t)lane;
+  auto dma_labels = [&](const TileSrc& t, int64_t n0, int buf) {
+    const uint32_t l = lane_b < (uint32_t)t.last ? lane_b : (uint32_t)t.last;
+    const uint32_t voff = l * 4u;
+    const float* src = y + n0;
+    const uint32_t dst = sy_addr + (uint32_t)(buf * kRows * 4);
+    asm volatile(
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dword %0, %1"
+        :
+        : "v"(voff), "s"(src), "s"(dst)
+        : "memory");
+  };
 
-  f16v G[FB];
+  f16v G[NT];
 #pragma unroll
-  for (int t = 0; t < FB; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) G[t][r] = 0.f;
   // log-likelihood of this lane's rows: summed per tile in float32 (16
@@ -267,6 +372,7 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2
   // gridDim.y > 1: the data rows are split into gridDim.y contiguous ranges of
   // whole tiles and this workgroup writes PARTIAL sums (reduced afterwards by
   // lb_reduce_splits_kernel) -- for shapes with fewer chain blocks than CUs
+
   const int64_t n_tiles_all = (N + kRows - 1) / kRows;
   const int64_t tiles_per_split = (n_tiles_all + gridDim.y - 1) / gridDim.y;
   const int64_t tile_begin = (int64_t)blockIdx.y * tiles_per_split;
@@ -288,36 +394,15 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  // OP 2: the class this lane's column (a*32 + lo of a 64-row block whose
-  // base is a multiple of the class stride) stands for
   const CatLane cat = cat_lane(lo, n_classes, OP == 2 ? cls_log2 : 0);
 
-  // residual exchange slots: [wave][r>>2][lane][r&3]  (b128, conflict-free)
-  float* __restrict__ sr_mine = sR + (wave * 4 * 64 + lane) * 4;
-  const float* __restrict__ sr_sib = sR + ((wave ^ 1) * 4 * 64 + lane) * 4;
-
-#ifdef ZS_LB_TIMING  // debug: per-phase shader clocks of wave 0 of block 0
-  long long tacc[6] = {0, 0, 0, 0, 0, 0};
-  long long tmark = clock64();
-  // fenced: nothing is scheduled across a mark, and the accumulators are
-  // forced complete (an MFMA is asynchronous) so that a phase owns its MFMAs
-#define ZS_LB_MARK(i)                                        \
-  {                                                          \
-    __builtin_amdgcn_sched_barrier(0);                       \
-    asm volatile("" ::"v"(S[0]), "v"(G[0][0]), "v"(G[FB - 1][15])); \
-    const long long _t = clock64();                          \
-    tacc[i] += _t - tmark;                                   \
-    tmark = _t;                                              \
-    __builtin_amdgcn_sched_barrier(0);                       \
-  }
-#else
-#define ZS_LB_MARK(i)
-#endif
-  // OP 1: the counts x[c, n] of one tile for this lane (a gather: every lane
-  // reads its own chain's row of the counts matrix, 32 rows per instruction,
-  // so the instruction count is what costs).  Rows padded with zeros to a
-  // multiple of 4 floats and 16-B aligned (the caller's count_stride): 4 x
-  // 16 B per lane instead of 16 x 4 B.
+  // OP 1: the counts x[c, n] of one tile for this lane (chain a*32+lo, rows
+  // b*32 + 8j + 4hi .. +3), 4 x 16 B when rows are padded and aligned (the
+  // caller's count_stride).  The NEXT tile's go out at the top of a tile and
+  // are consumed one tile later: hipcc waits for its own loads with `s_waitcnt
+  // vmcnt(n)` counted WITHOUT the hand-issued DMA rows behind them in the same
+  // in-order queue, so a load used in this tile's residual would drag the whole
+  // next X tile's DMA into the wait; the end-of-tile vmcnt(0) lands these.
   float xcnt[16], xnext[16];
   auto load_counts = [&](int64_t t, float* dst) {
     const int64_t cr = row_at(a * 32 + lo);
@@ -342,64 +427,114 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2
     }
   };
   if (OP == 1) load_counts(tile_begin, xcnt);
-  // One tile.  FULL: all 64 rows of the tile exist (every tile but possibly
-  // the last of the row range): the row-validity compares and selects of the
-  // element-wise stage are compiled out.
-  auto tile_body = [&](auto full_tag, int64_t tile) {
-    constexpr bool FULL = decltype(full_tag)::value;
-    const int buf = (int)((tile - tile_begin) & 1);       // sY slot
-    const int xbuf = kBuf == 2 ? buf : 0;                 // sX slot
-    const float* __restrict__ xb = sX + xbuf * kRows * LD;
+
+  // LDS byte addresses of this lane's operands in buffer 0:
+  //   phase 1, A: X[b*32 + lo][8 kk + 4 hi .. +3]      (+ 32 kk bytes)
+  //   phase 3, B: X[b*32 + 4 hi + rowoff(r)][(t/VW)*32*VW + lo*VW + t%VW]
+  //   labels    : sY[b*32 + 4 hi + 8 g .. +3]
+  const uint32_t a_off = sx_addr + (uint32_t)(((b * 32 + lo) * LD + hi * 4) * 4);
+  const uint32_t x_off =
+      sx_addr + (uint32_t)(((b * 32 + 4 * hi) * LD + lo * VW) * 4);
+  const uint32_t y_off = sy_addr + (uint32_t)((b * 32 + 4 * hi) * 4);
+  f4 av[2];        // phase-1 operand ping-pong
+  XV xv[2][NH];    // phase-3 operand ping-pong
+  f4 yv[4];        // the tile's labels of this lane's 16 rows (OP 0 / 2)
+  // first reads of a tile (its A operand of step 0, its labels)
+  auto head = [&](int buf) {
+    lds_read<0>(av[0], a_off + (uint32_t)buf * kBufBytes);
+    if (OP != 1) {
+      const uint32_t ya = y_off + (uint32_t)(buf * kRows * 4);
+      lds_read<0>(yv[0], ya);
+      lds_read<32>(yv[1], ya);
+      lds_read<64>(yv[2], ya);
+      lds_read<96>(yv[3], ya);
+    }
+  };
+  // An asm read's destination is the compiler's to reuse from the last use
+  // it can see -- while the data may still be in flight.  Where a head's
+  // reads are NOT consumed (behind the last tile; in front of the re-issue
+  // below) they are landed here, with the registers held until they have.
+  auto land_head = [&]() {
+    if constexpr (OP != 1)
+      land_reads(av[0], yv[0], yv[1], yv[2], yv[3]);
+    else
+      land_reads(av[0]);
+  };
+  head(0);
+
+  // Rows of a tile past N (only the last tile of the row range can have them)
+  // hold a copy of row N-1 (the DMA clamps).  With the log-likelihood the
+  // element-wise stage masks them (valid); the gradient-only instantiations
+  // -- where a trajectory spends its time -- carry no masks at all: those rows
+  // of the LDS tile are ZEROED before the tile is used, so whatever residual
+  // they get meets a zero operand row in phase 3.
+  constexpr bool MASK = LL;
+#ifdef ZS_LB_TIMING  // debug: shader clocks per phase, wave 0 of block 0
+  long long tacc[4] = {0, 0, 0, 0};
+  long long tmark = clock64();
+#define ZS_LB_MARK(i)                   \
+  {                                      \
+    __builtin_amdgcn_sched_barrier(0);   \
+    const long long _t = clock64();      \
+    tacc[i] += _t - tmark;               \
+    tmark = _t;                          \
+    __builtin_amdgcn_sched_barrier(0);   \
+  }
+#else
+#define ZS_LB_MARK(i)
+#endif
+  auto tile_body = [&](int64_t tile) {
+    const int buf = (int)((tile - tile_begin) & 1);
+    if (!MASK && (tile + 1) * kRows > N) {
+      land_head();
+      const int first = (int)(N - tile * kRows);   // 1 .. 63, workgroup-uniform
+      float* __restrict__ xt = sX + buf * kRows * LD;
+      for (int i = first * LD + tid; i < kRows * LD; i += 256) xt[i] = 0.f;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __syncthreads();
+      head(buf);   // the reads issued behind the previous barrier saw old rows
+    }
+    const uint32_t a_addr = a_off + (uint32_t)buf * kBufBytes;
+    const uint32_t x_addr = x_off + (uint32_t)buf * kBufBytes;
     const bool more = tile + 1 < n_tiles;
-    // rows of tile+1 (the last tile re-streams itself: clamped rows, unused)
     const int64_t n_next = (more ? tile + 1 : tile) * kRows;
-    const TileSrc tnext = tile_src(n_next, kBuf == 2 ? (xbuf ^ 1) : 0);
-    if (OP != 1 && tid < kRows) {
-      const int64_t nr = n_next + tid;
-      yr = nr < N ? y[nr] : 0.f;
-    }
-    // OP 1: this lane's 16 counts (chain a*32+lo, rows b*32 + 8j + 4hi .. +3)
-    // of the NEXT tile go out now and are consumed one tile later: hipcc waits
-    // for its own loads with `s_waitcnt vmcnt(n)` counted WITHOUT the
-    // hand-issued DMA rows behind them in the same in-order queue, so a load
-    // used in this tile's residual would drag the whole next X tile's DMA
-    // into the wait; the end-of-tile vmcnt(0) lands these for free.
+    const TileSrc tnext = tile_src(n_next, buf ^ 1);
     if (OP == 1) load_counts(more ? tile + 1 : tile, xnext);
+    __builtin_amdgcn_sched_barrier(0);
 
-    // ---- phase 1 (own 32 rows, full K) --------------------------------------
-    // Hand-pipelined: the LDS read of step kk+1 and one DMA row of tile+1 go
-    // out in front of the 4 MFMAs of step kk (a lone wave per SIMD has nobody
-    // else to hide its latencies).
+    // ---- phase 1: own 32 rows, full K, one accumulator chain ---------------
     f16v S;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) S[r] = 0.f;
-    {
-      const float* __restrict__ arow = xb + (b * 32 + lo) * LD + hi * 4;
-      f4 av = *reinterpret_cast<const f4*>(arow);
-#pragma unroll
-      for (int kk = 0; kk < KK; ++kk) {
-        f4 an = av;
-        if (kk + 1 < KK) an = *reinterpret_cast<const f4*>(arow + (kk + 1) * 8);
-        // one DMA row of tile t+1 per step over the first 16 steps (KK >= 16)
-        // or kDmaPer rows per step (KK = 8): issued as early as the buffer is
-        // free, in front of the step's MFMAs
-        // (ZS_LB_DMA_PHASE3, an A/B switch: the rows under phase 3b instead)
-        if (kBuf == 2 && KK >= 16 && kk < 16 && !(GRAD && ZS_LB_DMA_PHASE3))
-          dma_row(tnext, kk);
-        if (kBuf == 2 && KK < 16) {
-#pragma unroll
-          for (int j = 0; j < kDmaPer; ++j) dma_row(tnext, kk * kDmaPer + j);
+    static_for<KK>([&](auto kc) {
+      constexpr int kk = decltype(kc)::value;
+      if constexpr (kk + 1 < KK) {
+        lds_read<(kk + 1) * 32>(av[(kk + 1) & 1], a_addr);
+        wait_lgkm<1>();
+      } else {
+        wait_lgkm<0>();
+        if constexpr (GRAD) {  // phase 3's first operand row
+          static_for<NH>([&](auto hc) {
+            constexpr int h = decltype(hc)::value;
+            lds_read<h * 32 * VW * 4>(xv[0][h], x_addr);
+          });
         }
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-          S = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], wreg[kk * 4 + m], S, 0,
-                                                   0, 0);
-        av = an;
       }
-    }
+      // the 16 DMA rows of tile t+1 over the first steps
+      if constexpr (kk == 0 && OP != 1) {
+        if (wave_u == 0) dma_labels(tnext, n_next, buf ^ 1);
+      }
+      if constexpr (kk * kDmaPer < 16) {
+#pragma unroll
+        for (int j = 0; j < kDmaPer; ++j) dma_row(tnext, kk * kDmaPer + j);
+      }
+      p1_step<kk == 0>(S, av[kk & 1], wreg[kk * 4], wreg[kk * 4 + 1],
+                       wreg[kk * 4 + 2], wreg[kk * 4 + 3]);
+    });
+    // S is complete 16 passes + write-back after the last MFMA issued
+    ZS_LB_MARK(0)  // head + phase 1 (issue)
+    mfma_drain(S);
+    __builtin_amdgcn_sched_barrier(0);
 
-    ZS_LB_MARK(0)  // head + phase 1
-    // ---- residual on the accumulator layout ----------------------------------
+    // ---- element-wise stage on the accumulator layout ------------------------
     // lane holds chain i = a*32 + lo, rows n = b*32 + (r&3) + 8*(r>>2) + 4*hi.
     // Bernoulli._log_prob (univariate.py:398-403):
     //   l*y - max(l,0) - log1p(exp(-|l|));   d/dl = y - sigmoid(l).
@@ -408,267 +543,175 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel_v2
                                                            : kRows);
     auto residual = [&](int r) {
       const int nl = b * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      const bool valid = FULL || nl < rows_left;
+      const bool valid = !MASK || nl < rows_left;
       const float sv = S[r];
       if (OP == 0) {
-        const float yv = sY[buf * kRows + nl];
+        const float yv_ = yv[r >> 2][r & 3];
         if (LL) {
           const float e =
               __builtin_amdgcn_exp2f(-1.4426950408889634f * fabsf(sv));
           const float t1 = 1.0f + e;
-          const float inv = __builtin_amdgcn_rcpf(t1);  // sigmoid(|l|) >= 1/2
-          // sigmoid(l) = 1/2 + copysign(inv - 1/2, l): one v_bfi instead of
-          // a compare + select
+          const float inv = __builtin_amdgcn_rcpf(t1);
           const float sig = 0.5f + __builtin_copysignf(inv - 0.5f, sv);
-          S[r] = valid ? yv - sig : 0.f;
-          const float lp = sv * yv - fmaxf(sv, 0.f) -
+          S[r] = valid ? yv_ - sig : 0.f;
+          const float lp = sv * yv_ - fmaxf(sv, 0.f) -
                            0.6931471805599453f * __builtin_amdgcn_logf(t1);
           ll_tile += valid ? lp : 0.f;
         } else {
-          // gradient only: sigmoid(l) = 1 / (1 + 2^(-l log2 e)) as it stands
-          // (l -> -inf: 1 / inf = 0; l -> +inf: 1 / 1): mul, exp, add, rcp, sub
           const float sig = __builtin_amdgcn_rcpf(
               1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * sv));
-          S[r] = valid ? yv - sig : 0.f;
+          S[r] = valid ? yv_ - sig : 0.f;
         }
       } else if (OP == 2) {
-        S[r] = categorical_residual<LL>(sv, sY[buf * kRows + nl], cat, valid,
+        S[r] = categorical_residual<LL>(sv, yv[r >> 2][r & 3], cat, valid,
                                         ll_tile);
       } else {
-        // sum_v x_v log((theta.phi)_v) and d/d(theta.phi) = x / (theta.phi);
-        // x = 0 contributes nothing (also where the product underflows) --
-        // and the counts of rows past N are loaded as zeros
-        const float xv = xcnt[r];
-        const bool on = xv != 0.f;
-        S[r] = on ? xv * __builtin_amdgcn_rcpf(sv) : 0.f;
+        const float xv_ = xcnt[r];
+        const bool on = xv_ != 0.f;
+        S[r] = on ? xv_ * __builtin_amdgcn_rcpf(sv) : 0.f;
         if (LL) {
           const float lp =
-              xv * (0.6931471805599453f * __builtin_amdgcn_logf(sv));
+              xv_ * (0.6931471805599453f * __builtin_amdgcn_logf(sv));
           ll_tile += on ? lp : 0.f;
         }
       }
     };
-    // B operand of phase 3: X[row][b*HALF + lo*FB .. +FB-1]
-    typedef typename VecF<FB>::type V;
-    auto xrow = [&](int blk, int r) -> V {
-      const int nl = blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      return *reinterpret_cast<const V*>(xb + nl * LD + b * HALF + lo * FB);
+    // end of tile: labels of tile t+1 published, its X rows landed, barrier,
+    // and the first reads of tile t+1 behind it
+    auto end_of_tile = [&]() {
+      if (OP == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xcnt[r] = xnext[r];
+      }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __syncthreads();
+      head(buf ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
     };
 
-    if (GRAD) {
-      // ---- phase 3a: own rows, A = the residual registers; the residual of
-      // group g+1 (VALU) is issued under the MFMAs of group g ----------------
-      // The B operands (four X rows per group) can be read from LDS ONE GROUP
-      // AHEAD: read at the top of their own group they expose an LDS round
-      // trip per group (phase 3a 5 514 and 3b 4 604 clocks against 4 096 of
-      // MFMAs each at D = 256, profiles/r03z_lb_phase_timing_v2.txt).
-      // Measured per width and phase (profiles/r03z_prefetch3_ab.txt, four
-      // builds side by side): D = 128 (the topic model's K) gains 1.9 % --
-      // 123.5 -> 125.9 TFLOP/s -- and all of it from phase 3a; at D = 256
-      // phase 3b reading ahead changes nothing (129.4 / 129.3) and phase 3a
-      // reading ahead LOSES 2.6 % (126.0: what that phase is short of is
-      // issue slots for the residual's VALU, and the extra live registers do
-      // not help); at D = 64 the registers would spill under the 168-VGPR
-      // bound of three workgroups per CU.
-      // Second pass (profiles/r03dd_prefetch_fence_ab.txt): the ISA showed why
-      // D = 256 gained nothing -- hipcc sinks every read back to just in front
-      // of the MFMAs that use it (`ds_read, s_waitcnt, 4 MFMAs` per row).  A
-      // scheduling fence behind the next group's reads holds them in place:
-      // with it phase 3b reading ahead gains 2.1 % at D = 256 (129.5 -> 132.3
-      // TFLOP/s, 0.823 -> 0.841; with phase 3a too: 131.0), while D = 128 --
-      // two workgroups per CU, whose reads the other workgroup's MFMAs cover
-      // -- loses 1 % to the fence (126.3 -> 125.0).  So: D = 128 both phases,
-      // unfenced; D = 256 phase 3b, fenced.
-#ifndef ZS_LB_PREFETCH_FENCE
-#define ZS_LB_PREFETCH_FENCE(D) ((D) == 256)
-#endif
-#ifndef ZS_LB_PREFETCH3A
-#define ZS_LB_PREFETCH3A(D) ((D) == 128)
-#endif
-#ifndef ZS_LB_PREFETCH3A_INSIDE
-#define ZS_LB_PREFETCH3A_INSIDE 0
-#endif
-#ifndef ZS_LB_PREFETCH3B
-#define ZS_LB_PREFETCH3B(D) ((D) >= 128)
-#endif
-      constexpr bool kPreA = ZS_LB_PREFETCH3A(D), kPreB = ZS_LB_PREFETCH3B(D);
-      static_assert(!kPreA || kPreB, "phase 3a hands phase 3b its first group");
-      V xv[4], xn[4];
-      if (kPreA) {
+    if constexpr (GRAD) {
+      // The element-wise stage runs kRG rows at a time: one element's
+      // mul-exp-add-rcp-sub is a dependent chain (~45 clocks exposed against
+      // 22 of issue -- the wave's own VALU does not run under its MFMAs);
+      // kRG independent chains in one slot fill each other's latencies.
+      constexpr int kRG = 4;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) xv[q] = xrow(b, q);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) residual(r);
-      ZS_LB_MARK(1)  // first residual group
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        if (kPreA) {
-          // group g+1's rows; past the last group: the first of phase 3b
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            xn[q] = g + 1 < 4 ? xrow(b, (g + 1) * 4 + q) : xrow(b ^ 1, q);
+      for (int q = 0; q < kRG; ++q) residual(q);
+      __builtin_amdgcn_sched_barrier(0);
+      ZS_LB_MARK(1)  // drain + first residual
+      // ---- phase 3: own rows, A = the residual register ---------------------
+      static_for<16>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        if constexpr (r + 1 < 16) {
+          constexpr int ro = ((r + 1) & 3) + 8 * ((r + 1) >> 2);
+          static_for<NH>([&](auto hc) {
+            constexpr int h = decltype(hc)::value;
+            lds_read<ro * LD * 4 + h * 32 * VW * 4>(xv[(r + 1) & 1][h], x_addr);
+          });
+          wait_lgkm<NH>();
         } else {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) xv[q] = xrow(b, g * 4 + q);
+          wait_lgkm<0>();
         }
-        *reinterpret_cast<f4*>(sr_mine + g * 256) =
-            f4{S[g * 4], S[g * 4 + 1], S[g * 4 + 2], S[g * 4 + 3]};
-        // (ZS_LB_PREFETCH_FENCE: hipcc sinks each of the reads above to just in
-        // front of the MFMAs that use it -- `ds_read, s_waitcnt, 4 MFMAs` per
-        // row in the ISA, an LDS round trip exposed per row; the fence keeps
-        // the next group's reads in front of this group's MFMAs)
-        if (kPreA && ZS_LB_PREFETCH_FENCE(D)) __builtin_amdgcn_sched_barrier(0);
+        constexpr int kSplit = NT / 2;
+        static_for<kSplit>([&](auto tc) {
+          constexpr int t = decltype(tc)::value;
+          mfma_a(G[t], S[r], vget<VW>(xv[r & 1][t / VW], t % VW));
+        });
+        if constexpr (r + 1 < 16 && (r + 1) % kRG == 0) {
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int t = 0; t < FB; ++t)
-            G[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                S[g * 4 + q], vget<FB>(xv[q], t), G[t], 0, 0, 0);
-        if (g + 1 < 4) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) residual((g + 1) * 4 + r);
-#ifndef ZS_LB_NO_SGB
-          // A wave issues in order: left alone, hipcc emits the 4*FB MFMAs of
-          // this group back to back and the ~60 VALU / transcendental ops of the
-          // next group's residual after them, where only the last MFMA is
-          // left to hide them.  Ask for the LDS traffic first (the next
-          // group's rows), then one MFMA, then a slice of the VALU.
-          // (ZS_LB_PREFETCH3A_INSIDE: the next group's four reads as slots
-          // INSIDE the pipeline, one behind each of the first four MFMAs,
-          // instead of in front of it -- measured at D = 256 without the
-          // fence: 126.3 against 131.6 TFLOP/s, off)
-          if (kPreA && !ZS_LB_PREFETCH_FENCE(D) && !ZS_LB_PREFETCH3A_INSIDE) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);  // DS read
-            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write
-          }
-#pragma unroll
-          for (int i = 0; i < 4 * FB; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             // MFMA
-            if (kPreA && ZS_LB_PREFETCH3A_INSIDE && i < 4)
-              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);           // DS read
-            __builtin_amdgcn_sched_group_barrier(0x002, 16 / FB, 0);       // VALU
-            __builtin_amdgcn_sched_group_barrier(0x400, (2 + FB) / FB, 0);  // trans
-          }
-#endif
+          for (int q = 0; q < kRG; ++q) residual(r + 1 + q);
+          __builtin_amdgcn_sched_barrier(0);
+        } else if (r + 1 == 16) {
+          // every read of this buffer has returned (lgkmcnt(0) above); the
+          // rest of the row works from registers
+          __builtin_amdgcn_sched_barrier(0);
+          end_of_tile();
         }
-        if (kPreA) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) xv[q] = xn[q];
-        }
-      }
-      ZS_LB_MARK(2)  // phase 3a
-      __syncthreads();  // the sibling's residuals are in LDS
-      ZS_LB_MARK(3)  // barrier 1
-      // ---- phase 3b: the sibling's rows, A from LDS ----------------------------
-      f4 rs = *reinterpret_cast<const f4*>(sr_sib), rs_next = rs;
-      if (kPreB && !kPreA) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) xv[q] = xrow(b ^ 1, q);
-      }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        if (kPreB) {
-          if (g + 1 < 4) {
-            rs_next = *reinterpret_cast<const f4*>(sr_sib + (g + 1) * 256);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) xn[q] = xrow(b ^ 1, (g + 1) * 4 + q);
-          }
-        } else {
-          rs = *reinterpret_cast<const f4*>(sr_sib + g * 256);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) xv[q] = xrow(b ^ 1, g * 4 + q);
-        }
-        if (kPreB && ZS_LB_PREFETCH_FENCE(D)) __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          // one DMA row of tile t+1 in front of each q's MFMAs (independent
-          // accumulators: the issue hides under the previous MFMA)
-          if (kBuf == 2 && KK >= 16 && ZS_LB_DMA_PHASE3) dma_row(tnext, g * 4 + q);
-#pragma unroll
-          for (int t = 0; t < FB; ++t)
-            G[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                rs[q], vget<FB>(xv[q], t), G[t], 0, 0, 0);
-        }
-        if (kPreB) {
-          rs = rs_next;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) xv[q] = xn[q];
-        }
-      }
+        static_for<NT - kSplit>([&](auto tc) {
+          constexpr int t = kSplit + decltype(tc)::value;
+          mfma_a(G[t], S[r], vget<VW>(xv[r & 1][t / VW], t % VW));
+        });
+      });
+      ZS_LB_MARK(2)  // phase 3 (the tile barrier inside it)
     } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) residual(r);
+      __builtin_amdgcn_sched_barrier(0);
+      end_of_tile();
     }
-    ZS_LB_MARK(4)  // phase 3b
-    if (OP != 1 && tid < kRows) sY[(buf ^ 1) * kRows + tid] = yr;
-    if (kBuf == 1) {
-      __syncthreads();  // every wave is done reading the only X buffer
-      if (more) {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) dma_row(tnext, j);
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA rows landed
-    if (OP == 1) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) xcnt[r] = xnext[r];
-    }
-    __syncthreads();  // tile+1 published; this buffer free for tile+2
     if (LL) {
       ll_lane += (double)ll_tile;
       ll_tile = 0.f;
     }
-    ZS_LB_MARK(5)  // DMA wait + barrier 2
+    ZS_LB_MARK(3)  // end of tile
   };
-  // (two copies of the tile only in the gradient-only instantiations -- the
-  // ones a trajectory spends its time in: with the log-likelihood terms alive
-  // as well the second copy costs D = 128 its second workgroup per CU and
-  // D = 64 eleven spilled registers)
-  for (int64_t tile = tile_begin; tile < n_tiles; ++tile) {
-    if constexpr (!LL) {
-      if ((tile + 1) * kRows <= N) {
-        tile_body(std::true_type{}, tile);
-        continue;
-      }
-    }
-    tile_body(std::false_type{}, tile);
-  }
+  for (int64_t tile = tile_begin; tile < n_tiles; ++tile) tile_body(tile);
 #ifdef ZS_LB_TIMING
   if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && GRAD) {
-    for (int i = 0; i < 6; ++i) gW[wave * 8 + i] = (float)tacc[i];
+    for (int i = 0; i < 4; ++i) gW[wave * 8 + i] = (float)tacc[i];
     gW[wave * 8 + 6] = (float)(n_tiles - tile_begin);
   }
   if (blockIdx.x == 0 && blockIdx.y == 0 && GRAD) return;
 #endif
+  land_head();   // the reads behind the last barrier (a tile that does not exist)
 
   // ---- epilogue -----------------------------------------------------------
-  // G[t][r]: chain = c0 + a*32 + (r&3) + 8*(r>>2) + 4*hi,
-  //          feature = b*HALF + lo*FB + t
+  // G[t][r]: chain = a*32 + (r&3) + 8*(r>>2) + 4*hi,
+  //          feature = (t/VW)*32*VW + lo*VW + t%VW; partial over the wave's rows.
+  // The sibling wave (a, b^1) holds the other rows' partial: each wave parks
+  // the accumulators of the half of t it does not store in the (now idle) X
+  // buffers, and adds the sibling's to the half it does.
   if (GRAD) {
+    // the last MFMAs have written their AGPRs
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int pos = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      if (pos < n_valid) {
-        const int64_t chain = row_base + pos * row_stride;
+    for (int t = 0; t < NT; ++t) mfma_drain_a(G[t]);
+    __syncthreads();
+    constexpr int NTH = NT / 2;   // >= 1
+    float* __restrict__ ex = sX;  // [wave][NTH][4][64][4]
 #pragma unroll
-        for (int t = 0; t < FB; ++t)
-          gW[chain * ldw + b * HALF + lo * FB + t] = G[t][r];
+    for (int tt = 0; tt < NTH; ++tt) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f4 o;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          o[m] = b == 0 ? G[NTH + tt][g * 4 + m] : G[tt][g * 4 + m];
+        *reinterpret_cast<f4*>(
+            ex + ((((wave * NTH + tt) * 4 + g) * 64 + lane) * 4)) = o;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tt = 0; tt < NTH; ++tt) {
+      const int t = b * NTH + tt;
+      const int feat = (t / VW) * 32 * VW + lo * VW + t % VW;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f4 o = *reinterpret_cast<const f4*>(
+            ex + (((((wave ^ 1) * NTH + tt) * 4 + g) * 64 + lane) * 4));
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int r = g * 4 + m;
+          const int pos = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          // fixed order: row block 0's partial + row block 1's
+          const float mine = b == 0 ? G[tt][r] : G[NTH + tt][r];
+          const float sum = b == 0 ? mine + o[m] : o[m] + mine;
+          if (pos < n_valid)
+            gW[(row_base + pos * row_stride) * ldw + feat] = sum;
+        }
       }
     }
   }
-  // ll of chain a*32+lo: this lane's 16 rows per tile + lane^32's + the
-  // sibling wave's 32 rows (through the exchange slots, now idle)
   if (LL) {
     const double ll_half = ll_lane + __shfl_xor(ll_lane, 32, 64);
-    double* __restrict__ sRd = reinterpret_cast<double*>(sR);  // 64 doubles
-    if (hi == 0) sRd[wave * 32 + lo] = ll_half;
+    if (hi == 0) sE[wave * 32 + lo] = ll_half;
     __syncthreads();
     if (b == 0 && hi == 0) {
       const int pos = a * 32 + lo;
       if (pos < n_valid)
         ll[row_base + pos * row_stride] =
-            (float)(ll_half + sRd[(wave ^ 1) * 32 + lo]);
+            (float)(ll_half + sE[(wave ^ 1) * 32 + lo]);
     }
   }
 }
@@ -695,28 +738,28 @@ __global__ __launch_bounds__(256) void lb_reduce_splits_kernel(
 }
 
 template <int D, int OP>
-static int launch_v2(const float* W, const float* X, const float* y,
+static int launch_lb(const float* W, const float* X, const float* y,
                      const float* yc, int64_t yc_rows, int64_t ldy, int64_t C,
                      int64_t N, int64_t ldw, int64_t ldx, float* ll, float* gW,
                      hipStream_t s, int n_splits = 1,
                      float* workspace = nullptr, int doc_major = 0,
                      int n_classes = 0, int cls_log2 = 0) {
   constexpr int LD = D + 4;
-  const size_t lds =
-      (size_t)(ZS_LB_BUF(D) * 64 * LD + 2 * 64 + 4 * 16 * 64) * sizeof(float);
+  // two X tile buffers, two label buffers, 128 doubles for the epilogue
+  const size_t lds = (size_t)(2 * 64 * LD + 2 * 64) * sizeof(float) + 128 * 8;
   static bool attr2 = false;
   if (!attr2) {
     hipError_t e = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(linear_bernoulli_kernel_v2<D, true, OP>),
+        reinterpret_cast<const void*>(linear_bernoulli_kernel<D, true, OP>),
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e == hipSuccess)
       e = hipFuncSetAttribute(
-          reinterpret_cast<const void*>(linear_bernoulli_kernel_v2<D, false, OP>),
+          reinterpret_cast<const void*>(linear_bernoulli_kernel<D, false, OP>),
           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e == hipSuccess)
       e = hipFuncSetAttribute(
           reinterpret_cast<const void*>(
-              linear_bernoulli_kernel_v2<D, true, OP, false>),
+              linear_bernoulli_kernel<D, true, OP, false>),
           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return check_hip(e, "hipFuncSetAttribute(LDS)");
     attr2 = true;
@@ -730,18 +773,18 @@ static int launch_v2(const float* W, const float* X, const float* y,
   float* g_out = S > 1 ? (gW ? workspace + (int64_t)S * C : nullptr) : gW;
   const dim3 grid(gx, S);
   if (gW && !ll)
-    hipLaunchKernelGGL((linear_bernoulli_kernel_v2<D, true, OP, false>), grid,
+    hipLaunchKernelGGL((linear_bernoulli_kernel<D, true, OP, false>), grid,
                        dim3(256), lds, s, W, X, y, yc, yc_rows, ldy, C, N, ldw, ldx,
                        ll_out, g_out, doc_major, n_classes, cls_log2);
   else if (gW)
-    hipLaunchKernelGGL((linear_bernoulli_kernel_v2<D, true, OP>), grid,
+    hipLaunchKernelGGL((linear_bernoulli_kernel<D, true, OP>), grid,
                        dim3(256), lds, s, W, X, y, yc, yc_rows, ldy, C, N, ldw, ldx,
                        ll_out, g_out, doc_major, n_classes, cls_log2);
   else
-    hipLaunchKernelGGL((linear_bernoulli_kernel_v2<D, false, OP>), grid,
+    hipLaunchKernelGGL((linear_bernoulli_kernel<D, false, OP>), grid,
                        dim3(256), lds, s, W, X, y, yc, yc_rows, ldy, C, N, ldw, ldx,
                        ll_out, g_out, doc_major, n_classes, cls_log2);
-  ZS_LAUNCH_CHECK("linear_bernoulli_kernel_v2 launch");
+  ZS_LAUNCH_CHECK("linear_bernoulli_kernel launch");
   if (S > 1) {
     const int64_t n = C + (gW ? C * ldw : 0);
     int64_t blocks = (n + 255) / 256;
@@ -804,14 +847,14 @@ extern "C" int zshmc_linear_bernoulli_log_lik(const float* W, const float* X,
   }
   switch (n_features) {
     case 64:
-      return launch_v2<64, 0>(W, X, y, nullptr, 1, n_rows, n_chains, n_rows, 64,
+      return launch_lb<64, 0>(W, X, y, nullptr, 1, n_rows, n_chains, n_rows, 64,
                               64, log_lik, grad_w, s, n_splits, workspace);
     case 128:
-      return launch_v2<128, 0>(W, X, y, nullptr, 1, n_rows, n_chains, n_rows,
+      return launch_lb<128, 0>(W, X, y, nullptr, 1, n_rows, n_chains, n_rows,
                                128, 128, log_lik, grad_w, s, n_splits,
                                workspace);
     default:
-      return launch_v2<256, 0>(W, X, y, nullptr, 1, n_rows, n_chains, n_rows,
+      return launch_lb<256, 0>(W, X, y, nullptr, 1, n_rows, n_chains, n_rows,
                                256, 256, log_lik, grad_w, s, n_splits,
                                workspace);
   }
@@ -856,15 +899,15 @@ extern "C" int zshmc_linear_categorical_log_lik(
                                    n_splits, workspace, s);
   switch (n_features) {
     case 64:
-      return launch_v2<64, 2>(W, X, labels, nullptr, 1, n_rows, n_cols, n_rows,
+      return launch_lb<64, 2>(W, X, labels, nullptr, 1, n_rows, n_cols, n_rows,
                               64, 64, log_lik, grad_w, s, n_splits, workspace,
                               0, n_classes, cls_log2);
     case 128:
-      return launch_v2<128, 2>(W, X, labels, nullptr, 1, n_rows, n_cols,
+      return launch_lb<128, 2>(W, X, labels, nullptr, 1, n_rows, n_cols,
                                n_rows, 128, 128, log_lik, grad_w, s, n_splits,
                                workspace, 0, n_classes, cls_log2);
     default:
-      return launch_v2<256, 2>(W, X, labels, nullptr, 1, n_rows, n_cols,
+      return launch_lb<256, 2>(W, X, labels, nullptr, 1, n_rows, n_cols,
                                n_rows, 256, 256, log_lik, grad_w, s, n_splits,
                                workspace, 0, n_classes, cls_log2);
   }
@@ -923,16 +966,16 @@ extern "C" int zshmc_linear_multinomial_log_lik(const float* theta,
       (n_chains % kMC == 0 || n_chains >= 512);
   switch (n_topics) {
     case 64:
-      return launch_v2<64, 1>(theta, phi_t, nullptr, counts, count_rows,
+      return launch_lb<64, 1>(theta, phi_t, nullptr, counts, count_rows,
                               count_stride, n_rows, n_vocab, 64, 64, log_lik,
                               grad_theta, s, n_splits, workspace, doc_major);
     case 128:
-      return launch_v2<128, 1>(theta, phi_t, nullptr, counts, count_rows,
+      return launch_lb<128, 1>(theta, phi_t, nullptr, counts, count_rows,
                                count_stride, n_rows, n_vocab, 128, 128,
                                log_lik, grad_theta, s, n_splits, workspace,
                                doc_major);
     default:
-      return launch_v2<256, 1>(theta, phi_t, nullptr, counts, count_rows,
+      return launch_lb<256, 1>(theta, phi_t, nullptr, counts, count_rows,
                                count_stride, n_rows, n_vocab, 256, 256,
                                log_lik, grad_theta, s, n_splits, workspace,
                                doc_major);
