@@ -138,13 +138,13 @@ def test_likelihood_kernels_have_no_spills_and_keep_their_occupancy(lb_build):
     remarks, _ = lb_build
     table = {k: v for k, v in _kernels(remarks).items()
              if 'linear_bernoulli_kernelILi' in k}
-    # 3 widths x 3 element-wise stages x {ll+grad, grad only, ll only}
-    assert len(table) == 27, sorted(table)
+    # 4 widths x 3 element-wise stages x {ll+grad, grad only, ll only}
+    assert len(table) == 36, sorted(table)
     for name, row in table.items():
         assert row['VGPRs Spill'] == 0, (name, row)
         assert row['ScratchSize [bytes/lane]'] == 0, (name, row)
         width = int(re.search(r'kernelILi(\d+)E', name).group(1))
-        want = {256: 1, 128: 2, 64: 3}[width]
+        want = {256: 1, 192: 1, 128: 2, 64: 3}[width]
         assert row['Occupancy [waves/SIMD]'] >= want, (name, row)
 
 
@@ -180,4 +180,4 @@ def test_likelihood_tile_loop_is_hand_ordered(lb_build):
                        if l.strip().startswith('v_mfma'))
             moved = [l for l in lines[first:last] if 'v_accvgpr' in l]
             assert not moved, moved[:4]
-    assert n == 27
+    assert n == 36

@@ -90,9 +90,22 @@ def test_ctypes_table_matches_header(lib):
 
 
 def test_version_and_limits_callable_without_gpu(lib):
-    assert lib.zshmc_version() == 400
+    assert lib.zshmc_version() == 410
     assert lib.zshmc_fused_max_n_data() == 2048
     assert lib.zshmc_last_error() is not None
+
+
+def test_likelihood_widths(lib):
+    """zshmc_likelihood_width: the next instantiated kernel width, 0 beyond
+    the widest; what the host pads W and X to (zhusuan_amd/_ops.py)."""
+    from zhusuan_amd import _ops
+    got = [int(lib.zshmc_likelihood_width(n)) for n in
+           (0, 1, 64, 65, 128, 129, 192, 193, 256, 257, 512, 513, 1024, 1025)]
+    assert got == [0, 64, 64, 128, 128, 192, 192, 256, 256, 512, 512, 1024,
+                   1024, 0]
+    assert _ops.likelihood_width(_ops.MAX_LIKELIHOOD_WIDTH) == \
+        _ops.MAX_LIKELIHOOD_WIDTH
+    assert lib.zshmc_likelihood_width(_ops.MAX_LIKELIHOOD_WIDTH + 1) == 0
 
 
 def test_bad_arguments_are_rejected_before_any_launch(lib):

@@ -43,6 +43,9 @@ def _ref(W, X, y):
 @pytest.mark.parametrize('C,N,D', [(64, 32, 64), (100, 1000, 256), (7, 45, 128),
                                    (130, 333, 20), (64, 4096, 200), (1, 1, 3),
                                    (256, 10000, 256),
+                                   # the 192-wide instantiation (b64 operand
+                                   # reads, 12-byte DMA lanes)
+                                   (100, 777, 150), (64, 64, 192), (3, 130, 129),
                                    # the feature-split kernel (512 / 1024):
                                    # ragged 32-chain blocks, ragged 32-row
                                    # tiles, one-row and one-chain shapes

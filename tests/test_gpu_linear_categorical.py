@@ -52,6 +52,7 @@ SHAPES = [
     (33, 3, 17, 257),      # padding class + padding columns
     (40, 10, 100, 515),    # MNIST-like class count
     (24, 16, 128, 300),
+    (20, 8, 150, 333),     # the 192-wide instantiation
     (9, 32, 256, 96),      # a full half-wave of classes
     (12, 20, 300, 200),    # wide kernel (512), 12 padding classes
     (6, 10, 784, 150),     # wide kernel (1024)

@@ -34,6 +34,8 @@ def _data(n_chains, n_docs, K, V, seed):
 # multiple of 64, counts shared across the chain axis
 @pytest.mark.parametrize('n_chains,n_docs,K,V', [(3, 7, 5, 40), (2, 50, 100, 1003),
                                                   (1, 130, 128, 777), (4, 33, 200, 129),
+                                                  (2, 40, 150, 500),   # K padded to 192
+                                                  (64, 3, 192, 200),
                                                   (1, 1, 3, 1),
                                                   # the feature-split kernel
                                                   # (K padded to 512 / 1024):

@@ -455,11 +455,19 @@ class UnnormalizedMultinomialLogProb(_Function):
 # ----------------------------------------------------------------------------
 # dense-logit Bernoulli likelihood (fp32 MFMA, csrc/linear_bernoulli.hip)
 # ----------------------------------------------------------------------------
-# padded feature / topic counts of the fused likelihood kernels (both modes):
-# the 64-chain-block kernel of csrc/linear_bernoulli.hip up to 256, the
-# feature-split kernel of csrc/linear_bernoulli_wide.hip above
-LINEAR_BERNOULLI_WIDTHS = (64, 128, 256, 512, 1024)
-MIXTURE_WIDTHS = LINEAR_BERNOULLI_WIDTHS
+# The padded feature / topic count of the fused likelihood kernels is the
+# library's to say (zshmc_likelihood_width: the 64-chain-block kernel of
+# csrc/linear_bernoulli.hip up to 256 in steps of 64, the feature-split kernel
+# of csrc/linear_bernoulli_wide.hip above); the host only knows the widest.
+MAX_LIKELIHOOD_WIDTH = 1024
+
+
+def likelihood_width(n):
+    """Kernel width for rows of n features / topics (n <= MAX_LIKELIHOOD_WIDTH)."""
+    w = int(_capi.load().zshmc_likelihood_width(int(n)))
+    if w <= 0:
+        raise ValueError('no likelihood kernel for rows of %d columns' % n)
+    return w
 
 
 def _chain_block(width):
@@ -576,7 +584,7 @@ class LinearBernoulliLogLik(_Function):
     def forward(ctx, w, X, y):
         require_device(w, X, y)
         d = w.shape[-1]
-        width = next(v for v in LINEAR_BERNOULLI_WIDTHS if v >= d)
+        width = likelihood_width(d)
         w2 = _pad_features(w.detach().reshape(-1, d).to(_F32), width)
         Xp = _padded_x(X, width)
         yf = y.detach().to(_F32).contiguous()
@@ -653,7 +661,7 @@ class LinearCategoricalLogLik(_Function):
         require_device(w, X, labels_f)
         K, F = int(w.shape[-2]), int(w.shape[-1])
         G = class_stride(K)
-        width = next(v for v in LINEAR_BERNOULLI_WIDTHS if v >= F)
+        width = likelihood_width(F)
         w3 = w.detach().reshape(-1, K, F).to(_F32)
         C = w3.shape[0]
         wp = pack_class_rows(w3, G, width)
@@ -737,7 +745,7 @@ class MixtureMultinomialLogLik(_Function):
     def forward(ctx, theta, phi, x):
         require_device(theta, phi, x)
         k = theta.shape[-1]
-        width = next(v for v in MIXTURE_WIDTHS if v >= k)
+        width = likelihood_width(k)
         t2 = _pad_features(theta.detach().reshape(-1, k).to(_F32), width)
         pt = _padded_phi_t(phi, width)
         xf, x_stride = _padded_counts(x)

@@ -58,11 +58,22 @@ __device__ __forceinline__ float vget(const V& v, int t) {
     return v[t];
 }
 
-// global -> LDS, BYTES (4, 8 = 2x4, 16) per lane, LDS dest = dst + lane*BYTES
+// global -> LDS, BYTES (4, 8 = 2x4, 12, 16) per lane, LDS dest = dst + lane*BYTES
 template <int BYTES>
 __device__ __forceinline__ void lds_dma_row(const float* src, uint32_t dst,
                                             uint32_t lane) {
-  if constexpr (BYTES == 16) {
+  static_assert(BYTES == 4 || BYTES == 8 || BYTES == 12 || BYTES == 16,
+                "a row is 256 B, 512 B, 768 B or 1 KB");
+  if constexpr (BYTES == 12) {
+    const uint32_t voff = lane * 12u;
+    asm volatile(
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx3 %0, %1"
+        :
+        : "v"(voff), "s"(src), "s"(dst)
+        : "memory");
+  } else if constexpr (BYTES == 16) {
     const uint32_t voff = lane * 16u;
     asm volatile(
         "s_mov_b32 m0, %2\n\t"
@@ -227,7 +238,7 @@ __device__ __forceinline__ void p1_step(f16v& S, const f4& aa, float w0,
           "v"(w2), "v"(w3));
 }
 #ifndef ZS_LB_MINW  // waves per SIMD the register budget is held to
-#define ZS_LB_MINW(D) ((D) == 256 ? 1 : (D) == 128 ? 2 : 3)
+#define ZS_LB_MINW(D) ((D) >= 192 ? 1 : (D) == 128 ? 2 : 3)
 #endif
 
 template <int D, bool GRAD, int OP, bool LL = true>
@@ -241,8 +252,8 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel(
   constexpr int kRows = 64;          // data rows per tile
   constexpr int KK = D / 8;          // phase-1 steps of 4 MFMAs (8 features)
   constexpr int NT = D / 32;         // phase-3 accumulators (32 features each)
-  constexpr int VW = NT >= 4 ? 4 : NT;  // floats per phase-3 operand read
-  constexpr int NH = NT / VW;        // operand reads per data row (1, 1, 2)
+  constexpr int VW = NT % 4 == 0 ? 4 : 2;  // floats per phase-3 operand read
+  constexpr int NH = NT / VW;        // operand reads per data row (1, 1, 3, 2)
   typedef typename VecF<VW>::type XV;
   constexpr uint32_t kBufBytes = kRows * LD * 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -312,7 +323,7 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel(
   // All address arithmetic is scalar: the tile's first row pointer and the last
   // valid row offset are formed once per tile (tile_src); a row then costs one
   // s_min, one 32-bit s_mul and a 64-bit add.
-  constexpr int kDmaB = D / 16;  // bytes per lane per row: 16 (D=256), 8, 4
+  constexpr int kDmaB = D / 16;  // bytes per lane per row: 16 (D=256), 12, 8, 4
   // 16 rows per wave and tile over the first phase-1 steps
   constexpr int kDmaPer = KK >= 16 ? 1 : 16 / KK;
   const uint32_t sx_addr = (uint32_t)reinterpret_cast<uintptr_t>(sX);
@@ -816,6 +827,16 @@ int linear_categorical_wide(const float* W, const float* X, const float* labels,
 
 using namespace zshmc;
 
+// The padded width (features / topics per row of W and X) the two-GEMM
+// likelihood kernels take for a model with n columns: the next instantiated
+// width, 0 beyond the widest.
+extern "C" int64_t zshmc_likelihood_width(int64_t n) {
+  static const int64_t widths[] = {64, 128, 192, 256, 512, 1024};
+  for (int64_t w : widths)
+    if (n <= w) return n < 1 ? 0 : w;
+  return 0;
+}
+
 extern "C" int zshmc_linear_bernoulli_log_lik(const float* W, const float* X,
                                               const float* y, int64_t n_chains,
                                               int64_t n_rows, int64_t n_features,
@@ -827,10 +848,10 @@ extern "C" int zshmc_linear_bernoulli_log_lik(const float* W, const float* X,
              "zshmc_linear_bernoulli_log_lik: null pointer");
   ZS_REQUIRE(n_chains > 0 && n_rows > 0,
              "zshmc_linear_bernoulli_log_lik: bad shape");
-  ZS_REQUIRE(n_features == 64 || n_features == 128 || n_features == 256 ||
-                 n_features == 512 || n_features == 1024,
-             "zshmc_linear_bernoulli_log_lik: n_features must be 64, 128, 256, "
-             "512 or 1024 (zero-pad W and X), got %lld", (long long)n_features);
+  ZS_REQUIRE(zshmc_likelihood_width(n_features) == n_features,
+             "zshmc_linear_bernoulli_log_lik: n_features must be a kernel width "
+             "(zshmc_likelihood_width: 64, 128, 192, 256, 512 or 1024; zero-pad "
+             "W and X), got %lld", (long long)n_features);
   ZS_REQUIRE((reinterpret_cast<uintptr_t>(W) & 15) == 0 &&
                  (reinterpret_cast<uintptr_t>(X) & 15) == 0 &&
                  (!grad_w || (reinterpret_cast<uintptr_t>(grad_w) & 3) == 0),
@@ -852,6 +873,10 @@ extern "C" int zshmc_linear_bernoulli_log_lik(const float* W, const float* X,
     case 128:
       return launch_lb<128, 0>(W, X, y, nullptr, 1, n_rows, n_chains, n_rows,
                                128, 128, log_lik, grad_w, s, n_splits,
+                               workspace);
+    case 192:
+      return launch_lb<192, 0>(W, X, y, nullptr, 1, n_rows, n_chains, n_rows,
+                               192, 192, log_lik, grad_w, s, n_splits,
                                workspace);
     default:
       return launch_lb<256, 0>(W, X, y, nullptr, 1, n_rows, n_chains, n_rows,
@@ -879,10 +904,9 @@ extern "C" int zshmc_linear_categorical_log_lik(
              n_classes, class_stride);
   ZS_REQUIRE(n_cols > 0 && n_rows > 0 && n_cols % class_stride == 0,
              "zshmc_linear_categorical_log_lik: bad shape");
-  ZS_REQUIRE(n_features == 64 || n_features == 128 || n_features == 256 ||
-                 n_features == 512 || n_features == 1024,
-             "zshmc_linear_categorical_log_lik: n_features must be 64, 128, "
-             "256, 512 or 1024 (zero-pad W and X), got %lld",
+  ZS_REQUIRE(zshmc_likelihood_width(n_features) == n_features,
+             "zshmc_linear_categorical_log_lik: n_features must be a kernel "
+             "width (zshmc_likelihood_width; zero-pad W and X), got %lld",
              (long long)n_features);
   ZS_REQUIRE((reinterpret_cast<uintptr_t>(W) & 15) == 0 &&
                  (reinterpret_cast<uintptr_t>(X) & 15) == 0 &&
@@ -906,6 +930,10 @@ extern "C" int zshmc_linear_categorical_log_lik(
       return launch_lb<128, 2>(W, X, labels, nullptr, 1, n_rows, n_cols,
                                n_rows, 128, 128, log_lik, grad_w, s, n_splits,
                                workspace, 0, n_classes, cls_log2);
+    case 192:
+      return launch_lb<192, 2>(W, X, labels, nullptr, 1, n_rows, n_cols,
+                               n_rows, 192, 192, log_lik, grad_w, s, n_splits,
+                               workspace, 0, n_classes, cls_log2);
     default:
       return launch_lb<256, 2>(W, X, labels, nullptr, 1, n_rows, n_cols,
                                n_rows, 256, 256, log_lik, grad_w, s, n_splits,
@@ -928,10 +956,9 @@ extern "C" int zshmc_linear_multinomial_log_lik(const float* theta,
   ZS_REQUIRE(n_rows > 0 && n_vocab > 0 && count_rows > 0 &&
                  n_rows % count_rows == 0 && count_stride >= n_vocab,
              "zshmc_linear_multinomial_log_lik: bad shape");
-  ZS_REQUIRE(n_topics == 64 || n_topics == 128 || n_topics == 256 ||
-                 n_topics == 512 || n_topics == 1024,
-             "zshmc_linear_multinomial_log_lik: n_topics must be 64, 128, 256, "
-             "512 or 1024 (zero-pad theta and phi^T), got %lld",
+  ZS_REQUIRE(zshmc_likelihood_width(n_topics) == n_topics,
+             "zshmc_linear_multinomial_log_lik: n_topics must be a kernel width "
+             "(zshmc_likelihood_width; zero-pad theta and phi^T), got %lld",
              (long long)n_topics);
   ZS_REQUIRE((reinterpret_cast<uintptr_t>(theta) & 15) == 0 &&
                  (reinterpret_cast<uintptr_t>(phi_t) & 15) == 0,
@@ -972,6 +999,11 @@ extern "C" int zshmc_linear_multinomial_log_lik(const float* theta,
     case 128:
       return launch_lb<128, 1>(theta, phi_t, nullptr, counts, count_rows,
                                count_stride, n_rows, n_vocab, 128, 128,
+                               log_lik, grad_theta, s, n_splits, workspace,
+                               doc_major);
+    case 192:
+      return launch_lb<192, 1>(theta, phi_t, nullptr, counts, count_rows,
+                               count_stride, n_rows, n_vocab, 192, 192,
                                log_lik, grad_theta, s, n_splits, workspace,
                                doc_major);
     default:

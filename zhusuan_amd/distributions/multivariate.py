@@ -216,7 +216,7 @@ class UnnormalizedMultinomial(Distribution):
             # fused only without re-normalisation and without a gradient
             # through phi; otherwise the dense logits
             if normalize_logits or logits.phi.requires_grad or \
-                    logits.phi.shape[0] > _ops.MIXTURE_WIDTHS[-1]:
+                    logits.phi.shape[0] > _ops.MAX_LIKELIHOOD_WIDTH:
                 logits = logits.dense()
             else:
                 self._lazy = logits

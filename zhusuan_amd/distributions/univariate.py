@@ -413,7 +413,7 @@ class Bernoulli(Distribution):
                 # the fused kernel differentiates w.r.t. w only: a design
                 # matrix that needs a gradient takes the dense path
                 not lazy.design_requires_grad() and not given.requires_grad and
-                lazy.n_features <= _ops.LINEAR_BERNOULLI_WIDTHS[-1] and
+                lazy.n_features <= _ops.MAX_LIKELIHOOD_WIDTH and
                 len(lazy.lead_shape) >= self._group_ndims - 1):
             w_all, x_all = lazy.packed()
             ll = _ops.LinearBernoulliLogLik.apply(w_all, x_all, given)
@@ -488,7 +488,7 @@ class LinearClassLogits(object):
 
     def fused_ok(self):
         return (self.n_classes <= _ops.MAX_CLASSES and
-                self.n_features <= _ops.LINEAR_BERNOULLI_WIDTHS[-1] and
+                self.n_features <= _ops.MAX_LIKELIHOOD_WIDTH and
                 not self.X.requires_grad and self.dtype == torch.float32)
 
     def dense(self):

@@ -1286,15 +1286,13 @@ class _DenseLikelihoodPlan(_PlanBase):
             K, F = (int(v) for v in self.q[0].shape[-2:])
             self.n_classes, self.seg_len = K, F
             self.stride = _ops.class_stride(K)
-            self.width = next(v for v in _ops.LINEAR_BERNOULLI_WIDTHS
-                              if v >= F)
+            self.width = _ops.likelihood_width(F)
             self.lik_rows = C * self.stride
             self.seg_ws = torch.empty(
                 int(_capi.load().zshmc_model_seg_workspace(C, D)), **f32)
             need_operand = not (K == self.stride and F == self.width)
         else:
-            self.width = next(v for v in _ops.LINEAR_BERNOULLI_WIDTHS
-                              if v >= ld)
+            self.width = _ops.likelihood_width(ld)
             self.lik_rows = C
             need_operand = self.softmax or self.width != ld
         self.grad = torch.empty(self.lik_rows, self.width, **f32)
