@@ -65,11 +65,16 @@ __device__ __forceinline__ void lds_dma_row(const float* src, uint32_t dst,
   static_assert(BYTES == 4 || BYTES == 8 || BYTES == 12 || BYTES == 16,
                 "a row is 256 B, 512 B, 768 B or 1 KB");
   if constexpr (BYTES == 12) {
-    const uint32_t voff = lane * 12u;
+    // a 768-byte row: the 16-byte form with the last quarter of the wave
+    // masked off for the one instruction (the destination is M0 + 16 * lane
+    // for the lanes that run; global_load_lds_dwordx3 does NOT pack its lanes
+    // 12 bytes apart).  Called with all 64 lanes active.
+    const uint32_t voff = lane * 16u;
     asm volatile(
         "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx3 %0, %1"
+        "s_bfm_b64 exec, 48, 0\n\t"
+        "global_load_lds_dwordx4 %0, %1\n\t"
+        "s_mov_b64 exec, -1"
         :
         : "v"(voff), "s"(src), "s"(dst)
         : "memory");
