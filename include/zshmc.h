@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ZSHMC_VERSION 410 /* 0.4.1: + zshmc_likelihood_width */
+#define ZSHMC_VERSION 410 /* 0.4.1: + zshmc_likelihood_plan */
 
 /* status codes */
 #define ZSHMC_OK 0
@@ -592,11 +592,14 @@ int zshmc_model_kick_drift_seg(
  * tf.gradients (hmc.py:430-432) computes through them; the [C, N] logits are
  * never materialised.  W [n_chains, n_features], X [n_rows, n_features]
  * row-major, 16-byte aligned; y [n_rows] float (0/1); n_features a
- * kernel width -- zshmc_likelihood_width(n) gives the one to zero-pad n
- * columns to (up to 256 in steps of 64: 64-chain blocks with W in registers,
- * csrc/linear_bernoulli.hip; 512 and 1024: 32-chain blocks whose four waves
- * split the features, csrc/linear_bernoulli_wide.hip); grad_w may be NULL
- * (16-byte aligned), or
+ * kernel width -- zshmc_likelihood_plan(n, 0, &width, &chain_block) names the
+ * one to zero-pad n columns to, and the chains a workgroup takes (64 .. 256 in
+ * steps of 64: 64-chain blocks, a 32-chain block of W in each wave's registers,
+ * csrc/linear_bernoulli.hip; 320 .. 576 in steps of 64: the same with 16-chain
+ * blocks on the 16x16x4 MFMA, csrc/linear_bernoulli_mid.hip; 1024 -- and 512
+ * for a Categorical with 32 classes -- 32-chain blocks whose four waves split
+ * the features, csrc/linear_bernoulli_wide.hip); grad_w may be NULL (16-byte
+ * aligned), or
  * log_lik may be (ABI 0.4.0: gradient only -- what the interior evaluations
  * of a leapfrog trajectory need, hmc.py:348-372; the element-wise stage then
  * skips the log and the kernel is 2-4 % faster), not both.
@@ -605,7 +608,8 @@ int zshmc_model_kick_drift_seg(
  * partial sums go to `workspace` (n_splits * n_chains * (n_features + 1)
  * floats) and are added in a fixed order, so the result is deterministic.
  */
-int64_t zshmc_likelihood_width(int64_t n_columns); /* 0: wider than any */
+int zshmc_likelihood_plan(int64_t n_columns, int class_stride, int64_t* width,
+                          int* chain_block); /* class_stride: 0 unless Categorical */
 int zshmc_linear_bernoulli_log_lik(const float* W, const float* X,
                                    const float* y, int64_t n_chains,
                                    int64_t n_rows, int64_t n_features,

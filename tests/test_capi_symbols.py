@@ -95,17 +95,26 @@ def test_version_and_limits_callable_without_gpu(lib):
     assert lib.zshmc_last_error() is not None
 
 
-def test_likelihood_widths(lib):
-    """zshmc_likelihood_width: the next instantiated kernel width, 0 beyond
-    the widest; what the host pads W and X to (zhusuan_amd/_ops.py)."""
+def test_likelihood_plans(lib):
+    """zshmc_likelihood_plan: the kernel width rows of n columns are padded to
+    and the chains a workgroup takes -- what the host asks instead of keeping
+    a table (zhusuan_amd/_ops.py)."""
     from zhusuan_amd import _ops
-    got = [int(lib.zshmc_likelihood_width(n)) for n in
-           (0, 1, 64, 65, 128, 129, 192, 193, 256, 257, 512, 513, 1024, 1025)]
-    assert got == [0, 64, 64, 128, 128, 192, 192, 256, 256, 512, 512, 1024,
-                   1024, 0]
-    assert _ops.likelihood_width(_ops.MAX_LIKELIHOOD_WIDTH) == \
-        _ops.MAX_LIKELIHOOD_WIDTH
-    assert lib.zshmc_likelihood_width(_ops.MAX_LIKELIHOOD_WIDTH + 1) == 0
+    got = [_ops.likelihood_plan(n) for n in
+           (1, 64, 65, 129, 192, 193, 256, 257, 320, 321, 449, 512, 513, 576,
+            577, 1024)]
+    assert got == [(64, 64), (64, 64), (128, 64), (192, 64), (192, 64),
+                   (256, 64), (256, 64), (320, 64), (320, 64), (384, 64),
+                   (512, 64), (512, 64), (576, 64), (576, 64), (1024, 32),
+                   (1024, 32)]
+    # a Categorical's classes must sit inside one wave's chain block
+    assert _ops.likelihood_plan(300, 16) == (320, 64)
+    assert _ops.likelihood_plan(300, 32) == (512, 32)
+    assert _ops.likelihood_plan(200, 32) == (256, 64)
+    assert _ops.likelihood_plan(600, 32) == (1024, 32)
+    assert lib.zshmc_likelihood_plan(_ops.MAX_LIKELIHOOD_WIDTH + 1, 0, None,
+                                     None) != 0
+    assert lib.zshmc_likelihood_plan(0, 0, None, None) != 0
 
 
 def test_bad_arguments_are_rejected_before_any_launch(lib):

@@ -46,10 +46,16 @@ def _ref(W, X, y):
                                    # the 192-wide instantiation (b64 operand
                                    # reads, 12-byte DMA lanes)
                                    (100, 777, 150), (64, 64, 192), (3, 130, 129),
-                                   # the feature-split kernel (512 / 1024):
-                                   # ragged 32-chain blocks, ragged 32-row
-                                   # tiles, one-row and one-chain shapes
+                                   # the 16-chain-block kernel (320 .. 576:
+                                   # csrc/linear_bernoulli_mid.hip): every
+                                   # width, ragged 64-chain blocks, ragged
+                                   # 16-row tiles
                                    (100, 1000, 512), (33, 77, 300),
+                                   (70, 500, 384), (20, 130, 450), (65, 200, 576),
+                                   (5, 17, 520), (130, 16, 321), (1, 15, 448),
+                                   # the feature-split kernel (1024): ragged
+                                   # 32-chain blocks, ragged 32-row tiles,
+                                   # one-row and one-chain shapes
                                    (70, 2051, 1024), (64, 333, 700), (1, 1, 257),
                                    (31, 32, 1000)])
 def test_loglik_and_grad_match_float64_reference(env, C, N, D):

@@ -55,6 +55,9 @@ SHAPES = [
     (20, 8, 150, 333),     # the 192-wide instantiation
     (9, 32, 256, 96),      # a full half-wave of classes
     (12, 20, 300, 200),    # wide kernel (512), 12 padding classes
+    (12, 10, 300, 200),    # 16-chain-block kernel (320), stride 16
+    (6, 16, 500, 150),     # 16-chain-block kernel (512), a full row of classes
+    (9, 3, 400, 77),       # (448), stride 4, one padding class
     (6, 10, 784, 150),     # wide kernel (1024)
     (130, 5, 8, 64),
 ]

@@ -28,6 +28,8 @@ def env():
 CASES = {
     'd300': ([('w', 300, 1.0)], 70, 500),
     'd1000': ([('w', 1000, 1.0)], 40, 300),
+    'd400': ([('w', 400, 1.0)], 70, 210),
+    'd520': ([('w', 520, 1.0)], 30, 100),
     'd10': ([('w', 10, 1.0)], 96, 400),
     'd37': ([('w', 37, 0.7)], 50, 333),
     'd1': ([('w', 1, 1.0)], 64, 200),
@@ -220,7 +222,7 @@ def test_one_latent_per_term_is_required(env):
 @pytest.mark.parametrize('K', [260, 6])
 def test_topic_model_beyond_256_topics_and_ragged_k(env, K):
     """The logistic-normal topic model E step (lntm_mcem.py:33-48,97-102) with
-    K = 260 topics (padded to 512: the feature-split kernel's multinomial
+    K = 260 topics (padded to 320: the 16-chain-block kernel's multinomial
     mode) and K = 6 (rows padded to 8, the padding out of the softmax): the
     native plan, equal to the generic plan's free run."""
     zs, torch, dev = env
@@ -254,7 +256,7 @@ def test_topic_model_beyond_256_topics_and_ragged_k(env, K):
         assert hmc.plan_kind == ('mixture_multinomial' if native
                                  else 'generic')
         if native:
-            assert hmc._plan.width == (512 if K > 256 else 64)
+            assert hmc._plan.width == (320 if K > 256 else 64)
         lps, eps = [], []
         for it in range(7):
             op.run()

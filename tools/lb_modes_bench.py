@@ -21,7 +21,7 @@ if os.environ.get('LB_LIB'):
     _capi.LIB_PATH = os.path.abspath(os.environ['LB_LIB'])
     print('# library: %s' % _capi.LIB_PATH, flush=True)
 WIDTHS = tuple(int(w) for w in os.environ.get(
-    'LB_WIDTHS', '64,128,192,256,512,1024').split(','))
+    'LB_WIDTHS', '64,128,192,256,320,384,448,512,576,1024').split(','))
 dev = torch.device('cuda', 0)
 s = torch.cuda.current_stream().cuda_stream
 PEAK = 157.3
@@ -51,8 +51,8 @@ def report(tag, D, flop_full, modes):
 
 g = torch.Generator(device=dev).manual_seed(1)
 for D in WIDTHS:
-    C = 32768 if D <= 256 else 8192
-    N = int(scale * (32768 * 256 // D if D <= 256 else 65536 * 256 // D))
+    C = 32768 if D <= 576 else 8192
+    N = int(scale * (32768 * 256 // D if D <= 576 else 65536 * 256 // D))
     X = torch.randn(N, D, device=dev, generator=g)
     y = (torch.rand(N, device=dev, generator=g) < 0.4).float()
     W = torch.randn(C, D, device=dev, generator=g) * (0.5 / D ** 0.5)
@@ -82,7 +82,8 @@ for D in WIDTHS:
     del X, W, gw
 
 # mixture multinomial at the topic model's shapes: rows = chains x documents
-for K, n_chains, n_docs in ((128, 256, 512), (192, 128, 512), (256, 128, 512), (512, 64, 512),
+for K, n_chains, n_docs in ((128, 256, 512), (192, 128, 512), (256, 128, 512),
+                            (384, 128, 512), (512, 64, 512),
                             (1024, 32, 512)):
     if K not in WIDTHS:
         continue

@@ -208,7 +208,7 @@ PROTOTYPES = {
         _p, _p, _p, c_int64, c_int64, c_int, _p]),
     'zshmc_unnormalized_multinomial_log_prob_grad': (c_int, [
         _p, _p, _p, _p, c_int64, c_int64, c_int, _p]),
-    'zshmc_likelihood_width': (c_int64, [c_int64]),
+    'zshmc_likelihood_plan': (c_int, [c_int64, c_int, _p, _p]),
     'zshmc_linear_bernoulli_log_lik': (c_int, [
         _p, _p, _p, c_int64, c_int64, c_int64, _p, _p, c_int, _p, _p]),
     'zshmc_linear_categorical_log_lik': (c_int, [

@@ -455,24 +455,30 @@ class UnnormalizedMultinomialLogProb(_Function):
 # ----------------------------------------------------------------------------
 # dense-logit Bernoulli likelihood (fp32 MFMA, csrc/linear_bernoulli.hip)
 # ----------------------------------------------------------------------------
-# The padded feature / topic count of the fused likelihood kernels is the
-# library's to say (zshmc_likelihood_width: the 64-chain-block kernel of
-# csrc/linear_bernoulli.hip up to 256 in steps of 64, the feature-split kernel
-# of csrc/linear_bernoulli_wide.hip above); the host only knows the widest.
+# The padded feature / topic count of the fused likelihood kernels, and the
+# chains one workgroup takes, are the library's to say (zshmc_likelihood_plan:
+# csrc/linear_bernoulli.hip up to 256 columns, csrc/linear_bernoulli_mid.hip up
+# to 576, csrc/linear_bernoulli_wide.hip above); the host only knows the widest.
 MAX_LIKELIHOOD_WIDTH = 1024
+_plan_cache = {}
 
 
-def likelihood_width(n):
-    """Kernel width for rows of n features / topics (n <= MAX_LIKELIHOOD_WIDTH)."""
-    w = int(_capi.load().zshmc_likelihood_width(int(n)))
-    if w <= 0:
-        raise ValueError('no likelihood kernel for rows of %d columns' % n)
-    return w
+def likelihood_plan(n, class_stride=0):
+    """(kernel width, chains per workgroup) for rows of n features / topics;
+    class_stride: the Categorical family's padded class count, else 0."""
+    key = (int(n), int(class_stride))
+    hit = _plan_cache.get(key)
+    if hit is None:
+        import ctypes
+        width, block = ctypes.c_int64(0), ctypes.c_int(0)
+        _capi.call('zshmc_likelihood_plan', key[0], key[1],
+                   ctypes.byref(width), ctypes.byref(block))
+        hit = _plan_cache[key] = (int(width.value), int(block.value))
+    return hit
 
 
-def _chain_block(width):
-    """Chains (rows of W) per workgroup of the kernel for this width."""
-    return 64 if width <= 256 else 32
+def likelihood_width(n, class_stride=0):
+    return likelihood_plan(n, class_stride)[0]
 
 
 def _pad_features(t, width):
@@ -560,7 +566,7 @@ def packed_design(blocks, n_rows, device, width=None):
     return out
 
 
-def _row_splits(n_blocks_rows, n_inner, device, width=256):
+def _row_splits(n_blocks_rows, n_inner, device, block=64):
     """Fewer chain blocks (64 rows; 32 for the wide kernel) than compute
     units: cut the inner (data row / vocabulary) range so that about two
     workgroups land on every CU, at least 256 inner rows per slice, at most
@@ -568,7 +574,6 @@ def _row_splits(n_blocks_rows, n_inner, device, width=256):
     x 100 topics x 12 419 words, two chain blocks: 16 slices of >= 512 rows
     1 788 us per L = 20 transition, 32 of >= 256 rows 1 232 us, 64 of >= 128
     rows 1 213 us; profiles/r04e_row_splits_ab.txt.)"""
-    block = _chain_block(width)
     n_wg = (n_blocks_rows + block - 1) // block
     cus = torch.cuda.get_device_properties(device).multi_processor_count
     if n_wg >= cus:
@@ -584,7 +589,7 @@ class LinearBernoulliLogLik(_Function):
     def forward(ctx, w, X, y):
         require_device(w, X, y)
         d = w.shape[-1]
-        width = likelihood_width(d)
+        width, block = likelihood_plan(d)
         w2 = _pad_features(w.detach().reshape(-1, d).to(_F32), width)
         Xp = _padded_x(X, width)
         yf = y.detach().to(_F32).contiguous()
@@ -592,7 +597,7 @@ class LinearBernoulliLogLik(_Function):
         ll = torch.empty(C, dtype=_F32, device=w.device)
         need_grad = ctx.needs_input_grad[0]
         gw = torch.empty_like(w2) if need_grad else None
-        splits = _row_splits(C, N, w.device, width)
+        splits = _row_splits(C, N, w.device, block)
         ws = torch.empty(splits * C * (width + 1), dtype=_F32,
                          device=w.device) if splits > 1 else None
         _capi.call('zshmc_linear_bernoulli_log_lik', w2.data_ptr(),
@@ -661,7 +666,7 @@ class LinearCategoricalLogLik(_Function):
         require_device(w, X, labels_f)
         K, F = int(w.shape[-2]), int(w.shape[-1])
         G = class_stride(K)
-        width = likelihood_width(F)
+        width, block = likelihood_plan(F, G)
         w3 = w.detach().reshape(-1, K, F).to(_F32)
         C = w3.shape[0]
         wp = pack_class_rows(w3, G, width)
@@ -671,7 +676,7 @@ class LinearCategoricalLogLik(_Function):
         need_grad = ctx.needs_input_grad[0]
         gw = torch.empty(C * G, width, dtype=_F32, device=w.device) \
             if need_grad else None
-        splits = _row_splits(C * G, N, w.device, width)
+        splits = _row_splits(C * G, N, w.device, block)
         ws = torch.empty(splits * C * G * (width + 1), dtype=_F32,
                          device=w.device) if splits > 1 else None
         _capi.call('zshmc_linear_categorical_log_lik', wp.data_ptr(),
@@ -745,7 +750,7 @@ class MixtureMultinomialLogLik(_Function):
     def forward(ctx, theta, phi, x):
         require_device(theta, phi, x)
         k = theta.shape[-1]
-        width = likelihood_width(k)
+        width, block = likelihood_plan(k)
         t2 = _pad_features(theta.detach().reshape(-1, k).to(_F32), width)
         pt = _padded_phi_t(phi, width)
         xf, x_stride = _padded_counts(x)
@@ -754,7 +759,7 @@ class MixtureMultinomialLogLik(_Function):
         need_grad = ctx.needs_input_grad[0]
         gt = torch.empty_like(t2) if need_grad else None
         # fewer 64-row chain blocks than CUs: split the vocabulary range
-        splits = _row_splits(rows, vocab, theta.device, width)
+        splits = _row_splits(rows, vocab, theta.device, block)
         ws = torch.empty(splits * rows * (width + 1), dtype=_F32,
                          device=theta.device) if splits > 1 else None
         _capi.call('zshmc_linear_multinomial_log_lik', t2.data_ptr(),

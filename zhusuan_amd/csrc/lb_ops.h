@@ -83,4 +83,50 @@ __device__ __forceinline__ float categorical_residual(float sv, float label,
   return (valid && c.cls_on) ? (hit ? 1.0f : 0.f) - p : 0.f;
 }
 
+
+// The element-wise stage between the two GEMMs of the fused likelihood
+// kernels, on one logit `sv` of (chain, data row): returns the residual
+// d log_lik / d logit and adds the row's log-likelihood term to `ll_tile`.
+//   OP 0  Bernoulli._log_prob (univariate.py:398-403): l*y - max(l,0) -
+//         log1p(exp(-|l|)), d/dl = y - sigmoid(l); `aux` = y.
+//         log1p(e) = ln2*log2(1+e) with e in (0,1] is good to ~1e-7 absolute.
+//   OP 1  UnnormalizedMultinomial over a mixture (multivariate.py:435-443,
+//         normalize_logits = False): x*log(S), d/dS = x / S; `aux` = the
+//         count x (0 contributes nothing, also where the product underflows).
+//   OP 2  Categorical (csrc/lb_ops.h above); `aux` = the label.
+// LL = false: the residual alone (sigmoid as 1 / (1 + 2^(-l log2 e)): l ->
+// -inf gives 1 / inf = 0, l -> +inf 1 / 1).  `valid` = false: a row past N.
+template <int OP, bool LL>
+__device__ __forceinline__ float lb_residual(float sv, float aux,
+                                             const CatLane& cat, bool valid,
+                                             float& ll_tile) {
+  if constexpr (OP == 0) {
+    if constexpr (LL) {
+      const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * fabsf(sv));
+      const float t1 = 1.0f + e;
+      const float inv = __builtin_amdgcn_rcpf(t1);  // sigmoid(|l|) >= 1/2
+      // sigmoid(l) = 1/2 + copysign(inv - 1/2, l): one v_bfi instead of a
+      // compare + select
+      const float sig = 0.5f + __builtin_copysignf(inv - 0.5f, sv);
+      const float lp = sv * aux - fmaxf(sv, 0.f) -
+                       0.6931471805599453f * __builtin_amdgcn_logf(t1);
+      ll_tile += valid ? lp : 0.f;
+      return valid ? aux - sig : 0.f;
+    } else {
+      const float sig = __builtin_amdgcn_rcpf(
+          1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * sv));
+      return valid ? aux - sig : 0.f;
+    }
+  } else if constexpr (OP == 2) {
+    return categorical_residual<LL>(sv, aux, cat, valid, ll_tile);
+  } else {
+    const bool on = valid && aux != 0.f;
+    if constexpr (LL) {
+      const float lp = aux * (0.6931471805599453f * __builtin_amdgcn_logf(sv));
+      ll_tile += on ? lp : 0.f;
+    }
+    return on ? aux * __builtin_amdgcn_rcpf(sv) : 0.f;
+  }
+}
+
 }  // namespace zshmc

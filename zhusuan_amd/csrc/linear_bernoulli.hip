@@ -12,7 +12,7 @@
 // The reference materialises logits [C, N] (131 GB at config 3) and runs two
 // GEMMs plus ~10 element-wise passes per gradient evaluation.  Here the two
 // GEMMs are fused flash-attention style: a workgroup owns 64 chains, streams
-// X in 32-row tiles through LDS (double buffered), computes the 32x64 logits
+// X in 64-row tiles through LDS (double buffered), computes the logits
 // tile on v_mfma_f32_32x32x2_f32 (exact fp32, so the 1 % acceptance parity is
 // not at risk), applies the sigmoid residual in the accumulator registers,
 // and feeds those registers straight back as the A operand of the second
@@ -22,90 +22,13 @@
 // 4*N*D*C flop per call.
 #include <stdlib.h>
 
-#include <type_traits>
-#include <utility>
-
 #include "common.h"
+#include "lb_asm.h"
 #include "lb_ops.h"
 
 namespace zshmc {
 
-typedef float f4 __attribute__((ext_vector_type(4)));
-typedef float f16v __attribute__((ext_vector_type(16)));
-
 constexpr int kMC = 64;  // chains per workgroup
-
-template <int FB>
-struct VecF {};
-template <>
-struct VecF<1> {
-  typedef float type;
-};
-template <>
-struct VecF<2> {
-  typedef float type __attribute__((ext_vector_type(2)));
-};
-template <>
-struct VecF<4> {
-  typedef f4 type;
-};
-
-template <int FB, typename V>
-__device__ __forceinline__ float vget(const V& v, int t) {
-  if constexpr (FB == 1)
-    return v;
-  else
-    return v[t];
-}
-
-// global -> LDS, BYTES (4, 8 = 2x4, 12, 16) per lane, LDS dest = dst + lane*BYTES
-template <int BYTES>
-__device__ __forceinline__ void lds_dma_row(const float* src, uint32_t dst,
-                                            uint32_t lane) {
-  static_assert(BYTES == 4 || BYTES == 8 || BYTES == 12 || BYTES == 16,
-                "a row is 256 B, 512 B, 768 B or 1 KB");
-  if constexpr (BYTES == 12) {
-    // a 768-byte row: the 16-byte form with the last quarter of the wave
-    // masked off for the one instruction (the destination is M0 + 16 * lane
-    // for the lanes that run; global_load_lds_dwordx3 does NOT pack its lanes
-    // 12 bytes apart).  Called with all 64 lanes active.
-    const uint32_t voff = lane * 16u;
-    asm volatile(
-        "s_mov_b32 m0, %2\n\t"
-        "s_bfm_b64 exec, 48, 0\n\t"
-        "global_load_lds_dwordx4 %0, %1\n\t"
-        "s_mov_b64 exec, -1"
-        :
-        : "v"(voff), "s"(src), "s"(dst)
-        : "memory");
-  } else if constexpr (BYTES == 16) {
-    const uint32_t voff = lane * 16u;
-    asm volatile(
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %0, %1"
-        :
-        : "v"(voff), "s"(src), "s"(dst)
-        : "memory");
-  } else {
-    const uint32_t voff = lane * 4u;
-    asm volatile(
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dword %0, %1"
-        :
-        : "v"(voff), "s"(src), "s"(dst)
-        : "memory");
-    if constexpr (BYTES == 8)
-      asm volatile(
-          "s_mov_b32 m0, %2\n\t"
-          "s_nop 0\n\t"
-          "global_load_lds_dword %0, %1 offset:256"
-          :
-          : "v"(voff), "s"(src), "s"(dst)
-          : "memory");
-  }
-}
 
 // ---------------------------------------------------------------------------
 // 64-row tiles, W in registers, rows stay with their wave.
@@ -159,89 +82,6 @@ __device__ __forceinline__ void lds_dma_row(const float* src, uint32_t dst,
 // cannot see it cannot protect: the wait states between an MFMA's write of S
 // and the first VALU read (s_nop) and the landing of LDS data before a
 // consumer are placed by hand below.
-typedef float f2 __attribute__((ext_vector_type(2)));
-
-template <typename F, int... I>
-__device__ __forceinline__ void static_for_impl(F&& f,
-                                                std::integer_sequence<int, I...>) {
-  (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-  static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
-
-template <int OFF>
-__device__ __forceinline__ void lds_read(f4& d, uint32_t addr) {
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
-}
-template <int OFF>
-__device__ __forceinline__ void lds_read(f2& d, uint32_t addr) {
-  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
-}
-// 20 wait states: a 16-pass MFMA's result is in its VGPRs (and the compiler,
-// which cannot see the MFMA inside an asm statement, reads `acc` after this)
-__device__ __forceinline__ void mfma_drain(f16v& acc) {
-  asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc));
-}
-// the same for an AGPR tile, before the compiler's own reads of it
-__device__ __forceinline__ void mfma_drain_a(f16v& acc) {
-  asm volatile("s_nop 15\n\ts_nop 3" : "+a"(acc));
-}
-// lgkmcnt(0) with the destinations of pending asm reads held until then
-__device__ __forceinline__ void land_reads(f4& a) {
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a) : : "memory");
-}
-__device__ __forceinline__ void land_reads(f4& a, f4& b, f4& c, f4& d, f4& e) {
-  asm volatile("s_waitcnt lgkmcnt(0)"
-               : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e)
-               :
-               : "memory");
-}
-template <int N>
-__device__ __forceinline__ void wait_lgkm() {
-  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
-}
-// accumulate into an AGPR tile (G: touched by MFMAs only until the epilogue)
-// (`s_nop 1`: hipcc may materialise an input with a VALU copy -- an AGPR-parked
-// value, a sub-register move -- right in front of the statement, and an MFMA
-// reading a VGPR needs two wait states behind a VALU write of it; inside an asm
-// statement that is ours to provide.  Under the previous MFMA's 16 passes the
-// two issue cycles are free.)
-__device__ __forceinline__ void mfma_a(f16v& acc, float a, float b) {
-  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0"
-               : "+a"(acc)
-               : "v"(a), "v"(b));
-}
-
-// One phase-1 step, 4 MFMAs of one accumulator chain, as ONE statement:
-// between two asm statements that pass a VGPR hipcc puts an `s_nop 0` (it
-// cannot see what the first one did to the register) and schedules its own
-// scalar arithmetic -- issue slots between dependent MFMAs of a chain.
-template <bool FIRST>
-__device__ __forceinline__ void p1_step(f16v& S, const f4& aa, float w0,
-                                        float w1, float w2, float w3) {
-  if constexpr (FIRST)
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_mfma_f32_32x32x2_f32 %0, %1, %5, 0\n\t"
-        "v_mfma_f32_32x32x2_f32 %0, %2, %6, %0\n\t"
-        "v_mfma_f32_32x32x2_f32 %0, %3, %7, %0\n\t"
-        "v_mfma_f32_32x32x2_f32 %0, %4, %8, %0"
-        : "=&v"(S)
-        : "v"(aa[0]), "v"(aa[1]), "v"(aa[2]), "v"(aa[3]), "v"(w0), "v"(w1),
-          "v"(w2), "v"(w3));
-  else
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_mfma_f32_32x32x2_f32 %0, %1, %5, %0\n\t"
-        "v_mfma_f32_32x32x2_f32 %0, %2, %6, %0\n\t"
-        "v_mfma_f32_32x32x2_f32 %0, %3, %7, %0\n\t"
-        "v_mfma_f32_32x32x2_f32 %0, %4, %8, %0"
-        : "+v"(S)
-        : "v"(aa[0]), "v"(aa[1]), "v"(aa[2]), "v"(aa[3]), "v"(w0), "v"(w1),
-          "v"(w2), "v"(w3));
-}
 #ifndef ZS_LB_MINW  // waves per SIMD the register budget is held to
 #define ZS_LB_MINW(D) ((D) >= 192 ? 1 : (D) == 128 ? 2 : 3)
 #endif
@@ -550,47 +390,15 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel(
     mfma_drain(S);
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- element-wise stage on the accumulator layout ------------------------
-    // lane holds chain i = a*32 + lo, rows n = b*32 + (r&3) + 8*(r>>2) + 4*hi.
-    // Bernoulli._log_prob (univariate.py:398-403):
-    //   l*y - max(l,0) - log1p(exp(-|l|));   d/dl = y - sigmoid(l).
-    // log1p(e) = ln2*log2(1+e) with e in (0,1] is good to ~1e-7 absolute.
+    // ---- element-wise stage on the accumulator layout (csrc/lb_ops.h) --------
+    // lane holds chain i = a*32 + lo, rows n = b*32 + (r&3) + 8*(r>>2) + 4*hi
     const int rows_left = (int)((N - tile * kRows) < kRows ? (N - tile * kRows)
                                                            : kRows);
     auto residual = [&](int r) {
       const int nl = b * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
       const bool valid = !MASK || nl < rows_left;
-      const float sv = S[r];
-      if (OP == 0) {
-        const float yv_ = yv[r >> 2][r & 3];
-        if (LL) {
-          const float e =
-              __builtin_amdgcn_exp2f(-1.4426950408889634f * fabsf(sv));
-          const float t1 = 1.0f + e;
-          const float inv = __builtin_amdgcn_rcpf(t1);
-          const float sig = 0.5f + __builtin_copysignf(inv - 0.5f, sv);
-          S[r] = valid ? yv_ - sig : 0.f;
-          const float lp = sv * yv_ - fmaxf(sv, 0.f) -
-                           0.6931471805599453f * __builtin_amdgcn_logf(t1);
-          ll_tile += valid ? lp : 0.f;
-        } else {
-          const float sig = __builtin_amdgcn_rcpf(
-              1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * sv));
-          S[r] = valid ? yv_ - sig : 0.f;
-        }
-      } else if (OP == 2) {
-        S[r] = categorical_residual<LL>(sv, yv[r >> 2][r & 3], cat, valid,
-                                        ll_tile);
-      } else {
-        const float xv_ = xcnt[r];
-        const bool on = xv_ != 0.f;
-        S[r] = on ? xv_ * __builtin_amdgcn_rcpf(sv) : 0.f;
-        if (LL) {
-          const float lp =
-              xv_ * (0.6931471805599453f * __builtin_amdgcn_logf(sv));
-          ll_tile += on ? lp : 0.f;
-        }
-      }
+      const float aux = OP == 1 ? xcnt[r] : yv[r >> 2][r & 3];
+      S[r] = lb_residual<OP, LL>(S[r], aux, cat, valid, ll_tile);
     };
     // end of tile: labels of tile t+1 published, its X rows landed, barrier,
     // and the first reads of tile t+1 behind it
@@ -812,7 +620,14 @@ static int launch_lb(const float* W, const float* X, const float* y,
   return ZSHMC_OK;
 }
 
-// csrc/linear_bernoulli_wide.hip: 256 < n_features / n_topics <= 1024
+// csrc/linear_bernoulli_mid.hip: widths 320 .. 576 (16-chain blocks per wave)
+int linear_likelihood_mid(int op, const float* W, const float* X,
+                          const float* y, const float* yc, int64_t yc_rows,
+                          int64_t ldy, int64_t C, int64_t N, int64_t D,
+                          float* ll, float* gW, int n_splits, float* workspace,
+                          int doc_major, int n_classes, int cls_log2,
+                          hipStream_t s);
+// csrc/linear_bernoulli_wide.hip: 512 (32-class Categorical only) and 1024
 int linear_multinomial_wide(const float* theta, const float* phi_t,
                             const float* counts, int64_t count_rows,
                             int64_t count_stride, int64_t n_rows,
@@ -832,14 +647,39 @@ int linear_categorical_wide(const float* W, const float* X, const float* labels,
 
 using namespace zshmc;
 
-// The padded width (features / topics per row of W and X) the two-GEMM
-// likelihood kernels take for a model with n columns: the next instantiated
-// width, 0 beyond the widest.
-extern "C" int64_t zshmc_likelihood_width(int64_t n) {
-  static const int64_t widths[] = {64, 128, 192, 256, 512, 1024};
-  for (int64_t w : widths)
-    if (n <= w) return n < 1 ? 0 : w;
-  return 0;
+// Which kernel takes rows of n columns (include/zshmc.h): the padded width
+// and the chains per workgroup.  class_stride: 0 / 1 for the Bernoulli and
+// multinomial families; the Categorical family's classes of one chain must
+// sit inside one wave's chain block (32 rows; 16 in the 320..576 kernel).
+extern "C" int zshmc_likelihood_plan(int64_t n, int class_stride,
+                                     int64_t* width, int* chain_block) {
+  ZS_REQUIRE(n >= 1 && n <= 1024,
+             "zshmc_likelihood_plan: 1 <= n_columns <= 1024, got %lld",
+             (long long)n);
+  ZS_REQUIRE(class_stride >= 0 && class_stride <= 32,
+             "zshmc_likelihood_plan: class_stride <= 32, got %d", class_stride);
+  int64_t w;
+  int block;
+  if (n <= 256) {
+    w = (n + 63) / 64 * 64;
+    block = kMC;
+  } else if (n <= 576 && class_stride <= 16) {
+    w = n <= 320 ? 320 : (n + 63) / 64 * 64;
+    block = 64;
+  } else {
+    w = n <= 512 ? 512 : 1024;
+    block = 32;
+  }
+  if (width) *width = w;
+  if (chain_block) *chain_block = block;
+  return ZSHMC_OK;
+}
+
+static bool is_plan_width(int64_t n, int class_stride) {
+  int64_t w = 0;
+  return n >= 1 && n <= 1024 &&
+         zshmc_likelihood_plan(n, class_stride, &w, nullptr) == ZSHMC_OK &&
+         w == n;
 }
 
 extern "C" int zshmc_linear_bernoulli_log_lik(const float* W, const float* X,
@@ -853,10 +693,10 @@ extern "C" int zshmc_linear_bernoulli_log_lik(const float* W, const float* X,
              "zshmc_linear_bernoulli_log_lik: null pointer");
   ZS_REQUIRE(n_chains > 0 && n_rows > 0,
              "zshmc_linear_bernoulli_log_lik: bad shape");
-  ZS_REQUIRE(zshmc_likelihood_width(n_features) == n_features,
+  ZS_REQUIRE(is_plan_width(n_features, 0),
              "zshmc_linear_bernoulli_log_lik: n_features must be a kernel width "
-             "(zshmc_likelihood_width: 64, 128, 192, 256, 512 or 1024; zero-pad "
-             "W and X), got %lld", (long long)n_features);
+             "(zshmc_likelihood_plan: 64 .. 256 and 320 .. 576 in steps of 64, "
+             "1024; zero-pad W and X), got %lld", (long long)n_features);
   ZS_REQUIRE((reinterpret_cast<uintptr_t>(W) & 15) == 0 &&
                  (reinterpret_cast<uintptr_t>(X) & 15) == 0 &&
                  (!grad_w || (reinterpret_cast<uintptr_t>(grad_w) & 3) == 0),
@@ -868,6 +708,10 @@ extern "C" int zshmc_linear_bernoulli_log_lik(const float* W, const float* X,
   if (n_features > 256) {
     ZS_REQUIRE(!grad_w || (reinterpret_cast<uintptr_t>(grad_w) & 15) == 0,
                "zshmc_linear_bernoulli_log_lik: grad_w must be 16-byte aligned");
+    if (n_features <= 576)
+      return linear_likelihood_mid(0, W, X, y, nullptr, 1, n_rows, n_chains,
+                                   n_rows, n_features, log_lik, grad_w,
+                                   n_splits, workspace, 0, 0, 0, s);
     return linear_bernoulli_wide(W, X, y, n_chains, n_rows, n_features, log_lik,
                                  grad_w, n_splits, workspace, s);
   }
@@ -909,10 +753,10 @@ extern "C" int zshmc_linear_categorical_log_lik(
              n_classes, class_stride);
   ZS_REQUIRE(n_cols > 0 && n_rows > 0 && n_cols % class_stride == 0,
              "zshmc_linear_categorical_log_lik: bad shape");
-  ZS_REQUIRE(zshmc_likelihood_width(n_features) == n_features,
-             "zshmc_linear_categorical_log_lik: n_features must be a kernel "
-             "width (zshmc_likelihood_width; zero-pad W and X), got %lld",
-             (long long)n_features);
+  ZS_REQUIRE(is_plan_width(n_features, class_stride),
+             "zshmc_linear_categorical_log_lik: n_features must be the kernel "
+             "width of zshmc_likelihood_plan for this class stride (zero-pad W "
+             "and X), got %lld", (long long)n_features);
   ZS_REQUIRE((reinterpret_cast<uintptr_t>(W) & 15) == 0 &&
                  (reinterpret_cast<uintptr_t>(X) & 15) == 0 &&
                  (!grad_w || (reinterpret_cast<uintptr_t>(grad_w) & 15) == 0),
@@ -922,6 +766,10 @@ extern "C" int zshmc_linear_categorical_log_lik(
              "zshmc_linear_categorical_log_lik: 1 <= n_splits <= 64 and a "
              "workspace of n_splits*n_cols*(n_features+1) floats when > 1");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (n_features > 256 && n_features <= 576 && class_stride <= 16)
+    return linear_likelihood_mid(2, W, X, labels, nullptr, 1, n_rows, n_cols,
+                                 n_rows, n_features, log_lik, grad_w, n_splits,
+                                 workspace, 0, n_classes, cls_log2, s);
   if (n_features > 256)
     return linear_categorical_wide(W, X, labels, n_cols, n_rows, n_features,
                                    n_classes, cls_log2, log_lik, grad_w,
@@ -961,9 +809,9 @@ extern "C" int zshmc_linear_multinomial_log_lik(const float* theta,
   ZS_REQUIRE(n_rows > 0 && n_vocab > 0 && count_rows > 0 &&
                  n_rows % count_rows == 0 && count_stride >= n_vocab,
              "zshmc_linear_multinomial_log_lik: bad shape");
-  ZS_REQUIRE(zshmc_likelihood_width(n_topics) == n_topics,
+  ZS_REQUIRE(is_plan_width(n_topics, 0),
              "zshmc_linear_multinomial_log_lik: n_topics must be a kernel width "
-             "(zshmc_likelihood_width; zero-pad theta and phi^T), got %lld",
+             "(zshmc_likelihood_plan; zero-pad theta and phi^T), got %lld",
              (long long)n_topics);
   ZS_REQUIRE((reinterpret_cast<uintptr_t>(theta) & 15) == 0 &&
                  (reinterpret_cast<uintptr_t>(phi_t) & 15) == 0,
@@ -982,10 +830,18 @@ extern "C" int zshmc_linear_multinomial_log_lik(const float* theta,
   const bool allow_doc_major = true;
   const int64_t n_chains = n_rows / count_rows;
   if (n_topics > 256) {
-    // 32-row blocks (csrc/linear_bernoulli_wide.hip): same rule, half the size
     ZS_REQUIRE(!grad_theta || (reinterpret_cast<uintptr_t>(grad_theta) & 15) == 0,
                "zshmc_linear_multinomial_log_lik: grad_theta must be 16-byte "
                "aligned");
+    if (n_topics <= 576) {
+      const int dm64 = allow_doc_major && count_rows > 1 &&
+                       (n_chains % 64 == 0 || n_chains >= 512);
+      return linear_likelihood_mid(1, theta, phi_t, nullptr, counts, count_rows,
+                                   count_stride, n_rows, n_vocab, n_topics,
+                                   log_lik, grad_theta, n_splits, workspace,
+                                   dm64, 0, 0, s);
+    }
+    // 32-row blocks (csrc/linear_bernoulli_wide.hip): same rule, half the size
     const int dm = allow_doc_major && count_rows > 1 &&
                    (n_chains % 32 == 0 || n_chains >= 256);
     return linear_multinomial_wide(theta, phi_t, counts, count_rows,

@@ -1286,13 +1286,13 @@ class _DenseLikelihoodPlan(_PlanBase):
             K, F = (int(v) for v in self.q[0].shape[-2:])
             self.n_classes, self.seg_len = K, F
             self.stride = _ops.class_stride(K)
-            self.width = _ops.likelihood_width(F)
+            self.width, self.block = _ops.likelihood_plan(F, self.stride)
             self.lik_rows = C * self.stride
             self.seg_ws = torch.empty(
                 int(_capi.load().zshmc_model_seg_workspace(C, D)), **f32)
             need_operand = not (K == self.stride and F == self.width)
         else:
-            self.width = _ops.likelihood_width(ld)
+            self.width, self.block = _ops.likelihood_plan(ld)
             self.lik_rows = C
             need_operand = self.softmax or self.width != ld
         self.grad = torch.empty(self.lik_rows, self.width, **f32)
@@ -1363,7 +1363,7 @@ class _DenseLikelihoodPlan(_PlanBase):
             if C % self.obs.shape[0] != 0:
                 raise ValueError("counts rows do not divide the chain rows")
         R = self.lik_rows
-        self.splits = ops._row_splits(R, n_inner, self.device, self.width)
+        self.splits = ops._row_splits(R, n_inner, self.device, self.block)
         need = self.splits * R * (self.width + 1) if self.splits > 1 else 0
         if need and (self._ws is None or self._ws.numel() < need):
             self._ws = torch.empty(need, dtype=torch.float32,
