@@ -595,7 +595,7 @@ int zshmc_model_kick_drift_seg(
  * kernel width -- zshmc_likelihood_plan(n, 0, &width, &chain_block) names the
  * one to zero-pad n columns to, and the chains a workgroup takes (64 .. 256 in
  * steps of 64: 64-chain blocks, a 32-chain block of W in each wave's registers,
- * csrc/linear_bernoulli.hip; 320 .. 576 in steps of 64: the same with 16-chain
+ * csrc/linear_bernoulli.hip; 320 .. 896 in steps of 64: the same with 16-chain
  * blocks on the 16x16x4 MFMA, csrc/linear_bernoulli_mid.hip; 1024 -- and 512
  * for a Categorical with 32 classes -- 32-chain blocks whose four waves split
  * the features, csrc/linear_bernoulli_wide.hip); grad_w may be NULL (16-byte

@@ -102,16 +102,17 @@ def test_likelihood_plans(lib):
     from zhusuan_amd import _ops
     got = [_ops.likelihood_plan(n) for n in
            (1, 64, 65, 129, 192, 193, 256, 257, 320, 321, 449, 512, 513, 576,
-            577, 1024)]
+            577, 784, 896, 897, 1024)]
     assert got == [(64, 64), (64, 64), (128, 64), (192, 64), (192, 64),
                    (256, 64), (256, 64), (320, 64), (320, 64), (384, 64),
-                   (512, 64), (512, 64), (576, 64), (576, 64), (1024, 32),
-                   (1024, 32)]
+                   (512, 64), (512, 64), (576, 64), (576, 64), (640, 64),
+                   (832, 64), (896, 64), (1024, 32), (1024, 32)]
     # a Categorical's classes must sit inside one wave's chain block
     assert _ops.likelihood_plan(300, 16) == (320, 64)
     assert _ops.likelihood_plan(300, 32) == (512, 32)
     assert _ops.likelihood_plan(200, 32) == (256, 64)
     assert _ops.likelihood_plan(600, 32) == (1024, 32)
+    assert _ops.likelihood_plan(784, 16) == (832, 64)
     assert lib.zshmc_likelihood_plan(_ops.MAX_LIKELIHOOD_WIDTH + 1, 0, None,
                                      None) != 0
     assert lib.zshmc_likelihood_plan(0, 0, None, None) != 0

@@ -53,6 +53,7 @@ def _ref(W, X, y):
                                    (100, 1000, 512), (33, 77, 300),
                                    (70, 500, 384), (20, 130, 450), (65, 200, 576),
                                    (5, 17, 520), (130, 16, 321), (1, 15, 448),
+                                   (40, 100, 600), (66, 70, 768), (10, 33, 890),
                                    # the feature-split kernel (1024): ragged
                                    # 32-chain blocks, ragged 32-row tiles,
                                    # one-row and one-chain shapes

@@ -46,7 +46,7 @@ def _data(n_chains, n_docs, K, V, seed):
                                                   (2, 41, 300, 1003), (32, 5, 512, 77),
                                                   # (K padded to 320 / 512 above: the
                                                   # 16-chain-block kernel; 448, 576:)
-                                                  (64, 3, 400, 200), (3, 7, 570, 130),
+                                                  (64, 3, 400, 200), (3, 7, 570, 130), (2, 5, 700, 90),
                                                   (3, 7, 1000, 130), (1, 1, 257, 1),
                                                   (64, 3, 700, 333)])
 def test_loglik_and_grad_match_float64(env, n_chains, n_docs, K, V):

@@ -21,7 +21,7 @@ if os.environ.get('LB_LIB'):
     _capi.LIB_PATH = os.path.abspath(os.environ['LB_LIB'])
     print('# library: %s' % _capi.LIB_PATH, flush=True)
 WIDTHS = tuple(int(w) for w in os.environ.get(
-    'LB_WIDTHS', '64,128,192,256,320,384,448,512,576,1024').split(','))
+    'LB_WIDTHS', '64,128,192,256,320,384,448,512,576,640,768,832,896,1024').split(','))
 dev = torch.device('cuda', 0)
 s = torch.cuda.current_stream().cuda_stream
 PEAK = 157.3
@@ -51,8 +51,8 @@ def report(tag, D, flop_full, modes):
 
 g = torch.Generator(device=dev).manual_seed(1)
 for D in WIDTHS:
-    C = 32768 if D <= 576 else 8192
-    N = int(scale * (32768 * 256 // D if D <= 576 else 65536 * 256 // D))
+    C = 32768 if D <= 896 else 8192
+    N = int(scale * (32768 * 256 // D if D <= 896 else 65536 * 256 // D))
     X = torch.randn(N, D, device=dev, generator=g)
     y = (torch.rand(N, device=dev, generator=g) < 0.4).float()
     W = torch.randn(C, D, device=dev, generator=g) * (0.5 / D ** 0.5)

@@ -620,7 +620,7 @@ static int launch_lb(const float* W, const float* X, const float* y,
   return ZSHMC_OK;
 }
 
-// csrc/linear_bernoulli_mid.hip: widths 320 .. 576 (16-chain blocks per wave)
+// csrc/linear_bernoulli_mid.hip: widths 320 .. 896 (16-chain blocks per wave)
 int linear_likelihood_mid(int op, const float* W, const float* X,
                           const float* y, const float* yc, int64_t yc_rows,
                           int64_t ldy, int64_t C, int64_t N, int64_t D,
@@ -650,7 +650,7 @@ using namespace zshmc;
 // Which kernel takes rows of n columns (include/zshmc.h): the padded width
 // and the chains per workgroup.  class_stride: 0 / 1 for the Bernoulli and
 // multinomial families; the Categorical family's classes of one chain must
-// sit inside one wave's chain block (32 rows; 16 in the 320..576 kernel).
+// sit inside one wave's chain block (32 rows; 16 in the 320..896 kernel).
 extern "C" int zshmc_likelihood_plan(int64_t n, int class_stride,
                                      int64_t* width, int* chain_block) {
   ZS_REQUIRE(n >= 1 && n <= 1024,
@@ -663,7 +663,7 @@ extern "C" int zshmc_likelihood_plan(int64_t n, int class_stride,
   if (n <= 256) {
     w = (n + 63) / 64 * 64;
     block = kMC;
-  } else if (n <= 576 && class_stride <= 16) {
+  } else if (n <= 896 && class_stride <= 16) {
     w = n <= 320 ? 320 : (n + 63) / 64 * 64;
     block = 64;
   } else {
@@ -695,7 +695,7 @@ extern "C" int zshmc_linear_bernoulli_log_lik(const float* W, const float* X,
              "zshmc_linear_bernoulli_log_lik: bad shape");
   ZS_REQUIRE(is_plan_width(n_features, 0),
              "zshmc_linear_bernoulli_log_lik: n_features must be a kernel width "
-             "(zshmc_likelihood_plan: 64 .. 256 and 320 .. 576 in steps of 64, "
+             "(zshmc_likelihood_plan: 64 .. 256 and 320 .. 896 in steps of 64, "
              "1024; zero-pad W and X), got %lld", (long long)n_features);
   ZS_REQUIRE((reinterpret_cast<uintptr_t>(W) & 15) == 0 &&
                  (reinterpret_cast<uintptr_t>(X) & 15) == 0 &&
@@ -708,7 +708,7 @@ extern "C" int zshmc_linear_bernoulli_log_lik(const float* W, const float* X,
   if (n_features > 256) {
     ZS_REQUIRE(!grad_w || (reinterpret_cast<uintptr_t>(grad_w) & 15) == 0,
                "zshmc_linear_bernoulli_log_lik: grad_w must be 16-byte aligned");
-    if (n_features <= 576)
+    if (n_features <= 896)
       return linear_likelihood_mid(0, W, X, y, nullptr, 1, n_rows, n_chains,
                                    n_rows, n_features, log_lik, grad_w,
                                    n_splits, workspace, 0, 0, 0, s);
@@ -766,7 +766,7 @@ extern "C" int zshmc_linear_categorical_log_lik(
              "zshmc_linear_categorical_log_lik: 1 <= n_splits <= 64 and a "
              "workspace of n_splits*n_cols*(n_features+1) floats when > 1");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (n_features > 256 && n_features <= 576 && class_stride <= 16)
+  if (n_features > 256 && n_features <= 896 && class_stride <= 16)
     return linear_likelihood_mid(2, W, X, labels, nullptr, 1, n_rows, n_cols,
                                  n_rows, n_features, log_lik, grad_w, n_splits,
                                  workspace, 0, n_classes, cls_log2, s);
@@ -833,7 +833,7 @@ extern "C" int zshmc_linear_multinomial_log_lik(const float* theta,
     ZS_REQUIRE(!grad_theta || (reinterpret_cast<uintptr_t>(grad_theta) & 15) == 0,
                "zshmc_linear_multinomial_log_lik: grad_theta must be 16-byte "
                "aligned");
-    if (n_topics <= 576) {
+    if (n_topics <= 896) {
       const int dm64 = allow_doc_major && count_rows > 1 &&
                        (n_chains % 64 == 0 || n_chains >= 512);
       return linear_likelihood_mid(1, theta, phi_t, nullptr, counts, count_rows,

@@ -1,12 +1,12 @@
-// The two-GEMM likelihood of csrc/linear_bernoulli.hip for rows of 257 .. 576
-// features or topics (padded widths 320 / 384 / 448 / 512 / 576): same
+// The two-GEMM likelihood of csrc/linear_bernoulli.hip for rows of 257 .. 896
+// features or topics (padded widths 320 .. 896 in steps of 64): same
 // mathematics (Bernoulli._log_prob univariate.py:398-403, Categorical :496-548,
 // UnnormalizedMultinomial over a mixture multivariate.py:435-443, each summed
 // by group_ndims = 1, and the gradient tf.gradients yields through the matmul,
 // hmc.py:430-432), same "rows stay with their wave" decomposition, on the
 // 16 x 16 x 4 fp32 MFMA: a 32-chain block of W at these widths (D/2 registers)
 // plus its gradient accumulators (D/2 more) no longer fits a wave; a 16-chain
-// block does (D/4 + D/4).
+// block does (D/4 + D/4: 448 of the 512 registers at D = 896).
 //
 // A workgroup owns 64 chains: wave a (0..3) the chains 16a .. 16a+15 -- all
 // four waves work on the SAME 16 data rows of a tile, each for its own chains:
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256, 1) void linear_bernoulli_mid_kernel(
     int64_t yc_rows, int64_t ldy, int64_t C, int64_t N, int64_t ldw,
     int64_t ldx, float* __restrict__ ll, float* __restrict__ gW,
     int doc_major, int n_classes, int cls_log2) {
-  static_assert(D % 64 == 0 && D > 256 && D <= 576, "widths of this kernel");
+  static_assert(D % 64 == 0 && D > 256 && D <= 896, "widths of this kernel");
   constexpr int LD = D + 4;       // padded LDS row: conflict-free b128 reads
   constexpr int kRows = kMidR;
   constexpr int KS = D / 16;      // phase-1 steps of 4 MFMAs (16 features)
@@ -431,7 +431,7 @@ static int launch_mid(const float* W, const float* X, const float* y,
   return ZSHMC_OK;
 }
 
-// widths 320 .. 576; OP as in csrc/linear_bernoulli.hip.  Called by the three
+// widths 320 .. 896; OP as in csrc/linear_bernoulli.hip.  Called by the three
 // zshmc_linear_*_log_lik entry points (operand checks done there).
 int linear_likelihood_mid(int op, const float* W, const float* X,
                           const float* y, const float* yc, int64_t yc_rows,
@@ -458,6 +458,11 @@ int linear_likelihood_mid(int op, const float* W, const float* X,
     ZS_MID_CASE(448)
     ZS_MID_CASE(512)
     ZS_MID_CASE(576)
+    ZS_MID_CASE(640)
+    ZS_MID_CASE(704)
+    ZS_MID_CASE(768)
+    ZS_MID_CASE(832)
+    ZS_MID_CASE(896)
   }
 #undef ZS_MID_CASE
   set_error("linear_likelihood_mid: width %lld is not instantiated", (long long)D);
