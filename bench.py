@@ -281,6 +281,16 @@ def _time_transitions(torch, hmc, op, info, feed, n_warm, n_timed, barrier):
     return elapsed, kern, acc
 
 
+def _lik_kernel_name(width, block):
+    """The likelihood kernel the library dispatches for a plan's width and
+    chain block (zshmc_likelihood_plan)."""
+    if width <= 256:
+        return 'linear_bernoulli_kernel<%d>' % width
+    if block == 64:
+        return 'linear_bernoulli_mid_kernel<%d>' % width
+    return 'linear_bernoulli_wide_kernel<%d>' % width
+
+
 def _mfma_roofline(kernel, kern_ms, flop_eval, n_evals, ms_transition):
     """`kern_ms`: {'grad': ms, 'll_grad': ms} of _time_transitions (or one
     number).  The roofline entry is the gradient-only launch -- n_evals - 2 of
@@ -460,7 +470,7 @@ def extra_config3(torch, zs, dev, n_rows=1000000, n_chains=32768, n_feat=256,
                       'timed rate' % (n_sub, n_chains),
         },
         'roofline': _mfma_roofline(
-            'linear_bernoulli_kernel<%d>' % n_feat, kern_ms, flop_eval,
+            _lik_kernel_name(hmc._plan.width, hmc._plan.block), kern_ms, flop_eval,
             n_leapfrogs + 1, ms),
     }
 
@@ -513,7 +523,7 @@ def extra_wide_regression(torch, zs, dev, n_rows=65536, n_chains=8192,
         'unit': 'chain-leapfrog-steps/s',
         'mean_acceptance': acc,
         'roofline': dict(_mfma_roofline(
-            'linear_bernoulli_wide_kernel<%d>' % width, kern_ms, flop_eval,
+            _lik_kernel_name(hmc._plan.width, hmc._plan.block), kern_ms, flop_eval,
             n_leapfrogs + 1, ms),
             note='flops counted at the padded width %d (%d useful columns)'
                  % (width, n_feat + 1)),
@@ -568,7 +578,7 @@ def extra_softmax_regression(torch, zs, dev, n_rows=60000, n_feat=784,
         'unit': 'chain-leapfrog-steps/s',
         'mean_acceptance': acc,
         'roofline': dict(_mfma_roofline(
-            'linear_bernoulli_wide_kernel<%d, OP=2 categorical>' % plan.width,
+            _lik_kernel_name(plan.width, plan.block) + ' (Categorical mode)',
             kern_ms, flop_eval, n_leapfrogs + 1, ms),
             note='flops counted at the padded shape: width %d, class stride '
                  '%d; useful fraction of them %.3f (%d features, %d classes)'
@@ -730,7 +740,7 @@ def lntm_workload(torch, zs, dev, n_chains, sharding=None, dist=None,
     rows = rows_rank * world
     flop_eval = 4.0 * rows_rank * n_topics * n_vocab      # per GPU per launch
     roof = _mfma_roofline(
-        'linear_bernoulli_kernel<%d> (multinomial mode)' % n_topics,
+        _lik_kernel_name(hmc._plan.width, hmc._plan.block) + ' (multinomial mode)',
         kern_ms, flop_eval, n_leapfrogs + 1, ms)
     roof['note'] = 'per GPU (rank 0): one launch covers this rank\'s rows'
     return {

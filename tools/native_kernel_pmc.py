@@ -3,7 +3,7 @@
 fp32-MFMA likelihood kernel AT THE SHAPES THE BENCH LINE QUOTES -- BASELINE
 configs[2] (32 768 chains x 10^6 rows x 256) and configs[4] (8 192 x 5 000
 (chain, document) rows x K = 128 x V = 12 419) -- launched straight through
-the C-ABI, two launches each, so that rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+the C-ABI, two launches of each call form, so that rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
 can put their HBM traffic next to the algorithmic bytes.
   python tools/native_kernel_pmc.py [n_chains_config5]"""
 import os
@@ -25,9 +25,11 @@ y = (torch.rand(N, device=dev, generator=g) < 0.5).float()
 W = torch.randn(C, D, device=dev, generator=g) * 0.05
 ll = torch.empty(C, device=dev)
 gw = torch.empty(C, D, device=dev)
-for _ in range(2):
+# two launches of each form a transition issues: likelihood + gradient (its two
+# ends) and gradient only (the L - 1 interior evaluations: log_lik = NULL)
+for ll_ptr in (ll.data_ptr(), ll.data_ptr(), None, None):
     _capi.call('zshmc_linear_bernoulli_log_lik', W.data_ptr(), X.data_ptr(),
-               y.data_ptr(), C, N, D, ll.data_ptr(), gw.data_ptr(), 1, None, s)
+               y.data_ptr(), C, N, D, ll_ptr, gw.data_ptr(), 1, None, s)
 torch.cuda.synchronize()
 print('config3 shape: C=%d N=%d D=%d; algorithmic bytes per launch: X %.3e '
       '(streamed once per 64-chain block: x%d = %.3e) + W, grad 2 x %.3e' % (
@@ -46,10 +48,10 @@ phi_t = _ops._padded_phi_t(phi, K)
 xp, stride = _ops._padded_counts(x)
 ll = torch.empty(rows, device=dev)
 gt = torch.empty(rows, K, device=dev)
-for _ in range(2):
+for ll_ptr in (ll.data_ptr(), ll.data_ptr(), None, None):
     _capi.call('zshmc_linear_multinomial_log_lik', theta.data_ptr(),
                phi_t.data_ptr(), xp.data_ptr(), xp.shape[0], stride, rows, V,
-               K, ll.data_ptr(), gt.data_ptr(), 1, None, s)
+               K, ll_ptr, gt.data_ptr(), 1, None, s)
 torch.cuda.synchronize()
 print('config5 shape: rows=%d K=%d V=%d; algorithmic bytes per launch: theta + '
       'grad 2 x %.3e, phi^T %.3e (x%d row blocks = %.3e), counts gathered '
