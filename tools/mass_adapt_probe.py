@@ -12,6 +12,11 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import zhusuan_amd as zs  # noqa: E402
+from zhusuan_amd import _capi  # noqa: E402
+
+if os.environ.get('PROBE_LIB'):   # another build (tools/build_variants.sh)
+    _capi.LIB_PATH = os.path.abspath(os.environ['PROBE_LIB'])
+    print('# library: %s' % _capi.LIB_PATH, flush=True)
 
 dev = torch.device('cuda', 0)
 
