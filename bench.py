@@ -477,11 +477,13 @@ def extra_config3(torch, zs, dev, n_rows=1000000, n_chains=32768, n_feat=256,
 
 def extra_wide_regression(torch, zs, dev, n_rows=65536, n_chains=8192,
                           n_feat=1000, n_leapfrogs=10, n_warm=4, n_timed=3):
-    """Beyond BASELINE.json: logistic regression with
-    1 000 features AND a per-chain bias, written `w @ X.T + b[:, None]`: two
-    Normal-prior latents on the native plan's packed state (rows of 1 004
-    floats), likelihood on the feature-split MFMA kernel
-    (csrc/linear_bernoulli_wide.hip, padded width 1 024)."""
+    """Beyond BASELINE.json: logistic regression with n_feat features AND a
+    per-chain bias, written `w @ X.T + b[:, None]`: two Normal-prior latents on
+    the native plan's packed state, padded to the kernel width the library
+    names (zshmc_likelihood_plan).  1 000 features: rows of 1 004 floats on
+    the feature-split MFMA kernel (csrc/linear_bernoulli_wide.hip, width
+    1 024); 299 features: the 16-chain-block kernel at width 320
+    (csrc/linear_bernoulli_mid.hip; round 3 padded these to 512)."""
     g = torch.Generator(device=dev).manual_seed(0)
     X = torch.randn(n_rows, n_feat, device=dev, generator=g)
     w_true = torch.randn(n_feat, device=dev, generator=g)
@@ -526,7 +528,8 @@ def extra_wide_regression(torch, zs, dev, n_rows=65536, n_chains=8192,
             _lik_kernel_name(hmc._plan.width, hmc._plan.block), kern_ms, flop_eval,
             n_leapfrogs + 1, ms),
             note='flops counted at the padded width %d (%d useful columns)'
-                 % (width, n_feat + 1)),
+                 % (width, n_feat + 1),
+            useful_flop_fraction=(n_feat + 1.0) / width),
     }
 
 
@@ -1452,6 +1455,8 @@ def main():
             todo = ((extra_config1, {}), (extra_config3, {}),
                     (extra_config5, {'n_chains': args.config5_chains}),
                     (extra_wide_regression, {}),
+                    (extra_wide_regression, {'n_feat': 299,
+                                             'n_chains': 16384}),
                     (extra_softmax_regression, {}), (extra_pmf, {}))
         else:
             todo = ((lntm_workload, dict(

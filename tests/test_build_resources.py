@@ -181,3 +181,56 @@ def test_likelihood_tile_loop_is_hand_ordered(lb_build):
             moved = [l for l in lines[first:last] if 'v_accvgpr' in l]
             assert not moved, moved[:4]
     assert n == 36
+
+
+# The 16-chain-block kernel (csrc/linear_bernoulli_mid.hip, widths 320 .. 896):
+# the same contract -- no scratch, every MFMA from an asm statement.
+MID_SRC = os.path.join(ROOT, 'zhusuan_amd', 'csrc', 'linear_bernoulli_mid.hip')
+
+
+@pytest.fixture(scope='module')
+def mid_build(tmp_path_factory):
+    out = tmp_path_factory.mktemp('midasm')
+    import __graft_entry__ as ge
+    cmd = [_hipcc()] + ge.HIPCC_FLAGS + [
+        '-c', MID_SRC, '-save-temps', '-Rpass-analysis=kernel-resource-usage',
+        '-o', str(out / 'mid.o')]
+    p = subprocess.run(cmd, cwd=str(out), stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, universal_newlines=True)
+    assert p.returncode == 0, p.stdout[-4000:]
+    asm = [f for f in os.listdir(str(out)) if f.endswith('gfx950.s')]
+    assert asm, os.listdir(str(out))
+    return p.stdout, open(os.path.join(str(out), asm[0])).read()
+
+
+def test_mid_likelihood_kernels_have_no_spills_and_hand_ordered_mfmas(mid_build):
+    remarks, asm = mid_build
+    table = {k: v for k, v in _kernels(remarks).items()
+             if 'linear_bernoulli_mid_kernelILi' in k}
+    # 10 widths x 3 element-wise stages x {ll+grad, grad only, ll only}
+    assert len(table) == 90, len(table)
+    for name, row in table.items():
+        assert row['VGPRs Spill'] == 0, (name, row)
+        assert row['ScratchSize [bytes/lane]'] == 0, (name, row)
+    n = 0
+    for m in re.finditer(r'^(_ZN5zshmc27linear_bernoulli_mid_kernelILi(\d+)ELb(\d)'
+                         r'ELi(\d)ELb(\d)E\w+):[^\n]*\n(.*?)s_endpgm',
+                         asm, re.S | re.M):
+        n += 1
+        name, width, grad, op, ll, body = m.groups()
+        in_asm, mfma_out, mfma_in = False, 0, 0
+        for line in body.splitlines():
+            if '#ASMSTART' in line:
+                in_asm = True
+            elif '#ASMEND' in line:
+                in_asm = False
+            if line.strip().startswith('v_mfma'):
+                if in_asm:
+                    mfma_in += 1
+                else:
+                    mfma_out += 1
+        assert mfma_out == 0, name
+        # D/4 MFMAs of phase 1 (+ D/4 of phase 3), one copy of the tile
+        assert mfma_in == int(width) // 4 * (2 if grad == '1' else 1), (
+            name, mfma_in)
+    assert n == 90
