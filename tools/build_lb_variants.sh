@@ -1,8 +1,8 @@
 #!/bin/bash
 # A/B builds of the two-GEMM likelihood kernels:
 #   tools/build_lb_variants.sh TAG "-DFLAG ..." [TAG2 "..."]...
-# -> build/variants/libzshmc_TAG.so (only csrc/linear_bernoulli.hip and
-# csrc/linear_bernoulli_wide.hip are recompiled with the extra flags; the other
+# -> build/variants/libzshmc_TAG.so (only csrc/linear_bernoulli*.hip are
+# recompiled with the extra flags; the other
 # objects come from build/obj).  Time them with
 #   LB_LIB=build/variants/libzshmc_TAG.so python tools/lb_modes_bench.py
 set -e
@@ -14,7 +14,7 @@ python -c "import __graft_entry__ as g; g.build()" >/dev/null
 while [ $# -ge 2 ]; do
   tag=$1; extra=$2; shift 2
   d=build/variants/obj_$tag; mkdir -p $d
-  for f in linear_bernoulli linear_bernoulli_wide; do
+  for f in linear_bernoulli linear_bernoulli_mid linear_bernoulli_wide; do
     $HIPCC $FLAGS $extra -c zhusuan_amd/csrc/$f.hip -o $d/$f.hip.o &
   done
   wait
