@@ -37,20 +37,6 @@ __device__ __forceinline__ float swizzle_xor16(float v) {
       float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401f));
 }
 
-// all-reduce over the aligned group of 2^gl consecutive lanes (gl = 0..5,
-// wave-uniform) a lane belongs to
-template <bool MAX>
-__device__ __forceinline__ float lane_group_allreduce(float v, int gl) {
-#define ZS_COMBINE(o) v = MAX ? fmaxf(v, (o)) : v + (o)
-  if (gl >= 1) ZS_COMBINE(dpp_move<0xb1>(v));   // quad_perm [1,0,3,2]
-  if (gl >= 2) ZS_COMBINE(dpp_move<0x4e>(v));   // quad_perm [2,3,0,1]
-  if (gl >= 3) ZS_COMBINE(dpp_move<0x141>(v));  // row_half_mirror
-  if (gl >= 4) ZS_COMBINE(dpp_move<0x140>(v));  // row_mirror
-  if (gl >= 5) ZS_COMBINE(swizzle_xor16(v));
-#undef ZS_COMBINE
-  return v;
-}
-
 struct CatLane {
   int gl;          // log2 of the class stride G
   float kcls;      // this lane's class (column % G) as a float
@@ -63,26 +49,91 @@ __device__ __forceinline__ CatLane cat_lane(int column, int n_classes,
   return CatLane{gl, (float)k, k < n_classes};
 }
 
+// One butterfly step as ONE instruction: v <- op(v, dpp(v)) with the DPP
+// modifier on the operand (hipcc's fmaxf on a moved value is v_mov_b32_dpp + a
+// canonicalising v_max + the v_max: three).  A DPP read of a VGPR needs two
+// wait states behind a VALU write of it and hipcc does not look inside asm:
+// `s_nop 1` in front (free next to the MFMAs around it).
+#define ZS_DPP_STEP(NAME, OPC, CTRL)                                          \
+  __device__ __forceinline__ float NAME(float v) {                            \
+    asm("s_nop 1\n\t" OPC " %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf"    \
+        : "+v"(v));                                                           \
+    return v;                                                                 \
+  }
+ZS_DPP_STEP(dpp_max_q1, "v_max_f32_dpp", "quad_perm:[1,0,3,2]")
+ZS_DPP_STEP(dpp_max_q2, "v_max_f32_dpp", "quad_perm:[2,3,0,1]")
+ZS_DPP_STEP(dpp_max_hm, "v_max_f32_dpp", "row_half_mirror")
+ZS_DPP_STEP(dpp_max_rm, "v_max_f32_dpp", "row_mirror")
+ZS_DPP_STEP(dpp_add_q1, "v_add_f32_dpp", "quad_perm:[1,0,3,2]")
+ZS_DPP_STEP(dpp_add_q2, "v_add_f32_dpp", "quad_perm:[2,3,0,1]")
+ZS_DPP_STEP(dpp_add_hm, "v_add_f32_dpp", "row_half_mirror")
+ZS_DPP_STEP(dpp_add_rm, "v_add_f32_dpp", "row_mirror")
+#undef ZS_DPP_STEP
+
+// all-reduce over the aligned group of 2^GL consecutive lanes a lane belongs
+// to, GL = 0..5 a compile-time constant (straight-line code)
+template <int GL, bool MAX>
+__device__ __forceinline__ float lane_group_allreduce_c(float v) {
+  if constexpr (GL >= 1) v = MAX ? dpp_max_q1(v) : dpp_add_q1(v);
+  if constexpr (GL >= 2) v = MAX ? dpp_max_q2(v) : dpp_add_q2(v);
+  if constexpr (GL >= 3) v = MAX ? dpp_max_hm(v) : dpp_add_hm(v);
+  if constexpr (GL >= 4) v = MAX ? dpp_max_rm(v) : dpp_add_rm(v);
+  if constexpr (GL >= 5) {
+    const float o = swizzle_xor16(v);
+    v = MAX ? fmaxf(v, o) : v + o;
+  }
+  return v;
+}
+
 // logit `sv` of (chain, class) column for data row n with label `label`
 // (a float holding 0 .. n_classes-1): returns the residual
 // [k == label] - softmax_k and adds the row's log-likelihood term to `lp` on
 // the label's lane.  Every lane of the wave must call it (cross-lane ops).
-template <bool LL = true>
-__device__ __forceinline__ float categorical_residual(float sv, float label,
-                                                      const CatLane& c,
-                                                      bool valid, float& lp) {
+// GL = log2 of the class stride, compile-time (categorical_residual_n picks it).
+template <int GL, bool LL>
+__device__ __forceinline__ float categorical_residual_c(float sv, float label,
+                                                        const CatLane& c,
+                                                        bool valid, float& lp) {
   const float sm = c.cls_on ? sv : -INFINITY;
-  const float m = lane_group_allreduce<true>(sm, c.gl);
+  const float m = lane_group_allreduce_c<GL, true>(sm);
   const float d = sv - m;
   const float e =
       c.cls_on ? __builtin_amdgcn_exp2f(1.4426950408889634f * d) : 0.f;
-  const float z = lane_group_allreduce<false>(e, c.gl);   // in [1, G]
+  const float z = lane_group_allreduce_c<GL, false>(e);   // in [1, G]
   const float p = e * __builtin_amdgcn_rcpf(z);
   const bool hit = valid && label == c.kcls;
   if (LL) lp += hit ? d - 0.6931471805599453f * __builtin_amdgcn_logf(z) : 0.f;
   return (valid && c.cls_on) ? (hit ? 1.0f : 0.f) - p : 0.f;
 }
 
+// N logits at once (the rows of one element-wise slot of the kernels): ONE
+// wave-uniform branch on the class stride for all of them, then straight-line
+// code in which the N independent butterflies fill each other's DPP wait
+// states.  (With the stride a run-time value inside the per-element code hipcc
+// emitted a scalar branch per butterfly step: 160 branches per 64-row tile.)
+template <bool LL, int N>
+__device__ __forceinline__ void categorical_residual_n(float (&sv)[N],
+                                                       const float (&label)[N],
+                                                       const CatLane& c,
+                                                       const bool (&valid)[N],
+                                                       float& lp) {
+#define ZS_CAT_CASE(G)                                                        \
+  case G:                                                                     \
+    _Pragma("unroll") for (int i = 0; i < N; ++i) sv[i] =                     \
+        categorical_residual_c<G, LL>(sv[i], label[i], c, valid[i], lp);      \
+    break;
+  switch (c.gl) {
+    ZS_CAT_CASE(0)
+    ZS_CAT_CASE(1)
+    ZS_CAT_CASE(2)
+    ZS_CAT_CASE(3)
+    ZS_CAT_CASE(4)
+    default:
+      _Pragma("unroll") for (int i = 0; i < N; ++i) sv[i] =
+          categorical_residual_c<5, LL>(sv[i], label[i], c, valid[i], lp);
+  }
+#undef ZS_CAT_CASE
+}
 
 // The element-wise stage between the two GEMMs of the fused likelihood
 // kernels, on one logit `sv` of (chain, data row): returns the residual
@@ -93,7 +144,8 @@ __device__ __forceinline__ float categorical_residual(float sv, float label,
 //   OP 1  UnnormalizedMultinomial over a mixture (multivariate.py:435-443,
 //         normalize_logits = False): x*log(S), d/dS = x / S; `aux` = the
 //         count x (0 contributes nothing, also where the product underflows).
-//   OP 2  Categorical (csrc/lb_ops.h above); `aux` = the label.
+//   OP 2  Categorical (above; the kernels take categorical_residual_n for a
+//         whole slot of rows instead); `aux` = the label.
 // LL = false: the residual alone (sigmoid as 1 / (1 + 2^(-l log2 e)): l ->
 // -inf gives 1 / inf = 0, l -> +inf 1 / 1).  `valid` = false: a row past N.
 template <int OP, bool LL>
@@ -118,7 +170,12 @@ __device__ __forceinline__ float lb_residual(float sv, float aux,
       return valid ? aux - sig : 0.f;
     }
   } else if constexpr (OP == 2) {
-    return categorical_residual<LL>(sv, aux, cat, valid, ll_tile);
+    // (one element: the kernels call categorical_residual_n on a slot's rows)
+    float v[1] = {sv};
+    const float l[1] = {aux};
+    const bool ok[1] = {valid};
+    categorical_residual_n<LL, 1>(v, l, cat, ok, ll_tile);
+    return v[0];
   } else {
     const bool on = valid && aux != 0.f;
     if constexpr (LL) {

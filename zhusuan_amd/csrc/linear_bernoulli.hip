@@ -400,6 +400,27 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel(
       const float aux = OP == 1 ? xcnt[r] : yv[r >> 2][r & 3];
       S[r] = lb_residual<OP, LL>(S[r], aux, cat, valid, ll_tile);
     };
+    // the four rows r0 .. r0+3 of one slot (r0 a multiple of 4: one register
+    // group, one b128 of labels); the Categorical takes them together -- one
+    // branch on the class stride for the slot (csrc/lb_ops.h)
+    auto residual4 = [&](int r0) {
+      if constexpr (OP == 2) {
+        float v[4], lab[4];
+        bool ok[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          v[q] = S[r0 + q];
+          lab[q] = yv[r0 >> 2][q];
+          ok[q] = !MASK || b * 32 + q + 8 * (r0 >> 2) + 4 * hi < rows_left;
+        }
+        categorical_residual_n<LL, 4>(v, lab, cat, ok, ll_tile);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) S[r0 + q] = v[q];
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) residual(r0 + q);
+      }
+    };
     // end of tile: labels of tile t+1 published, its X rows landed, barrier,
     // and the first reads of tile t+1 behind it
     auto end_of_tile = [&]() {
@@ -419,8 +440,7 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel(
       // 22 of issue -- the wave's own VALU does not run under its MFMAs);
       // kRG independent chains in one slot fill each other's latencies.
       constexpr int kRG = 4;
-#pragma unroll
-      for (int q = 0; q < kRG; ++q) residual(q);
+      residual4(0);
       __builtin_amdgcn_sched_barrier(0);
       ZS_LB_MARK(1)  // drain + first residual
       // ---- phase 3: own rows, A = the residual register ---------------------
@@ -443,8 +463,7 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel(
         });
         if constexpr (r + 1 < 16 && (r + 1) % kRG == 0) {
           __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int q = 0; q < kRG; ++q) residual(r + 1 + q);
+          residual4(r + 1);
           __builtin_amdgcn_sched_barrier(0);
         } else if (r + 1 == 16) {
           // every read of this buffer has returned (lgkmcnt(0) above); the
@@ -460,7 +479,7 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel(
       ZS_LB_MARK(2)  // phase 3 (the tile barrier inside it)
     } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) residual(r);
+      for (int g = 0; g < 4; ++g) residual4(4 * g);
       __builtin_amdgcn_sched_barrier(0);
       end_of_tile();
     }

@@ -273,11 +273,26 @@ __global__ __launch_bounds__(256, 1) void linear_bernoulli_mid_kernel(
     // ---- element-wise stage: lane holds chain 16a + l16, rows 4 q4 + r ------
     const int rows_left = (int)((N - tile * kRows) < kRows ? (N - tile * kRows)
                                                            : kRows);
+    if constexpr (OP == 2) {
+      // the four rows together: one branch on the class stride (csrc/lb_ops.h)
+      float v[4], lab[4];
+      bool ok[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const bool valid = !MASK || 4 * q4 + r < rows_left;
-      const float aux = OP == 1 ? xcnt[r] : yv[r];
-      S[r] = lb_residual<OP, LL>(S[r], aux, cat, valid, ll_tile);
+      for (int r = 0; r < 4; ++r) {
+        v[r] = S[r];
+        lab[r] = yv[r];
+        ok[r] = !MASK || 4 * q4 + r < rows_left;
+      }
+      categorical_residual_n<LL, 4>(v, lab, cat, ok, ll_tile);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) S[r] = v[r];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool valid = !MASK || 4 * q4 + r < rows_left;
+        const float aux = OP == 1 ? xcnt[r] : yv[r];
+        S[r] = lb_residual<OP, LL>(S[r], aux, cat, valid, ll_tile);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
 

@@ -330,8 +330,6 @@ __global__ __launch_bounds__(256, D == 256 ? 2 : 1) void linear_bernoulli_wide_k
     ZS_LBW_MARK(1)  // barrier 1
 
     // ---- residual of register group f (fixed summation order) --------------
-    // Bernoulli._log_prob (univariate.py:398-403):
-    //   l*y - max(l,0) - log1p(exp(-|l|));   d/dl = y - sigmoid(l)
     {
       w4 s = *reinterpret_cast<const w4*>(sP + ((0 * 4 + f) * 64 + lane) * 4);
 #pragma unroll
@@ -341,39 +339,27 @@ __global__ __launch_bounds__(256, D == 256 ? 2 : 1) void linear_bernoulli_wide_k
           (int)((N - tile * kWR) < kWR ? (N - tile * kWR) : kWR);
       float ll_tile = 0.f;
       w4 res;
+      // the element-wise stage of csrc/lb_ops.h on this lane's 4 elements
+      if constexpr (OP == 2) {
+        float v[4], lab[4];
+        bool ok[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int nl = j + 8 * f + 4 * hi;
-        const bool valid = nl < rows_left;
-        const float sv = s[j];
-        if (OP == 0) {
-          const float yv = sY[buf * kWR + nl];
-          const float e =
-              __builtin_amdgcn_exp2f(-1.4426950408889634f * fabsf(sv));
-          const float t1 = 1.0f + e;
-          const float inv = __builtin_amdgcn_rcpf(t1);
-          const float sig = 0.5f + __builtin_copysignf(inv - 0.5f, sv);
-          res[j] = valid ? yv - sig : 0.f;
-          if (LL) {
-            const float lp = sv * yv - fmaxf(sv, 0.f) -
-                             0.6931471805599453f * __builtin_amdgcn_logf(t1);
-            ll_tile += valid ? lp : 0.f;
-          }
-        } else if (OP == 2) {
-          res[j] = categorical_residual<LL>(sv, sY[buf * kWR + nl], cat, valid,
-                                            ll_tile);
-        } else {
-          // sum_v x_v log((theta.phi)_v) and d/d(theta.phi) = x / (theta.phi)
-          // (multivariate.py:435-443, normalize_logits = False); x = 0
-          // contributes nothing (also where the product underflows)
-          const float xv = xcnt[j];
-          const bool on = valid && xv != 0.f;
-          res[j] = on ? xv * __builtin_amdgcn_rcpf(sv) : 0.f;
-          if (LL) {
-            const float lp =
-                xv * (0.6931471805599453f * __builtin_amdgcn_logf(sv));
-            ll_tile += on ? lp : 0.f;
-          }
+        for (int j = 0; j < 4; ++j) {
+          const int nl = j + 8 * f + 4 * hi;
+          v[j] = s[j];
+          lab[j] = sY[buf * kWR + nl];
+          ok[j] = nl < rows_left;
+        }
+        categorical_residual_n<LL, 4>(v, lab, cat, ok, ll_tile);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) res[j] = v[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int nl = j + 8 * f + 4 * hi;
+          const bool valid = nl < rows_left;
+          const float aux = OP == 1 ? xcnt[j] : sY[buf * kWR + nl];
+          res[j] = lb_residual<OP, LL>(s[j], aux, cat, valid, ll_tile);
         }
       }
       if (LL) ll_lane += (double)ll_tile;
