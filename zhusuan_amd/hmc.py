@@ -653,6 +653,11 @@ class HMC(object):
         return out
 
     def set_state(self, state):
+        """Restore `get_state()`'s snapshot.  With sharded chains: call it on
+        every rank alike (and write to a sharded latent on every rank or on
+        none) -- whether the next run takes fresh column sums, and all-reduces
+        them, is decided from rank-local state; a rank that diverges here
+        enters a collective the others skip."""
         plan = self._plan
         plan.pending = None
         if plan.colsum_state in ('fresh', 'parts'):
