@@ -204,7 +204,7 @@ def test_config3_full_size_properties(env):
                                    atol=2e-5 * np.abs(g_ref).max())
 
 
-@pytest.mark.parametrize('D', [64, 256, 512, 1024])
+@pytest.mark.parametrize('D', [64, 192, 256, 320, 512, 832, 1024])
 def test_row_range_splits_match_single_pass(D):
     """n_splits > 1 (small chain counts) is the same sum in a different, fixed
     association: equal to the unsplit launch within fp32 re-association, and
@@ -240,6 +240,31 @@ def test_row_range_splits_match_single_pass(D):
         assert torch.equal(ll, ll_b) and torch.equal(gw, gw_b)
         ll_n, _ = run(splits, grad=False)
         torch.testing.assert_close(ll_n, ll1, rtol=1e-5, atol=1e-2)
+        # gradient only (log_lik = NULL), the form a trajectory's interior
+        # evaluations take: its own instantiation (no row masks, zeroed tail)
+        gw_o = torch.empty(C, D, device=dev)
+        ws = torch.empty(splits * C * (D + 1), device=dev)
+        _capi.call('zshmc_linear_bernoulli_log_lik', W.data_ptr(), X.data_ptr(),
+                   y.data_ptr(), C, N, D, None, gw_o.data_ptr(), splits,
+                   ws.data_ptr(), s)
+        torch.testing.assert_close(gw_o, g1, rtol=1e-4, atol=1e-3)
+    # more splits than tiles: the trailing row ranges are empty and contribute
+    # zeros (a caller of the C-ABI may ask for this; the front-end never does)
+    n_few = 70
+    ll_f = torch.empty(C, device=dev)
+    gw_f = torch.empty(C, D, device=dev)
+    ws = torch.empty(64 * C * (D + 1), device=dev)
+    _capi.call('zshmc_linear_bernoulli_log_lik', W.data_ptr(), X.data_ptr(),
+               y.data_ptr(), C, n_few, D, ll_f.data_ptr(), gw_f.data_ptr(), 64,
+               ws.data_ptr(), s)
+    z = (W.double() @ X[:n_few].double().t())
+    torch.testing.assert_close(
+        ll_f.double(), (y[:n_few].double() * z -
+                        torch.nn.functional.softplus(z)).sum(-1),
+        rtol=1e-5, atol=1e-3)
+    torch.testing.assert_close(
+        gw_f.double(), (y[:n_few].double() - torch.sigmoid(z)) @
+        X[:n_few].double(), rtol=1e-4, atol=1e-3)
     with pytest.raises(_capi.ZshmcError):
         ll = torch.empty(C, device=dev)
         _capi.call('zshmc_linear_bernoulli_log_lik', W.data_ptr(), X.data_ptr(),

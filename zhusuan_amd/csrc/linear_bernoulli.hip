@@ -240,7 +240,11 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel(
     if (GRAD) gW += (int64_t)blockIdx.y * C * ldw;
   }
   {
-    const TileSrc t0 = tile_src(tile_begin * kRows, 0);
+    // (a row range with no tiles -- more splits than tiles -- streams the last
+    // tile and never uses it: its partial sums are the zeros of the epilogue)
+    const int64_t t_first =
+        tile_begin < n_tiles_all ? tile_begin : n_tiles_all - 1;
+    const TileSrc t0 = tile_src(t_first * kRows, 0);
 #pragma unroll
     for (int j = 0; j < 16; ++j) dma_row(t0, j);
   }

@@ -165,7 +165,10 @@ __global__ __launch_bounds__(256, 1) void linear_bernoulli_mid_kernel(
     if (GRAD) gW += (int64_t)blockIdx.y * C * ldw;
   }
   {
-    const TileSrc t0 = tile_src(tile_begin * kRows, 0);
+    // (a row range with no tiles streams the last tile and never uses it)
+    const int64_t t_first =
+        tile_begin < n_tiles_all ? tile_begin : n_tiles_all - 1;
+    const TileSrc t0 = tile_src(t_first * kRows, 0);
     static_for<kDma>([&](auto ic) { dma_piece(t0, ic); });
   }
   if (OP != 1 && tid < kRows) {
