@@ -1,7 +1,9 @@
 #!/usr/bin/env python
-"""Round 3: the feature-split likelihood kernel (csrc/linear_bernoulli_wide.hip,
-padded widths 512 / 1024) timed against the 256-wide kernel at the same flop
-count, and checked against a float64 reference on a sub-block.
+"""The likelihood kernels above 256 columns -- width 512 (round 3: the
+feature-split kernel; since round 4 the 16-chain-block kernel of
+csrc/linear_bernoulli_mid.hip) and 1024 (csrc/linear_bernoulli_wide.hip) --
+timed against the 256-wide kernel at the same flop count, and checked against
+a float64 reference on a sub-block.
   python tools/lb_wide_bench.py [n_chains] [n_rows]"""
 import json
 import os

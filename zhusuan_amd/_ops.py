@@ -567,7 +567,7 @@ def packed_design(blocks, n_rows, device, width=None):
 
 
 def _row_splits(n_blocks_rows, n_inner, device, block=64):
-    """Fewer chain blocks (64 rows; 32 for the wide kernel) than compute
+    """Fewer chain blocks (`block` rows: zshmc_likelihood_plan) than compute
     units: cut the inner (data row / vocabulary) range so that about two
     workgroups land on every CU, at least 256 inner rows per slice, at most
     32 slices.  (Round 4, the E-step of lntm_mcem.py:157-182 -- 100 documents
