@@ -955,6 +955,10 @@ def main():
     sharding, collective_note = None, 'no collective'
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if os.environ['MASTER_ADDR'] in ('127.0.0.1', 'localhost'):
+            # one node: the bootstrap group talks over loopback whatever the
+            # box's hostname resolves to (or does not)
+            os.environ.setdefault('GLOO_SOCKET_IFNAME', 'lo')
         dist.init_process_group(backend='gloo', rank=rank, world_size=world)
     if args.workload == 'lntm':
         run_lntm_line(args, torch, zs, dist, ChainSharding, dev, world, rank,
