@@ -39,9 +39,12 @@ __device__ __forceinline__ float vget(const V& v, int t) {
 }
 
 // global -> LDS, BYTES (4, 8 = 2x4, 12, 16) per lane, LDS dest = dst + lane*BYTES
-template <int BYTES>
+// (HALF: a 512-byte row is two instructions; 0 / 1 issues only the first /
+// second, for callers that place them in different issue gaps)
+template <int BYTES, int HALF = -1>
 __device__ __forceinline__ void lds_dma_row(const float* src, uint32_t dst,
                                             uint32_t lane) {
+  if constexpr (BYTES != 8 && HALF == 1) return;  // one instruction: half 0
   static_assert(BYTES == 4 || BYTES == 8 || BYTES == 12 || BYTES == 16,
                 "a row is 256 B, 512 B, 768 B or 1 KB");
   if constexpr (BYTES == 12) {
@@ -69,14 +72,15 @@ __device__ __forceinline__ void lds_dma_row(const float* src, uint32_t dst,
         : "memory");
   } else {
     const uint32_t voff = lane * 4u;
-    asm volatile(
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dword %0, %1"
-        :
-        : "v"(voff), "s"(src), "s"(dst)
-        : "memory");
-    if constexpr (BYTES == 8)
+    if constexpr (HALF != 1)
+      asm volatile(
+          "s_mov_b32 m0, %2\n\t"
+          "s_nop 0\n\t"
+          "global_load_lds_dword %0, %1"
+          :
+          : "v"(voff), "s"(src), "s"(dst)
+          : "memory");
+    if constexpr (BYTES == 8 && HALF != 0)
       asm volatile(
           "s_mov_b32 m0, %2\n\t"
           "s_nop 0\n\t"
@@ -142,33 +146,24 @@ __device__ __forceinline__ void mfma_a(f16v& acc, float a, float b) {
                : "v"(a), "v"(b));
 }
 
-// One phase-1 step, 4 MFMAs of one accumulator chain, as ONE statement:
-// between two asm statements that pass a VGPR hipcc puts an `s_nop 0` (it
-// cannot see what the first one did to the register) and schedules its own
-// scalar arithmetic -- issue slots between dependent MFMAs of a chain.
+// One MFMA of a phase-1 accumulator chain in VGPRs (S = 0 + a b for the first).
+// One statement per MFMA: a wave issues one instruction per ~4 clocks and an
+// MFMA holds the pipe for 64 (32x32x2) or 32 (16x16x4), so ~15 / ~7 other
+// instructions fit between two MFMAs of a chain for free -- the callers put a
+// step's LDS read, DMA instructions and scalar arithmetic there.  (A dependent
+// MFMA on the same accumulator needs no wait states, and none are lost to
+// what is issued in between; hipcc adds an `s_nop 0` between two statements
+// that pass a VGPR: one slot.)
 template <bool FIRST>
-__device__ __forceinline__ void p1_step(f16v& S, const f4& aa, float w0,
-                                        float w1, float w2, float w3) {
+__device__ __forceinline__ void mfma_v(f16v& S, float a, float b) {
   if constexpr (FIRST)
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_mfma_f32_32x32x2_f32 %0, %1, %5, 0\n\t"
-        "v_mfma_f32_32x32x2_f32 %0, %2, %6, %0\n\t"
-        "v_mfma_f32_32x32x2_f32 %0, %3, %7, %0\n\t"
-        "v_mfma_f32_32x32x2_f32 %0, %4, %8, %0"
-        : "=&v"(S)
-        : "v"(aa[0]), "v"(aa[1]), "v"(aa[2]), "v"(aa[3]), "v"(w0), "v"(w1),
-          "v"(w2), "v"(w3));
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, 0"
+                 : "=&v"(S)
+                 : "v"(a), "v"(b));
   else
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_mfma_f32_32x32x2_f32 %0, %1, %5, %0\n\t"
-        "v_mfma_f32_32x32x2_f32 %0, %2, %6, %0\n\t"
-        "v_mfma_f32_32x32x2_f32 %0, %3, %7, %0\n\t"
-        "v_mfma_f32_32x32x2_f32 %0, %4, %8, %0"
-        : "+v"(S)
-        : "v"(aa[0]), "v"(aa[1]), "v"(aa[2]), "v"(aa[3]), "v"(w0), "v"(w1),
-          "v"(w2), "v"(w3));
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x2_f32 %0, %1, %2, %0"
+                 : "+v"(S)
+                 : "v"(a), "v"(b));
 }
 
 // ---- the same on v_mfma_f32_16x16x4_f32 (8 passes, 4 accumulator registers:
@@ -178,29 +173,17 @@ __device__ __forceinline__ void mfma16_a(f4& acc, float a, float b) {
                : "+a"(acc)
                : "v"(a), "v"(b));
 }
+// one MFMA of a phase-1 chain in VGPRs (S = 0 + a b for the first)
 template <bool FIRST>
-__device__ __forceinline__ void p1_step16(f4& S, const f4& aa, float w0,
-                                          float w1, float w2, float w3) {
+__device__ __forceinline__ void mfma16_v(f4& S, float a, float b) {
   if constexpr (FIRST)
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_mfma_f32_16x16x4_f32 %0, %1, %5, 0\n\t"
-        "v_mfma_f32_16x16x4_f32 %0, %2, %6, %0\n\t"
-        "v_mfma_f32_16x16x4_f32 %0, %3, %7, %0\n\t"
-        "v_mfma_f32_16x16x4_f32 %0, %4, %8, %0"
-        : "=&v"(S)
-        : "v"(aa[0]), "v"(aa[1]), "v"(aa[2]), "v"(aa[3]), "v"(w0), "v"(w1),
-          "v"(w2), "v"(w3));
+    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, 0"
+                 : "=&v"(S)
+                 : "v"(a), "v"(b));
   else
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_mfma_f32_16x16x4_f32 %0, %1, %5, %0\n\t"
-        "v_mfma_f32_16x16x4_f32 %0, %2, %6, %0\n\t"
-        "v_mfma_f32_16x16x4_f32 %0, %3, %7, %0\n\t"
-        "v_mfma_f32_16x16x4_f32 %0, %4, %8, %0"
-        : "+v"(S)
-        : "v"(aa[0]), "v"(aa[1]), "v"(aa[2]), "v"(aa[3]), "v"(w0), "v"(w1),
-          "v"(w2), "v"(w3));
+    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0"
+                 : "+v"(S)
+                 : "v"(a), "v"(b));
 }
 __device__ __forceinline__ void mfma_drain(f4& acc) {
   asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc));

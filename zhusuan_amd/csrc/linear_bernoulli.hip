@@ -187,25 +187,29 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel(
     return TileSrc{X + n0 * ldx, (int)(left < kRows - 1 ? left : kRows - 1),
                    dst_wave + (uint32_t)buf * kBufBytes};
   };
-  auto dma_row = [&](const TileSrc& t, int j) {
+  auto dma_row = [&](const TileSrc& t, int j, auto half) {
     const int row = wave_u * 16 + j;
     const int r = row < t.last ? row : t.last;
-    lds_dma_row<kDmaB>(t.base + r * ldx32, t.dst + (uint32_t)(j * LD * 4),
-                       (uint32_t)lane);
+    lds_dma_row<kDmaB, decltype(half)::value>(
+        t.base + r * ldx32, t.dst + (uint32_t)(j * LD * 4), (uint32_t)lane);
   };
-  // the 64 labels of a tile: one more DMA row (wave 0), lane n <- y[n0 + n],
-  // clamped like the X rows (what a row past N carries never matters: masked
-  // with the log-likelihood, a zero operand row without)
-  const uint32_t lane_b = (uint32_t)lane;
+  constexpr std::integral_constant<int, -1> kWhole{};
+  // the 64 labels of a tile: wave w brings labels 16w .. 16w+15 with one
+  // 16-lane DMA (no branch in the step), lane n <- y[n0 + 16w + n], clamped
+  // like the X rows (what a row past N carries never matters: masked with the
+  // log-likelihood, a zero operand row without)
+  const uint32_t lane_b = (uint32_t)(wave_u * 16) + ((uint32_t)lane & 15u);
   auto dma_labels = [&](const TileSrc& t, int64_t n0, int buf) {
     const uint32_t l = lane_b < (uint32_t)t.last ? lane_b : (uint32_t)t.last;
     const uint32_t voff = l * 4u;
     const float* src = y + n0;
-    const uint32_t dst = sy_addr + (uint32_t)(buf * kRows * 4);
+    const uint32_t dst =
+        sy_addr + (uint32_t)(buf * kRows * 4) + (uint32_t)(wave_u * 64);
     asm volatile(
         "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dword %0, %1"
+        "s_bfm_b64 exec, 16, 0\n\t"
+        "global_load_lds_dword %0, %1\n\t"
+        "s_mov_b64 exec, -1"
         :
         : "v"(voff), "s"(src), "s"(dst)
         : "memory");
@@ -246,7 +250,7 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel(
         tile_begin < n_tiles_all ? tile_begin : n_tiles_all - 1;
     const TileSrc t0 = tile_src(t_first * kRows, 0);
 #pragma unroll
-    for (int j = 0; j < 16; ++j) dma_row(t0, j);
+    for (int j = 0; j < 16; ++j) dma_row(t0, j, kWhole);
   }
   if (OP != 1 && tid < kRows) {
     const int64_t nr = tile_begin * kRows + tid;
@@ -364,30 +368,44 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel(
 
     // ---- phase 1: own 32 rows, full K, one accumulator chain ---------------
     f16v S;
+    // A step = 4 MFMAs (64 clocks each) of the one accumulator chain.  The
+    // wave issues one instruction per ~4 clocks, so a gap between two MFMAs
+    // takes ~15 other instructions for free: the step's LDS read, its DMA
+    // row(s) and the scalar address arithmetic are spread over the three gaps
+    // (all behind the fourth MFMA they were ~26 issue slots in a 16-slot gap:
+    // +41 clocks per step at D = 128, profiles/r04y_lb_phase_d128.txt).
     static_for<KK>([&](auto kc) {
       constexpr int kk = decltype(kc)::value;
+      if constexpr (kk == 0) wait_lgkm<0>();   // the head's reads
+      mfma_v<kk == 0>(S, av[kk & 1][0], wreg[kk * 4]);
+      // gap 1: the next step's operand / phase 3's first operand row
       if constexpr (kk + 1 < KK) {
         lds_read<(kk + 1) * 32>(av[(kk + 1) & 1], a_addr);
-        wait_lgkm<1>();
-      } else {
-        wait_lgkm<0>();
-        if constexpr (GRAD) {  // phase 3's first operand row
-          static_for<NH>([&](auto hc) {
-            constexpr int h = decltype(hc)::value;
-            lds_read<h * 32 * VW * 4>(xv[0][h], x_addr);
-          });
-        }
+        // (and, once, the wave's 16 labels of tile t+1)
+        if constexpr (OP != 1 && kk == 1) dma_labels(tnext, n_next, buf ^ 1);
+      } else if constexpr (GRAD) {
+        static_for<NH>([&](auto hc) {
+          constexpr int h = decltype(hc)::value;
+          lds_read<h * 32 * VW * 4>(xv[0][h], x_addr);
+        });
       }
-      // the 16 DMA rows of tile t+1 over the first steps
-      if constexpr (kk == 0 && OP != 1) {
-        if (wave_u == 0) dma_labels(tnext, n_next, buf ^ 1);
-      }
-      if constexpr (kk * kDmaPer < 16) {
+      mfma_v<false>(S, av[kk & 1][1], wreg[kk * 4 + 1]);
+      // gaps 2, 3: the 16 DMA rows of tile t+1 over the first steps
+      // (a 512-byte row is two instructions: one per gap)
+      constexpr bool kHalves = kDmaB == 8 && kDmaPer == 1;
+      if constexpr (kk * kDmaPer < 16)
+        dma_row(tnext, kk * kDmaPer,
+                std::integral_constant<int, kHalves ? 0 : -1>{});
+      mfma_v<false>(S, av[kk & 1][2], wreg[kk * 4 + 2]);
+      if constexpr (kHalves && kk < 16)
+        dma_row(tnext, kk, std::integral_constant<int, 1>{});
+      if constexpr (kDmaPer > 1 && kk * kDmaPer + 1 < 16) {
 #pragma unroll
-        for (int j = 0; j < kDmaPer; ++j) dma_row(tnext, kk * kDmaPer + j);
+        for (int j = 1; j < kDmaPer; ++j)
+          dma_row(tnext, kk * kDmaPer + j, kWhole);
       }
-      p1_step<kk == 0>(S, av[kk & 1], wreg[kk * 4], wreg[kk * 4 + 1],
-                       wreg[kk * 4 + 2], wreg[kk * 4 + 3]);
+      mfma_v<false>(S, av[kk & 1][3], wreg[kk * 4 + 3]);
+      wait_lgkm<0>();   // the read of gap 1, three MFMAs old
     });
     // S is complete 16 passes + write-back after the last MFMA issued
     ZS_LB_MARK(0)  // head + phase 1 (issue)
@@ -593,7 +611,12 @@ static int launch_lb(const float* W, const float* X, const float* y,
                      int n_classes = 0, int cls_log2 = 0) {
   constexpr int LD = D + 4;
   // two X tile buffers, two label buffers, 128 doubles for the epilogue
+#ifdef ZS_LB_LDS_PAD  // (A/B) fewer workgroups per CU
+  const size_t lds = (size_t)(2 * 64 * LD + 2 * 64) * sizeof(float) + 128 * 8 +
+                     (D <= 128 ? ZS_LB_LDS_PAD : 0);
+#else
   const size_t lds = (size_t)(2 * 64 * LD + 2 * 64) * sizeof(float) + 128 * 8;
+#endif
   static bool attr2 = false;
   if (!attr2) {
     hipError_t e = hipFuncSetAttribute(

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256, 1) void linear_bernoulli_mid_kernel(
   constexpr int kPieces = (kRowB + 1023) / 1024;
   constexpr int kLastLanes = (kRowB - (kPieces - 1) * 1024) / 16;
   constexpr int kDma = 4 * kPieces;   // DMA instructions per wave and tile
-  static_assert(kDma <= KS, "one DMA instruction per phase-1 step");
+  static_assert(kDma < KS, "one DMA instruction per phase-1 step, then the labels");
   const uint32_t sx_addr = (uint32_t)reinterpret_cast<uintptr_t>(sX);
   const uint32_t sy_addr = (uint32_t)reinterpret_cast<uintptr_t>(sY);
   const uint32_t dst_wave = sx_addr + (uint32_t)(a * 4 * LD * 4);
@@ -129,16 +129,18 @@ __global__ __launch_bounds__(256, 1) void linear_bernoulli_mid_kernel(
     else
       lds_dma_x4<kLastLanes>(src, dst, (uint32_t)lane);
   };
-  // the 16 labels of a tile: one 16-lane DMA (wave 0), clamped like the rows
-  const uint32_t lane_b = (uint32_t)lane;
+  // the 16 labels of a tile: wave a brings labels 4a .. 4a+3 with one 4-lane
+  // DMA (no branch in the step), clamped like the rows
+  const uint32_t lane_b = (uint32_t)(a * 4) + ((uint32_t)lane & 3u);
   auto dma_labels = [&](const TileSrc& t, int64_t n0, int buf) {
     const uint32_t l = lane_b < (uint32_t)t.last ? lane_b : (uint32_t)t.last;
     const uint32_t voff = l * 4u;
     const float* src = y + n0;
-    const uint32_t dst = sy_addr + (uint32_t)(buf * kRows * 4);
+    const uint32_t dst =
+        sy_addr + (uint32_t)(buf * kRows * 4) + (uint32_t)(a * 16);
     asm volatile(
         "s_mov_b32 m0, %2\n\t"
-        "s_bfm_b64 exec, 16, 0\n\t"
+        "s_bfm_b64 exec, 4, 0\n\t"
         "global_load_lds_dword %0, %1\n\t"
         "s_mov_b64 exec, -1"
         :
@@ -263,12 +265,15 @@ __global__ __launch_bounds__(256, 1) void linear_bernoulli_mid_kernel(
           read_x(std::integral_constant<int, 1>{});
         }
       }
-      if constexpr (s == 0 && OP != 1) {
-        if (a == 0) dma_labels(tnext, n_next, buf ^ 1);
-      }
+      // a step = 4 MFMAs of 32 clocks: ~7 other instructions fit in a gap
+      // (csrc/linear_bernoulli.hip).  The step's DMA instruction and the
+      // labels go between the MFMAs, not behind the fourth.
+      mfma16_v<s == 0>(S, av[s & 1][0], wreg[s * 4]);
+      mfma16_v<false>(S, av[s & 1][1], wreg[s * 4 + 1]);
       if constexpr (s < kDma) dma_piece(tnext, sc);
-      p1_step16<s == 0>(S, av[s & 1], wreg[s * 4], wreg[s * 4 + 1],
-                        wreg[s * 4 + 2], wreg[s * 4 + 3]);
+      mfma16_v<false>(S, av[s & 1][2], wreg[s * 4 + 2]);
+      if constexpr (s == kDma && OP != 1) dma_labels(tnext, n_next, buf ^ 1);
+      mfma16_v<false>(S, av[s & 1][3], wreg[s * 4 + 3]);
     });
     mfma_drain(S);
     __builtin_amdgcn_sched_barrier(0);

@@ -38,7 +38,11 @@ class ChainSharding(object):
     backend='rccl' : a communicator of libzshmc.so (ncclCommInitRank; the
         unique id is broadcast over the torch.distributed group, which may be
         a CPU/gloo group), collectives enqueued on the current HIP stream.
-        This is the production path: one process per GPU.
+        This is the production path: one process per GPU, each with its
+        device selected (torch.cuda.set_device) BEFORE the communicator is
+        made -- ncclCommInitRank binds to the calling thread's device.  Hosts
+        whose driver only supports dmabuf IPC need HSA_ENABLE_IPC_MODE_LEGACY=0
+        in the environment before the first HIP call (bench.py sets it).
     backend='torch': torch.distributed collectives on `process_group` -- the
         gloo world_size-2 CPU tests, and the functional test that lets two
         ranks share one GPU (RCCL refuses two ranks on one device)."""
