@@ -199,10 +199,9 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel(
   // like the X rows (what a row past N carries never matters: masked with the
   // log-likelihood, a zero operand row without)
   const uint32_t lane_b = (uint32_t)(wave_u * 16) + ((uint32_t)lane & 15u);
-  auto dma_labels = [&](const TileSrc& t, int64_t n0, int buf) {
+  auto dma_labels = [&](const TileSrc& t, const float* src, int buf) {
     const uint32_t l = lane_b < (uint32_t)t.last ? lane_b : (uint32_t)t.last;
     const uint32_t voff = l * 4u;
-    const float* src = y + n0;
     const uint32_t dst =
         sy_addr + (uint32_t)(buf * kRows * 4) + (uint32_t)(wave_u * 64);
     asm volatile(
@@ -243,15 +242,32 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel(
     if (LL) ll += (int64_t)blockIdx.y * C;
     if (GRAD) gW += (int64_t)blockIdx.y * C * ldw;
   }
+  // (a row range with no tiles -- more splits than tiles -- streams the last
+  // tile and never uses it: its partial sums are the zeros of the epilogue)
+  const int64_t t_first =
+      tile_begin < n_tiles_all ? tile_begin : n_tiles_all - 1;
   {
-    // (a row range with no tiles -- more splits than tiles -- streams the last
-    // tile and never uses it: its partial sums are the zeros of the epilogue)
-    const int64_t t_first =
-        tile_begin < n_tiles_all ? tile_begin : n_tiles_all - 1;
     const TileSrc t0 = tile_src(t_first * kRows, 0);
 #pragma unroll
     for (int j = 0; j < 16; ++j) dma_row(t0, j, kWhole);
   }
+  // Tile state: scalar, advanced by additions.  What a tile needs from its
+  // index -- buffer, rows (64, or fewer in X's last tile), the DMA source of
+  // the tile behind it -- is formed for tile t+1 in front of the last MFMAs of
+  // tile t (advance(), called from end_of_tile): recomputed from the index at
+  // the top of a tile it was ~55 scalar instructions (a 64-bit multiply, 64-bit
+  // compares on the vector unit) between the last MFMA of one tile and the
+  // first of the next, ~250 clocks of an idle matrix pipe per tile.
+  const int last_rows = (int)(N - (n_tiles_all - 1) * kRows);   // 1 .. 64
+  const bool ends_x = n_tiles == n_tiles_all;  // the range ends with X's last tile
+  int tiles_left = (int)(n_tiles - tile_begin);   // <= 0: no tiles
+  int buf = 0;
+  int cur_rows = (ends_x && tiles_left <= 1) ? last_rows : kRows;
+  const float* xcur = X + t_first * kRows * ldx;
+  const float* ycur = OP != 1 ? y + t_first * kRows : nullptr;
+  TileSrc nx;               // the tile behind the current one (or it again)
+  int nx_rows;
+  const float* ynx = nullptr;
   if (OP != 1 && tid < kRows) {
     const int64_t nr = tile_begin * kRows + tid;
     sY[tid] = nr < N ? y[nr] : 0.f;
@@ -268,12 +284,17 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel(
   // in-order queue, so a load used in this tile's residual would drag the whole
   // next X tile's DMA into the wait; the end-of-tile vmcnt(0) lands these.
   float xcnt[16], xnext[16];
-  auto load_counts = [&](int64_t t, float* dst) {
+  // counts rows repeat with period yc_rows (x[n_docs, V] shared by chains);
+  // this lane's first count of the current tile / of the tile behind it
+  const float* cnt_cur = nullptr;
+  const float* cnt_nx = nullptr;
+  if (OP == 1) {
     const int64_t cr = row_at(a * 32 + lo);
-    // counts rows repeat with period yc_rows (x[n_docs, V] shared by chains)
-    const float* __restrict__ xrow0 =
-        yc + (cr % yc_rows) * ldy + t * kRows + b * 32 + 4 * hi;
-    const int64_t left = N - (t * kRows + b * 32 + 4 * hi);  // may be <= 0
+    cnt_cur = yc + (cr % yc_rows) * ldy + t_first * kRows + b * 32 + 4 * hi;
+  }
+  auto load_counts = [&](const float* __restrict__ xrow0, int rows_in_tile,
+                         float* dst) {
+    const int left = rows_in_tile - (b * 32 + 4 * hi);  // may be <= 0
     if (yc_vec) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -290,7 +311,33 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel(
           dst[j * 4 + m] = (8 * j + m < left) ? xrow0[8 * j + m] : 0.f;
     }
   };
-  if (OP == 1) load_counts(tile_begin, xcnt);
+  if (OP == 1) load_counts(cnt_cur, cur_rows, xcnt);
+  // (in three parts, for three different gaps between MFMAs)
+  auto plan_next = [&](int part) {
+    const bool more = tiles_left > 1;
+    if (part == 0) {
+      nx_rows = more ? ((ends_x && tiles_left == 2) ? last_rows : kRows) : cur_rows;
+      nx.last = nx_rows - 1;
+      nx.dst = dst_wave + (uint32_t)(buf ^ 1) * kBufBytes;
+    } else if (part == 1) {
+      nx.base = more ? xcur + (int64_t)kRows * ldx : xcur;
+    } else {
+      if (OP != 1) ynx = more ? ycur + kRows : ycur;
+      if (OP == 1) cnt_nx = more ? cnt_cur + kRows : cnt_cur;
+    }
+  };
+  auto advance = [&](int part) {
+    if (part == 0) {
+      cur_rows = nx_rows;
+      xcur = nx.base;
+      if (OP != 1) ycur = ynx;
+      if (OP == 1) cnt_cur = cnt_nx;
+      tiles_left -= 1;
+      buf ^= 1;
+    }
+    plan_next(part);
+  };
+  for (int part = 0; part < 3; ++part) plan_next(part);
 
   // LDS byte addresses of this lane's operands in buffer 0:
   //   phase 1, A: X[b*32 + lo][8 kk + 4 hi .. +3]      (+ 32 kk bytes)
@@ -347,11 +394,10 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel(
 #else
 #define ZS_LB_MARK(i)
 #endif
-  auto tile_body = [&](int64_t tile) {
-    const int buf = (int)((tile - tile_begin) & 1);
-    if (!MASK && (tile + 1) * kRows > N) {
+  auto tile_body = [&]() {
+    if (!MASK && cur_rows < kRows) {
       land_head();
-      const int first = (int)(N - tile * kRows);   // 1 .. 63, workgroup-uniform
+      const int first = cur_rows;   // 1 .. 63, workgroup-uniform
       float* __restrict__ xt = sX + buf * kRows * LD;
       for (int i = first * LD + tid; i < kRows * LD; i += 256) xt[i] = 0.f;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -360,10 +406,10 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel(
     }
     const uint32_t a_addr = a_off + (uint32_t)buf * kBufBytes;
     const uint32_t x_addr = x_off + (uint32_t)buf * kBufBytes;
-    const bool more = tile + 1 < n_tiles;
-    const int64_t n_next = (more ? tile + 1 : tile) * kRows;
-    const TileSrc tnext = tile_src(n_next, buf ^ 1);
-    if (OP == 1) load_counts(more ? tile + 1 : tile, xnext);
+    const TileSrc tnext = nx;
+    const float* const ynext = ynx;
+    const int buf_next = buf ^ 1;
+    if (OP == 1) load_counts(cnt_nx, nx_rows, xnext);
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- phase 1: own 32 rows, full K, one accumulator chain ---------------
@@ -382,7 +428,7 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel(
       if constexpr (kk + 1 < KK) {
         lds_read<(kk + 1) * 32>(av[(kk + 1) & 1], a_addr);
         // (and, once, the wave's 16 labels of tile t+1)
-        if constexpr (OP != 1 && kk == 1) dma_labels(tnext, n_next, buf ^ 1);
+        if constexpr (OP != 1 && kk == 1) dma_labels(tnext, ynext, buf_next);
       } else if constexpr (GRAD) {
         static_for<NH>([&](auto hc) {
           constexpr int h = decltype(hc)::value;
@@ -414,8 +460,7 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel(
 
     // ---- element-wise stage on the accumulator layout (csrc/lb_ops.h) --------
     // lane holds chain i = a*32 + lo, rows n = b*32 + (r&3) + 8*(r>>2) + 4*hi
-    const int rows_left = (int)((N - tile * kRows) < kRows ? (N - tile * kRows)
-                                                           : kRows);
+    const int rows_left = cur_rows;
     auto residual = [&](int r) {
       const int nl = b * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
       const bool valid = !MASK || nl < rows_left;
@@ -452,7 +497,7 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel(
       }
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __syncthreads();
-      head(buf ^ 1);
+      head(buf_next);
       __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -483,7 +528,11 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel(
           constexpr int t = decltype(tc)::value;
           mfma_a(G[t], S[r], vget<VW>(xv[r & 1][t / VW], t % VW));
         });
-        if constexpr (r + 1 < 16 && (r + 1) % kRG == 0) {
+        if constexpr (r < 3) {
+          // tile t+1's state: everything below works from this tile's copies
+          // (tnext, ynext, buf_next, rows_left, the LDS addresses)
+          advance(r);
+        } else if constexpr (r + 1 < 16 && (r + 1) % kRG == 0) {
           __builtin_amdgcn_sched_barrier(0);
           residual4(r + 1);
           __builtin_amdgcn_sched_barrier(0);
@@ -504,6 +553,7 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel(
       for (int g = 0; g < 4; ++g) residual4(4 * g);
       __builtin_amdgcn_sched_barrier(0);
       end_of_tile();
+      for (int part = 0; part < 3; ++part) advance(part);
     }
     if (LL) {
       ll_lane += (double)ll_tile;
@@ -511,7 +561,7 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel(
     }
     ZS_LB_MARK(3)  // end of tile
   };
-  for (int64_t tile = tile_begin; tile < n_tiles; ++tile) tile_body(tile);
+  while (tiles_left > 0) tile_body();
 #ifdef ZS_LB_TIMING
   if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && GRAD) {
     for (int i = 0; i < 4; ++i) gW[wave * 8 + i] = (float)tacc[i];
