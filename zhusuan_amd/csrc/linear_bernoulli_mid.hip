@@ -132,10 +132,9 @@ __global__ __launch_bounds__(256, 1) void linear_bernoulli_mid_kernel(
   // the 16 labels of a tile: wave a brings labels 4a .. 4a+3 with one 4-lane
   // DMA (no branch in the step), clamped like the rows
   const uint32_t lane_b = (uint32_t)(a * 4) + ((uint32_t)lane & 3u);
-  auto dma_labels = [&](const TileSrc& t, int64_t n0, int buf) {
+  auto dma_labels = [&](const TileSrc& t, const float* src, int buf) {
     const uint32_t l = lane_b < (uint32_t)t.last ? lane_b : (uint32_t)t.last;
     const uint32_t voff = l * 4u;
-    const float* src = y + n0;
     const uint32_t dst =
         sy_addr + (uint32_t)(buf * kRows * 4) + (uint32_t)(a * 16);
     asm volatile(
@@ -166,13 +165,26 @@ __global__ __launch_bounds__(256, 1) void linear_bernoulli_mid_kernel(
     if (LL) ll += (int64_t)blockIdx.y * C;
     if (GRAD) gW += (int64_t)blockIdx.y * C * ldw;
   }
+  // (a row range with no tiles streams the last tile and never uses it)
+  const int64_t t_first =
+      tile_begin < n_tiles_all ? tile_begin : n_tiles_all - 1;
   {
-    // (a row range with no tiles streams the last tile and never uses it)
-    const int64_t t_first =
-        tile_begin < n_tiles_all ? tile_begin : n_tiles_all - 1;
     const TileSrc t0 = tile_src(t_first * kRows, 0);
     static_for<kDma>([&](auto ic) { dma_piece(t0, ic); });
   }
+  // Tile state, scalar and advanced by additions inside phase 3
+  // (csrc/linear_bernoulli.hip): rebuilt from the tile index at the top of a
+  // tile it is scalar code between two tiles' MFMAs.
+  const int last_rows = (int)(N - (n_tiles_all - 1) * kRows);   // 1 .. 16
+  const bool ends_x = n_tiles == n_tiles_all;
+  int tiles_left = (int)(n_tiles - tile_begin);   // <= 0: no tiles
+  int buf = 0;
+  int cur_rows = (ends_x && tiles_left <= 1) ? last_rows : kRows;
+  const float* xcur = X + t_first * kRows * ldx;
+  const float* ycur = OP != 1 ? y + t_first * kRows : nullptr;
+  TileSrc nx;               // the tile behind the current one (or it again)
+  int nx_rows;
+  const float* ynx = nullptr;
   if (OP != 1 && tid < kRows) {
     const int64_t nr = tile_begin * kRows + tid;
     sY[tid] = nr < N ? y[nr] : 0.f;
@@ -185,11 +197,13 @@ __global__ __launch_bounds__(256, 1) void linear_bernoulli_mid_kernel(
 
   // OP 1: this lane's 4 counts of a tile (chain 16a + l16, rows 4 q4 .. +3),
   // the NEXT tile's loaded at the top of a tile (csrc/linear_bernoulli.hip)
-  auto load_counts = [&](int64_t t) -> f4 {
-    const int64_t n0 = t * kRows + 4 * q4;
-    const float* __restrict__ xrow =
-        yc + (row_at(a * 16 + l16) % yc_rows) * ldy + n0;
-    const int64_t left = N - n0;  // may be <= 0
+  const float* cnt_cur = nullptr;   // this lane's first count of the tile
+  const float* cnt_nx = nullptr;
+  if (OP == 1)
+    cnt_cur = yc + (row_at(a * 16 + l16) % yc_rows) * ldy + t_first * kRows +
+              4 * q4;
+  auto load_counts = [&](const float* __restrict__ xrow, int rows_in_tile) -> f4 {
+    const int left = rows_in_tile - 4 * q4;  // may be <= 0
     f4 v = f4{0.f, 0.f, 0.f, 0.f};
     if (yc_vec) {
       if (left > 0) v = *reinterpret_cast<const f4*>(xrow);
@@ -201,7 +215,32 @@ __global__ __launch_bounds__(256, 1) void linear_bernoulli_mid_kernel(
     return v;
   };
   f4 xcnt = f4{0.f, 0.f, 0.f, 0.f}, xnext = xcnt;
-  if (OP == 1 && tile_begin < n_tiles) xcnt = load_counts(tile_begin);
+  if (OP == 1 && tiles_left > 0) xcnt = load_counts(cnt_cur, cur_rows);
+  auto plan_next = [&](int part) {
+    const bool more = tiles_left > 1;
+    if (part == 0) {
+      nx_rows = more ? ((ends_x && tiles_left == 2) ? last_rows : kRows) : cur_rows;
+      nx.last = nx_rows - 1;
+      nx.dst = dst_wave + (uint32_t)(buf ^ 1) * kBufBytes;
+    } else if (part == 1) {
+      nx.base = more ? xcur + (int64_t)kRows * ldx : xcur;
+    } else {
+      if (OP != 1) ynx = more ? ycur + kRows : ycur;
+      if (OP == 1) cnt_nx = more ? cnt_cur + kRows : cnt_cur;
+    }
+  };
+  auto advance = [&](int part) {
+    if (part == 0) {
+      cur_rows = nx_rows;
+      xcur = nx.base;
+      if (OP != 1) ycur = ynx;
+      if (OP == 1) cnt_cur = cnt_nx;
+      tiles_left -= 1;
+      buf ^= 1;
+    }
+    plan_next(part);
+  };
+  for (int part = 0; part < 3; ++part) plan_next(part);
 
   // LDS byte addresses of this lane's operands in buffer 0:
   //   phase 1, A: X[l16][16 s + 4 q4 .. +3]                  (+ 64 s bytes)
@@ -226,11 +265,10 @@ __global__ __launch_bounds__(256, 1) void linear_bernoulli_mid_kernel(
   head(0);
 
   constexpr bool MASK = LL;   // csrc/linear_bernoulli.hip: rows past N
-  auto tile_body = [&](int64_t tile) {
-    const int buf = (int)((tile - tile_begin) & 1);
-    if (!MASK && (tile + 1) * kRows > N) {
+  auto tile_body = [&]() {
+    if (!MASK && cur_rows < kRows) {
       land_head();
-      const int first = (int)(N - tile * kRows);   // 1 .. 15
+      const int first = cur_rows;   // 1 .. 15
       float* __restrict__ xt = sX + buf * kRows * LD;
       for (int i = first * LD + tid; i < kRows * LD; i += 256) xt[i] = 0.f;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -239,10 +277,10 @@ __global__ __launch_bounds__(256, 1) void linear_bernoulli_mid_kernel(
     }
     const uint32_t a_addr = a_off + (uint32_t)buf * kBufBytes;
     const uint32_t x_addr = x_off + (uint32_t)buf * kBufBytes;
-    const bool more = tile + 1 < n_tiles;
-    const int64_t n_next = (more ? tile + 1 : tile) * kRows;
-    const TileSrc tnext = tile_src(n_next, buf ^ 1);
-    if (OP == 1) xnext = load_counts(more ? tile + 1 : tile);
+    const TileSrc tnext = nx;
+    const float* const ynext = ynx;
+    const int buf_next = buf ^ 1;
+    if (OP == 1) xnext = load_counts(cnt_nx, nx_rows);
     __builtin_amdgcn_sched_barrier(0);
 
     // step i of phase 3: residual register r = i / NTT, feature block T = i % NTT
@@ -272,15 +310,14 @@ __global__ __launch_bounds__(256, 1) void linear_bernoulli_mid_kernel(
       mfma16_v<false>(S, av[s & 1][1], wreg[s * 4 + 1]);
       if constexpr (s < kDma) dma_piece(tnext, sc);
       mfma16_v<false>(S, av[s & 1][2], wreg[s * 4 + 2]);
-      if constexpr (s == kDma && OP != 1) dma_labels(tnext, n_next, buf ^ 1);
+      if constexpr (s == kDma && OP != 1) dma_labels(tnext, ynext, buf_next);
       mfma16_v<false>(S, av[s & 1][3], wreg[s * 4 + 3]);
     });
     mfma_drain(S);
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- element-wise stage: lane holds chain 16a + l16, rows 4 q4 + r ------
-    const int rows_left = (int)((N - tile * kRows) < kRows ? (N - tile * kRows)
-                                                           : kRows);
+    const int rows_left = cur_rows;
     if constexpr (OP == 2) {
       // the four rows together: one branch on the class stride (csrc/lb_ops.h)
       float v[4], lab[4];
@@ -308,7 +345,7 @@ __global__ __launch_bounds__(256, 1) void linear_bernoulli_mid_kernel(
       if (OP == 1) xcnt = xnext;
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __syncthreads();
-      head(buf ^ 1);
+      head(buf_next);
       __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -327,6 +364,9 @@ __global__ __launch_bounds__(256, 1) void linear_bernoulli_mid_kernel(
         }
         mfma16_a(G[4 * T], S[r], xv[i % 3][0]);
         mfma16_a(G[4 * T + 1], S[r], xv[i % 3][1]);
+        // tile t+1's state, a part per step: everything below works from this
+        // tile's copies (tnext, ynext, buf_next, rows_left, the LDS addresses)
+        if constexpr (i < 3) advance(i);
         if constexpr (i + 1 == NS) {
           // every read of this buffer has returned; the rest is registers
           __builtin_amdgcn_sched_barrier(0);
@@ -337,13 +377,14 @@ __global__ __launch_bounds__(256, 1) void linear_bernoulli_mid_kernel(
       });
     } else {
       end_of_tile();
+      for (int part = 0; part < 3; ++part) advance(part);
     }
     if (LL) {
       ll_lane += (double)ll_tile;
       ll_tile = 0.f;
     }
   };
-  for (int64_t tile = tile_begin; tile < n_tiles; ++tile) tile_body(tile);
+  while (tiles_left > 0) tile_body();
   land_head();   // the reads behind the last barrier (a tile that does not exist)
 
   // ---- epilogue -----------------------------------------------------------
