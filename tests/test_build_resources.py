@@ -148,6 +148,27 @@ def test_likelihood_kernels_have_no_spills_and_keep_their_occupancy(lb_build):
         assert row['Occupancy [waves/SIMD]'] >= want, (name, row)
 
 
+def _issue_slots_between_mfmas(body):
+    """Issue slots (instructions; `s_nop n` counts n + 1) between consecutive
+    MFMAs of a kernel body, and from the loop header to the first MFMA."""
+    lines = [l.split(';')[0].strip() for l in body.splitlines()]
+    lines = [l for l in lines if l and not l.startswith('.') and
+             not l.endswith(':')]
+
+    def cost(l):
+        m = re.match(r's_nop (\d+)', l)
+        return 1 + int(m.group(1)) if m else 1
+    gaps, run, seen = [], 0, False
+    for l in lines:
+        if l.startswith('v_mfma'):
+            if seen:
+                gaps.append(run)
+            seen, run = True, 0
+        elif seen:
+            run += cost(l)
+    return gaps
+
+
 def test_likelihood_tile_loop_is_hand_ordered(lb_build):
     _, asm = lb_build
     n = 0
@@ -234,3 +255,34 @@ def test_mid_likelihood_kernels_have_no_spills_and_hand_ordered_mfmas(mid_build)
         assert mfma_in == int(width) // 4 * (2 if grad == '1' else 1), (
             name, mfma_in)
     assert n == 90
+
+
+def test_likelihood_steps_fit_their_issue_slots(lb_build, mid_build):
+    """DESIGN 3.3, rules (a) and (b): a wave issues one instruction per ~4
+    clocks and a 32 x 32 x 2 MFMA holds the pipe for 64 (16 x 16 x 4: 32), so a
+    gap between two MFMAs takes ~15 (~7) other instructions for free.  In the
+    gradient-only instantiations no gap of GEMM 1 exceeds that (the steps'
+    LDS reads, DMA instructions and address arithmetic are spread), and GEMM 2's
+    only long gaps are the element-wise slots, the tile barrier and the three
+    parts of the next tile's state."""
+    _, asm = lb_build
+    for width in (64, 128, 192, 256):
+        m = re.search(r'^_ZN5zshmc23linear_bernoulli_kernelILi%dELb1ELi0ELb0E'
+                      r'\w+:[^\n]*\n(.*?)s_endpgm' % width, asm, re.S | re.M)
+        gaps = _issue_slots_between_mfmas(m.group(1))
+        n1 = width // 2            # MFMAs of GEMM 1; gaps[n1 - 1] is the drain
+        gemm1, gemm2 = gaps[:n1 - 1], gaps[n1:2 * n1 - 1]
+        assert max(gemm1) <= 18, (width, gemm1)
+        assert sorted(gemm1)[-2] <= 16 and sum(gemm1) / len(gemm1) <= 9, (
+            width, gemm1)
+        # GEMM 2: three element-wise slots, the tile barrier, three state parts
+        assert sum(g > 12 for g in gemm2) <= 7, (width, gemm2)
+    _, asm = mid_build
+    for width in (320, 512, 896):
+        m = re.search(r'^_ZN5zshmc27linear_bernoulli_mid_kernelILi%dELb1ELi0ELb0E'
+                      r'\w+:[^\n]*\n(.*?)s_endpgm' % width, asm, re.S | re.M)
+        gaps = _issue_slots_between_mfmas(m.group(1))
+        n1 = width // 4
+        gemm1, gemm2 = gaps[:n1 - 1], gaps[n1:2 * n1 - 1]
+        assert max(gemm1) <= 10, (width, gemm1)
+        assert sum(g > 8 for g in gemm2) <= 5, (width, gemm2)

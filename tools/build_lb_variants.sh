@@ -3,7 +3,10 @@
 #   tools/build_lb_variants.sh TAG "-DFLAG ..." [TAG2 "..."]...
 # -> build/variants/libzshmc_TAG.so (only csrc/linear_bernoulli*.hip are
 # recompiled with the extra flags; the other
-# objects come from build/obj).  Time them with
+# objects come from build/obj).  Compile-time switches the sources know:
+# -DZS_LB_TIMING (per-phase shader clocks, tools/lb_phase_timing.py),
+# -DZS_LB_LDS_PAD=bytes (extra LDS: fewer workgroups per CU at D <= 128).
+# Time them with
 #   LB_LIB=build/variants/libzshmc_TAG.so python tools/lb_modes_bench.py
 set -e
 cd "$(dirname "$0")/.."

@@ -1,8 +1,10 @@
 #!/usr/bin/env python
 """Debug: per-phase shader-clock breakdown of the two-GEMM likelihood kernel
-(csrc/linear_bernoulli.hip) from a library built with -DZS_LB3_TIMING
-(tools/build_lb_variants.sh timing "-DZS_LB3_TIMING"): the waves of block 0
-overwrite the first gradient words with their accumulated clocks.
+(csrc/linear_bernoulli.hip) from a library built with -DZS_LB_TIMING
+(tools/build_lb_variants.sh timing "-DZS_LB_TIMING"; add -DZS_LB_LDS_PAD=26000
+for ONE workgroup per CU at D <= 128, i.e. clocks without a partner wave on the
+SIMD): the waves of block 0 overwrite the first gradient words with their
+accumulated clocks.
 Usage: python tools/lb_phase_timing.py lib.so [D] [C] [N] [grad_only]"""
 import ctypes
 import sys
