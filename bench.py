@@ -293,9 +293,11 @@ def _lik_kernel_name(width, block):
 
 def _mfma_roofline(kernel, kern_ms, flop_eval, n_evals, ms_transition):
     """`kern_ms`: {'grad': ms, 'll_grad': ms} of _time_transitions (or one
-    number).  The roofline entry is the gradient-only launch -- n_evals - 2 of
-    a transition's n_evals launches; the likelihood + gradient launch of the
-    two ends is reported beside it."""
+    number).  The roofline entry is the gradient-only launch -- n_evals - 1 of
+    a transition's n_evals = L likelihood launches (the evaluation at the
+    start point is the previous transition's last one, carried over where the
+    chain accepted: zshmc_model_plan.grad_start); the likelihood + gradient
+    launch of the trajectory's end is reported beside it."""
     both = kern_ms if isinstance(kern_ms, dict) else {'grad': kern_ms}
     ms = both['grad']
     ach = flop_eval / (ms * 1e-3) / 1e12
@@ -305,8 +307,8 @@ def _mfma_roofline(kernel, kern_ms, flop_eval, n_evals, ms_transition):
         'kernel_ms': ms, 'achieved': ach, 'frac': ach / MFMA_F32_PEAK_TFLOPS,
         'traffic': None,
         'algorithmic_flop_per_launch': flop_eval,
-        'launches_per_transition': {'gradient_only': n_evals - 2,
-                                    'likelihood_and_gradient': 2},
+        'launches_per_transition': {'gradient_only': n_evals - 1,
+                                    'likelihood_and_gradient': 1},
         'sustained_over_transition': n_evals * flop_eval /
         (ms_transition * 1e-3) / 1e12,
     }
@@ -471,7 +473,7 @@ def extra_config3(torch, zs, dev, n_rows=1000000, n_chains=32768, n_feat=256,
         },
         'roofline': _mfma_roofline(
             _lik_kernel_name(hmc._plan.width, hmc._plan.block), kern_ms, flop_eval,
-            n_leapfrogs + 1, ms),
+            n_leapfrogs, ms),
     }
 
 
@@ -526,7 +528,7 @@ def extra_wide_regression(torch, zs, dev, n_rows=65536, n_chains=8192,
         'mean_acceptance': acc,
         'roofline': dict(_mfma_roofline(
             _lik_kernel_name(hmc._plan.width, hmc._plan.block), kern_ms, flop_eval,
-            n_leapfrogs + 1, ms),
+            n_leapfrogs, ms),
             note='flops counted at the padded width %d (%d useful columns)'
                  % (width, n_feat + 1),
             useful_flop_fraction=(n_feat + 1.0) / width),
@@ -582,7 +584,7 @@ def extra_softmax_regression(torch, zs, dev, n_rows=60000, n_feat=784,
         'mean_acceptance': acc,
         'roofline': dict(_mfma_roofline(
             _lik_kernel_name(plan.width, plan.block) + ' (Categorical mode)',
-            kern_ms, flop_eval, n_leapfrogs + 1, ms),
+            kern_ms, flop_eval, n_leapfrogs, ms),
             note='flops counted at the padded shape: width %d, class stride '
                  '%d; useful fraction of them %.3f (%d features, %d classes)'
                  % (plan.width, plan.stride, useful, n_feat, n_classes)),
@@ -744,7 +746,7 @@ def lntm_workload(torch, zs, dev, n_chains, sharding=None, dist=None,
     flop_eval = 4.0 * rows_rank * n_topics * n_vocab      # per GPU per launch
     roof = _mfma_roofline(
         _lik_kernel_name(hmc._plan.width, hmc._plan.block) + ' (multinomial mode)',
-        kern_ms, flop_eval, n_leapfrogs + 1, ms)
+        kern_ms, flop_eval, n_leapfrogs, ms)
     roof['note'] = 'per GPU (rank 0): one launch covers this rank\'s rows'
     return {
         'workload': 'configs[4]: logistic-normal topic model E-step, chain '

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ZSHMC_VERSION 410 /* 0.4.1: + zshmc_likelihood_plan */
+#define ZSHMC_VERSION 420 /* 0.4.2: + zshmc_model_plan.grad_start / ll_start */
 
 /* status codes */
 #define ZSHMC_OK 0
@@ -486,6 +486,17 @@ typedef struct zshmc_model_plan {
   float* grad;    /* [lik_rows, width] */
   float* ll;      /* [lik_rows] */
   int64_t lik_rows, width;
+  /* The likelihood evaluation AT THE STATE THE LATENTS HOLD (same shapes as
+   * grad / ll), or NULL.  With them a transition's first evaluation is the
+   * previous transition's last one where the chain accepted, its own first
+   * one where it did not: after the MH test the accepted chains' rows of
+   * grad / ll are copied over (L likelihood launches per transition instead
+   * of L + 1; results bit-identical).  start_valid: they hold the evaluation
+   * at the current latents on entry (else the first transition of the call
+   * evaluates into them); always valid on return when n_transitions >= 1. */
+  float* grad_start;
+  float* ll_start;
+  int32_t start_valid, start_pad;
   const float* inner; /* X / phi^T / the other factor table */
   int64_t n_inner;    /* data rows / vocabulary / rows of the other table */
   const float* obs;   /* labels / counts / ratings */

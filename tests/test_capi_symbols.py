@@ -90,7 +90,7 @@ def test_ctypes_table_matches_header(lib):
 
 
 def test_version_and_limits_callable_without_gpu(lib):
-    assert lib.zshmc_version() == 410
+    assert lib.zshmc_version() == 420
     assert lib.zshmc_fused_max_n_data() == 2048
     assert lib.zshmc_last_error() is not None
 
@@ -165,3 +165,30 @@ def test_header_is_plain_c_and_cpp(tmp_path):
         args += ['-x', 'c++' if cc == 'g++' else 'c', str(src)]
         r = subprocess.run(args, capture_output=True, text=True)
         assert r.returncode == 0, (cc, r.stderr[-1500:])
+
+
+def test_model_plan_layout_matches_header(tmp_path):
+    """The ctypes mirror of zshmc_model_plan against the C compiler's layout
+    of the header's struct: size and the offset of every field."""
+    import shutil
+    import subprocess
+    from zhusuan_amd import _capi
+    if shutil.which('gcc') is None:
+        pytest.skip('gcc not available')
+    names = [f[0] for f in _capi.ModelPlan._fields_]
+    src = tmp_path / 'layout.c'
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "zshmc.h"\n'
+        'int main(void) {\n  printf("%zu\\n", sizeof(zshmc_model_plan));\n' +
+        ''.join('  printf("%%zu\\n", offsetof(zshmc_model_plan, %s));\n' % n
+                for n in names) + '  return 0;\n}\n')
+    exe = tmp_path / 'layout'
+    r = subprocess.run(['gcc', '-std=c99', '-I' + os.path.join(ROOT, 'include'),
+                        str(src), '-o', str(exe)], capture_output=True,
+                       text=True)
+    assert r.returncode == 0, r.stderr[-1500:]
+    out = subprocess.run([str(exe)], capture_output=True, text=True).stdout
+    vals = [int(v) for v in out.split()]
+    assert vals[0] == ctypes.sizeof(_capi.ModelPlan)
+    for n, off in zip(names, vals[1:]):
+        assert getattr(_capi.ModelPlan, n).offset == off, n

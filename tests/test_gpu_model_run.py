@@ -258,3 +258,79 @@ def test_annealing_from_one_call_equals_the_python_loop(env):
     assert torch.equal(res[0][1], res[1][1])
     assert torch.equal(res[0][2], res[1][2])
     assert res[0][0] == res[1][0]
+
+
+LIK_CALLS = ('zshmc_linear_bernoulli_log_lik', 'zshmc_linear_multinomial_log_lik',
+             'zshmc_linear_categorical_log_lik', 'zshmc_gather_dot_normal_lik')
+
+
+@pytest.mark.parametrize('which', sorted(MODELS))
+def test_start_evaluation_is_carried_over(env, which):
+    """A transition's first likelihood evaluation is the previous transition's
+    last one where the chain accepted (zshmc_model_plan.grad_start / ll_start;
+    SURVEY 8d: "old log-prob carried over on the model-unchanged fast path"):
+    L launches per transition instead of L + 1, results bit-identical to
+    evaluating every start point -- through the Python loop and through
+    zshmc_hmc_model_run; an outside write to a latent makes the next
+    transition evaluate again."""
+    zs, torch, dev = env
+    from zhusuan_amd import _capi
+    build, observed, latents, kind = MODELS[which](zs, torch, dev)
+    L, out = 4, {}
+    for mode in ('carry', 'evaluate', 'carry_block', 'evaluate_block'):
+        f_ss, f_m = zs.placeholder(bool), zs.placeholder(bool)
+        hmc = zs.HMC(step_size=0.02, n_leapfrogs=L, seed=8, adapt_step_size=f_ss,
+                     adapt_mass=f_m, mass_collect_iters=3,
+                     target_acceptance_rate=0.7)
+        q = latents()
+        op, info = hmc.sample(build(), observed, q)
+        assert hmc.plan_kind == kind, hmc.plan_reason
+        hmc._plan.carry_start = mode.startswith('carry')
+        calls, real = [], _capi.call
+
+        def spy(name, *a):
+            calls.append(name)
+            return real(name, *a)
+        feeds = ((6, {f_ss: True, f_m: True}), (5, {f_ss: False, f_m: False}))
+        n_lik = []
+        for n, feed in feeds:
+            _capi.call = spy
+            try:
+                if mode.endswith('block'):
+                    op.run_many(n, feed_dict=feed)
+                else:
+                    for _ in range(n):
+                        op.run(feed_dict=feed)
+            finally:
+                _capi.call = real
+            n_lik.append(sum(c in LIK_CALLS for c in calls))
+            del calls[:]
+        if not mode.endswith('block'):
+            # the held stretch: no search, no first evaluation
+            assert n_lik[1] == 5 * (L if mode == 'carry' else L + 1), n_lik
+        # somebody else writes a latent: the start is evaluated again
+        name0 = sorted(q)[0]
+        q[name0].mul_(1.0)
+        _capi.call = spy
+        try:
+            op.run(feed_dict=feeds[1][1])
+        finally:
+            _capi.call = real
+        assert sum(c in LIK_CALLS for c in calls) == L + 1, calls
+        out[mode] = dict(
+            q={k: v.clone() for k, v in q.items()},
+            info={f: getattr(info, f).clone() for f in (
+                'acceptance_rate', 'orig_hamiltonian', 'hamiltonian',
+                'orig_log_prob', 'log_prob')},
+            state=hmc.get_state())
+    ref = out['evaluate']
+    for mode in ('carry', 'carry_block', 'evaluate_block'):
+        got = out[mode]
+        for k in ref['q']:
+            assert torch.equal(ref['q'][k], got['q'][k]), (mode, k)
+        for f in ref['info']:
+            assert torch.equal(ref['info'][f], got['info'][f]), (mode, f)
+        assert torch.equal(ref['state']['state'], got['state']['state']), mode
+        for key in ('ewmv_mean', 'ewmv_var', 'mass'):
+            for x, y in zip(ref['state'][key], got['state'][key]):
+                assert torch.equal(x, y), (mode, key)

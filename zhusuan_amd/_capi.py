@@ -67,6 +67,8 @@ class ModelPlan(Structure):
         ('n_chains', c_int64), ('n_total', c_int64), ('ld', c_int64),
         ('operand', c_void_p), ('grad', c_void_p), ('ll', c_void_p),
         ('lik_rows', c_int64), ('width', c_int64),
+        ('grad_start', c_void_p), ('ll_start', c_void_p),
+        ('start_valid', c_int32), ('start_pad', c_int32),
         ('inner', c_void_p), ('n_inner', c_int64),
         ('obs', c_void_p), ('obs_rows', c_int64), ('obs_stride', c_int64),
         ('split_ws', c_void_p),

@@ -6,7 +6,8 @@
 // One transition (reference zhusuan/hmc.py:418-520) is
 //   [mass update from the column sums of the state it starts in]   (:284-305)
 //   momentum                                                        (:458)
-//   likelihood + gradient at q, then (L+1) x [element-wise step:
+//   likelihood + gradient at q (or: carried over from the transition before,
+//     m.grad_start), then (L+1) x [element-wise step:
 //     prior + Jacobian + kick (+ drift + next operand), likelihood] (:348-372)
 //   MH accept, select                                               (:479-498)
 //   [column sums of the end state] [all-reduce] step-size update    (:501-505)
@@ -46,24 +47,25 @@ __global__ void ais_accumulate_kernel(float* __restrict__ log_w,
 
 // want_ll = false: the gradient alone (the interior evaluations of a
 // trajectory; the MFMA kernels then skip the log-likelihood terms)
+// (grad_out / ll_out: m.grad / m.ll, or the start buffers)
 int likelihood(const zshmc_model_plan& m, const float* q, bool want_ll,
-               void* s) {
+               float* grad_out, float* ll_out, void* s) {
   const float* w = m.operand ? m.operand : q;
   float* ws = m.n_splits > 1 ? m.split_ws : nullptr;
-  float* ll = want_ll ? m.ll : nullptr;
+  float* ll = want_ll ? ll_out : nullptr;
   switch (m.kind) {
     case ZSHMC_PLAN_LINEAR_BERNOULLI:
       return zshmc_linear_bernoulli_log_lik(w, m.inner, m.obs, m.n_chains,
-                                            m.n_inner, m.width, ll, m.grad,
+                                            m.n_inner, m.width, ll, grad_out,
                                             m.n_splits, ws, s);
     case ZSHMC_PLAN_MIXTURE_MULTINOMIAL:
       return zshmc_linear_multinomial_log_lik(
           w, m.inner, m.obs, m.obs_rows, m.obs_stride, m.n_chains, m.n_inner,
-          m.width, ll, m.grad, m.n_splits, ws, s);
+          m.width, ll, grad_out, m.n_splits, ws, s);
     case ZSHMC_PLAN_LINEAR_CATEGORICAL:
       return zshmc_linear_categorical_log_lik(
           w, m.inner, m.obs, m.lik_rows, m.n_inner, m.width, m.n_classes,
-          (int)m.groups, ll, m.grad, m.n_splits, ws, s);
+          (int)m.groups, ll, grad_out, m.n_splits, ws, s);
     case ZSHMC_PLAN_GATHERED_DOT: {
       const bool lat_u = m.gd_latent_is_u != 0;
       ZS_TRY(zshmc_gather_dot_normal_lik(
@@ -72,39 +74,43 @@ int likelihood(const zshmc_model_plan& m, const float* q, bool want_ll,
           lat_u ? m.gd_idx_other : m.gd_idx_latent, m.obs, m.obs_rows,
           m.gd_logstd, m.gd_lp_const, m.n_chains, lat_u ? m.gd_n_latent : m.n_inner,
           lat_u ? m.n_inner : m.gd_n_latent, m.gd_n_pairs, m.gd_n_dim,
-          m.gd_g_pairs, m.ll, m.split_ws, s));
+          m.gd_g_pairs, ll_out, m.split_ws, s));
       if (m.gd_n_pairs)
         return zshmc_gather_dot_grad(m.inner, m.gd_g_pairs, m.gd_seg,
                                      m.gd_order, m.gd_idx_other, m.n_chains,
                                      m.gd_n_latent, m.n_inner, m.gd_n_pairs,
-                                     m.gd_n_dim, m.grad, s);
-      return zshmc_zero(m.grad, 4 * m.n_chains * m.ld, s);
+                                     m.gd_n_dim, grad_out, s);
+      return zshmc_zero(grad_out, 4 * m.n_chains * m.ld, s);
     }
   }
   set_error("zshmc_hmc_model_run: unknown plan kind %d", m.kind);
   return ZSHMC_ERR_BAD_ARG;
 }
 
-int step(const zshmc_model_plan& m, bool use_grad, float kick, float drift,
-         float lik_scale, float* lp_out, float* kinetic, void* s) {
+// (grad / ll: the likelihood evaluation the step reads, or NULL: none)
+int step(const zshmc_model_plan& m, const float* grad, const float* ll,
+         float kick, float drift, float lik_scale, float* lp_out,
+         float* kinetic, void* s) {
   const float* mass = m.use_mass ? m.mass : nullptr;
   if (m.segmented)
     return zshmc_model_kick_drift_seg(
-        m.q_new, m.p, use_grad ? m.grad : nullptr, m.width, m.seg_len,
-        m.groups, m.operand, m.width, m.prior_mean, m.mean_rows,
-        m.prior_logstd, m.logstd_rows, mass, m.state, 0.f, kick, drift,
-        lik_scale, m.n_chains, m.n_total, m.ld, use_grad ? m.ll : nullptr,
+        m.q_new, m.p, grad, m.width, m.seg_len, m.groups, m.operand, m.width,
+        m.prior_mean, m.mean_rows, m.prior_logstd, m.logstd_rows, mass,
+        m.state, 0.f, kick, drift, lik_scale, m.n_chains, m.n_total, m.ld, ll,
         lp_out, kinetic, m.seg_ws, s);
   return zshmc_model_kick_drift(
-      m.q_new, m.p, use_grad ? m.grad : nullptr, m.width, m.operand, m.width,
-      m.softmax, m.prior_mean, m.mean_rows, m.prior_logstd, m.logstd_rows,
-      mass, m.state, 0.f, kick, drift, lik_scale, m.n_chains, m.n_total, m.ld,
-      use_grad ? m.ll : nullptr, lp_out, kinetic, s);
+      m.q_new, m.p, grad, m.width, m.operand, m.width, m.softmax, m.prior_mean,
+      m.mean_rows, m.prior_logstd, m.logstd_rows, mass, m.state, 0.f, kick,
+      drift, lik_scale, m.n_chains, m.n_total, m.ld, ll, lp_out, kinetic, s);
 }
 
+// start_valid: m.grad_start / m.ll_start hold the evaluation at the latents
 int transition(const zshmc_model_plan& m, uint32_t t, float lik_scale,
-               void* s) {
+               bool start_valid, void* s) {
   const int L = m.n_leapfrogs;
+  const bool carry = m.grad_start && m.ll_start;
+  float* g0 = carry ? m.grad_start : m.grad;
+  float* l0 = carry ? m.ll_start : m.ll;
   // the latents -> the packed working state
   for (int k = 0; k < m.n_latents; ++k)
     ZS_TRY(zshmc_copy_rows(m.q_new + m.latent_offset[k], m.ld, m.latent[k],
@@ -116,13 +122,21 @@ int transition(const zshmc_model_plan& m, uint32_t t, float lik_scale,
                                m.use_mass ? m.latent_mass[k] : nullptr,
                                m.n_chains, m.latent_size[k], m.chain_offset,
                                m.seed, t, (uint32_t)k, m.kin_old, s));
-  // operand(q), then likelihood + gradient at q
-  if (m.operand) ZS_TRY(step(m, false, 0.f, 0.f, lik_scale, nullptr, nullptr, s));
-  ZS_TRY(likelihood(m, m.q_new, true, s));
+  // operand(q), then likelihood + gradient at q -- unless the start buffers
+  // hold them already (the previous transition's, selected by its MH test)
+  if (!(carry && start_valid)) {
+    if (m.operand)
+      ZS_TRY(step(m, nullptr, nullptr, 0.f, 0.f, lik_scale, nullptr, nullptr, s));
+    ZS_TRY(likelihood(m, m.q_new, true, g0, l0, s));
+  } else if (m.softmax && m.operand) {
+    // the step's Jacobian reads theta = softmax(q) from the operand buffer,
+    // which holds the last PROPOSAL's
+    ZS_TRY(step(m, nullptr, nullptr, 0.f, 0.f, lik_scale, nullptr, nullptr, s));
+  }
   ZS_TRY(zshmc_zero(m.kin_new, 4 * m.n_chains, s));
   // trip 0: zero-length drift, half kick (hmc.py:352-364); the drift of trip
   // i+1 rides behind the kick of trip i
-  ZS_TRY(step(m, true, 0.5f, L >= 1 ? 1.f : 0.f, lik_scale, m.lp_old,
+  ZS_TRY(step(m, g0, l0, 0.5f, L >= 1 ? 1.f : 0.f, lik_scale, m.lp_old,
               L == 0 ? m.kin_new : nullptr, s));
   if (L == 0)
     ZS_TRY(check_hip(hipMemcpyAsync(m.lp_new, m.lp_old, 4 * m.n_chains,
@@ -131,8 +145,8 @@ int transition(const zshmc_model_plan& m, uint32_t t, float lik_scale,
                      "hipMemcpyAsync"));
   for (int i = 1; i <= L; ++i) {
     const bool last = i == L;
-    ZS_TRY(likelihood(m, m.q_new, last, s));
-    ZS_TRY(step(m, true, last ? 0.5f : 1.f, last ? 0.f : 1.f, lik_scale,
+    ZS_TRY(likelihood(m, m.q_new, last, m.grad, m.ll, s));
+    ZS_TRY(step(m, m.grad, m.ll, last ? 0.5f : 1.f, last ? 0.f : 1.f, lik_scale,
                 last ? m.lp_new : nullptr, last ? m.kin_new : nullptr, s));
   }
   ZS_TRY(zshmc_mh_accept(m.lp_old, m.lp_new, m.kin_old, m.kin_new, m.n_chains,
@@ -144,6 +158,17 @@ int transition(const zshmc_model_plan& m, uint32_t t, float lik_scale,
     ZS_TRY(zshmc_copy_rows(m.latent[k], m.latent_size[k],
                            m.q_new + m.latent_offset[k], m.ld, m.accept,
                            m.n_chains, m.latent_size[k], s));
+  // ... and the evaluation that goes with the state: the last one of the
+  // trajectory where the chain accepted (a chain's rows of the likelihood
+  // matrices are contiguous: lik_rows / n_chains rows of `width`)
+  if (carry && L >= 1) {
+    const int64_t per_chain = m.lik_rows / m.n_chains;
+    ZS_TRY(zshmc_copy_rows(m.grad_start, per_chain * m.width, m.grad,
+                           per_chain * m.width, m.accept, m.n_chains,
+                           per_chain * m.width, s));
+    ZS_TRY(zshmc_copy_rows(m.ll_start, per_chain, m.ll, per_chain, m.accept,
+                           m.n_chains, per_chain, s));
+  }
   return ZSHMC_OK;
 }
 
@@ -189,6 +214,9 @@ extern "C" int zshmc_hmc_model_run(const zshmc_model_plan* plan,
   ZS_REQUIRE(update_kind == ZSHMC_PEND_NONE || update_kind == ZSHMC_PEND_ADAPT ||
                  update_kind == ZSHMC_PEND_HOLD,
              "zshmc_hmc_model_run: bad update_kind");
+  ZS_REQUIRE(!m.grad_start == !m.ll_start && m.lik_rows % m.n_chains == 0,
+             "zshmc_hmc_model_run: grad_start and ll_start go together; "
+             "lik_rows is a multiple of n_chains");
   ZS_REQUIRE(!adapt_mass || (m.comm_buf && m.use_mass),
              "zshmc_hmc_model_run: mass adaptation needs the column-sum "
              "buffer and the mass vectors");
@@ -199,7 +227,7 @@ extern "C" int zshmc_hmc_model_run(const zshmc_model_plan* plan,
     // the end of the previous one -- by the caller before the first)
     if (adapt_mass) ZS_TRY(mass_update(m, stream));
     const float ls = lik_scale_host ? lik_scale_host[i] : 1.0f;
-    ZS_TRY(transition(m, t, ls, stream));
+    ZS_TRY(transition(m, t, ls, i > 0 || m.start_valid != 0, stream));
     if (adapt_mass) ZS_TRY(colstats(m, stream));
     if (comm) {
       if (adapt_mass)

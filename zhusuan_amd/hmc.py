@@ -1312,12 +1312,24 @@ class _DenseLikelihoodPlan(_PlanBase):
             self.mass = [self.mass_pack[o:o + d]
                          for o, d in zip(self.offsets, self.n_data)]
         self.ll = torch.empty(self.lik_rows, **f32)
+        # The likelihood evaluation AT THE STATE THE LATENTS HOLD: a transition
+        # starts from the previous one's last evaluation where the chain
+        # accepted, from its own first one where it did not (the accepted
+        # chains' rows of grad / ll are copied over behind the MH test), so a
+        # transition is L likelihood launches, not L + 1 -- as long as nobody
+        # else wrote the latents and the model's tensors are the same
+        # (`_start_is_valid`).  The likelihood term is carried UNSCALED
+        # (lik_scale is applied by the step), so annealing keeps it.
+        self.grad0 = torch.empty(self.lik_rows, self.width, **f32)
+        self.ll0 = torch.empty(self.lik_rows, **f32)
+        self.carry_start = True       # False: evaluate every start (tests)
+        self._start_valid = False
+        self._start_versions = []
         self.lp_old = self.orig_log_prob      # HMCInfo.orig_log_prob itself
         self.lp_new = torch.empty(C, **f32)
         self.kin_old = torch.zeros(C, **f32)
         self.kin_new = torch.zeros(C, **f32)
         self.accept = torch.zeros(C, dtype=torch.uint8, device=device)
-        self._search_cache = None
         self._in_search = False
         self._src = None
         self._ws = None
@@ -1340,6 +1352,7 @@ class _DenseLikelihoodPlan(_PlanBase):
         if self._src is not None and key == self._src[0]:
             return
         self._src = (key, t)
+        self._start_valid = False     # another model: another evaluation
         C = self.n_chains
         self._pack_prior(priors)
         ops = self._ops
@@ -1524,12 +1537,14 @@ class _DenseLikelihoodPlan(_PlanBase):
                        self.accept.data_ptr(), self.n_chains, self.n_data[k],
                        stream)
 
-    def _likelihood(self, q, stream, want_ll=True):
+    def _likelihood(self, q, stream, want_ll=True, start=False):
         """ll[c] and d ll / d operand at the operand derived from q.
         `want_ll=False`: the gradient alone -- the interior evaluations of a
         trajectory (hmc.py:348-372 reads the log-joint at its two ends only);
-        the MFMA kernels then skip the log-likelihood terms."""
-        ll_ptr = self.ll.data_ptr() if want_ll else None
+        the MFMA kernels then skip the log-likelihood terms.  `start`: into
+        the start buffers (grad0 / ll0) instead of the trajectory's."""
+        grad, ll = (self.grad0, self.ll0) if start else (self.grad, self.ll)
+        ll_ptr = ll.data_ptr() if want_ll else None
         w = self.operand if self.operand is not None else q
         ws = self._ws if self.splits > 1 else None
         if self.kind == 'gathered_dot':
@@ -1546,48 +1561,50 @@ class _DenseLikelihoodPlan(_PlanBase):
                 self.lp_const.data_ptr(), self.n_chains,
                 self.n_lat if lat_is_u else self.n_other,
                 self.n_other if lat_is_u else self.n_lat, self.n_pairs,
-                self.n_dim, self.g_pairs.data_ptr(), self.ll.data_ptr(),
+                self.n_dim, self.g_pairs.data_ptr(), ll.data_ptr(),
                 self._ws.data_ptr(), stream)
             if self.n_pairs:
                 _capi.call('zshmc_gather_dot_grad', self.other.data_ptr(),
                            self.g_pairs.data_ptr(), self.seg.data_ptr(),
                            self.order.data_ptr(), self.idx_other.data_ptr(),
                            self.n_chains, self.n_lat, self.n_other,
-                           self.n_pairs, self.n_dim, self.grad.data_ptr(),
+                           self.n_pairs, self.n_dim, grad.data_ptr(),
                            stream)
             else:
-                _capi.call('zshmc_zero', self.grad.data_ptr(),
-                           4 * self.grad.numel(), stream)
+                _capi.call('zshmc_zero', grad.data_ptr(),
+                           4 * grad.numel(), stream)
         elif self.kind == 'linear_categorical':
             _capi.call('zshmc_linear_categorical_log_lik', w.data_ptr(),
                        self.inner.data_ptr(), self.obs.data_ptr(),
                        self.lik_rows, self.inner.shape[0], self.width,
                        self.n_classes, self.stride, ll_ptr,
-                       self.grad.data_ptr(), self.splits, _capi.ptr(ws),
+                       grad.data_ptr(), self.splits, _capi.ptr(ws),
                        stream)
         elif self.kind == 'linear_bernoulli':
             _capi.call('zshmc_linear_bernoulli_log_lik', w.data_ptr(),
                        self.inner.data_ptr(), self.obs.data_ptr(),
                        self.n_chains, self.inner.shape[0], self.width,
-                       ll_ptr, self.grad.data_ptr(), self.splits,
+                       ll_ptr, grad.data_ptr(), self.splits,
                        _capi.ptr(ws), stream)
         else:
             _capi.call('zshmc_linear_multinomial_log_lik', w.data_ptr(),
                        self.inner.data_ptr(), self.obs.data_ptr(),
                        self.obs.shape[0], self.obs_stride, self.n_chains,
                        self.inner.shape[0], self.width, ll_ptr,
-                       self.grad.data_ptr(), self.splits, _capi.ptr(ws),
+                       grad.data_ptr(), self.splits, _capi.ptr(ws),
                        stream)
 
     def _step(self, q, p, use_grad, eps_host, kick, drift, lp_out, kinetic,
-              stream):
-        """csrc/hmc_model.hip: prior + Jacobian + kick + drift + operand."""
+              stream, start=False):
+        """csrc/hmc_model.hip: prior + Jacobian + kick + drift + operand.
+        `start`: the evaluation it reads is the start buffers'."""
+        grad, ll = (self.grad0, self.ll0) if start else (self.grad, self.ll)
         if self.segmented:
             # csrc/hmc_model_seg.hip: the class rows of a chain are rows
             # c * stride + k of the gradient / operand matrices
             _capi.call(
                 'zshmc_model_kick_drift_seg', q.data_ptr(), p.data_ptr(),
-                self.grad.data_ptr() if use_grad else None, self.width,
+                grad.data_ptr() if use_grad else None, self.width,
                 self.seg_len, self.stride, _capi.ptr(self.operand),
                 self.width, self.prior_mean.data_ptr(), self.mean_rows,
                 self.prior_logstd.data_ptr(), self.logstd_rows,
@@ -1596,12 +1613,12 @@ class _DenseLikelihoodPlan(_PlanBase):
                 0.0 if eps_host is None else float(eps_host), float(kick),
                 float(drift), float(self.lik_scale()), self.n_chains,
                 self.n_total, self.ld,
-                self.ll.data_ptr() if use_grad else None, _capi.ptr(lp_out),
+                ll.data_ptr() if use_grad else None, _capi.ptr(lp_out),
                 _capi.ptr(kinetic), self.seg_ws.data_ptr(), stream)
             return
         _capi.call(
             'zshmc_model_kick_drift', q.data_ptr(), p.data_ptr(),
-            self.grad.data_ptr() if use_grad else None, self.width,
+            grad.data_ptr() if use_grad else None, self.width,
             _capi.ptr(self.operand), self.width, int(self.softmax),
             self.prior_mean.data_ptr(), self.mean_rows,
             self.prior_logstd.data_ptr(), self.logstd_rows,
@@ -1610,7 +1627,7 @@ class _DenseLikelihoodPlan(_PlanBase):
             0.0 if eps_host is None else float(eps_host), float(kick),
             float(drift), float(self.lik_scale()), self.n_chains,
             self.n_total, self.ld,
-            self.ll.data_ptr() if use_grad else None, _capi.ptr(lp_out),
+            ll.data_ptr() if use_grad else None, _capi.ptr(lp_out),
             _capi.ptr(kinetic), stream)
 
     def _momentum(self, t, stream):
@@ -1625,11 +1642,46 @@ class _DenseLikelihoodPlan(_PlanBase):
                        self.hmc.seed, t & 0xFFFFFFFF, k,
                        self.kin_old.data_ptr(), stream)
 
+    def _start_is_valid(self):
+        """grad0 / ll0 hold the likelihood evaluation at the latents as they
+        are: left there by the last transition (or evaluation), the model's
+        tensors unchanged since (refresh_model), nobody else having written a
+        latent (our own writes go through the C-ABI and leave torch's version
+        counters alone)."""
+        return self.carry_start and self._start_valid and all(
+            q._version == v for q, v in zip(self.q, self._start_versions))
+
+    def _mark_start(self):
+        self._start_valid = True
+        self._start_versions = [q._version for q in self.q]
+
     def _first_evaluation(self, q, stream):
-        """operand(q), then likelihood + gradient at q (self.ll, self.grad)."""
+        """operand(q), then likelihood + gradient at q (ll0, grad0) -- unless
+        they are there already."""
+        if self._start_is_valid():
+            # (softmax: the step's Jacobian reads theta = softmax(q) from the
+            # operand buffer, which holds the last PROPOSAL's)
+            if self.softmax:
+                self._step(q, self.p, False, 0.0, 0.0, 0.0, None, None, stream)
+            return
         if self.operand is not None:
             self._step(q, self.p, False, 0.0, 0.0, 0.0, None, None, stream)
-        self._likelihood(q, stream)
+        self._likelihood(q, stream, start=True)
+        self._mark_start()
+
+    def _carry_start(self, stream):
+        """Behind the MH test and the select: the accepted chains' last
+        evaluation becomes the evaluation at their (new) state."""
+        if self.hmc.n_leapfrogs < 1:
+            return
+        n = self.lik_rows // self.n_chains * self.width
+        _capi.call('zshmc_copy_rows', self.grad0.data_ptr(), n,
+                   self.grad.data_ptr(), n, self.accept.data_ptr(),
+                   self.n_chains, n, stream)
+        g = self.lik_rows // self.n_chains
+        _capi.call('zshmc_copy_rows', self.ll0.data_ptr(), g,
+                   self.ll.data_ptr(), g, self.accept.data_ptr(),
+                   self.n_chains, g, stream)
 
     # -- step-size search (hmc.py:308-345) -----------------------------------
     def reduce_stats(self, sharding, stream):
@@ -1647,29 +1699,24 @@ class _DenseLikelihoodPlan(_PlanBase):
         self._momentum(t, stream)
         self._load_state(stream)
         self._first_evaluation(self.q_new, stream)
-        self._search_cache = (self.ll.clone(), self.grad.clone(),
-                              None if self.operand is None
-                              else self.operand.clone())
 
     def _restore_start(self, t, stream):
-        """(q, p0, ll, grad, operand) of the start point: q from the latent,
-        p0 regenerated from its Philox counters (cheaper in memory than a
-        copy: config 5 holds 21 GB per [rows, K] buffer), the evaluation from
-        the search cache."""
-        ll0, g0, op0 = self._search_cache
+        """(q, p0) of the start point: q from the latent, p0 regenerated from
+        its Philox counters (cheaper in memory than a copy: config 5 holds
+        21 GB per [rows, K] buffer); its evaluation sits in the start buffers,
+        which a search trip reads and never writes."""
         self._load_state(stream)
         self._momentum(t, stream)
-        self.ll.copy_(ll0)
-        self.grad.copy_(g0)
-        if op0 is not None:
-            self.operand.copy_(op0)
+        if self.softmax:      # theta(q) for the step's Jacobian (see above)
+            self._step(self.q_new, self.p, False, 0.0, 0.0, 0.0, None, None,
+                       stream)
 
     def search_trip(self, t, step_size, stream):
         self._in_search = True
         self._restore_start(t, stream)
         q1, p1 = self.q_new, self.p
         self._step(q1, p1, True, step_size, 0.5, 1.0, self.lp_old, None,
-                   stream)
+                   stream, start=True)
         self._likelihood(q1, stream)
         _capi.call('zshmc_zero', self.kin_new.data_ptr(), 4 * self.n_chains,
                    stream)
@@ -1712,6 +1759,10 @@ class _DenseLikelihoodPlan(_PlanBase):
         d.operand = c.ptr(self.operand)
         d.grad, d.ll = self.grad.data_ptr(), self.ll.data_ptr()
         d.lik_rows, d.width = self.lik_rows, self.width
+        if self.carry_start:
+            d.grad_start, d.ll_start = self.grad0.data_ptr(), \
+                self.ll0.data_ptr()
+            d.start_valid = int(self._start_is_valid())
         d.split_ws = c.ptr(self._ws)
         if self.segmented:
             d.seg_len, d.groups = self.seg_len, self.stride
@@ -1769,7 +1820,6 @@ class _DenseLikelihoodPlan(_PlanBase):
             self.compute_colstats(stream)
             if sharded:
                 sharding.all_reduce_sum(self.comm_buf[_capi.STATS_WORDS:])
-        self._search_cache = None
         d = self._descriptor()
         scales = None
         if lik_scales is not None:
@@ -1788,6 +1838,11 @@ class _DenseLikelihoodPlan(_PlanBase):
                    sharding._comm if sharded else None, stream)
         self.last_t = t_first + n - 1
         self.stats_local = False
+        if n >= 1:
+            if self.carry_start:
+                self._mark_start()
+            else:
+                self._start_valid = False
         if adapt_mass:
             self._mark_colstats()
             self._mass_ones = False
@@ -1800,19 +1855,18 @@ class _DenseLikelihoodPlan(_PlanBase):
         self.last_t = t
         L = self.hmc.n_leapfrogs
         q, p = self.q_new, self.p
-        if self._search_cache is not None:    # same q, same p0 (Appendix B 11)
-            self._restore_start(t, stream)
-            self._search_cache = None
-        else:
-            self._load_state(stream)
-            self._momentum(t, stream)
-            self._first_evaluation(q, stream)
+        # (behind a step-size search: same q, same p0 -- Appendix B 11 -- and
+        # the start evaluation is still in its buffers)
+        self._load_state(stream)
+        self._momentum(t, stream)
+        self._first_evaluation(q, stream)
         _capi.call('zshmc_zero', self.kin_new.data_ptr(), 4 * self.n_chains,
                    stream)
         # trip 0: zero-length drift, half kick (hmc.py:352-364); the drift of
         # trip i+1 rides behind the kick of trip i
         self._step(q, p, True, eps_host, 0.5, 1.0 if L >= 1 else 0.0,
-                   self.lp_old, self.kin_new if L == 0 else None, stream)
+                   self.lp_old, self.kin_new if L == 0 else None, stream,
+                   start=True)
         if L == 0:
             self.lp_new.copy_(self.lp_old)
         for i in range(1, L + 1):
@@ -1831,6 +1885,10 @@ class _DenseLikelihoodPlan(_PlanBase):
                    self.accept.data_ptr(), self.acc_sum.data_ptr(),
                    self.flags.data_ptr(), stream)
         self._store_state(stream)
+        if self.carry_start:
+            self._carry_start(stream)
+        else:
+            self._start_valid = False
 
 
 def _to_row_period(param, chain_shape, n_data):
@@ -2295,7 +2353,7 @@ def _try_gathered_dot_plan(hmc, meta_bn, names, values, chain_shape, device):
     plan._load_state(stream)
     plan._first_evaluation(plan.q_new, stream)
     plan._step(plan.q_new, plan.p, True, 0.0, 0.0, 0.0, plan.lp_new, None,
-               stream)
+               stream, start=True)
     diff = float((plan.lp_new - lp_user).abs().max().item())
     scale = max(1.0, float(lp_user.abs().max().item()))
     if not diff <= 2e-5 * scale + 1e-3:
