@@ -1351,8 +1351,14 @@ class _DenseLikelihoodPlan(_PlanBase):
                 a._version) for a in t]
         if self._src is not None and key == self._src[0]:
             return
+        # another likelihood (design matrix, observations): another
+        # evaluation at the start.  New PRIOR tensors alone -- a model function
+        # that builds `torch.zeros(d)` per call -- leave the likelihood term's
+        # carried evaluation valid: the step recomputes the prior.
+        n_prior = 2 * len(priors)
+        if self._src is None or key[n_prior:] != self._src[0][n_prior:]:
+            self._start_valid = False
         self._src = (key, t)
-        self._start_valid = False     # another model: another evaluation
         C = self.n_chains
         self._pack_prior(priors)
         ops = self._ops
