@@ -793,7 +793,7 @@ def extra_config5(torch, zs, dev, n_chains=None, **kw):
     free_b, _ = torch.cuda.mem_get_info()
     if n_chains is None:
         n_chains = 8192
-        # q, q_new, p, grad, operand + search cache (grad, operand) + headroom
+        # q, q_new, p, grad, grad_start, operand (21 GB each at 8 192) + headroom
         while n_chains > 64 and 9.0 * n_chains * 5000 * 128 * 4 > free_b:
             n_chains //= 2
     return lntm_workload(torch, zs, dev, n_chains, **kw)
