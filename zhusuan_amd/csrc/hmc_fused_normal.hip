@@ -205,13 +205,8 @@ __global__ __launch_bounds__(256, ZS_WAVES_PER_EU) void hmc_diag_normal_kernel(
     for (int k = 0; k < NCH; ++k) {
       const uint32_t group = (uint32_t)(k * G + l);
       float z0, z1, z2, z3;
-#ifdef ZS_NO_RNG
-      z0 = __uint_as_float(0x3f000000u | ((group * 2654435761u + gchain) & 0x7fffffu));
-      z1 = z0 - 0.75f; z2 = 0.6f - z0; z3 = z0 * z1;
-#else
       normal4(group, gchain, iteration, kStreamMomentum, key0, key1, z0, z1,
               z2, z3);
-#endif
       p[k] = f4{z0, z1, z2, z3};
       if (HAS_MASS) {
         p[k] = p[k] * *reinterpret_cast<const f4*>(s_sqrtm + (k * G + l) * 4);

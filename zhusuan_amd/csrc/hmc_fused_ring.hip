@@ -75,9 +75,6 @@ namespace zshmc {
                       // shallower ring shortens the read -> write-back distance
                       // of a row (0.0951 -> 0.0925 ms)
 #endif
-#ifndef ZS_RING_DMA_POS
-#define ZS_RING_DMA_POS 0
-#endif
 #ifndef ZS_RNG_PAIR
 #define ZS_RNG_PAIR 1  // generator runs two chunks interleaved (A/B knob)
 #endif
@@ -223,15 +220,6 @@ __device__ __forceinline__ float keep_if(float v, uint64_t mask) {
 // ZS_NO_LD / ZS_NO_ST: one direction of the row traffic)
 template <bool LOAD>
 __device__ __forceinline__ Mask mask_if(bool c) {
-#if defined(ZS_NO_MEM)
-  c = false;
-#endif
-#if defined(ZS_NO_LD)
-  if (LOAD) c = false;
-#endif
-#if defined(ZS_NO_ST)
-  if (!LOAD) c = false;
-#endif
   const uint32_t f = uni32(c ? 0xFFFFFFFFu : 0u);
   return Mask{f, f};
 }
@@ -272,42 +260,19 @@ __device__ __forceinline__ void store_row(uint32_t voff, uint32_t voff_last,
 // Waves per SIMD = the register budget that compiles WITHOUT scratch spills
 // (a spill is a VMEM instruction the vmcnt ledger does not know about;
 // tests/test_build_resources.py asserts "VGPRs Spill: 0" per instantiation).
-// COLSTATS instantiations (column sums of the end state, see the kernel); how
-// a chain's 4*NCH (q' - m) and (q' - m)^2 per lane reach the workgroup's
-// double tile, measured at 65 536 x 1 024, L = 10 (gpurun_out/r03c/kbench.txt;
-// plain launch 0.0924 ms, with a mass vector 0.0920 ms):
-// ZS_CS_MODE 0 (default): one ds_add_f64 per element per chain straight into
-//   the tile, no extra registers, the plain instantiation's waves per SIMD:
-//   0.1018 / 0.1022 ms (+10 / +11 %).  Double adds: the sums differ from run
-//   to run only by the order of the chains, at the 1e-16 level -- what the
-//   stand-alone column-statistics kernel's double atomics gave.
-// ZS_CS_MODE 1: DOUBLE register accumulators per lane over the chains its
-//   wave runs, added to the tile once after the loop: 8*NCH more VGPRs, two
-//   waves per SIMD at NCH >= 4: 0.1069 / 0.1045 ms at ring depth 1, 0.1117 /
-//   0.1071 at depth 2 (+14..+21 %): the lost occupancy costs more than the
-//   atomics.
-// ZS_CS_MODE 2: FLOAT register accumulators, three waves per SIMD: 0.0967 /
-//   0.0990 ms (+5 / +8 %) -- cheapest, but a float32 partial sum over the
-//   ~20 chains a wave happens to draw (tickets are dynamic) moves in its last
-//   bits from run to run, and with it the mass and every later transition.
-#ifndef ZS_CS_MODE
-#define ZS_CS_MODE 0
-#endif
-// waves per SIMD of the COLSTATS variants: what 8*NCH more VGPRs leave room
-// for without spills (ZS_CS_WAVES overrides, A/B)
-#ifndef ZS_CS_K
-#define ZS_CS_K 2  // ring depth of the COLSTATS variants where LDS has room
-#endif
+// COLSTATS instantiations (column sums of the end state, see the kernel): a
+// chain's 4*NCH (q' - m) and (q' - m)^2 per lane go straight into the
+// workgroup's double tile, one ds_add_f64 per element -- no extra registers,
+// the plain instantiation's waves per SIMD; the sums differ from run to run
+// only by the order of the chains, at the 1e-16 level.  Register accumulators
+// (double: two waves per SIMD; float: not bit-stable under dynamic tickets,
+// spills under static ones) were measured and lost: docs/LABNOTES.md 3.2, 10.
 constexpr int ring_waves_for(int nch, bool has_mass, bool colstats = false) {
   const int w = nch <= 3 ? 4
                          : (nch == 4 ? (has_mass ? 3 : ZS_RING_WAVES)
                                      : (nch == 5 && !has_mass ? 3 : 2));
-#ifdef ZS_CS_WAVES
-  const int cap = ZS_CS_WAVES;
-#else
-  const int cap = ZS_CS_MODE == 0 ? 4 : (nch <= 2 ? 4 : (nch == 3 ? 3 : 2));
-#endif
-  return (colstats && w > cap) ? cap : w;
+  (void)colstats;  // (the column sums cost no registers: same occupancy)
+  return w;
 }
 
 // STAGE: the workgroup's per-chain scalars (MH uniform in, five HMCInfo values
@@ -441,12 +406,7 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
   const float logz = wave_total_dpp(logz_part);
   // the drift's scalar factor: from an SGPR (v_pk_fma_f32 with a scalar
   // operand) or pinned in a VGPR (A/B knob, tools/kbench.py)
-#ifdef ZS_EPS_VGPR
-  float eps_l = eps;
-  asm volatile("" : "+v"(eps_l));
-#else
   const float eps_l = eps;
-#endif
   const int Lr = moving ? a.n_leapfrogs : 0;
   const float hk = moving ? 0.5f : 0.f;    // first half kick
   const float hk2 = Lr >= 1 ? 0.5f : 0.f;  // taken back from the last
@@ -460,25 +420,6 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
   if (wib == kWavesPerBlock - 1 && lane == 0)
     s_bad[2] = link_prepare(a.link, s_prep) ? 1 : 0;
 
-#ifdef ZS_PRIO_STAGGER
-  // A/B knob: static issue priorities by the wave's slot on its SIMD (waves
-  // of a workgroup are dealt round-robin to the 4 SIMDs: slot = wib >> 2).
-  // A high-priority wave runs its trip at nearly the full issue rate, so its
-  // row is written back sooner after it was read; the others fill its gaps.
-  // (tickets are drawn dynamically: the fast slots simply take more rows)
-  {
-    const int slot = __builtin_amdgcn_readfirstlane(wib >> 2);
-#if ZS_PRIO_STAGGER == 1
-    if (slot == 1) __builtin_amdgcn_s_setprio(1);
-    if (slot == 2) __builtin_amdgcn_s_setprio(2);
-    if (slot >= 3) __builtin_amdgcn_s_setprio(3);
-#elif ZS_PRIO_STAGGER == 2
-    if (slot == 0) __builtin_amdgcn_s_setprio(3);
-#else
-    if (slot < 2) __builtin_amdgcn_s_setprio(2);
-#endif
-  }
-#endif
   auto draw = [&]() -> int {  // next ticket of this workgroup (wave-uniform)
     int t = 0;
     if (lane == 0) t = atomicAdd(s_ticket, 1);
@@ -513,17 +454,6 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
 #ifdef ZS_TIMING
   unsigned long long n_done = 0;
 #endif
-#if ZS_CS_MODE == 2
-  typedef float cs_t;
-#else
-  typedef double cs_t;
-#endif
-  // COLSTATS, register modes: this lane's column sums over its wave's chains
-  cs_t cs1[COLSTATS ? NCH : 1][4], cs2[COLSTATS ? NCH : 1][4];
-#pragma unroll
-  for (int k = 0; k < (COLSTATS ? NCH : 1); ++k)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) cs1[k][j] = cs2[k][j] = 0;
   int slot = 0;
   for (int it = 0; tk[0] < count; ++it) {
     const int t_cur = tk[0];
@@ -541,11 +471,10 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
     else
       wait_vmcnt<(K - 1) * NCH + K * (NCH + kLedgerInfo)>();
     f4 r[NCH], p[NCH];
-    // refill of the slot this trip frees: where in the trip it is issued is
-    // an A/B knob (ZS_RING_DMA_POS: 0 right after the slot is in registers,
-    // 1 after the generator, 2 after the leapfrog -- later = a shorter
-    // distance between a row's read and its write-back); always before this
-    // trip's stores, so the vmcnt ledger does not change
+    // refill of the slot this trip frees: issued right after the slot is in
+    // registers (later in the trip -- a shorter distance between a row's read
+    // and its write-back -- measured no better); always before this trip's
+    // stores, so the vmcnt ledger does not change
     const float* late_src;
     uint32_t late_dst;
     bool late_on;
@@ -571,10 +500,8 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
                        (uint32_t)(COLSTATS ? (slot == 0 ? K : slot - 1) : slot) *
                            kRowB);
       late_on = nt < count;
-#if ZS_RING_DMA_POS == 0
       issue_row<NCH>(voff, voff_last, late_src, late_dst,
                      mask_if<true>(late_on));
-#endif
       slot = slot + 1 == kSlots ? 0 : slot + 1;
 #pragma unroll
       for (int j = 0; j + 1 < K; ++j) tk[j] = tk[j + 1];
@@ -587,9 +514,6 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
     // p += (s2/eps) * (nep * r), a drift is r += eps * p / m.
     uint32_t key0 = a.k0, key1 = a.k1;
     asm volatile("" : "+s"(key0), "+s"(key1));
-#ifdef ZS_PRIO_RNG
-    __builtin_amdgcn_s_setprio(ZS_PRIO_RNG);
-#endif
     f4 ko = f4{0.f, 0.f, 0.f, 0.f}, uo = ko;
     // one chunk's share of: p0 = z * sqrt(mass), K0, U0, first half kick
     auto start_chunk = [&](int k, float z0, float z1, float z2, float z3) {
@@ -606,15 +530,6 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
       uo += t * r[k];
       p[k] += hk * t;
     };
-#ifdef ZS_NO_RNG  // A/B probe only: how much of the trip is the generator
-#pragma unroll
-    for (int k = 0; k < NCH; ++k) {
-      const uint32_t group = (uint32_t)(k * kWave + lane);
-      const float z0 = __uint_as_float(
-          0x3f000000u | ((group * 2654435761u + gchain) & 0x7fffffu));
-      start_chunk(k, z0, z0 - 0.75f, 0.6f - z0, z0 * (z0 - 0.75f));
-    }
-#else
     // the generator runs two chunks at a time where the register budget has
     // room (philox.h: normal4x2), one otherwise
     constexpr int kPair = (ZS_RNG_PAIR && NCH <= 4) ? 2 : 1;
@@ -637,21 +552,10 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
                 z1, z2, z3);
         start_chunk(k, z0, z1, z2, z3);
       }
-#ifdef ZS_RING_SERIAL_RNG
-      // one generator state live at a time (register budget for 4 waves/SIMD)
-      __builtin_amdgcn_sched_barrier(0);
-#endif
     }
-#endif
 
-#if ZS_RING_DMA_POS == 1
-    issue_row<NCH>(voff, voff_last, late_src, late_dst, mask_if<true>(late_on));
-#endif
     // ---- leapfrog (hmc.py:348-372): L full drifts + full kicks; half of the
     // last kick is taken back below ----------------------------------------
-#ifdef ZS_PRIO_LF
-    __builtin_amdgcn_s_setprio(ZS_PRIO_LF);
-#endif
     // (bottom-tested: a top-tested loop makes hipcc copy r and p into fresh
     // registers on the zero-trip edge, 12-16 v_mov per chain)
     if (Lr > 0) {
@@ -668,12 +572,6 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
       } while (--i > 0);
     }
 
-#ifdef ZS_PRIO_END
-    __builtin_amdgcn_s_setprio(ZS_PRIO_END);
-#endif
-#if ZS_RING_DMA_POS == 2
-    issue_row<NCH>(voff, voff_last, late_src, late_dst, mask_if<true>(late_on));
-#endif
     // ---- Hamiltonians (hmc.py:30-35) and acceptance (hmc.py:46-61) -------
     f4 kn = f4{0.f, 0.f, 0.f, 0.f}, un = kn;
 #pragma unroll
@@ -690,13 +588,7 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
     float u_old = (uo[0] + uo[1]) + (uo[2] + uo[3]);
     float k_new = (kn[0] + kn[1]) + (kn[2] + kn[3]);
     float u_new = (un[0] + un[1]) + (un[2] + un[3]);
-#ifndef ZS_NO_REDUCE  // A/B probe only
-#ifdef ZS_SLOW_TAIL
-    wave_total4_dpp(k_old, u_old, k_new, u_new);
-#else
     wave_total4_swap(k_old, u_old, k_new, u_new);
-#endif
-#endif
     if (HAS_MASS) {  // sum p^2/m = (1/se) sum p^2 * (se/m)
       k_old *= inv_se;
       k_new *= inv_se;
@@ -706,11 +598,6 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
     const float h_old = -lp_old + 0.5f * k_old;
     const float h_new = -lp_new + 0.5f * k_new;
     const float dh = h_old - h_new;
-#ifdef ZS_SLOW_TAIL  // A/B probe only: libm expf + compiler-chosen selects
-    float acc = expf(fminf(dh, 0.0f));
-    // fminf drops a NaN operand: test explicitly (hmc.py:56-59)
-    if (!(dh == dh) || !isfinite(acc) || !isfinite(lp_new)) acc = 0.f;
-#else
     // exp(min(dh, 0)) on v_exp_f32 (argument <= 0: no overflow, underflow
     // flushes to 0), then the guards of hmc.py:56-59.  fminf drops a NaN
     // operand, so NaN is tested explicitly; exp of a non-positive finite
@@ -720,18 +607,13 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
     const float acc = keep_if(
         __builtin_amdgcn_exp2f(fminf(dh, 0.0f) * 1.4426950408889634f),
         __builtin_amdgcn_ballot_w64((dh == dh) && isfinite(lp_new)));
-#endif
     if (!isfinite(lp_old)) bad_old = true;
 
-#ifdef ZS_NO_UNIF  // A/B probe only
-    const float u = 0.5f;
-#else
     float u;
     if (STAGE)
       u = s_u[t_cur];
     else
       u = uniform_chain(gchain, iteration, key0, key1);
-#endif
     const bool accept = u < acc;  // strict, hmc.py:486
 
     // STAGE: the sum is taken from the staged values after the loop, in
@@ -759,12 +641,8 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
     // ---- the five HMCInfo scalars of this chain (lane 0; hmc.py:508-517) --
     // Staged in LDS under the chain's ticket and written back as whole lines
     // after the loop (STAGE), or stored from here as 5 ledger entries.
-#ifdef ZS_SLOW_TAIL
-    const float lp_sel = accept ? lp_new : lp_old;
-#else
     const float lp_sel =
         select_e64(__builtin_amdgcn_ballot_w64(accept), lp_new, lp_old);
-#endif
     if (STAGE) {
       if (lane == 0) {
         const int cap = a.info_cap;
@@ -795,40 +673,16 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
         const f4 d = v - *reinterpret_cast<const f4*>(s_cm + (k * kWave + lane) * 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-#if ZS_CS_MODE == 0
           const int idx = (k * 4 + j) * kWave + lane;
           __hip_atomic_fetch_add(&s_cs[idx], (double)d[j], __ATOMIC_RELAXED,
                                  __HIP_MEMORY_SCOPE_WORKGROUP);
           __hip_atomic_fetch_add(&s_cs[kRow + idx],
                                  (double)d[j] * (double)d[j], __ATOMIC_RELAXED,
                                  __HIP_MEMORY_SCOPE_WORKGROUP);
-#else
-          const cs_t dj = (cs_t)d[j];
-          cs1[k][j] += dj;
-          cs2[k][j] += dj * dj;  // (double: exact product, as the
-                                 // stand-alone kernel's)
-#endif
         }
       }
     }
   }
-#if ZS_CS_MODE != 0
-  if (COLSTATS) {
-    // this wave's sums into the workgroup's tile, once
-#pragma unroll
-    for (int k = 0; k < NCH; ++k) {
-      if (k == NCH - 1 && !valid_last) continue;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int idx = (k * 4 + j) * kWave + lane;
-        __hip_atomic_fetch_add(&s_cs[idx], (double)cs1[k][j], __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(&s_cs[kRow + idx], (double)cs2[k][j],
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-    }
-  }
-#endif
   // no DMA may outlive the wave (its LDS would be handed to another block)
   wait_vmcnt<0>();
 #ifdef ZS_TIMING
@@ -892,7 +746,7 @@ constexpr size_t kLdsLimit = 160 * 1024;
 // has to fit in LDS next to the double tile): NCH <= 2 keep K = 3, the wider
 // rows run one row ahead like NCH = 4 does anyway
 constexpr int ring_cs_k(int nch) {
-  return nch <= 2 ? 3 : (nch <= 5 && ZS_CS_MODE != 0 ? ZS_CS_K : 1);
+  return nch <= 2 ? 3 : 1;
 }
 constexpr int kRingCsMaxNch = 6;  // 7, 8: LDS / VGPR budget exhausted
 

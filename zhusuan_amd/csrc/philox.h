@@ -43,11 +43,7 @@ struct U4 {
 // of them with the SGPR round key as operand (the slow issue class,
 // tools/instr_bench.hip): 40 of the 60 VALU instructions of a Philox call.
 __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
-#ifdef ZS_NO_BITOP3  // A/B probe only
-  return a ^ b ^ c;
-#else
   return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
-#endif
 }
 
 __device__ __forceinline__ U4 philox4x32(uint32_t c0, uint32_t c1,
