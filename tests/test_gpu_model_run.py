@@ -317,6 +317,18 @@ def test_start_evaluation_is_carried_over(env, which):
         finally:
             _capi.call = real
         assert sum(c in LIK_CALLS for c in calls) == L + 1, calls
+        # ... and so does an in-place change of an observed tensor (another
+        # likelihood); the run after that carries again
+        for expect in (L + 1, L if mode.startswith('carry') else L + 1):
+            if expect == L + 1:
+                observed[sorted(observed)[0]].add_(0)
+            del calls[:]
+            _capi.call = spy
+            try:
+                op.run(feed_dict=feeds[1][1])
+            finally:
+                _capi.call = real
+            assert sum(c in LIK_CALLS for c in calls) == expect, (expect, calls)
         out[mode] = dict(
             q={k: v.clone() for k, v in q.items()},
             info={f: getattr(info, f).clone() for f in (
