@@ -329,6 +329,16 @@ def test_start_evaluation_is_carried_over(env, which):
             finally:
                 _capi.call = real
             assert sum(c in LIK_CALLS for c in calls) == expect, (expect, calls)
+        # a write torch's version counters do not see (x.data): announced
+        q[name0].data.mul_(1.0)
+        hmc.latents_changed()
+        del calls[:]
+        _capi.call = spy
+        try:
+            op.run(feed_dict=feeds[1][1])
+        finally:
+            _capi.call = real
+        assert sum(c in LIK_CALLS for c in calls) == L + 1, calls
         out[mode] = dict(
             q={k: v.clone() for k, v in q.items()},
             info={f: getattr(info, f).clone() for f in (

@@ -572,6 +572,23 @@ class HMC(object):
         if sync:
             self.check_numerics()
 
+    def latents_changed(self):
+        """Tell the sampler that a latent was written behind torch's back.
+
+        What the sampler keeps ABOUT the latents between runs -- the
+        likelihood evaluation at the current state (native model plans), the
+        column sums of the mass estimator -- is dropped when a latent's
+        version counter moved: every in-place torch op on the tensor does
+        that.  A write through `x.data`, a raw pointer or another library
+        does not; call this after one."""
+        plan = self._plan
+        if plan is None:
+            return
+        if hasattr(plan, '_start_valid'):
+            plan._start_valid = False
+        if plan.colsum_state in ('fresh', 'parts'):
+            plan.colsum_state = 'dirty'
+
     def flush(self):
         """Retire a step-size update still owed to the last transition (the
         fused plan carries it into the next launch); afterwards the device
