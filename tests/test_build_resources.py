@@ -286,3 +286,44 @@ def test_likelihood_steps_fit_their_issue_slots(lb_build, mid_build):
         gemm1, gemm2 = gaps[:n1 - 1], gaps[n1:2 * n1 - 1]
         assert max(gemm1) <= 10, (width, gemm1)
         assert sum(g > 8 for g in gemm2) <= 5, (width, gemm2)
+
+
+def _tile_loop_top(body):
+    """Instructions from the tile loop's header (the target of the backward
+    branch behind the last MFMA) to the first MFMA."""
+    lines = body.splitlines()
+    mf = [i for i, l in enumerate(lines) if l.strip().startswith('v_mfma')]
+    labels = {l.split(':')[0].strip(): i for i, l in enumerate(lines)
+              if re.match(r'^\.LBB\d+_\d+:', l)}
+    targets = []
+    for l in lines[mf[-1]:mf[-1] + 40]:
+        m = re.match(r'\s*(s_c?branch\w*)\s+(\.LBB\d+_\d+)', l)
+        if m and labels.get(m.group(2), 1 << 30) < mf[0]:
+            targets.append(labels[m.group(2)])
+            if m.group(1) == 's_branch':     # the back edge itself
+                break
+    assert targets
+    header = min(targets)
+    out = [l.split(';')[0].strip() for l in lines[header:mf[0]]]
+    return [l for l in out if l and not l.startswith('.') and
+            not l.endswith(':')]
+
+
+def test_nothing_heavy_sits_between_two_tiles(lb_build, mid_build):
+    """DESIGN 3.3, rule (b): a tile's state is advanced by additions inside
+    the tile before.  Between the last MFMA of a tile and the first of the
+    next there is no 64-bit multiply and no 64-bit compare on the vector unit
+    (what rebuilding the state from the tile index costs), and the whole top
+    of the loop -- the ragged-tile path included -- stays short."""
+    cases = [(lb_build[1], '_ZN5zshmc23linear_bernoulli_kernelILi%dELb1ELi%dELb0E', w, op)
+             for w in (64, 128, 256) for op in (0, 1)]
+    cases += [(mid_build[1], '_ZN5zshmc27linear_bernoulli_mid_kernelILi%dELb1ELi%dELb0E',
+               w, op) for w in (320, 896) for op in (0, 1)]
+    for asm, pat, width, op in cases:
+        m = re.search(r'^' + pat % (width, op) + r'\w+:[^\n]*\n(.*?)s_endpgm',
+                      asm, re.S | re.M)
+        top = _tile_loop_top(m.group(1))
+        heavy = [l for l in top if re.match(
+            r'(s_mul_hi_u32|v_mul_hi_u32|v_cmp_\w+_[iu]64|v_mad_u64_u32)', l)]
+        assert not heavy, (width, op, heavy)
+        assert len(top) <= 90, (width, op, len(top))

@@ -295,7 +295,16 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel(
   auto load_counts = [&](const float* __restrict__ xrow0, int rows_in_tile,
                          float* dst) {
     const int left = rows_in_tile - (b * 32 + 4 * hi);  // may be <= 0
-    if (yc_vec) {
+    if (yc_vec && rows_in_tile == kRows) {
+      // a full tile (all but X's last): every lane's four groups are inside
+      // it -- four plain loads, no per-lane tests
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f4 v = *reinterpret_cast<const f4*>(xrow0 + 8 * j);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) dst[j * 4 + m] = v[m];
+      }
+    } else if (yc_vec) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         f4 v = f4{0.f, 0.f, 0.f, 0.f};
@@ -409,7 +418,9 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel(
     const TileSrc tnext = nx;
     const float* const ynext = ynx;
     const int buf_next = buf ^ 1;
-    if (OP == 1) load_counts(cnt_nx, nx_rows, xnext);
+    // (OP 1: the counts of tile t+1 go out in phase 1's third step)
+    const float* const cnt_next = cnt_nx;
+    const int rows_next = nx_rows;
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- phase 1: own 32 rows, full K, one accumulator chain ---------------
@@ -427,8 +438,9 @@ __global__ __launch_bounds__(256, ZS_LB_MINW(D)) void linear_bernoulli_kernel(
       // gap 1: the next step's operand / phase 3's first operand row
       if constexpr (kk + 1 < KK) {
         lds_read<(kk + 1) * 32>(av[(kk + 1) & 1], a_addr);
-        // (and, once, the wave's 16 labels of tile t+1)
+        // (and, once, the wave's 16 labels of tile t+1 / this lane's counts)
         if constexpr (OP != 1 && kk == 1) dma_labels(tnext, ynext, buf_next);
+        if constexpr (OP == 1 && kk == 2) load_counts(cnt_next, rows_next, xnext);
       } else if constexpr (GRAD) {
         static_for<NH>([&](auto hc) {
           constexpr int h = decltype(hc)::value;
