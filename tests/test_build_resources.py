@@ -298,7 +298,10 @@ def _tile_loop_top(body):
     targets = []
     for l in lines[mf[-1]:mf[-1] + 40]:
         m = re.match(r'\s*(s_c?branch\w*)\s+(\.LBB\d+_\d+)', l)
-        if m and labels.get(m.group(2), 1 << 30) < mf[0]:
+        # (branches into the loop's own top: a few hundred lines at most in
+        # front of its first MFMA; the scan may run into later blocks whose
+        # branches go elsewhere)
+        if m and mf[0] - 400 < labels.get(m.group(2), 1 << 30) < mf[0]:
             targets.append(labels[m.group(2)])
             if m.group(1) == 's_branch':     # the back edge itself
                 break
