@@ -696,6 +696,19 @@ class HMC(object):
 # ----------------------------------------------------------------------------
 # execution plans
 # ----------------------------------------------------------------------------
+def _versions(tensors):
+    """torch's version counters of `tensors` (what an in-place op bumps), or
+    None when one of them does not keep one (an inference-mode tensor): then
+    nothing may be assumed about what happened to it between two runs."""
+    out = []
+    for t in tensors:
+        try:
+            out.append(t._version)
+        except RuntimeError:
+            return None
+    return out
+
+
 def _prod(shape):
     n = 1
     for s in shape:
@@ -763,8 +776,9 @@ class _PlanBase(object):
     # zshmc_mass_colstats need), 'fresh' (global column sums of the CURRENT
     # latents around the current EWMV mean, summed over the ranks), 'dirty'.
     def _colstats_fresh(self):
-        return self.colsum_state in ('fresh', 'parts') and all(
-            q._version == v for q, v in zip(self.q, self._colsum_versions))
+        now = _versions(self.q)
+        return self.colsum_state in ('fresh', 'parts') and now is not None \
+            and now == self._colsum_versions
 
     def compute_colstats(self, stream):
         """Local column sums of (q - m), (q - m)^2 of every latent."""
@@ -781,7 +795,7 @@ class _PlanBase(object):
 
     def _mark_colstats(self):
         self.colsum_state = 'fresh'
-        self._colsum_versions = [q._version for q in self.q]
+        self._colsum_versions = _versions(self.q)
 
     def update_mass(self, update, use_ones, stream, sharding):
         """HMC._adapt_mass (hmc.py:284-305) for every latent.  The column
@@ -1105,7 +1119,7 @@ class _FusedDiagNormalPlan(_PlanBase):
         if rows:
             self._cs_rows = rows
             self.colsum_state = 'parts'
-            self._colsum_versions = [q._version for q in self.q]
+            self._colsum_versions = _versions(self.q)
         if sharded and update is not None:
             # applied by the next launch's prologue (or flush()) once the
             # acceptance sums of all ranks have been added
@@ -1671,12 +1685,13 @@ class _DenseLikelihoodPlan(_PlanBase):
         tensors unchanged since (refresh_model), nobody else having written a
         latent (our own writes go through the C-ABI and leave torch's version
         counters alone)."""
-        return self.carry_start and self._start_valid and all(
-            q._version == v for q, v in zip(self.q, self._start_versions))
+        now = _versions(self.q)
+        return self.carry_start and self._start_valid and now is not None \
+            and now == self._start_versions
 
     def _mark_start(self):
         self._start_valid = True
-        self._start_versions = [q._version for q in self.q]
+        self._start_versions = _versions(self.q)
 
     def _first_evaluation(self, q, stream):
         """operand(q), then likelihood + gradient at q (ll0, grad0) -- unless
