@@ -1,0 +1,77 @@
+"""bench.py's multi-GPU bootstrap ("make the first 8-GPU
+contact boring"): when the RCCL communicator cannot be made, EVERY rank exits
+with status 3 and rank-tagged JSON on stderr -- a scaling curve over a silent
+host-staged fallback would be a curve of the wrong thing -- unless the gloo
+path was asked for (ZSHMC_ALLOW_GLOO_FALLBACK=1), in which case the line says
+so.  Two gloo ranks on CPU: there is no GPU here, so the attempt fails by
+construction (torch.cuda.set_device)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import torch
+import torch.distributed as dist
+import bench
+from zhusuan_amd.distributed import ChainSharding
+dist.init_process_group(backend='gloo', rank=int(os.environ['RANK']),
+                        world_size=int(os.environ['WORLD_SIZE']))
+sh, note = bench.make_sharding(dist, torch, ChainSharding, 'rccl',
+                               torch.device('cpu'), chain_offset=0,
+                               n_chains_global=8)
+print('NOTE', sh.backend, note)
+buf = torch.ones(2, dtype=torch.float64)
+sh.all_reduce_sum(buf)
+print('SUM', buf.tolist())
+dist.destroy_process_group()
+'''
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _run_two_ranks(tmp_path, extra_env):
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER % {'root': ROOT})
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE='2',
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   GLOO_SOCKET_IFNAME='lo')
+        env.pop('ZSHMC_ALLOW_GLOO_FALLBACK', None)
+        env.update(extra_env)
+        procs.append(subprocess.Popen(
+            [sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+            stderr=subprocess.PIPE, universal_newlines=True))
+    return [p.communicate(timeout=240) + (p.returncode,) for p in procs]
+
+
+def test_failed_rccl_bootstrap_exits_3_on_every_rank(tmp_path):
+    for rank, (out, err, rc) in enumerate(_run_two_ranks(tmp_path, {})):
+        assert rc == 3, (rank, rc, err[-600:])
+        assert 'NOTE' not in out
+        line = [l for l in err.splitlines() if l.startswith('{')][-1]
+        msg = json.loads(line)
+        assert 'RCCL communicator unavailable on rank %d of 2' % rank \
+            in msg['error']
+        assert 'ZSHMC_DIST_BACKEND=gloo' in msg['hint']
+
+
+def test_gloo_fallback_has_to_be_asked_for_and_says_so(tmp_path):
+    res = _run_two_ranks(tmp_path, {'ZSHMC_ALLOW_GLOO_FALLBACK': '1'})
+    for rank, (out, err, rc) in enumerate(res):
+        assert rc == 0, (rank, rc, err[-600:])
+        assert 'NOTE torch FALLBACK torch.distributed/gloo' in out, out
+        assert 'SUM [2.0, 2.0]' in out
