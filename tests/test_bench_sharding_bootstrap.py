@@ -75,3 +75,18 @@ def test_gloo_fallback_has_to_be_asked_for_and_says_so(tmp_path):
         assert rc == 0, (rank, rc, err[-600:])
         assert 'NOTE torch FALLBACK torch.distributed/gloo' in out, out
         assert 'SUM [2.0, 2.0]' in out
+
+
+def test_gpus_without_a_launcher_is_refused():
+    """`bench.py --gpus 2` started as ONE process names the launch line
+    instead of measuring one GPU under a two-GPU label."""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'),
+                        '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       universal_newlines=True, timeout=240)
+    assert p.returncode != 0
+    assert 'torch.distributed.run' in p.stderr and '--nproc-per-node 2' \
+        in p.stderr, p.stderr[-400:]
+    assert p.stdout.strip() == ''
