@@ -921,6 +921,29 @@ def run_lntm_line(args, torch, zs, dist, ChainSharding, dev, world, rank,
         dist.destroy_process_group()
 
 
+def self_launch(n_gpus):
+    """`python bench.py --gpus N ...` without a launcher: re-run the same
+    command line under `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N` on loopback (the container's hostname may not
+    resolve) and return its exit status.  stdout / stderr pass through, so
+    rank 0's one JSON line is this process's output."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           '--nproc-per-node', str(n_gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write('bench.py: no launcher environment, starting %d ranks: '
+                     '%s\n' % (n_gpus, ' '.join(cmd)))
+    sys.stderr.flush()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    return subprocess.call(cmd, env=env)
+
+
 def _capi_kernel_name(n_data, has_mass, zero_mean):
     from zhusuan_amd import _capi
     return _capi.load().zshmc_fused_kernel_name(n_data, has_mass,
@@ -937,11 +960,14 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # started as ONE process (`python bench.py --gpus N ...`): become the
+        # launcher -- one rank per GPU under torch.distributed.run on this
+        # node, rank 0 prints the JSON line, our exit status is the job's
+        raise SystemExit(self_launch(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(
-                'bench.py --gpus %d must be launched with torch.distributed.run '
-                '--nproc-per-node %d' % (args.gpus, args.gpus))
+        raise SystemExit('bench.py --gpus %d inside a launcher environment '
+                         'of WORLD_SIZE=%d' % (args.gpus, world))
     assert torch.cuda.is_available(), 'bench.py needs an MI355X'
     # One process per GPU.  torch.distributed (a CPU/gloo group) only
     # bootstraps: it carries the RCCL unique id, the barriers around the timed

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ZSHMC_VERSION 420 /* 0.4.2: + zshmc_model_plan.grad_start / ll_start */
+#define ZSHMC_VERSION 500 /* 0.5.0: + the bf16x3 likelihood kernels, zshmc_model_plan.inner_image */
 
 /* status codes */
 #define ZSHMC_OK 0
@@ -499,6 +499,11 @@ typedef struct zshmc_model_plan {
   int32_t start_valid, start_pad;
   const float* inner; /* X / phi^T / the other factor table */
   int64_t n_inner;    /* data rows / vocabulary / rows of the other table */
+  /* ABI 0.5.0: the bf16x3 tile image of `inner` (zshmc_bf16x3_split) or NULL.
+   * With it the Bernoulli and mixture-multinomial likelihood evaluations that
+   * want a gradient run on the bf16 matrix cores
+   * (zshmc_linear_*_log_lik_bf16x3); NULL: the exact-fp32 kernels. */
+  const void* inner_image;
   const float* obs;   /* labels / counts / ratings */
   int64_t obs_rows, obs_stride;
   float* split_ws; /* row-range partials; gathered dot: per-block sums */
@@ -626,6 +631,39 @@ int zshmc_linear_bernoulli_log_lik(const float* W, const float* X,
                                    int64_t n_rows, int64_t n_features,
                                    float* log_lik, float* grad_w, int n_splits,
                                    float* workspace, void* stream);
+
+/* ------------------------------------------------------------------------
+ * ABI 0.5.0 -- the same Bernoulli / mixture-multinomial likelihoods on the
+ * BF16 matrix cores with float32-level results (csrc/linear_bf16x3.hip):
+ * every float32 operand is split into three bfloat16 planes (hi + mid + lo =
+ * the value exactly) and a product is the six terms hi*hi, hi*mid, mid*hi,
+ * hi*lo, lo*hi, mid*mid on v_mfma_f32_32x32x16_bf16 with float32
+ * accumulation; what is dropped is <= 2^-24 relative.  Same formulas, same
+ * reference lines (univariate.py:398-403, multivariate.py:435-443,
+ * hmc.py:430-432) and same argument meaning as the fp32 entry points, except:
+ *   X_image / phi_image  the constant operand as a tile image, made once per
+ *          tensor version by zshmc_bf16x3_split from X [n_rows, ldx] (the
+ *          first `width` columns; width 64 / 128 / 192 / 256 = the fp32
+ *          kernels' width for <= 256 columns); zshmc_bf16x3_image_bytes names
+ *          its size (6 bytes per element, rows padded to 32);
+ *   grad_w / grad_theta  required (the log-likelihood alone stays with the
+ *          fp32 entry point); log_lik may be NULL;
+ *   a workgroup takes 128 chains (of ONE document when count_rows > 1: the
+ *          rows are chain * count_rows + doc).
+ * Not bit-identical to the fp32 kernels (other summation order), and held to
+ * the same parity tests at the same tolerances. */
+int zshmc_bf16x3_image_bytes(int64_t n_rows, int64_t width, int64_t* bytes);
+int zshmc_bf16x3_split(const float* X, int64_t n_rows, int64_t width,
+                       int64_t ldx, void* image, void* stream);
+int zshmc_linear_bernoulli_log_lik_bf16x3(
+    const float* W, const void* X_image, const float* y, int64_t n_chains,
+    int64_t n_rows, int64_t n_features, float* log_lik, float* grad_w,
+    int n_splits, float* workspace, void* stream);
+int zshmc_linear_multinomial_log_lik_bf16x3(
+    const float* theta, const void* phi_image, const float* counts,
+    int64_t count_rows, int64_t count_stride, int64_t n_rows, int64_t n_vocab,
+    int64_t n_topics, float* log_lik, float* grad_theta, int n_splits,
+    float* workspace, void* stream);
 
 /* ------------------------------------------------------------------------
  * Fused dense-logit Categorical likelihood on the fp32 matrix cores (softmax

@@ -77,16 +77,32 @@ def test_gloo_fallback_has_to_be_asked_for_and_says_so(tmp_path):
         assert 'SUM [2.0, 2.0]' in out
 
 
-def test_gpus_without_a_launcher_is_refused():
-    """`bench.py --gpus 2` started as ONE process names the launch line
-    instead of measuring one GPU under a two-GPU label."""
+def test_gpus_without_a_launcher_launches_itself():
+    """`python bench.py --gpus 2 ...` started as ONE process (the driver's
+    N = 1 command with another --gpus) becomes the launcher: two ranks under
+    torch.distributed.run on loopback, its exit status the job's.  There is
+    no GPU here, so each RANK stops at `bench.py needs an MI355X` -- which
+    shows the ranks were started, with the launcher's environment."""
     env = {k: v for k, v in os.environ.items()
            if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'),
                         '--gpus', '2', '--steps', '1', '--warmup', '0'],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       universal_newlines=True, timeout=600)
+    assert 'no launcher environment, starting 2 ranks' in p.stderr
+    assert '--nproc-per-node 2' in p.stderr and '127.0.0.1' in p.stderr
+    import torch
+    if not torch.cuda.is_available():
+        assert p.returncode != 0
+        assert p.stderr.count('bench.py needs an MI355X') >= 2, p.stderr[-800:]
+        assert p.stdout.strip() == ''
+
+
+def test_gpus_inside_a_mismatched_launcher_is_refused():
+    env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'),
+                        '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                        universal_newlines=True, timeout=240)
     assert p.returncode != 0
-    assert 'torch.distributed.run' in p.stderr and '--nproc-per-node 2' \
-        in p.stderr, p.stderr[-400:]
-    assert p.stdout.strip() == ''
+    assert 'inside a launcher environment of WORLD_SIZE=1' in p.stderr

@@ -1,0 +1,242 @@
+"""GPU parity of the bf16x3 likelihood kernels (csrc/linear_bf16x3.hip: three
+bfloat16 planes per float32 operand, six bf16 MFMAs per product, float32
+accumulation) against a float64 restatement of Bernoulli._log_prob
+(reference zhusuan/distributions/univariate.py:398-403) /
+UnnormalizedMultinomial._log_prob (multivariate.py:435-443) on materialised
+logits and of the gradient tf.gradients (hmc.py:430-432) gives through them
+-- at the tolerances the exact-fp32 kernels are held to
+(tests/test_gpu_linear_bernoulli.py, test_gpu_mixture_multinomial.py) -- and
+against the fp32 kernels themselves."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def env():
+    import torch
+    from zhusuan_amd import _capi
+    assert torch.cuda.is_available()
+    return torch, _capi, torch.device('cuda', 0)
+
+
+def _image(torch, _capi, X, width):
+    """X [N, width] float32 on the device -> the kernel's tile image."""
+    import ctypes
+    nb = ctypes.c_int64()
+    _capi.call('zshmc_bf16x3_image_bytes', X.shape[0], width,
+               ctypes.addressof(nb))
+    img = torch.empty(nb.value, dtype=torch.uint8, device=X.device)
+    _capi.call('zshmc_bf16x3_split', X.data_ptr(), X.shape[0], width,
+               X.stride(0), img.data_ptr(), _capi.current_stream())
+    return img
+
+
+def _bf16_planes(x):
+    """float64 emulation of the kernel's split: (hi, mid, lo) as float32."""
+    def rne(v):
+        u = np.asarray(v, np.float32).view(np.uint32).astype(np.uint64)
+        r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+        return r.astype(np.uint32).view(np.float32)
+    hi = rne(x)
+    mid = rne(x - hi)
+    lo = rne(x - hi - mid)
+    return hi, mid, lo
+
+
+def test_split_image_matches_the_layout_in_the_header(env):
+    """zshmc_bf16x3_split against a NumPy restatement of the image layout
+    (include/zshmc.h, csrc/linear_bf16x3.hip: b3_chunk): bit for bit."""
+    torch, _capi, dev = env
+    rng = np.random.RandomState(0)
+    N, D = 77, 128
+    X = rng.normal(size=(N, D)).astype(np.float32)
+    X[5, 3] = 0.0
+    X[6, :] *= 1e-20
+    img = _image(torch, _capi, torch.tensor(X, device=dev), D).cpu().numpy()
+    planes = _bf16_planes(X)
+    nt, np_ = (N + 31) // 32, D // 32
+    want = np.zeros((nt, 3, np_, 128, 8), np.uint16)
+    for p in range(3):
+        b = (planes[p].view(np.uint32) >> 16).astype(np.uint16)
+        for n in range(N):
+            t, m = divmod(n, 32)
+            for c8 in range(D // 8):
+                P, par, h = c8 >> 2, (c8 >> 1) & 1, c8 & 1
+                chunk = (m >> 2) * 16 + 4 * ((2 * h + par + (m >> 3)) & 3) + (m & 3)
+                want[t, p, P, chunk] = b[n, c8 * 8:c8 * 8 + 8]
+    got = img.view(np.uint16).reshape(nt, 3, np_, 128, 8)
+    np.testing.assert_array_equal(got, want)
+    # and the three planes add up to the value exactly
+    np.testing.assert_array_equal(
+        (planes[0].astype(np.float64) + planes[1] + planes[2]
+         ).astype(np.float32), X)
+
+
+def _bern_data(C, N, D, seed):
+    rng = np.random.RandomState(seed)
+    X = rng.normal(size=(N, D)).astype(np.float32)
+    w_true = rng.normal(size=D).astype(np.float32)
+    y = (rng.uniform(size=N) < 1 / (1 + np.exp(-X @ w_true / np.sqrt(D)))
+         ).astype(np.float32)
+    W = (rng.normal(size=(C, D)) * 0.3).astype(np.float32)
+    return X, y, W
+
+
+def _bern_ref(W, X, y):
+    l = W.astype(np.float64) @ X.astype(np.float64).T
+    ll = (y * l - np.maximum(l, 0) - np.log1p(np.exp(-np.abs(l)))).sum(1)
+    g = (y - 1 / (1 + np.exp(-l))) @ X.astype(np.float64)
+    return ll, g
+
+
+def _call_bern(torch, _capi, dev, W, X, y, D, want_ll, n_splits=1, fp32=False):
+    C, N = W.shape[0], X.shape[0]
+    Wt, Xt, yt = (torch.tensor(a, device=dev) for a in (W, X, y))
+    ll = torch.full((C,), float('nan'), device=dev) if want_ll else None
+    g = torch.full((C, D), float('nan'), device=dev)
+    ws = torch.empty(n_splits * C * (D + 1), device=dev) if n_splits > 1 else None
+    s = _capi.current_stream()
+    if fp32:
+        _capi.call('zshmc_linear_bernoulli_log_lik', Wt.data_ptr(),
+                   Xt.data_ptr(), yt.data_ptr(), C, N, D, _capi.ptr(ll),
+                   g.data_ptr(), n_splits, _capi.ptr(ws), s)
+    else:
+        img = _image(torch, _capi, Xt, D)
+        _capi.call('zshmc_linear_bernoulli_log_lik_bf16x3', Wt.data_ptr(),
+                   img.data_ptr(), yt.data_ptr(), C, N, D, _capi.ptr(ll),
+                   g.data_ptr(), n_splits, _capi.ptr(ws), s)
+    torch.cuda.synchronize()
+    return (ll.cpu().numpy() if want_ll else None), g.cpu().numpy()
+
+
+# every width; ragged chain blocks (128), ragged 32-row tiles, one tile, one
+# row, several tiles; chains past a multiple of 128
+@pytest.mark.parametrize('C,N,D', [
+    (128, 32, 64), (128, 64, 128), (100, 1000, 256), (7, 45, 128),
+    (130, 333, 64), (64, 4096, 192), (1, 1, 64), (256, 10000, 256),
+    (300, 777, 128), (3, 130, 192), (129, 31, 256), (128, 33, 256)])
+@pytest.mark.parametrize('want_ll', [True, False])
+def test_bernoulli_matches_float64_reference(env, C, N, D, want_ll):
+    torch, _capi, dev = env
+    X, y, W = _bern_data(C, N, D, seed=C + N + D)
+    ll, g = _call_bern(torch, _capi, dev, W, X, y, D, want_ll)
+    ll_ref, g_ref = _bern_ref(W, X, y)
+    if want_ll:
+        np.testing.assert_allclose(ll, ll_ref, rtol=2e-5, atol=2e-5 * N)
+    scale = np.abs(g_ref).max() + 1.0
+    np.testing.assert_allclose(g, g_ref, rtol=1e-4, atol=2e-5 * scale)
+
+
+@pytest.mark.parametrize('D', [64, 128, 192, 256])
+def test_bernoulli_is_as_close_to_float64_as_the_fp32_kernel(env, D):
+    """The claim of the design (tools/bf16x3_accuracy.py on the device): the
+    six-term split leaves the error of float32 accumulation itself -- within
+    2x of what the exact-fp32 MFMA kernel leaves on the same inputs."""
+    torch, _capi, dev = env
+    C, N = 256, 20000
+    X, y, W = _bern_data(C, N, D, seed=D)
+    ll_ref, g_ref = _bern_ref(W, X, y)
+    ll3, g3 = _call_bern(torch, _capi, dev, W, X, y, D, True)
+    ll1, g1 = _call_bern(torch, _capi, dev, W, X, y, D, True, fp32=True)
+    e3 = np.abs(g3 - g_ref).max() / np.abs(g_ref).max()
+    e1 = np.abs(g1 - g_ref).max() / np.abs(g_ref).max()
+    l3 = np.abs(ll3 - ll_ref).max()
+    l1 = np.abs(ll1 - ll_ref).max()
+    print('D=%d gradient max rel err: bf16x3 %.2e fp32 %.2e; log-lik max abs '
+          'err: bf16x3 %.2e fp32 %.2e (of %.0f)' % (
+              D, e3, e1, l3, l1, np.abs(ll_ref).max()))
+    assert e3 < 2 * e1 + 1e-7
+    assert l3 < 2 * l1 + 1e-3
+
+
+def test_bernoulli_row_splits_and_bit_stability(env):
+    torch, _capi, dev = env
+    C, N, D = 100, 5000, 128
+    X, y, W = _bern_data(C, N, D, seed=3)
+    ll_ref, g_ref = _bern_ref(W, X, y)
+    ll_a, g_a = _call_bern(torch, _capi, dev, W, X, y, D, True, n_splits=5)
+    ll_b, g_b = _call_bern(torch, _capi, dev, W, X, y, D, True, n_splits=5)
+    np.testing.assert_array_equal(ll_a, ll_b)
+    np.testing.assert_array_equal(g_a, g_b)
+    np.testing.assert_allclose(ll_a, ll_ref, rtol=2e-5, atol=2e-5 * N)
+    np.testing.assert_allclose(g_a, g_ref, rtol=1e-4,
+                               atol=2e-5 * (np.abs(g_ref).max() + 1))
+    # more slices than tiles
+    ll_c, g_c = _call_bern(torch, _capi, dev, W[:, :64].copy(), X[:40, :64].copy(),
+                           y[:40], 64, True, n_splits=4)
+    ll_r, g_r = _bern_ref(W[:, :64], X[:40, :64], y[:40])
+    np.testing.assert_allclose(ll_c, ll_r, rtol=2e-5, atol=1e-3)
+    np.testing.assert_allclose(g_c, g_r, rtol=1e-4, atol=1e-3)
+
+
+def test_bernoulli_nonfinite_chain_stays_in_its_rows(env):
+    """A diverged chain (inf / nan weights) poisons its own results only."""
+    torch, _capi, dev = env
+    C, N, D = 128, 200, 64
+    X, y, W = _bern_data(C, N, D, seed=9)
+    W[5, 3] = np.inf
+    W[70, 0] = np.nan
+    ll, g = _call_bern(torch, _capi, dev, W, X, y, D, True)
+    ok = np.ones(C, bool)
+    ok[[5, 70]] = False
+    Wc = W.copy()
+    Wc[~ok] = 0
+    ll_ref, g_ref = _bern_ref(Wc, X, y)
+    assert np.isfinite(ll[ok]).all() and np.isfinite(g[ok]).all()
+    assert not np.isfinite(ll[~ok]).any()
+    np.testing.assert_allclose(ll[ok], ll_ref[ok], rtol=2e-5, atol=2e-5 * N)
+    np.testing.assert_allclose(g[ok], g_ref[ok], rtol=1e-4, atol=1e-3)
+
+
+def _mult_data(n_chains, n_docs, V, K, seed):
+    rng = np.random.RandomState(seed)
+    eta = rng.normal(size=(n_chains * n_docs, K))
+    theta = np.exp(eta - eta.max(1, keepdims=True))
+    theta = (theta / theta.sum(1, keepdims=True)).astype(np.float32)
+    beta = rng.normal(size=(K, V))
+    phi = np.exp(beta - beta.max(1, keepdims=True))
+    phi = (phi / phi.sum(1, keepdims=True)).astype(np.float32)
+    x = rng.poisson(0.3, size=(n_docs, V)).astype(np.float32)
+    return theta, phi, x
+
+
+def _mult_ref(theta, phi, x, n_docs):
+    S = theta.astype(np.float64) @ phi.astype(np.float64)       # [R, V]
+    R = theta.shape[0]
+    xr = x[np.arange(R) % n_docs].astype(np.float64)            # row r: doc r % n_docs
+    with np.errstate(divide='ignore', invalid='ignore'):
+        ll = np.where(xr != 0, xr * np.log(S), 0.0).sum(1)
+        g = np.where(xr != 0, xr / S, 0.0) @ phi.astype(np.float64).T
+    return ll, g
+
+
+@pytest.mark.parametrize('n_chains,n_docs,V,K', [
+    (128, 3, 500, 64), (130, 2, 333, 128), (64, 1, 1000, 128),
+    (5, 7, 77, 256), (256, 2, 1241, 128), (40, 3, 100, 192)])
+@pytest.mark.parametrize('want_ll', [True, False])
+def test_multinomial_matches_float64_reference(env, n_chains, n_docs, V, K,
+                                               want_ll):
+    torch, _capi, dev = env
+    theta, phi, x = _mult_data(n_chains, n_docs, V, K, seed=V + K)
+    R = n_chains * n_docs
+    stride = (V + 3) // 4 * 4
+    xp = np.zeros((n_docs, stride), np.float32)
+    xp[:, :V] = x
+    th = torch.tensor(theta, device=dev)
+    pt = torch.tensor(np.ascontiguousarray(phi.T), device=dev)   # [V, K]
+    xt = torch.tensor(xp, device=dev)
+    img = _image(torch, _capi, pt, K)
+    ll = torch.full((R,), float('nan'), device=dev) if want_ll else None
+    g = torch.full((R, K), float('nan'), device=dev)
+    _capi.call('zshmc_linear_multinomial_log_lik_bf16x3', th.data_ptr(),
+               img.data_ptr(), xt.data_ptr(), n_docs, stride, R, V, K,
+               _capi.ptr(ll), g.data_ptr(), 1, None, _capi.current_stream())
+    torch.cuda.synchronize()
+    ll_ref, g_ref = _mult_ref(theta, phi, x, n_docs)
+    if want_ll:
+        np.testing.assert_allclose(ll.cpu().numpy(), ll_ref, rtol=2e-5,
+                                   atol=2e-5 * V)
+    np.testing.assert_allclose(g.cpu().numpy(), g_ref, rtol=1e-4,
+                               atol=2e-5 * (np.abs(g_ref).max() + 1))

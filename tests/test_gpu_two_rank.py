@@ -127,11 +127,19 @@ def test_two_rank_sharded_gpu_run_matches_single_process(tmp_path):
 
 
 def test_bench_two_ranks_prints_contract_json():
-    r = _launch(['bench.py', '--gpus', '2', '--steps', '10', '--warmup', '2',
-                 '--chains-per-gpu', '4096', '--no-ess',
-                 '--lntm-chains-per-gpu', '8', '--lntm-docs', '48',
-                 '--lntm-vocab', '700'], 2,
-                {'ZSHMC_DIST_BACKEND': 'gloo'})
+    """`python bench.py --gpus 2 ...` WITHOUT a launcher (the driver's N = 1
+    command line with another --gpus): bench.py starts its own ranks."""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR',
+                        'MASTER_PORT')}
+    env['ZSHMC_DIST_BACKEND'] = 'gloo'
+    r = subprocess.run(
+        [sys.executable, 'bench.py', '--gpus', '2', '--steps', '10',
+         '--warmup', '2', '--chains-per-gpu', '4096', '--no-ess',
+         '--lntm-chains-per-gpu', '8', '--lntm-docs', '48',
+         '--lntm-vocab', '700'], cwd=ROOT, env=env, capture_output=True,
+        text=True, timeout=600)
+    assert 'no launcher environment, starting 2 ranks' in r.stderr
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
     out = json.loads(line)

@@ -69,7 +69,7 @@ class ModelPlan(Structure):
         ('lik_rows', c_int64), ('width', c_int64),
         ('grad_start', c_void_p), ('ll_start', c_void_p),
         ('start_valid', c_int32), ('start_pad', c_int32),
-        ('inner', c_void_p), ('n_inner', c_int64),
+        ('inner', c_void_p), ('n_inner', c_int64), ('inner_image', c_void_p),
         ('obs', c_void_p), ('obs_rows', c_int64), ('obs_stride', c_int64),
         ('split_ws', c_void_p),
         ('seg_len', c_int64), ('groups', c_int64), ('seg_ws', c_void_p),
@@ -213,6 +213,13 @@ PROTOTYPES = {
     'zshmc_likelihood_plan': (c_int, [c_int64, c_int, _p, _p]),
     'zshmc_linear_bernoulli_log_lik': (c_int, [
         _p, _p, _p, c_int64, c_int64, c_int64, _p, _p, c_int, _p, _p]),
+    'zshmc_bf16x3_image_bytes': (c_int, [c_int64, c_int64, _p]),
+    'zshmc_bf16x3_split': (c_int, [_p, c_int64, c_int64, c_int64, _p, _p]),
+    'zshmc_linear_bernoulli_log_lik_bf16x3': (c_int, [
+        _p, _p, _p, c_int64, c_int64, c_int64, _p, _p, c_int, _p, _p]),
+    'zshmc_linear_multinomial_log_lik_bf16x3': (c_int, [
+        _p, _p, _p, c_int64, c_int64, c_int64, c_int64, c_int64, _p, _p,
+        c_int, _p, _p]),
     'zshmc_linear_categorical_log_lik': (c_int, [
         _p, _p, _p, c_int64, c_int64, c_int64, c_int, c_int, _p, _p, c_int, _p,
         _p]),

@@ -53,6 +53,18 @@ int likelihood(const zshmc_model_plan& m, const float* q, bool want_ll,
   const float* w = m.operand ? m.operand : q;
   float* ws = m.n_splits > 1 ? m.split_ws : nullptr;
   float* ll = want_ll ? ll_out : nullptr;
+  // the bf16x3 kernels (float32-level results on the bf16 matrix cores) where
+  // the plan carries the operand's tile image and a gradient is wanted
+  if (m.inner_image && grad_out) {
+    if (m.kind == ZSHMC_PLAN_LINEAR_BERNOULLI)
+      return zshmc_linear_bernoulli_log_lik_bf16x3(
+          w, m.inner_image, m.obs, m.n_chains, m.n_inner, m.width, ll, grad_out,
+          m.n_splits, ws, s);
+    if (m.kind == ZSHMC_PLAN_MIXTURE_MULTINOMIAL)
+      return zshmc_linear_multinomial_log_lik_bf16x3(
+          w, m.inner_image, m.obs, m.obs_rows, m.obs_stride, m.n_chains,
+          m.n_inner, m.width, ll, grad_out, m.n_splits, ws, s);
+  }
   switch (m.kind) {
     case ZSHMC_PLAN_LINEAR_BERNOULLI:
       return zshmc_linear_bernoulli_log_lik(w, m.inner, m.obs, m.n_chains,

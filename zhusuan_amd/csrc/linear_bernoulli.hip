@@ -664,6 +664,18 @@ __global__ __launch_bounds__(256) void lb_reduce_splits_kernel(
   }
 }
 
+// (for csrc/linear_bf16x3.hip: the same fixed-order reduction of its partials)
+int lb_reduce_splits(const float* ws, int64_t C, int64_t ldw, int S, float* ll,
+                     float* gW, hipStream_t s) {
+  const int64_t n = C + (gW ? C * ldw : 0);
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(lb_reduce_splits_kernel, dim3((int)blocks), dim3(256), 0, s,
+                     ws, C, ldw, S, ll, gW);
+  ZS_LAUNCH_CHECK("lb_reduce_splits_kernel launch");
+  return ZSHMC_OK;
+}
+
 template <int D, int OP>
 static int launch_lb(const float* W, const float* X, const float* y,
                      const float* yc, int64_t yc_rows, int64_t ldy, int64_t C,
