@@ -322,6 +322,47 @@ def _mfma_roofline(kernel, kern_ms, flop_eval, n_evals, ms_transition):
     return out
 
 
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def _b3_roofline(width, kern_ms, flop_eval, n_evals, ms_transition):
+    """The same launches on the bf16x3 kernels (csrc/linear_bf16x3.hip): every
+    float32 operand as three bfloat16 planes, a product = six bf16 MFMAs with
+    float32 accumulation.  `achieved` counts the ALGORITHMIC (float32-
+    equivalent) flops 4 N D C; the matrix cores issue six times that.  Two
+    fractions: against the fp32-MFMA peak the exact-fp32 kernels are priced
+    against (> 1: that is the point), and against the ceiling of this
+    arithmetic, the dense bf16 peak / 6."""
+    ceiling = MFMA_BF16_PEAK_TFLOPS / 6.0
+    ms = kern_ms['grad']
+    ach = flop_eval / (ms * 1e-3) / 1e12
+    ach2 = flop_eval / (kern_ms['ll_grad'] * 1e-3) / 1e12
+    sus = n_evals * flop_eval / (ms_transition * 1e-3) / 1e12
+    return {
+        'bound': 'mfma',
+        'dtype': 'bf16x3 (3 bf16 planes per f32 operand, 6-term products, '
+                 'fp32 accumulate)',
+        'kernel': 'linear_b3_kernel<%d> gradient only (log_lik = NULL)' % width,
+        'kernel_ms': ms, 'achieved': ach, 'unit': 'TFLOP/s',
+        'achieved_counts': 'algorithmic fp32-equivalent flops (4 N D C per '
+                           'launch); bf16 flops issued = 6x',
+        'peak': ceiling, 'frac': ach / ceiling,
+        'peak_is': 'dense bf16 MFMA peak %.0f / 6 terms' % MFMA_BF16_PEAK_TFLOPS,
+        'frac_of_fp32_mfma_peak': ach / MFMA_F32_PEAK_TFLOPS,
+        'traffic': None,
+        'algorithmic_flop_per_launch': flop_eval,
+        'launches_per_transition': {'gradient_only': n_evals - 1,
+                                    'likelihood_and_gradient': 1},
+        'likelihood_and_gradient': {
+            'kernel_ms': kern_ms['ll_grad'], 'achieved': ach2,
+            'frac': ach2 / ceiling,
+            'frac_of_fp32_mfma_peak': ach2 / MFMA_F32_PEAK_TFLOPS},
+        'sustained_over_transition': sus,
+        'sustained_frac': sus / ceiling,
+        'sustained_frac_of_fp32_mfma_peak': sus / MFMA_F32_PEAK_TFLOPS,
+    }
+
+
 def extra_config1(torch, zs, dev, n_chains=1000, n_x=10, n_leapfrogs=5):
     """BASELINE configs[0]: examples/toy_examples/gaussian.py (:29, :36-58):
     1 000 chains, 10-D, stdev_j = 1/(j+1), L = 5, target acceptance 0.9, step
@@ -411,7 +452,7 @@ def extra_config3(torch, zs, dev, n_rows=1000000, n_chains=32768, n_feat=256,
     del X_h, y_h
     zero, one = torch.zeros(n_feat, device=dev), torch.ones(n_feat, device=dev)
 
-    def build(n, sharding):
+    def build(n, sharding, arithmetic='fp32'):
         @zs.meta_bayesian_net()
         def blr():
             bn = zs.BayesianNet()
@@ -426,7 +467,7 @@ def extra_config3(torch, zs, dev, n_rows=1000000, n_chains=32768, n_feat=256,
         flag = zs.placeholder(bool)
         hmc = zs.HMC(step_size=1e-3, n_leapfrogs=n_leapfrogs,
                      adapt_step_size=flag, target_acceptance_rate=0.8, seed=2,
-                     sharding=sharding)
+                     sharding=sharding, likelihood_arithmetic=arithmetic)
         op, info = hmc.sample(blr(), {'y': y}, {'w': w})
         return hmc, op, info, w, (flag,)
 
@@ -443,6 +484,33 @@ def extra_config3(torch, zs, dev, n_rows=1000000, n_chains=32768, n_feat=256,
         torch, hmc, op, info, {flags[0]: False}, 1, n_timed, barrier)
     ms = elapsed / n_timed * 1e3
     flop_eval = 4.0 * n_rows * n_feat * n_chains
+    plan_kind, step_size = hmc.plan_kind, float(info.updated_step_size.item())
+    roof32 = _mfma_roofline(
+        _lik_kernel_name(hmc._plan.width, hmc._plan.block), kern_ms, flop_eval,
+        n_leapfrogs, ms)
+    # the same chains, state and step size with the likelihood on the bf16
+    # matrix cores (HMC(likelihood_arithmetic='bf16x3'))
+    del hmc, op, info
+    gc.collect()
+    hmc3, op3, info3, w3, flags3 = build(n_chains, None, 'bf16x3')
+    w3.copy_(w_sub.repeat(n_chains // n_sub, 1))
+    hmc3.set_state(state)
+    elapsed3, kern3, acc3 = _time_transitions(
+        torch, hmc3, op3, info3, {flags3[0]: False}, 1, n_timed, barrier)
+    ms3 = elapsed3 / n_timed * 1e3
+    b3 = {
+        'likelihood_arithmetic': hmc3.likelihood_arithmetic_used,
+        'ms_per_step': ms3, 'steps': n_timed,
+        'value': n_chains * n_leapfrogs / (ms3 * 1e-3),
+        'unit': 'chain-leapfrog-steps/s',
+        'speedup_over_fp32_transition': ms / ms3,
+        'mean_acceptance': acc3,
+        'image_bytes': int(hmc3._plan.inner_image.numel()),
+        'roofline': _b3_roofline(hmc3._plan.width, kern3, flop_eval,
+                                 n_leapfrogs, ms3),
+    }
+    del hmc3, op3, info3, w3
+    gc.collect()
     return {
         'workload': 'configs[2]: Bayesian logistic regression, synthetic '
                     '%d x %d, %d chains, L=%d, step size adapted on a subset '
@@ -450,7 +518,7 @@ def extra_config3(torch, zs, dev, n_rows=1000000, n_chains=32768, n_feat=256,
                     'model written with the reference\'s literal '
                     '`w @ X.T` logits' % (
                         n_rows, n_feat, n_chains, n_leapfrogs),
-        'plan': hmc.plan_kind,
+        'plan': plan_kind,
         'ms_per_step': ms,
         'steps': n_timed,
         'value': n_chains * n_leapfrogs / (ms * 1e-3),
@@ -458,7 +526,8 @@ def extra_config3(torch, zs, dev, n_rows=1000000, n_chains=32768, n_feat=256,
         'mean_acceptance': acc,
         'mean_acceptance_subset_held_phase': acc_sub,
         'target_acceptance': 0.8,
-        'step_size': float(info.updated_step_size.item()),
+        'step_size': step_size,
+        'bf16x3': b3,
         'start': TUNED_START_NOTE.replace(
             'run with adaptation ON', 'run with adaptation HELD (config 3)') +
                  ' Subset: %d chains, 60 adaptive + 240 recorded transitions '
@@ -471,9 +540,7 @@ def extra_config3(torch, zs, dev, n_rows=1000000, n_chains=32768, n_feat=256,
                       'with the same step size, scaled to %d chains at the '
                       'timed rate' % (n_sub, n_chains),
         },
-        'roofline': _mfma_roofline(
-            _lik_kernel_name(hmc._plan.width, hmc._plan.block), kern_ms, flop_eval,
-            n_leapfrogs, ms),
+        'roofline': roof32,
     }
 
 
@@ -676,7 +743,7 @@ def lntm_problem(torch, dev, n_docs, n_topics, n_vocab):
 
 def lntm_workload(torch, zs, dev, n_chains, sharding=None, dist=None,
                   n_docs=5000, n_topics=128, n_vocab=12419, n_leapfrogs=20,
-                  n_sub=4, n_timed=1, n_warm=1):
+                  n_sub=4, n_timed=1, n_warm=1, bf16x3=True):
     """BASELINE configs[4]: the E-step of the logistic-normal topic model at
     the lntm_mcem.py shape (chain axes [n_chains, n_docs = 5 000], K = 128,
     V = 12 419 -- the UCI "nips" vocabulary the example loads), step-size and
@@ -690,7 +757,7 @@ def lntm_workload(torch, zs, dev, n_chains, sharding=None, dist=None,
     eta_mean = torch.zeros(n_docs, n_topics, device=dev)
     eta_logstd = torch.zeros(n_topics, device=dev)
 
-    def build(n, sh):
+    def build(n, sh, arithmetic='fp32'):
         @zs.meta_bayesian_net()
         def lntm():
             bn = zs.BayesianNet()
@@ -707,7 +774,8 @@ def lntm_workload(torch, zs, dev, n_chains, sharding=None, dist=None,
         f_ss, f_m = zs.placeholder(bool), zs.placeholder(bool)
         hmc = zs.HMC(step_size=1e-3, n_leapfrogs=n_leapfrogs,
                      adapt_step_size=f_ss, adapt_mass=f_m,
-                     target_acceptance_rate=0.6, seed=3, sharding=sh)
+                     target_acceptance_rate=0.6, seed=3, sharding=sh,
+                     likelihood_arithmetic=arithmetic)
         op, info = hmc.sample(lntm(), {'x': x}, {'eta': eta})
         return hmc, op, info, eta, (f_ss, f_m)
 
@@ -748,6 +816,37 @@ def lntm_workload(torch, zs, dev, n_chains, sharding=None, dist=None,
         _lik_kernel_name(hmc._plan.width, hmc._plan.block) + ' (multinomial mode)',
         kern_ms, flop_eval, n_leapfrogs, ms)
     roof['note'] = 'per GPU (rank 0): one launch covers this rank\'s rows'
+    plan_kind, step_size = hmc.plan_kind, float(info.updated_step_size.item())
+    rccl_ranks = 0 if sharding is None else sharding.rccl_ranks
+    b3 = None
+    if world == 1 and bf16x3:
+        # the same rows, state, step size and mass with the likelihood on the
+        # bf16 matrix cores (the first plan's buffers are freed first: seven
+        # [rows, K] matrices each)
+        del hmc, op, info, eta
+        gc.collect()          # (sampler <-> plan <-> sample_op are a cycle)
+        torch.cuda.empty_cache()
+        hmc3, op3, info3, eta3, flags3 = build(n_chains, None, 'bf16x3')
+        eta3.copy_(eta_sub.repeat(n_chains // n_sub, 1, 1))
+        hmc3.set_state(state)
+        elapsed3, kern3, acc3 = _time_transitions(
+            torch, hmc3, op3, info3, {flags3[0]: True, flags3[1]: True},
+            n_warm, n_timed, barrier)
+        ms3 = elapsed3 / n_timed * 1e3
+        b3 = {
+            'likelihood_arithmetic': hmc3.likelihood_arithmetic_used,
+            'ms_per_step': ms3, 'steps': n_timed,
+            'value': rows * n_leapfrogs / (ms3 * 1e-3),
+            'unit': '(chain, document)-leapfrog-steps/s',
+            'speedup_over_fp32_transition': ms / ms3,
+            'mean_acceptance': acc3,
+            'roofline': _b3_roofline(hmc3._plan.width, kern3, flop_eval,
+                                     n_leapfrogs, ms3)
+            if hmc3.likelihood_arithmetic_used == 'bf16x3' else None,
+        }
+        del hmc3, op3, info3, eta3
+        gc.collect()
+        torch.cuda.empty_cache()
     return {
         'workload': 'configs[4]: logistic-normal topic model E-step, chain '
                     'axes [n_chains=%d, n_docs=%d] (= %d rows; "8 192 chains" '
@@ -756,7 +855,7 @@ def lntm_workload(torch, zs, dev, n_chains, sharding=None, dist=None,
                     'region, literal log(softmax(eta) @ phi) spelling' % (
                         n_chains * world, n_docs, rows, n_chains, n_topics,
                         n_vocab, n_leapfrogs),
-        'plan': hmc.plan_kind,
+        'plan': plan_kind,
         'n_gpus': world,
         'ms_per_step': ms,
         'steps': n_timed,
@@ -765,12 +864,13 @@ def lntm_workload(torch, zs, dev, n_chains, sharding=None, dist=None,
         'mean_acceptance': acc,
         'mean_acceptance_subset_held_phase': acc_sub,
         'target_acceptance': 0.6,
-        'step_size': float(info.updated_step_size.item()),
+        'step_size': step_size,
+        'bf16x3': b3,
         'collective': 'none' if world == 1 else
                       'ONE all-reduce of %d doubles per transition '
                       '[sum acc, flag, colsum[2 x %d]]' % (
                           2 + 2 * n_topics, n_topics),
-        'rccl_ranks': 0 if sharding is None else sharding.rccl_ranks,
+        'rccl_ranks': rccl_ranks,
         'start': TUNED_START_NOTE + ' Subset: %d chains x %d docs, 40 '
                  'adaptive + 150 recorded transitions (mean acceptance '
                  '%.3f).' % (n_sub, n_docs, acc_sub),

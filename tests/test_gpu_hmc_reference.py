@@ -33,12 +33,15 @@ def env():
 # symbolically, zhusuan_amd/_symbolic.py: native plan too), and a near miss
 # of it (`latent * 1.0` first) that must fall back to the generic plan and
 # still reproduce the traces
-VARIANTS = {'blr': ('native', 'generic', 'dense', 'nearmiss'),
-            'lntm': ('native', 'generic', 'dense', 'nearmiss'),
+# `bf16x3`: the literal spelling on the native plan with the likelihood on
+# the bf16 matrix cores (HMC(likelihood_arithmetic='bf16x3'),
+# csrc/linear_bf16x3.hip) -- the same traces at the same tolerances
+VARIANTS = {'blr': ('native', 'generic', 'dense', 'nearmiss', 'bf16x3'),
+            'lntm': ('native', 'generic', 'dense', 'nearmiss', 'bf16x3'),
             # the packed native plan: three latents in one row of 16 floats
             # (7 + 6 + 1, padded), topic rows of 6 padded to 8
-            'blr_bias': ('dense', 'generic', 'nearmiss'),
-            'lntm_k6': ('native', 'generic', 'dense', 'nearmiss'),
+            'blr_bias': ('dense', 'generic', 'nearmiss', 'bf16x3'),
+            'lntm_k6': ('native', 'generic', 'dense', 'nearmiss', 'bf16x3'),
             # north_star's third likelihood: X @ w^T under a Categorical --
             # the reference's literal spelling and zs.linear_class_logits on
             # the native plan (fp32-MFMA, csrc/lb_ops.h), the generic plan,
@@ -238,7 +241,8 @@ def _case_variants():
 
 
 @pytest.mark.parametrize('case,variant', list(_case_variants()))
-def test_device_reproduces_reference_hmc_traces(env, case, variant):
+def test_device_reproduces_reference_hmc_traces(env, case, variant,
+                                                monkeypatch):
     zs, torch, dev, traces = env
     name = case['name']
     qs = {k: torch.tensor(traces['%s/q0_%s' % (name, k)], device=dev)
@@ -252,10 +256,18 @@ def test_device_reproduces_reference_hmc_traces(env, case, variant):
         ph_m = kw['adapt_mass'] = zs.placeholder(bool)
     if variant == 'generic':
         kw['native_plans'] = False
+    if variant == 'bf16x3':
+        kw['likelihood_arithmetic'] = 'bf16x3'
+        variant = 'dense'
+        # (the traces' chain axes are a few chains per document: take the
+        # kernels whatever share of their 128-chain workgroups that fills)
+        monkeypatch.setattr(zs._ops, 'BF16X3_REQUIRE_FILL', False)
     hmc = zs.HMC(seed=case['seed'], **kw)
     model, plan, observed = _build(zs, torch, dev, case, qs, variant)
     op, info = hmc.sample(model, observed, qs)
     assert hmc.plan_kind == plan
+    if 'likelihood_arithmetic' in kw:
+        assert hmc.likelihood_arithmetic_used == 'bf16x3'
     n_flip = n_total = 0
     for i in range(case['n_iters']):
         f_ss, f_m = case['flags'](i)

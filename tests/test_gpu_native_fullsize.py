@@ -37,6 +37,16 @@ def env():
 
 
 # -- float64-likelihood oracle models on an explicit set of chain rows ---------
+# every test on the exact-fp32 MFMA kernels and on the bf16x3 ones
+# (csrc/linear_bf16x3.hip), at the SAME tolerances
+ARITH = pytest.mark.parametrize('arith', ['fp32', 'bf16x3'])
+
+
+def _used(hmc, arith):
+    assert hmc.likelihood_arithmetic_used == arith, (
+        hmc.likelihood_arithmetic_used, arith)
+
+
 def _normal_prior(q, mean, logstd):
     """(log N(q), d/dq) in float64, summed over the last axis
     (univariate.py:174-181, group_ndims = 1)."""
@@ -130,7 +140,8 @@ def _subset_info(info, ids_t):
                       'orig_log_prob', 'log_prob')}
 
 
-def test_config3_full_size_transition_matches_oracle_on_a_subset(env):
+@ARITH
+def test_config3_full_size_transition_matches_oracle_on_a_subset(env, arith):
     zs, torch, dev = env
     from oracle.hmc_ref import HMC as RefHMC
     C, N, D, L, eps, seed = 32768, 1000000, 256, 10, 2e-4, 31
@@ -167,9 +178,11 @@ def test_config3_full_size_transition_matches_oracle_on_a_subset(env):
         rng.randint(0, C, size=6)])).astype(np.int64)
     ids_t = torch.tensor(ids, device=dev)
     w_before = w[ids_t].cpu().numpy()
-    hmc = zs.HMC(step_size=eps, n_leapfrogs=L, seed=seed)
+    hmc = zs.HMC(step_size=eps, n_leapfrogs=L, seed=seed,
+                 likelihood_arithmetic=arith)
     op, info = hmc.sample(blr(), {'y': y}, {'w': w})
     assert hmc.plan_kind == 'linear_bernoulli'
+    _used(hmc, arith)
     op.run()
 
     model = blr_rows_model(X.cpu().numpy().astype(np.float64),
@@ -190,7 +203,8 @@ def test_config3_full_size_transition_matches_oracle_on_a_subset(env):
     assert abs(a_all - float(np.mean(rinfo.acceptance_rate))) < 0.25
 
 
-def test_config5_full_size_transition_matches_oracle_on_a_subset(env):
+@ARITH
+def test_config5_full_size_transition_matches_oracle_on_a_subset(env, arith):
     zs, torch, dev = env
     from oracle.hmc_ref import HMC as RefHMC
     n_docs, K, V, L, eps, seed = 5000, 128, 12419, 3, 0.04, 32
@@ -231,9 +245,12 @@ def test_config5_full_size_transition_matches_oracle_on_a_subset(env):
     ids_t = torch.tensor(ids, device=dev)
     flat = eta.view(rows, K)
     eta_before = flat[ids_t].cpu().numpy()
-    hmc = zs.HMC(step_size=eps, n_leapfrogs=L, seed=seed)
+    hmc = zs.HMC(step_size=eps, n_leapfrogs=L, seed=seed,
+                 likelihood_arithmetic=arith)
     op, info = hmc.sample(lntm(), {'x': x}, {'eta': eta})
     assert hmc.plan_kind == 'mixture_multinomial'
+    if n_chains >= 128:
+        _used(hmc, arith)
     op.run()
 
     docs = ids % n_docs
@@ -295,7 +312,8 @@ def _within_one_percent(got, want):
         assert abs(g - w) <= 0.01 * abs(w), (what, got, want)
 
 
-def test_free_running_logistic_regression_within_one_percent(env):
+@ARITH
+def test_free_running_logistic_regression_within_one_percent(env, arith):
     """The configs[2] family on the native plan, literal spelling, 1 536
     chains x 24 weights x 600 rows, step-size adaptation for the first 50 of
     350 transitions."""
@@ -324,17 +342,19 @@ def test_free_running_logistic_regression_within_one_percent(env):
         bn.bernoulli('y', w.tensor @ Xt.t(), group_ndims=1)
         return bn
     flag = zs.placeholder(bool)
-    hmc = zs.HMC(adapt_step_size=flag, **kw)
+    hmc = zs.HMC(adapt_step_size=flag, likelihood_arithmetic=arith, **kw)
     w = torch.tensor(w0, device=dev)
     op, info = hmc.sample(blr(), {'y': yt}, {'w': w})
     assert hmc.plan_kind == 'linear_bernoulli'
+    _used(hmc, arith)
     got, want = _free_run(zs, torch, hmc, op, info, w, (flag,), ref, xr, 50,
                           300)
     _within_one_percent(got, want)
     assert 0.6 < got[0] < 0.95
 
 
-def test_free_running_topic_model_within_one_percent(env):
+@ARITH
+def test_free_running_topic_model_within_one_percent(env, arith):
     """The configs[4] family on the native plan, literal spelling, E-step
     objective, chain axes [256, 16] (4 096 rows: the ESS estimator's mean over
     rows is then good to well under 1 % although free-running chains part
@@ -377,10 +397,12 @@ def test_free_running_topic_model_within_one_percent(env):
     model.log_joint = lambda bn: (bn.cond_log_prob('eta') +
                                   bn.cond_log_prob('x'))
     f_ss, f_m = zs.placeholder(bool), zs.placeholder(bool)
-    hmc = zs.HMC(adapt_step_size=f_ss, adapt_mass=f_m, **kw)
+    hmc = zs.HMC(adapt_step_size=f_ss, adapt_mass=f_m,
+                 likelihood_arithmetic=arith, **kw)
     eta = T(eta0)
     op, info = hmc.sample(model, {'x': x_t, 'beta': beta_t}, {'eta': eta})
     assert hmc.plan_kind == 'mixture_multinomial'
+    _used(hmc, arith)
     got, want = _free_run(zs, torch, hmc, op, info, eta, (f_ss, f_m), ref, xr,
                           50, 300)
     _within_one_percent(got, want)

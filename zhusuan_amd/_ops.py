@@ -566,6 +566,41 @@ def packed_design(blocks, n_rows, device, width=None):
     return out
 
 
+# ---- the bf16x3 likelihood kernels (csrc/linear_bf16x3.hip) ---------------
+BF16X3_WIDTHS = (64, 128, 192, 256)
+BF16X3_CHAIN_BLOCK = 128
+# A workgroup of the mixture-multinomial kernel takes 128 chains of ONE
+# document: by default the kernels are taken only where the chain axis fills
+# those workgroups (a multiple of 128, or >= 1024 chains: >= 89 % of the
+# slots) -- lntm_mcem.py's own E-step (n_chains = 1) stays on the fp32 kernel,
+# which packs consecutive (chain, document) rows.
+BF16X3_REQUIRE_FILL = True
+_image_cache = _Lru()
+
+
+def bf16x3_image(Xp):
+    """The tile image of a padded float32 operand [rows, width] (three
+    bfloat16 planes per element; zshmc_bf16x3_split), cached per tensor
+    version like the padded operand itself."""
+    import ctypes
+    rows, width = int(Xp.shape[0]), int(Xp.shape[1])
+    if width not in BF16X3_WIDTHS:
+        raise ValueError('bf16x3 kernels take widths %s, got %d'
+                         % (BF16X3_WIDTHS, width))
+    key = _tensor_key(Xp)
+    hit = _image_cache.get(key)
+    if hit is not None:
+        return hit
+    nbytes = ctypes.c_int64()
+    _capi.call('zshmc_bf16x3_image_bytes', rows, width,
+               ctypes.addressof(nbytes))
+    img = torch.empty(nbytes.value, dtype=torch.uint8, device=Xp.device)
+    _capi.call('zshmc_bf16x3_split', Xp.data_ptr(), rows, width,
+               Xp.stride(0), img.data_ptr(), _capi.current_stream())
+    _image_cache.put(key, img, Xp)
+    return img
+
+
 def _row_splits(n_blocks_rows, n_inner, device, block=64):
     """Fewer chain blocks (`block` rows: zshmc_likelihood_plan) than compute
     units: cut the inner (data row / vocabulary) range so that about two

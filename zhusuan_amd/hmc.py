@@ -231,14 +231,25 @@ class HMC(object):
     diagonal mass adaptation (hmc.py:204-281; same arguments and defaults).
 
     Extra keyword-only arguments: `seed` (Philox key; default derives from
-    zhusuan_amd.set_random_seed) and `sharding`
-    (zhusuan_amd.distributed.ChainSharding) for chains sharded over GPUs.
+    zhusuan_amd.set_random_seed), `sharding`
+    (zhusuan_amd.distributed.ChainSharding) for chains sharded over GPUs, and
+    `likelihood_arithmetic`: 'fp32' (default: the dense-likelihood plans'
+    two GEMMs on the exact-fp32 MFMAs) or 'bf16x3' (three bfloat16 planes
+    per float32 operand, six bf16 MFMAs per product, float32 accumulation:
+    float32-level results at 1.6-1.8x the fp32 matrix peak; taken where the
+    kernels exist -- Bernoulli / mixture-multinomial likelihoods of <= 256
+    columns -- `hmc.likelihood_arithmetic_used` says which ran).
     """
 
     def __init__(self, step_size=1., n_leapfrogs=10, adapt_step_size=None,
                  target_acceptance_rate=0.8, gamma=0.05, t0=100, kappa=0.75,
                  adapt_mass=None, mass_collect_iters=10, mass_decay=0.99,
-                 *, seed=None, sharding=None, native_plans=True):
+                 *, seed=None, sharding=None, native_plans=True,
+                 likelihood_arithmetic='fp32'):
+        if likelihood_arithmetic not in ('fp32', 'bf16x3'):
+            raise ValueError("likelihood_arithmetic must be 'fp32' or "
+                             "'bf16x3', got %r" % (likelihood_arithmetic,))
+        self.likelihood_arithmetic = likelihood_arithmetic
         self._init_step_size_value = float(step_size)
         self.n_leapfrogs = int(n_leapfrogs)
         self.target_acceptance_rate = float(target_acceptance_rate)
@@ -415,6 +426,16 @@ class HMC(object):
     @property
     def plan_kind(self):
         return None if self._plan is None else self._plan.kind
+
+    @property
+    def likelihood_arithmetic_used(self):
+        """'bf16x3' when the plan's likelihood evaluations run on the
+        bf16 matrix cores (csrc/linear_bf16x3.hip), 'fp32' for the exact-fp32
+        MFMA kernels, None for plans without a dense likelihood kernel."""
+        plan = self._plan
+        if plan is None or not hasattr(plan, 'inner_image'):
+            return None
+        return 'bf16x3' if plan.inner_image is not None else 'fp32'
 
     # -- one execution of sample_op ----------------------------------------
     def _run(self, feed_dict, sync):
@@ -1417,6 +1438,23 @@ class _DenseLikelihoodPlan(_PlanBase):
             n_inner = self.inner.shape[0]
             if C % self.obs.shape[0] != 0:
                 raise ValueError("counts rows do not divide the chain rows")
+        # the bf16x3 kernels, where asked for and where they exist: <= 256
+        # columns, and -- one document per 128-chain workgroup -- chain axes
+        # that fill those workgroups
+        self.inner_image = None
+        if self.hmc.likelihood_arithmetic == 'bf16x3' and \
+                self.kind in ('linear_bernoulli', 'mixture_multinomial') and \
+                self.width in ops.BF16X3_WIDTHS:
+            per_doc = C // self.obs.shape[0] \
+                if self.kind == 'mixture_multinomial' else C
+            n_docs = C // per_doc
+            if n_docs == 1 or not ops.BF16X3_REQUIRE_FILL or \
+                    per_doc % ops.BF16X3_CHAIN_BLOCK == 0 or \
+                    per_doc >= 8 * ops.BF16X3_CHAIN_BLOCK:
+                self.inner_image = ops.bf16x3_image(self.inner)
+                self.block = ops.BF16X3_CHAIN_BLOCK
+        if self.inner_image is None and self.kind != 'linear_categorical':
+            self.block = ops.likelihood_plan(self.width)[1]
         R = self.lik_rows
         self.splits = ops._row_splits(R, n_inner, self.device, self.block)
         need = self.splits * R * (self.width + 1) if self.splits > 1 else 0
@@ -1617,6 +1655,19 @@ class _DenseLikelihoodPlan(_PlanBase):
                        self.n_classes, self.stride, ll_ptr,
                        grad.data_ptr(), self.splits, _capi.ptr(ws),
                        stream)
+        elif self.inner_image is not None and self.kind == 'linear_bernoulli':
+            _capi.call('zshmc_linear_bernoulli_log_lik_bf16x3', w.data_ptr(),
+                       self.inner_image.data_ptr(), self.obs.data_ptr(),
+                       self.n_chains, self.inner.shape[0], self.width,
+                       ll_ptr, grad.data_ptr(), self.splits,
+                       _capi.ptr(ws), stream)
+        elif self.inner_image is not None:
+            _capi.call('zshmc_linear_multinomial_log_lik_bf16x3',
+                       w.data_ptr(), self.inner_image.data_ptr(),
+                       self.obs.data_ptr(), self.obs.shape[0],
+                       self.obs_stride, self.n_chains, self.inner.shape[0],
+                       self.width, ll_ptr, grad.data_ptr(), self.splits,
+                       _capi.ptr(ws), stream)
         elif self.kind == 'linear_bernoulli':
             _capi.call('zshmc_linear_bernoulli_log_lik', w.data_ptr(),
                        self.inner.data_ptr(), self.obs.data_ptr(),
@@ -1818,6 +1869,7 @@ class _DenseLikelihoodPlan(_PlanBase):
             d.gd_g_pairs = self.g_pairs.data_ptr()
         else:
             d.inner, d.n_inner = self.inner.data_ptr(), self.inner.shape[0]
+            d.inner_image = c.ptr(self.inner_image)
             d.obs = self.obs.data_ptr()
             if self.kind == 'mixture_multinomial':
                 d.obs_rows, d.obs_stride = self.obs.shape[0], self.obs_stride
