@@ -55,6 +55,23 @@ constexpr int kB3Chains = 128;  // chains per workgroup
 #ifndef ZS_B3_SWIZZLE
 #define ZS_B3_SWIZZLE 1
 #endif
+// Timing experiments only (wrong results): bit 0 no element-wise stage, bit 1
+// no tile DMA in the loop, bit 2 no label DMA / reads, bit 3 no GEMM 1,
+// bit 4 no GEMM 2, bit 5 no `s_nop 1` in front of the MFMAs
+// (tools/build_b3_variants.sh; profiles/r05*_b3_where_the_clocks_go.txt).
+#ifndef ZS_B3_SKIP
+#define ZS_B3_SKIP 0
+#endif
+// the DMA of the next tile in GEMM 1's gaps (1) or GEMM 2's first half (0);
+// default: GEMM 1 for the wide tiles (D >= 192), GEMM 2 for the narrow ones
+#ifndef ZS_B3_DMA_IN_GEMM1
+#define ZS_B3_DMA_IN_GEMM1 (D >= 192)
+#endif
+#if ZS_B3_SKIP & 32
+#define ZS_B3_NOP ""
+#else
+#define ZS_B3_NOP "s_nop 1\n\t"
+#endif
 
 // 16-byte chunk (row m of the tile, feature half h, 16-feature sub-block par)
 // of a 2 KB block of 32 rows x 32 features.  Swizzled: every 16-lane service
@@ -161,28 +178,28 @@ __device__ __forceinline__ u2 lds_tr(uint32_t addr, int off) {
 }
 // one 32x32x16 bf16 MFMA; the B operand in VGPRs or AGPRs
 __device__ __forceinline__ void mfma_bv(f16v& acc, const u4& a, const u4& b) {
-  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0"
+  asm volatile(ZS_B3_NOP "v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0"
                : "+v"(acc)
                : "v"(a), "v"(b));
 }
 __device__ __forceinline__ void mfma_bv0(f16v& acc, const u4& a, const u4& b) {
-  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0"
+  asm volatile(ZS_B3_NOP "v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0"
                : "=&v"(acc)
                : "v"(a), "v"(b));
 }
 __device__ __forceinline__ void mfma_ba(f16v& acc, const u4& a, const u4& b) {
-  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0"
+  asm volatile(ZS_B3_NOP "v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0"
                : "+v"(acc)
                : "v"(a), "a"(b));
 }
 __device__ __forceinline__ void mfma_ba0(f16v& acc, const u4& a, const u4& b) {
-  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0"
+  asm volatile(ZS_B3_NOP "v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0"
                : "=&v"(acc)
                : "v"(a), "a"(b));
 }
 // accumulate into an AGPR tile
 __device__ __forceinline__ void mfma_g(f16v& acc, const u4& a, const u4& b) {
-  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0"
+  asm volatile(ZS_B3_NOP "v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0"
                : "+a"(acc)
                : "v"(a), "v"(b));
 }
@@ -221,6 +238,8 @@ __device__ __forceinline__ void pin(float& a, float& b) {
 }
 __device__ __forceinline__ void pin(float& a) { asm volatile("" : "+v"(a)); }
 __device__ __forceinline__ void pin(unsigned& a) { asm volatile("" : "+v"(a)); }
+template <int I>
+using template_int = std::integral_constant<int, I>;
 // 10 wait states behind an 8-pass MFMA's write before a VALU read
 __device__ __forceinline__ void mfma_drain8(f16v& acc) {
   asm volatile("s_nop 11" : "+v"(acc));
@@ -331,11 +350,12 @@ __global__ __launch_bounds__(256, 1) void linear_b3_kernel(
                            dst + (uint32_t)((i >> 2) * 4096), voff);
   };
   // the tile's 32 labels: wave w brings rows 8 w .. 8 w + 7 (8-lane DMA),
-  // clamped to the last row (masked / met by zero rows of X)
-  const uint32_t lane_y = (uint32_t)(wave * 8) + ((uint32_t)lane & 7u);
+  // clamped to the last row of X (masked / met by zero rows of the image)
+  const int lane_y = wave * 8 + (lane & 7);
   auto dma_labels = [&](int64_t tile, uint32_t dst) {
-    const int64_t r = tile * kB3Rows + lane_y;
-    const uint32_t off = (uint32_t)((r < N ? r : N - 1) - tile * kB3Rows) * 4u;
+    const int64_t left = N - 1 - tile * kB3Rows;      // >= 0: the tile exists
+    const int last = left < kB3Rows - 1 ? (int)left : kB3Rows - 1;
+    const uint32_t off = (uint32_t)(lane_y < last ? lane_y : last) * 4u;
     const float* src = uniform_ptr(ysrc + tile * kB3Rows);
     asm volatile(
         "s_mov_b32 m0, %2\n\t"
@@ -411,23 +431,34 @@ __global__ __launch_bounds__(256, 1) void linear_b3_kernel(
   uint32_t a_addr0 = 0, a_addr1 = 0;
   const unsigned char* src_next = xsrc;
   uint32_t dst_next = dst_wave;
+  int64_t lab_next = t_first;
 
-  // ---- top of an iteration: tile `it` has landed, everyone is done with tile
-  // it-2; the labels of tile it+1 go out; first operand reads -----------------
-  auto top = [&](int it, auto with_ew) {
+  // ---- the boundary between two iterations (placed in front of the last
+  // MFMAs of the iteration that ends): this wave's DMA of tile it+1 has
+  // landed, barrier -- everyone's has, and everyone has issued AND landed its
+  // last reads of tile it-1 -- buffers rotate, and the first reads of
+  // iteration it+1 (A operand of k-step 0, the labels of tile `it`) go out
+  // under those last MFMAs ------------------------------------------------------
+  auto boundary = [&](int it) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    // tile it+1 (clamped to the last one: a harmless re-load)
-    const int nxt = it + 1 < T ? it + 1 : T - 1;
-    src_next = xsrc + (int64_t)nxt * kTile;
-    dst_next = dst_wave + b_next;
-    dma_labels(t_first + nxt, sy_addr + y_next);
+    {  // prev <- cur <- next <- prev
+      const uint32_t t = b_prev;
+      b_prev = b_cur;
+      b_cur = b_next;
+      b_next = t;
+      const uint32_t u = y_prev;
+      y_prev = y_cur;
+      y_cur = y_next;
+      y_next = u;
+    }
+    const int64_t left = N - (t_first + it) * kB3Rows;   // rows of tile `it`
+    rows_prev = left < kB3Rows ? (int)left : kB3Rows;
     a_addr0 = sx_addr + b_cur + a_lane[0];
     a_addr1 = sx_addr + b_cur + a_lane[1];
-    // head: A operand of k-step 0 (and the labels of tile it-1)
     opnd[0][0] = lds_u4(a_addr0, 0);
     opnd[0][1] = lds_u4(a_addr0, kPlane);
     opnd[0][2] = lds_u4(a_addr0, 2 * kPlane);
-    if constexpr (decltype(with_ew)::value) {
+    if (!(ZS_B3_SKIP & 4)) {
       const uint32_t y_addr = sy_addr + y_prev + y_lane;
       yv[0] = lds_f4(y_addr, 0);
       yv[1] = lds_f4(y_addr, 32);
@@ -435,6 +466,14 @@ __global__ __launch_bounds__(256, 1) void linear_b3_kernel(
       yv[3] = lds_f4(y_addr, 96);
     }
     __builtin_amdgcn_sched_barrier(0);
+  };
+  // where iteration `it` sends tile it+1 (clamped to the last one: a
+  // harmless re-load) and its labels
+  auto plan_dma = [&](int it) {
+    const int nxt = it + 1 < T ? it + 1 : T - 1;
+    src_next = xsrc + (int64_t)nxt * kTile;
+    dst_next = dst_wave + b_next;
+    lab_next = t_first + nxt;
   };
 
   // ---- element-wise stage of tile it-1, in pieces ------------------------------
@@ -525,15 +564,15 @@ __global__ __launch_bounds__(256, 1) void linear_b3_kernel(
     }
   };
   constexpr int kPieces = 8 * kSubs;
-  constexpr int kGaps = 6 * KS;
-  // pieces [first(g), first(g+1)) go behind MFMA g of GEMM 1; none in the
-  // first k-step (the labels are landing)
-  auto ew_gap = [&](auto gc) {
-    constexpr int g = decltype(gc)::value;
-    constexpr int lo_g = 6, n_g = kGaps - lo_g;
-    if constexpr (g >= lo_g) {
-      constexpr int first = (g - lo_g) * kPieces / n_g;
-      constexpr int last = (g - lo_g + 1) * kPieces / n_g;
+  // pieces [P0, P1) spread over the gaps [G0, G1) of a phase: gap g takes
+  // those whose share falls on it
+  auto ew_gaps = [&](auto gc, auto p0c, auto p1c, auto g0c, auto g1c) {
+    constexpr int g = decltype(gc)::value, P0 = decltype(p0c)::value,
+                  P1 = decltype(p1c)::value, G0 = decltype(g0c)::value,
+                  G1 = decltype(g1c)::value;
+    if constexpr (g >= G0 && g < G1 && !(ZS_B3_SKIP & 1)) {
+      constexpr int first = P0 + (g - G0) * (P1 - P0) / (G1 - G0);
+      constexpr int last = P0 + (g - G0 + 1) * (P1 - P0) / (G1 - G0);
       if constexpr (last > first) {
         static_for<last - first>([&](auto dc) {
           ew_piece(std::integral_constant<int, first + decltype(dc)::value>{});
@@ -542,10 +581,54 @@ __global__ __launch_bounds__(256, 1) void linear_b3_kernel(
       }
     }
   };
+  // pairs 0 .. kPairs1-1 ride in GEMM 1 (0 .. 3 are k-step 0's rows: they must),
+  // the rest in the first half of GEMM 2
+  // (shader clocks per 32-row tile, profiles/r05g_b3_phase_split.txt: the
+  // stage costs ~600 clocks wherever it rides -- a wave's VALU work is only
+  // partly hidden under its own bf16 MFMAs -- and the split moves 1-2 %)
+#ifdef ZS_B3_PAIRS1
+  constexpr int kPairs1 = ZS_B3_PAIRS1;
+#else
+  constexpr int kPairs1 = D >= 192 ? 5 : 6;
+#endif
+  static_assert(kPairs1 >= 4 && kPairs1 <= 8, "k-step 0's rows before GEMM 2");
+  template_int<0> c0;
+  template_int<kPairs1 * kSubs> cHalf;
+  template_int<kPieces> cAll;
 
-  // ---- GEMM 1 of tile `it`: S[n, c] over the wave's 32 chains, the
-  // element-wise stage of the tile before in its gaps ---------------------------
+  // tile it+1 and its labels: piece i (kDma of them, then the labels)
+  auto dma_step = [&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    if constexpr (i < kDma) {
+      if (!(ZS_B3_SKIP & 2)) dma_piece(ic, src_next, dst_next);
+    } else if constexpr (i == kDma) {
+      if (!(ZS_B3_SKIP & 4)) dma_labels(lab_next, sy_addr + y_next);
+    }
+  };
+
+  // B operand of GEMM 2's step (s, nb), plane p: two transposing reads
+  uint32_t t00 = 0, t01 = 0, t10 = 0, t11 = 0;
+  auto plan_b = [&]() {
+    const uint32_t tb = sx_addr + b_prev;
+    t00 = tb + t_lane[0][0], t01 = tb + t_lane[0][1];
+    t10 = tb + t_lane[1][0], t11 = tb + t_lane[1][1];
+  };
+  auto read_b = [&](auto stc, auto pc) -> u4 {
+    constexpr int st = decltype(stc)::value, p = decltype(pc)::value;
+    constexpr int s = st / NB, nb = st % NB;     // s-major: see gemm2
+    constexpr int off = p * kPlane + nb * 2048;
+    const u2 q0 = lds_tr(s == 0 ? t00 : t10, off);
+    const u2 q1 = lds_tr(s == 0 ? t01 : t11, off);
+    return u4{q0[0], q0[1], q1[0], q1[1]};
+  };
+
+  // ---- GEMM 1 of tile `it`: S[n, c] over the wave's 32 chains; in its gaps
+  // the first half of the element-wise stage of tile it-1 (pairs 0 .. 3: the
+  // rows of GEMM 2's k-step 0) and, in the last k-step's, the first operand
+  // reads of GEMM 2 -------------------------------------------------------------
   auto gemm1 = [&](auto with_ew) {
+    constexpr bool kEw = decltype(with_ew)::value;
+    if constexpr (kEw) plan_b();
     static_for<KS>([&](auto kc) {
       constexpr int ks = decltype(kc)::value;
       constexpr int cur = ks & 1, nx = cur ^ 1;
@@ -555,6 +638,7 @@ __global__ __launch_bounds__(256, 1) void linear_b3_kernel(
         constexpr int g = ks * 6 + term;
         constexpr bool first = ks == 0 && term < NACC;
         f16v& acc = (NACC == 2 && (term & 1)) ? Sb : Sa;
+        if (!(ZS_B3_SKIP & 8)) {
         if constexpr (pb == 0) {
           if constexpr (first) mfma_bv0(acc, opnd[cur][pa], wh[ks]);
           else mfma_bv(acc, opnd[cur][pa], wh[ks]);
@@ -567,25 +651,30 @@ __global__ __launch_bounds__(256, 1) void linear_b3_kernel(
           if constexpr (first) mfma_bv0(acc, opnd[cur][pa], wl[ks]);
           else mfma_bv(acc, opnd[cur][pa], wl[ks]);
         }
-        // gaps 0-2: the next k-step's operand planes; gaps 3, 4: DMA pieces
-        // (in the order the next k-step consumes them: lo, hi, mid)
-        if constexpr (ks + 1 < KS && term < 3) {
-          constexpr int P = (ks + 1) >> 1;
-          constexpr int pl = kTermA[term];
-          opnd[nx][pl] = lds_u4(((ks + 1) & 1) ? a_addr1 : a_addr0,
-                                pl * kPlane + P * 2048);
         }
-        if constexpr (term == 3 && ks < kDma)
-          dma_piece(std::integral_constant<int, ks>{}, src_next, dst_next);
-        if constexpr (term == 4 && ks + KS < kDma)   // (narrow tiles: two per k-step)
-          dma_piece(std::integral_constant<int, ks + KS>{}, src_next, dst_next);
+        // gaps 0-2: the next k-step's operand planes in the order it
+        // consumes them (lo, hi, mid) -- behind the last k-step GEMM 2's
+        // first (hi, mid, lo)
+        if constexpr (term < 3) {
+          if constexpr (ks + 1 < KS) {
+            constexpr int P = (ks + 1) >> 1;
+            constexpr int pl = kTermA[term];
+            opnd[nx][pl] = lds_u4(((ks + 1) & 1) ? a_addr1 : a_addr0,
+                                  pl * kPlane + P * 2048);
+          } else if constexpr (kEw) {
+            static_assert(nx == 0, "GEMM 2's step 0 reads from slot 0");
+            opnd[0][term] = read_b(c0, tc);
+          }
+        }
+        if constexpr (ZS_B3_DMA_IN_GEMM1 && kEw && term == 3 && ks <= kDma)
+          dma_step(template_int<ks>{});
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (decltype(with_ew)::value)
-          ew_gap(std::integral_constant<int, g>{});
+        if constexpr (kEw)
+          ew_gaps(template_int<g>{}, c0, cHalf, c0, template_int<6 * KS - 3>{});
       });
     });
   };
-  static_assert(kDma <= 2 * KS, "DMA pieces fit GEMM 1's k-steps");
+  static_assert(KS % 2 == 0, "the last k-step of GEMM 1 uses operand slot 1");
 
   // logits of the tile GEMM 1 just finished -> Sp (the accumulators are free
   // for the next GEMM 1); placed where its last MFMA is long done
@@ -600,76 +689,93 @@ __global__ __launch_bounds__(256, 1) void linear_b3_kernel(
     }
     __builtin_amdgcn_sched_barrier(0);
   };
-
-  // ---- GEMM 2 of tile it-1: G[c, f] += R^T X -----------------------------------
-  auto gemm2 = [&]() {
-    const uint32_t tb = sx_addr + b_prev;
-    const uint32_t t00 = tb + t_lane[0][0], t01 = tb + t_lane[0][1],
-                   t10 = tb + t_lane[1][0], t11 = tb + t_lane[1][1];
-    // B operand of step (nb, s), plane p: two transposing reads
-    auto read_b = [&](auto stc, auto pc) -> u4 {
-      constexpr int st = decltype(stc)::value, p = decltype(pc)::value;
-      constexpr int nb = st >> 1, s = st & 1;
-      constexpr int off = p * kPlane + nb * 2048;
-      const u2 q0 = lds_tr(s == 0 ? t00 : t10, off);
-      const u2 q1 = lds_tr(s == 0 ? t01 : t11, off);
-      return u4{q0[0], q0[1], q1[0], q1[1]};
-    };
-    static_for<3>([&](auto pc) {
-      opnd[0][decltype(pc)::value] =
-          read_b(std::integral_constant<int, 0>{}, pc);
-    });
-    __builtin_amdgcn_sched_barrier(0);
-    static_for<2 * NB>([&](auto stc) {
+  // ---- GEMM 2 of tile it-1: G[c, f] += R^T X, k-step 0 (rows 0 .. 15) over
+  // all feature blocks, then k-step 1: the second half of the element-wise
+  // stage (pairs 4 .. 7 = k-step 1's rows) and the DMA of tile it+1 ride in
+  // the first half's gaps, the logits of tile `it` and the iteration boundary
+  // in the second's ---------------------------------------------------------------
+  auto gemm2 = [&](int it) {
+    constexpr int kSteps = 2 * NB;
+    constexpr int kHalfGaps = 6 * NB;
+    // DMA pieces: one every kEvery gaps of the first half, from gap 1
+    constexpr int kEvery = (kHalfGaps - 1) / (kDma + 1);
+    static_assert(kEvery >= 1, "the DMA pieces fit GEMM 2's first half");
+    static_for<kSteps>([&](auto stc) {
       constexpr int st = decltype(stc)::value;
-      constexpr int nb = st >> 1, s = st & 1;
+      constexpr int s = st / NB, nb = st % NB;
       constexpr int cur = st & 1, nx = cur ^ 1;
+      if constexpr (st == kSteps - 1) boundary(it);
       static_for<6>([&](auto tc) {
         constexpr int term = decltype(tc)::value;
         constexpr int pa = kTermA[term], pb = kTermB[term];
-        mfma_g(G[nb], Rp[s][pa], opnd[cur][pb]);
-        if constexpr (st + 1 < 2 * NB && term < 3)
-          opnd[nx][term] = read_b(std::integral_constant<int, st + 1>{}, tc);
+        constexpr int g = st * 6 + term;
+        if (!(ZS_B3_SKIP & 16)) mfma_g(G[nb], Rp[s][pa], opnd[cur][pb]);
+        if constexpr (st + 1 < kSteps && term < 3)
+          opnd[nx][term] = read_b(template_int<st + 1>{}, tc);
+        if constexpr (!(ZS_B3_DMA_IN_GEMM1) && g < kHalfGaps && g >= 1 &&
+                      (g - 1) % kEvery == 0 && (g - 1) / kEvery <= kDma)
+          dma_step(template_int<(g - 1) / kEvery>{});
         __builtin_amdgcn_sched_barrier(0);
+        ew_gaps(template_int<g>{}, cHalf, cAll, c0,
+                template_int<kHalfGaps - 6>{});
       });
-      if constexpr (st == 1) take_logits();
+      if constexpr (st == NB + 1) take_logits();
     });
   };
-  auto rotate = [&](int it) {
-    // prev <- cur <- next <- prev
-    const uint32_t t = b_prev;
-    b_prev = b_cur;
-    b_cur = b_next;
-    b_next = t;
-    const uint32_t u = y_prev;
-    y_prev = y_cur;
-    y_cur = y_next;
-    y_next = u;
-    const int64_t left = N - (t_first + it) * kB3Rows;   // rows of tile `it`
-    rows_prev = left < kB3Rows ? (int)left : kB3Rows;
-  };
+  static_assert(NB >= 2, "GEMM 2's last step is not its first of k-step 1");
 
   if (T > 0) {
-    // iteration 0: GEMM 1 of the first tile alone
-    top(0, std::false_type{});
+    // iteration 0: GEMM 1 of the first tile alone, the DMA of the second
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    a_addr0 = sx_addr + b_cur + a_lane[0];
+    a_addr1 = sx_addr + b_cur + a_lane[1];
+    opnd[0][0] = lds_u4(a_addr0, 0);
+    opnd[0][1] = lds_u4(a_addr0, kPlane);
+    opnd[0][2] = lds_u4(a_addr0, 2 * kPlane);
+    plan_dma(0);
+    static_for<kDma + 1>([&](auto ic) { dma_step(ic); });
+    __builtin_amdgcn_sched_barrier(0);
     gemm1(std::false_type{});
     mfma_drain8(Sa);
     if constexpr (NACC == 2) mfma_drain8(Sb);
     take_logits();
-    rotate(0);
+    boundary(0);
     // iterations 1 .. T: GEMM 1 of tile `it` (of the last tile once more, unused,
     // in iteration T) around the element-wise stage of tile it-1, then GEMM 2
     // of tile it-1.  Nothing in the loop is conditional: the accumulators do
     // not pass through a phi (hipcc keeps a second set for one and copies).
     int it = 1;
+#ifdef ZS_B3_TIMING  // debug: shader clocks per phase, every wave of block 0
+    long long tacc[2] = {0, 0};
+    long long tmark = __builtin_readcyclecounter();
+#define ZS_B3_MARK(i)                                  \
+  {                                                     \
+    __builtin_amdgcn_sched_barrier(0);                  \
+    const long long _t = __builtin_readcyclecounter();  \
+    tacc[i] += _t - tmark;                              \
+    tmark = _t;                                         \
+    __builtin_amdgcn_sched_barrier(0);                  \
+  }
+#else
+#define ZS_B3_MARK(i)
+#endif
     do {
-      top(it, std::true_type{});
       ll_tile = 0.f;
+      plan_dma(it);
       gemm1(std::true_type{});
+      ZS_B3_MARK(0)
+      gemm2(it);
+      ZS_B3_MARK(1)
       if (LL) ll_lane += (double)ll_tile;
-      gemm2();
-      rotate(it);
     } while (++it <= T);
+#ifdef ZS_B3_TIMING
+    if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) {
+      gW[wave * 4 + 0] = (float)tacc[0];
+      gW[wave * 4 + 1] = (float)tacc[1];
+      gW[wave * 4 + 2] = (float)T;
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0) return;
+#endif
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
