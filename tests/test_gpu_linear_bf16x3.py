@@ -240,3 +240,47 @@ def test_multinomial_matches_float64_reference(env, n_chains, n_docs, V, K,
                                    atol=2e-5 * V)
     np.testing.assert_allclose(g.cpu().numpy(), g_ref, rtol=1e-4,
                                atol=2e-5 * (np.abs(g_ref).max() + 1))
+
+
+def test_hmc_on_bf16x3_run_many_equals_a_loop_of_runs(env):
+    """HMC(likelihood_arithmetic='bf16x3') through both launch loops -- the
+    Python one (sample_op.run) and the C one (zshmc_hmc_model_run:
+    sample_op.run_many) -- bit for bit, with the start evaluation carried and
+    with every start evaluated (reuse_start_evaluation=False)."""
+    torch, _capi, dev = env
+    import zhusuan_amd as zs
+    rng = np.random.RandomState(4)
+    N, D, C = 500, 40, 256
+    X = torch.tensor(rng.normal(size=(N, D)).astype(np.float32), device=dev)
+    y = torch.tensor((rng.uniform(size=N) < 0.5).astype(np.int32), device=dev)
+    w0 = (0.1 * rng.normal(size=(C, D))).astype(np.float32)
+
+    @zs.meta_bayesian_net()
+    def blr():
+        bn = zs.BayesianNet()
+        wn = bn.normal('w', torch.zeros(D, device=dev), std=1., n_samples=C,
+                       group_ndims=1)
+        bn.bernoulli('y', wn.tensor @ X.t(), group_ndims=1)
+        return bn
+    out = {}
+    for mode in ('loop', 'block', 'loop_evaluate', 'block_evaluate'):
+        flag = zs.placeholder(bool)
+        hmc = zs.HMC(step_size=0.02, n_leapfrogs=5, seed=11,
+                     adapt_step_size=flag, likelihood_arithmetic='bf16x3',
+                     reuse_start_evaluation=not mode.endswith('evaluate'))
+        w = torch.tensor(w0, device=dev)
+        op, info = hmc.sample(blr(), {'y': y}, {'w': w})
+        assert hmc.plan_kind == 'linear_bernoulli'
+        assert hmc.likelihood_arithmetic_used == 'bf16x3'
+        for n, feed in ((5, {flag: True}), (4, {flag: False})):
+            if mode.startswith('block'):
+                op.run_many(n, feed_dict=feed)
+            else:
+                for _ in range(n):
+                    op.run(feed_dict=feed)
+        out[mode] = (w.cpu().numpy(), info.log_prob.cpu().numpy(),
+                     float(info.updated_step_size.item()))
+    for mode in ('block', 'loop_evaluate', 'block_evaluate'):
+        np.testing.assert_array_equal(out[mode][0], out['loop'][0])
+        np.testing.assert_array_equal(out[mode][1], out['loop'][1])
+        assert out[mode][2] == out['loop'][2]

@@ -288,6 +288,8 @@ def clear_caches():
     _phi_cache.clear()
     _counts_cache.clear()
     _csr_cache.clear()
+    _image_cache.clear()
+    _label_cache.clear()
 
 
 def gathered_dot(u, select_u, v, select_v):
@@ -523,6 +525,7 @@ def _tensor_key(t):
 
 
 _x_cache = _Lru()
+_label_cache = _Lru()
 
 
 def _padded_x(X, width):
@@ -684,11 +687,21 @@ def labels_as_float(y, n_classes):
     """Class labels [N] (any int / float dtype) as the float32 vector the
     kernel compares its lane's class with; out-of-range labels are an error
     (tf.nn.sparse_softmax_cross_entropy_with_logits raises / returns NaN)."""
+    key = (_tensor_key(y), int(n_classes))
+    hit = _label_cache.get(key)
+    if hit is not None:        # validated once per tensor version: the check
+        return hit             # reads the device (two host syncs)
     yl = y.detach().reshape(-1)
-    if yl.numel() and (int(yl.min()) < 0 or int(yl.max()) >= n_classes):
-        raise ValueError("Categorical: labels must lie in [0, {})"
-                         .format(n_classes))
-    return yl.to(_F32).contiguous()
+    yf = yl.to(_F32).contiguous()
+    if yl.numel():
+        lo, hi = float(yf.min()), float(yf.max())
+        integral = True if not yl.dtype.is_floating_point else \
+            bool((yf == yf.round()).all())
+        if lo < 0 or hi >= n_classes or not integral:
+            raise ValueError("Categorical: labels must be integers in [0, {})"
+                             .format(n_classes))
+    _label_cache.put(key, yf, y)
+    return yf
 
 
 class LinearCategoricalLogLik(_Function):

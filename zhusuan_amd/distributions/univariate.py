@@ -39,7 +39,10 @@ _scalar_cache = {}
 
 def _scalar_param(value, device):
     """A Python number given as a distribution parameter -> ONE float32
-    device tensor per (value, device), reused by every later construction: a
+    device tensor per (value, device), reused by every later construction
+    (SHARED, and exposed as `dist.mean` / `.std` / `.logstd`: treat it as
+    read-only -- an in-place op on it changes every later distribution built
+    from the same number): a
     model function is re-evaluated on every run, and a fresh tensor each time
     would cost a host-to-device copy per evaluation and defeat the native
     plans' "parameters unchanged since last run" check (which goes by
@@ -49,9 +52,13 @@ def _scalar_param(value, device):
     if t is None:
         if len(_scalar_cache) > 256:
             _scalar_cache.clear()
-        t = _scalar_cache[key] = torch.tensor(float(value),
-                                              dtype=torch.float32,
-                                              device=device)
+        # (made OUTSIDE inference mode whatever the caller is in: a cached
+        # inference tensor would break later autograd use and has no version
+        # counter for the native plans' "unchanged" check)
+        with torch.inference_mode(False):
+            t = _scalar_cache[key] = torch.tensor(float(value),
+                                                  dtype=torch.float32,
+                                                  device=device)
     return t
 
 
@@ -90,10 +97,11 @@ class Normal(Distribution):
         # the rating likelihood of pmf_hmc.py:26-31, which the native
         # gathered-dot plan evaluates without materialising it; any use of it
         # as a tensor forces it)
-        self._mean = as_tensor(mean, dtype=None if isinstance(
-            mean, torch.Tensor) else f32, device=dev,
-            keep_symbolic=_symbolic.gathered_dot_mean(mean) is not None) \
-            if not isinstance(mean, (int, float)) else _scalar_param(mean, dev)
+        number = isinstance(mean, (int, float)) and not isinstance(mean, bool)
+        self._mean = _scalar_param(mean, dev) if number else as_tensor(
+            mean, dtype=None if isinstance(mean, torch.Tensor) else f32,
+            device=dev,
+            keep_symbolic=_symbolic.gathered_dot_mean(mean) is not None)
         # The parameter that was not given is derived on first use (a model
         # function is re-evaluated on every transition: an eager exp / log
         # would be one more kernel launch per evaluation), unless

@@ -29,7 +29,7 @@ import ctypes
 
 import torch
 
-from . import _capi, _symbolic
+from . import _capi, _symbolic, _writes
 from .distributions import Normal
 from .framework.bn import StochasticTensor
 from .framework.meta_bn import MetaBayesianNet
@@ -239,17 +239,39 @@ class HMC(object):
     float32-level results at 1.6-1.8x the fp32 matrix peak; taken where the
     kernels exist -- Bernoulli / mixture-multinomial likelihoods of <= 256
     columns -- `hmc.likelihood_arithmetic_used` says which ran).
+
+    The start evaluation (`reuse_start_evaluation`, native model plans).
+    The reference re-evaluates the log-joint at the state a transition starts
+    from on every `sess.run` (hmc.py:47-50).  With
+    `reuse_start_evaluation=True` (default) a native plan instead starts from
+    what it already has: the previous transition's last likelihood
+    evaluation where the chain accepted, its own first one where it did not
+    -- L likelihood launches per transition instead of L + 1, bit-identical
+    results AS LONG AS the model is the same function of the same values.
+    What invalidates it, automatically: an in-place torch op on a latent or on
+    a tensor the likelihood reads (version counters), a new tensor fed
+    through a placeholder, another sampler of this library writing the same
+    latent (zhusuan_amd/_writes.py), `set_state`.  What does not, and needs a
+    call: writes torch cannot see -- `x.data`, DLPack, a raw pointer --
+    `hmc.latents_changed()` for a latent, `hmc.observed_changed()` for an
+    observed / parameter tensor; and a log-joint that is random or depends on
+    state outside its tensors.  With `reuse_start_evaluation=False` every
+    transition evaluates its start, and every run re-reads the observed and
+    parameter tensors (no cached padded copies), exactly as the reference's
+    graph does.
     """
 
     def __init__(self, step_size=1., n_leapfrogs=10, adapt_step_size=None,
                  target_acceptance_rate=0.8, gamma=0.05, t0=100, kappa=0.75,
                  adapt_mass=None, mass_collect_iters=10, mass_decay=0.99,
                  *, seed=None, sharding=None, native_plans=True,
-                 likelihood_arithmetic='fp32'):
+                 likelihood_arithmetic='fp32', reuse_start_evaluation=True):
         if likelihood_arithmetic not in ('fp32', 'bf16x3'):
             raise ValueError("likelihood_arithmetic must be 'fp32' or "
                              "'bf16x3', got %r" % (likelihood_arithmetic,))
         self.likelihood_arithmetic = likelihood_arithmetic
+        # see the class docstring ("The start evaluation")
+        self.reuse_start_evaluation = bool(reuse_start_evaluation)
         self._init_step_size_value = float(step_size)
         self.n_leapfrogs = int(n_leapfrogs)
         self.target_acceptance_rate = float(target_acceptance_rate)
@@ -372,6 +394,9 @@ class HMC(object):
         answer as in _eval_log_joint: plain tensors from now on, and the
         recognisers run once more on those."""
         for _ in range(2):
+            # (what an earlier model / the pass before the SymbolicCut noted
+            # does not describe this one)
+            self._refusal = None
             try:
                 plan = _try_fused_plan(self, meta_bn, names, values,
                                        chain_shape, device)
@@ -610,6 +635,21 @@ class HMC(object):
         if plan.colsum_state in ('fresh', 'parts'):
             plan.colsum_state = 'dirty'
 
+    def observed_changed(self):
+        """Tell the sampler that an observed or parameter tensor of the model
+        was written behind torch's back (`X.data[...] = ...`, DLPack, a raw
+        pointer): the padded / re-laid-out copies the kernels read and the
+        carried start evaluation are dropped and rebuilt on the next run."""
+        from . import _ops
+        _ops.clear_caches()
+        plan = self._plan
+        if plan is None:
+            return
+        if hasattr(plan, '_src'):
+            plan._src = None
+        if hasattr(plan, '_start_valid'):
+            plan._start_valid = False
+
     def flush(self):
         """Retire a step-size update still owed to the last transition (the
         fused plan carries it into the next launch); afterwards the device
@@ -718,13 +758,16 @@ class HMC(object):
 # execution plans
 # ----------------------------------------------------------------------------
 def _versions(tensors):
-    """torch's version counters of `tensors` (what an in-place op bumps), or
-    None when one of them does not keep one (an inference-mode tensor): then
-    nothing may be assumed about what happened to it between two runs."""
+    """What identifies the CONTENTS of `tensors` between two runs: torch's
+    version counter (what an in-place torch op bumps) and the library's own
+    write generation of the storage (what every sampler bumps when it writes
+    a latent through the C-ABI, zhusuan_amd/_writes.py) -- or None when a
+    tensor keeps no version counter (an inference-mode tensor): then nothing
+    may be assumed about what happened to it between two runs."""
     out = []
     for t in tensors:
         try:
-            out.append(t._version)
+            out.append((t._version, _writes.generation(t)))
         except RuntimeError:
             return None
     return out
@@ -791,6 +834,16 @@ class _PlanBase(object):
     def refresh_model(self):
         """Called at the start of every run: the generic plan re-evaluates the
         model function on every gradient anyway."""
+
+    def _own_write(self):
+        """This plan has just written its latents (through the C-ABI): other
+        samplers on the same tensors must see that (zhusuan_amd/_writes.py),
+        while what THIS plan still knows about them -- the carried start
+        evaluation, which the writing call itself brought up to date -- stays
+        its own."""
+        _writes.note(self.q)
+        if getattr(self, '_start_valid', False):
+            self._start_versions = _versions(self.q)
 
     # -- mass adaptation (hmc.py:284-305) ------------------------------------
     # colsum life cycle: 'zero' (cleared, what the atomics of
@@ -1096,6 +1149,7 @@ class _FusedDiagNormalPlan(_PlanBase):
             self.hamiltonian.data_ptr(), self.orig_log_prob.data_ptr(),
             self.log_prob.data_ptr(), self.flags.data_ptr(),
             ctypes.byref(link), sharding._comm if sharded else None, stream)
+        self._own_write()
         self.last_t = t_first + n - 1
         self.pending = update if sharded else None
         self.stats_local = False
@@ -1137,6 +1191,7 @@ class _FusedDiagNormalPlan(_PlanBase):
         # the kernel of this shape can produce them
         rows = self._colstats_rows() if want_colstats else 0
         self._launch(t, eps_host, 1, self.hmc.n_leapfrogs, stream, retire, rows)
+        self._own_write()
         if rows:
             self._cs_rows = rows
             self.colsum_state = 'parts'
@@ -1273,6 +1328,7 @@ class _GenericPlan(_PlanBase):
             _capi.call('zshmc_select_rows', self.q[k].data_ptr(),
                        self.q_new[k].data_ptr(), self.accept.data_ptr(),
                        self.n_chains, self.n_data[k], stream)
+        self._own_write()
 
 
 class _DenseLikelihoodPlan(_PlanBase):
@@ -1374,7 +1430,7 @@ class _DenseLikelihoodPlan(_PlanBase):
         # (lik_scale is applied by the step), so annealing keeps it.
         self.grad0 = torch.empty(self.lik_rows, self.width, **f32)
         self.ll0 = torch.empty(self.lik_rows, **f32)
-        self.carry_start = True       # False: evaluate every start (tests)
+        self.carry_start = hmc.reuse_start_evaluation
         self._start_valid = False
         self._start_versions = []
         self.lp_old = self.orig_log_prob      # HMCInfo.orig_log_prob itself
@@ -1401,6 +1457,11 @@ class _DenseLikelihoodPlan(_PlanBase):
         # `X.t()` of the literal spelling is a new view object every time)
         key = [(a.data_ptr(), tuple(a.shape), tuple(a.stride()), a.dtype,
                 a._version) for a in t]
+        if not self.carry_start:
+            # reuse_start_evaluation=False: nothing about the model's tensors
+            # is remembered from one run to the next (hmc.py:47-50)
+            self._ops.clear_caches()
+            self._src = None
         if self._src is not None and key == self._src[0]:
             return
         # another likelihood (design matrix, observations): another
@@ -1922,6 +1983,11 @@ class _DenseLikelihoodPlan(_PlanBase):
                 log_w.numel() == self.n_chains):
             raise ValueError("annealing: log_weights must be a contiguous "
                              "float32 tensor with one entry per chain")
+        # (a call that fails part-way has already overwritten latents: the
+        # start evaluation is trusted again only behind a successful return)
+        self._start_valid = False
+        if adapt_mass:
+            self.colsum_state = 'dirty'
         _capi.call('zshmc_hmc_model_run', ctypes.byref(d),
                    t_first & 0xFFFFFFFF, n, kind, int(bool(adapt_mass)),
                    scales, _capi.ptr(log_w), int(bool(ends)),
@@ -1929,10 +1995,9 @@ class _DenseLikelihoodPlan(_PlanBase):
         self.last_t = t_first + n - 1
         self.stats_local = False
         if n >= 1:
+            self._own_write()
             if self.carry_start:
                 self._mark_start()
-            else:
-                self._start_valid = False
         if adapt_mass:
             self._mark_colstats()
             self._mass_ones = False
@@ -1979,6 +2044,7 @@ class _DenseLikelihoodPlan(_PlanBase):
             self._carry_start(stream)
         else:
             self._start_valid = False
+        self._own_write()
 
 
 def _to_row_period(param, chain_shape, n_data):

@@ -20,7 +20,7 @@ import math
 
 import torch
 
-from . import _capi
+from . import _capi, _writes
 from .framework.meta_bn import MetaBayesianNet
 from .hmc import bind_feed, deferred, placeholder
 from .utils import merge_dicts, next_sampler_seed
@@ -118,6 +118,9 @@ class SGMCMC(object):
         bind_feed(feed_dict, self._var_list[0].device)
         self._update(self._var_list, self._grad_func, feed_dict,
                      _capi.current_stream())
+        # (the latents were written through the C-ABI: a sampler that keeps
+        # something about the same tensors must see it)
+        _writes.note(self._var_list)
         self.t += 1                                           # sgmcmc.py:106
 
     def _define_variables(self, qs):
