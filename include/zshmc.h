@@ -496,7 +496,14 @@ typedef struct zshmc_model_plan {
    * evaluates into them); always valid on return when n_transitions >= 1. */
   float* grad_start;
   float* ll_start;
-  int32_t start_valid, start_pad;
+  int32_t start_valid;
+  /* ABI 0.5.0: 1 = run the L + 1 trips of a transition from ONE cooperative
+   * launch where the likelihood's grid (chain blocks x n_splits) fits the
+   * device at once (csrc/hmc_model_traj.hip: Bernoulli / mixture multinomial,
+   * <= 256 columns, fp32 kernels; zshmc_trajectory_capacity) -- same code,
+   * same order, bit-identical results; needs traj_sync.  0: one launch per
+   * likelihood evaluation / element-wise step. */
+  int32_t one_launch;
   const float* inner; /* X / phi^T / the other factor table */
   int64_t n_inner;    /* data rows / vocabulary / rows of the other table */
   /* ABI 0.5.0: the bf16x3 tile image of `inner` (zshmc_bf16x3_split) or NULL.
@@ -540,6 +547,10 @@ typedef struct zshmc_model_plan {
   double* comm_buf;
   int64_t comm_words;
   void* mass_ws;
+  /* 16 bytes, zeroed once by the caller: the grid barrier's arrival counter
+   * and generation, and a fault word the kernel sets (and the caller checks
+   * at its next synchronisation) should a barrier wait ever run out */
+  void* traj_sync;
 } zshmc_model_plan;
 
 /*   iteration_first   Philox iteration word of the first transition
@@ -561,6 +572,19 @@ int zshmc_hmc_model_run(const zshmc_model_plan* plan, uint32_t iteration_first,
                         int n_transitions, int update_kind, int adapt_mass,
                         const float* lik_scale_host, float* ais_log_weights,
                         int ais_ends_here, void* comm, void* stream);
+/* ABI 0.5.0: ONE transition of a native model plan and nothing around it
+ * (latents -> packed state, momentum, the L + 1 trips, MH test, select, the
+ * carried start evaluation): what zshmc_hmc_model_run does per transition
+ * between its mass update and its statistics -- for a host loop that keeps
+ * the adaptation on its side (sample_op.run) and still wants the one-launch
+ * trajectory.  The step size is the state block's. */
+int zshmc_hmc_model_transition(const zshmc_model_plan* plan, uint32_t iteration,
+                               float lik_scale, void* stream);
+/* Workgroups of the likelihood kernel of this width (64 / 128 / 192 / 256)
+ * and family (ZSHMC_PLAN_LINEAR_BERNOULLI / _MIXTURE_MULTINOMIAL) that can be
+ * resident at once: chain blocks x n_splits must not exceed it for the
+ * one-launch trajectory (the caller sizes n_splits with it); 0: unsupported. */
+int zshmc_trajectory_capacity(int64_t width, int kind, int* n_workgroups);
 
 /* ------------------------------------------------------------------------
  * zshmc_model_kick_drift for latents that are LONG per chain and whose
@@ -621,7 +645,7 @@ int zshmc_model_kick_drift_seg(
  * skips the log and the kernel is 2-4 % faster), not both.
  * n_splits > 1 cuts the n_rows range into that many slices per chain block
  * (for chain counts that would otherwise leave compute units idle); the
- * partial sums go to `workspace` (n_splits * n_chains * (n_features + 1)
+ * partial sums (n_splits <= 256) go to `workspace` (n_splits * n_chains * (n_features + 1)
  * floats) and are added in a fixed order, so the result is deterministic.
  */
 int zshmc_likelihood_plan(int64_t n_columns, int class_stride, int64_t* width,
@@ -738,7 +762,7 @@ int zshmc_gather_dot(const float* u, const float* v, const int32_t* select_u,
  *   g_out[k, e] = d log_lik[k] / d d[k, e]   (or NULL) -- what
  *                zshmc_gather_dot_grad scatters into the latent's gradient.
  * obs [obs_rows, n_pairs] with obs_rows 1 (shared by the chains) or n_chains.
- * Per-block partial sums go to `workspace`
+ * Per-block partial sums (n_splits <= 256) go to `workspace`
  * (zshmc_gather_dot_normal_workspace(n_chains, n_pairs) floats) and are added
  * per chain in block order: deterministic, no atomics. */
 int64_t zshmc_gather_dot_normal_workspace(int64_t n_chains, int64_t n_pairs);

@@ -187,8 +187,11 @@ def test_run_many_equals_a_loop_of_runs(env, which, adaptive):
     a, b = out
     assert a['t'] == b['t'] == 18
     assert b['calls'].count('zshmc_hmc_model_run') >= 2
-    # the block replaces the per-launch calls of the transitions it covers
-    assert len(b['calls']) < len(a['calls']) / 2
+    # the block replaces the per-transition calls of the transitions it
+    # covers (a single run is itself ONE call for the transition --
+    # zshmc_hmc_model_transition -- plus its statistics and update)
+    assert len(b['calls']) < len(a['calls'])
+    assert a['calls'].count('zshmc_hmc_model_transition') >= 10
     for k in a['q']:
         assert torch.equal(a['q'][k], b['q'][k]), k
     for f in a['info']:
@@ -286,6 +289,8 @@ def test_start_evaluation_is_carried_over(env, which):
         op, info = hmc.sample(build(), observed, q)
         assert hmc.plan_kind == kind, hmc.plan_reason
         hmc._plan.carry_start = mode.startswith('carry')
+        # (count the launches of the Python loop, not one C call per transition)
+        hmc._plan.c_transition = False
         calls, real = [], _capi.call
 
         def spy(name, *a):
@@ -356,3 +361,123 @@ def test_start_evaluation_is_carried_over(env, which):
         for key in ('ewmv_mean', 'ewmv_var', 'mass'):
             for x, y in zip(ref['state'][key], got['state'][key]):
                 assert torch.equal(x, y), (mode, key)
+
+
+# -- the one-launch trajectory (csrc/hmc_model_traj.hip) -----------------------
+def _estep(zs, torch, dev, n_chains=1, n_docs=100, K=100, V=1300):
+    """The E-step of examples/topic_models/lntm_mcem.py:62-70,157-182 at its
+    minibatch shape (one chain, 100 documents, K = 100; a vocabulary long
+    enough for several row-range slices)."""
+    return _lntm(zs, torch, dev, n_chains=n_chains, n_docs=n_docs, K=K, V=V)
+
+
+def _blr_long(zs, torch, dev):
+    """Few chains, many data rows: chain blocks x slices on one launch."""
+    g = torch.Generator(device=dev).manual_seed(11)
+    N, D, C = 5000, 200, 70
+    X = torch.randn(N, D, device=dev, generator=g)
+    y = (torch.rand(N, device=dev, generator=g) < 0.5).float()
+    zero = torch.zeros(D, device=dev)
+
+    @zs.meta_bayesian_net()
+    def model():
+        bn = zs.BayesianNet()
+        w = bn.normal('w', zero, std=1., n_samples=C, group_ndims=1)
+        bn.bernoulli('y', w.tensor @ X.t(), group_ndims=1, dtype=torch.float32)
+        return bn
+    return model, {'y': y}, lambda: {'w': torch.zeros(C, D, device=dev)}, \
+        'linear_bernoulli'
+
+
+TRAJ_MODELS = {'estep': _estep, 'blr_long': _blr_long, 'blr': _blr,
+               'blr3': _blr3, 'lntm': _lntm}
+
+
+@pytest.mark.parametrize('which', sorted(TRAJ_MODELS))
+def test_one_launch_trajectory_is_bit_identical_to_a_launch_per_trip(env, which):
+    """HMC(one_launch_trajectory=True): the L + 1 trips from one cooperative
+    launch with grid barriers against one launch per likelihood evaluation /
+    step -- the same device code in the same order (csrc/lb_body.h,
+    csrc/model_step.h), so every latent, HMCInfo field, the step size and the
+    mass are identical BIT FOR BIT; through sample_op.run and run_many, with
+    the step size and the mass adapting, held, and with the start evaluation
+    carried or not."""
+    zs, torch, dev = env
+    from zhusuan_amd import _capi
+    build, observed, latents, kind = TRAJ_MODELS[which](zs, torch, dev)
+    out = {}
+    for one, reuse, block in ((True, True, False), (False, True, False),
+                              (True, True, True), (True, False, False),
+                              (False, False, True)):
+        f_ss, f_m = zs.placeholder(bool), zs.placeholder(bool)
+        hmc = zs.HMC(step_size=0.02, n_leapfrogs=5, seed=21,
+                     adapt_step_size=f_ss, adapt_mass=f_m, mass_collect_iters=3,
+                     target_acceptance_rate=0.7, one_launch_trajectory=one,
+                     reuse_start_evaluation=reuse)
+        q = latents()
+        op, info = hmc.sample(build(), observed, q)
+        assert hmc.plan_kind == kind, hmc.plan_reason
+        calls, real = [], _capi.call
+
+        def spy(name, *a):
+            calls.append(name)
+            return real(name, *a)
+        _capi.call = spy
+        try:
+            for n, feed in ((6, {f_ss: True, f_m: True}),
+                            (4, {f_ss: False, f_m: False})):
+                if block:
+                    op.run_many(n, feed_dict=feed)
+                else:
+                    for _ in range(n):
+                        op.run(feed_dict=feed)
+        finally:
+            _capi.call = real
+        hmc.check_numerics()
+        assert bool(hmc._plan.traj_capacity > 0) == one
+        st = hmc.get_state()
+        out[(one, reuse, block)] = (
+            {k: v.cpu().numpy() for k, v in q.items()},
+            {f: getattr(info, f).cpu().numpy() for f in (
+                'acceptance_rate', 'orig_hamiltonian', 'hamiltonian',
+                'orig_log_prob', 'log_prob')},
+            float(info.updated_step_size.item()),
+            [m.cpu().numpy() for m in hmc._plan.mass], st)
+    ref = out[(False, True, False)]
+    for key, got in out.items():
+        for k in ref[0]:
+            np.testing.assert_array_equal(got[0][k], ref[0][k], err_msg=str(key))
+        for f in ref[1]:
+            np.testing.assert_array_equal(got[1][f], ref[1][f],
+                                          err_msg='%s %s' % (key, f))
+        assert got[2] == ref[2], key
+        for a, b in zip(got[3], ref[3]):
+            np.testing.assert_array_equal(a, b)
+    a = float(ref[1]['acceptance_rate'].mean())
+    assert 0.05 < a <= 1.0, a
+
+
+def test_estep_transition_time(env):
+    """The E-step shape of lntm_mcem.py (100 documents x K = 100 x V = 12 419,
+    L = 20): wall time per transition with and without the one-launch
+    trajectory (printed: profiles/r05k_* has the numbers and why the grid
+    barriers lose to kernel boundaries on this chip)."""
+    import time
+    zs, torch, dev = env
+    build, observed, latents, kind = _lntm(zs, torch, dev, n_chains=1,
+                                           n_docs=100, K=100, V=12419)
+    ms = {}
+    for one in (False, True):
+        hmc = zs.HMC(step_size=0.05, n_leapfrogs=20, seed=5,
+                     one_launch_trajectory=one)
+        op, info = hmc.sample(build(), observed, latents())
+        op.run_many(5)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        op.run_many(40)
+        torch.cuda.synchronize()
+        ms[one] = (time.perf_counter() - t0) / 40 * 1e3
+        hmc.check_numerics()
+    print('E-step transition: launch per trip %.3f ms, one launch %.3f ms' % (
+        ms[False], ms[True]))
+    assert ms[False] < 1.0          # (1.06 ms with 32 slices and the serial reduce)

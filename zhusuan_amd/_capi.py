@@ -68,7 +68,7 @@ class ModelPlan(Structure):
         ('operand', c_void_p), ('grad', c_void_p), ('ll', c_void_p),
         ('lik_rows', c_int64), ('width', c_int64),
         ('grad_start', c_void_p), ('ll_start', c_void_p),
-        ('start_valid', c_int32), ('start_pad', c_int32),
+        ('start_valid', c_int32), ('one_launch', c_int32),
         ('inner', c_void_p), ('n_inner', c_int64), ('inner_image', c_void_p),
         ('obs', c_void_p), ('obs_rows', c_int64), ('obs_stride', c_int64),
         ('split_ws', c_void_p),
@@ -96,7 +96,7 @@ class ModelPlan(Structure):
         ('ewmv_var', c_void_p * MAX_LATENTS),
         ('colsum', c_void_p * MAX_LATENTS),
         ('comm_buf', c_void_p), ('comm_words', c_int64),
-        ('mass_ws', c_void_p)]
+        ('mass_ws', c_void_p), ('traj_sync', c_void_p)]
 
 
 BCAST_FULL = 0
@@ -114,6 +114,8 @@ PROTOTYPES = {
     'zshmc_zero': (c_int, [_p, c_int64, _p]),
     'zshmc_fused_max_n_data': (c_int64, []),
     'zshmc_fused_kernel_name': (c_char_p, [c_int64, c_int, c_int]),
+    'zshmc_hmc_model_transition': (c_int, [_p, c_uint32, c_float, _p]),
+    'zshmc_trajectory_capacity': (c_int, [c_int64, c_int, _p]),
     'zshmc_linear_multinomial_log_lik': (c_int, [
         _p, _p, _p, c_int64, c_int64, c_int64, c_int64, c_int64, _p, _p, c_int,
         _p, _p]),

@@ -616,7 +616,13 @@ def _row_splits(n_blocks_rows, n_inner, device, block=64):
     cus = torch.cuda.get_device_properties(device).multi_processor_count
     if n_wg >= cus:
         return 1
-    return max(1, min(32, (2 * cus) // n_wg, (n_inner + 255) // 256))
+    # Round 5 (profiles/r05k_estep_kernel_trace.txt): at the E-step's shape a
+    # transition is NOT launch-bound -- its 32-slice likelihood launches are
+    # 36 us each, six 64-row tiles on the critical path of every workgroup,
+    # and the one-thread-per-element serial reduction of the partials 9 us.
+    # With the partials added eight loads at a time (sum_parts8) finer slices
+    # pay: two tiles (128 rows) per slice, about two workgroups per CU.
+    return max(1, min(256, (2 * cus) // n_wg, (n_inner + 127) // 128))
 
 
 class LinearBernoulliLogLik(_Function):

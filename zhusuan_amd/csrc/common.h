@@ -133,6 +133,32 @@ __device__ __forceinline__ void wave_total4_swap(float& a, float& b, float& c,
   d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 63));
 }
 
+// Sum of the S partials p[0], p[stride], p[2 stride], ... in a FIXED order
+// with eight loads in flight: partial s goes to accumulator s % 8 (in order
+// of s), the accumulators are folded ((0+1)+(2+3))+((4+5)+(6+7)).  The one
+// reduction of the row-range partials of a split likelihood launch
+// (lb_reduce_splits_kernel, and csrc/model_step.h where the step reads the
+// partials itself): deterministic, and the same bits wherever it runs.
+template <typename T>
+__device__ __forceinline__ T sum_parts8(const T* __restrict__ p, int64_t stride,
+                                        int S) {
+  T a[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) a[k] = T{};
+  int s = 0;
+  for (; s + 8 <= S; s += 8) {
+    T v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = p[(int64_t)(s + k) * stride];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] += v[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    if (s + k < S) a[k] += p[(int64_t)(s + k) * stride];
+  return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+}
+
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

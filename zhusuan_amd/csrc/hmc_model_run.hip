@@ -23,6 +23,13 @@
 
 using namespace zshmc;
 
+namespace zshmc {
+// csrc/hmc_model_traj.hip: the trips of a transition from one cooperative launch
+int trajectory_grid(const zshmc_model_plan& m, int* gx, int* doc_major);
+int trajectory_launch(const zshmc_model_plan& m, float lik_scale,
+                      bool start_valid, int gx, int doc_major, void* stream);
+}  // namespace zshmc
+
 namespace {
 
 __global__ void ais_accumulate_kernel(float* __restrict__ log_w,
@@ -134,6 +141,15 @@ int transition(const zshmc_model_plan& m, uint32_t t, float lik_scale,
                                m.use_mass ? m.latent_mass[k] : nullptr,
                                m.n_chains, m.latent_size[k], m.chain_offset,
                                m.seed, t, (uint32_t)k, m.kin_old, s));
+  // small problems: the L + 1 trips from ONE cooperative launch (the same
+  // device code in the same order, csrc/hmc_model_traj.hip)
+  int traj_gx = 0, traj_dm = 0;
+  const bool one_launch = m.traj_sync && trajectory_grid(m, &traj_gx, &traj_dm);
+  if (one_launch) {
+    ZS_TRY(zshmc_zero(m.kin_new, 4 * m.n_chains, s));
+    ZS_TRY(trajectory_launch(m, lik_scale, carry && start_valid, traj_gx,
+                             traj_dm, s));
+  } else {
   // operand(q), then likelihood + gradient at q -- unless the start buffers
   // hold them already (the previous transition's, selected by its MH test)
   if (!(carry && start_valid)) {
@@ -161,6 +177,7 @@ int transition(const zshmc_model_plan& m, uint32_t t, float lik_scale,
     ZS_TRY(step(m, m.grad, m.ll, last ? 0.5f : 1.f, last ? 0.f : 1.f, lik_scale,
                 last ? m.lp_new : nullptr, last ? m.kin_new : nullptr, s));
   }
+  }  // launch per trip
   ZS_TRY(zshmc_mh_accept(m.lp_old, m.lp_new, m.kin_old, m.kin_new, m.n_chains,
                          m.chain_offset, m.seed, t, m.acceptance_rate,
                          m.orig_hamiltonian, m.hamiltonian, m.log_prob,
@@ -262,5 +279,49 @@ extern "C" int zshmc_hmc_model_run(const zshmc_model_plan* plan,
       ZS_LAUNCH_CHECK("ais_accumulate_kernel launch");
     }
   }
+  return ZSHMC_OK;
+}
+
+extern "C" int zshmc_hmc_model_transition(const zshmc_model_plan* plan,
+                                          uint32_t iteration, float lik_scale,
+                                          void* stream) {
+  ZS_REQUIRE(plan, "zshmc_hmc_model_transition: null plan");
+  const zshmc_model_plan& m = *plan;
+  ZS_REQUIRE(m.n_latents >= 1 && m.n_latents <= ZSHMC_MAX_LATENTS &&
+                 m.n_chains > 0 && m.n_leapfrogs >= 0 &&
+                 !m.grad_start == !m.ll_start && m.lik_rows % m.n_chains == 0,
+             "zshmc_hmc_model_transition: bad plan");
+  return transition(m, iteration, lik_scale, m.start_valid != 0, stream);
+}
+
+extern "C" int zshmc_trajectory_capacity(int64_t width, int kind,
+                                         int* n_workgroups) {
+  ZS_REQUIRE(n_workgroups, "zshmc_trajectory_capacity: null pointer");
+  zshmc_model_plan m = {};
+  m.kind = kind;
+  m.width = width;
+  m.n_chains = 1;
+  m.obs_rows = 1;
+  m.n_leapfrogs = 1;
+  m.n_splits = 1;
+  m.one_launch = 1;
+  int gx = 0, dm = 0;
+  *n_workgroups = 0;
+  // (the largest grid trajectory_grid accepts: probe by doubling)
+  int lo = 0;
+  for (int64_t c = 1; c <= 4096; c *= 2) {
+    m.n_chains = c * 64;
+    if (!trajectory_grid(m, &gx, &dm)) break;
+    lo = (int)c;
+  }
+  if (lo) {
+    int hi = lo * 2;   // first power of two that failed (or 8192)
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) / 2;
+      m.n_chains = (int64_t)mid * 64;
+      if (trajectory_grid(m, &gx, &dm)) lo = mid; else hi = mid;
+    }
+  }
+  *n_workgroups = lo;
   return ZSHMC_OK;
 }

@@ -484,26 +484,10 @@ __global__ __launch_bounds__(256, D == 256 ? 2 : 1) void linear_bernoulli_wide_k
   }
 }
 
-// out[c(, f)] = sum over the S row-range partials written by a split launch
-__global__ __launch_bounds__(256) void lb_wide_reduce_splits_kernel(
-    const float* __restrict__ ws, int64_t C, int64_t ldw, int S,
-    float* __restrict__ ll, float* __restrict__ gW) {
-  const int64_t n_ll = C, n_g = gW ? C * ldw : 0;
-  const float* __restrict__ gpart = ws + (int64_t)S * C;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_ll + n_g;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    float acc = 0.f;
-    if (i < n_ll) {
-      if (!ll) continue;
-      for (int s = 0; s < S; ++s) acc += ws[(int64_t)s * C + i];
-      ll[i] = acc;
-    } else {
-      const int64_t j = i - n_ll;
-      for (int s = 0; s < S; ++s) acc += gpart[(int64_t)s * C * ldw + j];
-      gW[j] = acc;
-    }
-  }
-}
+// csrc/linear_bernoulli.hip: out[c(, f)] = the row-range partials of a split
+// launch added in a fixed order (sum_parts8, csrc/common.h)
+int lb_reduce_splits(const float* ws, int64_t C, int64_t ldw, int S, float* ll,
+                     float* gW, hipStream_t s);
 
 template <int D, int OP>
 static int launch_wide(const float* W, const float* X, const float* y,
@@ -557,12 +541,7 @@ static int launch_wide(const float* W, const float* X, const float* y,
                        cls_log2);
   ZS_LAUNCH_CHECK("linear_bernoulli_wide_kernel launch");
   if (S > 1) {
-    const int64_t n = C + (gW ? C * D : 0);
-    int64_t blocks = (n + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(lb_wide_reduce_splits_kernel, dim3((int)blocks),
-                       dim3(256), 0, s, workspace, C, (int64_t)D, S, ll, gW);
-    ZS_LAUNCH_CHECK("lb_wide_reduce_splits_kernel launch");
+    return lb_reduce_splits(workspace, C, (int64_t)D, S, ll, gW, s);
   }
   return ZSHMC_OK;
 }

@@ -893,8 +893,8 @@ extern "C" int zshmc_linear_bernoulli_log_lik_bf16x3(
                  (reinterpret_cast<uintptr_t>(X_image) & 15) == 0,
              "zshmc_linear_bernoulli_log_lik_bf16x3: W and the image must be "
              "16-byte aligned");
-  ZS_REQUIRE(n_splits >= 1 && n_splits <= 64 && (n_splits == 1 || workspace),
-             "zshmc_linear_bernoulli_log_lik_bf16x3: 1 <= n_splits <= 64 and a "
+  ZS_REQUIRE(n_splits >= 1 && n_splits <= 256 && (n_splits == 1 || workspace),
+             "zshmc_linear_bernoulli_log_lik_bf16x3: 1 <= n_splits <= 256 and a "
              "workspace of n_splits*n_chains*(n_features+1) floats when > 1");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const unsigned char* img = reinterpret_cast<const unsigned char*>(X_image);
@@ -931,8 +931,8 @@ extern "C" int zshmc_linear_multinomial_log_lik_bf16x3(
                  (reinterpret_cast<uintptr_t>(phi_image) & 15) == 0,
              "zshmc_linear_multinomial_log_lik_bf16x3: theta and the image "
              "must be 16-byte aligned");
-  ZS_REQUIRE(n_splits >= 1 && n_splits <= 64 && (n_splits == 1 || workspace),
-             "zshmc_linear_multinomial_log_lik_bf16x3: 1 <= n_splits <= 64 and "
+  ZS_REQUIRE(n_splits >= 1 && n_splits <= 256 && (n_splits == 1 || workspace),
+             "zshmc_linear_multinomial_log_lik_bf16x3: 1 <= n_splits <= 256 and "
              "a workspace of n_splits*n_rows*(n_topics+1) floats when > 1");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const unsigned char* img = reinterpret_cast<const unsigned char*>(phi_image);

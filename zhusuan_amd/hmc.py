@@ -240,6 +240,17 @@ class HMC(object):
     kernels exist -- Bernoulli / mixture-multinomial likelihoods of <= 256
     columns -- `hmc.likelihood_arithmetic_used` says which ran).
 
+    `one_launch_trajectory` (default False): native model plans whose
+    likelihood grid fits the device at once can run the L + 1 trips of a
+    transition inside ONE cooperative launch with grid-wide barriers
+    (csrc/hmc_model_traj.hip: the same device code in the same order,
+    bit-identical results).  Built for the sizes the reference's own loops
+    run at (lntm_mcem.py's E-step, AIS.run's 1 000 temperatures) -- and
+    measured SLOWER there (1.33 vs 1.06 ms per transition,
+    profiles/r05k_*): on this chip a dependent kernel boundary costs ~1.5 us
+    and a grid barrier 4-13 us; what a small transition costs is the length
+    of its kernels' critical paths, not their launches.
+
     The start evaluation (`reuse_start_evaluation`, native model plans).
     The reference re-evaluates the log-joint at the state a transition starts
     from on every `sess.run` (hmc.py:47-50).  With
@@ -265,13 +276,18 @@ class HMC(object):
                  target_acceptance_rate=0.8, gamma=0.05, t0=100, kappa=0.75,
                  adapt_mass=None, mass_collect_iters=10, mass_decay=0.99,
                  *, seed=None, sharding=None, native_plans=True,
-                 likelihood_arithmetic='fp32', reuse_start_evaluation=True):
+                 likelihood_arithmetic='fp32', reuse_start_evaluation=True,
+                 one_launch_trajectory=False):
         if likelihood_arithmetic not in ('fp32', 'bf16x3'):
             raise ValueError("likelihood_arithmetic must be 'fp32' or "
                              "'bf16x3', got %r" % (likelihood_arithmetic,))
         self.likelihood_arithmetic = likelihood_arithmetic
         # see the class docstring ("The start evaluation")
         self.reuse_start_evaluation = bool(reuse_start_evaluation)
+        # native model plans whose likelihood grid fits the device at once run
+        # the L + 1 trips of a transition from ONE cooperative launch
+        # (csrc/hmc_model_traj.hip; bit-identical to a launch per trip)
+        self.one_launch_trajectory = bool(one_launch_trajectory)
         self._init_step_size_value = float(step_size)
         self.n_leapfrogs = int(n_leapfrogs)
         self.target_acceptance_rate = float(target_acceptance_rate)
@@ -712,6 +728,14 @@ class HMC(object):
             torch.cuda.current_stream().synchronize()
         bad = int(flags.item()) != 0
         self._pending_check = False
+        sync_words = getattr(plan, 'traj_sync', None)
+        if sync_words is not None and int(sync_words[2].item()) != 0:
+            sync_words[2] = 0
+            raise RuntimeError(
+                "zhusuan_amd: a grid barrier of the one-launch trajectory "
+                "kernel timed out (its workgroups were not resident at once);"
+                " the results of that run are invalid -- construct the "
+                "sampler with one_launch_trajectory=False")
         if bad:
             plan.flags.zero_()
             raise InvalidArgumentError(OLD_LOG_PROB_MSG)
@@ -1441,6 +1465,20 @@ class _DenseLikelihoodPlan(_PlanBase):
         self._in_search = False
         self._src = None
         self._ws = None
+        # the one-launch trajectory: grid barrier words [arrivals, generation,
+        # fault, -]; how many workgroups of this kernel fit the device at once
+        # (False: the launch loop below, from Python -- what a transition
+        # behind a step-size search runs, and what the tests count calls of)
+        self.c_transition = True
+        self.traj_sync = torch.zeros(4, dtype=torch.int32, device=device)
+        self.traj_capacity = 0
+        if hmc.one_launch_trajectory and kind in (
+                'linear_bernoulli', 'mixture_multinomial') and \
+                self.width <= 256:
+            cap = ctypes.c_int(0)
+            _capi.call('zshmc_trajectory_capacity', self.width,
+                       _capi.PLAN_KINDS[kind], ctypes.addressof(cap))
+            self.traj_capacity = int(cap.value)
         # multiplies the likelihood term (log-density and gradient): 1 for the
         # joint; AIS installs its temperature (evaluation.py:101-103)
         self.lik_scale = lambda: 1.0
@@ -1518,6 +1556,11 @@ class _DenseLikelihoodPlan(_PlanBase):
             self.block = ops.likelihood_plan(self.width)[1]
         R = self.lik_rows
         self.splits = ops._row_splits(R, n_inner, self.device, self.block)
+        # (chain blocks x slices resident at once where the chain blocks
+        # alone are: the trips then run from one cooperative launch)
+        n_wg = (R + self.block - 1) // self.block
+        if self.inner_image is None and 0 < n_wg <= self.traj_capacity:
+            self.splits = max(1, min(self.splits, self.traj_capacity // n_wg))
         need = self.splits * R * (self.width + 1) if self.splits > 1 else 0
         if need and (self._ws is None or self._ws.numel() < need):
             self._ws = torch.empty(need, dtype=torch.float32,
@@ -1913,6 +1956,8 @@ class _DenseLikelihoodPlan(_PlanBase):
             d.grad_start, d.ll_start = self.grad0.data_ptr(), \
                 self.ll0.data_ptr()
             d.start_valid = int(self._start_is_valid())
+        d.one_launch = int(self.traj_capacity > 0)
+        d.traj_sync = self.traj_sync.data_ptr()
         d.split_ws = c.ptr(self._ws)
         if self.segmented:
             d.seg_len, d.groups = self.seg_len, self.stride
@@ -2010,6 +2055,19 @@ class _DenseLikelihoodPlan(_PlanBase):
         self.last_t = t
         L = self.hmc.n_leapfrogs
         q, p = self.q_new, self.p
+        if eps_host is None and not self._in_search and self.c_transition \
+                and len(self.q) <= _capi.MAX_LATENTS:
+            # the same sequence on the other side of the C-ABI (one foreign
+            # call instead of ~2 L + 8; small problems: the L + 1 trips from
+            # one cooperative launch) -- bit-identical
+            d = self._descriptor()
+            self._start_valid = False
+            _capi.call('zshmc_hmc_model_transition', ctypes.byref(d),
+                       t & 0xFFFFFFFF, float(self.lik_scale()), stream)
+            self._own_write()
+            if self.carry_start:
+                self._mark_start()
+            return
         # (behind a step-size search: same q, same p0 -- Appendix B 11 -- and
         # the start evaluation is still in its buffers)
         self._load_state(stream)
