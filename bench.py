@@ -202,6 +202,7 @@ def cpu_baseline_parallel(n_data, n_leapfrogs, budget_s):
 
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 MFMA, MI355X_MICROARCH.md
+L2_PEAK_GBPS = 34500.0         # aggregate L2, MI355X_MICROARCH.md
 EXTRA_TIMEOUT_S = 420          # N > 1: budget of the sharded configs[4] extra
 TUNED_START_NOTE = (
     "timed AFTER the reference's dual-averaging start-up transient (mu = "
@@ -698,9 +699,17 @@ def extra_pmf(torch, zs, dev, n_particles=8, n_users=6040, n_items=3706,
         torch, hmc, op, info, {}, n_warm, n_timed, torch.cuda.synchronize)
     ms = elapsed / n_timed * 1e3
     kern_ms = kern_ms['ll_grad']     # (this plan's launch always forms both)
-    # rating terms + their scatter: per (particle, pair) two factor rows read
-    # twice (forward, scatter) + the residual written and read
-    gathered = n_particles * n_pairs * (3.0 * n_factors * 4 + 8 + 8)
+    # Algorithmic bytes of one evaluation (likelihood + gradient): per
+    # (particle, pair) ONE gathered row of the other table (4 D bytes: the
+    # fused kernel uses it for the dot product and for the scatter), its index
+    # and rating (8 bytes, shared by the particles of a wave), plus the latent
+    # table read and its gradient written once.  The tables (10 MB) are L2 /
+    # Infinity-Cache resident: the bound is the L2 gather rate, not HBM.
+    fused = bool(getattr(hmc._plan, 'gd_fused', False))
+    rows = (1.0 if fused else 3.0) * n_factors * 4
+    gathered = n_particles * n_pairs * rows + n_pairs * 8.0 + \
+        2.0 * n_particles * n_users * n_factors * 4
+    ach = gathered / (kern_ms * 1e-3) / 1e9
     return {
         'workload': 'beyond BASELINE.json: the rating model of pmf_hmc.py at '
                     'the MovieLens-1M shape (%d x %d, %d ratings, %d '
@@ -713,15 +722,70 @@ def extra_pmf(torch, zs, dev, n_particles=8, n_users=6040, n_items=3706,
         'unit': 'chain-leapfrog-steps/s',
         'mean_acceptance': acc,
         'roofline': {
-            'bound': 'hbm', 'unit': 'GB/s', 'peak': HBM_PEAK_GBPS,
-            'kernel': 'gather_dot_normal_lik_kernel + gather_dot_grad_kernel',
-            'kernel_ms': kern_ms, 'achieved': gathered / (kern_ms * 1e-3) / 1e9,
-            'frac': gathered / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            'bound': 'l2-gather', 'unit': 'GB/s', 'peak': L2_PEAK_GBPS,
+            'peak_is': 'aggregate L2 rate of MI355X_MICROARCH.md (34.5 TB/s); '
+                       'the factor tables are cache-resident, HBM sees ~80 MB',
+            'kernel': 'gd_fused_kernel (likelihood + gradient in one pass '
+                      'over the segmented CSR pair list)' if fused else
+                      'gather_dot_normal_lik_kernel + gather_dot_grad_kernel',
+            'kernel_ms': kern_ms, 'achieved': ach,
+            'frac': ach / L2_PEAK_GBPS,
             'traffic': None,
-            'note': 'gathered bytes (factor rows where they lie: the tables '
-                    'are L2 / Infinity-Cache resident, so this is a cache '
-                    'rate quoted against the HBM peak), not HBM traffic',
+            'algorithmic_bytes_per_evaluation': gathered,
+            'note': 'round 4 (two kernels, three gathers per pair): 0.811 ms '
+                    'per evaluation at this shape',
         },
+    }
+
+
+def extra_estep(torch, zs, dev, n_docs=100, n_topics=100, n_vocab=12419,
+                n_leapfrogs=20, n_timed=40):
+    """The sizes the reference's OWN loop runs: the E-step of
+    examples/topic_models/lntm_mcem.py:62-70,157-182 -- one chain, a minibatch
+    of 100 documents, K = 100 topics, L = 20 -- timed through sample_op.run_many
+    (one C call, zshmc_hmc_model_run).  Not launch-bound (profiles/
+    r05k_estep_kernel_trace.txt): a transition is the sum of its kernels'
+    critical paths, so the likelihood's row range is cut into ~100 slices."""
+    phi, x = lntm_problem(torch, dev, n_docs, n_topics, n_vocab)
+    mean = torch.zeros(n_docs, n_topics, device=dev)
+    logstd = torch.zeros(n_topics, device=dev)
+
+    @zs.meta_bayesian_net()
+    def lntm():
+        bn = zs.BayesianNet()
+        eta = bn.normal('eta', mean, logstd=logstd, n_samples=1, group_ndims=1)
+        theta = torch.softmax(eta.tensor, -1)
+        bn.unnormalized_multinomial(
+            'x', torch.log((theta.reshape(-1, n_topics) @ phi).reshape(
+                1, n_docs, n_vocab)), normalize_logits=False,
+            dtype=torch.float32)
+        return bn
+    m = lntm()
+    m.log_joint = lambda bn: bn.cond_log_prob('eta') + bn.cond_log_prob('x')
+    hmc = zs.HMC(step_size=0.05, n_leapfrogs=n_leapfrogs, seed=5)
+    eta = torch.zeros(1, n_docs, n_topics, device=dev)
+    op, info = hmc.sample(m, {'x': x}, {'eta': eta})
+    op.run_many(5)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    op.run_many(n_timed)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n_timed * 1e3
+    plan = hmc._plan
+    flop = 4.0 * n_docs * plan.width * n_vocab * n_leapfrogs
+    return {
+        'workload': 'the reference\'s own loop size: lntm_mcem.py E-step, 1 '
+                    'chain x %d documents, K=%d (kernel width %d), V=%d, L=%d, '
+                    'fixed step size' % (n_docs, n_topics, plan.width, n_vocab,
+                                         n_leapfrogs),
+        'plan': hmc.plan_kind, 'ms_per_step': ms, 'steps': n_timed,
+        'value': n_docs * n_leapfrogs / (ms * 1e-3),
+        'unit': '(chain, document)-leapfrog-steps/s',
+        'mean_acceptance': float(info.acceptance_rate.mean().item()),
+        'row_range_slices': int(plan.splits),
+        'note': 'latency-bound by its kernels\' critical paths, not by '
+                'launches or flops (%.2f TFLOP/s sustained); round 4: 1.2 ms, '
+                '32 slices' % (flop / (ms * 1e-3) / 1e12),
     }
 
 
@@ -1589,7 +1653,8 @@ def main():
                     (extra_wide_regression, {}),
                     (extra_wide_regression, {'n_feat': 299,
                                              'n_chains': 16384}),
-                    (extra_softmax_regression, {}), (extra_pmf, {}))
+                    (extra_softmax_regression, {}), (extra_pmf, {}),
+                    (extra_estep, {}))
         else:
             todo = ((lntm_workload, dict(
                 n_chains=args.lntm_chains_per_gpu,

@@ -551,6 +551,13 @@ typedef struct zshmc_model_plan {
    * and generation, and a fault word the kernel sets (and the caller checks
    * at its next synchronisation) should a barrier wait ever run out */
   void* traj_sync;
+  /* ABI 0.5.0, gathered dot: the pair list as SEGMENTS of <= 256 consecutive
+   * CSR slots of one latent row (zshmc_gather_dot_normal_lik_grad: likelihood
+   * and gradient in one pass); gd_seg_ptr NULL: the two-kernel form */
+  const int32_t *gd_seg_ptr, *gd_seg_row, *gd_seg_first, *gd_long_rows;
+  int64_t gd_n_seg, gd_n_long;
+  const int32_t* gd_idx_other_csr;
+  const float* gd_obs_csr;
 } zshmc_model_plan;
 
 /*   iteration_first   Philox iteration word of the first transition
@@ -746,6 +753,29 @@ int zshmc_categorical_sample(int32_t* out, const float* logits,
  * over a CSR view of the pair list: `order` lists the pair ids grouped by
  * own_index, `seg_ptr[i] .. seg_ptr[i+1]` is row i's slice of it
  * (n_rows + 1 offsets).  No atomics: deterministic. */
+/* ABI 0.5.0 -- the rating likelihood of pmf_hmc.py:26-31 AND its gradient
+ * w.r.t. the latent table in ONE pass (csrc/gather_dot.hip: gd_fused_kernel).
+ * The pair list arrives as a CSR view by latent row, cut into segments:
+ *   seg_ptr [n_segments + 1]  CSR slots of segment s: seg_ptr[s] .. seg_ptr[s+1]
+ *                             (<= 256 of them, all of latent row seg_row[s];
+ *                             consecutive segments are consecutive slots)
+ *   seg_row [n_segments], seg_first [n_latent] (a row's first segment; every
+ *   row has >= 1, rows without pairs an empty one), long_rows [n_long] (the
+ *   rows with more than one segment)
+ *   other_index_csr [n_pairs] the other table's row, obs_csr [obs_rows,
+ *   n_pairs] the rating, of CSR slot q
+ *   log_lik[k] = sum over pairs of log N(obs; sigmoid(u_i . v_j), exp(logstd))
+ *                + lp_const[k];  grad [n_chains, n_latent, n_dim]
+ *   n_dim <= 128, a multiple of 4; tables 16-byte aligned;
+ *   workspace: n_chains * n_segments * (n_dim + 1) floats.
+ * Deterministic (fixed summation order, no atomics). */
+int zshmc_gather_dot_normal_lik_grad(
+    const float* latent, const float* other, const int32_t* seg_ptr,
+    const int32_t* seg_row, const int32_t* seg_first, const int32_t* long_rows,
+    int64_t n_long, const int32_t* other_index_csr, const float* obs_csr,
+    int64_t obs_rows, float logstd, const float* lp_const, int64_t n_chains,
+    int64_t n_latent, int64_t n_other, int64_t n_pairs, int64_t n_segments,
+    int64_t n_dim, float* grad, float* log_lik, float* workspace, void* stream);
 int zshmc_gather_dot(const float* u, const float* v, const int32_t* select_u,
                      const int32_t* select_v, int64_t n_chains, int64_t n_u,
                      int64_t n_v, int64_t n_pairs, int64_t n_dim, float* out,

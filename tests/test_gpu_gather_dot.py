@@ -427,3 +427,75 @@ def test_native_gathered_dot_plan_with_fed_minibatches(env):
         hmc.sample(odd(), {'r': torch.zeros(3, device=dev)},
                    {'u': torch.zeros(K, 7, 5, device=dev)})
     assert hmc.plan_kind == 'generic' and '35' in hmc.plan_reason
+
+
+# -- likelihood + gradient in one pass (zshmc_gather_dot_normal_lik_grad) ------
+@pytest.mark.parametrize('K,n_lat,n_other,E,D,per_chain_obs', [
+    (8, 40, 30, 3000, 32, False),    # long rows: several 256-slot segments
+    (5, 17, 9, 200, 4, True),        # chains not a multiple of 8, tiny rows
+    (1, 300, 50, 1000, 36, False),   # two 32-float chunks, rows without pairs
+    (3, 10, 10, 2600, 128, False),   # widest rows, every row long
+    (8, 6, 5, 0, 32, False)])        # no pairs at all
+def test_fused_likelihood_and_gradient_match_float64(K, n_lat, n_other, E, D,
+                                                     per_chain_obs):
+    """pmf_hmc.py:26-31 and what tf.gradients (hmc.py:430-432) gives for the
+    latent table, from the one-pass kernel over the segmented CSR view."""
+    import torch
+    from zhusuan_amd import _capi, _ops
+    dev = torch.device('cuda', 0)
+    rng = np.random.RandomState(E + D)
+    u = (0.4 * rng.normal(size=(K, n_lat, D))).astype(np.float32)
+    v = (0.4 * rng.normal(size=(K, n_other, D))).astype(np.float32)
+    # skewed: a few latent rows own most pairs; some own none
+    su = np.minimum((rng.exponential(0.15, size=E) * n_lat).astype(np.int64),
+                    n_lat - 1)
+    sv = rng.randint(0, n_other, size=E)
+    r = rng.uniform(size=(K if per_chain_obs else 1, E)).astype(np.float32)
+    logstd = -0.7
+    lp_const = rng.normal(size=K).astype(np.float32)
+    ut, vt = torch.tensor(u, device=dev), torch.tensor(v, device=dev)
+    sut = torch.tensor(su, device=dev)
+    if E == 0:
+        seg = torch.zeros(n_lat + 1, dtype=torch.int32, device=dev)
+        order = torch.zeros(0, dtype=torch.long, device=dev)
+    else:
+        _, seg, order = _ops._pair_csr(sut, n_lat, 'test_fused')
+        order = order.long()
+    sp, sr, sf, lr = _ops._csr_segments(seg, E)
+    assert int(sr.numel()) >= n_lat
+    if E > 2000:
+        assert lr.numel() > 0               # some rows really are cut
+    idx_csr = torch.tensor(sv, device=dev, dtype=torch.int32)[order].contiguous()
+    obs_csr = torch.tensor(r, device=dev)[:, order].contiguous()
+    grad = torch.full((K, n_lat, D), float('nan'), device=dev)
+    ll = torch.full((K,), float('nan'), device=dev)
+    ws = torch.empty(K * int(sr.numel()) * (D + 1) + 4, device=dev)
+    for rep in range(2):
+        _capi.call('zshmc_gather_dot_normal_lik_grad', ut.data_ptr(),
+                   vt.data_ptr(), sp.data_ptr(), sr.data_ptr(), sf.data_ptr(),
+                   lr.data_ptr() if lr.numel() else None, lr.numel(),
+                   idx_csr.data_ptr() if E else None,
+                   obs_csr.data_ptr() if E else None, r.shape[0], logstd,
+                   torch.tensor(lp_const, device=dev).data_ptr(), K, n_lat,
+                   n_other, E, sr.numel(), D, grad.data_ptr(), ll.data_ptr(),
+                   ws.data_ptr(), _capi.current_stream())
+        torch.cuda.synchronize()
+        if rep == 0:
+            g0, l0 = grad.cpu().numpy().copy(), ll.cpu().numpy().copy()
+    np.testing.assert_array_equal(grad.cpu().numpy(), g0)     # bit-stable
+    np.testing.assert_array_equal(ll.cpu().numpy(), l0)
+    u64, v64 = u.astype(np.float64), v.astype(np.float64)
+    d = np.einsum('ked,ked->ke', u64[:, su], v64[:, sv]) if E else \
+        np.zeros((K, 0))
+    pred = 1 / (1 + np.exp(-d))
+    prec = np.exp(-2 * logstd)
+    diff = r.astype(np.float64) - pred
+    ll_ref = (-0.5 * np.log(2 * np.pi) - logstd - 0.5 * prec * diff ** 2
+              ).sum(1) + lp_const
+    g = diff * prec * pred * (1 - pred)
+    g_ref = np.zeros((K, n_lat, D))
+    for k in range(K):
+        np.add.at(g_ref[k], su, g[k][:, None] * v64[k, sv])
+    np.testing.assert_allclose(l0, ll_ref, rtol=2e-5, atol=2e-4 * max(E, 1) ** .5)
+    np.testing.assert_allclose(g0, g_ref, rtol=1e-4,
+                               atol=2e-5 * (np.abs(g_ref).max() + 1))

@@ -30,6 +30,26 @@ gw = torch.empty(C, D, device=dev)
 for ll_ptr in (ll.data_ptr(), ll.data_ptr(), None, None):
     _capi.call('zshmc_linear_bernoulli_log_lik', W.data_ptr(), X.data_ptr(),
                y.data_ptr(), C, N, D, ll_ptr, gw.data_ptr(), 1, None, s)
+# ... and the same launches on the bf16x3 kernels (csrc/linear_bf16x3.hip)
+import ctypes  # noqa: E402
+
+
+def image(Xp, width):
+    nb = ctypes.c_int64()
+    _capi.call('zshmc_bf16x3_image_bytes', Xp.shape[0], width,
+               ctypes.addressof(nb))
+    img = torch.empty(nb.value, dtype=torch.uint8, device=dev)
+    _capi.call('zshmc_bf16x3_split', Xp.data_ptr(), Xp.shape[0], width,
+               Xp.stride(0), img.data_ptr(), s)
+    return img
+
+
+img = image(X, D)
+for ll_ptr in (ll.data_ptr(), ll.data_ptr(), None, None):
+    _capi.call('zshmc_linear_bernoulli_log_lik_bf16x3', W.data_ptr(),
+               img.data_ptr(), y.data_ptr(), C, N, D, ll_ptr, gw.data_ptr(), 1,
+               None, s)
+del img
 torch.cuda.synchronize()
 print('config3 shape: C=%d N=%d D=%d; algorithmic bytes per launch: X %.3e '
       '(streamed once per 64-chain block: x%d = %.3e) + W, grad 2 x %.3e' % (
@@ -52,6 +72,11 @@ for ll_ptr in (ll.data_ptr(), ll.data_ptr(), None, None):
     _capi.call('zshmc_linear_multinomial_log_lik', theta.data_ptr(),
                phi_t.data_ptr(), xp.data_ptr(), xp.shape[0], stride, rows, V,
                K, ll_ptr, gt.data_ptr(), 1, None, s)
+img = image(phi_t, K)
+for ll_ptr in (ll.data_ptr(), ll.data_ptr(), None, None):
+    _capi.call('zshmc_linear_multinomial_log_lik_bf16x3', theta.data_ptr(),
+               img.data_ptr(), xp.data_ptr(), xp.shape[0], stride, rows, V, K,
+               ll_ptr, gt.data_ptr(), 1, None, s)
 torch.cuda.synchronize()
 print('config5 shape: rows=%d K=%d V=%d; algorithmic bytes per launch: theta + '
       'grad 2 x %.3e, phi^T %.3e (x%d row blocks = %.3e), counts gathered '

@@ -96,7 +96,11 @@ class ModelPlan(Structure):
         ('ewmv_var', c_void_p * MAX_LATENTS),
         ('colsum', c_void_p * MAX_LATENTS),
         ('comm_buf', c_void_p), ('comm_words', c_int64),
-        ('mass_ws', c_void_p), ('traj_sync', c_void_p)]
+        ('mass_ws', c_void_p), ('traj_sync', c_void_p),
+        ('gd_seg_ptr', c_void_p), ('gd_seg_row', c_void_p),
+        ('gd_seg_first', c_void_p), ('gd_long_rows', c_void_p),
+        ('gd_n_seg', c_int64), ('gd_n_long', c_int64),
+        ('gd_idx_other_csr', c_void_p), ('gd_obs_csr', c_void_p)]
 
 
 BCAST_FULL = 0
@@ -231,6 +235,9 @@ PROTOTYPES = {
     'zshmc_gather_dot_normal_lik': (c_int, [
         _p, _p, _p, _p, _p, c_int64, c_float, _p, c_int64, c_int64, c_int64,
         c_int64, c_int64, _p, _p, _p, _p]),
+    'zshmc_gather_dot_normal_lik_grad': (c_int, [
+        _p, _p, _p, _p, _p, _p, c_int64, _p, _p, c_int64, c_float, _p,
+        c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, _p, _p, _p, _p]),
     'zshmc_gather_dot_grad': (c_int, [
         _p, _p, _p, _p, _p, c_int64, c_int64, c_int64, c_int64, c_int64, _p,
         _p]),

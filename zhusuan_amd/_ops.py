@@ -217,6 +217,30 @@ def _pair_csr(index, n_rows, slot):
     return val
 
 
+GD_SEGMENT_PAIRS = 256      # csrc/gather_dot.hip: kGdSegPairs
+
+
+def _csr_segments(seg, n_pairs):
+    """The CSR row ranges `seg` [n_rows + 1] cut into segments of at most
+    GD_SEGMENT_PAIRS slots (zshmc_gather_dot_normal_lik_grad): (seg_ptr
+    [n_seg + 1], seg_row [n_seg], seg_first [n_rows], long_rows [n_long]),
+    every row with at least one (possibly empty) segment."""
+    counts = (seg[1:] - seg[:-1]).to(torch.int64)
+    n_rows = counts.numel()
+    nseg = torch.clamp((counts + GD_SEGMENT_PAIRS - 1) // GD_SEGMENT_PAIRS,
+                       min=1)
+    first = torch.cumsum(nseg, 0) - nseg
+    rows = torch.repeat_interleave(
+        torch.arange(n_rows, device=seg.device), nseg)
+    within = torch.arange(rows.numel(), device=seg.device) - first[rows]
+    start = seg[:-1].to(torch.int64)[rows] + GD_SEGMENT_PAIRS * within
+    i32 = torch.int32
+    seg_ptr = torch.cat([start, torch.tensor([n_pairs], device=seg.device)])
+    return (seg_ptr.to(i32).contiguous(), rows.to(i32).contiguous(),
+            first.to(i32).contiguous(),
+            torch.nonzero(nseg > 1).reshape(-1).to(i32).contiguous())
+
+
 class GatheredDot(_Function):
     """out[..., e] = sum_d u[..., su[e], d] * v[..., sv[e], d]
     (examples/probabilistic_matrix_factorization/pmf_hmc.py:26-28 without the

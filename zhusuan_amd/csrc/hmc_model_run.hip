@@ -87,6 +87,13 @@ int likelihood(const zshmc_model_plan& m, const float* q, bool want_ll,
           (int)m.groups, ll, grad_out, m.n_splits, ws, s);
     case ZSHMC_PLAN_GATHERED_DOT: {
       const bool lat_u = m.gd_latent_is_u != 0;
+      if (m.gd_seg_ptr)   // likelihood + gradient in one pass over the pairs
+        return zshmc_gather_dot_normal_lik_grad(
+            q, m.inner, m.gd_seg_ptr, m.gd_seg_row, m.gd_seg_first,
+            m.gd_long_rows, m.gd_n_long, m.gd_idx_other_csr, m.gd_obs_csr,
+            m.obs_rows, m.gd_logstd, m.gd_lp_const, m.n_chains, m.gd_n_latent,
+            m.n_inner, m.gd_n_pairs, m.gd_n_seg, m.gd_n_dim, grad_out, ll_out,
+            m.split_ws, s);
       ZS_TRY(zshmc_gather_dot_normal_lik(
           lat_u ? q : m.inner, lat_u ? m.inner : q,
           lat_u ? m.gd_idx_latent : m.gd_idx_other,

@@ -1619,6 +1619,22 @@ class _DenseLikelihoodPlan(_PlanBase):
         self.lik_logstd = math.log(sp_v) if how == 'std' else sp_v
         need = int(_capi.load().zshmc_gather_dot_normal_workspace(
             self.n_chains, E))
+        # likelihood + gradient in one pass over the pair list where the rows
+        # are <= 128 floats, a multiple of 4 (csrc/gather_dot.hip:
+        # gd_fused_kernel): the CSR view cut into segments, the other side's
+        # indices and the ratings in CSR order
+        self.gd_fused = D % 4 == 0 and D <= 128 and E > 0
+        if self.gd_fused:
+            key = (self.seg.data_ptr(), self.order.data_ptr(),
+                   self.idx_other.data_ptr(), self.idx_other._version)
+            if getattr(self, '_gd_seg_key', None) != key:
+                self._gd_seg = ops._csr_segments(self.seg, E)
+                self._gd_idx_csr = self.idx_other[self.order.long()].contiguous()
+                self._gd_seg_key = key
+            self._gd_obs_csr = _aligned16(self.obs.view(
+                self.obs_rows, E)[:, self.order.long()].contiguous())
+            n_seg = int(self._gd_seg[1].numel())
+            need = max(need, self.n_chains * n_seg * (D + 1))
         if self._ws is None or self._ws.numel() < max(need, 1):
             self._ws = torch.empty(max(need, 1), dtype=torch.float32,
                                    device=self.device)
@@ -1730,6 +1746,19 @@ class _DenseLikelihoodPlan(_PlanBase):
             # rating terms + d/d logit in one pass over the pairs, then the
             # deterministic scatter into the latent's rows
             lat_is_u = self.side == 'u'
+            if self.gd_fused:
+                sp, sr, sf, lr = self._gd_seg
+                _capi.call(
+                    'zshmc_gather_dot_normal_lik_grad', q.data_ptr(),
+                    self.other.data_ptr(), sp.data_ptr(), sr.data_ptr(),
+                    sf.data_ptr(), lr.data_ptr() if lr.numel() else None,
+                    lr.numel(), self._gd_idx_csr.data_ptr(),
+                    self._gd_obs_csr.data_ptr(), self.obs_rows,
+                    self.lik_logstd, self.lp_const.data_ptr(), self.n_chains,
+                    self.n_lat, self.n_other, self.n_pairs, sr.numel(),
+                    self.n_dim, grad.data_ptr(), ll.data_ptr(),
+                    self._ws.data_ptr(), stream)
+                return
             _capi.call(
                 'zshmc_gather_dot_normal_lik',
                 q.data_ptr() if lat_is_u else self.other.data_ptr(),
@@ -1973,6 +2002,14 @@ class _DenseLikelihoodPlan(_PlanBase):
             d.gd_n_dim, d.gd_logstd = self.n_dim, self.lik_logstd
             d.gd_lp_const = self.lp_const.data_ptr()
             d.gd_g_pairs = self.g_pairs.data_ptr()
+            if self.gd_fused:
+                sp, sr, sf, lr = self._gd_seg
+                d.gd_seg_ptr, d.gd_seg_row = sp.data_ptr(), sr.data_ptr()
+                d.gd_seg_first = sf.data_ptr()
+                d.gd_long_rows = lr.data_ptr() if lr.numel() else None
+                d.gd_n_seg, d.gd_n_long = sr.numel(), lr.numel()
+                d.gd_idx_other_csr = self._gd_idx_csr.data_ptr()
+                d.gd_obs_csr = self._gd_obs_csr.data_ptr()
         else:
             d.inner, d.n_inner = self.inner.data_ptr(), self.inner.shape[0]
             d.inner_image = c.ptr(self.inner_image)
