@@ -282,6 +282,19 @@ def _time_transitions(torch, hmc, op, info, feed, n_warm, n_timed, barrier):
     return elapsed, kern, acc
 
 
+def _recorded_mfma_traffic(key):
+    """HBM bytes per launch of a likelihood kernel at its FULL BASELINE shape
+    from the recorded rocprofv3 PMC passes (profiles/pmc_traffic_mfma.json;
+    bench.py cannot run the profiler on itself): (bytes, source) or (None,
+    None).  Keys: 'bernoulli grad-only', 'multinomial bf16x3 grad-only', ..."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_traffic_mfma.json')
+    try:
+        rec = json.load(open(path))
+        return rec['hbm_bytes_per_launch'][key], rec['source']
+    except Exception:                                    # noqa: BLE001
+        return None, None
+
+
 def _lik_kernel_name(width, block):
     """The likelihood kernel the library dispatches for a plan's width and
     chain block (zshmc_likelihood_plan)."""
@@ -489,6 +502,9 @@ def extra_config3(torch, zs, dev, n_rows=1000000, n_chains=32768, n_feat=256,
     roof32 = _mfma_roofline(
         _lik_kernel_name(hmc._plan.width, hmc._plan.block), kern_ms, flop_eval,
         n_leapfrogs, ms)
+    if (n_rows, n_chains, n_feat) == (1000000, 32768, 256):
+        roof32['traffic'], roof32['traffic_source'] = _recorded_mfma_traffic(
+            'bernoulli grad-only')
     # the same chains, state and step size with the likelihood on the bf16
     # matrix cores (HMC(likelihood_arithmetic='bf16x3'))
     del hmc, op, info
@@ -510,6 +526,9 @@ def extra_config3(torch, zs, dev, n_rows=1000000, n_chains=32768, n_feat=256,
         'roofline': _b3_roofline(hmc3._plan.width, kern3, flop_eval,
                                  n_leapfrogs, ms3),
     }
+    if (n_rows, n_chains, n_feat) == (1000000, 32768, 256):
+        b3['roofline']['traffic'], b3['roofline']['traffic_source'] = \
+            _recorded_mfma_traffic('bernoulli bf16x3 grad-only')
     del hmc3, op3, info3, w3
     gc.collect()
     return {
@@ -880,6 +899,10 @@ def lntm_workload(torch, zs, dev, n_chains, sharding=None, dist=None,
         _lik_kernel_name(hmc._plan.width, hmc._plan.block) + ' (multinomial mode)',
         kern_ms, flop_eval, n_leapfrogs, ms)
     roof['note'] = 'per GPU (rank 0): one launch covers this rank\'s rows'
+    full5 = (n_chains, n_docs, n_topics, n_vocab) == (8192, 5000, 128, 12419)
+    if full5:
+        roof['traffic'], roof['traffic_source'] = _recorded_mfma_traffic(
+            'multinomial grad-only')
     plan_kind, step_size = hmc.plan_kind, float(info.updated_step_size.item())
     rccl_ranks = 0 if sharding is None else sharding.rccl_ranks
     b3 = None
@@ -908,6 +931,9 @@ def lntm_workload(torch, zs, dev, n_chains, sharding=None, dist=None,
                                      n_leapfrogs, ms3)
             if hmc3.likelihood_arithmetic_used == 'bf16x3' else None,
         }
+        if full5 and b3['roofline']:
+            b3['roofline']['traffic'], b3['roofline']['traffic_source'] = \
+                _recorded_mfma_traffic('multinomial bf16x3 grad-only')
         del hmc3, op3, info3, eta3
         gc.collect()
         torch.cuda.empty_cache()
@@ -1212,19 +1238,19 @@ def main():
     # The host is ~4x ahead of the device (0.025 ms per enqueue against a
     # 0.095 ms kernel), but a full collection of CPython's cyclic GC over a
     # process that has torch loaded stops it for ~40 ms -- 400 transitions'
-    # worth; tools/first_run_probe.py shows exactly one in the first few
+    # worth; tools/archive/first_run_probe.py shows exactly one in the first few
     # hundred runs of a process (the per-run model re-evaluation allocates
     # containers).  Timed regions run with the collector parked, as timeit
     # does.
     # Parked BEFORE the settle launches: the collection itself takes tens of
     # milliseconds, and a GPU left idle that long starts the timed region
-    # with its clocks down (tools/startup_probe.py: 106 us per launch over
+    # with its clocks down (tools/archive/startup_probe.py: 106 us per launch over
     # the 40 launches that follow a 20 ms pause, 93 after none).
     gc.collect()
     gc.freeze()
     gc.disable()
     # settle: the chip's clocks move for the first ~70 launches of a process
-    # (per-launch durations 77 -> 130 -> 108 us in profiles/r01i_rocprofv3_
+    # (per-launch durations 77 -> 130 -> 108 us in profiles/archive/r01i_rocprofv3_
     # summary.txt); keep that transient out of the timed region whatever
     # --warmup is
     # (run_many: the launch loop runs inside libzshmc.so -- one call for the

@@ -1,14 +1,14 @@
 #!/usr/bin/env python
 """configs[2] and the softmax-regression extra of bench.py alone (what the
 start-evaluation carry changes: ms per transition), without the headline.
-    python tools/carry_probe.py [config3|softmax|wide|all]"""
+    python tools/archive/carry_probe.py [config3|softmax|wide|all]"""
 import json
 import os
 import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench  # noqa: E402
 import zhusuan_amd as zs  # noqa: E402
 

@@ -3,7 +3,7 @@
 // execute in the XCD's own L2 (no scope bits) or at the device's coherence
 // point (agent scope)?  The question behind a two-level reduction of the mass
 // statistics (docs/LABNOTES.md section 10).
-// Build: hipcc --offload-arch=gfx950 -O3 tools/l2_atomic_probe.hip -o build/l2_atomic_probe
+// Build: hipcc --offload-arch=gfx950 -O3 tools/archive/l2_atomic_probe.hip -o build/l2_atomic_probe
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>

@@ -4,14 +4,14 @@ feature-split kernel; since round 4 the 16-chain-block kernel of
 csrc/linear_bernoulli_mid.hip) and 1024 (csrc/linear_bernoulli_wide.hip) --
 timed against the 256-wide kernel at the same flop count, and checked against
 a float64 reference on a sub-block.
-  python tools/lb_wide_bench.py [n_chains] [n_rows]"""
+  python tools/archive/lb_wide_bench.py [n_chains] [n_rows]"""
 import json
 import os
 import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from zhusuan_amd import _capi, _ops  # noqa: E402
 
 C = int(sys.argv[1]) if len(sys.argv) > 1 else 8192

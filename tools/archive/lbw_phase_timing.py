@@ -2,7 +2,7 @@
 """Debug: per-phase shader-clock breakdown of the feature-split likelihood
 kernel (csrc/linear_bernoulli_wide.hip built with -DZS_LBW_TIMING: every wave
 of block 0 overwrites the first gradient words with its accumulated clocks).
-Usage: python tools/lbw_phase_timing.py lib.so [D] [C] [N]"""
+Usage: python tools/archive/lbw_phase_timing.py lib.so [D] [C] [N]"""
 import ctypes
 import sys
 import torch

@@ -2,7 +2,7 @@
 """Where the cost of a mass-adapting fused transition goes: host time per
 `sample_op.run` call (measured on a tiny problem, where the device is idle),
 wall time per transition at the headline shape, with both adaptation flags
-on / off.    python tools/mass_adapt_probe.py [n_chains] [n_data]"""
+on / off.    python tools/archive/mass_adapt_probe.py [n_chains] [n_data]"""
 import gc
 import os
 import sys
@@ -10,7 +10,7 @@ import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import zhusuan_amd as zs  # noqa: E402
 from zhusuan_amd import _capi  # noqa: E402
 

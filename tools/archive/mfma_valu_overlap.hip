@@ -3,7 +3,7 @@
 // loop: 8 independent-accumulator v_mfma_f32_32x32x2_f32 only; 32 VALU + 8
 // transcendental ops only; both interleaved (1 MFMA : 4 VALU : 1 trans).
 // overlap  => t(both) ~ max(t_mfma, t_valu);  none => t(both) ~ sum.
-// Build: hipcc --offload-arch=gfx950 -O3 tools/mfma_valu_overlap.hip -o build/mfma_valu_overlap
+// Build: hipcc --offload-arch=gfx950 -O3 tools/archive/mfma_valu_overlap.hip -o build/mfma_valu_overlap
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef float f16v __attribute__((ext_vector_type(16)));

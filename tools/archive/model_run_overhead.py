@@ -10,14 +10,14 @@ own loops run --
     300 held-out documents, L = 20 (lntm_mcem.py:208-219).
 Prints wall microseconds per transition (device work included: the queue is
 drained at both ends of each measurement) and the host-only enqueue time.
-    python tools/model_run_overhead.py"""
+    python tools/archive/model_run_overhead.py"""
 import os
 import sys
 import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import zhusuan_amd as zs  # noqa: E402
 
 dev = torch.device('cuda', 0)

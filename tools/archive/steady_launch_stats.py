@@ -3,7 +3,7 @@
 split into the adaptive burn-in (step size and acceptance still moving, the
 first 50 transitions + step-size-search launches) and the steady region that
 bench.py times.  Usage:
-  python tools/steady_launch_stats.py gpurun_out/prof/<tag>_trace/trace_kernel_trace.csv [first_steady]"""
+  python tools/archive/steady_launch_stats.py gpurun_out/prof/<tag>_trace/trace_kernel_trace.csv [first_steady]"""
 import csv
 import sys
 

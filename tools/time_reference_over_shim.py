@@ -7,11 +7,11 @@ TF-CPU HMC timed on the host cores" -- TensorFlow is not installable -- and it
 can only run where /root/reference exists, i.e. in the BUILD container (the GPU
 box has no copy of the reference and the sources may not be vendored):
 bench.py therefore carries this number as a recorded value
-(profiles/r02_cpu_reference_over_shim.json, `measured_on` says where), next to
+(profiles/archive/r02_cpu_reference_over_shim.json, `measured_on` says where), next to
 the baselines it measures live on the GPU box's own cores.
 
     python tools/time_reference_over_shim.py [seconds] [C D L out.json]
-(e.g. `10 1000 10 5 profiles/r03_cpu_reference_over_shim_config1.json`:
+(e.g. `10 1000 10 5 profiles/archive/r03_cpu_reference_over_shim_config1.json`:
 BASELINE configs[0], the gaussian.py shape)
 """
 import json

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void softmax_family_kernel(
 // at once: U = 1.  U = 2 (both rows' loads in flight before the first of the
 // two wave reductions per row, interleaved shuffle chains) was measured for
 // the slowest of these passes, the categorical gradient at [65 536, 1 024]:
-// 4.34-4.40 TB/s against 4.68 with one row (profiles/r03y_softmax_rows.txt)
+// 4.34-4.40 TB/s against 4.68 with one row (profiles/archive/r03y_softmax_rows.txt)
 // -- the pass is not short of bytes in flight; -DZS_SMX_ROWS=2 keeps the A/B.
 template <int MODE, int NPL, int U>
 __global__ __launch_bounds__(256) void softmax_family_reg_kernel(

@@ -643,7 +643,7 @@ extern "C" int zshmc_hmc_diag_normal_step(
 // hipGraph was built and measured in round 3 and is gone: on ROCm 7.2 a
 // replayed kernel node costs MORE than a plain launch into a busy queue --
 // 5.85 against 4.39 us per transition at 1 000 x 10, 99.2 against 95.3 at
-// 65 536 x 1 024, profiles/r03l_run_graph.txt.)
+// 65 536 x 1 024, profiles/archive/r03l_run_graph.txt.)
 extern "C" int zshmc_hmc_diag_normal_run(
     float* q, const float* mean, const float* logstd, const float* mass,
     float step_size_host, int64_t n_chains, int64_t n_data,

@@ -22,7 +22,7 @@
 //     exactly NCH DMA loads + NCH stores and the `s_waitcnt vmcnt(N)` that
 //     guards a slot can be a compile-time count (gfx9 returns VMEM in order;
 //     EXEC=0 VMEM still passes through the counter -- probed on hardware,
-//     tools/glds_probe.hip).
+//     tools/archive/glds_probe.hip).
 //
 // vmcnt ledger (per wave; D(i) = NCH DMA loads of the row of trip i, S(i) =
 // NCH row stores + 5 HMCInfo scalar stores, all EXEC-predicated asm):
@@ -51,7 +51,7 @@ namespace zshmc {
 // row STORES non-temporal: 0.0910 -> 0.0877..0.0891 ms without a mass vector,
 // 0.0908 -> 0.0886 with one, 0.0931 -> 0.0901 with a mean tile; `sc0 sc1`
 // stores within 0.5 % of that; nt LOADS alone 0.0883, but nt loads AND nt
-// stores together 0.1033 (profiles/r03n_cache_policy_kbench.txt).
+// stores together 0.1033 (profiles/archive/r03n_cache_policy_kbench.txt).
 #ifndef ZS_LD_POL
 #define ZS_LD_POL 0
 #endif

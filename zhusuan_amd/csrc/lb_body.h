@@ -50,7 +50,7 @@ __device__ __forceinline__ void lb_body(
   // n_docs).  With consecutive rows every lane gathers its own document's
   // counts (32 different rows of the [n_docs, V] matrix per instruction, 2 TB
   // of gathered bytes per launch at BASELINE configs[4],
-  // profiles/r03e_native_full_shape_rocprofv3_summary.txt); with one document
+  // profiles/archive/r03e_native_full_shape_rocprofv3_summary.txt); with one document
   // per workgroup the same four loads per tile are broadcasts of one row.
   int64_t row_base = (int64_t)bx * kMC, row_stride = 1;
   int64_t n_valid = C - row_base;

@@ -46,9 +46,9 @@ constexpr int kWR = 32;  // data rows per tile
 // Sets of X slices in LDS.  Two fit at D = 512 (2 x 66 KB: the DMA of tile
 // t+1 is then free of the "row consumed" order) -- measured twice, no gain:
 // all rows at the top of the tile 110.4 against 110.0 TFLOP/s
-// (profiles/r03x_lb_wide_buffers.txt, before the DMA issue was spread); two
+// (profiles/archive/r03x_lb_wide_buffers.txt, before the DMA issue was spread); two
 // rows in front of each phase-1 step 106.9 against 120.6 with one set and the
-// rows spread under phase 3 (profiles/r03bb_lb_wide_buf2_ab.txt): phase 1 is
+// rows spread under phase 3 (profiles/archive/r03bb_lb_wide_buf2_ab.txt): phase 1 is
 // ONE dependent MFMA chain, a DMA instruction's ~50 clocks of issue between
 // its links are not hidden, while the independent accumulators of phase 3
 // absorb them.
@@ -111,7 +111,7 @@ __device__ __forceinline__ void wide_dma_row(const float* src, uint32_t dst,
 // (D = 256 also instantiates -- 54 KB of LDS and ~100 registers, two workgroups
 // per CU -- and was measured against the 64-chain-block kernel of
 // csrc/linear_bernoulli.hip: 0.77 against 0.82 of peak,
-// profiles/r03v_split256_ab.txt; the library does not dispatch it)
+// profiles/archive/r03v_split256_ab.txt; the library does not dispatch it)
 // OP as in csrc/linear_bernoulli.hip: 0 = Bernoulli over dense logits (y[n]
 // per data row); 1 = UnnormalizedMultinomial over a mixture (W = theta, X =
 // phi^T, the counts x[c, n] from `yc` [yc_rows, ldy] with row period yc_rows

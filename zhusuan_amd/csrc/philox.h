@@ -27,7 +27,7 @@ constexpr uint32_t kStreamDist = 2;
 // The stream is this repository's own documented mapping -- TensorFlow's
 // cannot be reproduced either way -- and the generator is 40 % of the fused
 // kernel's VALU work: 7 instead of 10 rounds took the headline launch from
-// 0.0955 to 0.0912 ms (profiles/r03e_philox7_kbench.txt).  Shared bit for bit
+// 0.0955 to 0.0912 ms (profiles/archive/r03e_philox7_kbench.txt).  Shared bit for bit
 // with oracle/philox.py (known-answer vectors for 7 AND 10 rounds pinned in
 // tests/test_oracle_philox.py); -DZS_PHILOX_ROUNDS=10 rebuilds the old stream.
 #ifndef ZS_PHILOX_ROUNDS
