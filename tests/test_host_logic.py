@@ -278,6 +278,7 @@ def test_native_plan_reprobes_the_model_on_a_meta_latent(monkeypatch):
     import torch
     import zhusuan_amd as zs
     from zhusuan_amd import hmc as H
+    from zhusuan_amd.plans import recognise as R
     n_chains, n_docs, K, V = 4, 6, 8, 20
     phi = torch.softmax(torch.randn(K, V), -1)
     x = torch.poisson(torch.full((n_docs, V), 2.0))
@@ -301,7 +302,7 @@ def test_native_plan_reprobes_the_model_on_a_meta_latent(monkeypatch):
         def __init__(self, hmc, names, values, cs, dev, probe, kind):
             self.probe, self.kind = probe, kind
 
-    monkeypatch.setattr(H, '_DenseLikelihoodPlan', Stub)
+    monkeypatch.setattr(R, '_DenseLikelihoodPlan', Stub)
     hmc = zs.HMC(step_size=1e-3)
     hmc._observed = {'x': x}
     q = torch.zeros(n_chains, n_docs, K)
@@ -376,7 +377,7 @@ def test_normal_derived_spread_keeps_the_tape_after_a_no_grad_first_use():
 def test_row_period_parameters_are_16_byte_aligned_copies_of_views():
     """a contiguous slice of a user tensor is a view whose storage
     offset can break the 16-byte alignment the row kernels require."""
-    from zhusuan_amd.hmc import _to_row_period, _aligned16
+    from zhusuan_amd.plans.dense import _to_row_period, _aligned16
     base = torch.arange(9 * 8, dtype=torch.float32).reshape(9, 8)
     view = base[:, 1:5].contiguous()[1:]          # contiguous, offset 16 B
     odd = torch.arange(33, dtype=torch.float32)[1:]   # offset 4 B
@@ -399,6 +400,7 @@ def test_native_plan_recognises_several_latents_per_likelihood(monkeypatch):
     import torch
     import zhusuan_amd as zs
     from zhusuan_amd import hmc as H
+    from zhusuan_amd.plans import recognise as R
     C, N = 6, 30
     X1, X2 = torch.randn(N, 5), torch.randn(N, 3)
     y = (torch.rand(N) < 0.5).to(torch.float32)
@@ -407,7 +409,7 @@ def test_native_plan_recognises_several_latents_per_likelihood(monkeypatch):
         def __init__(self, hmc, names, values, cs, dev, probe, kind):
             self.probe, self.kind, self.names = probe, kind, names
 
-    monkeypatch.setattr(H, '_DenseLikelihoodPlan', Stub)
+    monkeypatch.setattr(R, '_DenseLikelihoodPlan', Stub)
 
     def plan_of(model_fn, latents, log_joint=None):
         m = model_fn()
@@ -521,6 +523,7 @@ def test_plan_recognition_survives_a_foreign_autograd_function(monkeypatch):
     import torch
     import zhusuan_amd as zs
     from zhusuan_amd import _symbolic, hmc as H
+    from zhusuan_amd.plans import recognise as R
     C, D, N = 5, 4, 12
     X = torch.randn(N, D)
     y = (torch.rand(N) < 0.5).to(torch.float32)
@@ -547,7 +550,7 @@ def test_plan_recognition_survives_a_foreign_autograd_function(monkeypatch):
         def __init__(self, *a):
             raise AssertionError('a native plan was built')
 
-    monkeypatch.setattr(H, '_DenseLikelihoodPlan', Stub)
+    monkeypatch.setattr(R, '_DenseLikelihoodPlan', Stub)
     q = torch.zeros(C, D)
     hmc = zs.HMC(step_size=1e-3)
     hmc._observed = {'y': y}
@@ -571,6 +574,7 @@ def test_native_plan_recognises_the_softmax_regression_spellings(monkeypatch):
     import torch
     import zhusuan_amd as zs
     from zhusuan_amd import hmc as H
+    from zhusuan_amd.plans import recognise as R
     C, K, F, N = 6, 4, 5, 30
     X = torch.randn(N, F)
     y = torch.randint(0, K, (N,), dtype=torch.int32)
@@ -579,7 +583,7 @@ def test_native_plan_recognises_the_softmax_regression_spellings(monkeypatch):
         def __init__(self, hmc, names, values, cs, dev, probe, kind):
             self.probe, self.kind = probe, kind
 
-    monkeypatch.setattr(H, '_DenseLikelihoodPlan', Stub)
+    monkeypatch.setattr(R, '_DenseLikelihoodPlan', Stub)
 
     def plan_of(spell, n_classes=K):
         @zs.meta_bayesian_net()

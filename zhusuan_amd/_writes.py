@@ -5,7 +5,7 @@ at the current state, the column sums of the mass estimator -- must be
 dropped when ANOTHER sampler (a second HMC on the same tensor, an SGMCMC step)
 moved them in between.  Every sampler therefore notes its writes here: one
 generation counter per storage, process-wide, compared together with torch's
-own counters (zhusuan_amd.hmc._versions).  A write the library cannot see at
+own counters (zhusuan_amd.plans.base._versions).  A write the library cannot see at
 all (`x.data`, DLPack, a raw pointer) has `HMC.latents_changed()` /
 `HMC.observed_changed()`."""
 

@@ -1,5 +1,5 @@
 // K transitions of a NATIVE model plan from one call -- the launch loop of
-// zhusuan_amd/hmc.py::_DenseLikelihoodPlan.transition + _PlanBase.finish on
+// zhusuan_amd/plans/dense.py::_DenseLikelihoodPlan.transition + plans/base.py::_PlanBase.finish on
 // THIS side of the C-ABI (the counterpart of zshmc_hmc_diag_normal_run for
 // the dense-likelihood, dense-logit Categorical and gathered-dot plans).
 //

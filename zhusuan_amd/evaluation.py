@@ -45,7 +45,8 @@ def _proposal_is_prior_of(target, proposal, observed, latent):
     plans take.  Checked structurally, on one evaluation of each."""
     from .framework.bn import StochasticTensor
     from .framework.meta_bn import MetaBayesianNet
-    from .hmc import _summands_of, deferred, placeholder
+    from .hmc import deferred, placeholder
+    from .plans.recognise import _summands_of
     if not (isinstance(target, MetaBayesianNet) and
             isinstance(proposal, MetaBayesianNet)) or len(latent) != 1:
         return False

@@ -1,0 +1,852 @@
+"""The native model plans: Normal-prior latents + one observed node whose
+log-likelihood and gradient come from a fused kernel -- dense-logit Bernoulli
+/ Categorical, the mixture multinomial of lntm_mcem.py, the gathered-dot
+rating model of pmf_hmc.py (csrc/linear_*.hip, hmc_model*.hip,
+gather_dot.hip; reference zhusuan/hmc.py:348-372, :418-520)."""
+import ctypes
+
+import torch
+
+from .. import _capi, _symbolic, _writes
+from ..distributions import Normal
+from ..framework.bn import StochasticTensor
+from ..framework.meta_bn import MetaBayesianNet
+from ..utils import merge_dicts
+from .base import _PlanBase, _versions, _prod, _Unsupported
+
+
+class _DenseLikelihoodPlan(_PlanBase):
+    """Native plan for the dense-likelihood families (BASELINE configs 3 / 5):
+    latents with Normal priors and one observed node whose log-likelihood and
+    gradient come from the fused fp32-MFMA kernels --
+
+      'linear_bernoulli'    y ~ Bernoulli(w @ X^T [+ w2 @ X2^T ...] [+ b],
+                                          group_ndims=1)
+                            one latent per term, up to 1024 features in total
+      'mixture_multinomial' x ~ UnnormalizedMultinomial(
+                                    log_mixture(softmax(eta), phi),
+                                    normalize_logits=False)   (lntm_mcem.py:33-48)
+                            one latent, up to 1024 topics
+
+    The plan works on a PACKED state: the latents' columns side by side in
+    rows of `ld` floats (the total rounded up to a multiple of 4; the columns
+    behind the last latent stay zero) -- what the likelihood kernel takes as
+    its W operand once the design matrices are laid out the same way.  A
+    single latent whose size is a multiple of 4 is its own packed state.
+
+    A transition is momentum + (L+1) x [likelihood kernel, one element-wise
+    launch doing prior gradient / softmax Jacobian / kick / drift / next
+    operand] + MH + select: no autograd graph and no ATen kernel on the path
+    (csrc/hmc_model.hip).  The model function is still re-evaluated on the
+    host at the start of every run, so fed placeholders (mini-batches,
+    eta_mean / eta_logstd of lntm_mcem.py:164-169) and in-place parameter
+    updates are seen."""
+    can_skip_acc = False
+
+    def __init__(self, hmc, names, values, chain_shape, device, probe, kind):
+        super(_DenseLikelihoodPlan, self).__init__(hmc, names, values,
+                                                   chain_shape, device)
+        from .. import _ops
+        self._ops = _ops
+        self.kind = kind
+        self._probe = probe
+        f32 = dict(dtype=torch.float32, device=device)
+        C = self.n_chains
+        self.offsets = [sum(self.n_data[:k]) for k in range(len(self.n_data))]
+        D = self.n_total = sum(self.n_data)
+        self.ld = ld = (D + 3) // 4 * 4
+        self.packed = len(self.q) > 1 or ld != D
+        self.softmax = kind == 'mixture_multinomial'
+        # chain axes flattened: [C, D_k] views of the latents
+        self.q_rows = [q.view(C, d) for q, d in zip(self.q, self.n_data)]
+        self.p = torch.zeros(C, ld, **f32)
+        self.q_new = torch.zeros(C, ld, **f32)
+        self.segmented = kind in ('linear_categorical', 'gathered_dot')
+        if kind == 'gathered_dot':
+            # pmf_hmc.py:19-31: the latent is one of the two factor tables,
+            # [chains, n, D] -- a handful of chains of 10^4..10^5 elements.
+            # The gradient comes back from zshmc_gather_dot_grad as a plain
+            # [C, n * D] matrix: one "segment" per chain.
+            self.n_classes, self.seg_len, self.stride = 1, D, 1
+            self.width = ld
+            self.lik_rows = C
+            self.seg_ws = torch.empty(
+                int(_capi.load().zshmc_model_seg_workspace(C, D)), **f32)
+            self.lp_const = torch.zeros(C, **f32)
+            self._host_scalars = {}
+            self._logstd_dev = torch.zeros(8, **f32)
+            need_operand = False
+        elif self.segmented:
+            # w[c, 0:K, 0:F]: K class rows of F features per chain; the
+            # likelihood kernel's "chain rows" are the (chain, class) pairs,
+            # `stride` of them per chain (K rounded up to a power of two)
+            K, F = (int(v) for v in self.q[0].shape[-2:])
+            self.n_classes, self.seg_len = K, F
+            self.stride = _ops.class_stride(K)
+            self.width, self.block = _ops.likelihood_plan(F, self.stride)
+            self.lik_rows = C * self.stride
+            self.seg_ws = torch.empty(
+                int(_capi.load().zshmc_model_seg_workspace(C, D)), **f32)
+            need_operand = not (K == self.stride and F == self.width)
+        else:
+            self.width, self.block = _ops.likelihood_plan(ld)
+            self.lik_rows = C
+            need_operand = self.softmax or self.width != ld
+        self.grad = torch.empty(self.lik_rows, self.width, **f32)
+        # operand of the likelihood kernel: theta = softmax(q) / zero-padded q
+        # / the class rows of q (padding rows and columns stay zero)
+        self.operand = torch.zeros(self.lik_rows, self.width, **f32) \
+            if need_operand else None
+        if hmc.adapt_mass is not None:
+            # the latents' mass vectors are the columns of ONE packed vector
+            # (what the step kernel reads); the padding keeps mass 1
+            self.mass_pack = torch.ones(ld, **f32)
+            self.mass = [self.mass_pack[o:o + d]
+                         for o, d in zip(self.offsets, self.n_data)]
+        self.ll = torch.empty(self.lik_rows, **f32)
+        # The likelihood evaluation AT THE STATE THE LATENTS HOLD: a transition
+        # starts from the previous one's last evaluation where the chain
+        # accepted, from its own first one where it did not (the accepted
+        # chains' rows of grad / ll are copied over behind the MH test), so a
+        # transition is L likelihood launches, not L + 1 -- as long as nobody
+        # else wrote the latents and the model's tensors are the same
+        # (`_start_is_valid`).  The likelihood term is carried UNSCALED
+        # (lik_scale is applied by the step), so annealing keeps it.
+        self.grad0 = torch.empty(self.lik_rows, self.width, **f32)
+        self.ll0 = torch.empty(self.lik_rows, **f32)
+        self.carry_start = hmc.reuse_start_evaluation
+        self._start_valid = False
+        self._start_versions = []
+        self.lp_old = self.orig_log_prob      # HMCInfo.orig_log_prob itself
+        self.lp_new = torch.empty(C, **f32)
+        self.kin_old = torch.zeros(C, **f32)
+        self.kin_new = torch.zeros(C, **f32)
+        self.accept = torch.zeros(C, dtype=torch.uint8, device=device)
+        self._in_search = False
+        self._src = None
+        self._ws = None
+        # the one-launch trajectory: grid barrier words [arrivals, generation,
+        # fault, -]; how many workgroups of this kernel fit the device at once
+        # (False: the launch loop below, from Python -- what a transition
+        # behind a step-size search runs, and what the tests count calls of)
+        self.c_transition = True
+        self.traj_sync = torch.zeros(4, dtype=torch.int32, device=device)
+        self.traj_capacity = 0
+        if hmc.one_launch_trajectory and kind in (
+                'linear_bernoulli', 'mixture_multinomial') and \
+                self.width <= 256:
+            cap = ctypes.c_int(0)
+            _capi.call('zshmc_trajectory_capacity', self.width,
+                       _capi.PLAN_KINDS[kind], ctypes.addressof(cap))
+            self.traj_capacity = int(cap.value)
+        # multiplies the likelihood term (log-density and gradient): 1 for the
+        # joint; AIS installs its temperature (evaluation.py:101-103)
+        self.lik_scale = lambda: 1.0
+        self.refresh_model()
+
+    # -- model tensors -------------------------------------------------------
+    def refresh_model(self):
+        priors, inner, obs = self._probe()
+        # priors: [(mean, ('std' | 'logstd', tensor as given))] per latent
+        t = [m for m, _ in priors] + [sp[1] for _, sp in priors] + \
+            [a for a in _flat_tensors(inner)] + [obs]
+        # same storage, layout and version counter as last run (the tensors
+        # are held, so an address cannot have been handed to another one;
+        # `X.t()` of the literal spelling is a new view object every time)
+        key = [(a.data_ptr(), tuple(a.shape), tuple(a.stride()), a.dtype,
+                a._version) for a in t]
+        if not self.carry_start:
+            # reuse_start_evaluation=False: nothing about the model's tensors
+            # is remembered from one run to the next (hmc.py:47-50)
+            self._ops.clear_caches()
+            self._src = None
+        if self._src is not None and key == self._src[0]:
+            return
+        # another likelihood (design matrix, observations): another
+        # evaluation at the start.  New PRIOR tensors alone -- a model function
+        # that builds `torch.zeros(d)` per call -- leave the likelihood term's
+        # carried evaluation valid: the step recomputes the prior.
+        n_prior = 2 * len(priors)
+        if self._src is None or key[n_prior:] != self._src[0][n_prior:]:
+            self._start_valid = False
+        self._src = (key, t)
+        C = self.n_chains
+        self._pack_prior(priors)
+        ops = self._ops
+        if self.kind == 'linear_bernoulli':
+            y = obs
+            if self.packed:
+                self.inner = _aligned16(ops.packed_design(
+                    inner, int(y.shape[0]), self.device, self.width))
+            else:
+                self.inner = _aligned16(ops._padded_x(inner[0], self.width))
+            self.obs = _aligned16(y.detach().to(torch.float32).contiguous())
+            n_inner = self.inner.shape[0]
+        elif self.kind == 'gathered_dot':
+            self._refresh_gathered_dot(inner, obs)
+            return
+        elif self.kind == 'linear_categorical':
+            self.inner = _aligned16(ops._padded_x(inner[0], self.width))
+            self.obs = _aligned16(ops.labels_as_float(obs, self.n_classes))
+            n_inner = self.inner.shape[0]
+        else:
+            phi, x = inner[0], obs
+            self.inner = _aligned16(ops._padded_phi_t(phi, self.width))
+            self.obs, self.obs_stride = ops._padded_counts(x)
+            self.obs = _aligned16(self.obs)
+            n_inner = self.inner.shape[0]
+            if C % self.obs.shape[0] != 0:
+                raise ValueError("counts rows do not divide the chain rows")
+        # the bf16x3 kernels, where asked for and where they exist: <= 256
+        # columns, and -- one document per 128-chain workgroup -- chain axes
+        # that fill those workgroups
+        self.inner_image = None
+        if self.hmc.likelihood_arithmetic == 'bf16x3' and \
+                self.kind in ('linear_bernoulli', 'mixture_multinomial') and \
+                self.width in ops.BF16X3_WIDTHS:
+            per_doc = C // self.obs.shape[0] \
+                if self.kind == 'mixture_multinomial' else C
+            n_docs = C // per_doc
+            if n_docs == 1 or not ops.BF16X3_REQUIRE_FILL or \
+                    per_doc % ops.BF16X3_CHAIN_BLOCK == 0 or \
+                    per_doc >= 8 * ops.BF16X3_CHAIN_BLOCK:
+                self.inner_image = ops.bf16x3_image(self.inner)
+                self.block = ops.BF16X3_CHAIN_BLOCK
+        if self.inner_image is None and self.kind != 'linear_categorical':
+            self.block = ops.likelihood_plan(self.width)[1]
+        R = self.lik_rows
+        self.splits = ops._row_splits(R, n_inner, self.device, self.block)
+        # (chain blocks x slices resident at once where the chain blocks
+        # alone are: the trips then run from one cooperative launch)
+        n_wg = (R + self.block - 1) // self.block
+        if self.inner_image is None and 0 < n_wg <= self.traj_capacity:
+            self.splits = max(1, min(self.splits, self.traj_capacity // n_wg))
+        need = self.splits * R * (self.width + 1) if self.splits > 1 else 0
+        if need and (self._ws is None or self._ws.numel() < need):
+            self._ws = torch.empty(need, dtype=torch.float32,
+                                   device=self.device)
+
+    # -- the gathered-dot rating model (pmf_hmc.py:19-31) -----------------------
+    def _host_scalar(self, t):
+        """float(t) of a one-element device tensor, read once per (storage,
+        version): the per-run path does not synchronise."""
+        key = (t.data_ptr(), t._version)
+        hit = self._host_scalars.get(key)
+        if hit is None:
+            if len(self._host_scalars) > 64:
+                self._host_scalars.clear()
+            hit = self._host_scalars[key] = (float(t.item()), t)
+        return hit[0]
+
+    def _refresh_gathered_dot(self, inner, obs):
+        """inner = [side ('u' | 'v': which table the latent is), other table,
+        select (latent side), select (other side) or None, likelihood spread ('std' | 'logstd', tensor), constant nodes
+        [(observed tensor, mean, (how, spread))...]]."""
+        import math
+        ops = self._ops
+        self.side, other, sel_lat, sel_other, spread, consts = inner
+        self.splits = 1
+        q = self.q[0]
+        n_lat, D = int(q.shape[-2]), int(q.shape[-1])
+        self.n_lat, self.n_dim = n_lat, D
+        self.other = _aligned16(other.detach().to(torch.float32).contiguous())
+        self.n_other = int(self.other.shape[-2])
+        E = int(sel_lat.numel())
+        self.n_pairs = E
+        # CSR view of the pair list by the latent's rows (deterministic
+        # scatter of the gradient) -- cached per index tensor version
+        self.idx_lat, self.seg, self.order = ops._pair_csr(
+            sel_lat, n_lat, 'native_lat')
+        if sel_other is None:       # `other` is already gathered pair by pair
+            if getattr(self, '_iota', None) is None or \
+                    self._iota.numel() != E:
+                self._iota = torch.arange(E, dtype=torch.int32,
+                                          device=self.device)
+            self.idx_other = self._iota
+        else:
+            self.idx_other = ops._pair_csr(sel_other, self.n_other,
+                                           'native_other')[0]
+        r = obs.detach().to(torch.float32).contiguous()
+        if r.numel() == E:
+            self.obs, self.obs_rows = r.reshape(-1), 1
+        elif r.numel() == self.n_chains * E:
+            self.obs, self.obs_rows = r.reshape(-1), self.n_chains
+        else:
+            raise ValueError("HMC (native gathered_dot plan): %d observed "
+                             "ratings for %d pairs" % (r.numel(), E))
+        how, sp = spread
+        sp_v = self._host_scalar(sp)
+        self.lik_logstd = math.log(sp_v) if how == 'std' else sp_v
+        need = int(_capi.load().zshmc_gather_dot_normal_workspace(
+            self.n_chains, E))
+        # likelihood + gradient in one pass over the pair list where the rows
+        # are <= 128 floats, a multiple of 4 (csrc/gather_dot.hip:
+        # gd_fused_kernel): the CSR view cut into segments, the other side's
+        # indices and the ratings in CSR order
+        self.gd_fused = D % 4 == 0 and D <= 128 and E > 0
+        if self.gd_fused:
+            key = (self.seg.data_ptr(), self.order.data_ptr(),
+                   self.idx_other.data_ptr(), self.idx_other._version)
+            if getattr(self, '_gd_seg_key', None) != key:
+                self._gd_seg = ops._csr_segments(self.seg, E)
+                self._gd_idx_csr = self.idx_other[self.order.long()].contiguous()
+                self._gd_seg_key = key
+            self._gd_obs_csr = _aligned16(self.obs.view(
+                self.obs_rows, E)[:, self.order.long()].contiguous())
+            n_seg = int(self._gd_seg[1].numel())
+            need = max(need, self.n_chains * n_seg * (D + 1))
+        if self._ws is None or self._ws.numel() < max(need, 1):
+            self._ws = torch.empty(max(need, 1), dtype=torch.float32,
+                                   device=self.device)
+        if getattr(self, 'g_pairs', None) is None or \
+                self.g_pairs.numel() < self.n_chains * max(E, 1):
+            self.g_pairs = torch.empty(self.n_chains * max(E, 1),
+                                       dtype=torch.float32, device=self.device)
+        # the observed nodes that do not depend on the latent: their
+        # log-densities (a constant of this run) join every log-joint value
+        stream = _capi.current_stream()
+        if len(consts) > 1:
+            raise _Unsupported('more than one constant node in the joint')
+        if consts:
+            x, mean, (chow, csp) = consts[0]
+            xs = _aligned16(x.detach().to(torch.float32).contiguous())
+            cols = xs.numel() // self.n_chains
+            cv = self._host_scalar(csp)
+            _capi.call('zshmc_state_set', self._logstd_dev.data_ptr(), 0,
+                       math.log(cv) if chow == 'std' else cv, stream)
+            data_shape = tuple(xs.shape[len(self.chain_shape):])
+            m = mean.detach().to(torch.float32)
+            if m.numel() == 1:
+                m, mode = m.reshape(1), _capi.BCAST_SCALAR
+            elif tuple(m.shape[-len(data_shape):]) == data_shape and \
+                    m.numel() == cols:
+                m, mode = _aligned16(m.contiguous().reshape(-1)), \
+                    _capi.BCAST_ROW
+            else:
+                m, mode = _aligned16(m.expand(xs.shape).contiguous()), \
+                    _capi.BCAST_FULL
+            self._const_keep = (xs, m)
+            _capi.call('zshmc_normal_log_prob', xs.data_ptr(), m.data_ptr(),
+                       self._logstd_dev.data_ptr(), self.lp_const.data_ptr(),
+                       self.n_chains, cols, mode, _capi.BCAST_SCALAR, 1,
+                       stream)
+        else:
+            _capi.call('zshmc_zero', self.lp_const.data_ptr(),
+                       4 * self.n_chains, stream)
+
+    def _pack_prior(self, priors):
+        """Prior mean / log-std as [rows, ld] matrices used with row period
+        `rows` over the flattened chain axes (_to_row_period); several
+        latents: their columns side by side, a common row period."""
+        parts = []
+        for (mean, (how, spread)), d, q in zip(priors, self.n_data, self.q):
+            logstd = torch.log(spread) if how == 'std' else spread  # :96-103
+            if q.dim() == len(self.chain_shape):    # per-chain scalar latent
+                mean, logstd = mean.unsqueeze(-1), logstd.unsqueeze(-1)
+            elif q.dim() > len(self.chain_shape) + 1:   # [K, F] class rows
+                ds = tuple(q.shape[len(self.chain_shape):])
+                mean = _flatten_data_axes(mean, ds)
+                logstd = _flatten_data_axes(logstd, ds)
+            try:
+                parts.append((_to_row_period(mean, self.chain_shape, d),
+                              _to_row_period(logstd, self.chain_shape, d)))
+            except (RuntimeError, ValueError) as e:
+                raise _Unsupported(str(e))
+        if not self.packed:
+            (self.prior_mean, self.mean_rows), \
+                (self.prior_logstd, self.logstd_rows) = parts[0]
+            return
+        out = []
+        for which in (0, 1):
+            rows = max(p[which][1] for p in parts)
+            m = torch.zeros(rows, self.ld, dtype=torch.float32,
+                            device=self.device)
+            for p, o, d in zip(parts, self.offsets, self.n_data):
+                t, r = p[which]
+                if r not in (1, rows):
+                    raise _Unsupported(
+                        "HMC (native %s plan): the priors' parameters vary "
+                        "along different chain axes" % self.kind)
+                m[:, o:o + d] = t
+            out.append((m, rows))
+        (self.prior_mean, self.mean_rows), \
+            (self.prior_logstd, self.logstd_rows) = out
+
+    # -- building blocks -----------------------------------------------------
+    def _load_state(self, stream):
+        """The latents -> the packed working state q_new."""
+        if not self.packed:
+            self.q_new.copy_(self.q_rows[0])
+            return
+        for k, qk in enumerate(self.q_rows):
+            _capi.call('zshmc_copy_rows',
+                       self.q_new.data_ptr() + 4 * self.offsets[k], self.ld,
+                       qk.data_ptr(), self.n_data[k], None, self.n_chains,
+                       self.n_data[k], stream)
+
+    def _store_state(self, stream):
+        """where(accept, q_new, q) for every latent (hmc.py:488-497)."""
+        for k, qk in enumerate(self.q_rows):
+            _capi.call('zshmc_copy_rows', qk.data_ptr(), self.n_data[k],
+                       self.q_new.data_ptr() + 4 * self.offsets[k], self.ld,
+                       self.accept.data_ptr(), self.n_chains, self.n_data[k],
+                       stream)
+
+    def _likelihood(self, q, stream, want_ll=True, start=False):
+        """ll[c] and d ll / d operand at the operand derived from q.
+        `want_ll=False`: the gradient alone -- the interior evaluations of a
+        trajectory (hmc.py:348-372 reads the log-joint at its two ends only);
+        the MFMA kernels then skip the log-likelihood terms.  `start`: into
+        the start buffers (grad0 / ll0) instead of the trajectory's."""
+        grad, ll = (self.grad0, self.ll0) if start else (self.grad, self.ll)
+        ll_ptr = ll.data_ptr() if want_ll else None
+        w = self.operand if self.operand is not None else q
+        ws = self._ws if self.splits > 1 else None
+        if self.kind == 'gathered_dot':
+            # rating terms + d/d logit in one pass over the pairs, then the
+            # deterministic scatter into the latent's rows
+            lat_is_u = self.side == 'u'
+            if self.gd_fused:
+                sp, sr, sf, lr = self._gd_seg
+                _capi.call(
+                    'zshmc_gather_dot_normal_lik_grad', q.data_ptr(),
+                    self.other.data_ptr(), sp.data_ptr(), sr.data_ptr(),
+                    sf.data_ptr(), lr.data_ptr() if lr.numel() else None,
+                    lr.numel(), self._gd_idx_csr.data_ptr(),
+                    self._gd_obs_csr.data_ptr(), self.obs_rows,
+                    self.lik_logstd, self.lp_const.data_ptr(), self.n_chains,
+                    self.n_lat, self.n_other, self.n_pairs, sr.numel(),
+                    self.n_dim, grad.data_ptr(), ll.data_ptr(),
+                    self._ws.data_ptr(), stream)
+                return
+            _capi.call(
+                'zshmc_gather_dot_normal_lik',
+                q.data_ptr() if lat_is_u else self.other.data_ptr(),
+                self.other.data_ptr() if lat_is_u else q.data_ptr(),
+                (self.idx_lat if lat_is_u else self.idx_other).data_ptr(),
+                (self.idx_other if lat_is_u else self.idx_lat).data_ptr(),
+                self.obs.data_ptr(), self.obs_rows, self.lik_logstd,
+                self.lp_const.data_ptr(), self.n_chains,
+                self.n_lat if lat_is_u else self.n_other,
+                self.n_other if lat_is_u else self.n_lat, self.n_pairs,
+                self.n_dim, self.g_pairs.data_ptr(), ll.data_ptr(),
+                self._ws.data_ptr(), stream)
+            if self.n_pairs:
+                _capi.call('zshmc_gather_dot_grad', self.other.data_ptr(),
+                           self.g_pairs.data_ptr(), self.seg.data_ptr(),
+                           self.order.data_ptr(), self.idx_other.data_ptr(),
+                           self.n_chains, self.n_lat, self.n_other,
+                           self.n_pairs, self.n_dim, grad.data_ptr(),
+                           stream)
+            else:
+                _capi.call('zshmc_zero', grad.data_ptr(),
+                           4 * grad.numel(), stream)
+        elif self.kind == 'linear_categorical':
+            _capi.call('zshmc_linear_categorical_log_lik', w.data_ptr(),
+                       self.inner.data_ptr(), self.obs.data_ptr(),
+                       self.lik_rows, self.inner.shape[0], self.width,
+                       self.n_classes, self.stride, ll_ptr,
+                       grad.data_ptr(), self.splits, _capi.ptr(ws),
+                       stream)
+        elif self.inner_image is not None and self.kind == 'linear_bernoulli':
+            _capi.call('zshmc_linear_bernoulli_log_lik_bf16x3', w.data_ptr(),
+                       self.inner_image.data_ptr(), self.obs.data_ptr(),
+                       self.n_chains, self.inner.shape[0], self.width,
+                       ll_ptr, grad.data_ptr(), self.splits,
+                       _capi.ptr(ws), stream)
+        elif self.inner_image is not None:
+            _capi.call('zshmc_linear_multinomial_log_lik_bf16x3',
+                       w.data_ptr(), self.inner_image.data_ptr(),
+                       self.obs.data_ptr(), self.obs.shape[0],
+                       self.obs_stride, self.n_chains, self.inner.shape[0],
+                       self.width, ll_ptr, grad.data_ptr(), self.splits,
+                       _capi.ptr(ws), stream)
+        elif self.kind == 'linear_bernoulli':
+            _capi.call('zshmc_linear_bernoulli_log_lik', w.data_ptr(),
+                       self.inner.data_ptr(), self.obs.data_ptr(),
+                       self.n_chains, self.inner.shape[0], self.width,
+                       ll_ptr, grad.data_ptr(), self.splits,
+                       _capi.ptr(ws), stream)
+        else:
+            _capi.call('zshmc_linear_multinomial_log_lik', w.data_ptr(),
+                       self.inner.data_ptr(), self.obs.data_ptr(),
+                       self.obs.shape[0], self.obs_stride, self.n_chains,
+                       self.inner.shape[0], self.width, ll_ptr,
+                       grad.data_ptr(), self.splits, _capi.ptr(ws),
+                       stream)
+
+    def _step(self, q, p, use_grad, eps_host, kick, drift, lp_out, kinetic,
+              stream, start=False):
+        """csrc/hmc_model.hip: prior + Jacobian + kick + drift + operand.
+        `start`: the evaluation it reads is the start buffers'."""
+        grad, ll = (self.grad0, self.ll0) if start else (self.grad, self.ll)
+        if self.segmented:
+            # csrc/hmc_model_seg.hip: the class rows of a chain are rows
+            # c * stride + k of the gradient / operand matrices
+            _capi.call(
+                'zshmc_model_kick_drift_seg', q.data_ptr(), p.data_ptr(),
+                grad.data_ptr() if use_grad else None, self.width,
+                self.seg_len, self.stride, _capi.ptr(self.operand),
+                self.width, self.prior_mean.data_ptr(), self.mean_rows,
+                self.prior_logstd.data_ptr(), self.logstd_rows,
+                self.mass_pack.data_ptr() if self.use_mass else None,
+                None if eps_host is not None else self.state.data_ptr(),
+                0.0 if eps_host is None else float(eps_host), float(kick),
+                float(drift), float(self.lik_scale()), self.n_chains,
+                self.n_total, self.ld,
+                ll.data_ptr() if use_grad else None, _capi.ptr(lp_out),
+                _capi.ptr(kinetic), self.seg_ws.data_ptr(), stream)
+            return
+        _capi.call(
+            'zshmc_model_kick_drift', q.data_ptr(), p.data_ptr(),
+            grad.data_ptr() if use_grad else None, self.width,
+            _capi.ptr(self.operand), self.width, int(self.softmax),
+            self.prior_mean.data_ptr(), self.mean_rows,
+            self.prior_logstd.data_ptr(), self.logstd_rows,
+            self.mass_pack.data_ptr() if self.use_mass else None,
+            None if eps_host is not None else self.state.data_ptr(),
+            0.0 if eps_host is None else float(eps_host), float(kick),
+            float(drift), float(self.lik_scale()), self.n_chains,
+            self.n_total, self.ld,
+            ll.data_ptr() if use_grad else None, _capi.ptr(lp_out),
+            _capi.ptr(kinetic), stream)
+
+    def _momentum(self, t, stream):
+        _capi.call('zshmc_zero', self.kin_old.data_ptr(),
+                   4 * self.n_chains, stream)
+        # per latent, with the latent's own counters (the generic plan's and
+        # regenerate_momentum's: Philox stream word = latent index)
+        for k, d in enumerate(self.n_data):
+            _capi.call('zshmc_momentum_rows',
+                       self.p.data_ptr() + 4 * self.offsets[k], self.ld,
+                       self.mass_ptr(k), self.n_chains, d, self.chain_offset,
+                       self.hmc.seed, t & 0xFFFFFFFF, k,
+                       self.kin_old.data_ptr(), stream)
+
+    def _start_is_valid(self):
+        """grad0 / ll0 hold the likelihood evaluation at the latents as they
+        are: left there by the last transition (or evaluation), the model's
+        tensors unchanged since (refresh_model), nobody else having written a
+        latent (our own writes go through the C-ABI and leave torch's version
+        counters alone)."""
+        now = _versions(self.q)
+        return self.carry_start and self._start_valid and now is not None \
+            and now == self._start_versions
+
+    def _mark_start(self):
+        self._start_valid = True
+        self._start_versions = _versions(self.q)
+
+    def _first_evaluation(self, q, stream):
+        """operand(q), then likelihood + gradient at q (ll0, grad0) -- unless
+        they are there already."""
+        if self._start_is_valid():
+            # (softmax: the step's Jacobian reads theta = softmax(q) from the
+            # operand buffer, which holds the last PROPOSAL's)
+            if self.softmax:
+                self._step(q, self.p, False, 0.0, 0.0, 0.0, None, None, stream)
+            return
+        if self.operand is not None:
+            self._step(q, self.p, False, 0.0, 0.0, 0.0, None, None, stream)
+        self._likelihood(q, stream, start=True)
+        self._mark_start()
+
+    def _carry_start(self, stream):
+        """Behind the MH test and the select: the accepted chains' last
+        evaluation becomes the evaluation at their (new) state."""
+        if self.hmc.n_leapfrogs < 1:
+            return
+        n = self.lik_rows // self.n_chains * self.width
+        _capi.call('zshmc_copy_rows', self.grad0.data_ptr(), n,
+                   self.grad.data_ptr(), n, self.accept.data_ptr(),
+                   self.n_chains, n, stream)
+        g = self.lik_rows // self.n_chains
+        _capi.call('zshmc_copy_rows', self.ll0.data_ptr(), g,
+                   self.ll.data_ptr(), g, self.accept.data_ptr(),
+                   self.n_chains, g, stream)
+
+    # -- step-size search (hmc.py:308-345) -----------------------------------
+    def reduce_stats(self, sharding, stream):
+        if not self._in_search:
+            return
+        self.stats[1] = (self.flags != 0).to(torch.float64)[0]
+        if sharding is not None and sharding.active:
+            sharding.all_reduce_sum(self.stats)
+
+    def end_search_trip(self):
+        self.stats.zero_()
+        self._in_search = False
+
+    def begin_search(self, t, stream):
+        self._momentum(t, stream)
+        self._load_state(stream)
+        self._first_evaluation(self.q_new, stream)
+
+    def _restore_start(self, t, stream):
+        """(q, p0) of the start point: q from the latent, p0 regenerated from
+        its Philox counters (cheaper in memory than a copy: config 5 holds
+        21 GB per [rows, K] buffer); its evaluation sits in the start buffers,
+        which a search trip reads and never writes."""
+        self._load_state(stream)
+        self._momentum(t, stream)
+        if self.softmax:      # theta(q) for the step's Jacobian (see above)
+            self._step(self.q_new, self.p, False, 0.0, 0.0, 0.0, None, None,
+                       stream)
+
+    def search_trip(self, t, step_size, stream):
+        self._in_search = True
+        self._restore_start(t, stream)
+        q1, p1 = self.q_new, self.p
+        self._step(q1, p1, True, step_size, 0.5, 1.0, self.lp_old, None,
+                   stream, start=True)
+        self._likelihood(q1, stream)
+        _capi.call('zshmc_zero', self.kin_new.data_ptr(), 4 * self.n_chains,
+                   stream)
+        self._step(q1, p1, True, step_size, 0.5, 0.0, self.lp_new,
+                   self.kin_new, stream)
+        _capi.call('zshmc_mh_accept', self.lp_old.data_ptr(),
+                   self.lp_new.data_ptr(), self.kin_old.data_ptr(),
+                   self.kin_new.data_ptr(), self.n_chains, self.chain_offset,
+                   self.hmc.seed, t & 0xFFFFFFFF, None, None, None, None, None,
+                   self.acc_sum.data_ptr(), self.flags.data_ptr(), stream)
+
+    # -- n transitions from ONE call (csrc/hmc_model_run.hip) ------------------
+    can_run_block = True
+    block_adapts_mass = True
+
+    def _descriptor(self):
+        """zshmc_model_plan of the current buffers (rebuilt per block: the
+        model's tensors may have been re-fed since the last one)."""
+        hmc, c = self.hmc, _capi
+        if len(self.q) > c.MAX_LATENTS:
+            return None
+        d = c.ModelPlan()
+        d.kind = c.PLAN_KINDS[self.kind]
+        d.n_latents, d.n_leapfrogs = len(self.q), hmc.n_leapfrogs
+        d.softmax, d.segmented = int(self.softmax), int(self.segmented)
+        d.use_mass = int(self.use_mass)
+        d.n_splits = int(self.splits)
+        d.n_classes = int(getattr(self, 'n_classes', 0))
+        for k, qk in enumerate(self.q_rows):
+            d.latent[k] = qk.data_ptr()
+            d.latent_size[k] = self.n_data[k]
+            d.latent_offset[k] = self.offsets[k]
+            if hmc.adapt_mass is not None:
+                d.latent_mass[k] = self.mass[k].data_ptr()
+                d.ewmv_mean[k] = self.ewmv_mean[k].data_ptr()
+                d.ewmv_var[k] = self.ewmv_var[k].data_ptr()
+                d.colsum[k] = self.colsum[k].data_ptr()
+        d.q_new, d.p = self.q_new.data_ptr(), self.p.data_ptr()
+        d.n_chains, d.n_total, d.ld = self.n_chains, self.n_total, self.ld
+        d.operand = c.ptr(self.operand)
+        d.grad, d.ll = self.grad.data_ptr(), self.ll.data_ptr()
+        d.lik_rows, d.width = self.lik_rows, self.width
+        if self.carry_start:
+            d.grad_start, d.ll_start = self.grad0.data_ptr(), \
+                self.ll0.data_ptr()
+            d.start_valid = int(self._start_is_valid())
+        d.one_launch = int(self.traj_capacity > 0)
+        d.traj_sync = self.traj_sync.data_ptr()
+        d.split_ws = c.ptr(self._ws)
+        if self.segmented:
+            d.seg_len, d.groups = self.seg_len, self.stride
+            d.seg_ws = self.seg_ws.data_ptr()
+        if self.kind == 'gathered_dot':
+            d.inner, d.n_inner = self.other.data_ptr(), self.n_other
+            d.obs, d.obs_rows = self.obs.data_ptr(), self.obs_rows
+            d.gd_latent_is_u = int(self.side == 'u')
+            d.gd_idx_latent = self.idx_lat.data_ptr()
+            d.gd_idx_other = self.idx_other.data_ptr()
+            d.gd_seg, d.gd_order = self.seg.data_ptr(), self.order.data_ptr()
+            d.gd_n_latent, d.gd_n_pairs = self.n_lat, self.n_pairs
+            d.gd_n_dim, d.gd_logstd = self.n_dim, self.lik_logstd
+            d.gd_lp_const = self.lp_const.data_ptr()
+            d.gd_g_pairs = self.g_pairs.data_ptr()
+            if self.gd_fused:
+                sp, sr, sf, lr = self._gd_seg
+                d.gd_seg_ptr, d.gd_seg_row = sp.data_ptr(), sr.data_ptr()
+                d.gd_seg_first = sf.data_ptr()
+                d.gd_long_rows = lr.data_ptr() if lr.numel() else None
+                d.gd_n_seg, d.gd_n_long = sr.numel(), lr.numel()
+                d.gd_idx_other_csr = self._gd_idx_csr.data_ptr()
+                d.gd_obs_csr = self._gd_obs_csr.data_ptr()
+        else:
+            d.inner, d.n_inner = self.inner.data_ptr(), self.inner.shape[0]
+            d.inner_image = c.ptr(self.inner_image)
+            d.obs = self.obs.data_ptr()
+            if self.kind == 'mixture_multinomial':
+                d.obs_rows, d.obs_stride = self.obs.shape[0], self.obs_stride
+        d.prior_mean, d.mean_rows = self.prior_mean.data_ptr(), self.mean_rows
+        d.prior_logstd = self.prior_logstd.data_ptr()
+        d.logstd_rows = self.logstd_rows
+        if hmc.adapt_mass is not None:
+            d.mass = self.mass_pack.data_ptr()
+            d.comm_buf = self.comm_buf.data_ptr()
+            d.comm_words = self.comm_buf.numel()
+            d.mass_ws = self.mass_ws.data_ptr()
+        d.lp_old, d.lp_new = self.lp_old.data_ptr(), self.lp_new.data_ptr()
+        d.kin_old, d.kin_new = self.kin_old.data_ptr(), self.kin_new.data_ptr()
+        d.accept = self.accept.data_ptr()
+        d.acceptance_rate = self.acceptance_rate.data_ptr()
+        d.orig_hamiltonian = self.orig_hamiltonian.data_ptr()
+        d.hamiltonian = self.hamiltonian.data_ptr()
+        d.log_prob = self.log_prob.data_ptr()
+        d.acc_sum, d.flags = self.acc_sum.data_ptr(), self.flags.data_ptr()
+        d.state = self.state.data_ptr()
+        d.chain_offset, d.n_chains_global = self.chain_offset, \
+            self.n_chains_global
+        d.seed = hmc.seed
+        d.delta, d.gamma = hmc.target_acceptance_rate, hmc.gamma
+        d.t0, d.kappa = hmc.t0, hmc.kappa
+        d.mu = 10.0 * hmc._init_step_size_value            # hmc.py:79 (sic)
+        d.mass_decay = hmc.mass_decay
+        return d
+
+    def run_block(self, t_first, n, kind, stream, sharding, adapt_mass=False,
+                  lik_scales=None, ais=None):
+        """`n` transitions with the same feeds and flags -- no step-size
+        search, the mass at 1 / var -- from one call into libzshmc.so; with
+        `adapt_mass` every one of them updates the mass from the column sums
+        of its start state and leaves those of its end state."""
+        sharded = sharding is not None and sharding.active
+        if adapt_mass and not self._colstats_fresh():
+            self.compute_colstats(stream)
+            if sharded:
+                sharding.all_reduce_sum(self.comm_buf[_capi.STATS_WORDS:])
+        d = self._descriptor()
+        scales = None
+        if lik_scales is not None:
+            scales = (ctypes.c_float * n)(*[float(v) for v in lik_scales])
+        elif float(self.lik_scale()) != 1.0:
+            scales = (ctypes.c_float * n)(*([float(self.lik_scale())] * n))
+        log_w, ends = (None, False) if ais is None else ais
+        if log_w is not None and not (
+                log_w.is_contiguous() and log_w.dtype == torch.float32 and
+                log_w.numel() == self.n_chains):
+            raise ValueError("annealing: log_weights must be a contiguous "
+                             "float32 tensor with one entry per chain")
+        # (a call that fails part-way has already overwritten latents: the
+        # start evaluation is trusted again only behind a successful return)
+        self._start_valid = False
+        if adapt_mass:
+            self.colsum_state = 'dirty'
+        _capi.call('zshmc_hmc_model_run', ctypes.byref(d),
+                   t_first & 0xFFFFFFFF, n, kind, int(bool(adapt_mass)),
+                   scales, _capi.ptr(log_w), int(bool(ends)),
+                   sharding._comm if sharded else None, stream)
+        self.last_t = t_first + n - 1
+        self.stats_local = False
+        if n >= 1:
+            self._own_write()
+            if self.carry_start:
+                self._mark_start()
+        if adapt_mass:
+            self._mark_colstats()
+            self._mass_ones = False
+        elif self.colsum_state in ('fresh', 'parts'):
+            self.colsum_state = 'dirty'
+
+    # -- one transition --------------------------------------------------------
+    def transition(self, t, eps_host, stream, update=None,
+                   want_colstats=False):
+        self.last_t = t
+        L = self.hmc.n_leapfrogs
+        q, p = self.q_new, self.p
+        if eps_host is None and not self._in_search and self.c_transition \
+                and len(self.q) <= _capi.MAX_LATENTS:
+            # the same sequence on the other side of the C-ABI (one foreign
+            # call instead of ~2 L + 8; small problems: the L + 1 trips from
+            # one cooperative launch) -- bit-identical
+            d = self._descriptor()
+            self._start_valid = False
+            _capi.call('zshmc_hmc_model_transition', ctypes.byref(d),
+                       t & 0xFFFFFFFF, float(self.lik_scale()), stream)
+            self._own_write()
+            if self.carry_start:
+                self._mark_start()
+            return
+        # (behind a step-size search: same q, same p0 -- Appendix B 11 -- and
+        # the start evaluation is still in its buffers)
+        self._load_state(stream)
+        self._momentum(t, stream)
+        self._first_evaluation(q, stream)
+        _capi.call('zshmc_zero', self.kin_new.data_ptr(), 4 * self.n_chains,
+                   stream)
+        # trip 0: zero-length drift, half kick (hmc.py:352-364); the drift of
+        # trip i+1 rides behind the kick of trip i
+        self._step(q, p, True, eps_host, 0.5, 1.0 if L >= 1 else 0.0,
+                   self.lp_old, self.kin_new if L == 0 else None, stream,
+                   start=True)
+        if L == 0:
+            self.lp_new.copy_(self.lp_old)
+        for i in range(1, L + 1):
+            last = i == L
+            self._likelihood(q, stream, want_ll=last)
+            self._step(q, p, True, eps_host, 0.5 if last else 1.0,
+                       0.0 if last else 1.0, self.lp_new if last else None,
+                       self.kin_new if last else None, stream)
+        _capi.call('zshmc_mh_accept', self.lp_old.data_ptr(),
+                   self.lp_new.data_ptr(), self.kin_old.data_ptr(),
+                   self.kin_new.data_ptr(), self.n_chains, self.chain_offset,
+                   self.hmc.seed, t & 0xFFFFFFFF,
+                   self.acceptance_rate.data_ptr(),
+                   self.orig_hamiltonian.data_ptr(),
+                   self.hamiltonian.data_ptr(), self.log_prob.data_ptr(),
+                   self.accept.data_ptr(), self.acc_sum.data_ptr(),
+                   self.flags.data_ptr(), stream)
+        self._store_state(stream)
+        if self.carry_start:
+            self._carry_start(stream)
+        else:
+            self._start_valid = False
+        self._own_write()
+
+
+def _to_row_period(param, chain_shape, n_data):
+    """A prior parameter as a contiguous float32 [rows, n_data] matrix used
+    with row period `rows` over the flattened chain axes: the leading chain
+    axes it does not vary along are dropped (1 row: shared by every chain;
+    lntm's eta_mean [n_docs, K] under chain axes [n_chains, n_docs]: n_docs
+    rows)."""
+    t = param.detach().to(torch.float32)
+    full = tuple(chain_shape) + (n_data,)
+    if t.dim() > len(full):
+        t = t.reshape(t.shape[t.dim() - len(full):])
+    shape = (1,) * (len(full) - t.dim()) + tuple(t.shape)
+    t = t.reshape(shape)
+    lead = 0
+    while lead < len(chain_shape) and shape[lead] == 1:
+        lead += 1
+    tail = full[lead:]
+    t = t.reshape(shape[lead:]).expand(tail).contiguous()
+    rows = 1
+    for d in tail[:-1]:
+        rows *= int(d)
+    return _aligned16(t.reshape(rows, n_data)), rows
+
+
+def _flat_tensors(x):
+    """The tensors inside a nested list / tuple (None and strings skipped)."""
+    if isinstance(x, torch.Tensor):
+        yield x
+    elif isinstance(x, (list, tuple)):
+        for y in x:
+            for t in _flat_tensors(y):
+                yield t
+
+
+def _flatten_data_axes(param, data_shape):
+    """A prior parameter of a latent with several data axes ([K, F] class
+    rows) broadcast over them and flattened to one, leading (chain) axes
+    kept."""
+    nd = len(data_shape)
+    lead = tuple(param.shape[:max(param.dim() - nd, 0)])
+    t = param.expand(lead + tuple(data_shape))
+    return t.reshape(lead + (-1,))
+
+
+def _aligned16(t):
+    """`t` itself, or a copy if its storage offset breaks the 16-byte
+    alignment the row kernels require (a contiguous slice `param[1:]` of a
+    user tensor is a view)."""
+    return t if t.data_ptr() % 16 == 0 else t.clone()
