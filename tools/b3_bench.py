@@ -23,6 +23,7 @@ WIDTHS = tuple(int(w) for w in os.environ.get('B3_WIDTHS', '64,128,192,256').spl
 dev = torch.device('cuda', 0)
 s = torch.cuda.current_stream().cuda_stream
 PEAK32, PEAK16 = 157.3, 2500.0 / 6
+SPLITS = int(os.environ.get('B3_SPLITS', '1'))   # row-range slices (bf16x3 launches)
 
 
 def timeit(fn, reps=3):
@@ -69,6 +70,7 @@ for D in WIDTHS:
     ll = torch.empty(C, device=dev)
     gw = torch.empty(C, D, device=dev)
     img = image(X, D)
+    ws3 = torch.empty(SPLITS * C * (D + 1), device=dev) if SPLITS > 1 else None
     t_split = timeit(lambda: image(X, D))
 
     def call32(ll_, g_):
@@ -79,7 +81,7 @@ for D in WIDTHS:
     def call3(ll_, g_):
         _capi.call('zshmc_linear_bernoulli_log_lik_bf16x3', W.data_ptr(),
                    img.data_ptr(), y.data_ptr(), C, N, D, _capi.ptr(ll_),
-                   _capi.ptr(g_), 1, None, s)
+                   _capi.ptr(g_), SPLITS, _capi.ptr(ws3), s)
     print('# D=%d: C=%d N=%d, image split %.3f ms' % (D, C, N, t_split))
     report('bernoulli', D, 4.0 * N * D * C, [
         ('fp32   grad   ', lambda: call32(None, gw)),

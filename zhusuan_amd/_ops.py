@@ -628,7 +628,19 @@ def bf16x3_image(Xp):
     return img
 
 
-def _row_splits(n_blocks_rows, n_inner, device, block=64):
+def resident_per_cu(width, arithmetic='fp32'):
+    """Workgroups of the <= 256-column likelihood kernels one CU holds
+    (registers / LDS; csrc/lb_body.h ZS_LB_MINW, csrc/linear_bf16x3.hip
+    ZS_B3_WAVES): a second resident workgroup runs its element-wise stage
+    under the first one's MFMAs."""
+    if width > 256:
+        return 1
+    if arithmetic == 'bf16x3':
+        return 2 if width <= 128 else 1
+    return 3 if width <= 64 else 2 if width <= 128 else 1
+
+
+def _row_splits(n_blocks_rows, n_inner, device, block=64, per_cu=1):
     """Fewer chain blocks (`block` rows: zshmc_likelihood_plan) than compute
     units: cut the inner (data row / vocabulary) range so that about two
     workgroups land on every CU, at least 256 inner rows per slice, at most
@@ -638,8 +650,13 @@ def _row_splits(n_blocks_rows, n_inner, device, block=64):
     rows 1 213 us; profiles/r04e_row_splits_ab.txt.)"""
     n_wg = (n_blocks_rows + block - 1) // block
     cus = torch.cuda.get_device_properties(device).multi_processor_count
-    if n_wg >= cus:
+    if n_wg >= cus * per_cu:
         return 1
+    if n_wg >= cus:
+        # one wave of workgroups on a kernel that holds `per_cu` per CU: just
+        # enough slices to give every CU its partner(s) (bf16x3 at 128
+        # columns: +9 % with two resident, profiles/r05q_*)
+        return max(1, min((cus * per_cu) // n_wg, (n_inner + 127) // 128))
     # Round 5 (profiles/r05k_estep_kernel_trace.txt): at the E-step's shape a
     # transition is NOT launch-bound -- its 32-slice likelihood launches are
     # 36 us each, six 64-row tiles on the critical path of every workgroup,

@@ -245,14 +245,27 @@ __device__ __forceinline__ void mfma_drain8(f16v& acc) {
   asm volatile("s_nop 11" : "+v"(acc));
 }
 
-// The six terms of a product in issue order (A plane, B plane; 0 = hi,
-// 1 = mid, 2 = lo): the small ones first.
-constexpr int kTermA[6] = {2, 0, 1, 1, 0, 0};
-constexpr int kTermB[6] = {0, 2, 1, 0, 1, 0};
+// The six terms of a product in issue order (plane 0 = hi, 1 = mid, 2 = lo),
+// grouped by the plane of the operand that streams through LDS -- X: the A
+// operand of GEMM 1, the B operand of GEMM 2 -- so that ONE register set
+// holds it: plane p's last use in a step is term kLastUse[p], and the next
+// step's plane p is read right behind it (three to six MFMAs ahead of its
+// first use).  (A second, ping-pong set costs 12 registers: two waves per
+// SIMD at D = 128 do not have them.)
+constexpr int kTermX[6] = {0, 0, 0, 1, 1, 2};   // the streamed operand's plane
+constexpr int kTermR[6] = {0, 1, 2, 0, 1, 0};   // the register operand's plane
+constexpr int kLastUse[3] = {2, 4, 5};
+
+// Waves per SIMD the register budget is held to: two where the tile's three
+// buffers fit the LDS twice (D <= 128: 2 x 72 KB) -- one workgroup's
+// element-wise stage then runs under the other's MFMAs.
+#ifndef ZS_B3_WAVES
+#define ZS_B3_WAVES(D) ((D) <= 128 ? 2 : 1)
+#endif
 
 // ---------------------------------------------------------------------------
 template <int D, int OP, bool LL, int NACC>
-__global__ __launch_bounds__(256, 1) void linear_b3_kernel(
+__global__ __launch_bounds__(256, ZS_B3_WAVES(D)) void linear_b3_kernel(
     const float* __restrict__ W, const unsigned char* __restrict__ Ximg,
     const float* __restrict__ y, int64_t yc_rows, int64_t ldy, int64_t C,
     int64_t N, int64_t ldw, float* __restrict__ ll, float* __restrict__ gW,
@@ -416,13 +429,15 @@ __global__ __launch_bounds__(256, 1) void linear_b3_kernel(
   float Sp[16];             // the logits of the tile before
 #pragma unroll
   for (int r = 0; r < 16; ++r) Sp[r] = 0.f;
-  u4 opnd[2][3];            // operand ping-pong: A of GEMM 1 / B of GEMM 2
+  u4 opnd[3];               // the streamed operand's planes: A of GEMM 1 / B of GEMM 2
   u4 Rp[2][3];              // residual planes: [k-step][plane], A of GEMM 2
 #pragma unroll
   for (int s = 0; s < 2; ++s)
 #pragma unroll
     for (int p = 0; p < 3; ++p) Rp[s][p] = u4{0u, 0u, 0u, 0u};
-  f4 yv[4];
+  typedef float f2v __attribute__((ext_vector_type(2)));
+  f2v ypair = f2v{0.f, 0.f};   // the labels of the pair the stage works on
+  uint32_t y_addr = 0;         // the labels of tile it-1 for this lane
   const CatLane cat = cat_lane(0, 0, 0);
 
   int rows_prev = kB3Rows;   // valid rows of the tile the element-wise stage works on
@@ -455,16 +470,10 @@ __global__ __launch_bounds__(256, 1) void linear_b3_kernel(
     rows_prev = left < kB3Rows ? (int)left : kB3Rows;
     a_addr0 = sx_addr + b_cur + a_lane[0];
     a_addr1 = sx_addr + b_cur + a_lane[1];
-    opnd[0][0] = lds_u4(a_addr0, 0);
-    opnd[0][1] = lds_u4(a_addr0, kPlane);
-    opnd[0][2] = lds_u4(a_addr0, 2 * kPlane);
-    if (!(ZS_B3_SKIP & 4)) {
-      const uint32_t y_addr = sy_addr + y_prev + y_lane;
-      yv[0] = lds_f4(y_addr, 0);
-      yv[1] = lds_f4(y_addr, 32);
-      yv[2] = lds_f4(y_addr, 64);
-      yv[3] = lds_f4(y_addr, 96);
-    }
+    // (the labels of a pair -- two consecutive rows, 8 bytes -- are read by
+    // the pair's first piece: four registers of labels held per tile would
+    // not fit two waves per SIMD at D = 128)
+    y_addr = sy_addr + y_prev + y_lane;
     __builtin_amdgcn_sched_barrier(0);
   };
   // where iteration `it` sends tile it+1 (clamped to the last one: a
@@ -494,7 +503,13 @@ __global__ __launch_bounds__(256, 1) void linear_b3_kernel(
     constexpr int j0 = 2 * pr, j1 = 2 * pr + 1;
     constexpr int s = pr / 4, q = pr % 4;
     if constexpr (sub < kPre) {
-      float y0 = yv[j0 >> 2][j0 & 3], y1 = yv[j1 >> 2][j1 & 3];
+      if constexpr (sub == 0) {
+        // rows 8 (j0/4) + 4 hi + j0 % 4 and the next one
+        if (!(ZS_B3_SKIP & 4))
+          ypair = *reinterpret_cast<const ZS_LDS f2v*>(
+              (uintptr_t)(y_addr + (uint32_t)((8 * (j0 >> 2) + (j0 & 3)) * 4)));
+      }
+      float y0 = ypair[0], y1 = ypair[1];
       const int n0 = 8 * (j0 >> 2) + 4 * hi + (j0 & 3);
       const bool v0 = n0 < rows_prev, v1 = n0 + 1 < rows_prev;
       if constexpr (OP == 0 && !LL) {
@@ -631,39 +646,34 @@ __global__ __launch_bounds__(256, 1) void linear_b3_kernel(
     if constexpr (kEw) plan_b();
     static_for<KS>([&](auto kc) {
       constexpr int ks = decltype(kc)::value;
-      constexpr int cur = ks & 1, nx = cur ^ 1;
       static_for<6>([&](auto tc) {
         constexpr int term = decltype(tc)::value;
-        constexpr int pa = kTermA[term], pb = kTermB[term];
+        constexpr int pa = kTermX[term], pb = kTermR[term];
         constexpr int g = ks * 6 + term;
         constexpr bool first = ks == 0 && term < NACC;
         f16v& acc = (NACC == 2 && (term & 1)) ? Sb : Sa;
         if (!(ZS_B3_SKIP & 8)) {
         if constexpr (pb == 0) {
-          if constexpr (first) mfma_bv0(acc, opnd[cur][pa], wh[ks]);
-          else mfma_bv(acc, opnd[cur][pa], wh[ks]);
+          if constexpr (first) mfma_bv0(acc, opnd[pa], wh[ks]);
+          else mfma_bv(acc, opnd[pa], wh[ks]);
         } else if constexpr (pb == 1) {
-          mfma_ba(acc, opnd[cur][pa], wm[ks]);
+          if constexpr (first) mfma_ba0(acc, opnd[pa], wm[ks]);
+          else mfma_ba(acc, opnd[pa], wm[ks]);
         } else if constexpr (wl_agpr(ks)) {
-          if constexpr (first) mfma_ba0(acc, opnd[cur][pa], wl[ks]);
-          else mfma_ba(acc, opnd[cur][pa], wl[ks]);
+          mfma_ba(acc, opnd[pa], wl[ks]);
         } else {
-          if constexpr (first) mfma_bv0(acc, opnd[cur][pa], wl[ks]);
-          else mfma_bv(acc, opnd[cur][pa], wl[ks]);
+          mfma_bv(acc, opnd[pa], wl[ks]);
         }
         }
-        // gaps 0-2: the next k-step's operand planes in the order it
-        // consumes them (lo, hi, mid) -- behind the last k-step GEMM 2's
-        // first (hi, mid, lo)
-        if constexpr (term < 3) {
+        // behind a plane's last use: the next k-step's plane -- behind the
+        // last k-step GEMM 2's first operand
+        if constexpr (term == kLastUse[pa]) {
           if constexpr (ks + 1 < KS) {
             constexpr int P = (ks + 1) >> 1;
-            constexpr int pl = kTermA[term];
-            opnd[nx][pl] = lds_u4(((ks + 1) & 1) ? a_addr1 : a_addr0,
-                                  pl * kPlane + P * 2048);
+            opnd[pa] = lds_u4(((ks + 1) & 1) ? a_addr1 : a_addr0,
+                              pa * kPlane + P * 2048);
           } else if constexpr (kEw) {
-            static_assert(nx == 0, "GEMM 2's step 0 reads from slot 0");
-            opnd[0][term] = read_b(c0, tc);
+            opnd[pa] = read_b(c0, template_int<pa>{});
           }
         }
         if constexpr (ZS_B3_DMA_IN_GEMM1 && kEw && term == 3 && ks <= kDma)
@@ -674,7 +684,6 @@ __global__ __launch_bounds__(256, 1) void linear_b3_kernel(
       });
     });
   };
-  static_assert(KS % 2 == 0, "the last k-step of GEMM 1 uses operand slot 1");
 
   // logits of the tile GEMM 1 just finished -> Sp (the accumulators are free
   // for the next GEMM 1); placed where its last MFMA is long done
@@ -703,15 +712,21 @@ __global__ __launch_bounds__(256, 1) void linear_b3_kernel(
     static_for<kSteps>([&](auto stc) {
       constexpr int st = decltype(stc)::value;
       constexpr int s = st / NB, nb = st % NB;
-      constexpr int cur = st & 1, nx = cur ^ 1;
       if constexpr (st == kSteps - 1) boundary(it);
       static_for<6>([&](auto tc) {
         constexpr int term = decltype(tc)::value;
-        constexpr int pa = kTermA[term], pb = kTermB[term];
+        constexpr int pb = kTermX[term], pa = kTermR[term];
         constexpr int g = st * 6 + term;
-        if (!(ZS_B3_SKIP & 16)) mfma_g(G[nb], Rp[s][pa], opnd[cur][pb]);
-        if constexpr (st + 1 < kSteps && term < 3)
-          opnd[nx][term] = read_b(template_int<st + 1>{}, tc);
+        if (!(ZS_B3_SKIP & 16)) mfma_g(G[nb], Rp[s][pa], opnd[pb]);
+        // behind a plane's last use: the next step's plane -- behind the last
+        // step's the A operand of the next iteration's GEMM 1 (the boundary
+        // in front of this step has rotated the buffers)
+        if constexpr (term == kLastUse[pb]) {
+          if constexpr (st + 1 < kSteps)
+            opnd[pb] = read_b(template_int<st + 1>{}, template_int<pb>{});
+          else
+            opnd[pb] = lds_u4(a_addr0, pb * kPlane);
+        }
         if constexpr (!(ZS_B3_DMA_IN_GEMM1) && g < kHalfGaps && g >= 1 &&
                       (g - 1) % kEvery == 0 && (g - 1) / kEvery <= kDma)
           dma_step(template_int<(g - 1) / kEvery>{});
@@ -729,9 +744,9 @@ __global__ __launch_bounds__(256, 1) void linear_b3_kernel(
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     a_addr0 = sx_addr + b_cur + a_lane[0];
     a_addr1 = sx_addr + b_cur + a_lane[1];
-    opnd[0][0] = lds_u4(a_addr0, 0);
-    opnd[0][1] = lds_u4(a_addr0, kPlane);
-    opnd[0][2] = lds_u4(a_addr0, 2 * kPlane);
+    opnd[0] = lds_u4(a_addr0, 0);
+    opnd[1] = lds_u4(a_addr0, kPlane);
+    opnd[2] = lds_u4(a_addr0, 2 * kPlane);
     plan_dma(0);
     static_for<kDma + 1>([&](auto ic) { dma_step(ic); });
     __builtin_amdgcn_sched_barrier(0);
@@ -740,6 +755,10 @@ __global__ __launch_bounds__(256, 1) void linear_b3_kernel(
     if constexpr (NACC == 2) mfma_drain8(Sb);
     take_logits();
     boundary(0);
+    opnd[0] = lds_u4(a_addr0, 0);
+    opnd[1] = lds_u4(a_addr0, kPlane);
+    opnd[2] = lds_u4(a_addr0, 2 * kPlane);
+    __builtin_amdgcn_sched_barrier(0);
     // iterations 1 .. T: GEMM 1 of tile `it` (of the last tile once more, unused,
     // in iteration T) around the element-wise stage of tile it-1, then GEMM 2
     // of tile it-1.  Nothing in the loop is conditional: the accumulators do
@@ -810,11 +829,14 @@ static int launch_b3(const float* W, const unsigned char* Ximg, const float* y,
                      float* workspace, int doc_major) {
   constexpr int kTile = 3 * (D / 32) * 2048;
   const size_t lds = (size_t)3 * kTile + 3 * 128;
+  // accumulator chains of GEMM 1: two cost 16 registers and buy nothing
+  // measurable (dependent 32x32x16 MFMAs issue back to back); one where two
+  // waves per SIMD need the registers
 #ifndef ZS_B3_NACC
-#define ZS_B3_NACC 2
+#define ZS_B3_NACC(D) ((D) <= 128 ? 1 : 2)
 #endif
-  auto kll = linear_b3_kernel<D, OP, true, ZS_B3_NACC>;
-  auto kg = linear_b3_kernel<D, OP, false, ZS_B3_NACC>;
+  auto kll = linear_b3_kernel<D, OP, true, ZS_B3_NACC(D)>;
+  auto kg = linear_b3_kernel<D, OP, false, ZS_B3_NACC(D)>;
   static bool attr = false;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute(

@@ -215,7 +215,11 @@ class _DenseLikelihoodPlan(_PlanBase):
         if self.inner_image is None and self.kind != 'linear_categorical':
             self.block = ops.likelihood_plan(self.width)[1]
         R = self.lik_rows
-        self.splits = ops._row_splits(R, n_inner, self.device, self.block)
+        per_cu = 1 if self.kind == 'linear_categorical' else \
+            ops.resident_per_cu(self.width, 'bf16x3' if self.inner_image
+                                is not None else 'fp32')
+        self.splits = ops._row_splits(R, n_inner, self.device, self.block,
+                                      per_cu)
         # (chain blocks x slices resident at once where the chain blocks
         # alone are: the trips then run from one cooperative launch)
         n_wg = (R + self.block - 1) // self.block
