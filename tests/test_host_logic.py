@@ -619,3 +619,55 @@ def test_native_plan_recognises_the_softmax_regression_spellings(monkeypatch):
     # 40 classes: the lazy likelihood is there, the kernel's limit is not
     hmc, p = plan_of(lambda w: X.unsqueeze(0) @ w.transpose(-1, -2), 40)
     assert p is None and '40' in hmc._refusal[0]
+
+
+def test_csr_segments_cover_every_row_once():
+    """_ops._csr_segments (the pair list of zshmc_gather_dot_normal_lik_grad):
+    every latent row has at least one segment -- rows without pairs an empty
+    one --, no segment is longer than GD_SEGMENT_PAIRS, consecutive segments
+    are consecutive CSR slots, and a row's segments are contiguous."""
+    import torch
+    from zhusuan_amd import _ops
+    rng = np.random.RandomState(0)
+    n_rows = 37
+    counts = rng.poisson(120, size=n_rows)
+    counts[[3, 9]] = 0
+    counts[5] = 700                       # three segments
+    counts[20] = _ops.GD_SEGMENT_PAIRS    # exactly one full segment
+    seg = torch.zeros(n_rows + 1, dtype=torch.int32)
+    seg[1:] = torch.cumsum(torch.tensor(counts), 0).to(torch.int32)
+    E = int(counts.sum())
+    sp, sr, sf, lr = _ops._csr_segments(seg, E)
+    sp, sr, sf, lr = (t.numpy() for t in (sp, sr, sf, lr))
+    assert sp[0] == 0 and sp[-1] == E and (np.diff(sp) >= 0).all()
+    assert np.diff(sp).max() <= _ops.GD_SEGMENT_PAIRS
+    assert (np.diff(sr) >= 0).all() and set(sr) == set(range(n_rows))
+    for i in range(n_rows):
+        mine = np.nonzero(sr == i)[0]
+        assert mine[0] == sf[i] and (np.diff(mine) == 1).all()
+        assert sp[mine[0]] == seg[i] and sp[mine[-1] + 1] == seg[i + 1]
+    assert list(lr) == [5]
+    assert len(sr) == n_rows + 2
+
+
+def test_row_range_slices_policy(monkeypatch):
+    """_ops._row_splits: no slices once the chain blocks fill the device's
+    resident slots; otherwise about two workgroups per CU, slices of at least
+    two 64-row tiles, at most 256; a kernel that holds two workgroups per CU
+    gets its partner from slices when the chain blocks are one wave."""
+    import types
+    import torch
+    from zhusuan_amd import _ops
+    monkeypatch.setattr(torch.cuda, 'get_device_properties',
+                        lambda d: types.SimpleNamespace(multi_processor_count=256))
+    f = _ops._row_splits
+    assert f(32768, 10 ** 6, None, 64) == 1              # 512 blocks
+    assert f(100, 12419, None, 64) == 98                 # the E-step: 2 blocks
+    assert f(100, 200, None, 64) == 2                    # short inner range
+    assert f(64 * 300, 10 ** 6, None, 64) == 1
+    assert f(128 * 256, 10 ** 6, None, 128, per_cu=2) == 2   # bf16x3, 128 columns
+    assert f(128 * 256, 10 ** 6, None, 128, per_cu=1) == 1
+    assert f(64, 10 ** 6, None, 64) == 256
+    assert _ops.resident_per_cu(128, 'bf16x3') == 2
+    assert _ops.resident_per_cu(256, 'bf16x3') == 1
+    assert _ops.resident_per_cu(64) == 3 and _ops.resident_per_cu(512) == 1
