@@ -5,6 +5,8 @@ Forward and backward both run the hand-written HIP kernels
 the tape that chains these ops with whatever deterministic torch ops the user
 model contains (tf.gradients, reference hmc.py:430-432).
 """
+import os
+
 import torch
 
 from .utils import broadcast_shapes
@@ -663,7 +665,12 @@ def _row_splits(n_blocks_rows, n_inner, device, block=64, per_cu=1):
     # and the one-thread-per-element serial reduction of the partials 9 us.
     # With the partials added eight loads at a time (sum_parts8) finer slices
     # pay: two tiles (128 rows) per slice, about two workgroups per CU.
-    return max(1, min(256, (2 * cus) // n_wg, (n_inner + 127) // 128))
+    # (E-step, gpurun r05: 256 rows per slice 0.743 ms per transition, 128
+    # rows 0.639, 64 rows 0.792 -- the reduction and a second round of
+    # workgroups eat the shorter critical path; ZSHMC_MIN_SLICE_ROWS for A/B)
+    min_rows = int(os.environ.get('ZSHMC_MIN_SLICE_ROWS', '128'))
+    return max(1, min(256, (2 * cus) // n_wg,
+                      (n_inner + min_rows - 1) // min_rows))
 
 
 class LinearBernoulliLogLik(_Function):
