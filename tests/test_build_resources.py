@@ -330,3 +330,70 @@ def test_nothing_heavy_sits_between_two_tiles(lb_build, mid_build):
             r'(s_mul_hi_u32|v_mul_hi_u32|v_cmp_\w+_[iu]64|v_mad_u64_u32)', l)]
         assert not heavy, (width, op, heavy)
         assert len(top) <= 90, (width, op, len(top))
+
+
+# -- the bf16x3 likelihood kernel (csrc/linear_bf16x3.hip) ---------------------
+@pytest.fixture(scope='module')
+def b3_build(tmp_path_factory):
+    out = tmp_path_factory.mktemp('b3asm')
+    import __graft_entry__ as ge
+    src = os.path.join(ROOT, 'zhusuan_amd', 'csrc', 'linear_bf16x3.hip')
+    cmd = [_hipcc()] + ge.HIPCC_FLAGS + [
+        '-c', src, '-save-temps', '-Rpass-analysis=kernel-resource-usage',
+        '-o', str(out / 'b3.o')]
+    p = subprocess.run(cmd, cwd=str(out), stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, universal_newlines=True)
+    assert p.returncode == 0, p.stdout[-4000:]
+    asm = [f for f in os.listdir(str(out)) if f.endswith('gfx950.s')]
+    return p.stdout, open(os.path.join(str(out), asm[0])).read()
+
+
+def _b3_bodies(asm):
+    """name -> text of each linear_b3_kernel instantiation."""
+    out = {}
+    for m in re.finditer(r'^(_ZN5zshmc16linear_b3_kernelILi\d+ELi\dELb[01]E'
+                         r'Li\dEEE\w+):[^\n]*\n(.*?)s_endpgm', asm,
+                         re.S | re.M):
+        out[m.group(1)] = m.group(2)
+    return out
+
+
+def test_bf16x3_kernels_keep_their_registers_and_occupancy(b3_build):
+    """Two waves per SIMD (two workgroups per CU) at <= 128 columns, one
+    above; whatever hipcc parks in scratch is parked AROUND the tile loop
+    (epilogue addresses), never inside it: the loop's DMA waits are
+    `s_waitcnt vmcnt(0)` and a scratch access would sit in the same queue."""
+    remarks, asm = b3_build
+    table = {k: v for k, v in _kernels(remarks).items()
+             if 'linear_b3_kernelILi' in k}
+    # 4 widths x 2 families x {ll+grad, grad only}
+    assert len(table) == 16, sorted(table)
+    for name, row in table.items():
+        width = int(re.search(r'kernelILi(\d+)E', name).group(1))
+        assert row['Occupancy [waves/SIMD]'] >= (2 if width <= 128 else 1), \
+            (name, row)
+        grad_only = re.search(r'ELi\dELb0E', name) is not None
+        if width >= 192 or (width <= 128 and grad_only and 'ELi0ELb0' in name):
+            assert row['VGPRs Spill'] == 0, (name, row)
+        assert row['VGPRs Spill'] <= 12, (name, row)
+    bodies = _b3_bodies(asm)
+    assert len(bodies) == 16
+    for name, body in bodies.items():
+        # the tile loop: the backward branch with the most MFMAs in its body
+        loops = []
+        for m in re.finditer(r's_cbranch_\w+ (\.LBB\d+_\d+)\n', body):
+            at = body.find('\n' + m.group(1) + ':')
+            if 0 <= at < m.start():                      # a backward branch
+                loops.append(body[at:m.start()])
+        loop = max(loops, key=lambda t: t.count('v_mfma'))
+        width = int(re.search(r'kernelILi(\d+)E', name).group(1))
+        # GEMM 1: 6 terms x D/16 k-steps; GEMM 2: 6 terms x 2 x D/32 blocks
+        assert loop.count('v_mfma_f32_32x32x16_bf16') == 12 * (width // 16), \
+            (name, loop.count('v_mfma'))
+        assert 'scratch_' not in loop, name
+        assert loop.count('s_barrier') == 1, name          # ONE per tile
+        # no operand shuffling between the register files inside the loop
+        assert 'v_accvgpr_read' not in loop and 'v_accvgpr_write' not in loop \
+            and 'v_accvgpr_mov' not in loop, name
+        # the transposing read feeds GEMM 2: two per plane and step
+        assert loop.count('ds_read_b64_tr_b16') == 6 * 2 * (width // 32), name

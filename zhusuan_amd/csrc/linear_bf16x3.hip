@@ -30,13 +30,20 @@
 // read in any order) follows: slot i of lane half h is row 8 (i/4) + 4 h +
 // i%4 on both sides.  The residual never crosses lanes.
 //
-// A workgroup = 4 waves x 32 chains on the SAME 32-row tile (one wave per
-// SIMD: W planes 3 D/8 registers, gradient accumulators D/2).  The tile loop
-// is software-pipelined over THREE LDS buffers with one barrier per tile:
-//   iteration t:  barrier | DMA X(t+1) | GEMM 1 (t) with the element-wise
-//                 stage of tile t-1 in its issue gaps | GEMM 2 (t-1)
-// (a bf16 MFMA leaves ~5 issue slots per 32 clocks and -- unlike the fp32
-// MFMA, which runs on the vector ALUs -- a wave's VALU work runs under it).
+// A workgroup = 4 waves x 32 chains on the SAME 32-row tile (W planes 3 D/8
+// registers, gradient accumulators D/2: one wave per SIMD at 192 / 256
+// columns, two -- two workgroups per CU -- at <= 128).  The tile loop is
+// software-pipelined over THREE LDS buffers with one barrier per tile:
+//   iteration t:  GEMM 1 (t), the first pairs of the element-wise stage of
+//                 tile t-1 in its issue gaps
+//                 GEMM 2 (t-1), k-step-major: the rest of the stage (and, at
+//                 <= 128 columns, the DMA of tile t+1) in its first half; the
+//                 barrier, the buffer rotation and the first operand reads
+//                 of iteration t+1 in front of / under its last six MFMAs
+// A bf16 MFMA leaves ~5 issue slots per 32 clocks; a wave's VALU work is only
+// PARTLY hidden under its own MFMAs (the stage costs ~600 clocks per tile
+// wherever it rides, profiles/r05g_b3_phase_split.txt) -- a second resident
+// workgroup hides the rest.
 // Roofline: bf16 MFMA; algorithmic flops 4*N*D*C per call, issued 6x.
 #include <stdlib.h>
 
@@ -58,7 +65,7 @@ constexpr int kB3Chains = 128;  // chains per workgroup
 // Timing experiments only (wrong results): bit 0 no element-wise stage, bit 1
 // no tile DMA in the loop, bit 2 no label DMA / reads, bit 3 no GEMM 1,
 // bit 4 no GEMM 2, bit 5 no `s_nop 1` in front of the MFMAs
-// (tools/build_b3_variants.sh; profiles/r05*_b3_where_the_clocks_go.txt).
+// (tools/build_b3_variants.sh; profiles/r05g_b3_phase_split.txt).
 #ifndef ZS_B3_SKIP
 #define ZS_B3_SKIP 0
 #endif
