@@ -340,7 +340,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense, /opt/skills/guides/MI355X_MICROARCH.md
 
 
 def _b3_roofline(width, kern_ms, flop_eval, n_evals, ms_transition):
-    """The same launches on the bf16x3 kernels (csrc/linear_bf16x3.hip): every
+    """The same launches on the bf16x3 kernels (csrc/b3_kernel.h): every
     float32 operand as three bfloat16 planes, a product = six bf16 MFMAs with
     float32 accumulation.  `achieved` counts the ALGORITHMIC (float32-
     equivalent) flops 4 N D C; the matrix cores issue six times that.  Two

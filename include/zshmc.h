@@ -664,14 +664,15 @@ int zshmc_linear_bernoulli_log_lik(const float* W, const float* X,
                                    float* workspace, void* stream);
 
 /* ------------------------------------------------------------------------
- * ABI 0.5.0 -- the same Bernoulli / mixture-multinomial likelihoods on the
- * BF16 matrix cores with float32-level results (csrc/linear_bf16x3.hip):
+ * ABI 0.5.0 -- the same Bernoulli / mixture-multinomial / Categorical
+ * likelihoods on the BF16 matrix cores with float32-level results (csrc/b3_kernel.h):
  * every float32 operand is split into three bfloat16 planes (hi + mid + lo =
  * the value exactly) and a product is the six terms hi*hi, hi*mid, mid*hi,
  * hi*lo, lo*hi, mid*mid on v_mfma_f32_32x32x16_bf16 with float32
  * accumulation; what is dropped is <= 2^-24 relative.  Same formulas, same
- * reference lines (univariate.py:398-403, multivariate.py:435-443,
- * hmc.py:430-432) and same argument meaning as the fp32 entry points, except:
+ * reference lines (univariate.py:398-403, univariate.py:496-548,
+ * multivariate.py:435-443, hmc.py:430-432) and same argument meaning as the
+ * fp32 entry points, except:
  *   X_image / phi_image  the constant operand as a tile image, made once per
  *          tensor version by zshmc_bf16x3_split from X [n_rows, ldx] (the
  *          first `width` columns; width 64 / 128 / 192 / 256 = the fp32
@@ -695,6 +696,13 @@ int zshmc_linear_multinomial_log_lik_bf16x3(
     int64_t count_rows, int64_t count_stride, int64_t n_rows, int64_t n_vocab,
     int64_t n_topics, float* log_lik, float* grad_theta, int n_splits,
     float* workspace, void* stream);
+/* (declared here, described with zshmc_linear_categorical_log_lik below:
+ * W rows are (chain, class) pairs at `class_stride` rows per chain) */
+int zshmc_linear_categorical_log_lik_bf16x3(
+    const float* W, const void* X_image, const float* labels, int64_t n_cols,
+    int64_t n_rows, int64_t n_features, int n_classes, int class_stride,
+    float* log_lik, float* grad_w, int n_splits, float* workspace,
+    void* stream);
 
 /* ------------------------------------------------------------------------
  * Fused dense-logit Categorical likelihood on the fp32 matrix cores (softmax

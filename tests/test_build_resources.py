@@ -332,27 +332,40 @@ def test_nothing_heavy_sits_between_two_tiles(lb_build, mid_build):
         assert len(top) <= 90, (width, op, len(top))
 
 
-# -- the bf16x3 likelihood kernel (csrc/linear_bf16x3.hip) ---------------------
+# -- the bf16x3 likelihood kernel (csrc/b3_kernel.h) ---------------------------
+# two translation units: Bernoulli / multinomial, and the Categorical family
+# (one kernel per class stride)
+def _b3_compile(out, name):
+    import __graft_entry__ as ge
+    src = os.path.join(ROOT, 'zhusuan_amd', 'csrc', name + '.hip')
+    cmd = [_hipcc()] + ge.HIPCC_FLAGS + [
+        '-c', src, '-save-temps', '-Rpass-analysis=kernel-resource-usage',
+        '-o', str(out / (name + '.o'))]
+    return subprocess.Popen(cmd, cwd=str(out), stdout=subprocess.PIPE,
+                            stderr=subprocess.STDOUT, universal_newlines=True)
+
+
 @pytest.fixture(scope='module')
 def b3_build(tmp_path_factory):
     out = tmp_path_factory.mktemp('b3asm')
-    import __graft_entry__ as ge
-    src = os.path.join(ROOT, 'zhusuan_amd', 'csrc', 'linear_bf16x3.hip')
-    cmd = [_hipcc()] + ge.HIPCC_FLAGS + [
-        '-c', src, '-save-temps', '-Rpass-analysis=kernel-resource-usage',
-        '-o', str(out / 'b3.o')]
-    p = subprocess.run(cmd, cwd=str(out), stdout=subprocess.PIPE,
-                       stderr=subprocess.STDOUT, universal_newlines=True)
-    assert p.returncode == 0, p.stdout[-4000:]
-    asm = [f for f in os.listdir(str(out)) if f.endswith('gfx950.s')]
-    return p.stdout, open(os.path.join(str(out), asm[0])).read()
+    procs = [_b3_compile(out, n) for n in ('linear_bf16x3',
+                                           'linear_bf16x3_cat')]
+    remarks = ''
+    for p in procs:
+        text = p.communicate()[0]
+        assert p.returncode == 0, text[-4000:]
+        remarks += text
+    asm = ''.join(open(os.path.join(str(out), f)).read()
+                  for f in sorted(os.listdir(str(out)))
+                  if f.endswith('gfx950.s'))
+    return remarks, asm
 
 
 def _b3_bodies(asm):
-    """name -> text of each linear_b3_kernel instantiation."""
+    """name -> text of each linear_b3_kernel<D, OP, LL, NACC, GL>."""
     out = {}
     for m in re.finditer(r'^(_ZN5zshmc16linear_b3_kernelILi\d+ELi\dELb[01]E'
-                         r'Li\dEEE\w+):[^\n]*\n(.*?)s_endpgm', asm,
+                         r'Li\dELi\dEEE\w+):[^\n]*\n(.*?)s_endpgm', asm,
                          re.S | re.M):
         out[m.group(1)] = m.group(2)
     return out
@@ -366,8 +379,9 @@ def test_bf16x3_kernels_keep_their_registers_and_occupancy(b3_build):
     remarks, asm = b3_build
     table = {k: v for k, v in _kernels(remarks).items()
              if 'linear_b3_kernelILi' in k}
-    # 4 widths x 2 families x {ll+grad, grad only}
-    assert len(table) == 16, sorted(table)
+    # 4 widths x {ll+grad, grad only} x (Bernoulli, multinomial, the
+    # Categorical at class strides 1 .. 32)
+    assert len(table) == 8 * (2 + 6), sorted(table)
     for name, row in table.items():
         width = int(re.search(r'kernelILi(\d+)E', name).group(1))
         assert row['Occupancy [waves/SIMD]'] >= (2 if width <= 128 else 1), \
@@ -377,7 +391,7 @@ def test_bf16x3_kernels_keep_their_registers_and_occupancy(b3_build):
             assert row['VGPRs Spill'] == 0, (name, row)
         assert row['VGPRs Spill'] <= 12, (name, row)
     bodies = _b3_bodies(asm)
-    assert len(bodies) == 16
+    assert len(bodies) == 64
     for name, body in bodies.items():
         # the tile loop: the backward branch with the most MFMAs in its body
         loops = []

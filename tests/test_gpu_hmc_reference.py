@@ -35,7 +35,7 @@ def env():
 # still reproduce the traces
 # `bf16x3`: the literal spelling on the native plan with the likelihood on
 # the bf16 matrix cores (HMC(likelihood_arithmetic='bf16x3'),
-# csrc/linear_bf16x3.hip) -- the same traces at the same tolerances
+# csrc/b3_kernel.h) -- the same traces at the same tolerances
 VARIANTS = {'blr': ('native', 'generic', 'dense', 'nearmiss', 'bf16x3'),
             'lntm': ('native', 'generic', 'dense', 'nearmiss', 'bf16x3'),
             # the packed native plan: three latents in one row of 16 floats
@@ -45,8 +45,9 @@ VARIANTS = {'blr': ('native', 'generic', 'dense', 'nearmiss', 'bf16x3'),
             # north_star's third likelihood: X @ w^T under a Categorical --
             # the reference's literal spelling and zs.linear_class_logits on
             # the native plan (fp32-MFMA, csrc/lb_ops.h), the generic plan,
-            # and a near miss
-            'softmax_reg': ('dense', 'native', 'generic', 'nearmiss'),
+            # a near miss, and the native plan on the bf16x3 kernel
+            'softmax_reg': ('dense', 'native', 'generic', 'nearmiss',
+                            'bf16x3'),
             'pmf': ('fused', 'dense', 'generic')}
 
 

@@ -1,4 +1,4 @@
-"""GPU parity of the bf16x3 likelihood kernels (csrc/linear_bf16x3.hip: three
+"""GPU parity of the bf16x3 likelihood kernels (csrc/b3_kernel.h: three
 bfloat16 planes per float32 operand, six bf16 MFMAs per product, float32
 accumulation) against a float64 restatement of Bernoulli._log_prob
 (reference zhusuan/distributions/univariate.py:398-403) /
@@ -47,7 +47,7 @@ def _bf16_planes(x):
 
 def test_split_image_matches_the_layout_in_the_header(env):
     """zshmc_bf16x3_split against a NumPy restatement of the image layout
-    (include/zshmc.h, csrc/linear_bf16x3.hip: b3_chunk): bit for bit."""
+    (include/zshmc.h, csrc/b3_kernel.h: b3_chunk): bit for bit."""
     torch, _capi, dev = env
     rng = np.random.RandomState(0)
     N, D = 77, 128
@@ -240,6 +240,150 @@ def test_multinomial_matches_float64_reference(env, n_chains, n_docs, V, K,
                                    atol=2e-5 * V)
     np.testing.assert_allclose(g.cpu().numpy(), g_ref, rtol=1e-4,
                                atol=2e-5 * (np.abs(g_ref).max() + 1))
+
+
+# ---- Categorical (OP 2): rows of W are (chain, class) pairs ----------------
+def _cat_ref(w, X, y):
+    """ll [C], d ll / d w [C, K, F] in float64 (univariate.py:496-548 on
+    materialised logits; hmc.py:430-432)."""
+    w, X = w.astype(np.float64), X.astype(np.float64)
+    logits = np.einsum('nf,ckf->cnk', X, w)
+    m = logits.max(-1, keepdims=True)
+    lse = m[..., 0] + np.log(np.exp(logits - m).sum(-1))
+    ll = (np.take_along_axis(logits, y[None, :, None].astype(np.int64),
+                             -1)[..., 0] - lse).sum(-1)
+    res = -np.exp(logits - lse[..., None])
+    res[:, np.arange(len(y)), y] += 1.0
+    return ll, np.einsum('cnk,nf->ckf', res, X)
+
+
+def _call_cat(torch, _capi, dev, w, X, y, G, D, want_ll, n_splits=1,
+              fp32=False):
+    """w [C, K, F] -> the kernel's operand [C * G, D] (padding classes and
+    columns zero); returns ll [C, G], grad [C, G, D]."""
+    C, K, F = w.shape
+    N = X.shape[0]
+    Wp = np.zeros((C, G, D), np.float32)
+    Wp[:, :K, :F] = w
+    Xp = np.zeros((N, D), np.float32)
+    Xp[:, :F] = X
+    Wt, Xt = torch.tensor(Wp, device=dev), torch.tensor(Xp, device=dev)
+    yt = torch.tensor(y.astype(np.float32), device=dev)
+    ll = torch.full((C * G,), float('nan'), device=dev) if want_ll else None
+    g = torch.full((C * G, D), float('nan'), device=dev)
+    ws = torch.empty(n_splits * C * G * (D + 1), device=dev) \
+        if n_splits > 1 else None
+    s = _capi.current_stream()
+    if fp32:
+        _capi.call('zshmc_linear_categorical_log_lik', Wt.data_ptr(),
+                   Xt.data_ptr(), yt.data_ptr(), C * G, N, D, K, G,
+                   _capi.ptr(ll), g.data_ptr(), n_splits, _capi.ptr(ws), s)
+    else:
+        img = _image(torch, _capi, Xt, D)
+        _capi.call('zshmc_linear_categorical_log_lik_bf16x3', Wt.data_ptr(),
+                   img.data_ptr(), yt.data_ptr(), C * G, N, D, K, G,
+                   _capi.ptr(ll), g.data_ptr(), n_splits, _capi.ptr(ws), s)
+    torch.cuda.synchronize()
+    return (ll.cpu().numpy().reshape(C, G) if want_ll else None), \
+        g.cpu().numpy().reshape(C, G, D)
+
+
+def _cat_data(C, K, F, N, seed):
+    rng = np.random.RandomState(seed)
+    X = rng.normal(size=(N, F)).astype(np.float32)
+    w = (rng.normal(size=(C, K, F)) / np.sqrt(F)).astype(np.float32)
+    w[0] *= 30.0                       # one chain with |logits| ~ 30
+    y = rng.randint(0, K, size=N).astype(np.int32)
+    return X, y, w
+
+
+# every class stride 1 .. 32 with and without padding classes, every width,
+# ragged 128-row blocks and 32-row tiles
+@pytest.mark.parametrize('C,K,G,F,D,N', [
+    (10, 4, 4, 5, 64, 30),        # the reference trace's shape
+    (70, 2, 2, 64, 64, 130),
+    (33, 3, 4, 17, 64, 257),      # a padding class, padding columns
+    (40, 10, 16, 100, 128, 515),  # MNIST-like class count
+    (24, 16, 16, 128, 128, 300),
+    (20, 8, 8, 150, 192, 333),
+    (9, 32, 32, 256, 256, 96),    # a full half-wave of classes
+    (5, 20, 32, 200, 256, 1000),  # 12 padding classes
+    (130, 5, 8, 8, 64, 64),
+    (300, 1, 1, 30, 64, 50),      # one class: log-lik 0, gradient 0
+])
+@pytest.mark.parametrize('want_ll', [True, False])
+def test_categorical_matches_float64_reference(env, C, K, G, F, D, N, want_ll):
+    torch, _capi, dev = env
+    X, y, w = _cat_data(C, K, F, N, seed=C * 1000 + K)
+    ll, g = _call_cat(torch, _capi, dev, w, X, y, G, D, want_ll)
+    ll_ref, g_ref = _cat_ref(w, X, y)
+    if want_ll:
+        # (tests/test_gpu_linear_categorical.py's tolerances)
+        scale = np.abs(ll_ref).max()
+        np.testing.assert_allclose(ll.sum(-1), ll_ref, rtol=2e-6,
+                                   atol=2e-6 * scale + 1e-4)
+        assert np.abs(ll[:, K:]).max(initial=0.0) == 0.0
+    gs = np.abs(g_ref).max()
+    np.testing.assert_allclose(g[:, :K, :F], g_ref, rtol=0,
+                               atol=2e-5 * gs + 1e-5)
+    # padding classes and padding columns: exact zeros
+    assert np.abs(g[:, K:]).max(initial=0.0) == 0.0
+    assert np.abs(g[:, :, F:]).max(initial=0.0) == 0.0
+
+
+def test_categorical_is_as_close_to_float64_as_the_fp32_kernel(env):
+    torch, _capi, dev = env
+    C, K, G, F, D, N = 64, 10, 16, 128, 128, 20000
+    X, y, w = _cat_data(C, K, F, N, seed=7)
+    ll_ref, g_ref = _cat_ref(w, X, y)
+    ll3, g3 = _call_cat(torch, _capi, dev, w, X, y, G, D, True)
+    ll1, g1 = _call_cat(torch, _capi, dev, w, X, y, G, D, True, fp32=True)
+    e3 = np.abs(g3[:, :K] - g_ref).max() / np.abs(g_ref).max()
+    e1 = np.abs(g1[:, :K] - g_ref).max() / np.abs(g_ref).max()
+    l3 = np.abs(ll3.sum(-1) - ll_ref).max()
+    l1 = np.abs(ll1.sum(-1) - ll_ref).max()
+    print('categorical gradient max rel err: bf16x3 %.2e fp32 %.2e; log-lik '
+          'max abs err: bf16x3 %.2e fp32 %.2e (of %.0f)' % (
+              e3, e1, l3, l1, np.abs(ll_ref).max()))
+    assert e3 < 2 * e1 + 1e-7
+    assert l3 < 2 * l1 + 1e-3
+
+
+def test_categorical_row_splits_and_bit_stability(env):
+    torch, _capi, dev = env
+    C, K, G, F, D, N = 8, 10, 16, 100, 128, 6000
+    X, y, w = _cat_data(C, K, F, N, seed=1)
+    ll_ref, g_ref = _cat_ref(w, X, y)
+    a = _call_cat(torch, _capi, dev, w, X, y, G, D, True, n_splits=4)
+    b = _call_cat(torch, _capi, dev, w, X, y, G, D, True, n_splits=4)
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+    np.testing.assert_allclose(a[0].sum(-1), ll_ref, rtol=2e-6,
+                               atol=2e-6 * np.abs(ll_ref).max() + 1e-4)
+    np.testing.assert_allclose(a[1][:, :K, :F], g_ref, rtol=0,
+                               atol=2e-5 * np.abs(g_ref).max() + 1e-5)
+
+
+def test_categorical_refuses_what_the_kernel_does_not_take(env):
+    torch, _capi, dev = env
+    t = torch.zeros(128 * 512, device=dev)
+    img = torch.zeros(6 * 32 * 512, dtype=torch.uint8, device=dev)
+
+    def call(n_cols, n_rows, D, K, G, grad=True):
+        _capi.call('zshmc_linear_categorical_log_lik_bf16x3', t.data_ptr(),
+                   img.data_ptr(), t.data_ptr(), n_cols, n_rows, D, K, G,
+                   t.data_ptr(), t.data_ptr() if grad else None, 1, None,
+                   _capi.current_stream())
+    with pytest.raises(_capi.ZshmcError, match='power of two'):
+        call(12, 4, 64, 3, 3)
+    with pytest.raises(_capi.ZshmcError, match='power of two'):
+        call(64, 4, 64, 40, 64)
+    with pytest.raises(_capi.ZshmcError, match='bad shape'):
+        call(10, 4, 64, 4, 4)          # columns not whole chains
+    with pytest.raises(_capi.ZshmcError, match='bad shape'):
+        call(16, 4, 320, 4, 4)         # a width of the fp32 kernels only
+    with pytest.raises(_capi.ZshmcError, match='null pointer'):
+        call(16, 4, 64, 4, 4, grad=False)
 
 
 def test_hmc_on_bf16x3_run_many_equals_a_loop_of_runs(env):

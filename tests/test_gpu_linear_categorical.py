@@ -228,10 +228,14 @@ def _oracle_model(X, y, std):
     return lj, grad
 
 
+@pytest.mark.parametrize('arith', ['fp32', 'bf16x3'])
 @pytest.mark.parametrize('C,K,F,N', [(48, 4, 5, 60), (40, 10, 20, 200),
                                      (36, 3, 64, 150), (20, 7, 300, 120)])
-def test_native_plan_follows_the_oracle_and_the_generic_plan(env, C, K, F, N):
+def test_native_plan_follows_the_oracle_and_the_generic_plan(env, C, K, F, N,
+                                                             arith):
     zs, torch, dev = env
+    if arith == 'bf16x3' and F > 256:
+        pytest.skip('the bf16x3 kernels take <= 256 columns')
     X, y, w0 = _softmax_problem(C, K, F, N, seed=K * 100 + F)
     Xt, yt = torch.tensor(X, device=dev), torch.tensor(y, device=dev)
 
@@ -247,12 +251,13 @@ def test_native_plan_follows_the_oracle_and_the_generic_plan(env, C, K, F, N):
         q = torch.tensor(w0, device=dev)
         hmc = zs.HMC(step_size=0.01, n_leapfrogs=5, adapt_step_size=True,
                      adapt_mass=True, mass_collect_iters=2, seed=21,
-                     native_plans=native)
+                     native_plans=native, likelihood_arithmetic=arith)
         op, info = hmc.sample(model(), {'y': yt}, {'w': q})
         return hmc, op, info, q
 
     hmc, op, info, q = sampler(True)
     assert hmc.plan_kind == 'linear_categorical', hmc.plan_reason
+    assert hmc.likelihood_arithmetic_used == arith
     hg, opg, infog, qg = sampler(False)
     assert hg.plan_kind == 'generic'
     lj, grad = _oracle_model(X, y, 0.7)

@@ -38,7 +38,7 @@ def env():
 
 # -- float64-likelihood oracle models on an explicit set of chain rows ---------
 # every test on the exact-fp32 MFMA kernels and on the bf16x3 ones
-# (csrc/linear_bf16x3.hip), at the SAME tolerances
+# (csrc/b3_kernel.h), at the SAME tolerances
 ARITH = pytest.mark.parametrize('arith', ['fp32', 'bf16x3'])
 
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Round 5: the bf16x3 likelihood kernels (csrc/linear_bf16x3.hip) beside the
+"""Round 5: the bf16x3 likelihood kernels (csrc/b3_kernel.h) beside the
 exact-fp32 ones at the BASELINE shapes' widths -- gradient only (the interior
 evaluations of a trajectory) and likelihood + gradient.  TFLOP/s = 4 N D C /
 HIP-event time (fp32-equivalent flops), against the fp32-MFMA peak 157.3 and

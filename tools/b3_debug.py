@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""First-contact diagnostics for csrc/linear_bf16x3.hip: small structured
+"""First-contact diagnostics for csrc/b3_kernel.h: small structured
 cases whose error pattern names the layout assumption that is wrong
 (the MFMA operand slots, the transposing LDS read, the image placement)."""
 import ctypes

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Shader clocks per phase of the bf16x3 tile loop (a -DZS_B3_TIMING build of
-csrc/linear_bf16x3.hip: block 0 writes its waves' totals into grad_w).
+csrc/b3_kernel.h: block 0 writes its waves' totals into grad_w).
     LB_LIB=build/variants/libzshmc_timing.so python tools/b3_phase_timing.py
 MFMA issue per phase: 96 MFMAs x 32 clocks = 3072 at D = 256 (D * 12)."""
 import ctypes

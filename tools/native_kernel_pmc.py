@@ -30,7 +30,7 @@ gw = torch.empty(C, D, device=dev)
 for ll_ptr in (ll.data_ptr(), ll.data_ptr(), None, None):
     _capi.call('zshmc_linear_bernoulli_log_lik', W.data_ptr(), X.data_ptr(),
                y.data_ptr(), C, N, D, ll_ptr, gw.data_ptr(), 1, None, s)
-# ... and the same launches on the bf16x3 kernels (csrc/linear_bf16x3.hip)
+# ... and the same launches on the bf16x3 kernels (csrc/b3_kernel.h)
 import ctypes  # noqa: E402
 
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 evidence for the bf16x3 likelihood kernels (csrc/linear_bf16x3.hip)
+# rocprofv3 evidence for the bf16x3 likelihood kernels (csrc/b3_kernel.h)
 # beside the exact-fp32 ones: kernel trace of tools/b3_bench.py + a separate
 # MFMA-busy PMC pass (counters in their own run, kernel trace / stats only).
 #   bash tools/profile_b3.sh TAG "128,256"

@@ -226,6 +226,9 @@ PROTOTYPES = {
     'zshmc_linear_multinomial_log_lik_bf16x3': (c_int, [
         _p, _p, _p, c_int64, c_int64, c_int64, c_int64, c_int64, _p, _p,
         c_int, _p, _p]),
+    'zshmc_linear_categorical_log_lik_bf16x3': (c_int, [
+        _p, _p, _p, c_int64, c_int64, c_int64, c_int, c_int, _p, _p, c_int, _p,
+        _p]),
     'zshmc_linear_categorical_log_lik': (c_int, [
         _p, _p, _p, c_int64, c_int64, c_int64, c_int, c_int, _p, _p, c_int, _p,
         _p]),

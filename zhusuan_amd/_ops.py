@@ -595,7 +595,7 @@ def packed_design(blocks, n_rows, device, width=None):
     return out
 
 
-# ---- the bf16x3 likelihood kernels (csrc/linear_bf16x3.hip) ---------------
+# ---- the bf16x3 likelihood kernels (csrc/b3_kernel.h) ---------------
 BF16X3_WIDTHS = (64, 128, 192, 256)
 BF16X3_CHAIN_BLOCK = 128
 # A workgroup of the mixture-multinomial kernel takes 128 chains of ONE
@@ -632,7 +632,7 @@ def bf16x3_image(Xp):
 
 def resident_per_cu(width, arithmetic='fp32'):
     """Workgroups of the <= 256-column likelihood kernels one CU holds
-    (registers / LDS; csrc/lb_body.h ZS_LB_MINW, csrc/linear_bf16x3.hip
+    (registers / LDS; csrc/lb_body.h ZS_LB_MINW, csrc/b3_kernel.h
     ZS_B3_WAVES): a second resident workgroup runs its element-wise stage
     under the first one's MFMAs."""
     if width > 256:

@@ -71,6 +71,10 @@ int likelihood(const zshmc_model_plan& m, const float* q, bool want_ll,
       return zshmc_linear_multinomial_log_lik_bf16x3(
           w, m.inner_image, m.obs, m.obs_rows, m.obs_stride, m.n_chains,
           m.n_inner, m.width, ll, grad_out, m.n_splits, ws, s);
+    if (m.kind == ZSHMC_PLAN_LINEAR_CATEGORICAL)
+      return zshmc_linear_categorical_log_lik_bf16x3(
+          w, m.inner_image, m.obs, m.lik_rows, m.n_inner, m.width, m.n_classes,
+          (int)m.groups, ll, grad_out, m.n_splits, ws, s);
   }
   switch (m.kind) {
     case ZSHMC_PLAN_LINEAR_BERNOULLI:

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void lb_reduce_splits_kernel(
   }
 }
 
-// (for csrc/linear_bf16x3.hip: the same fixed-order reduction of its partials)
+// (for csrc/b3_kernel.h: the same fixed-order reduction of its partials)
 int lb_reduce_splits(const float* ws, int64_t C, int64_t ldw, int S, float* ll,
                      float* gW, hipStream_t s) {
   const int64_t n = C + (gW ? C * ldw : 0);

@@ -237,8 +237,9 @@ class HMC(object):
     two GEMMs on the exact-fp32 MFMAs) or 'bf16x3' (three bfloat16 planes
     per float32 operand, six bf16 MFMAs per product, float32 accumulation:
     float32-level results at 1.6-1.8x the fp32 matrix peak; taken where the
-    kernels exist -- Bernoulli / mixture-multinomial likelihoods of <= 256
-    columns -- `hmc.likelihood_arithmetic_used` says which ran).
+    kernels exist -- Bernoulli / mixture-multinomial / Categorical
+    likelihoods of <= 256 columns -- `hmc.likelihood_arithmetic_used` says
+    which ran).
 
     `one_launch_trajectory` (default False): native model plans whose
     likelihood grid fits the device at once can run the L + 1 trips of a
@@ -471,7 +472,7 @@ class HMC(object):
     @property
     def likelihood_arithmetic_used(self):
         """'bf16x3' when the plan's likelihood evaluations run on the
-        bf16 matrix cores (csrc/linear_bf16x3.hip), 'fp32' for the exact-fp32
+        bf16 matrix cores (csrc/b3_kernel.h), 'fp32' for the exact-fp32
         MFMA kernels, None for plans without a dense likelihood kernel."""
         plan = self._plan
         if plan is None or not hasattr(plan, 'inner_image'):

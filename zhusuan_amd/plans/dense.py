@@ -202,7 +202,8 @@ class _DenseLikelihoodPlan(_PlanBase):
         # that fill those workgroups
         self.inner_image = None
         if self.hmc.likelihood_arithmetic == 'bf16x3' and \
-                self.kind in ('linear_bernoulli', 'mixture_multinomial') and \
+                self.kind in ('linear_bernoulli', 'mixture_multinomial',
+                              'linear_categorical') and \
                 self.width in ops.BF16X3_WIDTHS:
             per_doc = C // self.obs.shape[0] \
                 if self.kind == 'mixture_multinomial' else C
@@ -215,7 +216,8 @@ class _DenseLikelihoodPlan(_PlanBase):
         if self.inner_image is None and self.kind != 'linear_categorical':
             self.block = ops.likelihood_plan(self.width)[1]
         R = self.lik_rows
-        per_cu = 1 if self.kind == 'linear_categorical' else \
+        per_cu = 1 if self.kind == 'linear_categorical' and \
+            self.inner_image is None else \
             ops.resident_per_cu(self.width, 'bf16x3' if self.inner_image
                                 is not None else 'fp32')
         self.splits = ops._row_splits(R, n_inner, self.device, self.block,
@@ -445,6 +447,14 @@ class _DenseLikelihoodPlan(_PlanBase):
             else:
                 _capi.call('zshmc_zero', grad.data_ptr(),
                            4 * grad.numel(), stream)
+        elif self.kind == 'linear_categorical' and \
+                self.inner_image is not None:
+            _capi.call('zshmc_linear_categorical_log_lik_bf16x3',
+                       w.data_ptr(), self.inner_image.data_ptr(),
+                       self.obs.data_ptr(), self.lik_rows,
+                       self.inner.shape[0], self.width, self.n_classes,
+                       self.stride, ll_ptr, grad.data_ptr(), self.splits,
+                       _capi.ptr(ws), stream)
         elif self.kind == 'linear_categorical':
             _capi.call('zshmc_linear_categorical_log_lik', w.data_ptr(),
                        self.inner.data_ptr(), self.obs.data_ptr(),
