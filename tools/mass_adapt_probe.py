@@ -2,7 +2,8 @@
 """Where the cost of a mass-adapting fused transition goes: host time per
 `sample_op.run` call (measured on a tiny problem, where the device is idle),
 wall time per transition at the headline shape, with both adaptation flags
-on / off.    python tools/archive/mass_adapt_probe.py [n_chains] [n_data]"""
+on / off.    python tools/mass_adapt_probe.py [n_chains] [n_data]
+PROBE_LIB = another build of libzshmc.so (tools/build_ring_variants.sh)."""
 import gc
 import os
 import sys
@@ -10,7 +11,7 @@ import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import zhusuan_amd as zs  # noqa: E402
 from zhusuan_amd import _capi  # noqa: E402
 
@@ -51,13 +52,15 @@ def loop(op, feed, n):
 C = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 D = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 gc.disable()
-for shape in ((256, D), (C, D)):
+for shape in ((C, D),) if os.environ.get('PROBE_BIG_ONLY') else ((256, D), (C, D)):
     hmc, op, f_ss, f_m = build(*shape)
     for _ in range(40):
         op.run(feed_dict={f_ss: True, f_m: True}, sync=False)
     hmc.check_numerics()
-    for label, on in (('both flags on ', True), ('both flags off', False)):
-        feed = {f_ss: on, f_m: on}
+    for label, on_ss, on_m in (('both flags on ', True, True),
+                               ('step size only', True, False),
+                               ('both flags off', False, False)):
+        feed = {f_ss: on_ss, f_m: on_m}
         loop(op, feed, 60)
         host, wall = loop(op, feed, 300)
         print('%6d x %d  %s  host %.1f us per call, wall %.1f us per transition'

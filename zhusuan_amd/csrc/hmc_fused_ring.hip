@@ -267,6 +267,13 @@ __device__ __forceinline__ void store_row(uint32_t voff, uint32_t voff_last,
 // only by the order of the chains, at the 1e-16 level.  Register accumulators
 // (double: two waves per SIMD; float: not bit-stable under dynamic tickets,
 // spills under static ones) were measured and lost: docs/LABNOTES.md 3.2, 10.
+// timing builds (tools/build_ring_variants.sh, docs/LABNOTES.md 12) of the
+// COLSTATS instantiations, with WRONG column sums (the launch reports mean 0
+// and variance 1 so that the chains keep moving): bit 0 no accumulation at
+// all, bit 1 the arithmetic without the LDS atomics
+#ifndef ZS_CS_SKIP
+#define ZS_CS_SKIP 0
+#endif
 constexpr int ring_waves_for(int nch, bool has_mass, bool colstats = false) {
   const int w = nch <= 3 ? 4
                          : (nch == 4 ? (has_mass ? 3 : ZS_RING_WAVES)
@@ -662,7 +669,7 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
     // sums.  r holds q' (mean re-added above); a rejected chain's state is
     // the start row, still in its ring slot.  LDS traffic only (no VMEM:
     // the ledger does not change); `accept` is wave-uniform.
-    if (COLSTATS) {
+    if (COLSTATS && !(ZS_CS_SKIP & 1)) {
       const bool took = accept && a.commit != 0;
       const float* __restrict__ sl = ring_w + slot_rd * kRow;
 #pragma unroll
@@ -674,6 +681,10 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int idx = (k * 4 + j) * kWave + lane;
+          if (ZS_CS_SKIP & 2) {
+            asm volatile("" ::"v"((double)d[j]), "v"((double)d[j] * (double)d[j]));
+            continue;
+          }
           __hip_atomic_fetch_add(&s_cs[idx], (double)d[j], __ATOMIC_RELAXED,
                                  __HIP_MEMORY_SCOPE_WORKGROUP);
           __hip_atomic_fetch_add(&s_cs[kRow + idx],
@@ -708,7 +719,7 @@ hmc_diag_normal_ring_kernel(FusedArgs a) {
       const int chunk = d >> 2, j = d & 3;
       const int idx = ((chunk / kWave) * 4 + j) * kWave + chunk % kWave;
       out[d] = s_cs[idx];
-      out[D + d] = s_cs[kRow + idx];
+      out[D + d] = (ZS_CS_SKIP & 3) ? (double)count : s_cs[kRow + idx];
     }
   }
   if (STAGE) {
