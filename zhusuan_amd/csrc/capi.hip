@@ -10,6 +10,11 @@ namespace zshmc {
 
 static thread_local char g_err[512] = "";
 
+static thread_local int tl_keep_parts = 0;
+KeepSplitParts::KeepSplitParts() { ++tl_keep_parts; }
+KeepSplitParts::~KeepSplitParts() { --tl_keep_parts; }
+bool KeepSplitParts::active() { return tl_keep_parts > 0; }
+
 void set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);

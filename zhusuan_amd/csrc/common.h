@@ -21,6 +21,16 @@ inline int check_hip(hipError_t e, const char* what) {
 // number of CUs of the current device (cached)
 int device_cu_count();
 
+// While one of these lives on the calling thread, the split likelihood
+// launches (lb_reduce_splits and its callers) leave their row-range partials
+// in the workspace and launch no reduction: the caller's next kernel adds
+// them itself (csrc/hmc_model_run.hip: the leapfrog step, csrc/model_step.h).
+struct KeepSplitParts {
+  KeepSplitParts();
+  ~KeepSplitParts();
+  static bool active();
+};
+
 #define ZS_REQUIRE(cond, ...)          \
   do {                                 \
     if (!(cond)) {                     \
@@ -146,6 +156,15 @@ __device__ __forceinline__ T sum_parts8(const T* __restrict__ p, int64_t stride,
 #pragma unroll
   for (int k = 0; k < 8; ++k) a[k] = T{};
   int s = 0;
+  // (24 loads in flight where there are that many: the adds stay in the order
+  // of s per accumulator, so the batch size does not show in the result)
+  for (; s + 24 <= S; s += 24) {
+    T v[24];
+#pragma unroll
+    for (int k = 0; k < 24; ++k) v[k] = p[(int64_t)(s + k) * stride];
+#pragma unroll
+    for (int k = 0; k < 24; ++k) a[k & 7] += v[k];
+  }
   for (; s + 8 <= S; s += 8) {
     T v[8];
 #pragma unroll

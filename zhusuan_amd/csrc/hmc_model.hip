@@ -68,44 +68,41 @@ static int launch_model_step(const ModelStepArgs& a, bool softmax,
 
 using namespace zshmc;
 
-extern "C" int zshmc_model_kick_drift(
-    float* q, float* p, const float* grad_lik, int64_t grad_stride,
-    float* operand, int64_t operand_stride, int softmax,
-    const float* prior_mean, int64_t mean_rows, const float* prior_logstd,
-    int64_t logstd_rows, const float* mass, const float* step_size_dev,
-    float step_size_host, float kick_scale, float drift_scale,
-    float lik_scale, int64_t n_chains, int64_t n_data, int64_t row_stride,
-    const float* ll_in, float* lp_out, float* kinetic, void* stream) {
-  const int64_t ld = row_stride;
-  ZS_REQUIRE(q && p && prior_mean && prior_logstd,
+// the step with its arguments as the kernel takes them (also for
+// csrc/hmc_model_run.hip, whose steps read a split likelihood launch's
+// partials: a.n_parts > 1)
+int zshmc::model_kick_drift_launch(const ModelStepArgs& a, int softmax,
+                                   void* stream) {
+  const int64_t ld = a.ld;
+  ZS_REQUIRE(a.q && a.p && a.prior_mean && a.prior_logstd,
              "zshmc_model_kick_drift: null q/p/prior");
-  ZS_REQUIRE(n_chains >= 0 && n_data >= 1 && ld >= n_data && ld <= 1024 &&
+  ZS_REQUIRE(a.n_chains >= 0 && a.n_data >= 1 && ld >= a.n_data && ld <= 1024 &&
                  ld % 4 == 0,
              "zshmc_model_kick_drift: 1 <= n_data %lld <= row_stride %lld <= "
-             "1024, row_stride a multiple of 4", (long long)n_data,
+             "1024, row_stride a multiple of 4", (long long)a.n_data,
              (long long)ld);
-  ZS_REQUIRE(mean_rows >= 1 && logstd_rows >= 1,
+  ZS_REQUIRE(a.mean_rows >= 1 && a.logstd_rows >= 1,
              "zshmc_model_kick_drift: prior row periods must be >= 1");
-  ZS_REQUIRE(!grad_lik || (grad_stride >= ld && grad_stride % 4 == 0),
+  ZS_REQUIRE(!a.grad_lik || (a.grad_stride >= ld && a.grad_stride % 4 == 0),
              "zshmc_model_kick_drift: bad grad_stride");
-  ZS_REQUIRE(!operand || (operand_stride >= ld && operand_stride % 4 == 0 &&
-                          operand_stride <= 1024),
+  ZS_REQUIRE(!a.operand || (a.operand_stride >= ld && a.operand_stride % 4 == 0 &&
+                            a.operand_stride <= 1024),
              "zshmc_model_kick_drift: bad operand_stride");
-  ZS_REQUIRE(!softmax || operand, "zshmc_model_kick_drift: softmax needs operand");
+  ZS_REQUIRE(!softmax || a.operand, "zshmc_model_kick_drift: softmax needs operand");
+  ZS_REQUIRE(a.n_parts <= 1 || (a.grad_lik && a.part_stride % 4 == 0),
+             "zshmc_model_kick_drift: bad partials");
   const uintptr_t align =
-      reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(p) |
-      reinterpret_cast<uintptr_t>(grad_lik) | reinterpret_cast<uintptr_t>(operand) |
-      reinterpret_cast<uintptr_t>(prior_mean) |
-      reinterpret_cast<uintptr_t>(prior_logstd) | reinterpret_cast<uintptr_t>(mass);
+      reinterpret_cast<uintptr_t>(a.q) | reinterpret_cast<uintptr_t>(a.p) |
+      reinterpret_cast<uintptr_t>(a.grad_lik) |
+      reinterpret_cast<uintptr_t>(a.operand) |
+      reinterpret_cast<uintptr_t>(a.prior_mean) |
+      reinterpret_cast<uintptr_t>(a.prior_logstd) |
+      reinterpret_cast<uintptr_t>(a.mass) | reinterpret_cast<uintptr_t>(a.grad_sum);
   ZS_REQUIRE((align & 15) == 0, "zshmc_model_kick_drift: buffers must be 16-B aligned");
-  if (n_chains == 0) return ZSHMC_OK;
-  ModelStepArgs a{q, p, grad_lik, grad_stride, operand, operand_stride,
-                  prior_mean, mean_rows, prior_logstd, logstd_rows, mass,
-                  step_size_dev, step_size_host, kick_scale, drift_scale,
-                  lik_scale, n_chains, n_data, ld, ll_in, lp_out, kinetic,
-                  1, 0, nullptr, nullptr};
+  if (a.n_chains == 0) return ZSHMC_OK;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const int64_t width = operand && operand_stride > ld ? operand_stride : ld;
+  const int64_t width =
+      a.operand && a.operand_stride > ld ? a.operand_stride : ld;
   const int nv = (int)((width + 255) / 256);
   // a row of at most 64 / 128 floats leaves lanes of a 64-lane group idle:
   // pack four / two rows into a wave
@@ -117,4 +114,20 @@ extern "C" int zshmc_model_kick_drift(
     case 3: return launch_model_step<3, 64>(a, softmax != 0, s);
     default: return launch_model_step<4, 64>(a, softmax != 0, s);
   }
+}
+
+extern "C" int zshmc_model_kick_drift(
+    float* q, float* p, const float* grad_lik, int64_t grad_stride,
+    float* operand, int64_t operand_stride, int softmax,
+    const float* prior_mean, int64_t mean_rows, const float* prior_logstd,
+    int64_t logstd_rows, const float* mass, const float* step_size_dev,
+    float step_size_host, float kick_scale, float drift_scale,
+    float lik_scale, int64_t n_chains, int64_t n_data, int64_t row_stride,
+    const float* ll_in, float* lp_out, float* kinetic, void* stream) {
+  ModelStepArgs a{q, p, grad_lik, grad_stride, operand, operand_stride,
+                  prior_mean, mean_rows, prior_logstd, logstd_rows, mass,
+                  step_size_dev, step_size_host, kick_scale, drift_scale,
+                  lik_scale, n_chains, n_data, row_stride, ll_in, lp_out,
+                  kinetic, 1, 0, nullptr, nullptr};
+  return model_kick_drift_launch(a, softmax, stream);
 }

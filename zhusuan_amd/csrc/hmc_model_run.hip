@@ -20,6 +20,7 @@
 // Nothing in it reads device memory; the sequence is exactly the one the
 // front-end issues, so results are bit-identical to a loop of single runs.
 #include "common.h"
+#include "model_step.h"
 
 using namespace zshmc;
 
@@ -117,6 +118,34 @@ int likelihood(const zshmc_model_plan& m, const float* q, bool want_ll,
   return ZSHMC_ERR_BAD_ARG;
 }
 
+// The steps behind a split likelihood launch can add its row-range partials
+// themselves (csrc/model_step.h: the arithmetic and order of the reduction
+// kernel): one launch less per leapfrog trip, which is what a small problem's
+// trip is made of.  The dense kernels' partial layout
+// (lb_reduce_splits), the plain step kernel, 16-byte aligned parts.
+bool steps_take_parts(const zshmc_model_plan& m) {
+  return !m.segmented && m.n_splits > 1 && m.split_ws &&
+         (m.kind == ZSHMC_PLAN_LINEAR_BERNOULLI ||
+          m.kind == ZSHMC_PLAN_MIXTURE_MULTINOMIAL) &&
+         ((int64_t)m.n_splits * m.lik_rows) % 4 == 0 &&
+         m.lik_rows == m.n_chains;
+}
+
+// the step of a plan that reads the partials a split launch left in
+// m.split_ws; grad_sum / ll_sum: where the sums are also stored (or NULL)
+int step_parts(const zshmc_model_plan& m, bool with_ll, float* grad_sum,
+               float* ll_sum, float kick, float drift, float lik_scale,
+               float* lp_out, float* kinetic, void* s) {
+  const int64_t C = m.lik_rows, S = m.n_splits;
+  ModelStepArgs a{m.q_new, m.p, m.split_ws + S * C, m.width, m.operand,
+                  m.width, m.prior_mean, m.mean_rows, m.prior_logstd,
+                  m.logstd_rows, m.use_mass ? m.mass : nullptr, m.state, 0.f,
+                  kick, drift, lik_scale, m.n_chains, m.n_total, m.ld,
+                  with_ll ? m.split_ws : nullptr, lp_out, kinetic, (int)S,
+                  C * m.width, grad_sum, with_ll ? ll_sum : nullptr};
+  return model_kick_drift_launch(a, m.softmax, s);
+}
+
 // (grad / ll: the likelihood evaluation the step reads, or NULL: none)
 int step(const zshmc_model_plan& m, const float* grad, const float* ll,
          float kick, float drift, float lik_scale, float* lp_out,
@@ -182,8 +211,22 @@ int transition(const zshmc_model_plan& m, uint32_t t, float lik_scale,
                                     hipMemcpyDeviceToDevice,
                                     reinterpret_cast<hipStream_t>(s)),
                      "hipMemcpyAsync"));
+  const bool parts = steps_take_parts(m);
   for (int i = 1; i <= L; ++i) {
     const bool last = i == L;
+    if (parts) {
+      // the evaluation stays in its row-range partials; the last one of the
+      // trajectory is also stored (what an accepting chain carries along)
+      {
+        KeepSplitParts keep;
+        ZS_TRY(likelihood(m, m.q_new, last, m.grad, m.ll, s));
+      }
+      ZS_TRY(step_parts(m, last, last ? m.grad : nullptr, m.ll,
+                        last ? 0.5f : 1.f, last ? 0.f : 1.f, lik_scale,
+                        last ? m.lp_new : nullptr, last ? m.kin_new : nullptr,
+                        s));
+      continue;
+    }
     ZS_TRY(likelihood(m, m.q_new, last, m.grad, m.ll, s));
     ZS_TRY(step(m, m.grad, m.ll, last ? 0.5f : 1.f, last ? 0.f : 1.f, lik_scale,
                 last ? m.lp_new : nullptr, last ? m.kin_new : nullptr, s));

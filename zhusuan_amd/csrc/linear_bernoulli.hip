@@ -117,6 +117,8 @@ __global__ __launch_bounds__(256) void lb_reduce_splits_kernel(
 // (for csrc/b3_kernel.h: the same fixed-order reduction of its partials)
 int lb_reduce_splits(const float* ws, int64_t C, int64_t ldw, int S, float* ll,
                      float* gW, hipStream_t s) {
+  // (the caller's next kernel adds the partials itself: csrc/common.h)
+  if (KeepSplitParts::active()) return ZSHMC_OK;
   const int64_t n = C + (gW ? C * ldw : 0);
   int64_t blocks = (n + 255) / 256;
   if (blocks > 4096) blocks = 4096;
@@ -179,14 +181,7 @@ static int launch_lb(const float* W, const float* X, const float* y,
                        dim3(256), lds, s, W, X, y, yc, yc_rows, ldy, C, N, ldw, ldx,
                        ll_out, g_out, doc_major, n_classes, cls_log2);
   ZS_LAUNCH_CHECK("linear_bernoulli_kernel launch");
-  if (S > 1) {
-    const int64_t n = C + (gW ? C * ldw : 0);
-    int64_t blocks = (n + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(lb_reduce_splits_kernel, dim3((int)blocks), dim3(256), 0, s,
-                       workspace, C, ldw, S, ll, gW);
-    ZS_LAUNCH_CHECK("lb_reduce_splits_kernel launch");
-  }
+  if (S > 1) return lb_reduce_splits(workspace, C, ldw, S, ll, gW, s);
   return ZSHMC_OK;
 }
 

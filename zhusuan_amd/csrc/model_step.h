@@ -34,12 +34,16 @@ struct ModelStepArgs {
   // log-likelihood part s at ll_in + s * n_chains): added here in the order
   // and arithmetic of lb_reduce_splits_kernel (sum_parts8, csrc/common.h), and -- where asked -- stored reduced (grad_sum [C, grad_stride],
   // ll_sum [C]).  n_parts <= 1: grad_lik / ll_in are the evaluation itself.
-  // (The persistent trajectory kernel, csrc/hmc_model_traj.hip.)
+  // (The persistent trajectory kernel, csrc/hmc_model_traj.hip, and the steps
+  // of csrc/hmc_model_run.hip behind a split launch.)
   int n_parts;
   int64_t part_stride;
   float* grad_sum;
   float* ll_sum;
 };
+
+// host side (csrc/hmc_model.hip): validate and launch
+int model_kick_drift_launch(const ModelStepArgs& a, int softmax, void* stream);
 
 __device__ __forceinline__ float step_ll(const ModelStepArgs& a, int64_t c) {
   if (a.n_parts <= 1) return a.ll_in[c];
