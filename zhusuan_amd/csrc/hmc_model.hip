@@ -47,10 +47,87 @@ __global__ __launch_bounds__(256) void model_kick_drift_kernel(ModelStepArgs a) 
       (int64_t)gridDim.x * (blockDim.x / 64));
 }
 
+// Few rows behind a split likelihood launch (a.n_parts > 1): what the step
+// waits for is the n_parts loads per element, a handful of dependent batches
+// from as many workgroups' L2s.  One workgroup per wave-load of rows, its
+// FOUR waves adding a quarter of the partials each -- wave w the accumulators
+// 2w and 2w + 1 of sum_parts8 (csrc/common.h), folded through LDS in
+// sum_parts8's order: the same bits, one batch of loads instead of five --
+// then wave 0 takes the step.
+template <int NV, bool SOFTMAX, int LANES>
+__global__ __launch_bounds__(256) void model_kick_drift_parts_kernel(
+    ModelStepArgs a) {
+  constexpr int kRows = 64 / LANES;
+  constexpr int kCh = 16;  // loads in flight per accumulator
+  __shared__ m4 sh[4][kRows * NV * LANES];
+  const int w = threadIdx.x / 64;
+  const int lane = threadIdx.x & (LANES - 1);
+  const int sub = (threadIdx.x & 63) / LANES;
+  const int64_t row = (int64_t)blockIdx.x * kRows + sub;
+  const bool row_on = row < a.n_chains;
+  const int64_t c = row_on ? row : a.n_chains - 1;
+  const int S = a.n_parts;
+  const int64_t stride = a.part_stride / 4;
+  const m4 zero = m4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int64_t d = (int64_t)(k * LANES + lane) * 4;
+    m4 a0 = zero, a1 = zero;
+    if (d < a.n_data) {
+      const m4* __restrict__ p =
+          reinterpret_cast<const m4*>(a.grad_lik + c * a.grad_stride + d);
+      for (int s0 = 2 * w; s0 < S; s0 += 8 * kCh) {
+        m4 v0[kCh], v1[kCh];
+#pragma unroll
+        for (int j = 0; j < kCh; ++j) {
+          const int s = s0 + 8 * j;
+          v0[j] = s < S ? p[(int64_t)s * stride] : zero;
+          v1[j] = s + 1 < S ? p[(int64_t)(s + 1) * stride] : zero;
+        }
+#pragma unroll
+        for (int j = 0; j < kCh; ++j) {
+          const int s = s0 + 8 * j;
+          if (s < S) a0 += v0[j];
+          if (s + 1 < S) a1 += v1[j];
+        }
+      }
+    }
+    sh[w][(sub * NV + k) * LANES + lane] = a0 + a1;
+  }
+  __syncthreads();
+  if (w != 0) return;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int i = (sub * NV + k) * LANES + lane;
+    const m4 gl = (sh[0][i] + sh[1][i]) + (sh[2][i] + sh[3][i]);
+    sh[0][i] = gl;  // (read back by the lane that wrote it)
+    const int64_t d = (int64_t)(k * LANES + lane) * 4;
+    if (a.grad_sum && row_on && d < a.n_data)
+      *reinterpret_cast<m4*>(a.grad_sum + c * a.grad_stride + d) = gl;
+  }
+  ModelStepArgs b = a;
+  b.grad_ready = reinterpret_cast<const float*>(&sh[0][0]);
+  b.grad_sum = nullptr;
+  model_step_rows<NV, SOFTMAX, LANES>(b, (int64_t)blockIdx.x,
+                                      (int64_t)gridDim.x);
+}
+
 template <int NV, int LANES>
 static int launch_model_step(const ModelStepArgs& a, bool softmax,
                              hipStream_t s) {
   constexpr int kRows = 64 / LANES;
+  const int64_t groups = (a.n_chains + kRows - 1) / kRows;
+  if (a.n_parts > 1 && a.grad_lik && groups <= 2 * (int64_t)device_cu_count()) {
+    const dim3 grid((unsigned)groups), block(256);
+    if (softmax)
+      hipLaunchKernelGGL((model_kick_drift_parts_kernel<NV, true, LANES>), grid,
+                         block, 0, s, a);
+    else
+      hipLaunchKernelGGL((model_kick_drift_parts_kernel<NV, false, LANES>),
+                         grid, block, 0, s, a);
+    ZS_LAUNCH_CHECK("model_kick_drift_parts_kernel launch");
+    return ZSHMC_OK;
+  }
   const int64_t need = (a.n_chains + 4 * kRows - 1) / (4 * kRows);
   const int64_t cap = (int64_t)device_cu_count() * 8;
   const dim3 grid((unsigned)(need < cap ? need : cap)), block(256);
@@ -128,6 +205,6 @@ extern "C" int zshmc_model_kick_drift(
                   prior_mean, mean_rows, prior_logstd, logstd_rows, mass,
                   step_size_dev, step_size_host, kick_scale, drift_scale,
                   lik_scale, n_chains, n_data, row_stride, ll_in, lp_out,
-                  kinetic, 1, 0, nullptr, nullptr};
+                  kinetic, 1, 0, nullptr, nullptr, nullptr};
   return model_kick_drift_launch(a, softmax, stream);
 }

@@ -142,7 +142,7 @@ int step_parts(const zshmc_model_plan& m, bool with_ll, float* grad_sum,
                   m.logstd_rows, m.use_mass ? m.mass : nullptr, m.state, 0.f,
                   kick, drift, lik_scale, m.n_chains, m.n_total, m.ld,
                   with_ll ? m.split_ws : nullptr, lp_out, kinetic, (int)S,
-                  C * m.width, grad_sum, with_ll ? ll_sum : nullptr};
+                  C * m.width, grad_sum, with_ll ? ll_sum : nullptr, nullptr};
   return model_kick_drift_launch(a, m.softmax, s);
 }
 

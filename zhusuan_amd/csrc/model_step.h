@@ -40,6 +40,10 @@ struct ModelStepArgs {
   int64_t part_stride;
   float* grad_sum;
   float* ll_sum;
+  // set by model_kick_drift_parts_kernel (csrc/hmc_model.hip), never by a
+  // caller: the partials' sum of this wave's rows, [64 / LANES][NV][LANES]
+  // float4 in LDS, formed by the workgroup's four waves together
+  const float* grad_ready;
 };
 
 // host side (csrc/hmc_model.hip): validate and launch
@@ -107,7 +111,10 @@ __device__ __forceinline__ void model_step_rows(const ModelStepArgs& a,
       }
       m4 gl = zero;
       if (a.grad_lik) {
-        if (a.n_parts <= 1) {
+        if (a.grad_ready) {
+          gl = reinterpret_cast<const m4*>(
+              a.grad_ready)[(sub * NV + k) * LANES + lane];
+        } else if (a.n_parts <= 1) {
           gl = *reinterpret_cast<const m4*>(a.grad_lik + c * a.grad_stride + d);
         } else {
           // (part_stride is a multiple of 4 floats: strides in m4 units)
