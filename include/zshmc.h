@@ -457,7 +457,11 @@ int zshmc_unnormalized_multinomial_log_prob_grad(
  * language pays its foreign-function overhead once per run of transitions
  * (the E-steps of lntm_mcem.py:157-182, the 1000 temperatures of AIS.run,
  * evaluation.py:119-165).  Every launch is one of the entry points above with
- * the plan's buffers: results are bit-identical to issuing them one by one.
+ * the plan's buffers -- except that behind a SPLIT likelihood launch
+ * (n_splits > 1, Bernoulli / mixture-multinomial plans) the step adds the
+ * row-range partials itself, in the order and arithmetic of the reduction
+ * that launch would have ended with (no reduction launch inside a
+ * trajectory); results are bit-identical to issuing them one by one.
  * Outside a run (one transition at a time): the step-size search
  * (hmc.py:308-345), iterations with the mass still at ones, anything that
  * changes the model's tensors.
@@ -507,8 +511,8 @@ typedef struct zshmc_model_plan {
   const float* inner; /* X / phi^T / the other factor table */
   int64_t n_inner;    /* data rows / vocabulary / rows of the other table */
   /* ABI 0.5.0: the bf16x3 tile image of `inner` (zshmc_bf16x3_split) or NULL.
-   * With it the Bernoulli and mixture-multinomial likelihood evaluations that
-   * want a gradient run on the bf16 matrix cores
+   * With it the Bernoulli, Categorical and mixture-multinomial likelihood
+   * evaluations that want a gradient run on the bf16 matrix cores
    * (zshmc_linear_*_log_lik_bf16x3); NULL: the exact-fp32 kernels. */
   const void* inner_image;
   const float* obs;   /* labels / counts / ratings */
