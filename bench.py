@@ -624,7 +624,7 @@ def extra_wide_regression(torch, zs, dev, n_rows=65536, n_chains=8192,
 
 def extra_softmax_regression(torch, zs, dev, n_rows=60000, n_feat=784,
                              n_classes=10, n_chains=1024, n_leapfrogs=10,
-                             n_warm=3, n_timed=3):
+                             n_warm=3, n_timed=3, bf16x3=False):
     """north_star's third likelihood: softmax regression
     at the MNIST shape -- 10 classes x 784 features per chain, 60 000 rows --
     written with the reference's literal `matmul(X, w, transpose_b=True)` under
@@ -658,6 +658,29 @@ def extra_softmax_regression(torch, zs, dev, n_rows=60000, n_feat=784,
     plan = hmc._plan
     flop_eval = 4.0 * n_rows * plan.width * plan.lik_rows
     useful = (n_feat / plan.width) * (n_classes / plan.stride)
+    b3 = None
+    if bf16x3 and plan.width <= 256:
+        # the same chains, state and step size on the bf16x3 Categorical
+        # kernels (csrc/linear_bf16x3_cat.hip)
+        width = plan.width
+        del hmc, op, info, plan
+        gc.collect()
+        w3 = (w_true / n_feat ** 0.5).unsqueeze(0).repeat(
+            n_chains, 1, 1).contiguous()
+        h3 = zs.HMC(step_size=eps, n_leapfrogs=n_leapfrogs, seed=6,
+                    likelihood_arithmetic='bf16x3')
+        op3, info3 = h3.sample(model(), {'y': y}, {'w': w3})
+        el3, k3, acc3 = _time_transitions(
+            torch, h3, op3, info3, {}, n_warm, n_timed, torch.cuda.synchronize)
+        ms3 = el3 / n_timed * 1e3
+        b3 = {'likelihood_arithmetic': h3.likelihood_arithmetic_used,
+              'ms_per_step': ms3, 'mean_acceptance': acc3,
+              'value': n_chains * n_leapfrogs / (ms3 * 1e-3),
+              'roofline': _b3_roofline(width, k3, flop_eval, n_leapfrogs, ms3)}
+        b3['roofline']['kernel'] = (
+            'linear_b3_kernel<%d, Categorical> gradient only' % width)
+        hmc = h3
+        plan = h3._plan
     return {
         'workload': 'beyond BASELINE.json (north_star\'s Categorical): '
                     'softmax regression, %d classes x %d features, synthetic '
@@ -675,6 +698,7 @@ def extra_softmax_regression(torch, zs, dev, n_rows=60000, n_feat=784,
             note='flops counted at the padded shape: width %d, class stride '
                  '%d; useful fraction of them %.3f (%d features, %d classes)'
                  % (plan.width, plan.stride, useful, n_feat, n_classes)),
+        **({'bf16x3': b3} if b3 else {}),
     }
 
 
@@ -1679,7 +1703,9 @@ def main():
                     (extra_wide_regression, {}),
                     (extra_wide_regression, {'n_feat': 299,
                                              'n_chains': 16384}),
-                    (extra_softmax_regression, {}), (extra_pmf, {}),
+                    (extra_softmax_regression, {}),
+                    (extra_softmax_regression, {'n_feat': 256, 'bf16x3': True}),
+                    (extra_pmf, {}),
                     (extra_estep, {}))
         else:
             todo = ((lntm_workload, dict(
