@@ -25,13 +25,10 @@ Two execution plans, chosen in `sample()`:
 Both use the same RNG counters and the same on-device adaptation state.
 """
 
-import ctypes
 
 import torch
 
-from . import _capi, _symbolic, _writes
-from .distributions import Normal
-from .framework.bn import StochasticTensor
+from . import _capi, _symbolic
 from .framework.meta_bn import MetaBayesianNet
 from .utils import merge_dicts, next_sampler_seed
 

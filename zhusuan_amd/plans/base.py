@@ -2,15 +2,10 @@
 on the device, the acceptance / column-sum statistics and their one
 all-reduce, the mass estimator (reference zhusuan/hmc.py:64-159,284-305,
 375-380), and how a plan knows that nobody else wrote its latents."""
-import ctypes
 
 import torch
 
-from .. import _capi, _symbolic, _writes
-from ..distributions import Normal
-from ..framework.bn import StochasticTensor
-from ..framework.meta_bn import MetaBayesianNet
-from ..utils import merge_dicts
+from .. import _capi, _writes
 
 
 def _versions(tensors):

@@ -7,12 +7,8 @@ import ctypes
 
 import torch
 
-from .. import _capi, _symbolic, _writes
-from ..distributions import Normal
-from ..framework.bn import StochasticTensor
-from ..framework.meta_bn import MetaBayesianNet
-from ..utils import merge_dicts
-from .base import _PlanBase, _versions, _prod, _Unsupported
+from .. import _capi
+from .base import _PlanBase, _versions, _Unsupported
 
 
 class _DenseLikelihoodPlan(_PlanBase):

@@ -6,7 +6,7 @@ import ctypes
 
 import torch
 
-from .. import _capi, _symbolic, _writes
+from .. import _capi
 from ..distributions import Normal
 from ..framework.bn import StochasticTensor
 from ..framework.meta_bn import MetaBayesianNet

@@ -1,16 +1,11 @@
 """The generic plan: any log-joint (callable or MetaBayesianNet); torch autograd
 over the HIP log_prob ops plays tf.gradients (reference zhusuan/hmc.py:430-432),
 momentum / kick + drift / MH / select are the kernels of csrc/hmc_generic.hip."""
-import ctypes
 
 import torch
 
-from .. import _capi, _symbolic, _writes
-from ..distributions import Normal
-from ..framework.bn import StochasticTensor
-from ..framework.meta_bn import MetaBayesianNet
-from ..utils import merge_dicts
-from .base import _PlanBase, _versions, _prod
+from .. import _capi
+from .base import _PlanBase
 
 
 class _GenericPlan(_PlanBase):

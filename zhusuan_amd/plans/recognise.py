@@ -3,18 +3,16 @@ on symbolic latents (zhusuan_amd/_symbolic.py) and match the node structure of
 the reference's examples -- logistic regression (w @ X.T [+ ...] under a
 Bernoulli), softmax regression, lntm_mcem.py:33-48, pmf_hmc.py:19-31 -- or say
 why not (hmc.plan_reason, NativePlanFallbackWarning)."""
-import ctypes
 
 import torch
 
-from .. import _capi, _symbolic, _writes
+from .. import _capi, _symbolic
 from ..distributions import Normal
 from ..framework.bn import StochasticTensor
 from ..framework.meta_bn import MetaBayesianNet
 from ..utils import merge_dicts
-from .base import _Unsupported, _prod
-from .dense import (_DenseLikelihoodPlan, _aligned16, _flat_tensors,
-                    _flatten_data_axes, _to_row_period)
+from .base import _Unsupported
+from .dense import _DenseLikelihoodPlan
 
 
 def _softmax_of(theta, probe):
