@@ -1,13 +1,14 @@
 """Categorical likelihood + gradient: the exact-fp32 MFMA kernel against the
 bf16x3 one (csrc/b3_kernel.h OP 2) on the same operands.
     python tools/cat_b3_bench.py [C K F N]..."""
+import os
 import sys
 import time
 
 import numpy as np
 import torch
 
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from zhusuan_amd import _capi, _ops  # noqa: E402
 
 
