@@ -149,21 +149,27 @@ __device__ __forceinline__ void wave_total4_swap(float& a, float& b, float& c,
 // reduction of the row-range partials of a split likelihood launch
 // (lb_reduce_splits_kernel, and csrc/model_step.h where the step reads the
 // partials itself): deterministic, and the same bits wherever it runs.
-template <typename T>
+// (ZS_PARTS_BATCHES x 8 loads in flight where there are that many parts: the
+// adds stay in the order of s per accumulator, so the batch size does not
+// show in the result; a translation unit short of registers sets it to 1)
+#ifndef ZS_PARTS_BATCHES
+#define ZS_PARTS_BATCHES 3
+#endif
+template <typename T, int NB = ZS_PARTS_BATCHES>
 __device__ __forceinline__ T sum_parts8(const T* __restrict__ p, int64_t stride,
                                         int S) {
   T a[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) a[k] = T{};
   int s = 0;
-  // (24 loads in flight where there are that many: the adds stay in the order
-  // of s per accumulator, so the batch size does not show in the result)
-  for (; s + 24 <= S; s += 24) {
-    T v[24];
+  if constexpr (NB > 1) {
+    for (; s + 8 * NB <= S; s += 8 * NB) {
+      T v[8 * NB];
 #pragma unroll
-    for (int k = 0; k < 24; ++k) v[k] = p[(int64_t)(s + k) * stride];
+      for (int k = 0; k < 8 * NB; ++k) v[k] = p[(int64_t)(s + k) * stride];
 #pragma unroll
-    for (int k = 0; k < 24; ++k) a[k & 7] += v[k];
+      for (int k = 0; k < 8 * NB; ++k) a[k & 7] += v[k];
+    }
   }
   for (; s + 8 <= S; s += 8) {
     T v[8];

@@ -20,6 +20,9 @@
 // where the launch-per-trip path has a kernel boundary.  Same arithmetic in
 // the same order: results are bit-identical to the launch-per-trip path
 // (tests/test_gpu_model_run.py).
+// (the persistent kernel holds a tile loop AND a step: eight partial loads in
+// flight is what its register budgets take without scratch)
+#define ZS_PARTS_BATCHES 1
 #include "common.h"
 #include "lb_body.h"
 #include "model_step.h"
