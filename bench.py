@@ -159,12 +159,20 @@ def cpu_reference_recorded():
     (tools/time_reference_over_shim.py).  It needs /root/reference, which does
     not exist on the GPU box, so the number is a RECORDED one and says where
     it was measured."""
-    path = os.path.join(ROOT, 'profiles', 'r02_cpu_reference_over_shim.json')
+    return _recorded('cpu_reference_over_shim.json')
+
+
+def _recorded(name):
+    """A committed record under profiles/.  A missing or unreadable file is
+    an error in the record (and a line on stderr), never a silent null."""
+    path = os.path.join(ROOT, 'profiles', name)
     try:
         with open(path) as f:
             return json.load(f)
-    except Exception:
-        return None
+    except Exception as e:                           # noqa: BLE001
+        sys.stderr.write('bench.py: recorded figure %s unreadable: %r\n' % (
+            path, e))
+        return {'error': 'profiles/%s unreadable: %r' % (name, e)}
 
 
 def cpu_baseline_parallel(n_data, n_leapfrogs, budget_s):
@@ -377,6 +385,33 @@ def _b3_roofline(width, kern_ms, flop_eval, n_evals, ms_transition):
     }
 
 
+def _lik_roofline(hmc, kern_ms, flop_eval, n_evals, ms_transition, mode=''):
+    """The roofline entry of a dense-likelihood plan's launches, priced
+    against the peak of the arithmetic that RAN (hmc.likelihood_arithmetic_
+    used): dense bf16 / 6 for bf16x3, the fp32 MFMA peak otherwise."""
+    plan = hmc._plan
+    if hmc.likelihood_arithmetic_used == 'bf16x3':
+        r = _b3_roofline(plan.width, kern_ms, flop_eval, n_evals,
+                         ms_transition)
+        if mode:
+            r['kernel'] = r['kernel'].replace('>', ', %s>' % mode, 1)
+        return r
+    return _mfma_roofline(
+        _lik_kernel_name(plan.width, plan.block) +
+        (' (%s mode)' % mode if mode else ''), kern_ms, flop_eval, n_evals,
+        ms_transition)
+
+
+def _other_arithmetic(used):
+    return 'fp32' if used == 'bf16x3' else 'bf16x3'
+
+
+ARITH_NOTE = ("HMC's default likelihood_arithmetic='auto' (bf16x3 where a "
+              "kernel exists and an evaluation is >= 1e10 flop, else fp32); "
+              "the other arithmetic on the same chains, state and step size "
+              "beside it")
+
+
 def extra_config1(torch, zs, dev, n_chains=1000, n_x=10, n_leapfrogs=5):
     """BASELINE configs[0]: examples/toy_examples/gaussian.py (:29, :36-58):
     1 000 chains, 10-D, stdev_j = 1/(j+1), L = 5, target acceptance 0.9, step
@@ -438,12 +473,8 @@ def extra_config1(torch, zs, dev, n_chains=1000, n_x=10, n_leapfrogs=5):
     out['kernel'] = _capi_kernel_name(n_x, 1, 1)
     # the reference's OWN hmc.py over the TensorFlow-API shim on this shape: a
     # RECORDED number (its sources do not travel to the GPU box)
-    try:
-        with open(os.path.join(ROOT, 'profiles',
-                               'r03_cpu_reference_over_shim_config1.json')) as f:
-            out['cpu_reference_over_shim'] = json.load(f)
-    except Exception:
-        out['cpu_reference_over_shim'] = None
+    out['cpu_reference_over_shim'] = _recorded(
+        'cpu_reference_over_shim_config1.json')
     return out
 
 
@@ -466,7 +497,7 @@ def extra_config3(torch, zs, dev, n_rows=1000000, n_chains=32768, n_feat=256,
     del X_h, y_h
     zero, one = torch.zeros(n_feat, device=dev), torch.ones(n_feat, device=dev)
 
-    def build(n, sharding, arithmetic='fp32'):
+    def build(n, sharding, arithmetic=None):
         @zs.meta_bayesian_net()
         def blr():
             bn = zs.BayesianNet()
@@ -479,75 +510,69 @@ def extra_config3(torch, zs, dev, n_rows=1000000, n_chains=32768, n_feat=256,
         # reference's step-size search accepts any step that runs uphill)
         w = (w_true / n_feat ** 0.5).repeat(n, 1).contiguous()
         flag = zs.placeholder(bool)
+        kw = {} if arithmetic is None else {'likelihood_arithmetic': arithmetic}
         hmc = zs.HMC(step_size=1e-3, n_leapfrogs=n_leapfrogs,
                      adapt_step_size=flag, target_acceptance_rate=0.8, seed=2,
-                     sharding=sharding, likelihood_arithmetic=arithmetic)
+                     sharding=sharding, **kw)
         op, info = hmc.sample(blr(), {'y': y}, {'w': w})
         return hmc, op, info, w, (flag,)
 
     state, w_sub, ess_pt, acc_sub = _tuned_start(
         torch, zs, build, n_sub, 60, 240, (True,))
-    hmc, op, info, w, flags = build(n_chains, None)
-    w.copy_(w_sub.repeat(n_chains // n_sub, 1))
-    hmc.set_state(state)
 
     def barrier():
         torch.cuda.synchronize()
-    # adaptation held in the timed region: step size = the dual-averaged one
-    elapsed, kern_ms, acc = _time_transitions(
-        torch, hmc, op, info, {flags[0]: False}, 1, n_timed, barrier)
-    ms = elapsed / n_timed * 1e3
     flop_eval = 4.0 * n_rows * n_feat * n_chains
-    plan_kind, step_size = hmc.plan_kind, float(info.updated_step_size.item())
-    roof32 = _mfma_roofline(
-        _lik_kernel_name(hmc._plan.width, hmc._plan.block), kern_ms, flop_eval,
-        n_leapfrogs, ms)
-    if (n_rows, n_chains, n_feat) == (1000000, 32768, 256):
-        roof32['traffic'], roof32['traffic_source'] = _recorded_mfma_traffic(
-            'bernoulli grad-only')
-    # the same chains, state and step size with the likelihood on the bf16
-    # matrix cores (HMC(likelihood_arithmetic='bf16x3'))
-    del hmc, op, info
-    gc.collect()
-    hmc3, op3, info3, w3, flags3 = build(n_chains, None, 'bf16x3')
-    w3.copy_(w_sub.repeat(n_chains // n_sub, 1))
-    hmc3.set_state(state)
-    elapsed3, kern3, acc3 = _time_transitions(
-        torch, hmc3, op3, info3, {flags3[0]: False}, 1, n_timed, barrier)
-    ms3 = elapsed3 / n_timed * 1e3
-    b3 = {
-        'likelihood_arithmetic': hmc3.likelihood_arithmetic_used,
-        'ms_per_step': ms3, 'steps': n_timed,
-        'value': n_chains * n_leapfrogs / (ms3 * 1e-3),
-        'unit': 'chain-leapfrog-steps/s',
-        'speedup_over_fp32_transition': ms / ms3,
-        'mean_acceptance': acc3,
-        'image_bytes': int(hmc3._plan.inner_image.numel()),
-        'roofline': _b3_roofline(hmc3._plan.width, kern3, flop_eval,
-                                 n_leapfrogs, ms3),
-    }
-    if (n_rows, n_chains, n_feat) == (1000000, 32768, 256):
-        b3['roofline']['traffic'], b3['roofline']['traffic_source'] = \
-            _recorded_mfma_traffic('bernoulli bf16x3 grad-only')
-    del hmc3, op3, info3, w3
-    gc.collect()
-    return {
+    full = (n_rows, n_chains, n_feat) == (1000000, 32768, 256)
+
+    def timed(arithmetic):
+        # adaptation held in the timed region: step size = the dual-averaged
+        # one of the subset
+        hmc, op, info, w, flags = build(n_chains, None, arithmetic)
+        w.copy_(w_sub.repeat(n_chains // n_sub, 1))
+        hmc.set_state(state)
+        elapsed, kern_ms, acc = _time_transitions(
+            torch, hmc, op, info, {flags[0]: False}, 1, n_timed, barrier)
+        ms = elapsed / n_timed * 1e3
+        used = hmc.likelihood_arithmetic_used
+        r = {
+            'likelihood_arithmetic_used': used,
+            'plan': hmc.plan_kind,
+            'ms_per_step': ms, 'steps': n_timed,
+            'value': n_chains * n_leapfrogs / (ms * 1e-3),
+            'unit': 'chain-leapfrog-steps/s',
+            'mean_acceptance': acc,
+            'step_size': float(info.updated_step_size.item()),
+            'roofline': _lik_roofline(hmc, kern_ms, flop_eval, n_leapfrogs,
+                                      ms),
+        }
+        if used == 'bf16x3':
+            r['image_bytes'] = int(hmc._plan.inner_image.numel())
+        if full:
+            r['roofline']['traffic'], r['roofline']['traffic_source'] = \
+                _recorded_mfma_traffic('bernoulli bf16x3 grad-only'
+                                       if used == 'bf16x3' else
+                                       'bernoulli grad-only')
+        del hmc, op, info, w
+        gc.collect()
+        return r
+    main = timed(None)                      # the default: 'auto'
+    other = timed(_other_arithmetic(main['likelihood_arithmetic_used']))
+    other['transition_time_over_default'] = \
+        other['ms_per_step'] / main['ms_per_step']
+    ms = main['ms_per_step']
+    out = dict(main)
+    out.update({
         'workload': 'configs[2]: Bayesian logistic regression, synthetic '
                     '%d x %d, %d chains, L=%d, step size adapted on a subset '
                     'and held in the timed region, the '
                     'model written with the reference\'s literal '
                     '`w @ X.T` logits' % (
                         n_rows, n_feat, n_chains, n_leapfrogs),
-        'plan': plan_kind,
-        'ms_per_step': ms,
-        'steps': n_timed,
-        'value': n_chains * n_leapfrogs / (ms * 1e-3),
-        'unit': 'chain-leapfrog-steps/s',
-        'mean_acceptance': acc,
+        'likelihood_arithmetic': ARITH_NOTE,
         'mean_acceptance_subset_held_phase': acc_sub,
         'target_acceptance': 0.8,
-        'step_size': step_size,
-        'bf16x3': b3,
+        other['likelihood_arithmetic_used']: other,
         'start': TUNED_START_NOTE.replace(
             'run with adaptation ON', 'run with adaptation HELD (config 3)') +
                  ' Subset: %d chains, 60 adaptive + 240 recorded transitions '
@@ -560,8 +585,8 @@ def extra_config3(torch, zs, dev, n_rows=1000000, n_chains=32768, n_feat=256,
                       'with the same step size, scaled to %d chains at the '
                       'timed rate' % (n_sub, n_chains),
         },
-        'roofline': roof32,
-    }
+    })
+    return out
 
 
 def extra_wide_regression(torch, zs, dev, n_rows=65536, n_chains=8192,
@@ -647,59 +672,52 @@ def extra_softmax_regression(torch, zs, dev, n_rows=60000, n_feat=784,
         bn.categorical('y', X.unsqueeze(0) @ w.tensor.transpose(-1, -2),
                        group_ndims=1)
         return bn
-    w = (w_true / n_feat ** 0.5).unsqueeze(0).repeat(n_chains, 1,
-                                                     1).contiguous()
     eps = 0.5 / n_rows ** 0.5 / (n_feat * n_classes) ** 0.25
-    hmc = zs.HMC(step_size=eps, n_leapfrogs=n_leapfrogs, seed=6)
-    op, info = hmc.sample(model(), {'y': y}, {'w': w})
-    elapsed, kern_ms, acc = _time_transitions(
-        torch, hmc, op, info, {}, n_warm, n_timed, torch.cuda.synchronize)
-    ms = elapsed / n_timed * 1e3
-    plan = hmc._plan
-    flop_eval = 4.0 * n_rows * plan.width * plan.lik_rows
-    useful = (n_feat / plan.width) * (n_classes / plan.stride)
-    b3 = None
-    if bf16x3 and plan.width <= 256:
-        # the same chains, state and step size on the bf16x3 Categorical
-        # kernels (csrc/linear_bf16x3_cat.hip)
-        width = plan.width
-        del hmc, op, info, plan
+
+    def timed(arithmetic):
+        w = (w_true / n_feat ** 0.5).unsqueeze(0).repeat(n_chains, 1,
+                                                         1).contiguous()
+        kw = {} if arithmetic is None else {'likelihood_arithmetic': arithmetic}
+        hmc = zs.HMC(step_size=eps, n_leapfrogs=n_leapfrogs, seed=6, **kw)
+        op, info = hmc.sample(model(), {'y': y}, {'w': w})
+        elapsed, kern_ms, acc = _time_transitions(
+            torch, hmc, op, info, {}, n_warm, n_timed, torch.cuda.synchronize)
+        ms = elapsed / n_timed * 1e3
+        plan = hmc._plan
+        flop_eval = 4.0 * n_rows * plan.width * plan.lik_rows
+        useful = (n_feat / plan.width) * (n_classes / plan.stride)
+        roof = _lik_roofline(hmc, kern_ms, flop_eval, n_leapfrogs, ms,
+                             'Categorical')
+        roof['note'] = (
+            'flops counted at the padded shape: width %d, class stride %d; '
+            'useful fraction of them %.3f (%d features, %d classes)' % (
+                plan.width, plan.stride, useful, n_feat, n_classes))
+        roof['useful_fraction'] = useful
+        r = {'likelihood_arithmetic_used': hmc.likelihood_arithmetic_used,
+             'arithmetic_reason': hmc.arithmetic_reason,
+             'plan': hmc.plan_kind, 'plan_reason': hmc.plan_reason,
+             'ms_per_step': ms, 'steps': n_timed,
+             'value': n_chains * n_leapfrogs / (ms * 1e-3),
+             'unit': 'chain-leapfrog-steps/s', 'mean_acceptance': acc,
+             'roofline': roof}
+        del hmc, op, info, plan, w
         gc.collect()
-        w3 = (w_true / n_feat ** 0.5).unsqueeze(0).repeat(
-            n_chains, 1, 1).contiguous()
-        h3 = zs.HMC(step_size=eps, n_leapfrogs=n_leapfrogs, seed=6,
-                    likelihood_arithmetic='bf16x3')
-        op3, info3 = h3.sample(model(), {'y': y}, {'w': w3})
-        el3, k3, acc3 = _time_transitions(
-            torch, h3, op3, info3, {}, n_warm, n_timed, torch.cuda.synchronize)
-        ms3 = el3 / n_timed * 1e3
-        b3 = {'likelihood_arithmetic': h3.likelihood_arithmetic_used,
-              'ms_per_step': ms3, 'mean_acceptance': acc3,
-              'value': n_chains * n_leapfrogs / (ms3 * 1e-3),
-              'roofline': _b3_roofline(width, k3, flop_eval, n_leapfrogs, ms3)}
-        b3['roofline']['kernel'] = (
-            'linear_b3_kernel<%d, Categorical> gradient only' % width)
-        hmc = h3
-        plan = h3._plan
-    return {
-        'workload': 'beyond BASELINE.json (north_star\'s Categorical): '
-                    'softmax regression, %d classes x %d features, synthetic '
-                    '%d rows, %d chains, L=%d, literal X @ w^T, fixed step '
-                    'size %.2e' % (n_classes, n_feat, n_rows, n_chains,
-                                   n_leapfrogs, eps),
-        'plan': hmc.plan_kind, 'plan_reason': hmc.plan_reason,
-        'ms_per_step': ms, 'steps': n_timed,
-        'value': n_chains * n_leapfrogs / (ms * 1e-3),
-        'unit': 'chain-leapfrog-steps/s',
-        'mean_acceptance': acc,
-        'roofline': dict(_mfma_roofline(
-            _lik_kernel_name(plan.width, plan.block) + ' (Categorical mode)',
-            kern_ms, flop_eval, n_leapfrogs, ms),
-            note='flops counted at the padded shape: width %d, class stride '
-                 '%d; useful fraction of them %.3f (%d features, %d classes)'
-                 % (plan.width, plan.stride, useful, n_feat, n_classes)),
-        **({'bf16x3': b3} if b3 else {}),
-    }
+        return r
+    main = timed(None)                      # the default: 'auto'
+    out = dict(main)
+    out['workload'] = (
+        'beyond BASELINE.json (north_star\'s Categorical): softmax '
+        'regression, %d classes x %d features, synthetic %d rows, %d chains, '
+        'L=%d, literal X @ w^T, fixed step size %.2e' % (
+            n_classes, n_feat, n_rows, n_chains, n_leapfrogs, eps))
+    out['likelihood_arithmetic'] = ARITH_NOTE
+    if bf16x3 and main['likelihood_arithmetic_used'] == 'bf16x3':
+        # the same chains, state and step size on the exact-fp32 kernels
+        other = timed('fp32')
+        other['transition_time_over_default'] = \
+            other['ms_per_step'] / main['ms_per_step']
+        out['fp32'] = other
+    return out
 
 
 def extra_pmf(torch, zs, dev, n_particles=8, n_users=6040, n_items=3706,
@@ -864,7 +882,7 @@ def lntm_workload(torch, zs, dev, n_chains, sharding=None, dist=None,
     eta_mean = torch.zeros(n_docs, n_topics, device=dev)
     eta_logstd = torch.zeros(n_topics, device=dev)
 
-    def build(n, sh, arithmetic='fp32'):
+    def build(n, sh, arithmetic=None):
         @zs.meta_bayesian_net()
         def lntm():
             bn = zs.BayesianNet()
@@ -879,10 +897,10 @@ def lntm_workload(torch, zs, dev, n_chains, sharding=None, dist=None,
             return bn
         eta = torch.zeros(n, n_docs, n_topics, device=dev)
         f_ss, f_m = zs.placeholder(bool), zs.placeholder(bool)
+        kw = {} if arithmetic is None else {'likelihood_arithmetic': arithmetic}
         hmc = zs.HMC(step_size=1e-3, n_leapfrogs=n_leapfrogs,
                      adapt_step_size=f_ss, adapt_mass=f_m,
-                     target_acceptance_rate=0.6, seed=3, sharding=sh,
-                     likelihood_arithmetic=arithmetic)
+                     target_acceptance_rate=0.6, seed=3, sharding=sh, **kw)
         op, info = hmc.sample(lntm(), {'x': x}, {'eta': eta})
         return hmc, op, info, eta, (f_ss, f_m)
 
@@ -897,71 +915,71 @@ def lntm_workload(torch, zs, dev, n_chains, sharding=None, dist=None,
         dist.broadcast_object_list(box, src=0)
     state, eta_sub, ess_pt, acc_sub = box[0]
     eta_sub = eta_sub.to(dev)
-    hmc, op, info, eta, flags = build(n_chains, sharding)
     assert n_chains % n_sub == 0
-    eta.copy_(eta_sub.repeat(n_chains // n_sub, 1, 1))
-    hmc.set_state(state)
 
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-    elapsed, kern_ms, acc = _time_transitions(
-        torch, hmc, op, info, {flags[0]: True, flags[1]: True}, n_warm,
-        n_timed, barrier)
-    if world > 1:
-        tt = torch.tensor([elapsed, acc], dtype=torch.float64)
-        dist.all_reduce(tt[:1], op=dist.ReduceOp.MAX)
-        dist.all_reduce(tt[1:], op=dist.ReduceOp.SUM)
-        elapsed, acc = float(tt[0].item()), float(tt[1].item()) / world
-    ms = elapsed / n_timed * 1e3
     rows_rank = n_chains * n_docs
     rows = rows_rank * world
     flop_eval = 4.0 * rows_rank * n_topics * n_vocab      # per GPU per launch
-    roof = _mfma_roofline(
-        _lik_kernel_name(hmc._plan.width, hmc._plan.block) + ' (multinomial mode)',
-        kern_ms, flop_eval, n_leapfrogs, ms)
-    roof['note'] = 'per GPU (rank 0): one launch covers this rank\'s rows'
     full5 = (n_chains, n_docs, n_topics, n_vocab) == (8192, 5000, 128, 12419)
-    if full5:
-        roof['traffic'], roof['traffic_source'] = _recorded_mfma_traffic(
-            'multinomial grad-only')
-    plan_kind, step_size = hmc.plan_kind, float(info.updated_step_size.item())
     rccl_ranks = 0 if sharding is None else sharding.rccl_ranks
-    b3 = None
-    if world == 1 and bf16x3:
-        # the same rows, state, step size and mass with the likelihood on the
-        # bf16 matrix cores (the first plan's buffers are freed first: seven
-        # [rows, K] matrices each)
-        del hmc, op, info, eta
-        gc.collect()          # (sampler <-> plan <-> sample_op are a cycle)
-        torch.cuda.empty_cache()
-        hmc3, op3, info3, eta3, flags3 = build(n_chains, None, 'bf16x3')
-        eta3.copy_(eta_sub.repeat(n_chains // n_sub, 1, 1))
-        hmc3.set_state(state)
-        elapsed3, kern3, acc3 = _time_transitions(
-            torch, hmc3, op3, info3, {flags3[0]: True, flags3[1]: True},
-            n_warm, n_timed, barrier)
-        ms3 = elapsed3 / n_timed * 1e3
-        b3 = {
-            'likelihood_arithmetic': hmc3.likelihood_arithmetic_used,
-            'ms_per_step': ms3, 'steps': n_timed,
-            'value': rows * n_leapfrogs / (ms3 * 1e-3),
+
+    def timed(arithmetic, sh):
+        hmc, op, info, eta, flags = build(n_chains, sh, arithmetic)
+        eta.copy_(eta_sub.repeat(n_chains // n_sub, 1, 1))
+        hmc.set_state(state)
+        elapsed, kern_ms, acc = _time_transitions(
+            torch, hmc, op, info, {flags[0]: True, flags[1]: True}, n_warm,
+            n_timed, barrier)
+        if world > 1:
+            tt = torch.tensor([elapsed, acc], dtype=torch.float64)
+            dist.all_reduce(tt[:1], op=dist.ReduceOp.MAX)
+            dist.all_reduce(tt[1:], op=dist.ReduceOp.SUM)
+            elapsed, acc = float(tt[0].item()), float(tt[1].item()) / world
+        ms = elapsed / n_timed * 1e3
+        used = hmc.likelihood_arithmetic_used
+        roof = _lik_roofline(hmc, kern_ms, flop_eval, n_leapfrogs, ms,
+                             'multinomial')
+        roof['note'] = 'per GPU (rank 0): one launch covers this rank\'s rows'
+        if full5:
+            roof['traffic'], roof['traffic_source'] = _recorded_mfma_traffic(
+                'multinomial bf16x3 grad-only' if used == 'bf16x3' else
+                'multinomial grad-only')
+        r = {
+            'likelihood_arithmetic_used': used,
+            'arithmetic_reason': hmc.arithmetic_reason,
+            'plan': hmc.plan_kind,
+            'ms_per_step': ms, 'steps': n_timed,
+            'value': rows * n_leapfrogs / (ms * 1e-3),
             'unit': '(chain, document)-leapfrog-steps/s',
-            'speedup_over_fp32_transition': ms / ms3,
-            'mean_acceptance': acc3,
-            'roofline': _b3_roofline(hmc3._plan.width, kern3, flop_eval,
-                                     n_leapfrogs, ms3)
-            if hmc3.likelihood_arithmetic_used == 'bf16x3' else None,
+            'mean_acceptance': acc,
+            'step_size': float(info.updated_step_size.item()),
+            'roofline': roof,
         }
-        if full5 and b3['roofline']:
-            b3['roofline']['traffic'], b3['roofline']['traffic_source'] = \
-                _recorded_mfma_traffic('multinomial bf16x3 grad-only')
-        del hmc3, op3, info3, eta3
+        # (the plan's buffers are freed before the next one is built: seven
+        # [rows, K] matrices each; sampler <-> plan <-> sample_op are a cycle)
+        del hmc, op, info, eta
         gc.collect()
         torch.cuda.empty_cache()
-    return {
+        return r
+    main = timed(None, sharding)            # the default: 'auto'
+    other = None
+    if world == 1 and bf16x3:
+        # the same rows, state, step size and mass on the other arithmetic
+        other = timed(_other_arithmetic(main['likelihood_arithmetic_used']),
+                      None)
+        other['transition_time_over_default'] = \
+            other['ms_per_step'] / main['ms_per_step']
+        if other['likelihood_arithmetic_used'] == \
+                main['likelihood_arithmetic_used']:
+            other = None       # (no bf16x3 kernel for this shape: one figure)
+    ms = main['ms_per_step']
+    out = dict(main)
+    out.update({
         'workload': 'configs[4]: logistic-normal topic model E-step, chain '
                     'axes [n_chains=%d, n_docs=%d] (= %d rows; "8 192 chains" '
                     'read as n_chains at 8 GPUs: %d per GPU), K=%d, V=%d, '
@@ -969,17 +987,10 @@ def lntm_workload(torch, zs, dev, n_chains, sharding=None, dist=None,
                     'region, literal log(softmax(eta) @ phi) spelling' % (
                         n_chains * world, n_docs, rows, n_chains, n_topics,
                         n_vocab, n_leapfrogs),
-        'plan': plan_kind,
+        'likelihood_arithmetic': ARITH_NOTE,
         'n_gpus': world,
-        'ms_per_step': ms,
-        'steps': n_timed,
-        'value': rows * n_leapfrogs / (ms * 1e-3),
-        'unit': '(chain, document)-leapfrog-steps/s',
-        'mean_acceptance': acc,
         'mean_acceptance_subset_held_phase': acc_sub,
         'target_acceptance': 0.6,
-        'step_size': step_size,
-        'bf16x3': b3,
         'collective': 'none' if world == 1 else
                       'ONE all-reduce of %d doubles per transition '
                       '[sum acc, flag, colsum[2 x %d]]' % (
@@ -996,8 +1007,10 @@ def lntm_workload(torch, zs, dev, n_chains, sharding=None, dist=None,
                       'subset run with the same step size and mass, scaled '
                       'to %d rows at the timed rate' % rows,
         },
-        'roofline': roof,
-    }
+    })
+    if other is not None:
+        out[other['likelihood_arithmetic_used']] = other
+    return out
 
 
 def extra_config5(torch, zs, dev, n_chains=None, **kw):
@@ -1097,6 +1110,29 @@ def _over_ranks(dist, torch, world, x):
     return float(lo.item()), float(hi.item())
 
 
+def lntm_line_record(r, world, steps, warmup, note):
+    """The record of a `--workload lntm` line from lntm_workload's result."""
+    out = {
+        'metric': 'leapfrog-steps/sec', 'value': r['value'],
+        'unit': r['unit'], 'n_gpus': world, 'steps': steps,
+        'warmup': warmup, 'ms_per_step': r['ms_per_step'],
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'bf16x3' if r.get('likelihood_arithmetic_used') == 'bf16x3'
+        else 'f32', 'data': 'synthetic',
+        'config': {'workload': r['workload'],
+                   'parallelism': 'leading chain axis sharded over %d '
+                                  'GPU(s); %s' % (world, r['collective'])},
+        'collective_backend': note,
+    }
+    for k in ('plan', 'mean_acceptance', 'target_acceptance', 'step_size',
+              'rccl_ranks', 'start', 'ess', 'roofline'):
+        out[k] = r[k]
+    for k in ('bf16x3', 'fp32', 'likelihood_arithmetic_used'):
+        if k in r:
+            out[k] = r[k]
+    return out
+
+
 def run_lntm_line(args, torch, zs, dist, ChainSharding, dev, world, rank,
                   backend):
     """`--workload lntm`: BASELINE configs[4] as the line's own workload.
@@ -1112,21 +1148,7 @@ def run_lntm_line(args, torch, zs, dist, ChainSharding, dev, world, rank,
                       n_docs=args.lntm_docs, n_vocab=args.lntm_vocab,
                       n_timed=args.steps, n_warm=args.warmup)
     if rank == 0:
-        out = {
-            'metric': 'leapfrog-steps/sec', 'value': r['value'],
-            'unit': r['unit'], 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': r['ms_per_step'],
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': r['workload'],
-                       'parallelism': 'leading chain axis sharded over %d '
-                                      'GPU(s); %s' % (world, r['collective'])},
-            'collective_backend': note,
-        }
-        for k in ('plan', 'mean_acceptance', 'target_acceptance', 'step_size',
-                  'rccl_ranks', 'start', 'ess', 'roofline'):
-            out[k] = r[k]
-        print(json.dumps(out))
+        emit(lntm_line_record(r, world, args.steps, args.warmup, note))
     if world > 1:
         try:
             sharding.close()
@@ -1156,6 +1178,255 @@ def self_launch(n_gpus):
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     return subprocess.call(cmd, env=env)
+
+
+# ---------------------------------------------------------------------------
+# Output.  stdout carries, in this order:
+#   `#bench-extra {...}`   one line per extra configuration, as it finishes
+#   `#bench-detail {...}`  everything measured around the headline
+#   `{...}`                THE contract line: last line, the only one that
+#                          starts with `{`, <= CONTRACT_MAX_BYTES, strict JSON
+# and bench_extras.json (next to bench.py) holds the full record.
+CONTRACT_MAX_BYTES = 4096
+EXTRA_PREFIX = '#bench-extra '
+DETAIL_PREFIX = '#bench-detail '
+EXTRAS_FILE = os.path.join(ROOT, 'bench_extras.json')
+
+_ROOFLINE_KEYS = ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac',
+                  'traffic', 'kernel_ms', 'kernel_launches_timed',
+                  'algorithmic_bytes_per_launch',
+                  'algorithmic_flop_per_launch', 'dtype', 'rng')
+_CPU_KEYS = ('value', 'unit', 'cores', 'kind', 'sample')
+# dropped from the contract line, last first, should it ever outgrow its bound
+_OPTIONAL = ('extras', 'strong_scaling', 'allreduce_latency_us', 'ess',
+             'cpu_reference_over_shim', 'mass_adaptation_overhead',
+             'other_adaptation_mode', 'elem_leapfrog_steps_per_sec',
+             'mean_acceptance', 'step_size')
+
+
+def strict(o):
+    """A copy of `o` that json.dumps(allow_nan=False) accepts: non-finite
+    floats become null, NumPy scalars / arrays become Python ones."""
+    if isinstance(o, dict):
+        return {str(k): strict(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [strict(v) for v in o]
+    if isinstance(o, np.ndarray):
+        return strict(o.tolist())
+    if isinstance(o, np.generic):
+        o = o.item()
+    if isinstance(o, float) and not np.isfinite(o):
+        return None
+    return o
+
+
+def _dumps(o):
+    return json.dumps(strict(o), allow_nan=False, separators=(',', ':'))
+
+
+def _short(x, digits=6):
+    return float('%.*g' % (digits, x)) if isinstance(x, float) else x
+
+
+def summarize_extra(e):
+    """One extra configuration in ~150 bytes for the contract line."""
+    s = {'id': e.get('id', str(e.get('workload', '?'))[:24])}
+    if 'error' in e:
+        s['error'] = str(e['error'])[:80]
+        return s
+    for k in ('ms_per_step', 'value', 'n_gpus'):
+        if k in e:
+            s[k] = _short(e[k])
+    roof = e.get('roofline') or {}
+    if roof.get('frac') is not None:
+        s['frac'] = _short(roof['frac'], 4)
+        s['bound'] = roof.get('bound')
+    if 'likelihood_arithmetic_used' in e:
+        s['arith'] = e['likelihood_arithmetic_used']
+    b3 = e.get('bf16x3')
+    if isinstance(b3, dict) and 'ms_per_step' in b3:
+        s['bf16x3'] = {'ms_per_step': _short(b3['ms_per_step'])}
+        f = (b3.get('roofline') or {}).get('frac')
+        if f is not None:
+            s['bf16x3']['frac'] = _short(f, 4)
+    f32 = e.get('fp32')
+    if isinstance(f32, dict) and 'ms_per_step' in f32:
+        s['fp32'] = {'ms_per_step': _short(f32['ms_per_step'])}
+        f = (f32.get('roofline') or {}).get('frac')
+        if f is not None:
+            s['fp32']['frac'] = _short(f, 4)
+    return s
+
+
+def contract_line(out):
+    """The compact object the driver parses: the contract keys, a trimmed
+    `roofline` and `cpu_baseline`, a few scalars, one short entry per extra
+    configuration.  Always <= CONTRACT_MAX_BYTES and strict JSON."""
+    line = {}
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup',
+              'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+              'dtype', 'data'):
+        line[k] = out.get(k)
+    cfg = dict(out.get('config') or {})
+    if len(str(cfg.get('workload', ''))) > 200:
+        cfg['workload'] = str(cfg['workload'])[:197] + '...'
+    line['config'] = cfg
+    for k in ('rccl_ranks', 'collective', 'plan'):
+        if k in out:
+            line[k] = out[k]
+    roof = out.get('roofline')
+    if roof is not None:
+        line['roofline'] = {k: roof[k] for k in _ROOFLINE_KEYS if k in roof}
+    cpu = out.get('cpu_baseline')
+    if cpu is not None:
+        line['cpu_baseline'] = {k: cpu[k] for k in _CPU_KEYS if k in cpu}
+        if 'error' in cpu:
+            line['cpu_baseline']['error'] = str(cpu['error'])[:120]
+    for k in ('mean_acceptance', 'step_size', 'elem_leapfrog_steps_per_sec'):
+        if k in out:
+            line[k] = out[k]
+    if out.get('ess'):
+        line['ess'] = {k: v for k, v in out['ess'].items() if k != 'method'}
+    om = out.get('other_adaptation_mode')
+    if om:
+        line['other_adaptation_mode'] = {k: om[k] for k in (
+            'adaptation', 'ms_per_step', 'value') if k in om}
+    mm = out.get('mass_adaptation_modes')
+    if mm and mm.get('overhead_of_adapting') is not None:
+        line['mass_adaptation_overhead'] = _short(mm['overhead_of_adapting'], 4)
+    ref = out.get('cpu_reference_over_shim')
+    if ref:
+        line['cpu_reference_over_shim'] = {k: ref[k] for k in (
+            'value', 'unit', 'cores', 'transitions_per_sec', 'config')
+            if k in ref}
+    ar = out.get('allreduce_latency_us')
+    if ar:
+        line['allreduce_latency_us'] = {k: _short(ar[k], 4) for k in (
+            'min_over_ranks', 'max_over_ranks') if k in ar}
+    ss = out.get('strong_scaling')
+    if ss:
+        line['strong_scaling'] = {k: ss[k] for k in (
+            'n_chains_total', 'chains_per_gpu', 'ms_per_step', 'value')
+            if k in ss}
+    if out.get('extra_configs'):
+        line['extras'] = [summarize_extra(e) for e in out['extra_configs']]
+    line['detail'] = 'bench_extras.json; stdout lines prefixed %s/ %s' % (
+        EXTRA_PREFIX.strip(), DETAIL_PREFIX.strip())
+    text = _dumps(line)
+    for k in _OPTIONAL:
+        if len(text) <= CONTRACT_MAX_BYTES:
+            break
+        line.pop(k, None)
+        text = _dumps(line)
+    if len(text) > CONTRACT_MAX_BYTES:
+        raise RuntimeError('contract line of %d bytes' % len(text))
+    return text
+
+
+_emit_lock = None
+_emitted = False
+
+
+def emit_extra(e, stream=None):
+    """An extra configuration's full record, on its own prefixed stdout line
+    the moment it is known."""
+    stream = stream or sys.stdout
+    stream.write(EXTRA_PREFIX + _dumps(e) + '\n')
+    stream.flush()
+
+
+def emit(out, stream=None, extras_file=''):
+    """Write the full record to bench_extras.json and to a prefixed stdout
+    line, then THE contract line -- once per process, whoever calls first
+    (the normal end of main, the watchdog, or the SIGTERM guard)."""
+    global _emitted
+    import threading
+    global _emit_lock
+    if _emit_lock is None:
+        _emit_lock = threading.Lock()
+    with _emit_lock:
+        if _emitted:
+            return None
+        _emitted = True
+        stream = stream or sys.stdout
+        full = strict(out)
+        if extras_file == '':
+            extras_file = EXTRAS_FILE
+        if extras_file:
+            try:
+                with open(extras_file, 'w') as f:
+                    json.dump(full, f, allow_nan=False, indent=1)
+                    f.write('\n')
+            except OSError as e:
+                sys.stderr.write('bench.py: %s not written: %r\n' % (
+                    extras_file, e))
+        detail = {k: v for k, v in full.items() if k != 'extra_configs'}
+        stream.write(DETAIL_PREFIX + _dumps(detail) + '\n')
+        text = contract_line(out)
+        stream.write(text + '\n')
+        stream.flush()
+        return text
+
+
+def guard_headline(out, rank, timeout_s):
+    """N > 1, while the sharded extra runs: should it stall (RCCL, a peer that
+    died) or the launcher tear the job down (SIGTERM after another rank's
+    failure), rank 0 still prints the headline measured before it and the
+    process ends.  Returns a `disarm()` callable.  The SIGTERM side does not
+    depend on the main thread reaching a bytecode boundary (it may sit in a
+    HIP call): the C-level handler writes to a wake-up pipe that a helper
+    thread blocks on."""
+    import signal
+    import threading
+
+    def give_up(why):
+        if rank == 0:
+            out.setdefault('extra_configs', []).append(
+                {'id': 'configs[4] sharded', 'error': why})
+            emit(out)
+        os._exit(0)
+
+    timer = threading.Timer(timeout_s + (0 if rank == 0 else 5), give_up,
+                            args=('did not finish within %d s' % timeout_s,))
+    timer.daemon = True
+    timer.start()
+    rd, wr = os.pipe()
+    os.set_blocking(wr, False)
+    state = {'armed': True}
+
+    def waiter():
+        while True:
+            try:
+                b = os.read(rd, 1)     # the number of the signal that arrived
+            except OSError:
+                return
+            if not state['armed'] or not b:
+                return
+            if b[0] == signal.SIGTERM:
+                give_up('SIGTERM from the launcher (a peer rank failed)')
+    th = threading.Thread(target=waiter, daemon=True)
+    th.start()
+    old_fd, old_handler = None, None
+    try:
+        old_handler = signal.signal(signal.SIGTERM, lambda *a: None)
+        old_fd = signal.set_wakeup_fd(wr, warn_on_full_buffer=False)
+    except ValueError:                 # not the main thread: timer only
+        pass
+
+    def disarm():
+        state['armed'] = False
+        timer.cancel()
+        try:
+            if old_handler is not None:
+                signal.set_wakeup_fd(old_fd if old_fd is not None else -1)
+                signal.signal(signal.SIGTERM, old_handler)
+        except ValueError:
+            pass
+        try:
+            os.write(wr, b'x')
+        except OSError:
+            pass
+    return disarm
 
 
 def _capi_kernel_name(n_data, has_mass, zero_mean):
@@ -1674,64 +1945,65 @@ def main():
     # 2 + 2 K doubles per transition on the same communicator.
     extras = None
     if not args.no_extra_configs:
-        # N > 1: the sharded extra has collectives in it; should a rank fail
-        # or RCCL stall there, the headline measured above must still be
-        # printed -- a watchdog emits it and ends the process
-        watchdog = None
+        # N > 1: the sharded extra has collectives in it; should a rank fail,
+        # RCCL stall there or the launcher tear the job down, the headline
+        # measured above must still be printed (guard_headline)
+        disarm = None
         if world > 1:
-            import threading
-
-            def give_up():
-                if rank == 0:
-                    out['extra_configs'] = [{
-                        'workload': 'configs[4] sharded', 'error':
-                        'did not finish within %d s' % EXTRA_TIMEOUT_S}]
-                    print(json.dumps(out))
-                    sys.stdout.flush()
-                os._exit(0)
-            watchdog = threading.Timer(EXTRA_TIMEOUT_S + (0 if rank == 0
-                                                          else 5), give_up)
-            watchdog.daemon = True
-            watchdog.start()
+            if rank == 0:
+                # (the same figures, early, where a log reader finds them even
+                # if the process is killed outright)
+                sys.stderr.write('#bench-headline ' + contract_line(out) + '\n')
+                sys.stderr.flush()
+            disarm = guard_headline(out, rank, EXTRA_TIMEOUT_S)
         del x
         torch.cuda.empty_cache()
         from zhusuan_amd import _ops
         extras = []
         if world == 1:
-            todo = ((extra_config1, {}), (extra_config3, {}),
-                    (extra_config5, {'n_chains': args.config5_chains}),
-                    (extra_wide_regression, {}),
-                    (extra_wide_regression, {'n_feat': 299,
-                                             'n_chains': 16384}),
-                    (extra_softmax_regression, {}),
-                    (extra_softmax_regression, {'n_feat': 256, 'bf16x3': True}),
-                    (extra_pmf, {}),
-                    (extra_estep, {}))
+            todo = (('configs[0]', extra_config1, {}),
+                    ('configs[2]', extra_config3, {}),
+                    ('configs[4]', extra_config5,
+                     {'n_chains': args.config5_chains}),
+                    ('blr-1000+bias', extra_wide_regression, {}),
+                    ('blr-299+bias', extra_wide_regression,
+                     {'n_feat': 299, 'n_chains': 16384}),
+                    ('softmax-10x784', extra_softmax_regression, {}),
+                    ('softmax-10x256', extra_softmax_regression,
+                     {'n_feat': 256, 'bf16x3': True}),
+                    ('pmf', extra_pmf, {}),
+                    ('lntm-estep', extra_estep, {}))
         else:
-            todo = ((lntm_workload, dict(
+            todo = (('configs[4] sharded', lntm_workload, dict(
                 n_chains=args.lntm_chains_per_gpu,
                 sharding=sharding.relayout(), dist=dist,
                 n_docs=args.lntm_docs, n_vocab=args.lntm_vocab)),)
-        for fn, kw in todo:
+        only = os.environ.get('ZSHMC_BENCH_EXTRAS')
+        if only:
+            todo = tuple(t for t in todo if t[0] in only.split(','))
+        for ident, fn, kw in todo:
             try:
-                extras.append(fn(torch, zs, dev, **kw))
-            except Exception as e:           # report, never lose the headline
+                e = fn(torch, zs, dev, **kw)
+            except Exception as err:         # report, never lose the headline
                 if world > 1:
-                    # (the peers are in a collective: let the watchdog print)
-                    sys.stderr.write('rank %d: %r\n' % (rank, e))
+                    # (the peers are in a collective: let the guard print)
+                    sys.stderr.write('rank %d: %r\n' % (rank, err))
                     time.sleep(EXTRA_TIMEOUT_S + 10)
-                extras.append({'workload': fn.__name__,
-                               'error': repr(e)[:300]})
+                e = {'workload': fn.__name__, 'error': repr(err)[:300]}
+            e = dict(e, id=ident)
+            extras.append(e)
+            if rank == 0:
+                emit_extra(e)
             _ops.clear_caches()
             torch.cuda.empty_cache()
         if world > 1:
             barrier()
-            watchdog.cancel()
+            disarm()
 
     if rank == 0:
         if extras is not None:
             out['extra_configs'] = extras
-        print(json.dumps(out))
+        emit(out)
     if world > 1:
         # every rank has passed the last barrier with an idle stream: the
         # communicator can go (a failure here must not cost the line above)

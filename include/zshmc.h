@@ -779,7 +779,8 @@ int zshmc_categorical_sample(int32_t* out, const float* logits,
  *   log_lik[k] = sum over pairs of log N(obs; sigmoid(u_i . v_j), exp(logstd))
  *                + lp_const[k];  grad [n_chains, n_latent, n_dim]
  *   n_dim <= 128, a multiple of 4; tables 16-byte aligned;
- *   workspace: n_chains * n_segments * (n_dim + 1) floats.
+ *   workspace: 16-byte aligned, n_chains * n_segments * n_dim +
+ *              round_up(n_chains * n_segments, 4) floats.
  * Deterministic (fixed summation order, no atomics). */
 int zshmc_gather_dot_normal_lik_grad(
     const float* latent, const float* other, const int32_t* seg_ptr,

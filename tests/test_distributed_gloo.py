@@ -1,4 +1,5 @@
-"""N > 1 path on CPU: two `gloo` ranks shard the chain axis.  The product's
+"""N > 1 path on CPU: 2, 4 and 8 `gloo` ranks shard the chain axis (even and
+uneven shards, down to ONE chain on a rank).  The product's
 ChainSharding (layout all-gather + adaptation all-reduces) is exercised for
 real; the per-rank transition is the NumPy oracle (no GPU here), fed through
 the same hooks the GPU plan uses (global chain offset for the RNG counters,
@@ -75,24 +76,36 @@ def _worker(rank, world, port, splits, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('splits', [[(0, 48), (48, 96)], [(0, 31), (31, 96)]])
-def test_two_rank_sharded_run_matches_single_process(tmp_path, splits):
+def _even(world):
+    from zhusuan_amd.distributed import shard_bounds
+    return [shard_bounds(C, r, world) for r in range(world)]
+
+
+@pytest.mark.parametrize('splits', [
+    [(0, 48), (48, 96)], [(0, 31), (31, 96)],
+    _even(4), [(0, 5), (5, 40), (40, 41), (41, 96)],
+    _even(8), [(0, 1), (1, 20), (20, 33), (33, 34), (34, 60), (60, 61),
+               (61, 90), (90, 96)]],
+    ids=['2-even', '2-uneven', '4-even', '4-uneven', '8-even', '8-uneven'])
+def test_sharded_run_matches_single_process(tmp_path, splits):
+    world = len(splits)
     _, _, q0 = _problem()
     eps1, acc1, q1, mass1 = _run_oracle(q0.copy())
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, splits, str(tmp_path)), nprocs=2,
+    mp.spawn(_worker, args=(world, port, splits, str(tmp_path)), nprocs=world,
              join=True)
     r = [np.load(os.path.join(str(tmp_path), 'rank%d.npz' % i))
-         for i in range(2)]
-    # replicated adaptation state is identical on both ranks
-    np.testing.assert_array_equal(r[0]['eps'], r[1]['eps'])
-    np.testing.assert_array_equal(r[0]['mass'], r[1]['mass'])
+         for i in range(world)]
+    # replicated adaptation state is identical on every rank
+    for other in r[1:]:
+        np.testing.assert_array_equal(r[0]['eps'], other['eps'])
+        np.testing.assert_array_equal(r[0]['mass'], other['mass'])
     # and equals the single-process run up to float32 summation order
     np.testing.assert_allclose(r[0]['eps'], eps1, rtol=2e-5)
     np.testing.assert_allclose(r[0]['mass'], mass1, rtol=2e-4)
-    acc = np.concatenate([r[0]['acc'], r[1]['acc']], axis=1)
+    acc = np.concatenate([x['acc'] for x in r], axis=1)
     np.testing.assert_allclose(acc, acc1, atol=2e-4)
-    q = np.concatenate([r[0]['q'], r[1]['q']], axis=0)
+    q = np.concatenate([x['q'] for x in r], axis=0)
     close = np.isclose(q, q1, atol=1e-3).all(axis=1)
     assert close.mean() >= 0.97       # a borderline accept may flip
 

@@ -428,3 +428,63 @@ def test_hmc_on_bf16x3_run_many_equals_a_loop_of_runs(env):
         np.testing.assert_array_equal(out[mode][0], out['loop'][0])
         np.testing.assert_array_equal(out[mode][1], out['loop'][1])
         assert out[mode][2] == out['loop'][2]
+
+
+def test_default_arithmetic_and_the_fallback_warning(env):
+    """likelihood_arithmetic='auto' (the default): bf16x3 where a kernel
+    exists and one evaluation is >= 1e10 flop, the fp32 kernels for small
+    (latency-bound) problems and for widths without a bf16x3 kernel --
+    silently.  An explicit 'bf16x3' that cannot be honoured runs fp32 too,
+    with a LikelihoodArithmeticWarning; `hmc.arithmetic_reason` says why."""
+    import warnings
+    torch, _capi, dev = env
+    import zhusuan_amd as zs
+    from zhusuan_amd import _ops
+    g = torch.Generator(device=dev).manual_seed(0)
+
+    def sampler(N, D, C, **kw):
+        X = torch.randn(N, D, device=dev, generator=g)
+        y = (torch.rand(N, device=dev, generator=g) < 0.5).float()
+
+        @zs.meta_bayesian_net()
+        def blr():
+            bn = zs.BayesianNet()
+            wn = bn.normal('w', torch.zeros(D, device=dev), std=1.,
+                           n_samples=C, group_ndims=1)
+            bn.bernoulli('y', wn.tensor @ X.t(), group_ndims=1,
+                         dtype=torch.float32)
+            return bn
+        hmc = zs.HMC(step_size=1e-3, n_leapfrogs=2, seed=1, **kw)
+        w = torch.zeros(C, D, device=dev)
+        op, info = hmc.sample(blr(), {'y': y}, {'w': w})
+        assert hmc.plan_kind == 'linear_bernoulli'
+        op.run()
+        assert bool(torch.isfinite(info.log_prob).all())
+        return hmc
+
+    with warnings.catch_warnings():
+        warnings.simplefilter('error', zs.LikelihoodArithmeticWarning)
+        # 4 * 20 000 * 128 * 2 048 = 2.1e10 flop: the matrix cores' problem
+        big = sampler(20000, 100, 2048)
+        assert big.likelihood_arithmetic == 'auto'
+        assert big.likelihood_arithmetic_used == 'bf16x3'
+        assert big.arithmetic_reason is None
+        # 4 * 500 * 64 * 256 = 3.3e7 flop: latency-bound
+        small = sampler(500, 40, 256)
+        assert small.likelihood_arithmetic_used == 'fp32'
+        assert 'latency-bound' in small.arithmetic_reason
+        # asked for by name, it is taken at any size
+        assert sampler(500, 40, 256, likelihood_arithmetic='bf16x3'
+                       ).likelihood_arithmetic_used == 'bf16x3'
+        # no bf16x3 kernel past 256 padded columns: 'auto' says nothing
+        wide = sampler(40000, 300, 1024)
+        assert wide.likelihood_arithmetic_used == 'fp32'
+        assert '320' in wide.arithmetic_reason
+        assert sampler(500, 40, 256, likelihood_arithmetic='fp32'
+                       ).arithmetic_reason is None
+    with pytest.warns(zs.LikelihoodArithmeticWarning, match='<= 256 padded'):
+        wide = sampler(2000, 300, 128, likelihood_arithmetic='bf16x3')
+    assert wide.likelihood_arithmetic_used == 'fp32'
+    with pytest.raises(ValueError, match="'auto', 'fp32' or 'bf16x3'"):
+        zs.HMC(likelihood_arithmetic='fp16')
+    assert _ops.BF16X3_AUTO_MIN_FLOP == 1.0e10

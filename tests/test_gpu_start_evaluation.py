@@ -159,3 +159,38 @@ def test_a_second_sampler_on_the_same_latent_invalidates_the_first(env):
     op1.run()
     ok, got, want = _start_matches(info1, w_before, Xh, yh)
     assert ok, np.abs(got - want).max()
+
+
+@pytest.mark.parametrize('D', [64, 60])
+def test_a_latent_observed_by_another_sampler(env, D):
+    """a Gibbs-style alternation -- sampler A's design
+    matrix IS sampler B's latent and the other way round.  B moves it through
+    the C-ABI (no torch version bump): A must drop the start evaluation it
+    carries, and (D = 60: not a kernel width) the zero-padded copy of the
+    design matrix it cached, and evaluate its start under the new values."""
+    zs, torch, dev = env
+    rng = np.random.RandomState(4)
+    N, C = 128, 96
+    Xt = torch.tensor((0.3 * rng.normal(size=(N, D))).astype(np.float32),
+                      device=dev)
+    Wt = torch.tensor((0.3 * rng.normal(size=(C, D))).astype(np.float32),
+                      device=dev)
+    ya = (rng.uniform(size=N) < 0.5).astype(np.int32)
+    yb = (rng.uniform(size=C) < 0.5).astype(np.int32)
+    ha, opa, infoa = _sampler(zs, torch, dev, Xt, torch.tensor(ya, device=dev),
+                              Wt, seed=11)
+    hb, opb, infob = _sampler(zs, torch, dev, Wt, torch.tensor(yb, device=dev),
+                              Xt, seed=12)
+    for i in range(4):
+        for op, info, lat, design, y in ((opa, infoa, Wt, Xt, ya),
+                                         (opb, infob, Xt, Wt, yb)):
+            before, other = lat.cpu().numpy(), design.cpu().numpy()
+            op.run()
+            ok, got, want = _start_matches(info, before, other, y)
+            assert ok, (i, np.abs(got - want).max())
+    # the C-side launch loop notes its writes too
+    opb.run_many(3)
+    before, other = Wt.cpu().numpy(), Xt.cpu().numpy()
+    opa.run()
+    ok, got, want = _start_matches(infoa, before, other, ya)
+    assert ok, np.abs(got - want).max()

@@ -1,5 +1,6 @@
-"""The N > 1 path of the NON-fused plans on real kernels: two processes
-(gloo rendezvous, both on cuda:0) shard the leading chain axis of the
+"""The N > 1 path of the NON-fused plans on real kernels: 2, 4 and 8
+processes (gloo rendezvous, all on cuda:0; 10 / 14 chains, so that at 8 ranks
+the shards are uneven and most hold ONE chain) shard the leading chain axis of the
 topic-model E step (BASELINE configs[4] family, `_DenseLikelihoodPlan`, mass
 adaptation on: ONE all-reduce of [sum acc, flag, colsum[2 K]] per
 transition) and of Bayesian logistic regression, on the native plans and on
@@ -36,17 +37,19 @@ def _free_port():
     return p
 
 
-@pytest.fixture(scope='module')
-def ranks(tmp_path_factory):
+@pytest.fixture(scope='module', params=[2, 4, 8],
+                ids=lambda w: 'world%d' % w)
+def ranks(request, tmp_path_factory):
+    world = request.param
     out = tmp_path_factory.mktemp('sharded_plans')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
-           '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
            '--master-port', str(_free_port()),
            os.path.join(HERE, 'sharded_plan_worker.py'), str(out)]
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True,
                        timeout=900)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
-    return [np.load(str(out / ('rank%d.npz' % i))) for i in range(2)]
+    return [np.load(str(out / ('rank%d.npz' % i))) for i in range(world)]
 
 
 @pytest.mark.parametrize('family', ['lntm', 'blr', 'blrb'])
@@ -65,11 +68,12 @@ def test_sharded_plan_matches_single_process(ranks, family, native):
     np.testing.assert_array_equal(q, one['q'])
     np.testing.assert_array_equal(acc, one['acc'].reshape(-1))
 
-    # adaptation on (step size + mass): replicated state identical on both
-    # ranks and equal to the single-process run up to summation order
+    # adaptation on (step size + mass): replicated state identical on every
+    # rank and equal to the single-process run up to summation order
     one = cases.run(zs, torch, dev, family, 0, n, True, None, native)
     for k in ('step_size', 'state', 'mass'):
-        np.testing.assert_array_equal(ranks[0][key(1, k)], ranks[1][key(1, k)])
+        for r in ranks[1:]:
+            np.testing.assert_array_equal(ranks[0][key(1, k)], r[key(1, k)])
     np.testing.assert_allclose(ranks[0][key(1, 'state')], one['state'],
                                rtol=2e-5, atol=1e-6)
     np.testing.assert_allclose(ranks[0][key(1, 'mass')], one['mass'],

@@ -671,3 +671,50 @@ def test_row_range_slices_policy(monkeypatch):
     assert _ops.resident_per_cu(128, 'bf16x3') == 2
     assert _ops.resident_per_cu(256, 'bf16x3') == 1
     assert _ops.resident_per_cu(64) == 3 and _ops.resident_per_cu(512) == 1
+
+
+def test_forget_drops_one_model_s_cached_operands_only():
+    """reuse_start_evaluation=False used to clear the process-wide
+    operand caches on every run; it now drops what was built from ITS model's
+    tensors (and what was built from those in turn), nothing else."""
+    import torch
+    from zhusuan_amd import _ops
+    _ops.clear_caches()
+    Xa, Xb = torch.randn(6, 5), torch.randn(7, 5)
+    pa, pb = _ops._padded_x(Xa, 8), _ops._padded_x(Xb, 8)
+    assert _ops._padded_x(Xa, 8) is pa and _ops._padded_x(Xb, 8) is pb
+    # something derived from the padded copy of A (as the bf16x3 image is)
+    _ops._image_cache.put(_ops._tensor_key(pa), 'image of A', pa)
+    _ops._image_cache.put(_ops._tensor_key(pb), 'image of B', pb)
+    phi = torch.rand(3, 9)
+    pt = _ops._padded_phi_t(phi, 4)
+    _ops.forget([Xa.t().t()])                    # a view: same storage
+    assert _ops._padded_x(Xb, 8) is pb
+    assert _ops._image_cache.get(_ops._tensor_key(pb)) == 'image of B'
+    assert _ops._image_cache.get(_ops._tensor_key(pa)) is None
+    assert _ops._padded_phi_t(phi, 4) is pt
+    assert _ops._padded_x(Xa, 8) is not pa
+    _ops.forget([phi, None])
+    assert _ops._padded_phi_t(phi, 4) is not pt
+    _ops.clear_caches()
+
+
+def test_write_generations_never_repeat():
+    """generations come from ONE counter, so an entry that was
+    evicted and made again cannot equal a value recorded before."""
+    import torch
+    from zhusuan_amd import _writes
+    a, b = torch.zeros(3), torch.zeros(3)
+    _writes.note([a])
+    ga = _writes.generation(a)
+    _writes.note([b])
+    assert _writes.generation(b) > ga
+    _writes._generation.pop(_writes._key(a))     # "evicted"
+    assert _writes.generation(a) == 0
+    _writes.note([a])
+    assert _writes.generation(a) > _writes.generation(b) > ga
+    # ... and it is part of every operand-cache key
+    from zhusuan_amd import _ops
+    k0 = _ops._tensor_key(a)
+    _writes.note([a])
+    assert _ops._tensor_key(a) != k0

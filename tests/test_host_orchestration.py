@@ -147,15 +147,16 @@ def _worker(rank, world, port, out_dir, read_every_run, mass):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('read_every_run,mass', [(True, False), (False, False),
-                                                 (False, True)])
-def test_two_rank_orchestration_matches_oracle(tmp_path, read_every_run, mass):
-    """Sharded chains: the update of transition t is applied in the prologue
-    of launch t + 1 from the all-reduced sum -- or by flush when the step
-    size is read first; both ranks follow the single-process oracle either
-    way."""
+@pytest.mark.parametrize('world,read_every_run,mass', [
+    (2, True, False), (2, False, False), (2, False, True),
+    (4, False, True), (8, True, False), (8, False, True)])
+def test_sharded_orchestration_matches_oracle(tmp_path, world, read_every_run,
+                                              mass):
+    """Sharded chains (2, 4, 8 ranks; uneven shards when C does not divide):
+    the update of transition t is applied in the prologue of launch t + 1
+    from the all-reduced sum -- or by flush when the step size is read first;
+    every rank follows the single-process oracle either way."""
     want_eps, want_q = _reference(mass)
-    world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path),
                             read_every_run, mass), nprocs=world, join=True)
     rows = []

@@ -7,11 +7,11 @@ TF-CPU HMC timed on the host cores" -- TensorFlow is not installable -- and it
 can only run where /root/reference exists, i.e. in the BUILD container (the GPU
 box has no copy of the reference and the sources may not be vendored):
 bench.py therefore carries this number as a recorded value
-(profiles/archive/r02_cpu_reference_over_shim.json, `measured_on` says where), next to
+(profiles/cpu_reference_over_shim.json, `measured_on` says where), next to
 the baselines it measures live on the GPU box's own cores.
 
     python tools/time_reference_over_shim.py [seconds] [C D L out.json]
-(e.g. `10 1000 10 5 profiles/archive/r03_cpu_reference_over_shim_config1.json`:
+(e.g. `10 1000 10 5 profiles/cpu_reference_over_shim_config1.json`:
 BASELINE configs[0], the gaussian.py shape)
 """
 import json
@@ -29,7 +29,7 @@ from oracle.make_golden_hmc import gaussian_model, load_reference  # noqa: E402
 
 C, D, L = 4096, 1024, 10
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 20.0
-OUT = os.path.join(ROOT, 'profiles', 'r02_cpu_reference_over_shim.json')
+OUT = os.path.join(ROOT, 'profiles', 'cpu_reference_over_shim.json')
 if len(sys.argv) > 5:
     C, D, L = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
     OUT = os.path.join(ROOT, sys.argv[5])

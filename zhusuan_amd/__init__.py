@@ -13,14 +13,15 @@ from .distributions import (linear_class_logits, linear_logits,
 from ._ops import gathered_dot, clear_caches
 from .evaluation import AIS
 from .hmc import (HMC, HMCInfo, InvalidArgumentError,
-                  NativePlanFallbackWarning, placeholder, deferred)
+                  NativePlanFallbackWarning, LikelihoodArithmeticWarning,
+                  placeholder, deferred)
 from .session import Session
 from .sgmcmc import SGMCMC, SGLD, PSGLD, SGHMC, SGNHT
 from .utils import merge_dicts, set_random_seed
 
 __version__ = '0.1.0'
 
-__all__ = ['SGMCMC', 'SGLD', 'PSGLD', 'SGHMC', 'SGNHT', 'AIS', 'evaluation', 'HMC', 'HMCInfo', 'InvalidArgumentError', 'NativePlanFallbackWarning', 'placeholder', 'deferred', 'Session',
+__all__ = ['SGMCMC', 'SGLD', 'PSGLD', 'SGHMC', 'SGNHT', 'AIS', 'evaluation', 'HMC', 'HMCInfo', 'InvalidArgumentError', 'NativePlanFallbackWarning', 'LikelihoodArithmeticWarning', 'placeholder', 'deferred', 'Session',
            'BayesianNet', 'MetaBayesianNet', 'StochasticTensor',
            'meta_bayesian_net', 'distributions', 'diagnostics', 'framework',
            'merge_dicts', 'set_random_seed', 'linear_logits', 'linear_class_logits', 'log_mixture', 'gathered_dot', 'clear_caches']

@@ -11,7 +11,7 @@ import torch
 
 from .utils import broadcast_shapes
 
-from . import _capi, _symbolic
+from . import _capi, _symbolic, _writes
 
 _F32 = torch.float32
 
@@ -197,7 +197,7 @@ def _pair_csr(index, n_rows, slot):
     passed again -- every leapfrog step of a transition reuses the pair list;
     the entry pins the tensor so its address cannot be recycled."""
     key = (index.data_ptr(), tuple(index.shape), index._version, int(n_rows),
-           index.dtype)
+           index.dtype, _writes.generation(index))
     hit = _csr_cache.get(slot)
     if hit is not None and hit[0] == key:
         return hit[1]
@@ -316,6 +316,41 @@ def clear_caches():
     _csr_cache.clear()
     _image_cache.clear()
     _label_cache.clear()
+
+
+def _storages(x, out):
+    if torch.is_tensor(x):
+        out.add((str(x.device), x.untyped_storage().data_ptr()))
+    elif isinstance(x, (tuple, list)):
+        for y in x:
+            _storages(y, out)
+    return out
+
+
+def forget(tensors):
+    """Drop the cached operands that were built from any of `tensors` (or
+    from a view of the same storage), and what was built from THOSE in turn
+    (the bf16x3 image of a padded copy) -- the other models' entries stay.
+    What a sampler with reuse_start_evaluation=False does before every run:
+    nothing about ITS model's tensors is remembered."""
+    gone = _storages(list(tensors), set())
+    caches = (_x_cache, _design_cache, _phi_cache, _counts_cache, _csr_cache,
+              _image_cache, _label_cache)
+    again = True
+    while again:
+        again = False
+        for c in caches:
+            slotted = isinstance(c, dict)       # {slot: (key, value, pins)}
+            for ref, item in list(c.items()) if slotted else \
+                    [(i, it) for i, it in enumerate(c.items)][::-1]:
+                if _storages(item[2], set()) & gone:
+                    n = len(gone)
+                    _storages(item[1], gone)
+                    again = again or len(gone) != n
+                    if slotted:
+                        del c[ref]
+                    else:
+                        del c.items[ref]
 
 
 def gathered_dot(u, select_u, v, select_v):
@@ -546,8 +581,10 @@ class _Lru(object):
 
 
 def _tensor_key(t):
+    # torch's version counter sees torch writes; a sampler that moved the
+    # tensor as ITS latent wrote through the C-ABI and noted it in _writes
     return (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t.dtype,
-            str(t.device), t._version)
+            str(t.device), t._version, _writes.generation(t))
 
 
 _x_cache = _Lru()
@@ -604,6 +641,11 @@ BF16X3_CHAIN_BLOCK = 128
 # slots) -- lntm_mcem.py's own E-step (n_chains = 1) stays on the fp32 kernel,
 # which packs consecutive (chain, document) rows.
 BF16X3_REQUIRE_FILL = True
+# likelihood_arithmetic='auto' (the default) takes them from this many flop
+# per evaluation (4 N D R over all ranks' rows) on: ~0.1 ms of the fp32 matrix
+# peak.  Below, a transition is bound by its kernels' critical paths and the
+# fp32 kernels' 16- / 32- / 64-row blocks spread it over more CUs.
+BF16X3_AUTO_MIN_FLOP = 1.0e10
 _image_cache = _Lru()
 
 
@@ -811,7 +853,7 @@ def _padded_phi_t(phi, width):
     recomputes phi = softmax(beta) on every joint evaluation simply misses
     (one K x V transpose, noise next to the likelihood kernel)."""
     key = (phi.data_ptr(), tuple(phi.shape), tuple(phi.stride()),
-           phi._version, width)
+           phi._version, width, _writes.generation(phi))
     hit = _phi_cache.get('phi')
     if hit is not None and hit[0] == key:
         return hit[1]
@@ -831,7 +873,8 @@ def _padded_counts(x):
     vp = (v + 3) // 4 * 4
     if vp == v and x.is_contiguous() and x.dtype == _F32:
         return x.reshape(-1, v), v
-    key = (x.data_ptr(), tuple(x.shape), tuple(x.stride()), x._version)
+    key = (x.data_ptr(), tuple(x.shape), tuple(x.stride()), x._version,
+           _writes.generation(x))
     hit = _counts_cache.get('x')
     if hit is not None and hit[0] == key:
         return hit[1], vp

@@ -9,7 +9,12 @@ own counters (zhusuan_amd.plans.base._versions).  A write the library cannot see
 all (`x.data`, DLPack, a raw pointer) has `HMC.latents_changed()` /
 `HMC.observed_changed()`."""
 
+import itertools
+
 _generation = {}
+# ONE counter for every storage: an entry evicted and made again can never
+# come back to a value some sampler recorded earlier
+_counter = itertools.count(1)
 
 
 def _key(t):
@@ -23,7 +28,7 @@ def note(tensors):
     """The caller has just (enqueued a kernel that has) written `tensors`."""
     for t in tensors:
         k = _key(t)
-        _generation[k] = _generation.get(k, 0) + 1
+        _generation[k] = next(_counter)
     if len(_generation) > 4096:           # storages long gone
         for k in list(_generation)[:2048]:
             del _generation[k]

@@ -396,7 +396,13 @@ extern "C" int zshmc_gather_dot_normal_lik_grad(
              "zshmc_gather_dot_normal_lik_grad: every latent row needs a "
              "segment (rows without pairs an empty one)");
   float* partial = workspace;                       // [n_chains, n_segments]
-  float* extra = workspace + n_chains * n_segments; // [n_chains, n_segments, D]
+  // (the partial sums are padded to a multiple of 4 floats: `extra` is written
+  // with 16-byte stores)
+  float* extra = workspace + ((n_chains * n_segments + 3) & ~int64_t(3));
+                                                    // [n_chains, n_segments, D]
+  ZS_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0,
+             "zshmc_gather_dot_normal_lik_grad: workspace must be 16-byte "
+             "aligned");
   if (n_segments > 0) {
     const int64_t groups = n_chains * n_segments;
     int64_t blocks = (groups + 31) / 32;

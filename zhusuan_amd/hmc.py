@@ -46,6 +46,14 @@ class NativePlanFallbackWarning(UserWarning):
     which construct was refused."""
 
 
+class LikelihoodArithmeticWarning(UserWarning):
+    """`HMC(likelihood_arithmetic='bf16x3')` was asked for a model whose
+    likelihood has no bf16x3 kernel (more than 256 padded columns, or a
+    topic model whose per-document chains do not fill the kernel's
+    workgroups): the exact-fp32 kernels run; `hmc.arithmetic_reason` says
+    why, `hmc.likelihood_arithmetic_used` what ran."""
+
+
 class InvalidArgumentError(ArithmeticError):
     """Raised where the reference's tf.check_numerics raises
     tf.errors.InvalidArgumentError (hmc.py:51-53)."""
@@ -230,13 +238,18 @@ class HMC(object):
     Extra keyword-only arguments: `seed` (Philox key; default derives from
     zhusuan_amd.set_random_seed), `sharding`
     (zhusuan_amd.distributed.ChainSharding) for chains sharded over GPUs, and
-    `likelihood_arithmetic`: 'fp32' (default: the dense-likelihood plans'
-    two GEMMs on the exact-fp32 MFMAs) or 'bf16x3' (three bfloat16 planes
-    per float32 operand, six bf16 MFMAs per product, float32 accumulation:
-    float32-level results at 1.6-1.8x the fp32 matrix peak; taken where the
-    kernels exist -- Bernoulli / mixture-multinomial / Categorical
-    likelihoods of <= 256 columns -- `hmc.likelihood_arithmetic_used` says
-    which ran).
+    `likelihood_arithmetic`: 'fp32' (the dense-likelihood plans' two GEMMs
+    on the exact-fp32 MFMAs), 'bf16x3' (three bfloat16 planes per float32
+    operand, six bf16 MFMAs per product, float32 accumulation: float32-level
+    results -- every parity test of the fp32 kernels holds on it at the same
+    tolerances -- at 1.6-1.8x the fp32 matrix peak; taken where the kernels
+    exist: Bernoulli / mixture-multinomial / Categorical likelihoods of <=
+    256 padded columns; elsewhere the fp32 kernels run and a
+    LikelihoodArithmeticWarning says so) or 'auto' (the default: bf16x3
+    where a kernel exists AND one evaluation is >= 1e10 flop, i.e. bound by
+    the matrix cores; fp32 for the latency-bound small problems, silently).
+    `hmc.likelihood_arithmetic_used` says which ran,
+    `hmc.arithmetic_reason` why fp32 did.
 
     `one_launch_trajectory` (default False): native model plans whose
     likelihood grid fits the device at once can run the L + 1 trips of a
@@ -274,11 +287,11 @@ class HMC(object):
                  target_acceptance_rate=0.8, gamma=0.05, t0=100, kappa=0.75,
                  adapt_mass=None, mass_collect_iters=10, mass_decay=0.99,
                  *, seed=None, sharding=None, native_plans=True,
-                 likelihood_arithmetic='fp32', reuse_start_evaluation=True,
+                 likelihood_arithmetic='auto', reuse_start_evaluation=True,
                  one_launch_trajectory=False):
-        if likelihood_arithmetic not in ('fp32', 'bf16x3'):
-            raise ValueError("likelihood_arithmetic must be 'fp32' or "
-                             "'bf16x3', got %r" % (likelihood_arithmetic,))
+        if likelihood_arithmetic not in ('auto', 'fp32', 'bf16x3'):
+            raise ValueError("likelihood_arithmetic must be 'auto', 'fp32' "
+                             "or 'bf16x3', got %r" % (likelihood_arithmetic,))
         self.likelihood_arithmetic = likelihood_arithmetic
         # see the class docstring ("The start evaluation")
         self.reuse_start_evaluation = bool(reuse_start_evaluation)
@@ -475,6 +488,13 @@ class HMC(object):
         if plan is None or not hasattr(plan, 'inner_image'):
             return None
         return 'bf16x3' if plan.inner_image is not None else 'fp32'
+
+    @property
+    def arithmetic_reason(self):
+        """Why the fp32 kernels run where 'auto' / 'bf16x3' was asked for
+        (None when bf16x3 runs, when 'fp32' was asked for, or when the plan
+        has no dense likelihood kernel)."""
+        return getattr(self._plan, 'arithmetic_reason', None)
 
     # -- one execution of sample_op ----------------------------------------
     def _run(self, feed_dict, sync):
@@ -718,22 +738,36 @@ class HMC(object):
             return
         plan = self._plan
         self.flush()
-        flags = plan.flags
-        if self.sharding is not None and self.sharding.active:
-            flags = self.sharding.all_reduce_sum(
-                (plan.flags != 0).to(torch.float64))
-        elif sync:
-            torch.cuda.current_stream().synchronize()
-        bad = int(flags.item()) != 0
-        self._pending_check = False
+        # the one-launch trajectory kernel's barrier-fault word is read only
+        # where that kernel can have run (one more device-to-host copy
+        # otherwise, on every synchronous run of the small plans)
         sync_words = getattr(plan, 'traj_sync', None)
-        if sync_words is not None and int(sync_words[2].item()) != 0:
-            sync_words[2] = 0
+        if getattr(plan, 'traj_capacity', 0) <= 0:
+            sync_words = None
+        if self.sharding is not None and self.sharding.active:
+            # one message: every rank raises on a peer's fault too (a rank
+            # raising alone would leave the others in the next collective)
+            words = (plan.flags != 0).to(torch.float64).reshape(-1)[:1]
+            if sync_words is not None:
+                words = torch.cat(
+                    [words, (sync_words[2:3] != 0).to(torch.float64)])
+            words = self.sharding.all_reduce_sum(words).tolist()
+        else:
+            words = [int(plan.flags.item())]       # (the copy synchronises)
+            if sync_words is not None:
+                words.append(int(sync_words[2].item()))
+        bad = words[0] != 0
+        self._pending_check = False
+        if sync_words is not None and words[1] != 0:
+            # the arrival counter of the barrier that timed out is left
+            # non-zero: clear all of it, and stay off that kernel
+            sync_words.zero_()
+            plan.traj_capacity = 0
             raise RuntimeError(
                 "zhusuan_amd: a grid barrier of the one-launch trajectory "
                 "kernel timed out (its workgroups were not resident at once);"
-                " the results of that run are invalid -- construct the "
-                "sampler with one_launch_trajectory=False")
+                " the results of that run are invalid -- this sampler has "
+                "switched to one_launch_trajectory=False")
         if bad:
             plan.flags.zero_()
             raise InvalidArgumentError(OLD_LOG_PROB_MSG)
@@ -760,6 +794,10 @@ class HMC(object):
         enters a collective the others skip."""
         plan = self._plan
         plan.pending = None
+        if hasattr(plan, '_start_valid'):
+            # (a snapshot goes with a state the caller is about to write, or
+            # has written: the carried start evaluation is not part of it)
+            plan._start_valid = False
         if plan.colsum_state in ('fresh', 'parts'):
             plan.colsum_state = 'dirty'   # taken around the EWMV mean of before
         plan._mass_ones = None

@@ -7,7 +7,7 @@ import ctypes
 
 import torch
 
-from .. import _capi
+from .. import _capi, _writes
 from .base import _PlanBase, _versions, _Unsupported
 
 
@@ -149,12 +149,15 @@ class _DenseLikelihoodPlan(_PlanBase):
         # same storage, layout and version counter as last run (the tensors
         # are held, so an address cannot have been handed to another one;
         # `X.t()` of the literal spelling is a new view object every time)
+        # -- and no sampler has moved it as ITS latent in between: those
+        # writes go through the C-ABI, past torch's counter (_writes)
         key = [(a.data_ptr(), tuple(a.shape), tuple(a.stride()), a.dtype,
-                a._version) for a in t]
+                a._version, _writes.generation(a)) for a in t]
         if not self.carry_start:
             # reuse_start_evaluation=False: nothing about the model's tensors
-            # is remembered from one run to the next (hmc.py:47-50)
-            self._ops.clear_caches()
+            # is remembered from one run to the next (hmc.py:47-50) -- about
+            # THIS model's: the other samplers' cached operands stay
+            self._ops.forget(t)
             self._src = None
         if self._src is not None and key == self._src[0]:
             return
@@ -193,22 +196,52 @@ class _DenseLikelihoodPlan(_PlanBase):
             n_inner = self.inner.shape[0]
             if C % self.obs.shape[0] != 0:
                 raise ValueError("counts rows do not divide the chain rows")
-        # the bf16x3 kernels, where asked for and where they exist: <= 256
-        # columns, and -- one document per 128-chain workgroup -- chain axes
-        # that fill those workgroups
+        # the bf16x3 kernels ('bf16x3': wherever they exist -- <= 256 columns
+        # and, one document per 128-chain workgroup, chain axes that fill
+        # those workgroups -- with a warning where they do not; 'auto', the
+        # default: there, when the evaluation is large enough to be bound by
+        # the matrix cores rather than by its critical path)
         self.inner_image = None
-        if self.hmc.likelihood_arithmetic == 'bf16x3' and \
-                self.kind in ('linear_bernoulli', 'mixture_multinomial',
-                              'linear_categorical') and \
-                self.width in ops.BF16X3_WIDTHS:
+        self.arithmetic_reason = None
+        arith = self.hmc.likelihood_arithmetic
+        if arith in ('bf16x3', 'auto') and self.kind in (
+                'linear_bernoulli', 'mixture_multinomial',
+                'linear_categorical'):
+            why = None
             per_doc = C // self.obs.shape[0] \
                 if self.kind == 'mixture_multinomial' else C
             n_docs = C // per_doc
-            if n_docs == 1 or not ops.BF16X3_REQUIRE_FILL or \
-                    per_doc % ops.BF16X3_CHAIN_BLOCK == 0 or \
-                    per_doc >= 8 * ops.BF16X3_CHAIN_BLOCK:
+            if self.width not in ops.BF16X3_WIDTHS:
+                why = ('the bf16x3 kernels take <= %d padded columns, this '
+                       'likelihood has %d' % (max(ops.BF16X3_WIDTHS),
+                                              self.width))
+            elif not (n_docs == 1 or not ops.BF16X3_REQUIRE_FILL or
+                      per_doc % ops.BF16X3_CHAIN_BLOCK == 0 or
+                      per_doc >= 8 * ops.BF16X3_CHAIN_BLOCK):
+                why = ('%d chains per document do not fill the %d-chain '
+                       'workgroups of the bf16x3 multinomial kernel' % (
+                           per_doc, ops.BF16X3_CHAIN_BLOCK))
+            elif arith == 'auto':
+                # (of ALL ranks' chains: every shard of one problem runs the
+                # same arithmetic, whatever the number of ranks)
+                rows = self.lik_rows * (self.n_chains_global /
+                                        max(self.n_chains, 1))
+                flop = 4.0 * n_inner * self.width * rows
+                if flop < ops.BF16X3_AUTO_MIN_FLOP:
+                    why = ('%.2g flop per evaluation: latency-bound, the '
+                           'finer-grained fp32 kernels' % flop)
+            if why is None:
                 self.inner_image = ops.bf16x3_image(self.inner)
                 self.block = ops.BF16X3_CHAIN_BLOCK
+            else:
+                self.arithmetic_reason = why
+                if arith == 'bf16x3':
+                    import warnings
+                    from ..hmc import LikelihoodArithmeticWarning
+                    warnings.warn(
+                        "HMC(likelihood_arithmetic='bf16x3'): this model's "
+                        "likelihood runs on the fp32 kernels -- " + why,
+                        LikelihoodArithmeticWarning, stacklevel=2)
         if self.inner_image is None and self.kind != 'linear_categorical':
             self.block = ops.likelihood_plan(self.width)[1]
         R = self.lik_rows
@@ -296,7 +329,10 @@ class _DenseLikelihoodPlan(_PlanBase):
             self._gd_obs_csr = _aligned16(self.obs.view(
                 self.obs_rows, E)[:, self.order.long()].contiguous())
             n_seg = int(self._gd_seg[1].numel())
-            need = max(need, self.n_chains * n_seg * (D + 1))
+            # (partial sums rounded up to 4 floats: the per-segment gradient
+            # rows behind them are written with 16-byte stores)
+            groups = self.n_chains * n_seg
+            need = max(need, groups * D + (groups + 3) // 4 * 4)
         if self._ws is None or self._ws.numel() < max(need, 1):
             self._ws = torch.empty(max(need, 1), dtype=torch.float32,
                                    device=self.device)
