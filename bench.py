@@ -1237,6 +1237,9 @@ def summarize_extra(e):
     for k in ('ms_per_step', 'value', 'n_gpus'):
         if k in e:
             s[k] = _short(e[k])
+    if isinstance(e.get('run_many'), dict):       # configs[0]: the front-end
+        s['transitions_per_sec'] = _short(
+            e['run_many'].get('transitions_per_sec'))
     roof = e.get('roofline') or {}
     if roof.get('frac') is not None:
         s['frac'] = _short(roof['frac'], 4)
@@ -1325,12 +1328,27 @@ def contract_line(out):
 
 _emit_lock = None
 _emitted = False
+_OUT = None
+
+
+def claim_stdout():
+    """Keep file descriptor 1 for the lines of this file: a private duplicate
+    becomes the channel of emit / emit_extra, and descriptor 1 itself is
+    pointed at stderr -- so that what ELSE writes to stdout in this process
+    (gloo's C++ "[Gloo] Rank 0 is connected to ..." banner, library chatter)
+    cannot land between, or after, the contract line."""
+    global _OUT
+    if _OUT is None:
+        sys.stdout.flush()
+        _OUT = os.fdopen(os.dup(1), 'w')
+        os.dup2(2, 1)
+    return _OUT
 
 
 def emit_extra(e, stream=None):
     """An extra configuration's full record, on its own prefixed stdout line
     the moment it is known."""
-    stream = stream or sys.stdout
+    stream = stream or _OUT or sys.stdout
     stream.write(EXTRA_PREFIX + _dumps(e) + '\n')
     stream.flush()
 
@@ -1348,7 +1366,7 @@ def emit(out, stream=None, extras_file=''):
         if _emitted:
             return None
         _emitted = True
-        stream = stream or sys.stdout
+        stream = stream or _OUT or sys.stdout
         full = strict(out)
         if extras_file == '':
             extras_file = EXTRAS_FILE
@@ -1445,6 +1463,8 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus == 1 or 'WORLD_SIZE' in os.environ:
+        claim_stdout()           # (a rank; the launcher passes its own through)
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # started as ONE process (`python bench.py --gpus N ...`): become the
         # launcher -- one rank per GPU under torch.distributed.run on this
@@ -1686,7 +1706,9 @@ def main():
     sample_op.run_many(5, feed_dict=other_feed, sync=False)
     barrier()
     t1 = time.perf_counter()
-    n_other = max(20, min(args.steps, 100))
+    # (side measurements: 200 transitions whatever --steps is -- over 20 of
+    # them the drained pipeline at either end of a region is 5-10 % of it)
+    n_other = 200
     sample_op.run_many(n_other, feed_dict=other_feed, sync=False)
     barrier()
     other_elapsed = time.perf_counter() - t1

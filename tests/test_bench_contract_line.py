@@ -254,3 +254,33 @@ def test_disarmed_guard_leaves_the_normal_path_alone(tmp_path):
     assert p.returncode == 0, err[-800:]
     line = _contract_of(out)
     assert line['extras'] == [{'id': 'configs[4] sharded', 'ms_per_step': 1.0}]
+
+
+def test_foreign_writes_to_stdout_end_up_on_stderr(tmp_path):
+    """gloo's C++ layer prints "[Gloo] Rank 0 is connected to ..." on file
+    descriptor 1 of every rank: bench.py keeps a private duplicate of the
+    descriptor for its own lines and points fd 1 at stderr."""
+    script = tmp_path / 'claim.py'
+    script.write_text(r'''
+import json, os, sys
+sys.path.insert(0, %(root)r)
+import bench
+with open(%(record)r) as f:
+    out = json.load(f)
+bench.claim_stdout()
+os.write(1, b'[Gloo] Rank 0 is connected to 7 peer ranks.\n')
+print('a library greets the user')
+bench.emit_extra({'id': 'configs[0]', 'ms_per_step': 1.0})
+os.write(1, b'more chatter\n')
+bench.emit(out, extras_file=None)
+os.write(1, b'and after the line\n')
+''' % dict(root=ROOT, record=RECORD))
+    p = subprocess.run([sys.executable, str(script)], capture_output=True,
+                       text=True, timeout=120)
+    assert p.returncode == 0, p.stderr[-800:]
+    lines = p.stdout.splitlines()
+    assert [l[:13] for l in lines[:2]] == ['#bench-extra ', '#bench-detail']
+    assert len(lines) == 3 and lines[2].startswith('{"metric"')
+    for noise in ('[Gloo] Rank 0', 'a library greets', 'more chatter',
+                  'and after the line'):
+        assert noise in p.stderr and noise not in p.stdout

@@ -83,10 +83,10 @@ def _even(world):
 
 @pytest.mark.parametrize('splits', [
     [(0, 48), (48, 96)], [(0, 31), (31, 96)],
-    _even(4), [(0, 5), (5, 40), (40, 41), (41, 96)],
+    [(0, 5), (5, 40), (40, 41), (41, 96)],
     _even(8), [(0, 1), (1, 20), (20, 33), (33, 34), (34, 60), (60, 61),
                (61, 90), (90, 96)]],
-    ids=['2-even', '2-uneven', '4-even', '4-uneven', '8-even', '8-uneven'])
+    ids=['2-even', '2-uneven', '4-uneven', '8-even', '8-uneven'])
 def test_sharded_run_matches_single_process(tmp_path, splits):
     world = len(splits)
     _, _, q0 = _problem()

@@ -149,7 +149,7 @@ def _worker(rank, world, port, out_dir, read_every_run, mass):
 
 @pytest.mark.parametrize('world,read_every_run,mass', [
     (2, True, False), (2, False, False), (2, False, True),
-    (4, False, True), (8, True, False), (8, False, True)])
+    (4, False, True), (8, False, True)])
 def test_sharded_orchestration_matches_oracle(tmp_path, world, read_every_run,
                                               mass):
     """Sharded chains (2, 4, 8 ranks; uneven shards when C does not divide):

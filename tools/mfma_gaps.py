@@ -8,7 +8,7 @@ A wave issues one instruction per ~4 clocks; a 32 x 32 x 2 fp32 MFMA holds the
 pipe for 64 clocks, a 16 x 16 x 4 one for 32: ~15 / ~7 other instructions fit
 in a gap for free and not one more (DESIGN 3.3 rule (a)); whatever is between
 two tiles' MFMAs is exposed in full (rule (b)).  The two changes of round 4's
-last session (profiles/r04y_*) came from reading exactly these two lists.
+last session (profiles/archive/r04y_*) came from reading exactly these two lists.
 
     python tools/mfma_gaps.py zhusuan_amd/csrc/linear_bernoulli.hip 'linear_bernoulli_kernelILi128ELb1ELi0ELb0E'
     python tools/mfma_gaps.py file.s REGEX      # an existing hipcc -S output

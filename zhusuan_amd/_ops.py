@@ -691,7 +691,7 @@ def _row_splits(n_blocks_rows, n_inner, device, block=64, per_cu=1):
     32 slices.  (Round 4, the E-step of lntm_mcem.py:157-182 -- 100 documents
     x 100 topics x 12 419 words, two chain blocks: 16 slices of >= 512 rows
     1 788 us per L = 20 transition, 32 of >= 256 rows 1 232 us, 64 of >= 128
-    rows 1 213 us; profiles/r04e_row_splits_ab.txt.)"""
+    rows 1 213 us; profiles/archive/r04e_row_splits_ab.txt.)"""
     n_wg = (n_blocks_rows + block - 1) // block
     cus = torch.cuda.get_device_properties(device).multi_processor_count
     if n_wg >= cus * per_cu:

@@ -363,7 +363,7 @@ __device__ __forceinline__ void lb_body(
     // takes ~15 other instructions for free: the step's LDS read, its DMA
     // row(s) and the scalar address arithmetic are spread over the three gaps
     // (all behind the fourth MFMA they were ~26 issue slots in a 16-slot gap:
-    // +41 clocks per step at D = 128, profiles/r04y_lb_phase_d128.txt).
+    // +41 clocks per step at D = 128, profiles/archive/r04y_lb_phase_d128.txt).
     static_for<KK>([&](auto kc) {
       constexpr int kk = decltype(kc)::value;
       if constexpr (kk == 0) wait_lgkm<0>();   // the head's reads
