@@ -233,7 +233,17 @@ constexpr int kLastUse[3] = {2, 4, 5};
 
 // ---------------------------------------------------------------------------
 // GL: log2 of the class stride (OP 2)
-template <int D, int OP, bool LL, int NACC, int GL = 0>
+// PK (OP 1): packed rows -- row r of theta belongs to document r % yc_rows (a
+// few chains x many documents, lntm_mcem.py's own layout: n_chains = 1), so
+// every chain of a workgroup has its OWN counts row: the "labels" of a tile
+// are [32 vocabulary rows][128 chains] floats (16 KB per buffer instead of
+// 128 B), brought by four 16-byte-per-lane DMAs per wave -- lane (lo, hi) of
+// DMA g fetches x[doc(chain lo)][32 t + 8 g + 4 hi .. + 3] into slot
+// g * 64 + lane, exactly where the element-wise stage's lane reads its pairs
+// from.  Needs counts rows padded to a multiple of 32 floats (no clamping at
+// the last tile) and a counts matrix below 4 GB (32-bit lane offsets); three
+// tile buffers + 48 KB fit the LDS up to D = 192, one workgroup per CU.
+template <int D, int OP, bool LL, int NACC, int GL = 0, bool PK = false>
 __global__ __launch_bounds__(256, ZS_B3_WAVES(D)) void linear_b3_kernel(
     const float* __restrict__ W, const unsigned char* __restrict__ Ximg,
     const float* __restrict__ y, int64_t yc_rows, int64_t ldy, int64_t C,
@@ -241,6 +251,8 @@ __global__ __launch_bounds__(256, ZS_B3_WAVES(D)) void linear_b3_kernel(
     int doc_major, int n_classes) {
   static_assert(D % 32 == 0 && D >= 32 && D <= 256, "32 .. 256 features");
   static_assert(NACC == 1 || NACC == 2, "accumulator chains of GEMM 1");
+  static_assert(!PK || (OP == 1 && D <= 192), "packed rows: multinomial, LDS");
+  constexpr int kYBuf = PK ? 16384 : 128;   // bytes of one label buffer
   constexpr int KS = D / 16;             // k-steps of GEMM 1 (16 features)
   constexpr int NB = D / 32;             // gradient accumulators (32 features)
   constexpr int kPlane = NB * 2048;      // bytes of one plane of a tile
@@ -253,7 +265,7 @@ __global__ __launch_bounds__(256, ZS_B3_WAVES(D)) void linear_b3_kernel(
   // hipcc then shuffles every operand through one spare quad.
   auto wl_agpr = [](int ks) constexpr { return D <= 192 || ks < KS / 2; };
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // [3][kTile] tiles, [3][32] labels
+  // [3][kTile] tiles, [3][32] labels (PK: [3][4 waves][4 groups][64 lanes][4])
   const uint32_t sx_addr = (uint32_t)reinterpret_cast<uintptr_t>(smem);
   const uint32_t sy_addr = sx_addr + 3 * kTile;
 
@@ -267,7 +279,7 @@ __global__ __launch_bounds__(256, ZS_B3_WAVES(D)) void linear_b3_kernel(
   int64_t row_base = (int64_t)blockIdx.x * kB3Chains, row_stride = 1;
   int64_t n_valid = C - row_base;
   int64_t doc = 0;
-  if (OP == 1 && doc_major) {
+  if (OP == 1 && !PK && doc_major) {
     const int64_t grp = blockIdx.x / yc_rows;
     doc = blockIdx.x % yc_rows;
     row_base = grp * kB3Chains * yc_rows + doc;
@@ -279,7 +291,11 @@ __global__ __launch_bounds__(256, ZS_B3_WAVES(D)) void linear_b3_kernel(
     return row_base + (int64_t)(i < n_valid ? i : (int)n_valid - 1) * row_stride;
   };
   // labels (OP 0) / the document's counts (OP 1) of the data rows
-  const float* ysrc = uniform_ptr(OP == 1 ? y + doc * ldy : y);
+  const float* ysrc = uniform_ptr(OP == 1 && !PK ? y + doc * ldy : y);
+  // PK: byte offset of this lane's counts (its chain's document, rows 4 hi ..)
+  const uint32_t pk_voff =
+      PK ? (uint32_t)(((row_at(wave * 32 + lo) % yc_rows) * ldy + 4 * hi) * 4)
+         : 0u;
 
   // ---- this wave's chain block of W -> three bf16 planes (B operand of
   // GEMM 1: lane = chain, k-slot i of half hi = feature 16 ks + 8 hi + i) ----
@@ -335,6 +351,21 @@ __global__ __launch_bounds__(256, ZS_B3_WAVES(D)) void linear_b3_kernel(
   // clamped to the last row of X (masked / met by zero rows of the image)
   const int lane_y = wave * 8 + (lane & 7);
   auto dma_labels = [&](int64_t tile, uint32_t dst) {
+    if constexpr (PK) {
+      const float* src = uniform_ptr(ysrc + tile * kB3Rows);
+      const uint32_t d0 = dst + (uint32_t)(wave * 4096);
+      static_for<4>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        asm volatile(
+            "s_mov_b32 m0, %2\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %0, %1"
+            :
+            : "v"(pk_voff), "s"(src + g * 8), "s"(d0 + (uint32_t)(g * 1024))
+            : "memory");
+      });
+      return;
+    }
     const int64_t left = N - 1 - tile * kB3Rows;      // >= 0: the tile exists
     const int last = left < kB3Rows - 1 ? (int)left : kB3Rows - 1;
     const uint32_t off = (uint32_t)(lane_y < last ? lane_y : last) * 4u;
@@ -370,7 +401,8 @@ __global__ __launch_bounds__(256, ZS_B3_WAVES(D)) void linear_b3_kernel(
       }
   }
   // labels of this lane's rows: group g = rows 8 g + 4 hi .. + 3
-  const uint32_t y_lane = (uint32_t)(hi * 16);
+  const uint32_t y_lane =
+      PK ? (uint32_t)(wave * 4096 + lane * 16) : (uint32_t)(hi * 16);
 
   // (zeroed BY an MFMA, 0 * 0 + 0, straight in their AGPRs: zeros written
   // by the compiler arrive through a second set of D/2 registers that then
@@ -388,7 +420,7 @@ __global__ __launch_bounds__(256, ZS_B3_WAVES(D)) void linear_b3_kernel(
 
   // buffer rotation: cur = GEMM 1's tile, prev = GEMM 2's, next = DMA target
   uint32_t b_cur = 0, b_prev = 2 * kTile, b_next = kTile;
-  uint32_t y_cur = 0, y_prev = 256, y_next = 128;
+  uint32_t y_cur = 0, y_prev = 2 * kYBuf, y_next = kYBuf;
 
   // prologue: tile 0 -> buffer 0
   static_for<kDma>([&](auto ic) { dma_piece(ic, xsrc, dst_wave + b_cur); });
@@ -477,8 +509,9 @@ __global__ __launch_bounds__(256, ZS_B3_WAVES(D)) void linear_b3_kernel(
       if constexpr (sub == 0) {
         // rows 8 (j0/4) + 4 hi + j0 % 4 and the next one
         if (!(ZS_B3_SKIP & 4))
-          ypair = *reinterpret_cast<const ZS_LDS f2v*>(
-              (uintptr_t)(y_addr + (uint32_t)((8 * (j0 >> 2) + (j0 & 3)) * 4)));
+          ypair = *reinterpret_cast<const ZS_LDS f2v*>((uintptr_t)(
+              y_addr + (uint32_t)(PK ? (j0 >> 2) * 1024 + (j0 & 3) * 4
+                                     : (8 * (j0 >> 2) + (j0 & 3)) * 4)));
       }
       float y0 = ypair[0], y1 = ypair[1];
       const int n0 = 8 * (j0 >> 2) + 4 * hi + (j0 & 3);
@@ -799,21 +832,21 @@ __global__ __launch_bounds__(256, ZS_B3_WAVES(D)) void linear_b3_kernel(
 int lb_reduce_splits(const float* ws, int64_t C, int64_t ldw, int S, float* ll,
                      float* gW, hipStream_t s);
 
-template <int D, int OP, int GL = 0>
+template <int D, int OP, int GL = 0, bool PK = false>
 static int launch_b3(const float* W, const unsigned char* Ximg, const float* y,
                      int64_t yc_rows, int64_t ldy, int64_t C, int64_t N,
                      float* ll, float* gW, hipStream_t s, int n_splits,
                      float* workspace, int doc_major, int n_classes = 0) {
   constexpr int kTile = 3 * (D / 32) * 2048;
-  const size_t lds = (size_t)3 * kTile + 3 * 128;
+  const size_t lds = (size_t)3 * kTile + 3 * (PK ? 16384 : 128);
   // accumulator chains of GEMM 1: two cost 16 registers and buy nothing
   // measurable (dependent 32x32x16 MFMAs issue back to back); one where two
   // waves per SIMD need the registers
 #ifndef ZS_B3_NACC
 #define ZS_B3_NACC(D) ((D) <= 128 ? 1 : 2)
 #endif
-  auto kll = linear_b3_kernel<D, OP, true, ZS_B3_NACC(D), GL>;
-  auto kg = linear_b3_kernel<D, OP, false, ZS_B3_NACC(D), GL>;
+  auto kll = linear_b3_kernel<D, OP, true, ZS_B3_NACC(D), GL, PK>;
+  auto kg = linear_b3_kernel<D, OP, false, ZS_B3_NACC(D), GL, PK>;
   static bool attr = false;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute(

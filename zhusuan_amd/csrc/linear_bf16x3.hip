@@ -114,6 +114,12 @@ extern "C" int zshmc_linear_bernoulli_log_lik_bf16x3(
   }
 }
 
+extern "C" int zshmc_bf16x3_multinomial_rows_packed(int64_t count_rows,
+                                                    int64_t chains_per_doc) {
+  return count_rows > 1 && chains_per_doc % kB3Chains != 0 &&
+         chains_per_doc < 8 * kB3Chains;
+}
+
 extern "C" int zshmc_linear_multinomial_log_lik_bf16x3(
     const float* theta, const void* phi_image, const float* counts,
     int64_t count_rows, int64_t count_stride, int64_t n_rows, int64_t n_vocab,
@@ -136,8 +142,42 @@ extern "C" int zshmc_linear_multinomial_log_lik_bf16x3(
              "a workspace of n_splits*n_rows*(n_topics+1) floats when > 1");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const unsigned char* img = reinterpret_cast<const unsigned char*>(phi_image);
-  // one document per workgroup (rows chain * count_rows + doc)
+  // rows are chain * count_rows + doc.  One document per workgroup (128
+  // chains of it) where the chain axis fills such workgroups; otherwise --
+  // a few chains x many documents, lntm_mcem.py's own layout -- 128
+  // CONSECUTIVE rows per workgroup, every row with its own counts row
+  // (b3_kernel.h, PK)
+  const int64_t per_doc = n_rows / count_rows;
+  // (taken where its preconditions hold: <= 192 topics -- three tile buffers
+  // + 48 KB of counts in the LDS --, 16-byte aligned counts rows padded with
+  // zeros to a multiple of 32 floats -- no clamping at the last tile --, a
+  // counts matrix below 4 GB -- 32-bit lane offsets; otherwise one document
+  // per workgroup whatever the fill)
+  const bool packed =
+      zshmc_bf16x3_multinomial_rows_packed(count_rows, per_doc) &&
+      n_topics <= 192 && count_stride % 4 == 0 &&
+      count_stride >= (n_vocab + 31) / 32 * 32 &&
+      count_rows * count_stride < (1ll << 30) &&
+      (reinterpret_cast<uintptr_t>(counts) & 15) == 0;
   const int dm = count_rows > 1;
+  if (packed) {
+    switch (n_topics) {
+      case 64:
+        return launch_b3<64, 1, 0, true>(theta, img, counts, count_rows,
+                                         count_stride, n_rows, n_vocab, log_lik,
+                                         grad_theta, s, n_splits, workspace, 0);
+      case 128:
+        return launch_b3<128, 1, 0, true>(theta, img, counts, count_rows,
+                                          count_stride, n_rows, n_vocab,
+                                          log_lik, grad_theta, s, n_splits,
+                                          workspace, 0);
+      default:
+        return launch_b3<192, 1, 0, true>(theta, img, counts, count_rows,
+                                          count_stride, n_rows, n_vocab,
+                                          log_lik, grad_theta, s, n_splits,
+                                          workspace, 0);
+    }
+  }
   switch (n_topics) {
     case 64:
       return launch_b3<64, 1>(theta, img, counts, count_rows, count_stride,
