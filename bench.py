@@ -823,31 +823,49 @@ def extra_estep(torch, zs, dev, n_docs=100, n_topics=100, n_vocab=12419,
         return bn
     m = lntm()
     m.log_joint = lambda bn: bn.cond_log_prob('eta') + bn.cond_log_prob('x')
-    hmc = zs.HMC(step_size=0.05, n_leapfrogs=n_leapfrogs, seed=5)
-    eta = torch.zeros(1, n_docs, n_topics, device=dev)
-    op, info = hmc.sample(m, {'x': x}, {'eta': eta})
-    op.run_many(5)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    op.run_many(n_timed)
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / n_timed * 1e3
-    plan = hmc._plan
-    flop = 4.0 * n_docs * plan.width * n_vocab * n_leapfrogs
-    return {
-        'workload': 'the reference\'s own loop size: lntm_mcem.py E-step, 1 '
-                    'chain x %d documents, K=%d (kernel width %d), V=%d, L=%d, '
-                    'fixed step size' % (n_docs, n_topics, plan.width, n_vocab,
-                                         n_leapfrogs),
-        'plan': hmc.plan_kind, 'ms_per_step': ms, 'steps': n_timed,
-        'value': n_docs * n_leapfrogs / (ms * 1e-3),
-        'unit': '(chain, document)-leapfrog-steps/s',
-        'mean_acceptance': float(info.acceptance_rate.mean().item()),
-        'row_range_slices': int(plan.splits),
-        'note': 'latency-bound by its kernels\' critical paths, not by '
-                'launches or flops (%.2f TFLOP/s sustained); round 4: 1.2 ms, '
-                '32 slices' % (flop / (ms * 1e-3) / 1e12),
-    }
+
+    def timed(arithmetic):
+        kw = {} if arithmetic is None else {'likelihood_arithmetic': arithmetic}
+        hmc = zs.HMC(step_size=0.05, n_leapfrogs=n_leapfrogs, seed=5, **kw)
+        eta = torch.zeros(1, n_docs, n_topics, device=dev)
+        op, info = hmc.sample(m, {'x': x}, {'eta': eta})
+        op.run_many(5)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        op.run_many(n_timed)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / n_timed * 1e3
+        plan = hmc._plan
+        flop = 4.0 * n_docs * plan.width * n_vocab * n_leapfrogs
+        return {
+            'likelihood_arithmetic_used': hmc.likelihood_arithmetic_used,
+            'arithmetic_reason': hmc.arithmetic_reason,
+            'plan': hmc.plan_kind, 'ms_per_step': ms, 'steps': n_timed,
+            'value': n_docs * n_leapfrogs / (ms * 1e-3),
+            'unit': '(chain, document)-leapfrog-steps/s',
+            'mean_acceptance': float(info.acceptance_rate.mean().item()),
+            'row_range_slices': int(plan.splits),
+            'kernel_width': int(plan.width),
+            'sustained_tflops': flop / (ms * 1e-3) / 1e12,
+        }
+    out = timed(None)                       # the default: 'auto' -> fp32 here
+    out['workload'] = (
+        'the reference\'s own loop size: lntm_mcem.py E-step, 1 chain x %d '
+        'documents, K=%d (kernel width %d), V=%d, L=%d, fixed step size' % (
+            n_docs, n_topics, out['kernel_width'], n_vocab, n_leapfrogs))
+    out['note'] = ('latency-bound by its kernels\' critical paths, not by '
+                   'launches or flops (%.2f TFLOP/s sustained); round 4: 1.2 '
+                   'ms, 32 slices' % out['sustained_tflops'])
+    # the packed-rows form of the bf16x3 kernel (one 128-row block, 32-row
+    # vocabulary tiles) on the same problem, asked for by name
+    try:
+        other = timed('bf16x3')
+        other['transition_time_over_default'] = \
+            other['ms_per_step'] / out['ms_per_step']
+        out['bf16x3'] = other
+    except Exception as e:                           # noqa: BLE001
+        out['bf16x3'] = {'error': repr(e)[:200]}
+    return out
 
 
 def lntm_problem(torch, dev, n_docs, n_topics, n_vocab):
@@ -868,7 +886,7 @@ def lntm_problem(torch, dev, n_docs, n_topics, n_vocab):
 
 def lntm_workload(torch, zs, dev, n_chains, sharding=None, dist=None,
                   n_docs=5000, n_topics=128, n_vocab=12419, n_leapfrogs=20,
-                  n_sub=4, n_timed=1, n_warm=1, bf16x3=True):
+                  n_sub=4, n_timed=1, n_warm=1, bf16x3=True, label=None):
     """BASELINE configs[4]: the E-step of the logistic-normal topic model at
     the lntm_mcem.py shape (chain axes [n_chains, n_docs = 5 000], K = 128,
     V = 12 419 -- the UCI "nips" vocabulary the example loads), step-size and
@@ -980,7 +998,8 @@ def lntm_workload(torch, zs, dev, n_chains, sharding=None, dist=None,
     ms = main['ms_per_step']
     out = dict(main)
     out.update({
-        'workload': 'configs[4]: logistic-normal topic model E-step, chain '
+        'workload': (label or 'configs[4]') +
+                    ': logistic-normal topic model E-step, chain '
                     'axes [n_chains=%d, n_docs=%d] (= %d rows; "8 192 chains" '
                     'read as n_chains at 8 GPUs: %d per GPU), K=%d, V=%d, '
                     'L=%d, step-size and mass adaptation on in the timed '
@@ -1994,7 +2013,13 @@ def main():
                     ('softmax-10x256', extra_softmax_regression,
                      {'n_feat': 256, 'bf16x3': True}),
                     ('pmf', extra_pmf, {}),
-                    ('lntm-estep', extra_estep, {}))
+                    ('lntm-estep', extra_estep, {}),
+                    # lntm_mcem.py's own layout at scale: ONE chain, many
+                    # documents (every row its own counts row)
+                    ('lntm-1chain-32768docs', lntm_workload, dict(
+                        n_chains=1, n_docs=32768, n_sub=1, n_timed=3,
+                        label='beyond BASELINE.json, lntm_mcem.py:62-70\'s '
+                              'layout (n_chains = 1 x many documents)')))
         else:
             todo = (('configs[4] sharded', lntm_workload, dict(
                 n_chains=args.lntm_chains_per_gpu,

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ZSHMC_VERSION 500 /* 0.5.0: + the bf16x3 likelihood kernels, zshmc_model_plan.inner_image */
+#define ZSHMC_VERSION 510 /* 0.5.1: + packed rows in the bf16x3 multinomial kernel, zshmc_bf16x3_multinomial_rows_packed (0.5.0: the bf16x3 likelihood kernels, zshmc_model_plan.inner_image) */
 
 /* status codes */
 #define ZSHMC_OK 0
@@ -684,8 +684,17 @@ int zshmc_linear_bernoulli_log_lik(const float* W, const float* X,
  *          its size (6 bytes per element, rows padded to 32);
  *   grad_w / grad_theta  required (the log-likelihood alone stays with the
  *          fp32 entry point); log_lik may be NULL;
- *   a workgroup takes 128 chains (of ONE document when count_rows > 1: the
- *          rows are chain * count_rows + doc).
+ *   a workgroup takes 128 chains.  Mixture multinomial, count_rows > 1 (the
+ *          rows are chain * count_rows + doc): 128 chains of ONE document
+ *          where the chain axis fills such workgroups (chains per document a
+ *          multiple of 128, or >= 1 024); otherwise -- a few chains x many
+ *          documents, lntm_mcem.py:62-70's own layout --
+ *          zshmc_bf16x3_multinomial_rows_packed() is 1 and a workgroup takes
+ *          128 CONSECUTIVE rows, each with its own counts row (ABI 0.5.1),
+ *          provided n_topics <= 192, the counts rows are 16-byte aligned and
+ *          zero-padded to a multiple of 32 floats (count_stride >=
+ *          round_up(n_vocab, 32)) and the counts matrix is below 4 GB; where
+ *          those do not hold, one document per workgroup whatever the fill.
  * Not bit-identical to the fp32 kernels (other summation order), and held to
  * the same parity tests at the same tolerances. */
 int zshmc_bf16x3_image_bytes(int64_t n_rows, int64_t width, int64_t* bytes);
@@ -695,6 +704,8 @@ int zshmc_linear_bernoulli_log_lik_bf16x3(
     const float* W, const void* X_image, const float* y, int64_t n_chains,
     int64_t n_rows, int64_t n_features, float* log_lik, float* grad_w,
     int n_splits, float* workspace, void* stream);
+int zshmc_bf16x3_multinomial_rows_packed(int64_t count_rows,
+                                        int64_t chains_per_doc);
 int zshmc_linear_multinomial_log_lik_bf16x3(
     const float* theta, const void* phi_image, const float* counts,
     int64_t count_rows, int64_t count_stride, int64_t n_rows, int64_t n_vocab,

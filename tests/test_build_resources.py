@@ -362,10 +362,10 @@ def b3_build(tmp_path_factory):
 
 
 def _b3_bodies(asm):
-    """name -> text of each linear_b3_kernel<D, OP, LL, NACC, GL>."""
+    """name -> text of each linear_b3_kernel<D, OP, LL, NACC, GL, PK>."""
     out = {}
     for m in re.finditer(r'^(_ZN5zshmc16linear_b3_kernelILi\d+ELi\dELb[01]E'
-                         r'Li\dELi\dEEE\w+):[^\n]*\n(.*?)s_endpgm', asm,
+                         r'Li\dELi\dELb[01]EEE\w+):[^\n]*\n(.*?)s_endpgm', asm,
                          re.S | re.M):
         out[m.group(1)] = m.group(2)
     return out
@@ -380,18 +380,26 @@ def test_bf16x3_kernels_keep_their_registers_and_occupancy(b3_build):
     table = {k: v for k, v in _kernels(remarks).items()
              if 'linear_b3_kernelILi' in k}
     # 4 widths x {ll+grad, grad only} x (Bernoulli, multinomial, the
-    # Categorical at class strides 1 .. 32)
-    assert len(table) == 8 * (2 + 6), sorted(table)
+    # Categorical at class strides 1 .. 32) + the packed-rows multinomial
+    # (PK: 64 / 128 / 192 columns; 48 KB of counts in the LDS: one workgroup
+    # per CU, so one wave per SIMD is its register budget -- and no spills)
+    assert len(table) == 8 * (2 + 6) + 6, sorted(table)
     for name, row in table.items():
         width = int(re.search(r'kernelILi(\d+)E', name).group(1))
-        assert row['Occupancy [waves/SIMD]'] >= (2 if width <= 128 else 1), \
-            (name, row)
-        grad_only = re.search(r'ELi\dELb0E', name) is not None
-        if width >= 192 or (width <= 128 and grad_only and 'ELi0ELb0' in name):
+        packed = re.search(r'ELb1EEE', name) is not None
+        if packed:
+            assert re.search(r'kernelILi\d+ELi1ELb', name) and width <= 192, \
+                name                                        # OP 1 only
+            assert row['VGPRs Spill'] == 0, (name, row)
+        assert row['Occupancy [waves/SIMD]'] >= (
+            2 if width <= 128 and not packed else 1), (name, row)
+        op, ll = re.search(r'kernelILi\d+ELi(\d)ELb([01])E', name).groups()
+        grad_only = ll == '0'
+        if width >= 192 or (width <= 128 and grad_only and op == '0'):
             assert row['VGPRs Spill'] == 0, (name, row)
         assert row['VGPRs Spill'] <= 12, (name, row)
     bodies = _b3_bodies(asm)
-    assert len(bodies) == 64
+    assert len(bodies) == 70
     for name, body in bodies.items():
         # the tile loop: the backward branch with the most MFMAs in its body
         loops = []

@@ -242,6 +242,71 @@ def test_multinomial_matches_float64_reference(env, n_chains, n_docs, V, K,
                                atol=2e-5 * (np.abs(g_ref).max() + 1))
 
 
+@pytest.mark.parametrize('n_chains,n_docs,V,K,n_splits', [
+    (1, 100, 1241, 128, 1), (1, 100, 1241, 128, 7), (3, 50, 333, 64, 1),
+    (2, 77, 500, 192, 3), (5, 7, 77, 128, 1), (1, 300, 1000, 128, 2),
+    (127, 3, 96, 64, 1), (1, 2, 31, 64, 1)])
+@pytest.mark.parametrize('want_ll', [True, False])
+def test_multinomial_packed_rows_match_float64_reference(env, n_chains, n_docs,
+                                                         V, K, n_splits,
+                                                         want_ll):
+    """ABI 0.5.1: a few chains x many documents (lntm_mcem.py:62-70 runs
+    n_chains = 1) -- a workgroup takes 128 CONSECUTIVE (chain, document) rows,
+    every row with its own counts row, brought tile by tile as [32 vocabulary
+    rows][128 chains] by four 16-byte-per-lane DMAs per wave.  Taken when the
+    counts rows are padded to 32 floats; ragged last blocks, vocabularies that
+    are not whole tiles, vocabulary slices."""
+    torch, _capi, dev = env
+    lib = _capi.load()
+    assert lib.zshmc_bf16x3_multinomial_rows_packed(n_docs, n_chains) == 1
+    assert lib.zshmc_bf16x3_multinomial_rows_packed(n_docs, 128) == 0
+    assert lib.zshmc_bf16x3_multinomial_rows_packed(n_docs, 1024) == 0
+    assert lib.zshmc_bf16x3_multinomial_rows_packed(1, n_chains) == 0
+    theta, phi, x = _mult_data(n_chains, n_docs, V, K, seed=V + K + n_docs)
+    R = n_chains * n_docs
+    stride = (V + 31) // 32 * 32
+    xp = np.zeros((n_docs, stride), np.float32)
+    xp[:, :V] = x
+    th = torch.tensor(theta, device=dev)
+    pt = torch.tensor(np.ascontiguousarray(phi.T), device=dev)   # [V, K]
+    xt = torch.tensor(xp, device=dev)
+    img = _image(torch, _capi, pt, K)
+    ws = torch.empty(n_splits * R * (K + 1), device=dev) if n_splits > 1 \
+        else None
+    out = []
+    for rep in range(2):
+        ll = torch.full((R,), float('nan'), device=dev) if want_ll else None
+        g = torch.full((R, K), float('nan'), device=dev)
+        _capi.call('zshmc_linear_multinomial_log_lik_bf16x3', th.data_ptr(),
+                   img.data_ptr(), xt.data_ptr(), n_docs, stride, R, V, K,
+                   _capi.ptr(ll), g.data_ptr(), n_splits, _capi.ptr(ws),
+                   _capi.current_stream())
+        torch.cuda.synchronize()
+        out.append((None if ll is None else ll.cpu().numpy(),
+                    g.cpu().numpy()))
+    np.testing.assert_array_equal(out[0][1], out[1][1])        # bit-stable
+    ll_ref, g_ref = _mult_ref(theta, phi, x, n_docs)
+    if want_ll:
+        np.testing.assert_array_equal(out[0][0], out[1][0])
+        np.testing.assert_allclose(out[0][0], ll_ref, rtol=2e-5,
+                                   atol=2e-5 * V)
+    np.testing.assert_allclose(out[0][1], g_ref, rtol=1e-4,
+                               atol=2e-5 * (np.abs(g_ref).max() + 1))
+    # ... and the same rows through the one-document-per-workgroup form (counts
+    # rows padded to 4 floats only: the packed form's precondition fails)
+    s4 = (V + 3) // 4 * 4
+    if s4 != stride:
+        x4 = torch.tensor(np.ascontiguousarray(xp[:, :s4]), device=dev)
+        g4 = torch.full((R, K), float('nan'), device=dev)
+        _capi.call('zshmc_linear_multinomial_log_lik_bf16x3', th.data_ptr(),
+                   img.data_ptr(), x4.data_ptr(), n_docs, s4, R, V, K, None,
+                   g4.data_ptr(), n_splits, _capi.ptr(ws),
+                   _capi.current_stream())
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(g4.cpu().numpy(), out[0][1], rtol=2e-5,
+                                   atol=2e-6 * (np.abs(g_ref).max() + 1))
+
+
 # ---- Categorical (OP 2): rows of W are (chain, class) pairs ----------------
 def _cat_ref(w, X, y):
     """ll [C], d ll / d w [C, K, F] in float64 (univariate.py:496-548 on

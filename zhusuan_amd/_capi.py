@@ -223,6 +223,7 @@ PROTOTYPES = {
     'zshmc_bf16x3_split': (c_int, [_p, c_int64, c_int64, c_int64, _p, _p]),
     'zshmc_linear_bernoulli_log_lik_bf16x3': (c_int, [
         _p, _p, _p, c_int64, c_int64, c_int64, _p, _p, c_int, _p, _p]),
+    'zshmc_bf16x3_multinomial_rows_packed': (c_int, [c_int64, c_int64]),
     'zshmc_linear_multinomial_log_lik_bf16x3': (c_int, [
         _p, _p, _p, c_int64, c_int64, c_int64, c_int64, c_int64, _p, _p,
         c_int, _p, _p]),

@@ -641,6 +641,10 @@ BF16X3_CHAIN_BLOCK = 128
 # slots) -- lntm_mcem.py's own E-step (n_chains = 1) stays on the fp32 kernel,
 # which packs consecutive (chain, document) rows.
 BF16X3_REQUIRE_FILL = True
+# ... unless the packed-rows form of the kernel takes them (ABI 0.5.1: 128
+# consecutive (chain, document) rows per workgroup, each with its own counts
+# row): <= 192 topics, counts rows padded to 32 floats, counts below 4 GB
+BF16X3_PACKED_MAX_WIDTH = 192
 # likelihood_arithmetic='auto' (the default) takes them from this many flop
 # per evaluation (4 N D R over all ranks' rows) on: ~0.1 ms of the fp32 matrix
 # peak.  Below, a transition is bound by its kernels' critical paths and the
@@ -865,16 +869,18 @@ def _padded_phi_t(phi, width):
 _counts_cache = {}
 
 
-def _padded_counts(x):
-    """counts [R0, V] -> contiguous float32 [R0, V rounded up to 4] with a zero
-    pad, cached while the SAME tensor (storage, version) is passed again: the
-    likelihood kernel gathers one row per chain and wants 16-B groups."""
+def _padded_counts(x, multiple=4):
+    """counts [R0, V] -> contiguous float32 [R0, V rounded up to `multiple`]
+    with a zero pad, cached while the SAME tensor (storage, version) is passed
+    again: the likelihood kernel gathers one row per chain and wants 16-B
+    groups (multiple = 4); the packed-rows form of the bf16x3 multinomial
+    kernel reads whole 32-row tiles of a chain's counts (multiple = 32)."""
     v = x.shape[-1]
-    vp = (v + 3) // 4 * 4
+    vp = (v + multiple - 1) // multiple * multiple
     if vp == v and x.is_contiguous() and x.dtype == _F32:
         return x.reshape(-1, v), v
     key = (x.data_ptr(), tuple(x.shape), tuple(x.stride()), x._version,
-           _writes.generation(x))
+           _writes.generation(x), multiple)
     hit = _counts_cache.get('x')
     if hit is not None and hit[0] == key:
         return hit[1], vp

@@ -244,7 +244,7 @@ constexpr int kLastUse[3] = {2, 4, 5};
 // the last tile) and a counts matrix below 4 GB (32-bit lane offsets); three
 // tile buffers + 48 KB fit the LDS up to D = 192, one workgroup per CU.
 template <int D, int OP, bool LL, int NACC, int GL = 0, bool PK = false>
-__global__ __launch_bounds__(256, ZS_B3_WAVES(D)) void linear_b3_kernel(
+__global__ __launch_bounds__(256, PK ? 1 : ZS_B3_WAVES(D)) void linear_b3_kernel(
     const float* __restrict__ W, const unsigned char* __restrict__ Ximg,
     const float* __restrict__ y, int64_t yc_rows, int64_t ldy, int64_t C,
     int64_t N, int64_t ldw, float* __restrict__ ll, float* __restrict__ gW,
@@ -354,16 +354,10 @@ __global__ __launch_bounds__(256, ZS_B3_WAVES(D)) void linear_b3_kernel(
     if constexpr (PK) {
       const float* src = uniform_ptr(ysrc + tile * kB3Rows);
       const uint32_t d0 = dst + (uint32_t)(wave * 4096);
-      static_for<4>([&](auto gc) {
-        constexpr int g = decltype(gc)::value;
-        asm volatile(
-            "s_mov_b32 m0, %2\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %0, %1"
-            :
-            : "v"(pk_voff), "s"(src + g * 8), "s"(d0 + (uint32_t)(g * 1024))
-            : "memory");
-      });
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        b3_dma<0>(reinterpret_cast<const unsigned char*>(src + g * 8),
+                  d0 + (uint32_t)(g * 1024), pk_voff);
       return;
     }
     const int64_t left = N - 1 - tile * kB3Rows;      // >= 0: the tile exists

@@ -191,7 +191,9 @@ class _DenseLikelihoodPlan(_PlanBase):
         else:
             phi, x = inner[0], obs
             self.inner = _aligned16(ops._padded_phi_t(phi, self.width))
-            self.obs, self.obs_stride = ops._padded_counts(x)
+            # (rows padded to 32 floats: what the packed-rows form of the
+            # bf16x3 kernel wants; the other kernels take any stride)
+            self.obs, self.obs_stride = ops._padded_counts(x, 32)
             self.obs = _aligned16(self.obs)
             n_inner = self.inner.shape[0]
             if C % self.obs.shape[0] != 0:
@@ -203,6 +205,7 @@ class _DenseLikelihoodPlan(_PlanBase):
         # the matrix cores rather than by its critical path)
         self.inner_image = None
         self.arithmetic_reason = None
+        self.packed_rows = False
         arith = self.hmc.likelihood_arithmetic
         if arith in ('bf16x3', 'auto') and self.kind in (
                 'linear_bernoulli', 'mixture_multinomial',
@@ -217,10 +220,17 @@ class _DenseLikelihoodPlan(_PlanBase):
                                               self.width))
             elif not (n_docs == 1 or not ops.BF16X3_REQUIRE_FILL or
                       per_doc % ops.BF16X3_CHAIN_BLOCK == 0 or
-                      per_doc >= 8 * ops.BF16X3_CHAIN_BLOCK):
+                      per_doc >= 8 * ops.BF16X3_CHAIN_BLOCK) and not (
+                          self.width <= ops.BF16X3_PACKED_MAX_WIDTH and
+                          self.obs.numel() < (1 << 30)):
+                # (a few chains x many documents run on the packed-rows form
+                # of the kernel -- 128 consecutive rows per workgroup, each
+                # with its own counts row -- up to 192 topics)
                 why = ('%d chains per document do not fill the %d-chain '
-                       'workgroups of the bf16x3 multinomial kernel' % (
-                           per_doc, ops.BF16X3_CHAIN_BLOCK))
+                       'workgroups of the bf16x3 multinomial kernel, and its '
+                       'packed-rows form takes <= %d topics and counts below '
+                       '4 GB' % (per_doc, ops.BF16X3_CHAIN_BLOCK,
+                                 ops.BF16X3_PACKED_MAX_WIDTH))
             elif arith == 'auto':
                 # (of ALL ranks' chains: every shard of one problem runs the
                 # same arithmetic, whatever the number of ranks)
@@ -233,6 +243,13 @@ class _DenseLikelihoodPlan(_PlanBase):
             if why is None:
                 self.inner_image = ops.bf16x3_image(self.inner)
                 self.block = ops.BF16X3_CHAIN_BLOCK
+                # (the library's rule: zshmc_bf16x3_multinomial_rows_packed)
+                self.packed_rows = bool(
+                    self.kind == 'mixture_multinomial' and
+                    self.width <= ops.BF16X3_PACKED_MAX_WIDTH and
+                    self.obs.numel() < (1 << 30) and
+                    _capi.load().zshmc_bf16x3_multinomial_rows_packed(
+                        n_docs, per_doc))
             else:
                 self.arithmetic_reason = why
                 if arith == 'bf16x3':
@@ -245,8 +262,9 @@ class _DenseLikelihoodPlan(_PlanBase):
         if self.inner_image is None and self.kind != 'linear_categorical':
             self.block = ops.likelihood_plan(self.width)[1]
         R = self.lik_rows
-        per_cu = 1 if self.kind == 'linear_categorical' and \
-            self.inner_image is None else \
+        # (packed rows: three tile buffers + 48 KB of counts, one per CU)
+        per_cu = 1 if (self.kind == 'linear_categorical' and
+                       self.inner_image is None) or self.packed_rows else \
             ops.resident_per_cu(self.width, 'bf16x3' if self.inner_image
                                 is not None else 'fp32')
         self.splits = ops._row_splits(R, n_inner, self.device, self.block,
