@@ -1,8 +1,11 @@
 """The native model plans: Normal-prior latents + one observed node whose
-log-likelihood and gradient come from a fused kernel -- dense-logit Bernoulli
-/ Categorical, the mixture multinomial of lntm_mcem.py, the gathered-dot
-rating model of pmf_hmc.py (csrc/linear_*.hip, hmc_model*.hip,
-gather_dot.hip; reference zhusuan/hmc.py:348-372, :418-520)."""
+log-likelihood and gradient come from a fused kernel (reference
+zhusuan/hmc.py:348-372, :418-520).  This module is what the four families
+share -- the packed state, the transition, the carried start evaluation, the
+choice of arithmetic, the C-side block runs (csrc/hmc_model*.hip); the
+families themselves (dense-logit Bernoulli / Categorical, the mixture
+multinomial of lntm_mcem.py, the gathered-dot rating model of pmf_hmc.py)
+are subclasses in zhusuan_amd/plans/families.py."""
 import ctypes
 
 import torch
@@ -14,15 +17,10 @@ from .base import _PlanBase, _versions, _Unsupported
 class _DenseLikelihoodPlan(_PlanBase):
     """Native plan for the dense-likelihood families (BASELINE configs 3 / 5):
     latents with Normal priors and one observed node whose log-likelihood and
-    gradient come from the fused fp32-MFMA kernels --
-
-      'linear_bernoulli'    y ~ Bernoulli(w @ X^T [+ w2 @ X2^T ...] [+ b],
-                                          group_ndims=1)
-                            one latent per term, up to 1024 features in total
-      'mixture_multinomial' x ~ UnnormalizedMultinomial(
-                                    log_mixture(softmax(eta), phi),
-                                    normalize_logits=False)   (lntm_mcem.py:33-48)
-                            one latent, up to 1024 topics
+    gradient come from a fused MFMA (or gather) kernel.  The base class of
+    families.py's _LinearBernoulliPlan, _MixtureMultinomialPlan,
+    _LinearCategoricalPlan and _GatheredDotPlan; `_DenseLikelihoodPlan(...,
+    kind)` builds the family named `kind`.
 
     The plan works on a PACKED state: the latents' columns side by side in
     rows of `ld` floats (the total rounded up to a multiple of 4; the columns
@@ -39,12 +37,29 @@ class _DenseLikelihoodPlan(_PlanBase):
     updates are seen."""
     can_skip_acc = False
 
-    def __init__(self, hmc, names, values, chain_shape, device, probe, kind):
+    # what a family declares (zhusuan_amd/plans/families.py)
+    kind = None            # the name HMC.plan_kind reports
+    softmax = False        # the operand is softmax(q) (Jacobian in the step)
+    segmented = False      # class rows / table rows: csrc/hmc_model_seg.hip
+    takes_bf16x3 = False   # csrc/b3_kernel.h has this likelihood
+    one_launch_capable = False   # csrc/hmc_model_traj.hip has it
+
+    def __new__(cls, hmc, names, values, chain_shape, device, probe,
+                kind=None):
+        # `_DenseLikelihoodPlan(..., kind)` builds the family's plan
+        if cls is _DenseLikelihoodPlan:
+            from .families import FAMILIES
+            cls = FAMILIES[kind]
+        return super(_DenseLikelihoodPlan, cls).__new__(cls)
+
+    def __init__(self, hmc, names, values, chain_shape, device, probe,
+                 kind=None):
         super(_DenseLikelihoodPlan, self).__init__(hmc, names, values,
                                                    chain_shape, device)
         from .. import _ops
         self._ops = _ops
-        self.kind = kind
+        assert kind in (None, self.kind), (kind, self.kind)
+        kind = self.kind
         self._probe = probe
         f32 = dict(dtype=torch.float32, device=device)
         C = self.n_chains
@@ -52,42 +67,12 @@ class _DenseLikelihoodPlan(_PlanBase):
         D = self.n_total = sum(self.n_data)
         self.ld = ld = (D + 3) // 4 * 4
         self.packed = len(self.q) > 1 or ld != D
-        self.softmax = kind == 'mixture_multinomial'
         # chain axes flattened: [C, D_k] views of the latents
         self.q_rows = [q.view(C, d) for q, d in zip(self.q, self.n_data)]
         self.p = torch.zeros(C, ld, **f32)
         self.q_new = torch.zeros(C, ld, **f32)
-        self.segmented = kind in ('linear_categorical', 'gathered_dot')
-        if kind == 'gathered_dot':
-            # pmf_hmc.py:19-31: the latent is one of the two factor tables,
-            # [chains, n, D] -- a handful of chains of 10^4..10^5 elements.
-            # The gradient comes back from zshmc_gather_dot_grad as a plain
-            # [C, n * D] matrix: one "segment" per chain.
-            self.n_classes, self.seg_len, self.stride = 1, D, 1
-            self.width = ld
-            self.lik_rows = C
-            self.seg_ws = torch.empty(
-                int(_capi.load().zshmc_model_seg_workspace(C, D)), **f32)
-            self.lp_const = torch.zeros(C, **f32)
-            self._host_scalars = {}
-            self._logstd_dev = torch.zeros(8, **f32)
-            need_operand = False
-        elif self.segmented:
-            # w[c, 0:K, 0:F]: K class rows of F features per chain; the
-            # likelihood kernel's "chain rows" are the (chain, class) pairs,
-            # `stride` of them per chain (K rounded up to a power of two)
-            K, F = (int(v) for v in self.q[0].shape[-2:])
-            self.n_classes, self.seg_len = K, F
-            self.stride = _ops.class_stride(K)
-            self.width, self.block = _ops.likelihood_plan(F, self.stride)
-            self.lik_rows = C * self.stride
-            self.seg_ws = torch.empty(
-                int(_capi.load().zshmc_model_seg_workspace(C, D)), **f32)
-            need_operand = not (K == self.stride and F == self.width)
-        else:
-            self.width, self.block = _ops.likelihood_plan(ld)
-            self.lik_rows = C
-            need_operand = self.softmax or self.width != ld
+        # kernel width, chain block, likelihood rows, family buffers
+        need_operand = self._layout(C, D, ld, f32)
         self.grad = torch.empty(self.lik_rows, self.width, **f32)
         # operand of the likelihood kernel: theta = softmax(q) / zero-padded q
         # / the class rows of q (padding rows and columns stay zero)
@@ -128,8 +113,7 @@ class _DenseLikelihoodPlan(_PlanBase):
         self.c_transition = True
         self.traj_sync = torch.zeros(4, dtype=torch.int32, device=device)
         self.traj_capacity = 0
-        if hmc.one_launch_trajectory and kind in (
-                'linear_bernoulli', 'mixture_multinomial') and \
+        if hmc.one_launch_trajectory and self.one_launch_capable and \
                 self.width <= 256:
             cap = ctypes.c_int(0)
             _capi.call('zshmc_trajectory_capacity', self.width,
@@ -172,32 +156,9 @@ class _DenseLikelihoodPlan(_PlanBase):
         C = self.n_chains
         self._pack_prior(priors)
         ops = self._ops
-        if self.kind == 'linear_bernoulli':
-            y = obs
-            if self.packed:
-                self.inner = _aligned16(ops.packed_design(
-                    inner, int(y.shape[0]), self.device, self.width))
-            else:
-                self.inner = _aligned16(ops._padded_x(inner[0], self.width))
-            self.obs = _aligned16(y.detach().to(torch.float32).contiguous())
-            n_inner = self.inner.shape[0]
-        elif self.kind == 'gathered_dot':
-            self._refresh_gathered_dot(inner, obs)
+        n_inner = self._operands(inner, obs)
+        if n_inner is None:         # (the family keeps no dense operand)
             return
-        elif self.kind == 'linear_categorical':
-            self.inner = _aligned16(ops._padded_x(inner[0], self.width))
-            self.obs = _aligned16(ops.labels_as_float(obs, self.n_classes))
-            n_inner = self.inner.shape[0]
-        else:
-            phi, x = inner[0], obs
-            self.inner = _aligned16(ops._padded_phi_t(phi, self.width))
-            # (rows padded to 32 floats: what the packed-rows form of the
-            # bf16x3 kernel wants; the other kernels take any stride)
-            self.obs, self.obs_stride = ops._padded_counts(x, 32)
-            self.obs = _aligned16(self.obs)
-            n_inner = self.inner.shape[0]
-            if C % self.obs.shape[0] != 0:
-                raise ValueError("counts rows do not divide the chain rows")
         # the bf16x3 kernels ('bf16x3': wherever they exist -- <= 256 columns
         # and, one document per 128-chain workgroup, chain axes that fill
         # those workgroups -- with a warning where they do not; 'auto', the
@@ -207,12 +168,9 @@ class _DenseLikelihoodPlan(_PlanBase):
         self.arithmetic_reason = None
         self.packed_rows = False
         arith = self.hmc.likelihood_arithmetic
-        if arith in ('bf16x3', 'auto') and self.kind in (
-                'linear_bernoulli', 'mixture_multinomial',
-                'linear_categorical'):
+        if arith in ('bf16x3', 'auto') and self.takes_bf16x3:
             why = None
-            per_doc = C // self.obs.shape[0] \
-                if self.kind == 'mixture_multinomial' else C
+            per_doc = self._chains_per_counts_row()
             n_docs = C // per_doc
             if self.width not in ops.BF16X3_WIDTHS:
                 why = ('the bf16x3 kernels take <= %d padded columns, this '
@@ -245,7 +203,7 @@ class _DenseLikelihoodPlan(_PlanBase):
                 self.block = ops.BF16X3_CHAIN_BLOCK
                 # (the library's rule: zshmc_bf16x3_multinomial_rows_packed)
                 self.packed_rows = bool(
-                    self.kind == 'mixture_multinomial' and
+                    n_docs > 1 and
                     self.width <= ops.BF16X3_PACKED_MAX_WIDTH and
                     self.obs.numel() < (1 << 30) and
                     _capi.load().zshmc_bf16x3_multinomial_rows_packed(
@@ -259,14 +217,11 @@ class _DenseLikelihoodPlan(_PlanBase):
                         "HMC(likelihood_arithmetic='bf16x3'): this model's "
                         "likelihood runs on the fp32 kernels -- " + why,
                         LikelihoodArithmeticWarning, stacklevel=2)
-        if self.inner_image is None and self.kind != 'linear_categorical':
-            self.block = ops.likelihood_plan(self.width)[1]
+        if self.inner_image is None:
+            self.block = self._fp32_block()
         R = self.lik_rows
         # (packed rows: three tile buffers + 48 KB of counts, one per CU)
-        per_cu = 1 if (self.kind == 'linear_categorical' and
-                       self.inner_image is None) or self.packed_rows else \
-            ops.resident_per_cu(self.width, 'bf16x3' if self.inner_image
-                                is not None else 'fp32')
+        per_cu = 1 if self.packed_rows else self._resident_per_cu()
         self.splits = ops._row_splits(R, n_inner, self.device, self.block,
                                       per_cu)
         # (chain blocks x slices resident at once where the chain blocks
@@ -279,116 +234,40 @@ class _DenseLikelihoodPlan(_PlanBase):
             self._ws = torch.empty(need, dtype=torch.float32,
                                    device=self.device)
 
-    # -- the gathered-dot rating model (pmf_hmc.py:19-31) -----------------------
-    def _host_scalar(self, t):
-        """float(t) of a one-element device tensor, read once per (storage,
-        version): the per-run path does not synchronise."""
-        key = (t.data_ptr(), t._version)
-        hit = self._host_scalars.get(key)
-        if hit is None:
-            if len(self._host_scalars) > 64:
-                self._host_scalars.clear()
-            hit = self._host_scalars[key] = (float(t.item()), t)
-        return hit[0]
+    # -- what a family implements (zhusuan_amd/plans/families.py) -------------
+    def _layout(self, C, D, ld, f32):
+        """Set width, block, lik_rows (+ the family's buffers) for C chains
+        of D packed floats in rows of ld; return whether the likelihood
+        kernel needs an operand other than the packed state itself."""
+        raise NotImplementedError
 
-    def _refresh_gathered_dot(self, inner, obs):
-        """inner = [side ('u' | 'v': which table the latent is), other table,
-        select (latent side), select (other side) or None, likelihood spread ('std' | 'logstd', tensor), constant nodes
-        [(observed tensor, mean, (how, spread))...]]."""
-        import math
-        ops = self._ops
-        self.side, other, sel_lat, sel_other, spread, consts = inner
-        self.splits = 1
-        q = self.q[0]
-        n_lat, D = int(q.shape[-2]), int(q.shape[-1])
-        self.n_lat, self.n_dim = n_lat, D
-        self.other = _aligned16(other.detach().to(torch.float32).contiguous())
-        self.n_other = int(self.other.shape[-2])
-        E = int(sel_lat.numel())
-        self.n_pairs = E
-        # CSR view of the pair list by the latent's rows (deterministic
-        # scatter of the gradient) -- cached per index tensor version
-        self.idx_lat, self.seg, self.order = ops._pair_csr(
-            sel_lat, n_lat, 'native_lat')
-        if sel_other is None:       # `other` is already gathered pair by pair
-            if getattr(self, '_iota', None) is None or \
-                    self._iota.numel() != E:
-                self._iota = torch.arange(E, dtype=torch.int32,
-                                          device=self.device)
-            self.idx_other = self._iota
-        else:
-            self.idx_other = ops._pair_csr(sel_other, self.n_other,
-                                           'native_other')[0]
-        r = obs.detach().to(torch.float32).contiguous()
-        if r.numel() == E:
-            self.obs, self.obs_rows = r.reshape(-1), 1
-        elif r.numel() == self.n_chains * E:
-            self.obs, self.obs_rows = r.reshape(-1), self.n_chains
-        else:
-            raise ValueError("HMC (native gathered_dot plan): %d observed "
-                             "ratings for %d pairs" % (r.numel(), E))
-        how, sp = spread
-        sp_v = self._host_scalar(sp)
-        self.lik_logstd = math.log(sp_v) if how == 'std' else sp_v
-        need = int(_capi.load().zshmc_gather_dot_normal_workspace(
-            self.n_chains, E))
-        # likelihood + gradient in one pass over the pair list where the rows
-        # are <= 128 floats, a multiple of 4 (csrc/gather_dot.hip:
-        # gd_fused_kernel): the CSR view cut into segments, the other side's
-        # indices and the ratings in CSR order
-        self.gd_fused = D % 4 == 0 and D <= 128 and E > 0
-        if self.gd_fused:
-            key = (self.seg.data_ptr(), self.order.data_ptr(),
-                   self.idx_other.data_ptr(), self.idx_other._version)
-            if getattr(self, '_gd_seg_key', None) != key:
-                self._gd_seg = ops._csr_segments(self.seg, E)
-                self._gd_idx_csr = self.idx_other[self.order.long()].contiguous()
-                self._gd_seg_key = key
-            self._gd_obs_csr = _aligned16(self.obs.view(
-                self.obs_rows, E)[:, self.order.long()].contiguous())
-            n_seg = int(self._gd_seg[1].numel())
-            # (partial sums rounded up to 4 floats: the per-segment gradient
-            # rows behind them are written with 16-byte stores)
-            groups = self.n_chains * n_seg
-            need = max(need, groups * D + (groups + 3) // 4 * 4)
-        if self._ws is None or self._ws.numel() < max(need, 1):
-            self._ws = torch.empty(max(need, 1), dtype=torch.float32,
-                                   device=self.device)
-        if getattr(self, 'g_pairs', None) is None or \
-                self.g_pairs.numel() < self.n_chains * max(E, 1):
-            self.g_pairs = torch.empty(self.n_chains * max(E, 1),
-                                       dtype=torch.float32, device=self.device)
-        # the observed nodes that do not depend on the latent: their
-        # log-densities (a constant of this run) join every log-joint value
-        stream = _capi.current_stream()
-        if len(consts) > 1:
-            raise _Unsupported('more than one constant node in the joint')
-        if consts:
-            x, mean, (chow, csp) = consts[0]
-            xs = _aligned16(x.detach().to(torch.float32).contiguous())
-            cols = xs.numel() // self.n_chains
-            cv = self._host_scalar(csp)
-            _capi.call('zshmc_state_set', self._logstd_dev.data_ptr(), 0,
-                       math.log(cv) if chow == 'std' else cv, stream)
-            data_shape = tuple(xs.shape[len(self.chain_shape):])
-            m = mean.detach().to(torch.float32)
-            if m.numel() == 1:
-                m, mode = m.reshape(1), _capi.BCAST_SCALAR
-            elif tuple(m.shape[-len(data_shape):]) == data_shape and \
-                    m.numel() == cols:
-                m, mode = _aligned16(m.contiguous().reshape(-1)), \
-                    _capi.BCAST_ROW
-            else:
-                m, mode = _aligned16(m.expand(xs.shape).contiguous()), \
-                    _capi.BCAST_FULL
-            self._const_keep = (xs, m)
-            _capi.call('zshmc_normal_log_prob', xs.data_ptr(), m.data_ptr(),
-                       self._logstd_dev.data_ptr(), self.lp_const.data_ptr(),
-                       self.n_chains, cols, mode, _capi.BCAST_SCALAR, 1,
-                       stream)
-        else:
-            _capi.call('zshmc_zero', self.lp_const.data_ptr(),
-                       4 * self.n_chains, stream)
+    def _operands(self, inner, obs):
+        """The model's tensors -> self.inner / self.obs in the kernel's
+        layout; returns the number of inner (data / vocabulary) rows, or None
+        when the family keeps no dense operand."""
+        raise NotImplementedError
+
+    def _evaluate(self, w, q, grad, ll, ll_ptr, ws, stream):
+        """One likelihood + gradient launch at operand w (state q)."""
+        raise NotImplementedError
+
+    def _describe(self, d):
+        """The family's fields of zshmc_model_plan."""
+        d.inner, d.n_inner = self.inner.data_ptr(), self.inner.shape[0]
+        d.inner_image = _capi.ptr(self.inner_image)
+        d.obs = self.obs.data_ptr()
+
+    def _chains_per_counts_row(self):
+        """Chains that share one row of the observed operand (all of them,
+        except in the topic model: one counts row per document)."""
+        return self.n_chains
+
+    def _fp32_block(self):
+        return self._ops.likelihood_plan(self.width)[1]
+
+    def _resident_per_cu(self):
+        return self._ops.resident_per_cu(
+            self.width, 'bf16x3' if self.inner_image is not None else 'fp32')
 
     def _pack_prior(self, priors):
         """Prior mean / log-std as [rows, ld] matrices used with row period
@@ -458,86 +337,7 @@ class _DenseLikelihoodPlan(_PlanBase):
         ll_ptr = ll.data_ptr() if want_ll else None
         w = self.operand if self.operand is not None else q
         ws = self._ws if self.splits > 1 else None
-        if self.kind == 'gathered_dot':
-            # rating terms + d/d logit in one pass over the pairs, then the
-            # deterministic scatter into the latent's rows
-            lat_is_u = self.side == 'u'
-            if self.gd_fused:
-                sp, sr, sf, lr = self._gd_seg
-                _capi.call(
-                    'zshmc_gather_dot_normal_lik_grad', q.data_ptr(),
-                    self.other.data_ptr(), sp.data_ptr(), sr.data_ptr(),
-                    sf.data_ptr(), lr.data_ptr() if lr.numel() else None,
-                    lr.numel(), self._gd_idx_csr.data_ptr(),
-                    self._gd_obs_csr.data_ptr(), self.obs_rows,
-                    self.lik_logstd, self.lp_const.data_ptr(), self.n_chains,
-                    self.n_lat, self.n_other, self.n_pairs, sr.numel(),
-                    self.n_dim, grad.data_ptr(), ll.data_ptr(),
-                    self._ws.data_ptr(), stream)
-                return
-            _capi.call(
-                'zshmc_gather_dot_normal_lik',
-                q.data_ptr() if lat_is_u else self.other.data_ptr(),
-                self.other.data_ptr() if lat_is_u else q.data_ptr(),
-                (self.idx_lat if lat_is_u else self.idx_other).data_ptr(),
-                (self.idx_other if lat_is_u else self.idx_lat).data_ptr(),
-                self.obs.data_ptr(), self.obs_rows, self.lik_logstd,
-                self.lp_const.data_ptr(), self.n_chains,
-                self.n_lat if lat_is_u else self.n_other,
-                self.n_other if lat_is_u else self.n_lat, self.n_pairs,
-                self.n_dim, self.g_pairs.data_ptr(), ll.data_ptr(),
-                self._ws.data_ptr(), stream)
-            if self.n_pairs:
-                _capi.call('zshmc_gather_dot_grad', self.other.data_ptr(),
-                           self.g_pairs.data_ptr(), self.seg.data_ptr(),
-                           self.order.data_ptr(), self.idx_other.data_ptr(),
-                           self.n_chains, self.n_lat, self.n_other,
-                           self.n_pairs, self.n_dim, grad.data_ptr(),
-                           stream)
-            else:
-                _capi.call('zshmc_zero', grad.data_ptr(),
-                           4 * grad.numel(), stream)
-        elif self.kind == 'linear_categorical' and \
-                self.inner_image is not None:
-            _capi.call('zshmc_linear_categorical_log_lik_bf16x3',
-                       w.data_ptr(), self.inner_image.data_ptr(),
-                       self.obs.data_ptr(), self.lik_rows,
-                       self.inner.shape[0], self.width, self.n_classes,
-                       self.stride, ll_ptr, grad.data_ptr(), self.splits,
-                       _capi.ptr(ws), stream)
-        elif self.kind == 'linear_categorical':
-            _capi.call('zshmc_linear_categorical_log_lik', w.data_ptr(),
-                       self.inner.data_ptr(), self.obs.data_ptr(),
-                       self.lik_rows, self.inner.shape[0], self.width,
-                       self.n_classes, self.stride, ll_ptr,
-                       grad.data_ptr(), self.splits, _capi.ptr(ws),
-                       stream)
-        elif self.inner_image is not None and self.kind == 'linear_bernoulli':
-            _capi.call('zshmc_linear_bernoulli_log_lik_bf16x3', w.data_ptr(),
-                       self.inner_image.data_ptr(), self.obs.data_ptr(),
-                       self.n_chains, self.inner.shape[0], self.width,
-                       ll_ptr, grad.data_ptr(), self.splits,
-                       _capi.ptr(ws), stream)
-        elif self.inner_image is not None:
-            _capi.call('zshmc_linear_multinomial_log_lik_bf16x3',
-                       w.data_ptr(), self.inner_image.data_ptr(),
-                       self.obs.data_ptr(), self.obs.shape[0],
-                       self.obs_stride, self.n_chains, self.inner.shape[0],
-                       self.width, ll_ptr, grad.data_ptr(), self.splits,
-                       _capi.ptr(ws), stream)
-        elif self.kind == 'linear_bernoulli':
-            _capi.call('zshmc_linear_bernoulli_log_lik', w.data_ptr(),
-                       self.inner.data_ptr(), self.obs.data_ptr(),
-                       self.n_chains, self.inner.shape[0], self.width,
-                       ll_ptr, grad.data_ptr(), self.splits,
-                       _capi.ptr(ws), stream)
-        else:
-            _capi.call('zshmc_linear_multinomial_log_lik', w.data_ptr(),
-                       self.inner.data_ptr(), self.obs.data_ptr(),
-                       self.obs.shape[0], self.obs_stride, self.n_chains,
-                       self.inner.shape[0], self.width, ll_ptr,
-                       grad.data_ptr(), self.splits, _capi.ptr(ws),
-                       stream)
+        self._evaluate(w, q, grad, ll, ll_ptr, ws, stream)
 
     def _step(self, q, p, use_grad, eps_host, kick, drift, lp_out, kinetic,
               stream, start=False):
@@ -712,34 +512,7 @@ class _DenseLikelihoodPlan(_PlanBase):
         d.one_launch = int(self.traj_capacity > 0)
         d.traj_sync = self.traj_sync.data_ptr()
         d.split_ws = c.ptr(self._ws)
-        if self.segmented:
-            d.seg_len, d.groups = self.seg_len, self.stride
-            d.seg_ws = self.seg_ws.data_ptr()
-        if self.kind == 'gathered_dot':
-            d.inner, d.n_inner = self.other.data_ptr(), self.n_other
-            d.obs, d.obs_rows = self.obs.data_ptr(), self.obs_rows
-            d.gd_latent_is_u = int(self.side == 'u')
-            d.gd_idx_latent = self.idx_lat.data_ptr()
-            d.gd_idx_other = self.idx_other.data_ptr()
-            d.gd_seg, d.gd_order = self.seg.data_ptr(), self.order.data_ptr()
-            d.gd_n_latent, d.gd_n_pairs = self.n_lat, self.n_pairs
-            d.gd_n_dim, d.gd_logstd = self.n_dim, self.lik_logstd
-            d.gd_lp_const = self.lp_const.data_ptr()
-            d.gd_g_pairs = self.g_pairs.data_ptr()
-            if self.gd_fused:
-                sp, sr, sf, lr = self._gd_seg
-                d.gd_seg_ptr, d.gd_seg_row = sp.data_ptr(), sr.data_ptr()
-                d.gd_seg_first = sf.data_ptr()
-                d.gd_long_rows = lr.data_ptr() if lr.numel() else None
-                d.gd_n_seg, d.gd_n_long = sr.numel(), lr.numel()
-                d.gd_idx_other_csr = self._gd_idx_csr.data_ptr()
-                d.gd_obs_csr = self._gd_obs_csr.data_ptr()
-        else:
-            d.inner, d.n_inner = self.inner.data_ptr(), self.inner.shape[0]
-            d.inner_image = c.ptr(self.inner_image)
-            d.obs = self.obs.data_ptr()
-            if self.kind == 'mixture_multinomial':
-                d.obs_rows, d.obs_stride = self.obs.shape[0], self.obs_stride
+        self._describe(d)
         d.prior_mean, d.mean_rows = self.prior_mean.data_ptr(), self.mean_rows
         d.prior_logstd = self.prior_logstd.data_ptr()
         d.logstd_rows = self.logstd_rows
