@@ -5,7 +5,10 @@ diagonal Gaussian, L = 10 leapfrog steps per HMC transition, on N MI355X
 
 A "step" is one full HMC transition over all chains (momentum resample, L+1
 gradient kicks, L drifts, MH accept, step-size update).  State is resident in
-HBM before the timed region.  Prints ONE JSON line (see the task contract):
+HBM before the timed region.  The LAST stdout line is the contract object
+(<= 4 KB, strict JSON, the only line that starts with `{`); the full records
+travel before it on `#bench-extra` / `#bench-detail` lines and in
+bench_extras.json (see "Output" below):
 
   value     = chain-leapfrog-steps/s = n_chains_total * L * steps / t
   roofline  = algorithmic bytes (8 B per chain-latent per transition:
@@ -14,11 +17,14 @@ HBM before the timed region.  Prints ONE JSON line (see the task contract):
               (bounded sample, rank 0, N = 1); beside it the op-for-op ports
               (torch-CPU all threads, NumPy one core) and the recorded timing
               of the reference's own hmc.py over the TensorFlow-API shim
-  extra_configs = BASELINE configs[2] (logistic regression, 10^6 x 256, 32 768
-              chains) and configs[4] (topic model, 5 000 docs x 128 topics),
-              MFMA-bound, through the native plans; and, beyond
-              BASELINE.json, a 1 000-feature + bias regression (two latents on
-              the packed native plan, the feature-split MFMA kernel)
+  extras    = one short entry per extra configuration (full records on the
+              `#bench-extra` lines): BASELINE configs[0], configs[2] (logistic
+              regression, 10^6 x 256, 32 768 chains) and configs[4] (topic
+              model, 5 000 docs x 128 topics), MFMA-bound, through the native
+              plans on HMC's default arithmetic with the other one beside it;
+              and, beyond BASELINE.json, wide regressions, softmax
+              regressions, the PMF rating model, the topic model at the
+              reference's own minibatch size and in its own one-chain layout
 
     python bench.py --gpus 1 --steps 200 --warmup 20
     python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8

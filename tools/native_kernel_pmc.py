@@ -18,6 +18,39 @@ dev = torch.device('cuda', 0)
 s = torch.cuda.current_stream().cuda_stream
 g = torch.Generator(device=dev).manual_seed(0)
 
+if len(sys.argv) > 1 and sys.argv[1] == 'packed':
+    # round 6: lntm_mcem.py's own layout at scale -- ONE chain x 32 768
+    # documents (every row of theta its own counts row), K = 128, V = 12 419:
+    # the fp32 kernel and the packed-rows form of the bf16x3 kernel
+    #   bash tools/profile_native_full.sh r06p packed
+    import ctypes
+    n_docs, K, V = 32768, 128, 12419
+    phi = torch.softmax(torch.randn(K, V, device=dev, generator=g), -1)
+    x = torch.poisson(torch.full((n_docs, V), 0.08, device=dev), generator=g)
+    theta = torch.softmax(torch.randn(n_docs, K, device=dev, generator=g), -1)
+    phi_t = _ops._padded_phi_t(phi, K)
+    xp, stride = _ops._padded_counts(x, 32)
+    assert _capi.load().zshmc_bf16x3_multinomial_rows_packed(n_docs, 1) == 1
+    ll = torch.empty(n_docs, device=dev)
+    gt = torch.empty(n_docs, K, device=dev)
+    nb = ctypes.c_int64()
+    _capi.call('zshmc_bf16x3_image_bytes', phi_t.shape[0], K,
+               ctypes.addressof(nb))
+    img = torch.empty(nb.value, dtype=torch.uint8, device=dev)
+    _capi.call('zshmc_bf16x3_split', phi_t.data_ptr(), phi_t.shape[0], K,
+               phi_t.stride(0), img.data_ptr(), s)
+    for name, inner in (('zshmc_linear_multinomial_log_lik', phi_t),
+                        ('zshmc_linear_multinomial_log_lik_bf16x3', img)):
+        for ll_ptr in (ll.data_ptr(), ll.data_ptr(), None, None, None):
+            _capi.call(name, theta.data_ptr(), inner.data_ptr(),
+                       xp.data_ptr(), xp.shape[0], stride, n_docs, V, K,
+                       ll_ptr, gt.data_ptr(), 1, None, s)
+    torch.cuda.synchronize()
+    print('config5 shape: rows=%d K=%d V=%d; PACKED ROWS (1 chain x %d '
+          'documents): counts streamed per launch %.3e B' % (
+              n_docs, K, V, n_docs, 4.0 * n_docs * stride))
+    sys.exit(0)
+
 # ---- configs[2]: Bernoulli mode --------------------------------------------
 C, N, D = 32768, 1000000, 256
 X = torch.randn(N, D, device=dev, generator=g)

@@ -33,7 +33,13 @@ def mode_of(name):
             m = re.search(r'ILi(\d+)ELi(\d)ELb([01])E', tail)
             op, ll = int(m.group(2)), m.group(3) == '1'
         fam = {0: 'bernoulli', 1: 'multinomial'}[op]
-        return '%s bf16x3 %s' % (fam, 'll+grad' if ll else 'grad-only')
+        # round 6: the packed-rows instantiations (6th template argument)
+        args = re.search(r'<([^>]*)>', tail)
+        packed = (args is not None and
+                  args.group(1).replace(' ', '').split(',')[5:6] == ['true']) \
+            or re.search(r'ELi\dELi\dELb1EEE', tail) is not None
+        return '%s bf16x3%s %s' % (fam, ' packed-rows' if packed else '',
+                                   'll+grad' if ll else 'grad-only')
     tail = name.split('linear_bernoulli_kernel')[1][:80]
     m = re.search(r'<\s*(\d+),\s*(true|false),\s*(\d)(?:,\s*(true|false))?\s*>',
                   tail)
