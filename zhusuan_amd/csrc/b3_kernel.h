@@ -232,17 +232,26 @@ constexpr int kLastUse[3] = {2, 4, 5};
 #endif
 
 // ---------------------------------------------------------------------------
+#ifndef ZS_B3_PK_AHEAD
+#define ZS_B3_PK_AHEAD 2   // PK, D <= 128: tiles the counts are fetched ahead
+#endif
 // GL: log2 of the class stride (OP 2)
 // PK (OP 1): packed rows -- row r of theta belongs to document r % yc_rows (a
 // few chains x many documents, lntm_mcem.py's own layout: n_chains = 1), so
 // every chain of a workgroup has its OWN counts row: the "labels" of a tile
 // are [32 vocabulary rows][128 chains] floats (16 KB per buffer instead of
-// 128 B), brought by four 16-byte-per-lane DMAs per wave -- lane (lo, hi) of
-// DMA g fetches x[doc(chain lo)][32 t + 8 g + 4 hi .. + 3] into slot
-// g * 64 + lane, exactly where the element-wise stage's lane reads its pairs
-// from.  Needs counts rows padded to a multiple of 32 floats (no clamping at
-// the last tile) and a counts matrix below 4 GB (32-bit lane offsets); three
-// tile buffers + 48 KB fit the LDS up to D = 192, one workgroup per CU.
+// 128 B), brought by four 16-byte-per-lane DMAs per wave -- DMA g the
+// 128-byte lines of chains 8 g .. 8 g + 7, eight consecutive lanes a line,
+// each chain's eight 16-byte pieces rotated by the chain on their way into
+// the LDS (the DMA's global side is per lane, its LDS side linear by lane: the
+// DMA itself is the permutation) so that the element-wise stage's lanes read
+// their pairs without more than the two-way conflict 8-byte reads of 16-byte
+// slots have anyway.  At D <= 128 the counts are fetched TWO tiles ahead (they
+// come from HBM, every workgroup its own; the tile image is L2-resident).
+// Needs counts rows padded to a multiple of 32 floats (no clamping at the last
+// tile) and a counts matrix below 4 GB (32-bit lane offsets); three tile
+// buffers + 48 KB (64 KB at D <= 128) fit the LDS up to D = 192, one workgroup
+// per CU.
 template <int D, int OP, bool LL, int NACC, int GL = 0, bool PK = false>
 __global__ __launch_bounds__(256, PK ? 1 : ZS_B3_WAVES(D)) void linear_b3_kernel(
     const float* __restrict__ W, const unsigned char* __restrict__ Ximg,
@@ -253,6 +262,14 @@ __global__ __launch_bounds__(256, PK ? 1 : ZS_B3_WAVES(D)) void linear_b3_kernel
   static_assert(NACC == 1 || NACC == 2, "accumulator chains of GEMM 1");
   static_assert(!PK || (OP == 1 && D <= 192), "packed rows: multinomial, LDS");
   constexpr int kYBuf = PK ? 16384 : 128;   // bytes of one label buffer
+  // PK: the counts of a tile come from HBM (every workgroup its own rows; the
+  // tile image is shared and L2-resident): where the LDS has room (D <= 128:
+  // 72 + 64 KB) they are fetched TWO tiles ahead into a ring of four buffers,
+  // and the iteration boundary waits for everything but those four DMAs
+  // (vmcnt(4): they are the last issued) -- an HBM round trip is as long as
+  // a tile (rocprofv3, r06p: MFMA busy 0.52 with the counts one tile ahead)
+  constexpr int kYAhead = (PK && D <= 128) ? ZS_B3_PK_AHEAD : 1;
+  constexpr int kYN = kYAhead + 2;          // label buffers
   constexpr int KS = D / 16;             // k-steps of GEMM 1 (16 features)
   constexpr int NB = D / 32;             // gradient accumulators (32 features)
   constexpr int kPlane = NB * 2048;      // bytes of one plane of a tile
@@ -268,6 +285,9 @@ __global__ __launch_bounds__(256, PK ? 1 : ZS_B3_WAVES(D)) void linear_b3_kernel
   // [3][kTile] tiles, [3][32] labels (PK: [3][4 waves][4 groups][64 lanes][4])
   const uint32_t sx_addr = (uint32_t)reinterpret_cast<uintptr_t>(smem);
   const uint32_t sy_addr = sx_addr + 3 * kTile;
+  auto y_slot = [&](int t) -> uint32_t {    // PK: tile t (local index)
+    return (uint32_t)((t % kYN) * kYBuf);
+  };
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -292,10 +312,26 @@ __global__ __launch_bounds__(256, PK ? 1 : ZS_B3_WAVES(D)) void linear_b3_kernel
   };
   // labels (OP 0) / the document's counts (OP 1) of the data rows
   const float* ysrc = uniform_ptr(OP == 1 && !PK ? y + doc * ldy : y);
-  // PK: byte offset of this lane's counts (its chain's document, rows 4 hi ..)
-  const uint32_t pk_voff =
-      PK ? (uint32_t)(((row_at(wave * 32 + lo) % yc_rows) * ldy + 4 * hi) * 4)
-         : 0u;
+  // PK: byte offsets of this lane's share of the four counts DMAs of a tile.
+  // DMA g brings chains 8 g .. 8 g + 7 of the wave, EIGHT CONSECUTIVE LANES a
+  // chain's whole 128-byte line (32 rows) -- one request to the texture path
+  // per line instead of one per lane; lane l is chain c = 8 g + l / 8 and lands
+  // in slot l % 8 of the chain's row of the buffer, which holds piece (rows
+  // 4 P .. 4 P + 3) P = (l % 8 - c / 2) mod 8: rotated by the chain so that
+  // the stage's reads -- 32 chains, the SAME piece -- spread over all banks
+  // (row-major placement: 16-way conflicts)
+  uint32_t pk_voff[4] = {0u, 0u, 0u, 0u};
+  if constexpr (PK) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int c = 8 * g + (lane >> 3);
+      const int P = ((lane & 7) - (c >> 1)) & 7;
+      pk_voff[g] = (uint32_t)(((row_at(wave * 32 + c) % yc_rows) * ldy + 4 * P) * 4);
+    }
+  }
+  // ... and where the stage's lane (chain lo, half hi) finds piece 2 G + hi:
+  // slot (2 G + hi + lo / 2) mod 8 of its chain's row
+  const int pk_rot = hi + (lo >> 1);
 
   // ---- this wave's chain block of W -> three bf16 planes (B operand of
   // GEMM 1: lane = chain, k-slot i of half hi = feature 16 ks + 8 hi + i) ----
@@ -356,8 +392,8 @@ __global__ __launch_bounds__(256, PK ? 1 : ZS_B3_WAVES(D)) void linear_b3_kernel
       const uint32_t d0 = dst + (uint32_t)(wave * 4096);
 #pragma unroll
       for (int g = 0; g < 4; ++g)
-        b3_dma<0>(reinterpret_cast<const unsigned char*>(src + g * 8),
-                  d0 + (uint32_t)(g * 1024), pk_voff);
+        b3_dma<0>(reinterpret_cast<const unsigned char*>(src),
+                  d0 + (uint32_t)(g * 1024), pk_voff[g]);
       return;
     }
     const int64_t left = N - 1 - tile * kB3Rows;      // >= 0: the tile exists
@@ -396,7 +432,7 @@ __global__ __launch_bounds__(256, PK ? 1 : ZS_B3_WAVES(D)) void linear_b3_kernel
   }
   // labels of this lane's rows: group g = rows 8 g + 4 hi .. + 3
   const uint32_t y_lane =
-      PK ? (uint32_t)(wave * 4096 + lane * 16) : (uint32_t)(hi * 16);
+      PK ? (uint32_t)(wave * 4096 + lo * 128) : (uint32_t)(hi * 16);
 
   // (zeroed BY an MFMA, 0 * 0 + 0, straight in their AGPRs: zeros written
   // by the compiler arrive through a second set of D/2 registers that then
@@ -419,6 +455,12 @@ __global__ __launch_bounds__(256, PK ? 1 : ZS_B3_WAVES(D)) void linear_b3_kernel
   // prologue: tile 0 -> buffer 0
   static_for<kDma>([&](auto ic) { dma_piece(ic, xsrc, dst_wave + b_cur); });
   dma_labels(t_first, sy_addr + y_cur);
+  if constexpr (PK && kYAhead > 1) {  // (past the last tile: clamped, harmless)
+#pragma unroll
+    for (int a = 1; a < kYAhead; ++a)
+      dma_labels(t_first + (a < T ? a : (T > 0 ? T - 1 : 0)),
+                 sy_addr + y_slot(a));
+  }
 
   f16v Sa, Sb;              // GEMM 1's accumulator chains
   float Sp[16];             // the logits of the tile before
@@ -452,7 +494,12 @@ __global__ __launch_bounds__(256, PK ? 1 : ZS_B3_WAVES(D)) void linear_b3_kernel
   // iteration it+1 (A operand of k-step 0, the labels of tile `it`) go out
   // under those last MFMAs ------------------------------------------------------
   auto boundary = [&](int it) {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if constexpr (PK && kYAhead == 2)
+      asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else if constexpr (PK && kYAhead == 3)
+      asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     {  // prev <- cur <- next <- prev
       const uint32_t t = b_prev;
       b_prev = b_cur;
@@ -470,7 +517,7 @@ __global__ __launch_bounds__(256, PK ? 1 : ZS_B3_WAVES(D)) void linear_b3_kernel
     // (the labels of a pair -- two consecutive rows, 8 bytes -- are read by
     // the pair's first piece: four registers of labels held per tile would
     // not fit two waves per SIMD at D = 128)
-    y_addr = sy_addr + y_prev + y_lane;
+    y_addr = sy_addr + (PK ? y_slot(it) : y_prev) + y_lane;
     __builtin_amdgcn_sched_barrier(0);
   };
   // where iteration `it` sends tile it+1 (clamped to the last one: a
@@ -480,6 +527,11 @@ __global__ __launch_bounds__(256, PK ? 1 : ZS_B3_WAVES(D)) void linear_b3_kernel
     src_next = xsrc + (int64_t)nxt * kTile;
     dst_next = dst_wave + b_next;
     lab_next = t_first + nxt;
+    if constexpr (PK) {       // the counts of tile it + kYAhead, into its slot
+      const int far = it + kYAhead < T ? it + kYAhead : T - 1;
+      lab_next = t_first + far;
+      y_next = y_slot(it + kYAhead);
+    }
   };
 
   // ---- element-wise stage of tile it-1, in pieces ------------------------------
@@ -504,8 +556,9 @@ __global__ __launch_bounds__(256, PK ? 1 : ZS_B3_WAVES(D)) void linear_b3_kernel
         // rows 8 (j0/4) + 4 hi + j0 % 4 and the next one
         if (!(ZS_B3_SKIP & 4))
           ypair = *reinterpret_cast<const ZS_LDS f2v*>((uintptr_t)(
-              y_addr + (uint32_t)(PK ? (j0 >> 2) * 1024 + (j0 & 3) * 4
-                                     : (8 * (j0 >> 2) + (j0 & 3)) * 4)));
+              y_addr +
+              (uint32_t)(PK ? ((pk_rot + 2 * (j0 >> 2)) & 7) * 16 + (j0 & 3) * 4
+                            : (8 * (j0 >> 2) + (j0 & 3)) * 4)));
       }
       float y0 = ypair[0], y1 = ypair[1];
       const int n0 = 8 * (j0 >> 2) + 4 * hi + (j0 & 3);
@@ -832,7 +885,10 @@ static int launch_b3(const float* W, const unsigned char* Ximg, const float* y,
                      float* ll, float* gW, hipStream_t s, int n_splits,
                      float* workspace, int doc_major, int n_classes = 0) {
   constexpr int kTile = 3 * (D / 32) * 2048;
-  const size_t lds = (size_t)3 * kTile + 3 * (PK ? 16384 : 128);
+  // (PK: four buffers of counts where they are fetched two tiles ahead)
+  const size_t lds =
+      (size_t)3 * kTile +
+      (PK ? (D <= 128 ? ZS_B3_PK_AHEAD + 2 : 3) * 16384 : 3 * 128);
   // accumulator chains of GEMM 1: two cost 16 registers and buy nothing
   // measurable (dependent 32x32x16 MFMAs issue back to back); one where two
   // waves per SIMD need the registers
