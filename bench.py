@@ -966,16 +966,30 @@ def lntm_workload(torch, zs, dev, n_chains, sharding=None, dist=None,
             elapsed, acc = float(tt[0].item()), float(tt[1].item()) / world
         ms = elapsed / n_timed * 1e3
         used = hmc.likelihood_arithmetic_used
-        roof = _lik_roofline(hmc, kern_ms, flop_eval, n_leapfrogs, ms,
-                             'multinomial')
+        # the vocabulary rows an evaluation really runs over: all of them, or
+        # -- one document per workgroup on the bf16x3 kernel -- the mean length
+        # of the documents' own (padded) word lists
+        n_run = int(getattr(hmc._plan, 'n_inner_run', n_vocab))
+        own = getattr(hmc._plan, 'obs_sp', None) is not None
+        roof = _lik_roofline(hmc, kern_ms, flop_eval * n_run / n_vocab,
+                             n_leapfrogs, ms, 'multinomial')
         roof['note'] = 'per GPU (rank 0): one launch covers this rank\'s rows'
-        if full5:
+        if own:
+            roof['kernel'] = roof['kernel'].replace(
+                'multinomial', 'multinomial, own vocabulary')
+            roof['note'] += (
+                '; flops counted over the documents\' OWN vocabularies (%d of '
+                '%d words per document on average, padded to whole tiles): '
+                'words with a zero count contribute exactly nothing and are '
+                'not run' % (n_run, n_vocab))
+        if full5 and not own:
             roof['traffic'], roof['traffic_source'] = _recorded_mfma_traffic(
                 'multinomial bf16x3 grad-only' if used == 'bf16x3' else
                 'multinomial grad-only')
         r = {
             'likelihood_arithmetic_used': used,
             'arithmetic_reason': hmc.arithmetic_reason,
+            'own_vocabulary': own, 'vocabulary_rows_run': n_run,
             'plan': hmc.plan_kind,
             'ms_per_step': ms, 'steps': n_timed,
             'value': rows * n_leapfrogs / (ms * 1e-3),

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ZSHMC_VERSION 510 /* 0.5.1: + packed rows in the bf16x3 multinomial kernel, zshmc_bf16x3_multinomial_rows_packed (0.5.0: the bf16x3 likelihood kernels, zshmc_model_plan.inner_image) */
+#define ZSHMC_VERSION 600 /* 0.6.0: + the documents' own vocabularies in the bf16x3 multinomial kernel (zshmc_linear_multinomial_log_lik_bf16x3_sparse, zshmc_model_plan.obs_sp_*); 0.5.1: packed rows, zshmc_bf16x3_multinomial_rows_packed; 0.5.0: the bf16x3 likelihood kernels, zshmc_model_plan.inner_image */
 
 /* status codes */
 #define ZSHMC_OK 0
@@ -562,6 +562,13 @@ typedef struct zshmc_model_plan {
   int64_t gd_n_seg, gd_n_long;
   const int32_t* gd_idx_other_csr;
   const float* gd_obs_csr;
+  /* ABI 0.6.0, mixture multinomial with inner_image: the documents' OWN
+   * vocabularies (zshmc_linear_multinomial_log_lik_bf16x3_sparse) -- compacted
+   * counts, the words' rows of phi^T, [obs_rows + 1] offsets; obs_sp_rows
+   * NULL: the dense counts in `obs` */
+  const float* obs_sp_counts;
+  const int32_t* obs_sp_rows;
+  const int64_t* obs_sp_off;
 } zshmc_model_plan;
 
 /*   iteration_first   Philox iteration word of the first transition
@@ -711,6 +718,22 @@ int zshmc_linear_multinomial_log_lik_bf16x3(
     int64_t count_rows, int64_t count_stride, int64_t n_rows, int64_t n_vocab,
     int64_t n_topics, float* log_lik, float* grad_theta, int n_splits,
     float* workspace, void* stream);
+/* ABI 0.6.0 -- the same likelihood over the documents' OWN vocabularies.  A
+ * bag of words is sparse (lntm_mcem.py's corpus: ~1 000 tokens over 12 419
+ * words) and a word a document does not contain contributes exactly nothing
+ * to multivariate.py:435-443 (x = 0: 0 * log S, d/dS = 0): a workgroup -- 128
+ * chains of ONE document, rows chain * count_rows + doc -- runs its tile loop
+ * over that document's nonzero words only, gathering their rows of the
+ * phi^T image.  Document d's words are slots doc_offsets[d] ..
+ * doc_offsets[d + 1] (a multiple of 32, >= 32: padded with count 0 / row 0)
+ * of counts_csr (the counts) and row_index (rows of phi^T, < n_vocab).
+ * Same results as the dense form up to summation order; n_splits cuts every
+ * document's word list. */
+int zshmc_linear_multinomial_log_lik_bf16x3_sparse(
+    const float* theta, const void* phi_image, const float* counts_csr,
+    const int32_t* row_index, const int64_t* doc_offsets, int64_t count_rows,
+    int64_t n_rows, int64_t n_vocab, int64_t n_topics, float* log_lik,
+    float* grad_theta, int n_splits, float* workspace, void* stream);
 /* (declared here, described with zshmc_linear_categorical_log_lik below:
  * W rows are (chain, class) pairs at `class_stride` rows per chain) */
 int zshmc_linear_categorical_log_lik_bf16x3(

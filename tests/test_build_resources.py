@@ -362,10 +362,10 @@ def b3_build(tmp_path_factory):
 
 
 def _b3_bodies(asm):
-    """name -> text of each linear_b3_kernel<D, OP, LL, NACC, GL, PK>."""
+    """name -> text of each linear_b3_kernel<D, OP, LL, NACC, GL, PK, SP>."""
     out = {}
     for m in re.finditer(r'^(_ZN5zshmc16linear_b3_kernelILi\d+ELi\dELb[01]E'
-                         r'Li\dELi\dELb[01]EEE\w+):[^\n]*\n(.*?)s_endpgm', asm,
+                         r'Li\dELi\dELb[01]ELb[01]EEE\w+):[^\n]*\n(.*?)s_endpgm', asm,
                          re.S | re.M):
         out[m.group(1)] = m.group(2)
     return out
@@ -383,10 +383,12 @@ def test_bf16x3_kernels_keep_their_registers_and_occupancy(b3_build):
     # Categorical at class strides 1 .. 32) + the packed-rows multinomial
     # (PK: 64 / 128 / 192 columns; 48 KB of counts in the LDS: one workgroup
     # per CU, so one wave per SIMD is its register budget -- and no spills)
-    assert len(table) == 8 * (2 + 6) + 6, sorted(table)
+    # + the own-vocabulary multinomial (SP: all four widths, the occupancy
+    # of the dense form)
+    assert len(table) == 8 * (2 + 6) + 6 + 8, sorted(table)
     for name, row in table.items():
         width = int(re.search(r'kernelILi(\d+)E', name).group(1))
-        packed = re.search(r'ELb1EEE', name) is not None
+        packed = re.search(r'ELb1ELb0EEE', name) is not None
         if packed:
             assert re.search(r'kernelILi\d+ELi1ELb', name) and width <= 192, \
                 name                                        # OP 1 only
@@ -399,7 +401,7 @@ def test_bf16x3_kernels_keep_their_registers_and_occupancy(b3_build):
             assert row['VGPRs Spill'] == 0, (name, row)
         assert row['VGPRs Spill'] <= 12, (name, row)
     bodies = _b3_bodies(asm)
-    assert len(bodies) == 70
+    assert len(bodies) == 78
     for name, body in bodies.items():
         # the tile loop: the backward branch with the most MFMAs in its body
         loops = []

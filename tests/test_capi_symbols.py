@@ -90,7 +90,7 @@ def test_ctypes_table_matches_header(lib):
 
 
 def test_version_and_limits_callable_without_gpu(lib):
-    assert lib.zshmc_version() == 510
+    assert lib.zshmc_version() == 600
     assert lib.zshmc_fused_max_n_data() == 2048
     assert lib.zshmc_last_error() is not None
 

@@ -307,6 +307,75 @@ def test_multinomial_packed_rows_match_float64_reference(env, n_chains, n_docs,
                                    atol=2e-6 * (np.abs(g_ref).max() + 1))
 
 
+@pytest.mark.parametrize('n_chains,n_docs,V,K,n_splits,rate', [
+    (128, 3, 500, 64, 1, 0.3), (130, 2, 333, 128, 1, 0.05),
+    (64, 1, 1000, 128, 1, 0.1), (256, 2, 1241, 128, 3, 0.08),
+    (40, 3, 100, 192, 1, 0.3), (5, 7, 77, 256, 1, 0.5),
+    (128, 4, 12419, 128, 4, 0.08), (256, 3, 2000, 256, 2, 0.02)])
+@pytest.mark.parametrize('want_ll', [True, False])
+def test_multinomial_own_vocabulary_matches_float64_reference(
+        env, n_chains, n_docs, V, K, n_splits, rate, want_ll):
+    """ABI 0.6.0: one document per workgroup, the tile loop over the
+    document's OWN vocabulary (words with a zero count contribute exactly
+    nothing): tiles gathered from the phi^T image through per-lane DMA
+    offsets.  Documents without words, documents that use every word, word
+    lists that are not whole tiles, row-range slices -- against float64 and
+    against the dense form of the same kernel."""
+    torch, _capi, dev = env
+    from zhusuan_amd import _ops
+    theta, phi, _ = _mult_data(n_chains, n_docs, V, K, seed=V + K + n_docs)
+    rng = np.random.RandomState(V + n_docs)
+    x = rng.poisson(rate, size=(n_docs, V)).astype(np.float32)
+    if n_docs > 1:
+        x[-1] = 0.0                      # a document without words
+    if n_docs > 2:
+        x[1] = 1.0 + rng.poisson(1.0, size=V)     # ... and one with all of them
+    R = n_chains * n_docs
+    th = torch.tensor(theta, device=dev)
+    pt = torch.tensor(np.ascontiguousarray(phi.T), device=dev)   # [V, K]
+    xt = torch.tensor(x, device=dev)
+    img = _image(torch, _capi, pt, K)
+    vals, rows, off, total = _ops.counts_csr(xt)
+    assert total % 32 == 0 and off.shape[0] == n_docs + 1
+    lens = (off[1:] - off[:-1]).cpu().numpy()
+    assert (lens % 32 == 0).all() and (lens >= 32).all()
+    assert int(rows.max()) < V and float(vals.sum()) == float(x.sum())
+    ws = torch.empty(n_splits * R * (K + 1), device=dev) if n_splits > 1 \
+        else None
+    out = []
+    for rep in range(2):
+        ll = torch.full((R,), float('nan'), device=dev) if want_ll else None
+        g = torch.full((R, K), float('nan'), device=dev)
+        _capi.call('zshmc_linear_multinomial_log_lik_bf16x3_sparse',
+                   th.data_ptr(), img.data_ptr(), vals.data_ptr(),
+                   rows.data_ptr(), off.data_ptr(), n_docs, R, V, K,
+                   _capi.ptr(ll), g.data_ptr(), n_splits, _capi.ptr(ws),
+                   _capi.current_stream())
+        torch.cuda.synchronize()
+        out.append((None if ll is None else ll.cpu().numpy(),
+                    g.cpu().numpy()))
+    np.testing.assert_array_equal(out[0][1], out[1][1])        # bit-stable
+    ll_ref, g_ref = _mult_ref(theta, phi, x, n_docs)
+    if want_ll:
+        np.testing.assert_array_equal(out[0][0], out[1][0])
+        np.testing.assert_allclose(out[0][0], ll_ref, rtol=2e-5,
+                                   atol=2e-5 * V)
+    np.testing.assert_allclose(out[0][1], g_ref, rtol=1e-4,
+                               atol=2e-5 * (np.abs(g_ref).max() + 1))
+    # the dense form of the same kernel on the same operands
+    s4 = (V + 3) // 4 * 4
+    xp = np.zeros((n_docs, s4), np.float32)
+    xp[:, :V] = x
+    x4 = torch.tensor(xp, device=dev)
+    g4 = torch.full((R, K), float('nan'), device=dev)
+    _capi.call('zshmc_linear_multinomial_log_lik_bf16x3', th.data_ptr(),
+               img.data_ptr(), x4.data_ptr(), n_docs, s4, R, V, K, None,
+               g4.data_ptr(), n_splits, _capi.ptr(ws), _capi.current_stream())
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out[0][1], g4.cpu().numpy(), rtol=2e-5,
+                               atol=2e-6 * (np.abs(g_ref).max() + 1))
+
+
 # ---- Categorical (OP 2): rows of W are (chain, class) pairs ----------------
 def _cat_ref(w, X, y):
     """ll [C], d ll / d w [C, K, F] in float64 (univariate.py:496-548 on

@@ -100,7 +100,9 @@ class ModelPlan(Structure):
         ('gd_seg_ptr', c_void_p), ('gd_seg_row', c_void_p),
         ('gd_seg_first', c_void_p), ('gd_long_rows', c_void_p),
         ('gd_n_seg', c_int64), ('gd_n_long', c_int64),
-        ('gd_idx_other_csr', c_void_p), ('gd_obs_csr', c_void_p)]
+        ('gd_idx_other_csr', c_void_p), ('gd_obs_csr', c_void_p),
+        ('obs_sp_counts', c_void_p), ('obs_sp_rows', c_void_p),
+        ('obs_sp_off', c_void_p)]
 
 
 BCAST_FULL = 0
@@ -224,6 +226,9 @@ PROTOTYPES = {
     'zshmc_linear_bernoulli_log_lik_bf16x3': (c_int, [
         _p, _p, _p, c_int64, c_int64, c_int64, _p, _p, c_int, _p, _p]),
     'zshmc_bf16x3_multinomial_rows_packed': (c_int, [c_int64, c_int64]),
+    'zshmc_linear_multinomial_log_lik_bf16x3_sparse': (c_int, [
+        _p, _p, _p, _p, _p, c_int64, c_int64, c_int64, c_int64, _p, _p, c_int,
+        _p, _p]),
     'zshmc_linear_multinomial_log_lik_bf16x3': (c_int, [
         _p, _p, _p, c_int64, c_int64, c_int64, c_int64, c_int64, _p, _p,
         c_int, _p, _p]),

@@ -316,6 +316,7 @@ def clear_caches():
     _csr_cache.clear()
     _image_cache.clear()
     _label_cache.clear()
+    _counts_csr_cache.clear()
 
 
 def _storages(x, out):
@@ -335,7 +336,7 @@ def forget(tensors):
     nothing about ITS model's tensors is remembered."""
     gone = _storages(list(tensors), set())
     caches = (_x_cache, _design_cache, _phi_cache, _counts_cache, _csr_cache,
-              _image_cache, _label_cache)
+              _image_cache, _label_cache, _counts_csr_cache)
     again = True
     while again:
         again = False
@@ -645,6 +646,10 @@ BF16X3_REQUIRE_FILL = True
 # consecutive (chain, document) rows per workgroup, each with its own counts
 # row): <= 192 topics, counts rows padded to 32 floats, counts below 4 GB
 BF16X3_PACKED_MAX_WIDTH = 192
+# The one-document-per-workgroup form runs over the document's OWN vocabulary
+# (ABI 0.6.0: words with a zero count contribute exactly nothing) when the
+# padded word lists are at most this share of the dense [documents, V] counts
+BF16X3_SPARSE_MAX_FILL = 0.6
 # likelihood_arithmetic='auto' (the default) takes them from this many flop
 # per evaluation (4 N D R over all ranks' rows) on: ~0.1 ms of the fp32 matrix
 # peak.  Below, a transition is bound by its kernels' critical paths and the
@@ -888,6 +893,41 @@ def _padded_counts(x, multiple=4):
     xp[:, :v] = x.detach().reshape(-1, v)
     _counts_cache['x'] = (key, xp, x)
     return xp, vp
+
+
+_counts_csr_cache = _Lru(2)
+
+
+def counts_csr(x):
+    """The documents' OWN vocabularies for
+    zshmc_linear_multinomial_log_lik_bf16x3_sparse: counts [R0, V] ->
+    (compacted counts float32 [n], the words' rows int32 [n], offsets int64
+    [R0 + 1], n) with every document's slice padded to whole 32-row tiles (at
+    least one) by count 0 / row 0.  Built once per tensor version (one host
+    read: the total)."""
+    key = _tensor_key(x)
+    hit = _counts_csr_cache.get(key)
+    if hit is not None:
+        return hit
+    v = x.shape[-1]
+    xf = x.detach().reshape(-1, v).to(_F32)
+    nz = xf != 0
+    cnt = nz.sum(1)
+    pad = torch.clamp((cnt + 31) // 32 * 32, min=32)
+    off = torch.zeros(xf.shape[0] + 1, dtype=torch.int64, device=x.device)
+    off[1:] = torch.cumsum(pad, 0)
+    total = int(off[-1].item())
+    vals = torch.zeros(total, dtype=_F32, device=x.device)
+    rows = torch.zeros(total, dtype=torch.int32, device=x.device)
+    d_idx, v_idx = nz.nonzero(as_tuple=True)          # row-major order
+    start = torch.cumsum(cnt, 0) - cnt
+    pos = off[:-1][d_idx] + (torch.arange(d_idx.numel(), device=x.device) -
+                             start[d_idx])
+    vals[pos] = xf[d_idx, v_idx]
+    rows[pos] = v_idx.to(torch.int32)
+    out = (vals, rows, off, total)
+    _counts_csr_cache.put(key, out, x)
+    return out
 
 
 class MixtureMultinomialLogLik(_Function):

@@ -252,12 +252,30 @@ constexpr int kLastUse[3] = {2, 4, 5};
 // tile) and a counts matrix below 4 GB (32-bit lane offsets); three tile
 // buffers + 48 KB (64 KB at D <= 128) fit the LDS up to D = 192, one workgroup
 // per CU.
-template <int D, int OP, bool LL, int NACC, int GL = 0, bool PK = false>
+// SP (OP 1, one document per workgroup): the document's OWN vocabulary.  A
+// bag of words is sparse -- ~1 000 tokens over 12 419 words in lntm_mcem.py's
+// corpus -- and a word the document does not contain contributes exactly
+// nothing (x = 0: r = x / S = 0, 0 * log S = 0; multivariate.py:435-443).  The
+// tile loop therefore runs over the document's nonzero words only: `y` is the
+// compacted counts, `sp_rows` the words' rows of phi^T, both at sp_off[doc]
+// .. sp_off[doc + 1] (padded to whole tiles with count 0 / row 0).  A tile is
+// GATHERED: the image is 16-byte chunks and global_load_lds takes a per-lane
+// global offset, so lane l of a 1 KB piece fetches the chunk that belongs at
+// its place -- row sp_rows[32 t + m'] of the image, m' the tile row of the
+// LDS chunk, the swizzle of b3_chunk re-applied for the source row's position
+// in ITS tile.  The 32 row indices of tile t + 2 travel into a small LDS ring
+// with the labels of tile t + 1; two lane offsets per tile (a piece is half a
+// 2 KB block: 16 of its 32 rows) are all the state.  Same MFMA schedule.
+template <int D, int OP, bool LL, int NACC, int GL = 0, bool PK = false,
+          bool SP = false>
 __global__ __launch_bounds__(256, PK ? 1 : ZS_B3_WAVES(D)) void linear_b3_kernel(
     const float* __restrict__ W, const unsigned char* __restrict__ Ximg,
     const float* __restrict__ y, int64_t yc_rows, int64_t ldy, int64_t C,
-    int64_t N, int64_t ldw, float* __restrict__ ll, float* __restrict__ gW,
-    int doc_major, int n_classes) {
+    int64_t N_arg, int64_t ldw, float* __restrict__ ll, float* __restrict__ gW,
+    int doc_major, int n_classes, const int32_t* __restrict__ sp_rows,
+    const int64_t* __restrict__ sp_off) {
+  static_assert(!SP || (OP == 1 && !PK), "own vocabulary: one document per "
+                                         "workgroup, multinomial");
   static_assert(D % 32 == 0 && D >= 32 && D <= 256, "32 .. 256 features");
   static_assert(NACC == 1 || NACC == 2, "accumulator chains of GEMM 1");
   static_assert(!PK || (OP == 1 && D <= 192), "packed rows: multinomial, LDS");
@@ -285,6 +303,7 @@ __global__ __launch_bounds__(256, PK ? 1 : ZS_B3_WAVES(D)) void linear_b3_kernel
   // [3][kTile] tiles, [3][32] labels (PK: [3][4 waves][4 groups][64 lanes][4])
   const uint32_t sx_addr = (uint32_t)reinterpret_cast<uintptr_t>(smem);
   const uint32_t sy_addr = sx_addr + 3 * kTile;
+  const uint32_t sr_addr = sy_addr + kYN * kYBuf;   // SP: [4][32] row indices
   auto y_slot = [&](int t) -> uint32_t {    // PK: tile t (local index)
     return (uint32_t)((t % kYN) * kYBuf);
   };
@@ -299,7 +318,7 @@ __global__ __launch_bounds__(256, PK ? 1 : ZS_B3_WAVES(D)) void linear_b3_kernel
   int64_t row_base = (int64_t)blockIdx.x * kB3Chains, row_stride = 1;
   int64_t n_valid = C - row_base;
   int64_t doc = 0;
-  if (OP == 1 && !PK && doc_major) {
+  if (OP == 1 && !PK && (doc_major || SP)) {
     const int64_t grp = blockIdx.x / yc_rows;
     doc = blockIdx.x % yc_rows;
     row_base = grp * kB3Chains * yc_rows + doc;
@@ -311,7 +330,12 @@ __global__ __launch_bounds__(256, PK ? 1 : ZS_B3_WAVES(D)) void linear_b3_kernel
     return row_base + (int64_t)(i < n_valid ? i : (int)n_valid - 1) * row_stride;
   };
   // labels (OP 0) / the document's counts (OP 1) of the data rows
-  const float* ysrc = uniform_ptr(OP == 1 && !PK ? y + doc * ldy : y);
+  // SP: this document's slice of the compacted counts / row indices
+  const int64_t sp0 = SP ? sp_off[doc] : 0;
+  const int64_t N = SP ? sp_off[doc + 1] - sp0 : N_arg;   // whole tiles
+  const int32_t* rsrc = SP ? uniform_ptr(sp_rows + sp0) : nullptr;
+  const float* ysrc = uniform_ptr(
+      SP ? y + sp0 : (OP == 1 && !PK ? y + doc * ldy : y));
   // PK: byte offsets of this lane's share of the four counts DMAs of a tile.
   // DMA g brings chains 8 g .. 8 g + 7 of the wave, EIGHT CONSECUTIVE LANES a
   // chain's whole 128-byte line (32 rows) -- one request to the texture path
@@ -374,14 +398,52 @@ __global__ __launch_bounds__(256, PK ? 1 : ZS_B3_WAVES(D)) void linear_b3_kernel
   // ---- DMA: a tile is 4 x kDma linear KBs, wave w moves its quarter --------
   const uint32_t voff = (uint32_t)lane * 16u;
   const unsigned char* xsrc =   // this wave's quarter of the first tile
-      uniform_ptr(Ximg + t_first * (int64_t)kTile + wave * (kTile / 4));
+      SP ? uniform_ptr(Ximg + wave * (kTile / 4) - 1024)  // (see sp_voff)
+         : uniform_ptr(Ximg + t_first * (int64_t)kTile + wave * (kTile / 4));
   const uint32_t dst_wave = sx_addr + (uint32_t)(wave * (kTile / 4));
+  // SP: the lane offsets of the tile being fetched.  Piece i of this wave is
+  // half b = (wave * kDma + i) & 1 of a 2 KB block: LDS chunk c' = 64 b + lane
+  // = tile row m' = 4 (c' / 16) + c' % 4, slot column q' = (c' / 4) % 4, i.e.
+  // feature group hp = 2 h + par = (q' - m' / 8) mod 4 (b3_chunk).  Its data
+  // is chunk (m_s / 4) * 16 + 4 ((hp + m_s / 8) mod 4) + m_s % 4 of the same
+  // block of image tile r / 32, m_s = r % 32, r the word's row.  The offset
+  // carries + 1024 - 1024 b (the base is 1 KB low) so that it stays >= 0.
+  uint32_t sp_v[2] = {0u, 0u};            // [b ^ first_half]: pieces i even / odd
+  const int sp_first = (wave * kDma) & 1;
+  auto sp_voff = [&](int r, int b) -> uint32_t {
+    const int c = 64 * b + lane;
+    const int mp = 4 * (c >> 4) + (c & 3);
+    const int hp = (((c >> 2) & 3) - (mp >> 3)) & 3;
+    const int ms = r & 31;
+    const int chunk = (ms >> 2) * 16 + 4 * ((hp + (ms >> 3)) & 3) + (ms & 3);
+    return (uint32_t)((r >> 5) * kTile + chunk * 16 + 1024 - 1024 * b);
+  };
+  // tile row of this lane's chunk in half b (what sp_voff calls m')
+  auto sp_row = [&](int b) -> int {
+    const int c = 64 * b + lane;
+    return 4 * (c >> 4) + (c & 3);
+  };
   auto dma_piece = [&](auto ic, const unsigned char* src, uint32_t dst) {
     constexpr int i = decltype(ic)::value;
     // (the immediate offset -- added to the global address AND to the LDS
     // address -- reaches 4 KB: a fresh pair of bases every fourth piece)
     b3_dma<(i & 3) * 1024>(src + (i >> 2) * 4096,
-                           dst + (uint32_t)((i >> 2) * 4096), voff);
+                           dst + (uint32_t)((i >> 2) * 4096),
+                           SP ? sp_v[i & 1] : voff);
+  };
+  // SP: the 32 row indices of a tile -> ring slot (8-lane DMA like the labels)
+  auto dma_rows = [&](int64_t tile, int slot) {
+    const uint32_t off = (uint32_t)(wave * 8 + (lane & 7)) * 4u;
+    const int32_t* src = uniform_ptr(rsrc + tile * kB3Rows);
+    asm volatile(
+        "s_mov_b32 m0, %2\n\t"
+        "s_bfm_b64 exec, 8, 0\n\t"
+        "global_load_lds_dword %0, %1\n\t"
+        "s_mov_b64 exec, -1"
+        :
+        : "v"(off), "s"(src),
+          "s"(sr_addr + (uint32_t)((slot & 3) * 128 + wave * 32))
+        : "memory");
   };
   // the tile's 32 labels: wave w brings rows 8 w .. 8 w + 7 (8-lane DMA),
   // clamped to the last row of X (masked / met by zero rows of the image)
@@ -453,8 +515,19 @@ __global__ __launch_bounds__(256, PK ? 1 : ZS_B3_WAVES(D)) void linear_b3_kernel
   uint32_t y_cur = 0, y_prev = 2 * kYBuf, y_next = kYBuf;
 
   // prologue: tile 0 -> buffer 0
+  // (SP: the row indices of the first two tiles by plain loads -- the ring
+  // is fed from iteration 0 on -- tile 0's offsets now, tile 1's behind its DMA)
+  auto sp_load = [&](int64_t tile) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int b = (sp_first + k) & 1;
+      sp_v[k] = sp_voff(rsrc[tile * kB3Rows + sp_row(b)], b);
+    }
+  };
+  if constexpr (SP) sp_load(t_first);
   static_for<kDma>([&](auto ic) { dma_piece(ic, xsrc, dst_wave + b_cur); });
   dma_labels(t_first, sy_addr + y_cur);
+  if constexpr (SP) sp_load(t_first + (T > 1 ? 1 : 0));
   if constexpr (PK && kYAhead > 1) {  // (past the last tile: clamped, harmless)
 #pragma unroll
     for (int a = 1; a < kYAhead; ++a)
@@ -486,6 +559,8 @@ __global__ __launch_bounds__(256, PK ? 1 : ZS_B3_WAVES(D)) void linear_b3_kernel
   const unsigned char* src_next = xsrc;
   uint32_t dst_next = dst_wave;
   int64_t lab_next = t_first;
+  int64_t row_next = t_first;   // SP: the tile whose row indices go out next
+  int row_slot = 0;
 
   // ---- the boundary between two iterations (placed in front of the last
   // MFMAs of the iteration that ends): this wave's DMA of tile it+1 has
@@ -524,9 +599,24 @@ __global__ __launch_bounds__(256, PK ? 1 : ZS_B3_WAVES(D)) void linear_b3_kernel
   // harmless re-load) and its labels
   auto plan_dma = [&](int it) {
     const int nxt = it + 1 < T ? it + 1 : T - 1;
-    src_next = xsrc + (int64_t)nxt * kTile;
+    src_next = SP ? xsrc : xsrc + (int64_t)nxt * kTile;
     dst_next = dst_wave + b_next;
     lab_next = t_first + nxt;
+    if constexpr (SP) {
+      // the rows of tile `nxt` came into ring slot it + 1 during iteration
+      // it - 1 (iteration 0: by the prologue's plain loads)
+      if (it > 0) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int b = (sp_first + k) & 1;
+          const int r = *reinterpret_cast<const ZS_LDS int*>((uintptr_t)(
+              sr_addr + (uint32_t)(((it + 1) & 3) * 128 + sp_row(b) * 4)));
+          sp_v[k] = sp_voff(r, b);
+        }
+      }
+      row_next = t_first + (it + 2 < T ? it + 2 : T - 1);
+      row_slot = it + 2;
+    }
     if constexpr (PK) {       // the counts of tile it + kYAhead, into its slot
       const int far = it + kYAhead < T ? it + kYAhead : T - 1;
       lab_next = t_first + far;
@@ -675,6 +765,7 @@ __global__ __launch_bounds__(256, PK ? 1 : ZS_B3_WAVES(D)) void linear_b3_kernel
       if (!(ZS_B3_SKIP & 2)) dma_piece(ic, src_next, dst_next);
     } else if constexpr (i == kDma) {
       if (!(ZS_B3_SKIP & 4)) dma_labels(lab_next, sy_addr + y_next);
+      if constexpr (SP) dma_rows(row_next, row_slot);
     }
   };
 
@@ -879,24 +970,27 @@ __global__ __launch_bounds__(256, PK ? 1 : ZS_B3_WAVES(D)) void linear_b3_kernel
 int lb_reduce_splits(const float* ws, int64_t C, int64_t ldw, int S, float* ll,
                      float* gW, hipStream_t s);
 
-template <int D, int OP, int GL = 0, bool PK = false>
+template <int D, int OP, int GL = 0, bool PK = false, bool SP = false>
 static int launch_b3(const float* W, const unsigned char* Ximg, const float* y,
                      int64_t yc_rows, int64_t ldy, int64_t C, int64_t N,
                      float* ll, float* gW, hipStream_t s, int n_splits,
-                     float* workspace, int doc_major, int n_classes = 0) {
+                     float* workspace, int doc_major, int n_classes = 0,
+                     const int32_t* sp_rows = nullptr,
+                     const int64_t* sp_off = nullptr) {
   constexpr int kTile = 3 * (D / 32) * 2048;
   // (PK: four buffers of counts where they are fetched two tiles ahead)
   const size_t lds =
       (size_t)3 * kTile +
-      (PK ? (D <= 128 ? ZS_B3_PK_AHEAD + 2 : 3) * 16384 : 3 * 128);
+      (PK ? (D <= 128 ? ZS_B3_PK_AHEAD + 2 : 3) * 16384 : 3 * 128) +
+      (SP ? 4 * 128 : 0);
   // accumulator chains of GEMM 1: two cost 16 registers and buy nothing
   // measurable (dependent 32x32x16 MFMAs issue back to back); one where two
   // waves per SIMD need the registers
 #ifndef ZS_B3_NACC
 #define ZS_B3_NACC(D) ((D) <= 128 ? 1 : 2)
 #endif
-  auto kll = linear_b3_kernel<D, OP, true, ZS_B3_NACC(D), GL, PK>;
-  auto kg = linear_b3_kernel<D, OP, false, ZS_B3_NACC(D), GL, PK>;
+  auto kll = linear_b3_kernel<D, OP, true, ZS_B3_NACC(D), GL, PK, SP>;
+  auto kg = linear_b3_kernel<D, OP, false, ZS_B3_NACC(D), GL, PK, SP>;
   static bool attr = false;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute(
@@ -918,10 +1012,12 @@ static int launch_b3(const float* W, const unsigned char* Ximg, const float* y,
   const dim3 grid(gx, S);
   if (ll)
     hipLaunchKernelGGL(kll, grid, dim3(256), lds, s, W, Ximg, y, yc_rows, ldy,
-                       C, N, (int64_t)D, ll_out, g_out, doc_major, n_classes);
+                       C, N, (int64_t)D, ll_out, g_out, doc_major, n_classes,
+                       sp_rows, sp_off);
   else
     hipLaunchKernelGGL(kg, grid, dim3(256), lds, s, W, Ximg, y, yc_rows, ldy, C,
-                       N, (int64_t)D, ll_out, g_out, doc_major, n_classes);
+                       N, (int64_t)D, ll_out, g_out, doc_major, n_classes, sp_rows,
+                       sp_off);
   ZS_LAUNCH_CHECK("linear_b3_kernel launch");
   if (S > 1) return lb_reduce_splits(workspace, C, (int64_t)D, S, ll, gW, s);
   return ZSHMC_OK;

@@ -68,6 +68,11 @@ int likelihood(const zshmc_model_plan& m, const float* q, bool want_ll,
       return zshmc_linear_bernoulli_log_lik_bf16x3(
           w, m.inner_image, m.obs, m.n_chains, m.n_inner, m.width, ll, grad_out,
           m.n_splits, ws, s);
+    if (m.kind == ZSHMC_PLAN_MIXTURE_MULTINOMIAL && m.obs_sp_rows)
+      return zshmc_linear_multinomial_log_lik_bf16x3_sparse(
+          w, m.inner_image, m.obs_sp_counts, m.obs_sp_rows, m.obs_sp_off,
+          m.obs_rows, m.n_chains, m.n_inner, m.width, ll, grad_out, m.n_splits,
+          ws, s);
     if (m.kind == ZSHMC_PLAN_MIXTURE_MULTINOMIAL)
       return zshmc_linear_multinomial_log_lik_bf16x3(
           w, m.inner_image, m.obs, m.obs_rows, m.obs_stride, m.n_chains,

@@ -197,3 +197,42 @@ extern "C" int zshmc_linear_multinomial_log_lik_bf16x3(
                                n_splits, workspace, dm);
   }
 }
+
+extern "C" int zshmc_linear_multinomial_log_lik_bf16x3_sparse(
+    const float* theta, const void* phi_image, const float* counts_csr,
+    const int32_t* row_index, const int64_t* doc_offsets, int64_t count_rows,
+    int64_t n_rows, int64_t n_vocab, int64_t n_topics, float* log_lik,
+    float* grad_theta, int n_splits, float* workspace, void* stream) {
+  if (n_rows == 0) return ZSHMC_OK;
+  ZS_REQUIRE(theta && phi_image && counts_csr && row_index && doc_offsets &&
+                 grad_theta,
+             "zshmc_linear_multinomial_log_lik_bf16x3_sparse: null pointer");
+  ZS_REQUIRE(n_rows > 0 && n_vocab > 0 && count_rows > 0 &&
+                 n_rows % count_rows == 0 && b3_width(n_topics) &&
+                 n_vocab * n_topics * 6 < (1ll << 31),
+             "zshmc_linear_multinomial_log_lik_bf16x3_sparse: bad shape "
+             "(n_topics 64 / 128 / 192 / 256; the image below 2 GB)");
+  ZS_REQUIRE((reinterpret_cast<uintptr_t>(theta) & 15) == 0 &&
+                 (reinterpret_cast<uintptr_t>(phi_image) & 15) == 0 &&
+                 (reinterpret_cast<uintptr_t>(counts_csr) & 3) == 0,
+             "zshmc_linear_multinomial_log_lik_bf16x3_sparse: theta and the "
+             "image must be 16-byte aligned");
+  ZS_REQUIRE(n_splits >= 1 && n_splits <= 256 && (n_splits == 1 || workspace),
+             "zshmc_linear_multinomial_log_lik_bf16x3_sparse: 1 <= n_splits <= "
+             "256 and a workspace of n_splits*n_rows*(n_topics+1) floats when "
+             "> 1");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const unsigned char* img = reinterpret_cast<const unsigned char*>(phi_image);
+#define ZS_SP(D)                                                              \
+  launch_b3<D, 1, 0, false, true>(theta, img, counts_csr, count_rows, 0,      \
+                                  n_rows, n_vocab, log_lik, grad_theta, s,    \
+                                  n_splits, workspace, 1, 0, row_index,       \
+                                  doc_offsets)
+  switch (n_topics) {
+    case 64: return ZS_SP(64);
+    case 128: return ZS_SP(128);
+    case 192: return ZS_SP(192);
+    default: return ZS_SP(256);
+  }
+#undef ZS_SP
+}

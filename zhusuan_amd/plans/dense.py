@@ -219,6 +219,9 @@ class _DenseLikelihoodPlan(_PlanBase):
                         LikelihoodArithmeticWarning, stacklevel=2)
         if self.inner_image is None:
             self.block = self._fp32_block()
+        # (a family may shorten the inner range it really runs over: the topic
+        # model's documents' own vocabularies)
+        n_inner = self._inner_rows_run(n_inner)
         R = self.lik_rows
         # (packed rows: three tile buffers + 48 KB of counts, one per CU)
         per_cu = 1 if self.packed_rows else self._resident_per_cu()
@@ -264,6 +267,11 @@ class _DenseLikelihoodPlan(_PlanBase):
 
     def _fp32_block(self):
         return self._ops.likelihood_plan(self.width)[1]
+
+    def _inner_rows_run(self, n_inner):
+        """Inner rows one evaluation runs over (called once the arithmetic is
+        chosen): all of them, unless the family knows better."""
+        return n_inner
 
     def _resident_per_cu(self):
         return self._ops.resident_per_cu(

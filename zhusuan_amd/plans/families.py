@@ -61,6 +61,7 @@ class _MixtureMultinomialPlan(_DenseLikelihoodPlan):
     softmax = True
     takes_bf16x3 = True
     one_launch_capable = True
+    obs_sp = None          # (compacted counts, rows, offsets) or None
 
     def _layout(self, C, D, ld, f32):
         self.width, self.block = self._ops.likelihood_plan(ld)
@@ -70,6 +71,7 @@ class _MixtureMultinomialPlan(_DenseLikelihoodPlan):
     def _operands(self, inner, obs):
         ops = self._ops
         phi, x = inner[0], obs
+        self._counts_src = x
         self.inner = _aligned16(ops._padded_phi_t(phi, self.width))
         # (rows padded to 32 floats: what the packed-rows form of the
         # bf16x3 kernel wants; the other kernels take any stride)
@@ -82,7 +84,34 @@ class _MixtureMultinomialPlan(_DenseLikelihoodPlan):
     def _chains_per_counts_row(self):
         return self.n_chains // self.obs.shape[0]
 
+    def _inner_rows_run(self, n_inner):
+        # One document per workgroup on the bf16x3 kernel: the tile loop runs
+        # over the document's OWN vocabulary (a bag of words is sparse, and a
+        # word with a zero count contributes exactly nothing:
+        # multivariate.py:435-443) where that is the smaller job
+        ops = self._ops
+        self.obs_sp = None
+        self.n_inner_run = n_inner
+        if self.inner_image is None or self.packed_rows or \
+                n_inner * self.width * 6 >= (1 << 31):
+            return n_inner
+        vals, rows, off, total = ops.counts_csr(self._counts_src)
+        n_docs = self.obs.shape[0]
+        if total <= ops.BF16X3_SPARSE_MAX_FILL * n_docs * n_inner:
+            self.obs_sp = (vals, rows, off)
+            self.n_inner_run = max(32, total // n_docs)
+        return self.n_inner_run
+
     def _evaluate(self, w, q, grad, ll, ll_ptr, ws, stream):
+        if self.inner_image is not None and self.obs_sp is not None:
+            vals, rows, off = self.obs_sp
+            _capi.call('zshmc_linear_multinomial_log_lik_bf16x3_sparse',
+                       w.data_ptr(), self.inner_image.data_ptr(),
+                       vals.data_ptr(), rows.data_ptr(), off.data_ptr(),
+                       self.obs.shape[0], self.n_chains, self.inner.shape[0],
+                       self.width, ll_ptr, grad.data_ptr(), self.splits,
+                       _capi.ptr(ws), stream)
+            return
         name = 'zshmc_linear_multinomial_log_lik'
         inner = self.inner
         if self.inner_image is not None:
@@ -95,6 +124,10 @@ class _MixtureMultinomialPlan(_DenseLikelihoodPlan):
     def _describe(self, d):
         super(_MixtureMultinomialPlan, self)._describe(d)
         d.obs_rows, d.obs_stride = self.obs.shape[0], self.obs_stride
+        if self.inner_image is not None and self.obs_sp is not None:
+            vals, rows, off = self.obs_sp
+            d.obs_sp_counts, d.obs_sp_rows = vals.data_ptr(), rows.data_ptr()
+            d.obs_sp_off = off.data_ptr()
 
 
 class _LinearCategoricalPlan(_DenseLikelihoodPlan):
