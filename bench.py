@@ -1285,6 +1285,8 @@ def summarize_extra(e):
         s['bound'] = roof.get('bound')
     if 'likelihood_arithmetic_used' in e:
         s['arith'] = e['likelihood_arithmetic_used']
+    if e.get('own_vocabulary'):        # topic model: zero-count words not run
+        s['vocab_rows_run'] = e.get('vocabulary_rows_run')
     b3 = e.get('bf16x3')
     if isinstance(b3, dict) and 'ms_per_step' in b3:
         s['bf16x3'] = {'ms_per_step': _short(b3['ms_per_step'])}

@@ -622,3 +622,72 @@ def test_default_arithmetic_and_the_fallback_warning(env):
     with pytest.raises(ValueError, match="'auto', 'fp32' or 'bf16x3'"):
         zs.HMC(likelihood_arithmetic='fp16')
     assert _ops.BF16X3_AUTO_MIN_FLOP == 1.0e10
+
+
+def test_hmc_topic_model_runs_over_the_documents_own_vocabularies(env,
+                                                                  monkeypatch):
+    """A topic model whose chain axis fills one-document workgroups, on the
+    bf16x3 kernel: the plan hands the kernel the documents' OWN vocabularies
+    (sparse bag-of-words counts; ABI 0.6.0) -- through sample_op.run (Python
+    launch loop) and run_many (zshmc_hmc_model_run: the descriptor's obs_sp_*
+    fields) bit for bit, and within float32 summation noise of the dense form
+    of the same kernel and of the fp32 kernel."""
+    torch, _capi, dev = env
+    import zhusuan_amd as zs
+    rng = np.random.RandomState(8)
+    n_chains, n_docs, K, V = 128, 3, 20, 900
+    beta = torch.tensor(rng.normal(size=(K, V)).astype(np.float32), device=dev)
+    x = rng.poisson(0.06, size=(n_docs, V)).astype(np.float32)
+    x[2] = 0.0
+    x_t = torch.tensor(x, device=dev)
+    eta0 = (0.3 * rng.normal(size=(n_chains, n_docs, K))).astype(np.float32)
+    phi = torch.softmax(beta, -1)
+
+    out = {}
+    for mode, arithmetic, fill in (('loop', 'bf16x3', 0.6),
+                                   ('block', 'bf16x3', 0.6),
+                                   ('loop', 'bf16x3', 0.0),
+                                   ('loop', 'fp32', 0.6)):
+        monkeypatch.setattr(zs._ops, 'BF16X3_SPARSE_MAX_FILL', fill)
+        zs._ops.clear_caches()
+
+        @zs.meta_bayesian_net(scope='lntm')
+        def lntm():
+            bn = zs.BayesianNet()
+            eta = bn.normal('eta', torch.zeros(n_docs, K, device=dev),
+                            logstd=0., n_samples=n_chains, group_ndims=1)
+            bn.unnormalized_multinomial(
+                'x', zs.log_mixture(torch.softmax(eta.tensor, -1), phi),
+                normalize_logits=False, dtype=torch.float32)
+            return bn
+        m = lntm()
+        m.log_joint = lambda bn: (bn.cond_log_prob('eta') +
+                                  bn.cond_log_prob('x'))
+        hmc = zs.HMC(step_size=0.02, n_leapfrogs=4, seed=3,
+                     likelihood_arithmetic=arithmetic)
+        eta = torch.tensor(eta0, device=dev)
+        op, info = hmc.sample(m, {'x': x_t}, {'eta': eta})
+        assert hmc.plan_kind == 'mixture_multinomial'
+        assert hmc.likelihood_arithmetic_used == arithmetic
+        own = hmc._plan.obs_sp is not None
+        assert own == (arithmetic == 'bf16x3' and fill > 0), (mode, fill)
+        if own:
+            assert hmc._plan.n_inner_run < V // 4
+        if mode == 'block':
+            op.run_many(3)
+        else:
+            for _ in range(3):
+                op.run()
+        out[(mode, arithmetic, fill)] = (eta.cpu().numpy(),
+                                         info.log_prob.cpu().numpy())
+    a = out[('loop', 'bf16x3', 0.6)]
+    b = out[('block', 'bf16x3', 0.6)]
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+    for other in (out[('loop', 'bf16x3', 0.0)], out[('loop', 'fp32', 0.6)]):
+        close = np.isclose(a[0], other[0], atol=2e-4).reshape(
+            n_chains * n_docs, -1).all(1)
+        assert close.mean() > 0.98       # a borderline accept may flip
+        np.testing.assert_allclose(a[1][close.reshape(a[1].shape)],
+                                   other[1][close.reshape(a[1].shape)],
+                                   rtol=2e-5, atol=2e-3)
