@@ -39,10 +39,10 @@
 
 namespace zshmc {
 
-template <int NV, bool SOFTMAX, int LANES>
+template <int NV, bool SOFTMAX, int LANES, bool PARTS>
 __global__ __launch_bounds__(256) void model_kick_drift_kernel(ModelStepArgs a) {
   // (csrc/model_step.h)
-  model_step_rows<NV, SOFTMAX, LANES>(
+  model_step_rows<NV, SOFTMAX, LANES, PARTS>(
       a, (int64_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64,
       (int64_t)gridDim.x * (blockDim.x / 64));
 }
@@ -131,12 +131,21 @@ static int launch_model_step(const ModelStepArgs& a, bool softmax,
   const int64_t need = (a.n_chains + 4 * kRows - 1) / (4 * kRows);
   const int64_t cap = (int64_t)device_cu_count() * 8;
   const dim3 grid((unsigned)(need < cap ? need : cap)), block(256);
-  if (softmax)
-    hipLaunchKernelGGL((model_kick_drift_kernel<NV, true, LANES>), grid, block,
-                       0, s, a);
+  // (the instantiation with the partial-sum path only where there are
+  // partials: it costs the kernel its occupancy, csrc/model_step.h)
+  const bool parts = a.n_parts > 1;
+  if (softmax && parts)
+    hipLaunchKernelGGL((model_kick_drift_kernel<NV, true, LANES, true>), grid,
+                       block, 0, s, a);
+  else if (softmax)
+    hipLaunchKernelGGL((model_kick_drift_kernel<NV, true, LANES, false>), grid,
+                       block, 0, s, a);
+  else if (parts)
+    hipLaunchKernelGGL((model_kick_drift_kernel<NV, false, LANES, true>), grid,
+                       block, 0, s, a);
   else
-    hipLaunchKernelGGL((model_kick_drift_kernel<NV, false, LANES>), grid, block,
-                       0, s, a);
+    hipLaunchKernelGGL((model_kick_drift_kernel<NV, false, LANES, false>), grid,
+                       block, 0, s, a);
   ZS_LAUNCH_CHECK("model_kick_drift_kernel launch");
   return ZSHMC_OK;
 }

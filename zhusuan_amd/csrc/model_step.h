@@ -65,7 +65,13 @@ __device__ __forceinline__ float group_max(float v) {
 // LANES lanes per row (64, 32 or 16): a wave holds 64 / LANES rows at once.
 // `wave` of `n_waves`: this wave's place among those that share the rows (the
 // launch's grid -- or the persistent trajectory kernel's, csrc/hmc_model_traj.hip).
-template <int NV, bool SOFTMAX, int LANES>
+// PARTS = false: an instantiation without the partial-sum path (a.n_parts <=
+// 1 is the caller's promise).  sum_parts8 keeps 24 16-byte loads in flight;
+// compiled in, it is 216 VGPRs = two waves per SIMD for the whole kernel, and
+// the plain step -- six HBM streams, nothing to add up -- ran at 3.7 TB/s
+// where it had run at 5.5 (round 6: configs[4]'s own-vocabulary likelihood
+// kernel made the step a third of a transition).
+template <int NV, bool SOFTMAX, int LANES, bool PARTS = true>
 __device__ __forceinline__ void model_step_rows(const ModelStepArgs& a,
                                                 const int64_t wave,
                                                 const int64_t n_waves) {
@@ -114,9 +120,9 @@ __device__ __forceinline__ void model_step_rows(const ModelStepArgs& a,
         if (a.grad_ready) {
           gl = reinterpret_cast<const m4*>(
               a.grad_ready)[(sub * NV + k) * LANES + lane];
-        } else if (a.n_parts <= 1) {
+        } else if (!PARTS || a.n_parts <= 1) {
           gl = *reinterpret_cast<const m4*>(a.grad_lik + c * a.grad_stride + d);
-        } else {
+        } else if constexpr (PARTS) {
           // (part_stride is a multiple of 4 floats: strides in m4 units)
           gl = sum_parts8(reinterpret_cast<const m4*>(
                               a.grad_lik + c * a.grad_stride + d),
