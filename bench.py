@@ -859,9 +859,10 @@ def extra_estep(torch, zs, dev, n_docs=100, n_topics=100, n_vocab=12419,
         'the reference\'s own loop size: lntm_mcem.py E-step, 1 chain x %d '
         'documents, K=%d (kernel width %d), V=%d, L=%d, fixed step size' % (
             n_docs, n_topics, out['kernel_width'], n_vocab, n_leapfrogs))
-    out['note'] = ('latency-bound by its kernels\' critical paths, not by '
-                   'launches or flops (%.2f TFLOP/s sustained); round 4: 1.2 '
-                   'ms, 32 slices' % out['sustained_tflops'])
+    out['note'] = ('default arithmetic: exact fp32, row by row over each '
+                   'row\'s own words on the vector ALU (csrc/sparse_multinomial'
+                   '.hip; the fp32 MFMA kernel: 0.51 ms, 17 us per likelihood '
+                   'launch whatever the arithmetic); round 4: 1.2 ms')
     # the packed-rows form of the bf16x3 kernel (one 128-row block, 32-row
     # vocabulary tiles) on the same problem, asked for by name
     try:

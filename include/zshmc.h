@@ -565,7 +565,9 @@ typedef struct zshmc_model_plan {
   /* ABI 0.6.0, mixture multinomial with inner_image: the documents' OWN
    * vocabularies (zshmc_linear_multinomial_log_lik_bf16x3_sparse) -- compacted
    * counts, the words' rows of phi^T, [obs_rows + 1] offsets; obs_sp_rows
-   * NULL: the dense counts in `obs` */
+   * NULL: the dense counts in `obs`.  WITHOUT inner_image the same fields
+   * route the evaluations to zshmc_sparse_multinomial_log_lik (row by row,
+   * exact float32: small problems) */
   const float* obs_sp_counts;
   const int32_t* obs_sp_rows;
   const int64_t* obs_sp_off;
@@ -731,6 +733,21 @@ int zshmc_linear_multinomial_log_lik_bf16x3(
  * document's word list. */
 int zshmc_linear_multinomial_log_lik_bf16x3_sparse(
     const float* theta, const void* phi_image, const float* counts_csr,
+    const int32_t* row_index, const int64_t* doc_offsets, int64_t count_rows,
+    int64_t n_rows, int64_t n_vocab, int64_t n_topics, float* log_lik,
+    float* grad_theta, int n_splits, float* workspace, void* stream);
+/* ABI 0.6.0 -- the same likelihood and gradient ROW BY ROW over each row's
+ * own words, in exact float32 on the vector ALU (csrc/sparse_multinomial.hip):
+ * the small-problem form -- lntm_mcem.py:62-70,157-182 runs ONE chain x a
+ * minibatch of 100 documents, 100 rows with a word list each, which the
+ * matrix-core kernels cannot use (a workgroup's chains would have to share a
+ * document) and on which their launch costs 17 us whatever the arithmetic.
+ * Arguments as above with phi_t [n_vocab, n_topics] float32 (n_topics = 64 /
+ * 128 / 192 / 256 padded columns = the row strides of theta, phi_t and the
+ * gradient) instead of the image; a workgroup per (row, slice of its word
+ * list).  Deterministic. */
+int zshmc_sparse_multinomial_log_lik(
+    const float* theta, const float* phi_t, const float* counts_csr,
     const int32_t* row_index, const int64_t* doc_offsets, int64_t count_rows,
     int64_t n_rows, int64_t n_vocab, int64_t n_topics, float* log_lik,
     float* grad_theta, int n_splits, float* workspace, void* stream);

@@ -226,6 +226,9 @@ PROTOTYPES = {
     'zshmc_linear_bernoulli_log_lik_bf16x3': (c_int, [
         _p, _p, _p, c_int64, c_int64, c_int64, _p, _p, c_int, _p, _p]),
     'zshmc_bf16x3_multinomial_rows_packed': (c_int, [c_int64, c_int64]),
+    'zshmc_sparse_multinomial_log_lik': (c_int, [
+        _p, _p, _p, _p, _p, c_int64, c_int64, c_int64, c_int64, _p, _p, c_int,
+        _p, _p]),
     'zshmc_linear_multinomial_log_lik_bf16x3_sparse': (c_int, [
         _p, _p, _p, _p, _p, c_int64, c_int64, c_int64, c_int64, _p, _p, c_int,
         _p, _p]),

@@ -650,6 +650,13 @@ BF16X3_PACKED_MAX_WIDTH = 192
 # (ABI 0.6.0: words with a zero count contribute exactly nothing) when the
 # padded word lists are at most this share of the dense [documents, V] counts
 BF16X3_SPARSE_MAX_FILL = 0.6
+# Small topic models on the exact-fp32 path -- the reference's own loop is ONE
+# chain x a minibatch of 100 documents (lntm_mcem.py:62-70) -- run row by row
+# over each row's own words on the vector ALU (csrc/sparse_multinomial.hip):
+# up to this many (chain, document) rows (beyond, phi^T rows gathered per row
+# out of L2 cost more than the matrix cores' dense tiles) and this fill
+SPARSE_ROWS_MAX = 4096
+SPARSE_ROWS_MAX_FILL = 0.5
 # likelihood_arithmetic='auto' (the default) takes them from this many flop
 # per evaluation (4 N D R over all ranks' rows) on: ~0.1 ms of the fp32 matrix
 # peak.  Below, a transition is bound by its kernels' critical paths and the

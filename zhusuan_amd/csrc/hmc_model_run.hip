@@ -82,6 +82,13 @@ int likelihood(const zshmc_model_plan& m, const float* q, bool want_ll,
           w, m.inner_image, m.obs, m.lik_rows, m.n_inner, m.width, m.n_classes,
           (int)m.groups, ll, grad_out, m.n_splits, ws, s);
   }
+  // a small topic model on the exact-fp32 path: row by row over each row's
+  // own words (csrc/sparse_multinomial.hip)
+  if (m.kind == ZSHMC_PLAN_MIXTURE_MULTINOMIAL && !m.inner_image &&
+      m.obs_sp_rows && grad_out)
+    return zshmc_sparse_multinomial_log_lik(
+        w, m.inner, m.obs_sp_counts, m.obs_sp_rows, m.obs_sp_off, m.obs_rows,
+        m.n_chains, m.n_inner, m.width, ll, grad_out, m.n_splits, ws, s);
   switch (m.kind) {
     case ZSHMC_PLAN_LINEAR_BERNOULLI:
       return zshmc_linear_bernoulli_log_lik(w, m.inner, m.obs, m.n_chains,

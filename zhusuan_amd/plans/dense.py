@@ -225,8 +225,7 @@ class _DenseLikelihoodPlan(_PlanBase):
         R = self.lik_rows
         # (packed rows: three tile buffers + 48 KB of counts, one per CU)
         per_cu = 1 if self.packed_rows else self._resident_per_cu()
-        self.splits = ops._row_splits(R, n_inner, self.device, self.block,
-                                      per_cu)
+        self.splits = self._choose_splits(R, n_inner, per_cu)
         # (chain blocks x slices resident at once where the chain blocks
         # alone are: the trips then run from one cooperative launch)
         n_wg = (R + self.block - 1) // self.block
@@ -272,6 +271,12 @@ class _DenseLikelihoodPlan(_PlanBase):
         """Inner rows one evaluation runs over (called once the arithmetic is
         chosen): all of them, unless the family knows better."""
         return n_inner
+
+    def _choose_splits(self, R, n_inner, per_cu):
+        """Slices of the inner range per likelihood launch (their partials
+        are added by the step / a reduction launch)."""
+        return self._ops._row_splits(R, n_inner, self.device, self.block,
+                                     per_cu)
 
     def _resident_per_cu(self):
         return self._ops.resident_per_cu(

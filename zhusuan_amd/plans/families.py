@@ -62,6 +62,7 @@ class _MixtureMultinomialPlan(_DenseLikelihoodPlan):
     takes_bf16x3 = True
     one_launch_capable = True
     obs_sp = None          # (compacted counts, rows, offsets) or None
+    sparse_rows = False    # csrc/sparse_multinomial.hip runs the likelihood
 
     def _layout(self, C, D, ld, f32):
         self.width, self.block = self._ops.likelihood_plan(ld)
@@ -91,18 +92,60 @@ class _MixtureMultinomialPlan(_DenseLikelihoodPlan):
         # multivariate.py:435-443) where that is the smaller job
         ops = self._ops
         self.obs_sp = None
+        self.sparse_rows = False
         self.n_inner_run = n_inner
-        if self.inner_image is None or self.packed_rows or \
-                n_inner * self.width * 6 >= (1 << 31):
+        n_docs = self.obs.shape[0]
+        if self.inner_image is None:
+            # exact fp32: a SMALL problem (the reference's own E-step: one
+            # chain x 100 documents) runs row by row over each row's own words
+            # on the vector ALU (csrc/sparse_multinomial.hip) -- no tile
+            # pipeline to fill, 8 % of the dense flops
+            if self.width <= 256 and self.lik_rows <= ops.SPARSE_ROWS_MAX:
+                vals, rows, off, total = ops.counts_csr(self._counts_src)
+                if total <= ops.SPARSE_ROWS_MAX_FILL * n_docs * n_inner:
+                    self.obs_sp = (vals, rows, off)
+                    self.sparse_rows = True
+                    self.traj_capacity = 0     # (not in the one-launch kernel)
+                    self.n_inner_run = max(32, total // n_docs)
+            return self.n_inner_run
+        if self.packed_rows or n_inner * self.width * 6 >= (1 << 31):
             return n_inner
         vals, rows, off, total = ops.counts_csr(self._counts_src)
-        n_docs = self.obs.shape[0]
         if total <= ops.BF16X3_SPARSE_MAX_FILL * n_docs * n_inner:
             self.obs_sp = (vals, rows, off)
             self.n_inner_run = max(32, total // n_docs)
         return self.n_inner_run
 
+    def _choose_splits(self, R, n_inner, per_cu):
+        if not self.sparse_rows:
+            return super(_MixtureMultinomialPlan, self)._choose_splits(
+                R, n_inner, per_cu)
+        # a workgroup per (row, slice of its word list): about eight per CU,
+        # slices of at least one 32-word tile; S * R a multiple of 4 (the step adds
+        # the partials itself: csrc/hmc_model_run.hip steps_take_parts)
+        cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+        import os
+        # (E-step, 100 rows x ~960 words, gpurun r06: 6 slices of 160 words
+        # 0.418 ms per transition, 11 x 96 0.334, 21 x 64 0.315, 30 x 32 0.329;
+        # the MFMA kernel 0.509 -- profiles/r06q_*; env knobs for A/B)
+        per_cu = float(os.environ.get('ZSHMC_SPARSE_WG_PER_CU', '8'))
+        min_words = int(os.environ.get('ZSHMC_SPARSE_MIN_WORDS', '32'))
+        want = max(1, min(int(per_cu * cus + R - 1) // R,
+                          n_inner // min_words, 256))
+        for s in range(want, min(want + 4, 257)):
+            if (s * R) % 4 == 0:
+                return s
+        return want
+
     def _evaluate(self, w, q, grad, ll, ll_ptr, ws, stream):
+        if self.sparse_rows:
+            vals, rows, off = self.obs_sp
+            _capi.call('zshmc_sparse_multinomial_log_lik', w.data_ptr(),
+                       self.inner.data_ptr(), vals.data_ptr(),
+                       rows.data_ptr(), off.data_ptr(), self.obs.shape[0],
+                       self.n_chains, self.inner.shape[0], self.width, ll_ptr,
+                       grad.data_ptr(), self.splits, _capi.ptr(ws), stream)
+            return
         if self.inner_image is not None and self.obs_sp is not None:
             vals, rows, off = self.obs_sp
             _capi.call('zshmc_linear_multinomial_log_lik_bf16x3_sparse',
@@ -124,7 +167,9 @@ class _MixtureMultinomialPlan(_DenseLikelihoodPlan):
     def _describe(self, d):
         super(_MixtureMultinomialPlan, self)._describe(d)
         d.obs_rows, d.obs_stride = self.obs.shape[0], self.obs_stride
-        if self.inner_image is not None and self.obs_sp is not None:
+        if self.obs_sp is not None:
+            # (with inner_image: the bf16x3 kernel over the documents' own
+            # vocabularies; without: the row-by-row vector-ALU form)
             vals, rows, off = self.obs_sp
             d.obs_sp_counts, d.obs_sp_rows = vals.data_ptr(), rows.data_ptr()
             d.obs_sp_off = off.data_ptr()
