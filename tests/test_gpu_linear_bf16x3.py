@@ -669,8 +669,11 @@ def test_hmc_topic_model_runs_over_the_documents_own_vocabularies(env,
         op, info = hmc.sample(m, {'x': x_t}, {'eta': eta})
         assert hmc.plan_kind == 'mixture_multinomial'
         assert hmc.likelihood_arithmetic_used == arithmetic
-        own = hmc._plan.obs_sp is not None
+        own = hmc._plan.obs_sp is not None and not hmc._plan.sparse_rows
         assert own == (arithmetic == 'bf16x3' and fill > 0), (mode, fill)
+        # (exact fp32, few rows, sparse counts: the row-by-row vector-ALU form,
+        # tests/test_gpu_sparse_multinomial.py)
+        assert hmc._plan.sparse_rows == (arithmetic == 'fp32')
         if own:
             assert hmc._plan.n_inner_run < V // 4
         if mode == 'block':
