@@ -179,3 +179,46 @@ def test_hmc_small_topic_model_runs_row_by_row(env, monkeypatch):
                                                       -1).all(1)
     assert close.mean() > 0.95, close.mean()       # a borderline accept flips
     np.testing.assert_allclose(a[2], c[2], rtol=1e-3)
+
+
+def test_auto_keeps_a_one_chain_corpus_on_the_row_by_row_kernel(env):
+    """lntm_mcem.py's layout at a size the matrix cores would take (5e10 flop
+    per evaluation): one chain x 8 192 documents.  The bf16x3 alternative is
+    the packed-rows form, which the row-by-row fp32 kernel beats up to ~16 000
+    rows (0.335 against 0.77 ms per launch here): 'auto' stays on exact fp32
+    and says why; 'bf16x3' asked for by name is honoured."""
+    torch, _capi, dev = env
+    import zhusuan_amd as zs
+    g = torch.Generator(device=dev).manual_seed(0)
+    n_docs, K, V = 8192, 128, 12419
+    phi = torch.softmax(torch.randn(K, V, device=dev, generator=g), -1)
+    x = torch.poisson(torch.full((n_docs, V), 0.08, device=dev), generator=g)
+    mean = torch.zeros(n_docs, K, device=dev)
+
+    def sampler(**kw):
+        @zs.meta_bayesian_net(scope='lntm')
+        def lntm():
+            bn = zs.BayesianNet()
+            eta = bn.normal('eta', mean, logstd=0., n_samples=1, group_ndims=1)
+            bn.unnormalized_multinomial(
+                'x', zs.log_mixture(torch.softmax(eta.tensor, -1), phi),
+                normalize_logits=False, dtype=torch.float32)
+            return bn
+        m = lntm()
+        m.log_joint = lambda bn: (bn.cond_log_prob('eta') +
+                                  bn.cond_log_prob('x'))
+        hmc = zs.HMC(step_size=0.01, n_leapfrogs=2, seed=1, **kw)
+        eta = torch.zeros(1, n_docs, K, device=dev)
+        op, info = hmc.sample(m, {'x': x}, {'eta': eta})
+        op.run()
+        assert bool(torch.isfinite(info.log_prob).all())
+        return hmc, info.log_prob.cpu().numpy()
+
+    auto, lp_a = sampler()
+    assert auto.likelihood_arithmetic_used == 'fp32'
+    assert auto._plan.sparse_rows and 'row-by-row' in auto.arithmetic_reason
+    b3, lp_b = sampler(likelihood_arithmetic='bf16x3')
+    assert b3.likelihood_arithmetic_used == 'bf16x3'
+    assert b3._plan.packed_rows and not b3._plan.sparse_rows
+    same = np.isclose(lp_a, lp_b, rtol=2e-5, atol=2e-2)
+    assert same.mean() > 0.99            # (a borderline accept may flip)

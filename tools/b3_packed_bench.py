@@ -54,6 +54,16 @@ def timeit(fn, reps=10):
     return e0.elapsed_time(e1) / reps
 
 
+# the row-by-row vector-ALU kernel (csrc/sparse_multinomial.hip, exact fp32)
+vals, rws, off, total = _ops.counts_csr(x)
+for form, ll_ptr in (('grad only', None), ('ll + grad', ll.data_ptr())):
+    ms = timeit(lambda: _capi.call(
+        'zshmc_sparse_multinomial_log_lik', theta.data_ptr(), phi_t.data_ptr(),
+        vals.data_ptr(), rws.data_ptr(), off.data_ptr(), n_docs, R, V, K,
+        ll_ptr, gt.data_ptr(), 1, None, s))
+    print('%-44s %-10s %d x %d rows, K=%d: %.3f ms (%d of %d words per row run)'
+          % ('zshmc_sparse_multinomial_log_lik', form, n_chains, n_docs, K, ms,
+             total // n_docs, V), flush=True)
 for name, inner in (('zshmc_linear_multinomial_log_lik', phi_t),
                     ('zshmc_linear_multinomial_log_lik_bf16x3', img)):
     for form, ll_ptr in (('grad only', None), ('ll + grad', ll.data_ptr())):

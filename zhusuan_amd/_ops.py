@@ -655,8 +655,16 @@ BF16X3_SPARSE_MAX_FILL = 0.6
 # over each row's own words on the vector ALU (csrc/sparse_multinomial.hip):
 # up to this many (chain, document) rows (beyond, phi^T rows gathered per row
 # out of L2 cost more than the matrix cores' dense tiles) and this fill
-SPARSE_ROWS_MAX = 4096
+# (1 chain x R documents, K = 128, ~970 of 12 419 words per document,
+# gradient-only launch, tools/b3_packed_bench.py, gpurun r06: R = 2 048
+# 0.083 ms against 0.82 fp32 MFMA / 0.74 packed-rows bf16x3; 8 192: 0.335 /
+# 0.84 / 0.77; 32 768: 1.30 / 1.50 / 0.955)
+SPARSE_ROWS_MAX = 32768
 SPARSE_ROWS_MAX_FILL = 0.5
+# 'auto' keeps such a problem on it -- exact fp32 AND faster -- up to this many
+# rows when the bf16x3 alternative is the packed-rows form (chain axes that do
+# not fill one-document workgroups); beyond, the packed-rows kernel wins
+SPARSE_ROWS_AUTO_MAX = 16384
 # likelihood_arithmetic='auto' (the default) takes them from this many flop
 # per evaluation (4 N D R over all ranks' rows) on: ~0.1 ms of the fp32 matrix
 # peak.  Below, a transition is bound by its kernels' critical paths and the

@@ -198,6 +198,10 @@ class _DenseLikelihoodPlan(_PlanBase):
                 if flop < ops.BF16X3_AUTO_MIN_FLOP:
                     why = ('%.2g flop per evaluation: latency-bound, the '
                            'finer-grained fp32 kernels' % flop)
+                else:
+                    # (a family may know an exact-fp32 kernel that beats the
+                    # bf16 matrix cores on this problem)
+                    why = self._auto_prefers_fp32(n_inner, per_doc, n_docs)
             if why is None:
                 self.inner_image = ops.bf16x3_image(self.inner)
                 self.block = ops.BF16X3_CHAIN_BLOCK
@@ -271,6 +275,12 @@ class _DenseLikelihoodPlan(_PlanBase):
         """Inner rows one evaluation runs over (called once the arithmetic is
         chosen): all of them, unless the family knows better."""
         return n_inner
+
+    def _auto_prefers_fp32(self, n_inner, per_doc, n_docs):
+        """likelihood_arithmetic='auto', a bf16x3 kernel exists and the
+        problem is large enough for it: a reason to stay on the fp32 path
+        anyway, or None."""
+        return None
 
     def _choose_splits(self, R, n_inner, per_cu):
         """Slices of the inner range per likelihood launch (their partials

@@ -100,13 +100,12 @@ class _MixtureMultinomialPlan(_DenseLikelihoodPlan):
             # chain x 100 documents) runs row by row over each row's own words
             # on the vector ALU (csrc/sparse_multinomial.hip) -- no tile
             # pipeline to fill, 8 % of the dense flops
-            if self.width <= 256 and self.lik_rows <= ops.SPARSE_ROWS_MAX:
+            if self._sparse_rows_fit(n_inner, ops.SPARSE_ROWS_MAX):
                 vals, rows, off, total = ops.counts_csr(self._counts_src)
-                if total <= ops.SPARSE_ROWS_MAX_FILL * n_docs * n_inner:
-                    self.obs_sp = (vals, rows, off)
-                    self.sparse_rows = True
-                    self.traj_capacity = 0     # (not in the one-launch kernel)
-                    self.n_inner_run = max(32, total // n_docs)
+                self.obs_sp = (vals, rows, off)
+                self.sparse_rows = True
+                self.traj_capacity = 0     # (not in the one-launch kernel)
+                self.n_inner_run = max(32, total // n_docs)
             return self.n_inner_run
         if self.packed_rows or n_inner * self.width * 6 >= (1 << 31):
             return n_inner
@@ -115,6 +114,27 @@ class _MixtureMultinomialPlan(_DenseLikelihoodPlan):
             self.obs_sp = (vals, rows, off)
             self.n_inner_run = max(32, total // n_docs)
         return self.n_inner_run
+
+    def _sparse_rows_fit(self, n_inner, max_rows):
+        """Whether the row-by-row kernel takes this problem: <= 256 padded
+        topics, at most max_rows rows, counts at most half full."""
+        ops = self._ops
+        if self.width > 256 or self.lik_rows > max_rows:
+            return False
+        total = ops.counts_csr(self._counts_src)[3]
+        return total <= ops.SPARSE_ROWS_MAX_FILL * self.obs.shape[0] * n_inner
+
+    def _auto_prefers_fp32(self, n_inner, per_doc, n_docs):
+        ops = self._ops
+        fills = n_docs == 1 or per_doc % ops.BF16X3_CHAIN_BLOCK == 0 or \
+            per_doc >= 8 * ops.BF16X3_CHAIN_BLOCK
+        if not fills and self._sparse_rows_fit(n_inner,
+                                               ops.SPARSE_ROWS_AUTO_MAX):
+            return ('%d rows with a word list each: the row-by-row fp32 '
+                    'kernel (csrc/sparse_multinomial.hip) beats the '
+                    'packed-rows bf16x3 form up to %d rows' % (
+                        self.lik_rows, ops.SPARSE_ROWS_AUTO_MAX))
+        return None
 
     def _choose_splits(self, R, n_inner, per_cu):
         if not self.sparse_rows:
