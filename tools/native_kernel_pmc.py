@@ -51,6 +51,43 @@ if len(sys.argv) > 1 and sys.argv[1] == 'packed':
               n_docs, K, V, n_docs, 4.0 * n_docs * stride))
     sys.exit(0)
 
+if len(sys.argv) > 1 and sys.argv[1] == 'own':
+    # round 6: configs[4] over the documents' OWN vocabularies (one document
+    # per workgroup, tiles gathered from the phi^T image): 2 048 chains x 5 000
+    # documents, K = 128, V = 12 419, beside the dense bf16x3 form
+    #   bash tools/profile_native_full.sh r06s own
+    import ctypes
+    n_chains, n_docs, K, V = 2048, 5000, 128, 12419
+    rows = n_chains * n_docs
+    phi = torch.softmax(torch.randn(K, V, device=dev, generator=g), -1)
+    x = torch.poisson(torch.full((n_docs, V), 0.08, device=dev), generator=g)
+    theta = torch.softmax(torch.randn(rows, K, device=dev, generator=g), -1)
+    phi_t = _ops._padded_phi_t(phi, K)
+    xp, stride = _ops._padded_counts(x, 32)
+    vals, rws, off, total = _ops.counts_csr(x)
+    ll = torch.empty(rows, device=dev)
+    gt = torch.empty(rows, K, device=dev)
+    nb = ctypes.c_int64()
+    _capi.call('zshmc_bf16x3_image_bytes', phi_t.shape[0], K,
+               ctypes.addressof(nb))
+    img = torch.empty(nb.value, dtype=torch.uint8, device=dev)
+    _capi.call('zshmc_bf16x3_split', phi_t.data_ptr(), phi_t.shape[0], K,
+               phi_t.stride(0), img.data_ptr(), s)
+    for ll_ptr in (ll.data_ptr(), None, None, None):
+        _capi.call('zshmc_linear_multinomial_log_lik_bf16x3_sparse',
+                   theta.data_ptr(), img.data_ptr(), vals.data_ptr(),
+                   rws.data_ptr(), off.data_ptr(), n_docs, rows, V, K, ll_ptr,
+                   gt.data_ptr(), 1, None, s)
+    for ll_ptr in (None, None):
+        _capi.call('zshmc_linear_multinomial_log_lik_bf16x3', theta.data_ptr(),
+                   img.data_ptr(), xp.data_ptr(), n_docs, stride, rows, V, K,
+                   ll_ptr, gt.data_ptr(), 1, None, s)
+    torch.cuda.synchronize()
+    print('config5 shape: rows=%d K=%d V=%d; OWN VOCABULARY: %d of %d words per '
+          'document run (padded); the dense form beside it' % (
+              rows, K, V, total // n_docs, V))
+    sys.exit(0)
+
 # ---- configs[2]: Bernoulli mode --------------------------------------------
 C, N, D = 32768, 1000000, 256
 X = torch.randn(N, D, device=dev, generator=g)

@@ -38,7 +38,13 @@ def mode_of(name):
         packed = (args is not None and
                   args.group(1).replace(' ', '').split(',')[5:6] == ['true']) \
             or re.search(r'ELi\dELi\dELb1EEE', tail) is not None
-        return '%s bf16x3%s %s' % (fam, ' packed-rows' if packed else '',
+        own = (args is not None and
+               args.group(1).replace(' ', '').split(',')[6:7] == ['true']) \
+            or re.search(r'ELb[01]ELb1EEE', tail) is not None
+        if own:
+            packed = False
+        return '%s bf16x3%s %s' % (fam, ' packed-rows' if packed else
+                                   (' own-vocabulary' if own else ''),
                                    'll+grad' if ll else 'grad-only')
     tail = name.split('linear_bernoulli_kernel')[1][:80]
     m = re.search(r'<\s*(\d+),\s*(true|false),\s*(\d)(?:,\s*(true|false))?\s*>',
