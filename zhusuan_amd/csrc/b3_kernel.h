@@ -232,6 +232,9 @@ constexpr int kLastUse[3] = {2, 4, 5};
 #endif
 
 // ---------------------------------------------------------------------------
+#ifndef ZS_B3_SP_XCD
+#define ZS_B3_SP_XCD 1    // SP: document-major order per XCD (A/B knob)
+#endif
 #ifndef ZS_B3_PK_AHEAD
 #define ZS_B3_PK_AHEAD 2   // PK, D <= 128: tiles the counts are fetched ahead
 #endif
@@ -319,8 +322,23 @@ __global__ __launch_bounds__(256, PK ? 1 : ZS_B3_WAVES(D)) void linear_b3_kernel
   int64_t n_valid = C - row_base;
   int64_t doc = 0;
   if (OP == 1 && !PK && (doc_major || SP)) {
-    const int64_t grp = blockIdx.x / yc_rows;
+    int64_t grp = blockIdx.x / yc_rows;
     doc = blockIdx.x % yc_rows;
+    if (SP && ZS_B3_SP_XCD && gridDim.y == 1) {
+      // The workgroups of ONE document gather the same ~30 tiles (730 KB of
+      // the image at K = 128), and the image (9.5 MB) does not fit an XCD's
+      // 4 MB L2: with documents interleaved over the grid every gathered tile
+      // came from the Infinity Cache (rocprofv3, r06s: 74 GB of fabric reads
+      // per launch).  Workgroups are dealt round-robin to the 8 XCDs, so XCD x
+      // takes a CONTIGUOUS range of a document-major order: a document's
+      // workgroups run one after the other on one XCD, out of its L2.
+      const int64_t total = gridDim.x, nG = total / yc_rows;
+      const int64_t x = blockIdx.x % 8, k = blockIdx.x / 8;
+      const int64_t q = total / 8, r = total % 8;
+      const int64_t j = x * q + (x < r ? x : r) + k;
+      doc = j / nG;
+      grp = j % nG;
+    }
     row_base = grp * kB3Chains * yc_rows + doc;
     row_stride = yc_rows;
     n_valid = C / yc_rows - grp * kB3Chains;
