@@ -971,11 +971,29 @@ def lntm_workload(torch, zs, dev, n_chains, sharding=None, dist=None,
         # -- one document per workgroup on the bf16x3 kernel -- the mean length
         # of the documents' own (padded) word lists
         n_run = int(getattr(hmc._plan, 'n_inner_run', n_vocab))
-        own = getattr(hmc._plan, 'obs_sp', None) is not None
+        own = getattr(hmc._plan, 'obs_sp', None) is not None and \
+            not getattr(hmc._plan, 'sparse_rows', False)
         roof = _lik_roofline(hmc, kern_ms, flop_eval * n_run / n_vocab,
                              n_leapfrogs, ms, 'multinomial')
         roof['note'] = 'per GPU (rank 0): one launch covers this rank\'s rows'
-        if own:
+        if getattr(hmc._plan, 'sparse_rows', False):
+            # the row-by-row vector-ALU kernel (csrc/sparse_multinomial.hip):
+            # not a matrix-core kernel -- priced as a gather out of L2 (every
+            # word of every row brings its phi^T row: width * 4 bytes)
+            k_ms = kern_ms['grad'] if isinstance(kern_ms, dict) else kern_ms
+            gb = rows_rank * float(n_run) * hmc._plan.width * 4.0
+            roof = {
+                'bound': 'l2-gather', 'dtype': 'f32', 'unit': 'GB/s',
+                'kernel': 'sparse_multinomial_kernel<%d> (row by row over '
+                          'each row\'s own words, vector ALU) gradient only'
+                          % hmc._plan.width,
+                'kernel_ms': k_ms, 'achieved': gb / (k_ms * 1e-3) / 1e9,
+                'peak': L2_PEAK_GBPS, 'frac': gb / (k_ms * 1e-3) / 1e9 /
+                L2_PEAK_GBPS, 'traffic': None,
+                'algorithmic_bytes_per_launch': gb,
+                'note': 'phi^T rows gathered per (row, word): %d of %d words '
+                        'per row run' % (n_run, n_vocab)}
+        elif own:
             roof['kernel'] = roof['kernel'].replace(
                 'multinomial', 'multinomial, own vocabulary')
             roof['note'] += (
