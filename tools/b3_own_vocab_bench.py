@@ -2,7 +2,7 @@
 """Round 6: the own-vocabulary form of the bf16x3 multinomial kernel (one
 document per workgroup, tiles gathered from the phi^T image) beside the dense
 form at the configs[4] family's shape.  LB_LIB = another build (A/B).
-    python tools/b3_own_vocab_bench.py [n_chains] [n_docs] [K]"""
+    python tools/b3_own_vocab_bench.py [n_chains] [n_docs] [K] [poisson rate]"""
 import ctypes
 import os
 import sys
@@ -18,13 +18,14 @@ if os.environ.get('LB_LIB'):
 n_chains = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 n_docs = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
 K = int(sys.argv[3]) if len(sys.argv) > 3 else 128
+rate = float(sys.argv[4]) if len(sys.argv) > 4 else 0.08   # Poisson rate per word
 V = 12419
 dev = torch.device('cuda', 0)
 s = torch.cuda.current_stream().cuda_stream
 g = torch.Generator(device=dev).manual_seed(0)
 R = n_chains * n_docs
 phi = torch.softmax(torch.randn(K, V, device=dev, generator=g), -1)
-x = torch.poisson(torch.full((n_docs, V), 0.08, device=dev), generator=g)
+x = torch.poisson(torch.full((n_docs, V), rate, device=dev), generator=g)
 theta = torch.softmax(torch.randn(R, K, device=dev, generator=g), -1)
 phi_t = _ops._padded_phi_t(phi, K)
 vals, rws, off, total = _ops.counts_csr(x)

@@ -639,8 +639,9 @@ BF16X3_CHAIN_BLOCK = 128
 # A workgroup of the mixture-multinomial kernel takes 128 chains of ONE
 # document: by default the kernels are taken only where the chain axis fills
 # those workgroups (a multiple of 128, or >= 1024 chains: >= 89 % of the
-# slots) -- lntm_mcem.py's own E-step (n_chains = 1) stays on the fp32 kernel,
-# which packs consecutive (chain, document) rows.
+# slots); other chain axes run the packed-rows form below, or -- small and
+# sparse, like lntm_mcem.py's own E-step (n_chains = 1) -- the row-by-row
+# fp32 kernel (SPARSE_ROWS_*).
 BF16X3_REQUIRE_FILL = True
 # ... unless the packed-rows form of the kernel takes them (ABI 0.5.1: 128
 # consecutive (chain, document) rows per workgroup, each with its own counts
