@@ -694,3 +694,54 @@ def test_hmc_topic_model_runs_over_the_documents_own_vocabularies(env,
         np.testing.assert_allclose(a[1][close.reshape(a[1].shape)],
                                    other[1][close.reshape(a[1].shape)],
                                    rtol=2e-5, atol=2e-3)
+
+
+def test_partly_filled_workgroups_over_own_vocabularies(env):
+    """16 chains x 600 documents with sparse counts: neither the chain axis
+    fills one-document workgroups nor is the problem small -- a workgroup of
+    16 valid chains over the document's ~60 words beats 128 packed rows over
+    all 3 000 (fill * 128 / 16 < 0.6): the own-vocabulary form, against the
+    packed-rows form asked for through the fill bound, within summation
+    noise."""
+    torch, _capi, dev = env
+    import zhusuan_amd as zs
+    g = torch.Generator(device=dev).manual_seed(1)
+    n_chains, n_docs, K, V = 16, 1200, 64, 3000
+    phi = torch.softmax(torch.randn(K, V, device=dev, generator=g), -1)
+    x = torch.poisson(torch.full((n_docs, V), 0.02, device=dev), generator=g)
+    mean = torch.zeros(n_docs, K, device=dev)
+    eta0 = 0.2 * torch.randn(n_chains, n_docs, K, device=dev, generator=g)
+    out = {}
+    for fill in (0.6, 0.0):
+        zs._ops.clear_caches()
+        old = zs._ops.BF16X3_SPARSE_MAX_FILL
+        zs._ops.BF16X3_SPARSE_MAX_FILL = fill
+        try:
+            @zs.meta_bayesian_net(scope='lntm')
+            def lntm():
+                bn = zs.BayesianNet()
+                eta = bn.normal('eta', mean, logstd=0., n_samples=n_chains,
+                                group_ndims=1)
+                bn.unnormalized_multinomial(
+                    'x', zs.log_mixture(torch.softmax(eta.tensor, -1), phi),
+                    normalize_logits=False, dtype=torch.float32)
+                return bn
+            m = lntm()
+            m.log_joint = lambda bn: (bn.cond_log_prob('eta') +
+                                      bn.cond_log_prob('x'))
+            hmc = zs.HMC(step_size=0.02, n_leapfrogs=3, seed=2,
+                         likelihood_arithmetic='bf16x3')
+            eta = eta0.clone()
+            op, info = hmc.sample(m, {'x': x}, {'eta': eta})
+            assert hmc.likelihood_arithmetic_used == 'bf16x3'
+            plan = hmc._plan
+            assert (plan.obs_sp is not None) == (fill > 0)
+            assert plan.packed_rows == (fill == 0)
+            op.run_many(2)
+            out[fill] = (eta.cpu().numpy(), info.log_prob.cpu().numpy())
+        finally:
+            zs._ops.BF16X3_SPARSE_MAX_FILL = old
+    a, b = out[0.6], out[0.0]
+    close = np.isclose(a[0], b[0], atol=2e-4).reshape(n_chains * n_docs,
+                                                      -1).all(1)
+    assert close.mean() > 0.98

@@ -651,6 +651,11 @@ BF16X3_PACKED_MAX_WIDTH = 192
 # (ABI 0.6.0: words with a zero count contribute exactly nothing) when the
 # padded word lists are at most this share of the dense [documents, V] counts
 BF16X3_SPARSE_MAX_FILL = 0.6
+# ... also for chain axes that do NOT fill those workgroups, from this many
+# chains per document on, when fill * 128 / chains_per_doc stays below the same
+# bound (a partly filled workgroup over few words against 128 packed rows over
+# all of them)
+BF16X3_SPARSE_MIN_CHAINS = 8
 # Small topic models on the exact-fp32 path -- the reference's own loop is ONE
 # chain x a minibatch of 100 documents (lntm_mcem.py:62-70) -- run row by row
 # over each row's own words on the vector ALU (csrc/sparse_multinomial.hip):

@@ -107,10 +107,23 @@ class _MixtureMultinomialPlan(_DenseLikelihoodPlan):
                 self.traj_capacity = 0     # (not in the one-launch kernel)
                 self.n_inner_run = max(32, total // n_docs)
             return self.n_inner_run
-        if self.packed_rows or n_inner * self.width * 6 >= (1 << 31):
+        if n_inner * self.width * 6 >= (1 << 31):
+            return n_inner
+        per_doc = self.n_chains // n_docs
+        if self.packed_rows and per_doc < ops.BF16X3_SPARSE_MIN_CHAINS:
             return n_inner
         vals, rows, off, total = ops.counts_csr(self._counts_src)
-        if total <= ops.BF16X3_SPARSE_MAX_FILL * n_docs * n_inner:
+        fill = total / float(n_docs * n_inner)
+        # Chain axes that do not fill one-document workgroups (8 .. 127 chains
+        # per document): a workgroup of `per_doc` valid chains over the
+        # document's own words still beats 128 packed rows over ALL words when
+        # the words are few enough -- tiles x 128 / per_doc against V tiles.
+        if self.packed_rows and \
+                fill * ops.BF16X3_CHAIN_BLOCK / per_doc > \
+                ops.BF16X3_SPARSE_MAX_FILL:
+            return n_inner
+        if fill <= ops.BF16X3_SPARSE_MAX_FILL:
+            self.packed_rows = False
             self.obs_sp = (vals, rows, off)
             self.n_inner_run = max(32, total // n_docs)
         return self.n_inner_run
@@ -128,8 +141,11 @@ class _MixtureMultinomialPlan(_DenseLikelihoodPlan):
         ops = self._ops
         fills = n_docs == 1 or per_doc % ops.BF16X3_CHAIN_BLOCK == 0 or \
             per_doc >= 8 * ops.BF16X3_CHAIN_BLOCK
-        if not fills and self._sparse_rows_fit(n_inner,
-                                               ops.SPARSE_ROWS_AUTO_MAX):
+        # (from ~16 chains per document on, partly filled one-document
+        # workgroups over the documents' own words beat it: 5 000 documents,
+        # K = 128, gpurun r06: 16 chains 1.52 ms against 2.80, 32: 1.56 / 5.4)
+        if not fills and per_doc < 2 * ops.BF16X3_SPARSE_MIN_CHAINS and \
+                self._sparse_rows_fit(n_inner, ops.SPARSE_ROWS_AUTO_MAX):
             return ('%d rows with a word list each: the row-by-row fp32 '
                     'kernel (csrc/sparse_multinomial.hip) beats the '
                     'packed-rows bf16x3 form up to %d rows' % (
