@@ -718,3 +718,36 @@ def test_write_generations_never_repeat():
     k0 = _ops._tensor_key(a)
     _writes.note([a])
     assert _ops._tensor_key(a) != k0
+
+
+def test_counts_csr_pads_every_document_to_whole_tiles():
+    """_ops.counts_csr (the documents' OWN vocabularies of the ABI 0.6.0
+    topic-model kernels): compacted counts, the words' rows, offsets; every
+    document's slice a multiple of 32, at least 32, padded with count 0 /
+    row 0; row-major order inside a document; cached per tensor version."""
+    import numpy as np
+    import torch
+    from zhusuan_amd import _ops
+    _ops.clear_caches()
+    rng = np.random.RandomState(0)
+    x = rng.poisson(0.1, size=(7, 300)).astype(np.float32)
+    x[2] = 0.0                                   # a document without words
+    x[4] = 1.0 + rng.poisson(1.0, size=300)      # one that uses every word
+    xt = torch.tensor(x)
+    vals, rows, off, total = _ops.counts_csr(xt)
+    off = off.numpy()
+    assert off[0] == 0 and off[-1] == total == vals.numel() == rows.numel()
+    lens = np.diff(off)
+    assert (lens % 32 == 0).all() and (lens >= 32).all()
+    assert lens[2] == 32 and lens[4] == 320
+    for d in range(7):
+        v = vals[off[d]:off[d + 1]].numpy()
+        r = rows[off[d]:off[d + 1]].numpy()
+        nz = np.flatnonzero(x[d])
+        np.testing.assert_array_equal(r[:len(nz)], nz)
+        np.testing.assert_array_equal(v[:len(nz)], x[d][nz])
+        assert (v[len(nz):] == 0).all() and (r[len(nz):] == 0).all()
+    assert _ops.counts_csr(xt)[0] is vals        # cached
+    xt[0, 0] += 1.0                              # a torch write: new version
+    assert _ops.counts_csr(xt)[0] is not vals
+    _ops.clear_caches()
